@@ -1,0 +1,124 @@
+"""ORACLE (test infrastructure, never shipped as a product path).
+
+Numpy restatement of the feature-extraction leg of the hot path:
+  abnet3/features.py:135-159  stack_fbanks         (pinned: tests/golden/stack.npz)
+  abnet3/features.py:99-114   do_fbank -> spectral.Spectral(...).transform
+
+PARITY UNPINNED for the filterbank arithmetic: spectral.Spectral lives in the
+un-vendored third-party package bootphon/spectral (requirements.txt:10, a git
+URL with no version pin), absent from /root/reference; no reference test calls
+do_fbank.  The only facts the reference fixes are the call-site arguments
+(nfilt=40, alpha=0.97, do_dct=False, fs=srate, frate=100, wlen=0.025,
+nfft=1024, no deltas) and the float32 cast.  This file restates the published
+algorithm of that package's lineage (the CMU Sphinx-III `mfcc.py` front end its
+parameter names come from) and IS the definition the HIP kernel is tested
+against:
+  frames:   nfr = int(len(sig)/fshift + 1), fshift = fs/frate, frame t starts
+            at round(t*fshift), wlen = int(0.025*fs) samples, zero-padded tail
+  pre-emph: y[i] = x[i] - alpha*x[i-1] inside the frame; for i=0 the previous
+            sample of the signal (0 before the first sample)
+  window:   numpy.hamming(wlen) (symmetric)
+  power:    |rfft(frame, nfft)|^2, nfft=1024 -> 513 bins
+  mel bank: 40 triangular filters between lowerf=133.3333 Hz and
+            upperf=6855.4976 Hz, mel(f)=2595 log10(1+f/700), edges rounded to
+            DFT bins, height 2/(width in Hz)
+  output:   log(max(power . filters, 1e-5)) as float32 [nfr, 40]
+"""
+import numpy as np
+
+LOWERF = 133.3333
+UPPERF = 6855.4976
+FLOOR = 1e-5
+
+
+def stack_fbanks(features, nframes=7):
+    """features.py:135-159: row t = concat(rows t-n//2 .. t+n//2), zero padded."""
+    assert nframes % 2 == 1, 'number of stacked frames must be odd'
+    T, dim = features.shape
+    h = nframes // 2
+    out = np.zeros((T, dim * nframes), dtype=features.dtype)
+    for k in range(nframes):
+        lo = max(0, h - k)
+        hi = min(T, T + h - k)
+        if hi > lo:
+            out[lo:hi, k * dim:(k + 1) * dim] = features[lo + k - h:hi + k - h]
+    return out
+
+
+def mel(f):
+    return 2595.0 * np.log10(1.0 + f / 700.0)
+
+
+def melinv(m):
+    return 700.0 * (np.power(10.0, m / 2595.0) - 1.0)
+
+
+def mel_filterbank(fs, nfft=1024, nfilt=40, lowerf=LOWERF, upperf=UPPERF):
+    """[nfft/2+1, nfilt] float64 triangular bank (see module docstring)."""
+    if upperf > fs / 2:
+        raise ValueError('Upper frequency %f exceeds Nyquist %f' % (upperf, fs / 2))
+    filters = np.zeros((nfft // 2 + 1, nfilt), dtype=np.float64)
+    dfreq = float(fs) / nfft
+    melmax, melmin = mel(upperf), mel(lowerf)
+    dmelbw = (melmax - melmin) / (nfilt + 1)
+    edges = melinv(melmin + dmelbw * np.arange(nfilt + 2, dtype=np.float64))
+    for w in range(nfilt):
+        leftfr = int(round(edges[w] / dfreq))
+        centerfr = int(round(edges[w + 1] / dfreq))
+        rightfr = int(round(edges[w + 2] / dfreq))
+        fwidth = (rightfr - leftfr) * dfreq
+        height = 2.0 / fwidth
+        leftslope = height / (centerfr - leftfr) if centerfr != leftfr else 0.0
+        freq = leftfr + 1
+        while freq < centerfr:
+            filters[freq, w] = (freq - leftfr) * leftslope
+            freq += 1
+        if freq == centerfr:
+            filters[freq, w] = height
+            freq += 1
+        if centerfr != rightfr:
+            rightslope = height / (centerfr - rightfr)
+        while freq < rightfr:
+            filters[freq, w] = (freq - rightfr) * rightslope
+            freq += 1
+    return filters
+
+
+def frame_count(nsamples, fs, frate=100):
+    return int(nsamples / (float(fs) / frate) + 1)
+
+
+def fbank(sig, fs, nfilt=40, alpha=0.97, frate=100, wlen=0.025, nfft=1024,
+          dtype=np.float64):
+    """Log mel filterbank energies, float32 [nfr, nfilt] (do_fbank's result).
+
+    `dtype` is the arithmetic type of the per-frame pipeline: float64 is the
+    definition; float32 mirrors what the HIP kernel computes in."""
+    sig = np.asarray(sig).astype(np.float64)
+    fshift = float(fs) / frate
+    wl = int(wlen * fs)
+    win = np.hamming(wl)
+    filt = mel_filterbank(fs, nfft, nfilt)
+    nfr = frame_count(len(sig), fs, frate)
+    out = np.zeros((nfr, nfilt), dtype=np.float32)
+    padded = np.concatenate((sig, np.zeros(wl + 1)))
+    for t in range(nfr):
+        start = int(round(t * fshift))
+        if start >= len(sig):
+            frame = np.zeros(wl)
+            prev = np.zeros(wl)
+        else:
+            frame = padded[start:start + wl].copy()
+            # samples past the end of the signal are zero, and so is the
+            # pre-emphasis history there
+            valid = max(0, min(wl, len(sig) - start))
+            frame[valid:] = 0.0
+            prev = np.empty(wl)
+            prev[0] = sig[start - 1] if start > 0 else 0.0
+            prev[1:] = frame[:-1]
+        pre = ((frame - alpha * prev) * win).astype(dtype)
+        spec = np.fft.rfft(pre.astype(np.float64), nfft)
+        power = (spec.real * spec.real + spec.imag * spec.imag).astype(dtype)
+        e = np.dot(power.astype(np.float64), filt)
+        out[t] = np.log(np.clip(e, FLOOR, np.inf)).astype(np.float32)
+    return out

@@ -1,0 +1,92 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def rel_err(a, b, floor=1e-30):
+    """max|a-b| / max(max|b|, floor): the '1e-5 relative fp32' bar of
+    BASELINE.json is applied per tensor against the tensor's largest magnitude.
+    `floor` keeps tensors that are mathematically zero (the Linear bias gradient
+    in front of a BatchNorm is pure rounding noise, ~1e-10) from dividing noise
+    by noise."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    denom = max(np.abs(b).max(), floor)
+    return np.abs(a - b).max() / denom
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden
+
+
+def is_pre_bn_bias(k, batch_norm):
+    if not batch_norm or not k.endswith('.bias'):
+        return False
+    parts = k.split('.')
+    return int(parts[1]) % 4 == 0 if parts[0] == 'hidden_layers' else parts[1] == '0'
+
+
+def check_params(mine, ref, keys, batch_norm, tol=1e-5):
+    """Parameters after some optimizer steps.  A Linear bias feeding a BatchNorm
+    has no effect on the network function and receives a rounding-noise
+    gradient, which normalising optimizers (Adam, RMSprop, Adagrad) blow up to
+    +-lr steps of arbitrary sign: those entries are not comparable and are
+    skipped."""
+    for k in keys:
+        if is_pre_bn_bias(k, batch_norm):
+            continue
+        assert rel_err(mine[k], ref[k]) < tol, (k, rel_err(mine[k], ref[k]))
+
+
+def check_grads(mine, ref, keys, batch_norm, tol=2e-5):
+    """Per-tensor relative check of parameter gradients.  With BatchNorm the
+    gradient of the Linear bias feeding it is mathematically zero (BN removes
+    the column mean), so both sides hold rounding noise there: bound its
+    magnitude against the model-wide gradient scale instead of comparing noise
+    with noise."""
+    gmax = max(np.abs(ref[k]).max() for k in keys)
+    for k in keys:
+        if is_pre_bn_bias(k, batch_norm):
+            assert np.abs(mine[k]).max() <= 1e-4 * gmax, k
+            assert np.abs(ref[k]).max() <= 1e-4 * gmax, k
+        else:
+            # a tensor whose entries are 100x below the model's largest
+            # gradient is a heavily cancelled sum: its fp32 error scales with
+            # the summands, not with the result
+            e = rel_err(mine[k], ref[k], floor=1e-2 * gmax)
+            assert e < tol, (k, e)
+
+
+def check_loss_grads(de1, de2, ref1, ref2, lname, tag=''):
+    """Row-wise comparison of d loss/d e against tests/golden/loss_edge.npz.
+    Rows span 1e-10 .. 1e4 in gradient magnitude, so each row is judged
+    against its own largest entry.  Rows 2-4 hold identical / opposite vectors:
+    the true gradient is zero and the reference holds ~1e-10 of rounding noise
+    there, so they get an absolute bound.  Row 11 has cos == margin to 1 ulp:
+    the hinge subgradient is decided by rounding and is not compared for
+    cosmargin(margin=0.5)."""
+    for r in range(len(de1)):
+        if r in (2, 3, 4):
+            assert np.abs(de1[r]).max() < 1e-8 and np.abs(de2[r]).max() < 1e-8, (r, tag)
+            continue
+        if r == 11 and lname == 'cosmargin' and '_m' not in tag:
+            continue
+        for mine, ref in ((de1[r], ref1[r]), (de2[r], ref2[r])):
+            scale = max(np.abs(ref).max(), 1e-30)
+            assert np.abs(mine - ref).max() <= 2e-5 * scale, (r, tag)

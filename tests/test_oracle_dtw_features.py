@@ -1,0 +1,129 @@
+"""Oracle DTW / cosine_distance / stack_fbanks / fbank against the golden
+vectors and against each other.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import dtw_oracle as D
+from oracle import features_np as F
+
+
+@pytest.mark.parametrize('name', ['f32', 'one', 'zero', 'near'])
+def test_cosine_distance_matches_reference(name):
+    g = load_golden('cosdist.npz')
+    d = D.cosine_distance(g[name + '.x'], g[name + '.y'])
+    ref = g[name + '.d']
+    assert d.dtype == np.float64 and d.shape == ref.shape
+    # arccos is ill-conditioned at |cos| -> 1 (near-duplicate frames), so the
+    # comparison is made on cos(pi d), where one float32 ulp of the dot product
+    # is one ulp of the result; plus a plain bound away from the poles.
+    assert np.abs(np.cos(np.pi * d) - np.cos(np.pi * ref)).max() < 5e-7
+    far = np.abs(np.cos(np.pi * ref)) < 0.99
+    assert np.abs(d - ref)[far].max() < 1e-6
+
+
+def test_cosine_distance_zero_rows_and_nan_drop():
+    g = load_golden('cosdist.npz')
+    d = D.cosine_distance(g['zero.x'], g['zero.y'])
+    assert (d[3] == np.where(np.arange(d.shape[1]) == 7, 0.0, 1.0)).all()
+    assert (d[:, 7] == np.where(np.isin(np.arange(d.shape[0]), (3, 10)), 0.0, 1.0)).all()
+    # identical rows push cos one ulp above 1 -> NaN -> the reference asserts
+    # (fixture holds 'AssertionError'); the oracle must refuse the pair too
+    assert str(g['pos.d']) == 'AssertionError'
+    with pytest.raises(AssertionError):
+        D.cosine_distance(g['pos.x'], g['pos.y'])
+
+
+def test_acosf_accuracy():
+    L = D.lib()
+    xs = np.concatenate([np.linspace(-1, 1, 20001), [1e-9, -1e-9, 0.5, -0.5, 0.49999997, 1.0, -1.0]])
+    got = np.array([L.abn_oracle_acosf(float(np.float32(x))) for x in xs])
+    ref = np.arccos(xs.astype(np.float32).astype(np.float64))
+    assert np.abs(got - ref).max() < 4e-7
+    assert np.isnan(L.abn_oracle_acosf(1.0000001))
+
+
+def test_dtw_c_matches_python_restatement():
+    rng = np.random.default_rng(0)
+    for t in range(60):
+        N, M = rng.integers(1, 40, 2)
+        d = rng.random((N, M))
+        if t % 3 == 0:
+            d = np.round(d * 4) / 4          # force ties
+        if t % 7 == 0:
+            d[:] = 0.25                      # all ties: pure diagonal-first
+        a = D.dtw_path(d)
+        b = D.dtw_path_py(d)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        # path invariants the call site relies on (utils.py:151-153)
+        assert a[0][0] == 0 and a[1][0] == 0 and a[0][-1] == N - 1 and a[1][-1] == M - 1
+        assert max(N, M) <= len(a[0]) <= N + M - 1
+        s1, s2 = np.diff(a[0]), np.diff(a[1])
+        assert ((s1 >= 0) & (s1 <= 1) & (s2 >= 0) & (s2 <= 1) & (s1 + s2 >= 1)).all()
+
+
+def test_dtw_tie_break_is_diagonal_then_up_then_left():
+    d = np.zeros((3, 3))
+    p1, p2 = D.dtw_path(d)
+    assert list(p1) == [0, 1, 2] and list(p2) == [0, 1, 2]
+    d = np.zeros((2, 4))
+    p1, p2 = D.dtw_path(d)
+    # from (1,3): diag -> (0,2), then row 0 can only go left
+    assert list(zip(p1, p2)) == [(0, 0), (0, 1), (0, 2), (1, 3)]
+    d = np.zeros((4, 2))
+    p1, p2 = D.dtw_path(d)
+    assert list(zip(p1, p2)) == [(0, 0), (1, 0), (2, 0), (3, 1)]
+
+
+def test_dtw_identical_sequences_follow_diagonal():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((25, 40)).astype(np.float32)
+    y = x + 1e-2 * rng.standard_normal((25, 40)).astype(np.float32)
+    p1, p2 = D.get_dtw_alignment(x, y)
+    assert (p1 == np.arange(25)).all() and (p2 == np.arange(25)).all()
+
+
+def test_dtw_batch_front_end():
+    rng = np.random.default_rng(2)
+    n1 = np.array([5, 9, 1, 12], dtype=np.int32)
+    n2 = np.array([7, 3, 1, 12], dtype=np.int32)
+    f1 = rng.standard_normal((n1.sum(), 40)).astype(np.float32)
+    f2 = rng.standard_normal((n2.sum(), 40)).astype(np.float32)
+    o1 = np.concatenate(([0], np.cumsum(n1)[:-1]))
+    o2 = np.concatenate(([0], np.cumsum(n2)[:-1]))
+    p1, p2, ln, cells = D.dtw_batch(f1, o1, n1, f2, o2, n2, 32)
+    assert cells == int((n1.astype(int) * n2).sum())
+    for p in range(4):
+        a, b = D.get_dtw_alignment(f1[o1[p]:o1[p] + n1[p]], f2[o2[p]:o2[p] + n2[p]])
+        assert ln[p] == len(a)
+        assert (p1[p, :ln[p]] == a).all() and (p2[p, :ln[p]] == b).all()
+
+
+@pytest.mark.parametrize('name', ['t100_n7', 't100_n3', 't5_n7', 't2_n7', 't17_n1'])
+def test_stack_fbanks_matches_reference(name):
+    g = load_golden('stack.npz')
+    out = F.stack_fbanks(g[name + '.in'], int(g[name + '.n']))
+    assert out.dtype == g[name + '.out'].dtype
+    assert out.shape == g[name + '.out'].shape
+    assert (out == g[name + '.out']).all()       # pure data movement: bit-exact
+
+
+def test_fbank_shape_and_sanity():
+    fs = 16000
+    rng = np.random.default_rng(3)
+    t = np.arange(fs) / fs
+    sig = (3000 * np.sin(2 * np.pi * 1000 * t) + 50 * rng.standard_normal(fs)).astype(np.int16)
+    fb = F.fbank(sig, fs)
+    assert fb.shape == (101, 40) and fb.dtype == np.float32
+    bank = F.mel_filterbank(fs)
+    assert bank.shape == (513, 40)
+    # every filter is a non-empty triangle and 1 kHz lands in the right band
+    assert (bank.sum(axis=0) > 0).all()
+    peak_band = np.argmax(bank[int(round(1000 / (fs / 1024)))])
+    assert np.argmax(fb[10:90].mean(axis=0)) == peak_band
+    # silence hits the 1e-5 floor
+    z = F.fbank(np.zeros(4000, dtype=np.int16), fs)
+    assert np.allclose(z, np.log(1e-5))
+    # float32 pipeline stays close to the float64 definition
+    fb32 = F.fbank(sig, fs, dtype=np.float32)
+    assert np.abs(fb32 - fb).max() < 1e-4

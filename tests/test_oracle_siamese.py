@@ -1,0 +1,160 @@
+"""The numpy oracle against the golden vectors produced by the reference
+(tools/make_golden.py).  CPU only."""
+import ast
+
+import numpy as np
+import pytest
+
+from conftest import (load_golden, rel_err, check_grads, check_params,
+                      check_loss_grads)
+from oracle import siamese_np as O
+
+TOL = 1e-5
+GFLOOR = 1e-6     # gradients below this are rounding noise (see conftest.rel_err)
+
+
+def spec_from(g):
+    kw = ast.literal_eval(str(g['kw']))
+    return O.TowerSpec(kw['input_dim'], kw['num_hidden_layers'], kw['hidden_dim'],
+                       kw['output_dim'], kw['activation_layer'],
+                       kw.get('batch_norm', False),
+                       kw.get('last_non_linearity', 'default')), kw
+
+
+def params_from(g, prefix='p.'):
+    return {k[len(prefix):]: v.copy() for k, v in g.items() if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize('name', ['sig', 'sig_bn', 'relu_bn', 'tanh', 'sig_lin',
+                                  'relu_h2'])
+def test_tower_forward_matches_reference(name):
+    g = load_golden('tower_%s.npz' % name)
+    spec, _ = spec_from(g)
+    p = params_from(g)
+    e1, _ = O.tower_forward(p, g['x1'], spec, train=False)
+    e2, _ = O.tower_forward(p, g['x2'], spec, train=False)
+    assert rel_err(e1, g['eval_e1']) < TOL
+    assert rel_err(e2, g['eval_e2']) < TOL
+    e1, e2, _ = O.siamese_forward(p, g['x1'], g['x2'], spec, train=True)
+    assert rel_err(e1, g['train_e1']) < TOL
+    assert rel_err(e2, g['train_e2']) < TOL
+    after = params_from(g, 'after.')
+    for k, v in after.items():
+        if 'running' in k:
+            assert rel_err(p[k], v) < TOL, k
+        if 'num_batches_tracked' in k:
+            assert int(p[k]) == int(v) == 2      # one update per tower call
+
+
+CASES_C1 = [(l, a, o) for l in ('coscos2', 'cosmargin') for a in (1, 0)
+            for o in ('sgd', 'adadelta')] + \
+           [('coscos2', 0, o) for o in ('adam', 'adagrad', 'RMSprop')]
+
+
+@pytest.mark.parametrize('bn', [0, 1])
+@pytest.mark.parametrize('lname,avg,oname', CASES_C1)
+def test_c1_grads_and_three_steps(bn, lname, avg, oname):
+    g = load_golden('train_c1_bn%d.npz' % bn)
+    spec, _ = spec_from(g)
+    p = params_from(g)
+    tag = '%s.avg%d.%s' % (lname, avg, oname)
+    lr = {'sgd': 0.001, 'adadelta': 0.1}.get(oname, 0.001)
+    opt = O.Optimizer(oname, lr)
+    losses = []
+    for s in range(3):
+        loss, grads, (e1, e2) = O.train_step(p, g['x1'], g['x2'], g['y'], spec,
+                                             opt, kind=lname, avg=bool(avg))
+        losses.append(loss)
+        if s == 0:
+            assert rel_err(e1, g[tag + '.e1_0']) < TOL
+            check_grads(grads, {k: g['%s.grad0.%s' % (tag, k)]
+                                for k in spec.param_keys()},
+                        spec.param_keys(), spec.batch_norm)
+    assert np.allclose(losses, g[tag + '.losses'], rtol=1e-5, atol=1e-6)
+    # Adam / Adagrad / RMSprop divide by sqrt(v)+eps: entries whose gradient is
+    # ~eps amplify the 1e-7 gradient rounding difference, hence the looser bar.
+    check_params(p, {k: g['%s.after.%s' % (tag, k)] for k in spec.param_keys()},
+                 spec.param_keys(), spec.batch_norm,
+                 1e-5 if oname in ('sgd', 'adadelta') else 1e-4)
+    if bn:
+        for k in p:
+            # running_mean absorbs the (non-comparable) pre-BN bias under the
+            # normalising optimizers; see conftest.check_params
+            if 'running_var' in k or ('running_mean' in k and
+                                      oname in ('sgd', 'adadelta')):
+                assert rel_err(p[k], g['%s.after.%s' % (tag, k)]) < TOL, k
+
+
+@pytest.mark.parametrize('bn', [0, 1])
+@pytest.mark.parametrize('oname', ['sgd', 'adadelta'])
+def test_mid_five_steps(bn, oname):
+    g = load_golden('train_mid_bn%d.npz' % bn)
+    spec, _ = spec_from(g)
+    p = params_from(g)
+    tag = 'coscos2.avg0.' + oname
+    opt = O.Optimizer(oname, {'sgd': 0.001, 'adadelta': 0.1}[oname])
+    losses = []
+    for s in range(5):
+        b = s % 3
+        loss, grads, _ = O.train_step(p, g['x1.%d' % b], g['x2.%d' % b],
+                                      g['y.%d' % b], spec, opt, avg=False)
+        losses.append(loss)
+        if s == 0:
+            # three narrow sigmoid layers leave cos in [0.99994, 0.99999]:
+            # d cos/d e is then a difference of nearly equal terms and the
+            # reference's own fp32 gradients sit up to 5.7e-4 (relative) away
+            # from an fp64 evaluation of the same graph (measured; the oracle,
+            # which forms the loss gradient in fp64, is within 1e-5 of it).
+            check_grads(grads, {k: g['%s.grad0.%s' % (tag, k)]
+                                for k in spec.param_keys()},
+                        spec.param_keys(), spec.batch_norm, tol=1e-3)
+    assert np.allclose(losses, g[tag + '.losses'], rtol=1e-5)
+    check_params(p, {k: g['%s.after.%s' % (tag, k)] for k in spec.param_keys()},
+                 spec.param_keys(), spec.batch_norm, 1e-3)   # biases = -lr*sum(grads)
+
+
+LOSS_TAGS = [(ls, ln, m, a) for ls in ('mixed', 'allsame', 'alldiff', 'f64')
+             for (ln, m) in (('coscos2', None), ('cosmargin', None), ('cosmargin', 0.2))
+             for a in (1, 0)]
+
+
+@pytest.mark.parametrize('ls,lname,margin,avg', LOSS_TAGS)
+def test_loss_edge_cases(ls, lname, margin, avg):
+    g = load_golden('loss_edge.npz')
+    tag = '%s.%s%s.avg%d' % (ls, lname, '' if margin is None else '_m%g' % margin, avg)
+    loss, de1, de2, _ = O.pair_loss(g['e1'], g['e2'], g['y.' + ls], lname,
+                                    0.5 if margin is None else margin, bool(avg))
+    assert abs(loss - float(g[tag + '.loss'])) <= 1e-5 * abs(float(g[tag + '.loss'])) + 1e-6
+    ref1, ref2 = g[tag + '.de1'], g[tag + '.de2']
+    check_loss_grads(de1, de2, ref1, ref2, lname, tag)
+
+
+def test_c2_losses_from_seeded_init():
+    """True C2 (40->500x2->100, B=4096): weights regenerated with torch's own
+    initialisers under the fixture's seed; 5 Adadelta steps."""
+    torch = pytest.importorskip('torch')
+    g = load_golden('train_c2_bn0.npz')
+    spec, kw = spec_from(g)
+    from oracle import torch_ref
+    net = torch_ref.build(seed=2, **kw)
+    p = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
+    for k, v in p.items():
+        assert np.allclose([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum()],
+                           g['chk.' + k], rtol=1e-9), k
+    opt = O.Optimizer('adadelta', 0.1)
+    losses = []
+    for s in range(5):
+        x1, x2, y = torch_ref.make_inputs(4096, 40, 20 + s % 2)
+        loss, grads, (e1, e2) = O.train_step(p, x1.numpy(), x2.numpy(), y, spec,
+                                             opt, avg=False)
+        losses.append(loss)
+        if s == 0:
+            assert rel_err(e1[:8], g['e1_rows']) < TOL
+            assert rel_err(e2[-8:], g['e2_rows']) < TOL
+            for k in spec.param_keys():
+                gg = grads[k].reshape(grads[k].shape[0], -1)
+                # at this init cos is in [0.99998, 0.999997]; the reference's
+                # fp32 gradients are themselves 1e-5..1.1e-4 away from an fp64
+                # evaluation of the same graph (measured, DESIGN.md "parity")
+                assert rel_err(gg[:4], g['grow.' + k], GFLOOR) < 3e-4, k
+    assert np.allclose(losses, g['losses'], rtol=2e-5)

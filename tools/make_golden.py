@@ -1,0 +1,409 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference); never on the GPU box.
+The reference's modules import five third-party packages that are absent here
+(h5features, dtw, spectral, h5py, tensorboardX); they are registered as empty
+stub modules in THIS process only, so that abnet3.model / abnet3.loss /
+abnet3.utils.cosine_distance / FeaturesGenerator.stack_fbanks can be imported
+and executed unmodified on torch-CPU.  Nothing of the reference is copied: the
+fixtures are inputs + the outputs the reference produced for them.
+
+Fixture sets:
+  G1 tower_*      SiameseNetwork forward, eval + train mode, BN on/off
+  G2 train_c1_*   loss scalar + every parameter gradient + params after 3 steps
+  G3 loss_edge    pair losses on edge-case rows (label 0, tiny norms, margin)
+  G4 train_mid / train_c2   reduced-width C2 with full tensors; true C2 scalars
+  G5 cosdist      abnet3.utils.cosine_distance
+  G6 stack        FeaturesGenerator.stack_fbanks
+  G7 frames       OriginalDataLoader.load_frames_from_pairs (needs the oracle DTW
+                  monkey-patched in as get_dtw_alignment; third-party dtw absent)
+
+usage: python tools/make_golden.py [--only G1,G3]
+"""
+import argparse
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+REF = '/root/reference'
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+
+def import_reference():
+    for name in ['h5features', 'dtw', 'spectral', 'h5py', 'tensorboardX']:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules['dtw'].DTW = None
+    sys.modules['spectral'].Spectral = None
+    sys.modules['tensorboardX'].SummaryWriter = None
+    sys.path.insert(0, REF)
+    import scipy
+    if not hasattr(scipy, 'arccos'):
+        scipy.arccos = np.arccos      # removed from scipy >= 1.12 (utils.py:50,53)
+    warnings.simplefilter('ignore')
+    import torch  # noqa
+    import abnet3.model
+    import abnet3.loss
+    import abnet3.utils
+    import abnet3.features
+    import abnet3.dataloader
+    return abnet3
+
+
+def sd_to_np(net, prefix='p.'):
+    return {prefix + k: v.detach().cpu().numpy().copy()
+            for k, v in net.state_dict().items()}
+
+
+def make_inputs(B, D, seed):
+    import torch
+    torch.manual_seed(seed)
+    x1 = torch.randn(B, D)
+    x2 = torch.randn(B, D)
+    np.random.seed(seed)
+    y = np.random.choice([1, -1], B)
+    return x1, x2, y
+
+
+def build_net(abnet3, seed, **kw):
+    import torch
+    torch.manual_seed(seed)
+    return abnet3.model.SiameseNetwork(**kw)
+
+
+OPTIMS = {
+    'sgd': lambda torch, p: torch.optim.SGD(p, lr=0.001, momentum=0.9),
+    'adadelta': lambda torch, p: torch.optim.Adadelta(p, lr=0.1),
+    'adam': lambda torch, p: torch.optim.Adam(p, lr=0.001),
+    'adagrad': lambda torch, p: torch.optim.Adagrad(p, lr=0.001),
+    'RMSprop': lambda torch, p: torch.optim.RMSprop(p, lr=0.001),
+}
+
+
+def g1_tower(abnet3):
+    """G1: tower forward in eval and train mode (model.py:179-196)."""
+    import torch
+    cases = {
+        'sig': dict(activation_layer='sigmoid', batch_norm=False),
+        'sig_bn': dict(activation_layer='sigmoid', batch_norm=True),
+        'relu_bn': dict(activation_layer='relu', batch_norm=True),
+        'tanh': dict(activation_layer='tanh', batch_norm=False),
+        'sig_lin': dict(activation_layer='sigmoid', batch_norm=False,
+                        last_non_linearity=None),
+        'relu_h2': dict(activation_layer='relu', batch_norm=False,
+                        num_hidden_layers=2),
+    }
+    for name, extra in cases.items():
+        kw = dict(input_dim=40, num_hidden_layers=0, hidden_dim=100,
+                  output_dim=50, p_dropout=0.0, type_init='xavier_uni')
+        kw.update(extra)
+        net = build_net(abnet3, 0, **kw)
+        x1, x2, y = make_inputs(32, 40, 0)
+        out = sd_to_np(net)
+        out['x1'], out['x2'], out['y'] = x1.numpy(), x2.numpy(), y
+        net.eval()
+        with torch.no_grad():
+            e1, e2 = net(x1, x2)
+        out['eval_e1'], out['eval_e2'] = e1.numpy(), e2.numpy()
+        net.train()
+        with torch.no_grad():
+            e1, e2 = net(x1, x2)
+        out['train_e1'], out['train_e2'] = e1.numpy(), e2.numpy()
+        out.update(sd_to_np(net, 'after.'))   # BN running stats after 2 calls
+        out['kw'] = np.array(repr(kw))
+        np.savez_compressed(os.path.join(OUT, 'tower_%s.npz' % name), **out)
+
+
+def run_steps(abnet3, net, loss_mod, optim_name, batches, nsteps, out, tag):
+    """Re-enacts trainer.py:236-242 (optimize_model's five statements)."""
+    import torch
+    opt = OPTIMS[optim_name](torch, net.parameters())
+    net.train()
+    losses = []
+    for s in range(nsteps):
+        x1, x2, y = batches[s % len(batches)]
+        e1, e2 = net(x1, x2)
+        lv = loss_mod(e1, e2, torch.from_numpy(y))
+        opt.zero_grad()
+        lv.backward()
+        if s == 0:
+            for k, p in net.named_parameters():
+                out['%s.grad0.%s' % (tag, k)] = p.grad.detach().numpy().copy()
+            out['%s.e1_0' % tag] = e1.detach().numpy().copy()
+            out['%s.e2_0' % tag] = e2.detach().numpy().copy()
+        opt.step()
+        losses.append(float(lv.detach()))
+    out['%s.losses' % tag] = np.array(losses, dtype=np.float64)
+    for k, v in net.state_dict().items():
+        out['%s.after.%s' % (tag, k)] = v.detach().numpy().copy()
+
+
+def g2_train_c1(abnet3):
+    """G2: C1 = 40->100->50, B=32. Loss, all grads, params after 3 steps."""
+    for bn in (False, True):
+        out = {}
+        kw = dict(input_dim=40, num_hidden_layers=0, hidden_dim=100,
+                  output_dim=50, p_dropout=0.0, type_init='xavier_uni',
+                  activation_layer='sigmoid', batch_norm=bn)
+        x1, x2, y = make_inputs(32, 40, 0)
+        out['x1'], out['x2'], out['y'] = x1.numpy(), x2.numpy(), y
+        net0 = build_net(abnet3, 0, **kw)
+        out.update(sd_to_np(net0))
+        for lname in ('coscos2', 'cosmargin'):
+            for avg in (True, False):
+                for oname in OPTIMS:
+                    if oname not in ('sgd', 'adadelta') and not (
+                            lname == 'coscos2' and avg is False):
+                        continue
+                    net = build_net(abnet3, 0, **kw)
+                    loss_mod = getattr(abnet3.loss, lname)(avg=avg)
+                    tag = '%s.avg%d.%s' % (lname, int(avg), oname)
+                    run_steps(abnet3, net, loss_mod, oname, [(x1, x2, y)], 3,
+                              out, tag)
+        out['kw'] = np.array(repr(kw))
+        np.savez_compressed(
+            os.path.join(OUT, 'train_c1_bn%d.npz' % int(bn)), **out)
+
+
+def g3_loss_edge(abnet3):
+    """G3: pair losses + autograd gradients on edge-case rows (loss.py:46-105)."""
+    import torch
+    torch.manual_seed(3)
+    B, D = 32, 50
+    e1 = torch.randn(B, D)
+    e2 = torch.randn(B, D)
+    np.random.seed(3)
+    y = np.random.choice([1, -1], B).astype(np.int64)
+    y[0] = 0            # any other label leaves raw cos (loss.py:60-63)
+    y[1] = 2
+    e2[2] = e1[2]       # identical rows, same
+    y[2] = 1
+    e2[3] = e1[3]       # identical rows, diff
+    y[3] = -1
+    e2[4] = -e1[4]      # opposite rows
+    y[4] = -1
+    e1[5] = e1[5] * 1e-8   # tiny norm -> eps clamp on one side
+    y[5] = 1
+    e1[6] = e1[6] * 1e-8
+    e2[6] = e2[6] * 1e-8   # both below eps
+    y[6] = -1
+    e1[7] = 0.0            # exact zero row
+    y[7] = 1
+    e1[8] = e1[8] * 1e-7   # around eps=1e-6 (norm ~ 7e-7)
+    y[8] = -1
+    # cos just above / below the default margin 0.5 for cosmargin
+    v = torch.randn(D)
+    w = torch.randn(D)
+    w = w - (w @ v) / (v @ v) * v
+    v = v / v.norm()
+    w = w / w.norm()
+    for row, c in ((9, 0.5005), (10, 0.4995), (11, 0.5)):
+        e1[row] = 2.0 * v
+        e2[row] = 3.0 * (c * v + float(np.sqrt(1 - c * c)) * w)
+        y[row] = -1
+    out = {'e1': e1.numpy().copy(), 'e2': e2.numpy().copy(), 'y': y}
+    label_sets = {
+        'mixed': y,
+        'allsame': np.ones(B, dtype=np.int64),
+        'alldiff': -np.ones(B, dtype=np.int64),
+        'f64': y.astype(np.float64),
+    }
+    for lsname, yy in label_sets.items():
+        out['y.' + lsname] = yy
+        for lname, kwargs in (('coscos2', {}), ('cosmargin', {}),
+                              ('cosmargin', {'margin': 0.2})):
+            for avg in (True, False):
+                a = e1.clone().requires_grad_(True)
+                b = e2.clone().requires_grad_(True)
+                mod = getattr(abnet3.loss, lname)(avg=avg, **kwargs)
+                lv = mod(a, b, torch.from_numpy(yy))
+                lv.backward()
+                tag = '%s.%s%s.avg%d' % (
+                    lsname, lname,
+                    '' if not kwargs else '_m%g' % kwargs['margin'], int(avg))
+                out[tag + '.loss'] = np.array(float(lv.detach()),
+                                              dtype=np.float64)
+                out[tag + '.de1'] = a.grad.numpy().copy()
+                out[tag + '.de2'] = b.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'loss_edge.npz'), **out)
+
+
+def g4_train_mid(abnet3):
+    """G4: reduced-width C2 with full tensors; true C2 with scalars only."""
+    import torch
+    # reduced width, odd sizes on purpose (tile tails): 40 -> 72 x2 -> 36, B=96
+    for bn in (False, True):
+        out = {}
+        kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=72,
+                  output_dim=36, p_dropout=0.0, type_init='xavier_uni',
+                  activation_layer='sigmoid', batch_norm=bn)
+        batches = []
+        for s in range(3):
+            x1, x2, y = make_inputs(96, 40, 10 + s)
+            batches.append((x1, x2, y))
+            out['x1.%d' % s], out['x2.%d' % s], out['y.%d' % s] = \
+                x1.numpy(), x2.numpy(), y
+        net0 = build_net(abnet3, 1, **kw)
+        out.update(sd_to_np(net0))
+        for oname in ('sgd', 'adadelta'):
+            net = build_net(abnet3, 1, **kw)
+            run_steps(abnet3, net, abnet3.loss.coscos2(avg=False), oname,
+                      batches, 5, out, 'coscos2.avg0.' + oname)
+        out['kw'] = np.array(repr(kw))
+        np.savez_compressed(
+            os.path.join(OUT, 'train_mid_bn%d.npz' % int(bn)), **out)
+
+    # true C2: 40 -> 500 x2 -> 100, B=4096; weights regenerated from the seed by
+    # torch's own initialisers, so only checksums + scalars + a few rows travel.
+    for bn in (False, True):
+        out = {}
+        kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=500,
+                  output_dim=100, p_dropout=0.0, type_init='xavier_uni',
+                  activation_layer='sigmoid', batch_norm=bn)
+        net = build_net(abnet3, 2, **kw)
+        for k, v in net.state_dict().items():
+            out['chk.' + k] = np.array([float(v.double().sum()),
+                                        float(v.double().abs().sum())])
+        batches = [make_inputs(4096, 40, 20 + s) for s in range(2)]
+        opt = torch.optim.Adadelta(net.parameters(), lr=0.1)
+        loss_mod = abnet3.loss.coscos2(avg=False)
+        net.train()
+        losses = []
+        for s in range(5):
+            x1, x2, y = batches[s % 2]
+            e1, e2 = net(x1, x2)
+            lv = loss_mod(e1, e2, torch.from_numpy(y))
+            opt.zero_grad()
+            lv.backward()
+            if s == 0:
+                out['e1_rows'] = e1.detach().numpy()[:8].copy()
+                out['e2_rows'] = e2.detach().numpy()[-8:].copy()
+                for k, p in net.named_parameters():
+                    g = p.grad.detach()
+                    out['gchk.' + k] = np.array(
+                        [float(g.double().sum()), float(g.double().abs().sum()),
+                         float(g.double().abs().max())])
+                    out['grow.' + k] = g.numpy().reshape(g.shape[0], -1)[:4].copy()
+            opt.step()
+            losses.append(float(lv.detach()))
+        out['losses'] = np.array(losses)
+        for k, v in net.state_dict().items():
+            out['after_chk.' + k] = np.array([float(v.double().sum()),
+                                              float(v.double().abs().sum())])
+        out['kw'] = np.array(repr(kw))
+        np.savez_compressed(
+            os.path.join(OUT, 'train_c2_bn%d.npz' % int(bn)), **out)
+
+
+def g5_cosdist(abnet3):
+    """G5: abnet3.utils.cosine_distance (utils.py:40-60)."""
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = {}
+    a = rng.standard_normal((37, 40)).astype(np.float32)
+    b = rng.standard_normal((29, 40)).astype(np.float32)
+    cases['f32'] = (a, b)
+    cases['f64'] = (a.astype(np.float64), b.astype(np.float64))
+    cases['one'] = (a[:1], b[:1])
+    az = a.copy()
+    bz = b.copy()
+    az[3] = 0
+    az[10] = 0
+    bz[7] = 0
+    cases['zero'] = (az, bz)
+    bd = a[:29] + 1e-3 * rng.standard_normal((29, 40)).astype(np.float32)
+    cases['near'] = (a, bd.astype(np.float32))
+    pos = np.abs(rng.standard_normal((50, 40))).astype(np.float32)
+    cases['pos'] = (pos[:30], pos[20:])
+    for name, (x, y) in cases.items():
+        out[name + '.x'], out[name + '.y'] = x, y
+        try:
+            out[name + '.d'] = abnet3.utils.cosine_distance(x, y)
+        except AssertionError:
+            out[name + '.d'] = np.array('AssertionError')
+    np.savez_compressed(os.path.join(OUT, 'cosdist.npz'), **out)
+
+
+def g6_stack(abnet3):
+    """G6: FeaturesGenerator.stack_fbanks (features.py:135-159)."""
+    rng = np.random.default_rng(6)
+    fg = abnet3.features.FeaturesGenerator.__new__(
+        abnet3.features.FeaturesGenerator)
+    out = {}
+    for name, (T, D, n) in {'t100_n7': (100, 40, 7), 't100_n3': (100, 40, 3),
+                            't5_n7': (5, 40, 7), 't2_n7': (2, 40, 7),
+                            't17_n1': (17, 13, 1)}.items():
+        f = rng.standard_normal((T, D)).astype(np.float32)
+        out[name + '.in'] = f
+        out[name + '.n'] = np.array(n)
+        out[name + '.out'] = fg.stack_fbanks(f, nframes=n)
+    np.savez_compressed(os.path.join(OUT, 'stack.npz'), **out)
+
+
+def g7_frames(abnet3):
+    """G7: OriginalDataLoader.load_frames_from_pairs (dataloader.py:166-261)
+    with a fake accessor and the build's oracle DTW standing in for the absent
+    third-party dtw.DTW (parity unpinned for the DTW itself)."""
+    sys.path.insert(0, REPO)
+    from oracle import dtw_oracle
+    rng = np.random.default_rng(7)
+    feats = {'u%d' % i: rng.standard_normal((n, 40)).astype(np.float32)
+             for i, n in enumerate((90, 70, 120, 64))}
+    times = {k: (np.arange(len(v)) * 0.01 + 0.0025) for k, v in feats.items()}
+    acc = abnet3.utils.Features_Accessor(times, feats)
+
+    def oracle_align(f1, f2):
+        d = abnet3.utils.cosine_distance(f1, f2)
+        p1, p2 = dtw_oracle.dtw_path(d)
+        return list(p1), list(p2)
+
+    abnet3.dataloader.get_dtw_alignment = oracle_align
+    out = {}
+    for k, v in feats.items():
+        out['feat.' + k] = v
+    pairs = [('u0', 0.10, 0.42, 'u1', 0.05, 0.31, 'same'),
+             ('u2', 0.50, 0.93, 'u3', 0.11, 0.37, 'same'),
+             ('u0', 0.33, 0.61, 'u2', 0.70, 1.05, 'diff'),
+             ('u1', 0.20, 0.20, 'u3', 0.30, 0.46, 'diff'),
+             ('u3', 0.40, 0.30, 'u1', 0.10, 0.20, 'same'),   # s>e: skipped
+             ('u1', 0.02, 0.29, 'u1', 0.31, 0.64, 'same')]
+    out['pairs'] = np.array([' '.join(map(str, p)) for p in pairs])
+    for align in (False, True):
+        dl = abnet3.dataloader.OriginalDataLoader(
+            'unused', 'unused', align_different_words=align)
+        dl.features = acc
+        grouped = abnet3.utils.group_pairs(pairs)
+        X1, X2, Y = dl.load_frames_from_pairs(grouped)
+        out['align%d.X1' % align] = X1
+        out['align%d.X2' % align] = X2
+        out['align%d.Y' % align] = Y
+    np.savez_compressed(os.path.join(OUT, 'frames.npz'), **out)
+
+
+ALL = {'G1': g1_tower, 'G2': g2_train_c1, 'G3': g3_loss_edge,
+       'G4': g4_train_mid, 'G5': g5_cosdist, 'G6': g6_stack, 'G7': g7_frames}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    abnet3 = import_reference()
+    import torch
+    torch.set_num_threads(1)      # deterministic summation order in fixtures
+    which = [s for s in args.only.split(',') if s] or list(ALL)
+    for g in which:
+        print('generating', g, flush=True)
+        ALL[g](abnet3)
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print('golden dir: %.1f KB' % (total / 1024))
+
+
+if __name__ == '__main__':
+    main()
