@@ -1,0 +1,120 @@
+"""ctypes binding of libabnet3_hip.so (include/abnet3_hip.h).
+
+There is no CPU fallback: if the shared object is missing or a tensor is not
+on a HIP device the call fails loudly.  torch is imported first so that the
+library binds to the HIP runtime torch already loaded (one runtime instance =
+shared streams and allocations).
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL: see module docstring)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libabnet3_hip.so')
+ABI_VERSION = 1
+MAX_LAYERS = 16
+
+ACT = {'none': 0, None: 0, 'sigmoid': 1, 'relu': 2, 'tanh': 3}
+LOSS = {'coscos2': 0, 'cosmargin': 1}
+OPT = {'sgd': 0, 'adadelta': 1, 'adam': 2, 'adagrad': 3, 'RMSprop': 4}
+Y_DTYPE = {torch.int8: 0, torch.int32: 1, torch.int64: 2, torch.float32: 3,
+           torch.float64: 4}
+
+# every symbol include/abnet3_hip.h declares: (restype, argtypes)
+_i64, _i32, _f32, _vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+SYMBOLS = {
+    'abn_abi_version': (C.c_int, []),
+    'abn_last_error': (C.c_char_p, []),
+    'abn_tower_ws_floats': (_i64, [_vp, _i64, _i64]),
+    'abn_tower_out_offset': (_i64, [_vp, _i64, _i64]),
+    'abn_tower_bwd_scratch_floats': (_i64, [_vp, _i64]),
+    'abn_tower_forward': (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int, _vp, _vp]),
+    'abn_tower_backward': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp,
+                                      _i64, _vp, _vp]),
+    'abn_pair_loss_ws_bytes': (_i64, [_i64]),
+    'abn_pair_loss': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, C.c_int,
+                                 _f32, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    'abn_optimizer_step': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _f32,
+                                      _f32, _f32, _f32, _i64, _f32, _vp]),
+    'abn_dtw_ws_bytes': (_i64, [_vp, _vp, _i64, _i64, _i64]),
+    'abn_dtw_host_stage_bytes': (_i64, [_vp, _vp, _i64]),
+    'abn_dtw_batched': (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
+                                   _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp,
+                                   _i64, _vp]),
+    'abn_cosine_distance': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
+    'abn_gather_rows': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    'abn_stack_frames': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    'abn_fbank': (C.c_int, [_vp, C.c_int, _i64, _i32, C.c_double, _i32, _i32,
+                             _f32, _vp, _vp, _i64, _vp, _vp]),
+}
+
+
+class TowerDesc(C.Structure):
+    """struct abn_tower_desc"""
+    _fields_ = [('n_layers', _i32), ('act', _i32), ('last_act', _i32),
+                ('batch_norm', _i32), ('dims', _i64 * (MAX_LAYERS + 1))] + [
+        (name, _vp * MAX_LAYERS)
+        for name in ('W', 'b', 'bn_w', 'bn_b', 'bn_rm', 'bn_rv', 'dW', 'db',
+                     'dbn_w', 'dbn_b')]
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Returns the bound library; raises HipLibraryError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            'abnet3_amd: %s is missing. Build it with `python -m abnet3_amd.build` '
+            '(hipcc, gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HipLibraryError('abnet3_amd: %s does not export %s '
+                                  '(stale build?)' % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.abn_abi_version() != ABI_VERSION:
+        raise HipLibraryError('abnet3_amd: ABI version mismatch (library %d, '
+                              'binding %d)' % (lib.abn_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().abn_last_error()
+        raise HipLibraryError('%s failed (%d): %s' % (
+            what, rc, msg.decode('utf-8', 'replace') if msg else ''))
+
+
+def require_device(*tensors):
+    """The accelerated path only takes contiguous fp32 HIP tensors."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HipLibraryError(
+                'abnet3_amd: expected a tensor on the MI355X (HIP) device, got '
+                'device=%s. The accelerated path has no CPU fallback; move the '
+                'module and its inputs to the GPU (.cuda()).' % t.device)
+        if not t.is_contiguous():
+            raise HipLibraryError('abnet3_amd: tensor must be contiguous')
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,528 @@
+// tower.hip -- SiameseNetwork tower forward / backward for gfx950.
+//
+// Replaces the torch op sequence behind abnet3/model.py:179-196 (forward_once /
+// forward) and its autograd (abnet3/trainer.py:239): per layer
+//   Linear (addmm) -> Dropout(p=0: identity) -> [BatchNorm1d] -> activation.
+// GEMMs run on the fp32 matrix cores (gemm_f32.h); bias + activation (forward)
+// and the activation derivative (dgrad) are fused into the GEMM epilogues; the
+// bias gradient rides in the wgrad GEMM as an extra all-ones input column.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+#include "gemm_f32.h"
+
+namespace abn {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------
+// GEMM dispatch
+// ---------------------------------------------------------------------------
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+static void launch_cfg(const GemmP& p, int splits, hipStream_t st)
+{
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    constexpr size_t lds = gemm_lds_bytes<BM, BN, A_KC, B_KC>();
+    auto k = gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>;
+    static bool attr_set = false;      // > 64 KiB of dynamic LDS needs the opt-in
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(256), lds, st, p);
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+static int launch_gemm(GemmP p, int splits, hipStream_t st)
+{
+    if (p.M <= 0 || p.N <= 0) return ABN_OK;
+    if (p.K <= 0) { set_error("gemm: empty reduction"); return ABN_E_ARG; }
+    auto tiles = [&](int bm, int bn) {
+        return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * splits;
+    };
+    // largest tile that still yields ~a workgroup per CU (256 CUs); among the
+    // two rectangular shapes prefer the one wasting less padding.
+    const int64_t want = 192;
+    if (p.M > 64 && p.N > 64 && tiles(128, 128) >= want)
+        launch_cfg<128, 128, A_KC, B_KC, EPI>(p, splits, st);
+    else {
+        const int64_t pad_a = (int64_t)((p.M + 127) / 128 * 128) * ((p.N + 63) / 64 * 64);
+        const int64_t pad_b = (int64_t)((p.M + 63) / 64 * 64) * ((p.N + 127) / 128 * 128);
+        if (p.M > 64 && tiles(128, 64) >= want && pad_a <= pad_b)
+            launch_cfg<128, 64, A_KC, B_KC, EPI>(p, splits, st);
+        else if (p.N > 64 && tiles(64, 128) >= want)
+            launch_cfg<64, 128, A_KC, B_KC, EPI>(p, splits, st);
+        else
+            launch_cfg<64, 64, A_KC, B_KC, EPI>(p, splits, st);
+    }
+    ABN_CHECK_LAUNCH("gemm_f32");
+    return ABN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// small elementwise / column-reduction kernels
+// ---------------------------------------------------------------------------
+__global__ void act_bwd_kernel(const float* __restrict__ a, const float* __restrict__ da,
+                               float* __restrict__ dz, int64_t n, int act)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dz[i] = da[i] * act_grad(a[i], act);
+}
+
+struct ReduceTable {
+    int n_layers;
+    int splits;
+    int64_t slab_stride;
+    int64_t off[ABN_MAX_LAYERS];     // packed offset of [W_l | b_l]
+    int64_t nW[ABN_MAX_LAYERS];
+    int64_t nb[ABN_MAX_LAYERS];
+    float* dW[ABN_MAX_LAYERS];
+    float* db[ABN_MAX_LAYERS];
+    int64_t total;
+};
+
+// grad[i] = sum_s slab[s][i] in fixed order (deterministic, unlike atomics)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, ReduceTable t)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < t.total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int k = 0; k < t.splits; ++k) s += slabs[(int64_t)k * t.slab_stride + i];
+        int l = 0;
+        while (l + 1 < t.n_layers && i >= t.off[l + 1]) ++l;
+        const int64_t j = i - t.off[l];
+        if (j < t.nW[l]) t.dW[l][j] = s;
+        else if (j - t.nW[l] < t.nb[l]) t.db[l][j - t.nW[l]] = s;
+    }
+}
+
+constexpr float BN_EPS = 1e-5f;
+constexpr float BN_MOMENTUM = 0.1f;
+
+// per (call, column): batch mean and 1/sqrt(biased var + eps) over the call's
+// rows.  32 columns x 8 row-lanes per block; fp64 accumulation.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int64_t rows_per_call,
+                                                       int C, float* __restrict__ mean,
+                                                       float* __restrict__ invstd,
+                                                       float* __restrict__ var_out)
+{
+    __shared__ double s1[8][33], s2[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx, g = blockIdx.y;
+    const float* zg = z + (int64_t)g * rows_per_call * C;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int64_t r = ty; r < rows_per_call; r += 8) {
+            const double v = zg[r * C + c];
+            a += v;
+            b += v * v;
+        }
+    s1[ty][tx] = a;
+    s2[ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { a += s1[k][tx]; b += s2[k][tx]; }
+        const double n = (double)rows_per_call;
+        const double m = a / n;
+        double var = b / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[(int64_t)g * C + c] = (float)m;
+        var_out[(int64_t)g * C + c] = (float)var;
+        invstd[(int64_t)g * C + c] = 1.0f / sqrtf((float)var + BN_EPS);
+    }
+}
+
+// running stats: one momentum update per forward_once call, in call order
+// (the reference updates twice per Siamese forward)
+__global__ void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                  int C, int n_calls, int64_t rows_per_call,
+                                  float* __restrict__ rm, float* __restrict__ rv)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float m = rm[c], v = rv[c];
+    const float unb = rows_per_call > 1 ? (float)((double)rows_per_call / (double)(rows_per_call - 1)) : 1.0f;
+    for (int g = 0; g < n_calls; ++g) {
+        m = (1.0f - BN_MOMENTUM) * m + BN_MOMENTUM * mean[(int64_t)g * C + c];
+        v = (1.0f - BN_MOMENTUM) * v + BN_MOMENTUM * (var[(int64_t)g * C + c] * unb);
+    }
+    rm[c] = m;
+    rv[c] = v;
+}
+
+// xhat = (z - mean) * invstd ; a = act(gamma * xhat + beta).  train: per-call
+// batch stats from ws; eval: running stats.
+__global__ void bn_apply_kernel(const float* z /* may alias xhat */, int64_t rows, int64_t rows_per_call, int C,
+                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                const float* __restrict__ rm, const float* __restrict__ rv, int train,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                int act, float* xhat, float* __restrict__ a)
+{
+    const int64_t n = rows * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t r = i / C;
+        float mu, is;
+        if (train) {
+            const int64_t g = r / rows_per_call;
+            mu = mean[g * C + c];
+            is = invstd[g * C + c];
+        } else {
+            mu = rm[c];
+            is = 1.0f / sqrtf(rv[c] + BN_EPS);
+        }
+        const float xh = (z[i] - mu) * is;
+        if (xhat) xhat[i] = xh;
+        a[i] = act_apply(xh * gamma[c] + beta[c], act);
+    }
+}
+
+// per (call, column): s1 = sum dy, s2 = sum dy*xhat with dy = da * act'(a)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ a, const float* __restrict__ da,
+                                                            const float* __restrict__ xhat, int64_t rows_per_call,
+                                                            int C, int act, float* __restrict__ s1o,
+                                                            float* __restrict__ s2o)
+{
+    __shared__ double s1[8][33], s2[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx, g = blockIdx.y;
+    const int64_t base = (int64_t)g * rows_per_call * C;
+    double u = 0.0, v = 0.0;
+    if (c < C)
+        for (int64_t r = ty; r < rows_per_call; r += 8) {
+            const int64_t i = base + r * C + c;
+            const double dy = (double)(da[i] * act_grad(a[i], act));
+            u += dy;
+            v += dy * xhat[i];
+        }
+    s1[ty][tx] = u;
+    s2[ty][tx] = v;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { u += s1[k][tx]; v += s2[k][tx]; }
+        s1o[(int64_t)g * C + c] = (float)u;
+        s2o[(int64_t)g * C + c] = (float)v;
+    }
+}
+
+// dz = gamma*invstd/n * (n*dy - s1 - xhat*s2); also dgamma = sum_g s2, dbeta = sum_g s1
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ a, const float* da,   // da may alias dz
+                                    const float* __restrict__ xhat, int64_t rows, int64_t rows_per_call,
+                                    int C, int act, const float* __restrict__ gamma,
+                                    const float* __restrict__ invstd, const float* __restrict__ s1,
+                                    const float* __restrict__ s2, int n_calls, float* dz,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    const int64_t n = rows * C;
+    const float nf = (float)rows_per_call;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t g = (i / C) / rows_per_call;
+        const float dy = da[i] * act_grad(a[i], act);
+        const float k = gamma[c] * invstd[g * C + c] / nf;
+        dz[i] = k * (nf * dy - s1[g * C + c] - xhat[i] * s2[g * C + c]);
+        if (i < C && dgamma) {
+            float sg = 0.0f, sb = 0.0f;
+            for (int q = 0; q < n_calls; ++q) { sg += s2[(int64_t)q * C + c]; sb += s1[(int64_t)q * C + c]; }
+            dgamma[c] = sg;
+            dbeta[c] = sb;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// workspace layout
+// ---------------------------------------------------------------------------
+struct Layout {
+    int64_t x;                           // [rows, dims[0]] copy of the inputs
+    int64_t a[ABN_MAX_LAYERS];           // post-activation outputs
+    int64_t xhat[ABN_MAX_LAYERS];        // BN only (z is produced here, then normalised in place)
+    int64_t mean[ABN_MAX_LAYERS], invstd[ABN_MAX_LAYERS], var[ABN_MAX_LAYERS];
+    int64_t total;
+};
+
+static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
+{
+    Layout L;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t r = o; o += align_up(n, 64); return r; };
+    L.x = take(rows * t->dims[0]);
+    for (int l = 0; l < t->n_layers; ++l) {
+        const int64_t w = t->dims[l + 1];
+        L.a[l] = take(rows * w);
+        if (t->batch_norm) {
+            L.xhat[l] = take(rows * w);
+            L.mean[l] = take(n_calls * w);
+            L.invstd[l] = take(n_calls * w);
+            L.var[l] = take(n_calls * w);
+        } else {
+            L.xhat[l] = L.mean[l] = L.invstd[l] = L.var[l] = -1;
+        }
+    }
+    L.total = o;
+    return L;
+}
+
+static int check_desc(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
+{
+    ABN_REQUIRE(t != nullptr, "tower: null descriptor");
+    ABN_REQUIRE(t->n_layers >= 1 && t->n_layers <= ABN_MAX_LAYERS, "tower: n_layers=%d out of range", t->n_layers);
+    ABN_REQUIRE(rows >= 0 && n_calls >= 1 && rows % n_calls == 0, "tower: rows=%lld not divisible by n_calls=%lld",
+                (long long)rows, (long long)n_calls);
+    for (int l = 0; l <= t->n_layers; ++l)
+        ABN_REQUIRE(t->dims[l] >= 1 && t->dims[l] < (1 << 24), "tower: dims[%d]=%lld invalid", l, (long long)t->dims[l]);
+    ABN_REQUIRE(rows < (1LL << 30), "tower: too many rows");
+    for (int a : {t->act, t->last_act})
+        if (a < ABN_ACT_NONE || a > ABN_ACT_TANH) { set_error("tower: unsupported activation %d", a); return ABN_E_UNSUPPORTED; }
+    for (int l = 0; l < t->n_layers; ++l) {
+        ABN_REQUIRE(t->W[l] && t->b[l], "tower: layer %d has null weight/bias", l);
+        if (t->batch_norm)
+            ABN_REQUIRE(t->bn_w[l] && t->bn_b[l] && t->bn_rm[l] && t->bn_rv[l], "tower: layer %d has null BN tensors", l);
+    }
+    return ABN_OK;
+}
+
+static int split_count(int64_t rows) { return (int)(rows / 512 < 1 ? 1 : (rows / 512 > 16 ? 16 : rows / 512)); }
+
+struct BwdLayout {
+    int64_t dz[2];
+    int64_t bn_s1, bn_s2;
+    int64_t slabs;
+    int64_t slab_stride;
+    int64_t off[ABN_MAX_LAYERS];
+    int splits;
+    int64_t total;
+};
+
+static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
+{
+    BwdLayout B;
+    int64_t maxw = 0, o = 0, packed = 0;
+    for (int l = 0; l <= t->n_layers; ++l) maxw = t->dims[l] > maxw ? t->dims[l] : maxw;
+    auto take = [&](int64_t n) { int64_t r = o; o += align_up(n, 64); return r; };
+    B.dz[0] = take(rows * maxw);
+    B.dz[1] = take(rows * maxw);
+    B.bn_s1 = take(8 * maxw);
+    B.bn_s2 = take(8 * maxw);
+    for (int l = 0; l < t->n_layers; ++l) {
+        B.off[l] = packed;
+        packed += t->dims[l + 1] * t->dims[l] + t->dims[l + 1];
+    }
+    B.slab_stride = align_up(packed, 64);
+    B.splits = split_count(rows);
+    B.slabs = take(B.slab_stride * B.splits);
+    B.total = o;
+    return B;
+}
+
+static inline int grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
+
+}  // namespace abn
+
+using namespace abn;
+
+extern "C" {
+
+int abn_abi_version(void) { return ABN_ABI_VERSION; }
+const char* abn_last_error(void) { return abn::g_err; }
+
+int64_t abn_tower_ws_floats(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
+{
+    if (check_desc(t, rows, n_calls) != ABN_OK) return -1;
+    return make_layout(t, rows, n_calls).total;
+}
+
+int64_t abn_tower_out_offset(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
+{
+    if (check_desc(t, rows, n_calls) != ABN_OK) return -1;
+    return make_layout(t, rows, n_calls).a[t->n_layers - 1];
+}
+
+int64_t abn_tower_bwd_scratch_floats(const abn_tower_desc* t, int64_t rows)
+{
+    if (check_desc(t, rows, 1) != ABN_OK) return -1;
+    return make_bwd_layout(t, rows).total;
+}
+
+int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2, int64_t rows,
+                      int64_t n_calls, int train, float* ws, void* stream)
+{
+    int rc = check_desc(t, rows, n_calls);
+    if (rc != ABN_OK) return rc;
+    ABN_REQUIRE(x1 && ws, "tower_forward: null input/workspace");
+    ABN_REQUIRE(x2 == nullptr || n_calls == 2, "tower_forward: x2 given but n_calls=%lld", (long long)n_calls);
+    ABN_REQUIRE(n_calls <= 8, "tower_forward: at most 8 calls per launch");
+    if (rows == 0) return ABN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const Layout L = make_layout(t, rows, n_calls);
+    const int64_t rpc = rows / n_calls;
+
+    const float* in = x1;
+    if (x2) {    // the two towers' inputs become one [2B, D] operand
+        const size_t half = (size_t)rpc * t->dims[0] * sizeof(float);
+        if (hipMemcpyAsync(ws + L.x, x1, half, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(ws + L.x + rpc * t->dims[0], x2, half, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            set_error("tower_forward: input copy failed");
+            return ABN_E_LAUNCH;
+        }
+        in = ws + L.x;
+    }
+    for (int l = 0; l < t->n_layers; ++l) {
+        const int K = (int)t->dims[l], N = (int)t->dims[l + 1];
+        const int act = (l == t->n_layers - 1) ? t->last_act : t->act;
+        float* a = ws + L.a[l];
+        GemmP p = {};
+        p.A = in; p.lda = K;
+        p.B = t->W[l]; p.ldb = K;
+        p.M = (int)rows; p.N = N; p.K = K; p.k_chunk = K;
+        p.bias = t->b[l];
+        p.a_vec = aligned16(in) && (K % 4 == 0);
+        p.b_vec = aligned16(t->W[l]) && (K % 4 == 0);
+        p.ones_col = -1;
+        if (!t->batch_norm) {
+            p.C = a; p.ldc = N; p.act = act;
+            rc = launch_gemm<true, true, EPI_FWD>(p, 1, st);
+            if (rc != ABN_OK) return rc;
+        } else {
+            float* z = ws + L.xhat[l];          // z lands where xhat will live
+            p.C = z; p.ldc = N; p.act = ACT_NONE;
+            rc = launch_gemm<true, true, EPI_FWD>(p, 1, st);
+            if (rc != ABN_OK) return rc;
+            if (train) {
+                hipLaunchKernelGGL(bn_stats_kernel, dim3((N + 31) / 32, (int)n_calls), dim3(256), 0, st, z, rpc, N,
+                                   ws + L.mean[l], ws + L.invstd[l], ws + L.var[l]);
+                hipLaunchKernelGGL(bn_running_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws + L.mean[l],
+                                   ws + L.var[l], N, (int)n_calls, rpc, t->bn_rm[l], t->bn_rv[l]);
+            }
+            hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, z, rows, rpc, N,
+                               ws + L.mean[l], ws + L.invstd[l], t->bn_rm[l], t->bn_rv[l], train, t->bn_w[l],
+                               t->bn_b[l], act, z, a);
+            ABN_CHECK_LAUNCH("batch_norm forward");
+        }
+        in = a;
+    }
+    return ABN_OK;
+}
+
+int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2, const float* d_out,
+                       int64_t rows, int64_t n_calls, const float* ws, float* scratch,
+                       int64_t scratch_floats, float* dx, void* stream)
+{
+    int rc = check_desc(t, rows, n_calls);
+    if (rc != ABN_OK) return rc;
+    ABN_REQUIRE(x1 && d_out && ws && scratch, "tower_backward: null pointer");
+    for (int l = 0; l < t->n_layers; ++l) {
+        ABN_REQUIRE(t->dW[l] && t->db[l], "tower_backward: layer %d has null gradient buffers", l);
+        if (t->batch_norm) ABN_REQUIRE(t->dbn_w[l] && t->dbn_b[l], "tower_backward: layer %d has null BN gradient buffers", l);
+    }
+    if (rows == 0) return ABN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const Layout L = make_layout(t, rows, n_calls);
+    const BwdLayout B = make_bwd_layout(t, rows);
+    if (scratch_floats < B.total) {
+        set_error("tower_backward: scratch too small (%lld < %lld floats)", (long long)scratch_floats, (long long)B.total);
+        return ABN_E_WORKSPACE;
+    }
+    const int64_t rpc = rows / n_calls;
+    const float* xin = x2 ? ws + L.x : x1;
+    const int nl = t->n_layers;
+    int cur = 0;
+
+    // dz of the output layer from d_out
+    {
+        const int N = (int)t->dims[nl];
+        const float* a = ws + L.a[nl - 1];
+        float* dz = scratch + B.dz[cur];
+        if (!t->batch_norm) {
+            hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, a, d_out, dz, rows * N,
+                               t->last_act);
+        } else {
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((N + 31) / 32, (int)n_calls), dim3(256), 0, st, a, d_out,
+                               ws + L.xhat[nl - 1], rpc, N, t->last_act, scratch + B.bn_s1, scratch + B.bn_s2);
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, a, d_out,
+                               ws + L.xhat[nl - 1], rows, rpc, N, t->last_act, t->bn_w[nl - 1],
+                               ws + L.invstd[nl - 1], scratch + B.bn_s1, scratch + B.bn_s2, (int)n_calls, dz,
+                               t->dbn_w[nl - 1], t->dbn_b[nl - 1]);
+        }
+        ABN_CHECK_LAUNCH("output-layer dz");
+    }
+
+    float* slabs = scratch + B.slabs;
+    for (int l = nl - 1; l >= 0; --l) {
+        const int Kin = (int)t->dims[l], Nout = (int)t->dims[l + 1];
+        const float* dz = scratch + B.dz[cur];
+        const float* a_in = (l == 0) ? xin : ws + L.a[l - 1];
+        // wgrad: dW[Nout, Kin] (+ db via the ones column) = dz^T a_in, split over rows
+        {
+            GemmP p = {};
+            p.A = dz; p.lda = Nout;
+            p.B = a_in; p.ldb = Kin;
+            p.C = slabs + B.off[l]; p.ldc = Kin;
+            p.C2 = slabs + B.off[l] + (int64_t)Nout * Kin;
+            p.slab_stride = B.slab_stride;
+            p.M = Nout; p.N = Kin + 1; p.K = (int)rows;
+            p.k_chunk = (int)align_up((rows + B.splits - 1) / B.splits, BK);
+            p.ones_col = Kin;
+            p.a_vec = aligned16(dz) && (Nout % 4 == 0);
+            p.b_vec = aligned16(a_in) && (Kin % 4 == 0);
+            rc = launch_gemm<false, false, EPI_WGRAD>(p, B.splits, st);
+            if (rc != ABN_OK) return rc;
+        }
+        // dgrad: d a_{l-1} = dz W_l, times act'(a_{l-1}) when no BN sits in between
+        if (l > 0 || dx) {
+            float* dst = (l == 0) ? dx : scratch + B.dz[cur ^ 1];
+            GemmP p = {};
+            p.A = dz; p.lda = Nout;
+            p.B = t->W[l]; p.ldb = Kin;
+            p.C = dst; p.ldc = Kin;
+            p.M = (int)rows; p.N = Kin; p.K = Nout; p.k_chunk = Nout;
+            p.a_vec = aligned16(dz) && (Nout % 4 == 0);
+            p.b_vec = aligned16(t->W[l]) && (Kin % 4 == 0);
+            p.ones_col = -1;
+            if (l > 0 && !t->batch_norm) { p.aux = ws + L.a[l - 1]; p.ldaux = Kin; p.act = t->act; }
+            rc = launch_gemm<true, false, EPI_DGRAD>(p, 1, st);
+            if (rc != ABN_OK) return rc;
+            if (l > 0 && t->batch_norm) {
+                // dst holds d a_{l-1}; turn it into d z_{l-1} through act' and BN
+                const float* a = ws + L.a[l - 1];
+                hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((Kin + 31) / 32, (int)n_calls), dim3(256), 0, st, a,
+                                   dst, ws + L.xhat[l - 1], rpc, Kin, t->act, scratch + B.bn_s1, scratch + B.bn_s2);
+                hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * Kin)), dim3(256), 0, st, a, dst,
+                                   ws + L.xhat[l - 1], rows, rpc, Kin, t->act, t->bn_w[l - 1], ws + L.invstd[l - 1],
+                                   scratch + B.bn_s1, scratch + B.bn_s2, (int)n_calls, dst, t->dbn_w[l - 1],
+                                   t->dbn_b[l - 1]);
+                ABN_CHECK_LAUNCH("batch_norm backward");
+            }
+            cur ^= 1;
+        }
+    }
+    ReduceTable rt = {};
+    rt.n_layers = nl;
+    rt.splits = B.splits;
+    rt.slab_stride = B.slab_stride;
+    for (int l = 0; l < nl; ++l) {
+        rt.off[l] = B.off[l];
+        rt.nW[l] = t->dims[l + 1] * t->dims[l];
+        rt.nb[l] = t->dims[l + 1];
+        rt.dW[l] = t->dW[l];
+        rt.db[l] = t->db[l];
+    }
+    rt.total = B.off[nl - 1] + rt.nW[nl - 1] + rt.nb[nl - 1];
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(rt.total)), dim3(256), 0, st, slabs, rt);
+    ABN_CHECK_LAUNCH("slab_reduce");
+    return ABN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+"""SiameseNetwork on MI355X: the class surface of abnet3/model.py, HIP inside.
+
+Mirrors (file:line relative to the reference checkout)
+  NetworkBuilder   abnet3/model.py:30-79
+  SiameseNetwork   abnet3/model.py:82-208   (same constructor kwargs, asserts,
+                   state_dict key names, init order and RNG consumption, so one
+                   torch.manual_seed gives the reference's initial weights and
+                   reference .pth files load unchanged)
+The nn.Linear / nn.BatchNorm1d modules are kept as parameter HOLDERS only; the
+arithmetic of forward_once / forward and of their autograd runs in
+libabnet3_hip.so (abn_tower_forward / abn_tower_backward).  There is no CPU
+path: calling the network with CPU tensors raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+activation_functions = {'relu': nn.ReLU,
+                        'sigmoid': nn.Sigmoid,
+                        'tanh': nn.Tanh,
+                        'softmax': nn.Softmax,
+                        }
+
+init_functions = {'xavier_uni': nn.init.xavier_uniform_,
+                  'xavier_normal': nn.init.xavier_normal_,
+                  'orthogonal': nn.init.orthogonal_}
+
+_ALIGN = 64     # floats: every tensor of the flat buffers starts 256-B aligned
+
+
+class NetworkBuilder(nn.Module):
+    """Generic Neural Network Model class (abnet3/model.py:30-79)."""
+
+    def __init__(self, *args, **kwargs):
+        super(NetworkBuilder, self).__init__()
+
+    def forward_once(self, *args, **kwargs):
+        raise NotImplementedError('Unimplemented forward_once for class:',
+                                  self.__class__.__name__)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('Unimplemented forward for class:',
+                                  self.__class__.__name__)
+
+    def whoami(self, *args, **kwargs):
+        raise NotImplementedError('Unimplemented whoami for class:',
+                                  self.__class__.__name__)
+
+    def save_network(self, *args, **kwargs):
+        raise NotImplementedError('Unimplemented save_network for class:',
+                                  self.__class__.__name__)
+
+    def load_network(self, *args, **kwargs):
+        raise NotImplementedError('Unimplemented load_network for class:',
+                                  self.__class__.__name__)
+
+    def init_weight_method(self, *args, **kwargs):
+        raise NotImplementedError('Unimplemented init_weight_method' +
+                                  'for class:',
+                                  self.__class__.__name__)
+
+    def plot_network(self, *args, **kwargs):
+        raise NotImplementedError('Unimplemented plot_network for class:',
+                                  self.__class__.__name__)
+
+
+class _TowerFunction(torch.autograd.Function):
+    """One launch sequence for n_calls forward_once calls sharing the weights."""
+
+    @staticmethod
+    def forward(ctx, net, n_calls, x1, x2, *params):
+        lib = _lib.load()
+        _lib.require_device(x1, x2, *params)
+        if x1.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
+            raise TypeError('abnet3_amd: features must be float32 (the reference '
+                            'casts them, abnet3/utils.py:228-235)')
+        if x1.dim() != 2 or x1.shape[1] != net.input_dim:
+            raise ValueError('abnet3_amd: expected input of shape [n, %d], got %s'
+                             % (net.input_dim, tuple(x1.shape)))
+        if x2 is not None and x2.shape != x1.shape:
+            raise ValueError('abnet3_amd: the two inputs must have the same shape')
+        train = bool(net.training)
+        rows = x1.shape[0] * (2 if x2 is not None else 1)
+        desc = net._descriptor(with_grads=False)
+        ws_floats = lib.abn_tower_ws_floats(_lib.C.byref(desc), rows, n_calls)
+        if ws_floats < 0:
+            _lib.check(-1, 'abn_tower_ws_floats')
+        ws = torch.empty(max(ws_floats, 1), dtype=torch.float32, device=x1.device)
+        _lib.check(lib.abn_tower_forward(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2),
+                                         rows, n_calls, int(train), _lib.ptr(ws),
+                                         _lib.stream()), 'abn_tower_forward')
+        if train and net.batch_norm:
+            for bn in net._bn_modules():
+                bn.num_batches_tracked += n_calls
+        off = lib.abn_tower_out_offset(_lib.C.byref(desc), rows, n_calls)
+        out = ws[off:off + rows * net.output_dim].view(rows, net.output_dim)
+        ctx.net, ctx.n_calls, ctx.train = net, n_calls, train
+        ctx.have_x2 = x2 is not None
+        ctx.save_for_backward(x1, x2, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        net = ctx.net
+        x1, x2, ws = ctx.saved_tensors
+        if net.batch_norm and not ctx.train:
+            raise NotImplementedError(
+                'abnet3_amd: backward through an eval-mode BatchNorm forward is '
+                'not on the accelerated path (the reference trains in train mode, '
+                'abnet3/trainer.py:234)')
+        d_out = d_out.contiguous()
+        _lib.require_device(d_out)
+        rows = d_out.shape[0]
+        grads = net._new_grad_views()
+        desc = net._descriptor(with_grads=True, grad_views=grads)
+        scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
+        scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32,
+                              device=d_out.device)
+        need_dx = ctx.needs_input_grad[2] or (ctx.have_x2 and ctx.needs_input_grad[3])
+        dx = torch.empty(rows, net.input_dim, dtype=torch.float32,
+                         device=d_out.device) if need_dx else None
+        _lib.check(lib.abn_tower_backward(
+            _lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(d_out), rows,
+            ctx.n_calls, _lib.ptr(ws), _lib.ptr(scratch), scratch_floats,
+            _lib.ptr(dx), _lib.stream()), 'abn_tower_backward')
+        dx1 = dx2 = None
+        if need_dx:
+            if ctx.have_x2:
+                dx1, dx2 = dx[:rows // 2], dx[rows // 2:]
+            else:
+                dx1 = dx
+        return (None, None, dx1, dx2) + tuple(grads)
+
+
+class SiameseNetwork(NetworkBuilder):
+    """Siamese neural network Architecture (abnet3/model.py:82-208).
+
+    Parameters: see the reference docstring; identical names and defaults.
+    """
+
+    def __init__(self, input_dim=None, num_hidden_layers=None, hidden_dim=None,
+                 output_dim=None, p_dropout=0.1, batch_norm=False,
+                 type_init='xavier_uni', activation_layer=None,
+                 output_path=None, last_non_linearity="default"):
+        super(SiameseNetwork, self).__init__()
+        assert activation_layer in ('relu', 'sigmoid', 'tanh')
+        assert type_init in ('xavier_uni', 'xavier_normal', 'orthogonal')
+        assert type(input_dim) == int, 'input dim should be int'
+        assert type(hidden_dim) == int, 'hidden dim should be int'
+        assert type(num_hidden_layers) == int, 'num hidden lay should be int'
+        assert type(output_dim) == int, 'output dim should be int'
+        assert num_hidden_layers + 2 <= _lib.MAX_LAYERS, 'too many layers'
+
+        self.input_dim = input_dim
+        self.num_hidden_layers = num_hidden_layers
+        self.hidden_dim = hidden_dim
+        self.output_dim = output_dim
+        self.activation_layer = activation_layer
+        self.batch_norm = batch_norm
+        self.type_init = type_init
+        self.last_non_linearity = last_non_linearity
+        self.p_dropout = p_dropout
+
+        activation = activation_functions[activation_layer]
+
+        # same module order as the reference => same state_dict keys and the
+        # same RNG consumption during construction
+        input_layer = [nn.Linear(input_dim, hidden_dim), nn.Dropout(p=p_dropout)]
+        if self.batch_norm:
+            input_layer.append(nn.BatchNorm1d(hidden_dim))
+        input_layer.append(activation())
+        self.input_emb = nn.Sequential(*input_layer)
+
+        hidden = []
+        for idx in range(self.num_hidden_layers):
+            hidden.append(nn.Linear(hidden_dim, hidden_dim))
+            hidden.append(nn.Dropout(p=p_dropout))
+            if self.batch_norm:
+                hidden.append(nn.BatchNorm1d(hidden_dim))
+            hidden.append(activation())
+        self.hidden_layers = nn.Sequential(*hidden)
+
+        output_layer = [nn.Linear(hidden_dim, output_dim), nn.Dropout(p=p_dropout)]
+        if self.batch_norm:
+            output_layer.append(nn.BatchNorm1d(output_dim))
+        if self.last_non_linearity == "default":
+            output_layer.append(activation())
+            self._last_act = activation_layer
+        elif self.last_non_linearity is None:
+            self._last_act = 'none'
+        else:
+            output_layer.append(activation_functions[self.last_non_linearity]())
+            self._last_act = self.last_non_linearity
+        self.output_layer = nn.Sequential(*output_layer)
+        self.output_path = output_path
+        self.apply(self.init_weight_method)
+        self._flat = None
+        self._last_grad_flat = None
+        self._offsets = None
+
+    def init_weight_method(self, layer):
+        if isinstance(layer, nn.Linear):
+            init_func = init_functions[self.type_init]
+            init_func(layer.weight.data,
+                      gain=nn.init.calculate_gain(self.activation_layer))
+            layer.bias.data.fill_(0.0)
+
+    # -- HIP plumbing ------------------------------------------------------
+    def _blocks(self):
+        """[(Linear, BatchNorm1d | None)] in forward order."""
+        out = []
+        for seq in (self.input_emb, self.hidden_layers, self.output_layer):
+            lin = None
+            for m in seq:
+                if isinstance(m, nn.Linear):
+                    if lin is not None:
+                        out.append((lin, None))
+                    lin = m
+                elif isinstance(m, nn.BatchNorm1d):
+                    out.append((lin, m))
+                    lin = None
+            if lin is not None:
+                out.append((lin, None))
+        return out
+
+    def _bn_modules(self):
+        return [bn for _, bn in self._blocks() if bn is not None]
+
+    def flatten_parameters(self):
+        """Re-homes every parameter into one flat fp32 buffer (gradients come
+        back in a buffer of the same layout): one optimizer launch and one RCCL
+        all-reduce per step instead of one per tensor.  Called lazily; redone
+        automatically when .cuda()/.to() replaced the storages."""
+        params = list(self.parameters())
+        dev = params[0].device
+        offs, o = [], 0
+        for p in params:
+            offs.append(o)
+            o += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        flat = torch.zeros(o, dtype=torch.float32, device=dev)
+        for p, off in zip(params, offs):
+            flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + p.numel()].view(p.shape)
+        self._flat = flat
+        self._offsets = offs
+        return flat
+
+    def _is_flat(self):
+        if self._flat is None:
+            return False
+        base = self._flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * off
+                   for p, off in zip(self.parameters(), self._offsets))
+
+    def flat_parameters(self):
+        if not self._is_flat():
+            self.flatten_parameters()
+        return self._flat
+
+    def _new_grad_views(self):
+        """A fresh flat gradient buffer per backward (caching allocator: no
+        memset, no sync) and its per-parameter views.  autograd takes the views
+        as p.grad without copying, so after one backward the whole gradient sits
+        in ONE buffer; a second backward before zero_grad() gets its own buffer
+        and autograd adds it into the first, as for any other module."""
+        self.flat_parameters()
+        buf = torch.empty_like(self._flat)
+        self._last_grad_flat = buf
+        return [buf[off:off + p.numel()].view(p.shape)
+                for p, off in zip(self.parameters(), self._offsets)]
+
+    def grads_in_flat_buffer(self):
+        """True when every p.grad IS its view of one flat gradient buffer."""
+        buf = getattr(self, '_last_grad_flat', None)
+        if buf is None or not self._is_flat():
+            return False
+        base = buf.data_ptr()
+        return all(p.grad is not None and p.grad.data_ptr() == base + 4 * off
+                   for p, off in zip(self.parameters(), self._offsets))
+
+    def flat_grad(self):
+        """The gradient of all parameters as one flat fp32 buffer laid out like
+        flat_parameters() (the all-reduce bucket).  Zero-copy after a single
+        backward; otherwise p.grad tensors are packed into a new buffer."""
+        if self.grads_in_flat_buffer():
+            return self._last_grad_flat
+        self.flat_parameters()
+        buf = torch.zeros_like(self._flat)
+        for p, off in zip(self.parameters(), self._offsets):
+            if p.grad is not None:
+                buf[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                p.grad = buf[off:off + p.numel()].view(p.shape)
+        self._last_grad_flat = buf
+        return buf
+
+    def _descriptor(self, with_grads, grad_views=None):
+        self.flat_parameters()
+        d = _lib.TowerDesc()
+        blocks = self._blocks()
+        d.n_layers = len(blocks)
+        d.act = _lib.ACT[self.activation_layer]
+        if self._last_act not in _lib.ACT:
+            raise NotImplementedError('abnet3_amd: last_non_linearity=%r is not on '
+                                      'the accelerated path' % (self._last_act,))
+        d.last_act = _lib.ACT[self._last_act]
+        d.batch_norm = int(bool(self.batch_norm))
+        d.dims[0] = self.input_dim
+        gi = 0
+        for l, (lin, bn) in enumerate(blocks):
+            d.dims[l + 1] = lin.out_features
+            d.W[l] = lin.weight.data_ptr()
+            d.b[l] = lin.bias.data_ptr()
+            if with_grads:
+                d.dW[l] = grad_views[gi].data_ptr()
+                d.db[l] = grad_views[gi + 1].data_ptr()
+            gi += 2
+            if bn is not None:
+                d.bn_w[l] = bn.weight.data_ptr()
+                d.bn_b[l] = bn.bias.data_ptr()
+                d.bn_rm[l] = bn.running_mean.data_ptr()
+                d.bn_rv[l] = bn.running_var.data_ptr()
+                if with_grads:
+                    d.dbn_w[l] = grad_views[gi].data_ptr()
+                    d.dbn_b[l] = grad_views[gi + 1].data_ptr()
+                gi += 2
+        return d
+
+    def _run(self, x1, x2):
+        if self.training and self.p_dropout > 0:
+            raise NotImplementedError(
+                'abnet3_amd: p_dropout > 0 in train mode is not on the accelerated '
+                'path yet (use p_dropout=0.0, the canonical configuration, '
+                'test/data/buckeye.yaml:50)')
+        n_calls = 2 if x2 is not None else 1
+        return _TowerFunction.apply(self, n_calls, x1, x2, *self.parameters())
+
+    # -- reference surface ---------------------------------------------------
+    def forward_once(self, x):
+        """Simple forward pass for one instance x (abnet3/model.py:179-186)."""
+        return self._run(x, None)
+
+    def forward(self, input1, input2):
+        """Forward pass through the same network (abnet3/model.py:188-196): both
+        towers in one launch sequence, BatchNorm statistics per tower call."""
+        out = self._run(input1, input2)
+        n = input1.shape[0]
+        return out[:n], out[n:]
+
+    def whoami(self):
+        return {'params': self.__dict__, 'class_name': self.__class__.__name__}
+
+    def save_network(self, epoch=''):
+        torch.save(self.state_dict(), self.output_path + str(epoch) + '.pth')
+
+    def load_network(self, network_path=None):
+        self.load_state_dict(torch.load(network_path))

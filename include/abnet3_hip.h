@@ -1,0 +1,178 @@
+/* abnet3_hip.h -- C ABI of libabnet3_hip.so, the MI355X (gfx950) implementation
+ * of bootphon/abnet3's Siamese training hot path.
+ *
+ * The reference has no FFI, plugin registry or native code: its boundary for
+ * this path is Python duck-typing (abnet3/gridsearch.py:145-202 builds the
+ * objects by class name).  This header is therefore NEW: it is what a
+ * maintainer of the reference would bind with ctypes to replace the torch op
+ * sequences cited per function below (citations are file:line relative to the
+ * reference checkout).  INTEGRATION.md shows the reference-side stubs.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch / C++ types.
+ *  - Every pointer named in a signature is a DEVICE pointer unless the comment
+ *    says "host".  The caller owns all buffers; the library never allocates,
+ *    frees or synchronises (graph-capturable), and keeps no global state apart
+ *    from a thread-local error string.
+ *  - Row-major contiguous fp32 tensors; sizes are int64_t; `stream` is a
+ *    hipStream_t passed as void* (NULL = the null stream).
+ *  - Return value: 0 = ok, negative = error (ABN_E_*); abn_last_error() gives
+ *    the message.  Nothing throws across the ABI.
+ */
+#ifndef ABNET3_HIP_H
+#define ABNET3_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABN_ABI_VERSION 1
+#define ABN_MAX_LAYERS 16
+
+enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
+       ABN_E_UNSUPPORTED = -4 };
+
+/* activation_functions table, abnet3/model.py:19-23 (softmax is not offered on
+ * the accelerated path: ABN_E_UNSUPPORTED) */
+enum { ABN_ACT_NONE = 0, ABN_ACT_SIGMOID = 1, ABN_ACT_RELU = 2, ABN_ACT_TANH = 3 };
+
+/* abnet3/loss.py:37 (coscos2), :70 (cosmargin) */
+enum { ABN_LOSS_COSCOS2 = 0, ABN_LOSS_COSMARGIN = 1 };
+
+/* label element types accepted by the pair loss: the reference compares with
+ * torch.eq(y, 1) / torch.eq(y, -1) on whatever dtype arrives (int64 in
+ * test/test_loss.py:28, float64 from abnet3/dataloader.py:206,231) */
+enum { ABN_Y_I8 = 0, ABN_Y_I32 = 1, ABN_Y_I64 = 2, ABN_Y_F32 = 3, ABN_Y_F64 = 4 };
+
+/* optimizer_type, abnet3/trainer.py:68-87 (torch.optim defaults otherwise) */
+enum { ABN_OPT_SGD = 0, ABN_OPT_ADADELTA = 1, ABN_OPT_ADAM = 2,
+       ABN_OPT_ADAGRAD = 3, ABN_OPT_RMSPROP = 4 };
+
+/* compute type of the tower GEMMs: exact fp32 MFMA (parity mode) */
+enum { ABN_COMPUTE_F32 = 0 };
+
+int abn_abi_version(void);
+const char* abn_last_error(void);          /* host string, thread-local */
+
+/* One SiameseNetwork tower (abnet3/model.py:110-170): n_layers Linear layers
+ * dims[0] -> dims[1] -> ... -> dims[n_layers], each followed by Dropout(p=0 on
+ * this path), optional BatchNorm1d, and an activation (`act`, or `last_act` for
+ * the output layer, model.py:161-166).  W[l] is [dims[l+1], dims[l]] row-major
+ * exactly as nn.Linear stores it; gradients are written to dW/db/dbn_* (same
+ * shapes).  All pointers are device pointers held in this HOST struct. */
+typedef struct abn_tower_desc {
+    int32_t n_layers;
+    int32_t act;
+    int32_t last_act;
+    int32_t batch_norm;
+    int64_t dims[ABN_MAX_LAYERS + 1];
+    const float* W[ABN_MAX_LAYERS];
+    const float* b[ABN_MAX_LAYERS];
+    const float* bn_w[ABN_MAX_LAYERS];     /* gamma; NULL when !batch_norm */
+    const float* bn_b[ABN_MAX_LAYERS];     /* beta */
+    float* bn_rm[ABN_MAX_LAYERS];          /* running_mean (updated in train) */
+    float* bn_rv[ABN_MAX_LAYERS];          /* running_var */
+    float* dW[ABN_MAX_LAYERS];             /* backward outputs; may be NULL   */
+    float* db[ABN_MAX_LAYERS];             /* when only forward is called     */
+    float* dbn_w[ABN_MAX_LAYERS];
+    float* dbn_b[ABN_MAX_LAYERS];
+} abn_tower_desc;
+
+/* Workspace of one forward call (saved activations for backward), in floats,
+ * and the offset inside it of the [rows, dims[n_layers]] output embedding. */
+int64_t abn_tower_ws_floats(const abn_tower_desc* t, int64_t rows, int64_t n_calls);
+int64_t abn_tower_out_offset(const abn_tower_desc* t, int64_t rows, int64_t n_calls);
+/* Scratch of one backward call (split-K slabs + dZ ping-pong), in floats. */
+int64_t abn_tower_bwd_scratch_floats(const abn_tower_desc* t, int64_t rows);
+
+/* SiameseNetwork.forward_once / forward, abnet3/model.py:179-196.
+ * `rows` input rows in total, made of `n_calls` forward_once calls of
+ * rows/n_calls rows each (1 = embed, 2 = Siamese pair): call c reads rows
+ * [c*rows/n_calls, ...) from x1 (c == 0) or x2 (c == 1; x2 may be NULL when
+ * x1 already holds all rows contiguously).  BatchNorm statistics and running
+ * stat updates are per call, as in the reference (two updates per Siamese
+ * forward).  train != 0: batch statistics, activations saved in ws;
+ * train == 0: running statistics.  Output: ws + abn_tower_out_offset(). */
+int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
+                      int64_t rows, int64_t n_calls, int train, float* ws,
+                      void* stream);
+
+/* Autograd of the above (what loss.backward() runs, abnet3/trainer.py:239).
+ * d_out: [rows, dims[n_layers]] gradient w.r.t. the output embeddings.
+ * Writes dW/db (+dbn_w/dbn_b) summed over all rows (both towers), and dx
+ * ([rows, dims[0]], may be NULL: the reference never needs it). */
+int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2,
+                       const float* d_out, int64_t rows, int64_t n_calls,
+                       const float* ws, float* scratch, int64_t scratch_floats,
+                       float* dx, void* stream);
+
+/* coscos2.forward / cosmargin.forward fused with their backward,
+ * abnet3/loss.py:46-67 and :85-105 (nn.CosineSimilarity(dim=1, eps=1e-6)).
+ * loss_out: device scalar (fp32).  de1/de2: [B, D] gradients of the (already
+ * /B-scaled when avg) loss; both may be NULL for a forward-only call.
+ * ws: abn_pair_loss_ws_bytes(B) bytes of device scratch. */
+int64_t abn_pair_loss_ws_bytes(int64_t B);
+int abn_pair_loss(const float* e1, const float* e2, const void* y, int y_dtype,
+                  int64_t B, int64_t D, int kind, float margin, int avg,
+                  float* loss_out, float* de1, float* de2, void* ws,
+                  void* stream);
+
+/* torch.optim.{SGD(momentum),Adadelta,Adam,Adagrad,RMSprop}.step over one flat
+ * fp32 parameter buffer (abnet3/trainer.py:68-87, :240).  state1/state2: flat
+ * buffers of n floats, zero-initialised by the caller before the first step
+ * (momentum_buffer | square_avg, acc_delta | exp_avg, exp_avg_sq | sum | -).
+ * `step` counts from 1.  hp0/hp1: momentum | rho=0.9 | beta1,beta2 | - | alpha.
+ * grad_scale multiplies the gradient first (1/world_size for avg=True DP). */
+int abn_optimizer_step(int kind, float* params, const float* grads, float* state1,
+                       float* state2, int64_t n, float lr, float hp0, float hp1,
+                       float eps, int64_t step, float grad_scale, void* stream);
+
+/* abnet3/utils.py:40-60 (cosine_distance) + :147-153 (get_dtw_alignment ->
+ * third-party dtw.DTW) for a batch of token pairs.  Pair p aligns rows
+ * [off1[p], off1[p]+n1[p]) of feats1 ([rows1, D] fp32, device) with rows
+ * [off2[p], off2[p]+n2[p]) of feats2.  The per-pair metadata (off*, n*) are
+ * HOST arrays -- token boundaries come from the pairs file, host data in the
+ * reference too -- which the call stages into `ws` through `host_stage` (a
+ * caller-owned host buffer, ideally pinned, that must stay untouched until the
+ * stream has passed this call).  path1/path2: [npairs, path_stride] int32
+ * (device), the path from (0,0) to (n1-1,n2-1); path_len[p] = 0 marks a pair
+ * the reference would have dropped (NaN distance, abnet3/dataloader.py:188-191).
+ * total_cost (device, [npairs] f64) may be NULL.  n1[p] <= 1024. */
+int64_t abn_dtw_ws_bytes(const int32_t* n1_host, const int32_t* n2_host,
+                         int64_t npairs, int64_t rows1, int64_t rows2);
+int64_t abn_dtw_host_stage_bytes(const int32_t* n1_host, const int32_t* n2_host,
+                                 int64_t npairs);
+int abn_dtw_batched(const float* feats1, int64_t rows1, const float* feats2,
+                    int64_t rows2, const int64_t* off1_host, const int32_t* n1_host,
+                    const int64_t* off2_host, const int32_t* n2_host, int64_t npairs,
+                    int64_t D, int32_t* path1, int32_t* path2, int32_t* path_len,
+                    int64_t path_stride, double* total_cost, void* ws,
+                    int64_t ws_bytes, void* host_stage, int64_t host_stage_bytes,
+                    void* stream);
+/* The distance matrix alone (utils.py:40-60), one pair, float64 [N, M] out. */
+int abn_cosine_distance(const float* x, int64_t N, const float* y, int64_t M,
+                        int64_t D, double* d, int32_t* bad_flag, void* stream);
+
+/* X[path] gathers of abnet3/dataloader.py:204-205, :673-684: out[i] = table[idx[i]] */
+int abn_gather_rows(const float* table, const int64_t* idx, int64_t n, int64_t D,
+                    float* out, void* stream);
+
+/* FeaturesGenerator.stack_fbanks, abnet3/features.py:135-159 */
+int abn_stack_frames(const float* feats, int64_t T, int64_t D, int32_t nframes,
+                     float* out, void* stream);
+
+/* FeaturesGenerator.do_fbank, abnet3/features.py:99-114 (-> third-party
+ * spectral.Spectral): int16 or fp32 mono samples -> [nframes, nfilt] log mel
+ * energies.  melbank: [nfft/2+1, nfilt] fp32 weights (host side builds it,
+ * abnet3_amd/features.py), window: [wlen] fp32. */
+int abn_fbank(const void* samples, int sample_is_i16, int64_t nsamples,
+              int32_t wlen, double fshift, int32_t nfft, int32_t nfilt,
+              float alpha, const float* window, const float* melbank,
+              int64_t nframes, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABNET3_HIP_H */

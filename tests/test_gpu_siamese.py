@@ -1,0 +1,248 @@
+"""Parity of the HIP tower + pair loss (through the C-ABI, behind the reference
+class surface) with the golden vectors produced by the reference and with the
+numpy oracle.  Needs an MI355X: run with -m gpu."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import (load_golden, rel_err, check_grads, check_params,
+                      check_loss_grads)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5       # BASELINE.json: 1e-5 relative fp32 on embeddings and losses
+
+
+def cuda_net(g, seed=None, prefix='p.'):
+    from abnet3_amd.model import SiameseNetwork
+    kw = ast.literal_eval(str(g['kw']))
+    if seed is not None:
+        torch.manual_seed(seed)
+    net = SiameseNetwork(**kw)
+    if prefix is not None:
+        sd = {k[len(prefix):]: torch.from_numpy(v.copy()) for k, v in g.items()
+              if k.startswith(prefix)}
+        net.load_state_dict(sd)
+    return net.cuda(), kw
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_library_is_the_hip_one():
+    from abnet3_amd import _lib
+    assert _lib.load().abn_abi_version() == _lib.ABI_VERSION
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize('name', ['sig', 'sig_bn', 'relu_bn', 'tanh', 'sig_lin', 'relu_h2'])
+def test_tower_forward_matches_reference(name):
+    g = load_golden('tower_%s.npz' % name)
+    net, kw = cuda_net(g)
+    x1, x2 = dev(g['x1']), dev(g['x2'])
+    net.eval()
+    with torch.no_grad():
+        e1, e2 = net(x1, x2)
+        o1 = net.forward_once(x1)
+    assert rel_err(e1.cpu().numpy(), g['eval_e1']) < TOL
+    assert rel_err(e2.cpu().numpy(), g['eval_e2']) < TOL
+    assert rel_err(o1.cpu().numpy(), g['eval_e1']) < TOL
+    net.train()
+    with torch.no_grad():
+        e1, e2 = net(x1, x2)
+    assert rel_err(e1.cpu().numpy(), g['train_e1']) < TOL
+    assert rel_err(e2.cpu().numpy(), g['train_e2']) < TOL
+    sd = net.state_dict()
+    for k, v in g.items():
+        if k.startswith('after.') and 'running' in k:
+            assert rel_err(sd[k[6:]].cpu().numpy(), v) < TOL, k
+        if k.startswith('after.') and 'num_batches_tracked' in k:
+            assert int(sd[k[6:]]) == int(v) == 2
+
+
+OPT = {'sgd': lambda p: torch.optim.SGD(p, lr=0.001, momentum=0.9),
+       'adadelta': lambda p: torch.optim.Adadelta(p, lr=0.1),
+       'adam': lambda p: torch.optim.Adam(p, lr=0.001),
+       'adagrad': lambda p: torch.optim.Adagrad(p, lr=0.001),
+       'RMSprop': lambda p: torch.optim.RMSprop(p, lr=0.001)}
+
+CASES_C1 = [(l, a, o) for l in ('coscos2', 'cosmargin') for a in (1, 0)
+            for o in ('sgd', 'adadelta')] + \
+           [('coscos2', 0, o) for o in ('adam', 'adagrad', 'RMSprop')]
+
+
+@pytest.mark.parametrize('bn', [0, 1])
+@pytest.mark.parametrize('lname,avg,oname', CASES_C1)
+def test_c1_grads_and_three_steps(bn, lname, avg, oname):
+    """C1 = 40->100->50, B=32 (BASELINE.json configs[0]); the statements of
+    trainer.py:236-242 with torch.optim driving the HIP network's parameters."""
+    import abnet3_amd.loss as L
+    g = load_golden('train_c1_bn%d.npz' % bn)
+    net, kw = cuda_net(g)
+    loss_mod = getattr(L, lname)(avg=bool(avg)).cuda()
+    opt = OPT[oname](net.parameters())
+    x1, x2, y = dev(g['x1']), dev(g['x2']), dev(g['y'])
+    tag = '%s.avg%d.%s' % (lname, avg, oname)
+    keys = [k for k, _ in net.named_parameters()]
+    net.train()
+    losses = []
+    for s in range(3):
+        e1, e2 = net(x1, x2)
+        lv = loss_mod(e1, e2, y)
+        opt.zero_grad()
+        lv.backward()
+        if s == 0:
+            assert rel_err(e1.detach().cpu().numpy(), g[tag + '.e1_0']) < TOL
+            grads = {k: p.grad.cpu().numpy() for k, p in net.named_parameters()}
+            check_grads(grads, {k: g['%s.grad0.%s' % (tag, k)] for k in keys}, keys, bool(bn))
+            assert net.grads_in_flat_buffer()      # zero-copy into the flat bucket
+        opt.step()
+        losses.append(float(lv.detach()))
+    assert np.allclose(losses, g[tag + '.losses'], rtol=1e-5, atol=1e-6)
+    params = {k: p.detach().cpu().numpy() for k, p in net.named_parameters()}
+    check_params(params, {k: g['%s.after.%s' % (tag, k)] for k in keys}, keys, bool(bn),
+                 1e-5 if oname in ('sgd', 'adadelta') else 3e-4)
+
+
+LOSS_TAGS = [(ls, ln, m, a) for ls in ('mixed', 'allsame', 'alldiff', 'f64')
+             for (ln, m) in (('coscos2', None), ('cosmargin', None), ('cosmargin', 0.2))
+             for a in (1, 0)]
+
+
+@pytest.mark.parametrize('ls,lname,margin,avg', LOSS_TAGS)
+def test_loss_edge_cases(ls, lname, margin, avg):
+    import abnet3_amd.loss as L
+    g = load_golden('loss_edge.npz')
+    tag = '%s.%s%s.avg%d' % (ls, lname, '' if margin is None else '_m%g' % margin, avg)
+    kwargs = {} if margin is None else {'margin': margin}
+    mod = getattr(L, lname)(avg=bool(avg), **kwargs)
+    e1 = dev(g['e1']).requires_grad_(True)
+    e2 = dev(g['e2']).requires_grad_(True)
+    lv = mod(e1, e2, dev(g['y.' + ls]))
+    assert lv.dim() == 0
+    lv.backward()
+    ref = float(g[tag + '.loss'])
+    assert abs(float(lv) - ref) <= 1e-5 * abs(ref) + 1e-6
+    check_loss_grads(e1.grad.cpu().numpy(), e2.grad.cpu().numpy(),
+                     g[tag + '.de1'], g[tag + '.de2'], lname, tag)
+
+
+@pytest.mark.parametrize('dtype', [torch.int8, torch.int32, torch.int64, torch.float32, torch.float64])
+def test_loss_label_dtypes_and_odd_width(dtype):
+    """labels of any dtype (loss.py:60-63) and an embedding width that forces
+    the scalar (non 16-byte) path."""
+    import abnet3_amd.loss as L
+    from oracle import siamese_np as O
+    rng = np.random.default_rng(11)
+    for D in (50, 37, 100, 3):
+        e1 = rng.standard_normal((19, D)).astype(np.float32)
+        e2 = rng.standard_normal((19, D)).astype(np.float32)
+        y = rng.choice([1, -1, 0], 19)
+        for kind in ('coscos2', 'cosmargin'):
+            a = dev(e1).requires_grad_(True)
+            b = dev(e2).requires_grad_(True)
+            lv = getattr(L, kind)(avg=False)(a, b, torch.from_numpy(y).to(dtype).cuda())
+            lv.backward()
+            ol, o1, o2, _ = O.pair_loss(e1, e2, y, kind, 0.5, False)
+            assert abs(float(lv) - ol) <= 1e-5 * abs(ol) + 1e-6
+            assert rel_err(a.grad.cpu().numpy(), o1) < TOL
+            assert rel_err(b.grad.cpu().numpy(), o2) < TOL
+
+
+@pytest.mark.parametrize('bn', [0, 1])
+def test_mid_width_against_oracle_and_reference(bn):
+    """40->72x2->36, B=96: odd widths exercise every tile tail."""
+    import abnet3_amd.loss as L
+    from oracle import siamese_np as O
+    g = load_golden('train_mid_bn%d.npz' % bn)
+    net, kw = cuda_net(g)
+    spec = O.TowerSpec(kw['input_dim'], kw['num_hidden_layers'], kw['hidden_dim'],
+                       kw['output_dim'], kw['activation_layer'], kw['batch_norm'])
+    p = {k[2:]: v.copy() for k, v in g.items() if k.startswith('p.')}
+    keys = spec.param_keys()
+    net.train()
+    e1, e2 = net(dev(g['x1.0']), dev(g['x2.0']))
+    lv = L.coscos2(avg=False)(e1, e2, dev(g['y.0']))
+    lv.backward()
+    ol, og, (oe1, oe2) = O.train_step(p, g['x1.0'], g['x2.0'], g['y.0'], spec,
+                                      O.Optimizer('sgd', 0.0), avg=False)
+    assert rel_err(e1.detach().cpu().numpy(), oe1) < TOL
+    assert abs(float(lv) - ol) <= 1e-5 * abs(ol)
+    grads = {k: q.grad.cpu().numpy() for k, q in net.named_parameters()}
+    # tight against the oracle (fp64 loss gradient on both sides) ...
+    check_grads(grads, og, keys, bool(bn), tol=5e-5)
+    # ... and within the reference's own fp32 noise against the golden
+    # (test_oracle_siamese.test_mid_five_steps explains the 1e-3)
+    tag = 'coscos2.avg0.sgd'
+    check_grads(grads, {k: g['%s.grad0.%s' % (tag, k)] for k in keys}, keys, bool(bn), tol=1e-3)
+
+
+@pytest.mark.parametrize('bn', [0, 1])
+def test_c2_five_adadelta_steps(bn):
+    """BASELINE.json configs[1]: 40->500x2->100, coscos2, B=4096, weights from
+    torch.manual_seed(2) (same RNG consumption as the reference constructor)."""
+    import abnet3_amd.loss as L
+    from oracle import torch_ref
+    g = load_golden('train_c2_bn%d.npz' % bn)
+    net, kw = cuda_net(g, seed=2, prefix=None)
+    for k, v in net.state_dict().items():
+        v = v.double().cpu()
+        assert np.allclose([float(v.sum()), float(v.abs().sum())], g['chk.' + k], rtol=1e-9), k
+    opt = torch.optim.Adadelta(net.parameters(), lr=0.1)
+    loss_mod = L.coscos2(avg=False)
+    net.train()
+    losses = []
+    for s in range(5):
+        x1, x2, y = torch_ref.make_inputs(4096, 40, 20 + s % 2)
+        e1, e2 = net(x1.cuda(), x2.cuda())
+        lv = loss_mod(e1, e2, torch.from_numpy(y).cuda())
+        opt.zero_grad()
+        lv.backward()
+        if s == 0:
+            assert rel_err(e1.detach().cpu().numpy()[:8], g['e1_rows']) < TOL
+            assert rel_err(e2.detach().cpu().numpy()[-8:], g['e2_rows']) < TOL
+            for k, q in net.named_parameters():
+                gg = q.grad.cpu().numpy().reshape(q.shape[0], -1)
+                if bn and k.endswith('bias') and 'running' not in k and (
+                        k.endswith('.0.bias') or int(k.split('.')[1]) % 4 == 0):
+                    continue          # pre-BN bias: rounding noise on both sides
+                assert rel_err(gg[:4], g['grow.' + k], 1e-6) < 3e-4, k
+        opt.step()
+        losses.append(float(lv.detach()))
+    assert np.allclose(losses, g['losses'], rtol=2e-5)
+    for k, v in net.state_dict().items():
+        if 'num_batches' in k or (bn and k.endswith('bias')) or 'running_mean' in k:
+            continue
+        v = v.double().cpu()
+        assert np.allclose([float(v.sum()), float(v.abs().sum())], g['after_chk.' + k],
+                           rtol=1e-4, atol=1e-3), k
+
+
+def test_second_backward_before_zero_grad_accumulates():
+    """two forward_once calls + two backwards must SUM gradients (autograd
+    semantics of the reference's two tower calls), not alias the flat buffer."""
+    import abnet3_amd.loss as L
+    g = load_golden('train_c1_bn0.npz')
+    net, _ = cuda_net(g)
+    net.train()
+    x1, x2, y = dev(g['x1']), dev(g['x2']), dev(g['y'])
+    e1, e2 = net(x1, x2)
+    L.coscos2(avg=False)(e1, e2, y).backward()
+    fused = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    a = net.forward_once(x1)
+    b = net.forward_once(x2)
+    L.coscos2(avg=False)(a, b, y).backward()
+    for f, p in zip(fused, net.parameters()):
+        assert rel_err(p.grad.cpu().numpy(), f.cpu().numpy()) < 1e-5
+
+
+def test_cpu_tensors_fail_loudly():
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd._lib import HipLibraryError
+    net = SiameseNetwork(input_dim=10, num_hidden_layers=1, hidden_dim=10, output_dim=5,
+                         p_dropout=0., activation_layer='relu')
+    with pytest.raises(HipLibraryError):
+        net(torch.randn(4, 10), torch.randn(4, 10))

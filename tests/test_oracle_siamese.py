@@ -75,7 +75,7 @@ def test_c1_grads_and_three_steps(bn, lname, avg, oname):
     # ~eps amplify the 1e-7 gradient rounding difference, hence the looser bar.
     check_params(p, {k: g['%s.after.%s' % (tag, k)] for k in spec.param_keys()},
                  spec.param_keys(), spec.batch_norm,
-                 1e-5 if oname in ('sgd', 'adadelta') else 1e-4)
+                 1e-5 if oname in ('sgd', 'adadelta') else 3e-4)
     if bn:
         for k in p:
             # running_mean absorbs the (non-comparable) pre-BN bias under the

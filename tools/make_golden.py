@@ -369,15 +369,19 @@ def g7_frames(abnet3):
     pairs = [('u0', 0.10, 0.42, 'u1', 0.05, 0.31, 'same'),
              ('u2', 0.50, 0.93, 'u3', 0.11, 0.37, 'same'),
              ('u0', 0.33, 0.61, 'u2', 0.70, 1.05, 'diff'),
-             ('u1', 0.20, 0.20, 'u3', 0.30, 0.46, 'diff'),
+             ('u1', 0.20, 0.21, 'u3', 0.30, 0.46, 'diff'),   # 1-frame token
              ('u3', 0.40, 0.30, 'u1', 0.10, 0.20, 'same'),   # s>e: skipped
              ('u1', 0.02, 0.29, 'u1', 0.31, 0.64, 'same')]
     out['pairs'] = np.array([' '.join(map(str, p)) for p in pairs])
+    # an empty token (no frame time inside [0.20, 0.20]) is legal only without
+    # align_different_words (the reference indexes into it otherwise)
+    empty = ('u1', 0.20, 0.20, 'u3', 0.30, 0.46, 'diff')
+    out['pairs_empty'] = np.array(' '.join(map(str, empty)))
     for align in (False, True):
         dl = abnet3.dataloader.OriginalDataLoader(
             'unused', 'unused', align_different_words=align)
         dl.features = acc
-        grouped = abnet3.utils.group_pairs(pairs)
+        grouped = abnet3.utils.group_pairs(pairs + ([] if align else [empty]))
         X1, X2, Y = dl.load_frames_from_pairs(grouped)
         out['align%d.X1' % align] = X1
         out['align%d.X2' % align] = X2
