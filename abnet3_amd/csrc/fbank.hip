@@ -42,11 +42,10 @@ __global__ __launch_bounds__(256) void fbank_kernel(const void* __restrict__ sam
         float v = 0.0f;
         if (n < wlen) {
             const int64_t i = start + n;
-            const float s = sample_at(i);
-            // history of the pre-emphasis filter: previous SIGNAL sample; zero
-            // before the signal and past its end (oracle/features_np.py)
-            const float prev = (i < nsamples) ? sample_at(i - 1) : 0.0f;
-            v = (i < nsamples ? (s - alpha * prev) : 0.0f) * window[n];
+            // pre-emphasis runs over the zero-padded frame: its history is the
+            // previous SIGNAL sample (0 before the first one), so the first
+            // padded sample still sees -alpha * last (oracle/features_np.py)
+            v = (sample_at(i) - alpha * sample_at(i - 1)) * window[n];
         }
         const unsigned r = bitrev((unsigned)n, log2n);
         re[r] = v;

@@ -1,0 +1,405 @@
+"""Pair -> frame batch builders on MI355X: the surface of abnet3/dataloader.py.
+
+Mirrors (file:line relative to the reference checkout)
+  DataLoader            abnet3/dataloader.py:29-40
+  OriginalDataLoader    abnet3/dataloader.py:43-352  (load_frames_from_pairs,
+                        batch_iterator, temporal coherence pairs)
+  FramesDataLoader      abnet3/dataloader.py:580-739 (align once, frame batches)
+What changes underneath: the whole feature corpus lives in HBM as ONE
+[frames, D] tensor (DeviceCorpus); "same" word pairs are DTW-aligned on the GPU
+in batched launches (utils.dtw_align_batch) and cached, since the alignment of a
+pair never changes between epochs (the reference recomputes it every epoch,
+dataloader.py:189); frames are gathered on the device (abn_gather_rows), so the
+iterator yields device tensors and the trainer's .cuda() is a no-op.  Batch
+composition, order, the seed-0 permutation and label dtypes follow the
+reference statement by statement.
+"""
+import os
+import random
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .utils import (Features_Accessor, dtw_align_batch, group_pairs, read_dataset)
+
+
+class DataLoader:
+
+    def batch_iterator(self, train_mode=True):
+        raise NotImplementedError("You must implement batch iterator" +
+                                  " in DataLoader class.")
+
+    def whoami(self):
+        raise NotImplementedError("You must implement whoami in DataLoader class")
+
+
+def gather_rows(table, idx):
+    """table[idx] on the device (feat[path, :], dataloader.py:204-205)."""
+    lib = _lib.load()
+    idx = idx.to(torch.int64).contiguous()
+    _lib.require_device(table, idx)
+    out = torch.empty(idx.numel(), table.shape[1], dtype=torch.float32, device=table.device)
+    _lib.check(lib.abn_gather_rows(_lib.ptr(table), _lib.ptr(idx), idx.numel(),
+                                   table.shape[1], _lib.ptr(out), _lib.stream()),
+               'abn_gather_rows')
+    return out
+
+
+class DeviceCorpus(object):
+    """Every utterance's frames as one [total_frames, D] float32 tensor in HBM,
+    plus host-side row offsets and frame times (Features_Accessor semantics:
+    a token is the frames with on <= t <= off, utils.py:127-131)."""
+
+    def __init__(self, features, times):
+        self.names = list(features.keys())
+        self.offset, self.length, self.times = {}, {}, {}
+        chunks, o = [], 0
+        for k in self.names:
+            f = np.ascontiguousarray(features[k], dtype=np.float32)
+            self.offset[k], self.length[k] = o, f.shape[0]
+            self.times[k] = np.asarray(times[k])
+            chunks.append(f)
+            o += f.shape[0]
+        self.dim = chunks[0].shape[1]
+        self.table = torch.from_numpy(np.concatenate(chunks, axis=0)).cuda()
+        self.total = o
+
+    def _name(self, f):
+        b = f.encode('UTF-8') if isinstance(f, str) else f
+        return b if b in self.offset else f
+
+    def token(self, f, on, off):
+        """(first global row, number of frames) of the token (f, on, off)."""
+        k = self._name(f)
+        t = self.times[k]
+        ind = Features_Accessor.get_indices_between(t, on, off)
+        if len(ind) == 0:
+            return self.offset[k], 0
+        assert ind[-1] - ind[0] + 1 == len(ind), 'frame times must be sorted'
+        return self.offset[k] + int(ind[0]), len(ind)
+
+    def token_frames(self, f, frame_on, frame_off):
+        k = self._name(f)
+        lo, hi, _ = slice(frame_on, frame_off).indices(self.length[k])
+        return self.offset[k] + lo, max(0, hi - lo)
+
+
+class OriginalDataLoader(DataLoader):
+    """Loads the pairs file created by the sampler, creates the frame pairs and
+    shuffles inside the batches (abnet3/dataloader.py:43-352)."""
+
+    TCL_DISTANCE_SAME = [1]
+    TCL_DISTANCES_DIFF = [15, 20, 25, 30]
+
+    def __init__(self, pairs_path, features_path, num_max_minibatches=1000,
+                 seed=None, batch_size=8, shuffle_between_epochs=False,
+                 align_different_words=False,
+                 tcl=0.0):
+        assert 0 <= tcl < 1
+        self.pairs_path = pairs_path
+        self.features_path = features_path
+        self.statistics_training = defaultdict(int)
+        self.seed = seed
+        self.num_max_minibatches = num_max_minibatches
+        self.batch_size = batch_size
+        self.features = None          # DeviceCorpus
+        self.shuffle_between_epochs = shuffle_between_epochs
+        self.align_different_words = align_different_words
+        self.tcl = tcl
+        self.train_files = None
+        self.pairs = {'train': None, 'dev': None}
+        self._align = {}              # (f1,s1,e1,f2,s2,e2) -> (idx1, idx2) | None
+
+    def __getstate__(self):
+        return (self.pairs_path, self.features_path, self.statistics_training,
+                self.seed, self.num_max_minibatches, self.batch_size)
+
+    def whoami(self):
+        return {'params': self.__getstate__(),
+                'class_name': self.__class__.__name__}
+
+    # -- data ----------------------------------------------------------------
+    def set_data(self, features, times, train_pairs=None, dev_pairs=None):
+        """In-memory injection of what load_data() reads from disk: features
+        {utt: [T, D]}, times {utt: [T]}, pairs [(f1,s1,e1,f2,s2,e2,type), ...]."""
+        self.features = DeviceCorpus(features, times)
+        if train_pairs is not None:
+            self.pairs['train'] = list(train_pairs)
+        if dev_pairs is not None:
+            self.pairs['dev'] = list(dev_pairs)
+        if self.pairs['train'] is not None:
+            self.train_files = list({p[0] for p in self.pairs['train']} |
+                                    {p[3] for p in self.pairs['train']})
+
+    def load_data(self):
+        """Load only once the features, and the pairs (dataloader.py:125-145)."""
+        if self.features is None:
+            try:
+                import h5features
+            except ImportError:
+                raise ImportError('features_path is an h5features file and the '
+                                  'h5features package is not installed; use '
+                                  'set_data() with in-memory arrays')
+            with h5features.Reader(self.features_path, 'features') as fh:
+                feats = fh.read()
+            self.features = DeviceCorpus(feats.dict_features(), feats.dict_labels())
+        if self.pairs['train'] is None:
+            self.pairs['train'] = read_dataset(
+                os.path.join(self.pairs_path, 'train_pairs/dataset'))
+        if self.pairs['dev'] is None:
+            self.pairs['dev'] = read_dataset(
+                os.path.join(self.pairs_path, 'dev_pairs/dataset'))
+        self.train_files = list({p[0] for p in self.pairs['train']} |
+                                {p[3] for p in self.pairs['train']})
+
+    # -- alignment -------------------------------------------------------------
+    def _token(self, f, s, e, frames):
+        return self.features.token_frames(f, s, e) if frames else self.features.token(f, s, e)
+
+    def align_pairs(self, same_pairs, frames=False):
+        """DTW-aligns every not-yet-cached 'same' pair in ONE batched GPU call
+        (get_dtw_alignment, dataloader.py:189).  Dropped pairs (NaN distance,
+        dataloader.py:188-191) are cached as None."""
+        todo = []
+        for p in same_pairs:
+            key = tuple(p) + (frames,)
+            if key in self._align or key in todo:
+                continue
+            f1, s1, e1, f2, s2, e2 = p
+            if (s1 > e1) or (s2 > e2):
+                continue
+            todo.append(key)
+        if not todo:
+            return
+        o1, n1, o2, n2 = [], [], [], []
+        for f1, s1, e1, f2, s2, e2, fr in todo:
+            a, b = self._token(f1, s1, e1, fr), self._token(f2, s2, e2, fr)
+            o1.append(a[0]); n1.append(a[1]); o2.append(b[0]); n2.append(b[1])
+        table = self.features.table
+        res = dtw_align_batch(table, o1, n1, table, o2, n2)
+        lens = res.path_len.cpu().numpy()
+        stride = res.path1.shape[1]
+        dev = table.device
+        mask = torch.arange(stride, device=dev)[None, :] < res.path_len[:, None]
+        g1 = (res.path1.long() + torch.tensor(o1, device=dev)[:, None])[mask]
+        g2 = (res.path2.long() + torch.tensor(o2, device=dev)[:, None])[mask]
+        start = 0
+        for key, ln in zip(todo, lens):
+            if ln == 0:
+                # an empty token or a NaN distance: the reference's try/except
+                # drops the pair (dataloader.py:188-191)
+                self._align[key] = None
+            else:
+                self._align[key] = (g1[start:start + ln], g2[start:start + ln])
+            start += int(ln)
+
+    def prefetch_alignments(self):
+        """Aligns every 'same' pair of the train and dev sets up front, in one
+        large batched launch each (what FramesDataLoader.load_all_frames does
+        serially, dataloader.py:617-671)."""
+        self.load_data()
+        for mode in ('train', 'dev'):
+            if self.pairs[mode]:
+                self.align_pairs(group_pairs(self.pairs[mode])['same'])
+
+    # -- batches ---------------------------------------------------------------
+    def frames_from_pairs_device(self, pairs, seed=0, frames=False):
+        """load_frames_from_pairs (dataloader.py:166-261) producing device
+        tensors: X1, X2 float32 [n, D], y float64 [n]."""
+        self.align_pairs(pairs['same'], frames)
+        dev = self.features.table.device
+        idx1, idx2, ys = [], [], []
+        for f1, s1, e1, f2, s2, e2 in pairs['same']:
+            if (s1 > e1) or (s2 > e2):
+                continue
+            al = self._align.get((f1, s1, e1, f2, s2, e2, frames))
+            if al is None:
+                continue
+            self.statistics_training['SameType'] += 1
+            idx1.append(al[0]); idx2.append(al[1])
+            ys.append(np.ones(len(al[0])))
+        for f1, s1, e1, f2, s2, e2 in pairs['diff']:
+            if (s1 > e1) or (s2 > e2):
+                continue
+            (a0, n1), (b0, n2) = self._token(f1, s1, e1, frames), self._token(f2, s2, e2, frames)
+            if self.align_different_words:
+                # the shorter word is stretched along the diagonal (:216-225);
+                # key=len keeps the FIRST on ties, like min()/max()
+                if n2 < n1:
+                    mn0, mnl, mx0, mxl = b0, n2, a0, n1
+                else:
+                    mn0, mnl = a0, n1
+                    mx0, mxl = (b0, n2) if n2 > n1 else (a0, n1)
+                mapping = np.rint(np.linspace(0, mnl - 1, num=mxl)).astype(int)
+                w1 = mx0 + np.arange(mxl)
+                w2 = mn0 + mapping
+            else:
+                m = min(n1, n2)
+                w1 = a0 + np.arange(m)
+                w2 = b0 + np.arange(m)
+            idx1.append(torch.from_numpy(w1.astype(np.int64)).to(dev))
+            idx2.append(torch.from_numpy(w2.astype(np.int64)).to(dev))
+            ys.append(-1 * np.ones(min(n1, n2)))
+            self.statistics_training['DiffType'] += 1
+        if not idx1:
+            raise ValueError('need at least one array to concatenate')
+        i1, i2 = torch.cat(idx1), torch.cat(idx2)
+        y = np.concatenate(ys)
+        np.random.seed(seed)
+        ind = np.random.permutation(len(y))
+        ind_d = torch.from_numpy(ind).to(dev)
+        X1 = gather_rows(self.features.table, i1[ind_d])
+        X2 = gather_rows(self.features.table, i2[ind_d])
+        return X1, X2, torch.from_numpy(y[ind]).to(dev)
+
+    def load_frames_from_pairs(self, pairs, seed=0, fid2spk=None, frames=False):
+        """numpy front end with the reference's return types."""
+        if fid2spk:
+            raise NotImplementedError('speaker labels belong to MultiTaskDataLoader')
+        X1, X2, y = self.frames_from_pairs_device(pairs, seed, frames)
+        return X1.cpu().numpy(), X2.cpu().numpy(), y.cpu().numpy()
+
+    def batch_iterator(self, train_mode=True):
+        """Iterator over (X1, X2, y) batches of `batch_size` WORD pairs
+        (dataloader.py:263-312)."""
+        self.load_data()
+        mode = 'train' if train_mode else 'dev'
+        pairs = self.pairs[mode]
+        num_pairs = len(pairs)
+        if self.shuffle_between_epochs:
+            random.shuffle(pairs)
+        batches = [pairs[idx:idx + self.batch_size]
+                   for idx in range(0, num_pairs, self.batch_size)]
+        num_batches = len(batches)
+        if self.num_max_minibatches < num_batches:
+            selected_batches = np.random.choice(range(num_batches),
+                                                self.num_max_minibatches,
+                                                replace=False)
+        else:
+            selected_batches = np.random.permutation(range(num_batches))
+        # one batched DTW launch for everything this epoch will touch
+        self.align_pairs([p[:6] for b in selected_batches for p in batches[b]
+                          if p[6] == 'same'])
+        for batch_id in selected_batches:
+            batch = self.frames_from_pairs_device(group_pairs(batches[batch_id]))
+            if self.tcl > 0:
+                batch = self.add_tcl_to_batch(batch)
+            yield batch
+
+    def add_tcl_to_batch(self, batch):
+        X1, X2, Y = batch
+        num_pairs = len(Y)
+        num_pairs_to_add = int((self.tcl * num_pairs) / (1 - self.tcl))
+        X1_tcl, X2_tcl, Y_tcl = self.temporal_coherence_loss(num_pairs_to_add)
+        return (torch.cat((X1, X1_tcl)), torch.cat((X2, X2_tcl)),
+                torch.cat((Y, Y_tcl.to(Y.dtype))))
+
+    def temporal_coherence_loss(self, num_pairs):
+        """Dupoux & Synnaeve (2016) temporal coherence pairs (dataloader.py:324-352)."""
+        c = self.features
+        i1, i2, Y = [], [], []
+        per_it = len(self.TCL_DISTANCES_DIFF) + len(self.TCL_DISTANCE_SAME)
+        for _ in range(round(num_pairs / per_it)):
+            files = self.train_files if self.train_files is not None else c.names
+            f = c._name(random.choice(files))
+            t = random.choice(range(c.length[f] - max(self.TCL_DISTANCES_DIFF)))
+            for delta in self.TCL_DISTANCE_SAME:
+                i1.append(c.offset[f] + t); i2.append(c.offset[f] + t + delta); Y.append(1)
+            for delta in self.TCL_DISTANCES_DIFF:
+                i1.append(c.offset[f] + t); i2.append(c.offset[f] + t + delta); Y.append(-1)
+        dev = c.table.device
+        return (gather_rows(c.table, torch.tensor(i1, dtype=torch.int64, device=dev)),
+                gather_rows(c.table, torch.tensor(i2, dtype=torch.int64, device=dev)),
+                torch.tensor(Y, device=dev))
+
+
+class FramesDataLoader(OriginalDataLoader):
+    """Batches of exactly `batch_size` FRAME pairs, shuffled across the whole
+    dataset; alignment happens once (abnet3/dataloader.py:580-739)."""
+
+    def __init__(self, pairs_path, features_path,
+                 batch_size=100, randomize_dataset=True, max_batches_per_epoch=None):
+        super().__init__(pairs_path, features_path)
+        self.randomize_dataset = randomize_dataset
+        self.batch_size = batch_size
+        self.frame_pairs = {'train': None, 'dev': None}   # (idx1, idx2, y) device
+        self.max_batches_per_epoch = max_batches_per_epoch
+        if self.max_batches_per_epoch is not None:
+            self.batch_position = 0
+
+    def load_data(self):
+        super(FramesDataLoader, self).load_data()
+        for mode in ('train', 'dev'):
+            if self.frame_pairs[mode] is None and self.pairs[mode] is not None:
+                self.frame_pairs[mode] = self.load_all_frames(self.pairs[mode])
+
+    def load_all_frames(self, pairs):
+        """The frame-pair dataset (global row of frame 1, of frame 2, +-1) for
+        all word pairs (dataloader.py:617-671), shuffled once."""
+        pairs = group_pairs(pairs)
+        self.align_pairs(pairs['same'])
+        dev = self.features.table.device
+        i1, i2, ys = [], [], []
+        for f1, s1, e1, f2, s2, e2 in pairs['same']:
+            if (s1 > e1) or (s2 > e2):
+                continue
+            al = self._align.get((f1, s1, e1, f2, s2, e2, False))
+            if al is None:
+                continue
+            i1.append(al[0]); i2.append(al[1])
+            ys.append(np.ones(len(al[0]), dtype=np.int64))
+            self.statistics_training['SameType'] += 1
+        for f1, s1, e1, f2, s2, e2 in pairs['diff']:
+            if (s1 > e1) or (s2 > e2):
+                continue
+            (a0, n1), (b0, n2) = self.features.token(f1, s1, e1), self.features.token(f2, s2, e2)
+            m = min(n1, n2)
+            i1.append(torch.arange(a0, a0 + m, device=dev))
+            i2.append(torch.arange(b0, b0 + m, device=dev))
+            ys.append(-np.ones(m, dtype=np.int64))
+            self.statistics_training['DiffType'] += 1
+        if not i1:
+            z = torch.zeros(0, dtype=torch.int64, device=dev)
+            return z, z, z
+        i1, i2 = torch.cat(i1), torch.cat(i2)
+        y = torch.from_numpy(np.concatenate(ys)).to(dev)
+        return self._shuffle((i1, i2, y))
+
+    @staticmethod
+    def _shuffle(fp):
+        # np.random.shuffle(list) and np.random.permutation(n) draw the same
+        # permutation from the same global state (dataloader.py:670)
+        perm = torch.from_numpy(np.random.permutation(len(fp[2]))).to(fp[2].device)
+        return fp[0][perm], fp[1][perm], fp[2][perm]
+
+    def load_batch(self, sl, mode):
+        i1, i2, y = self.frame_pairs[mode]
+        return (gather_rows(self.features.table, i1[sl]),
+                gather_rows(self.features.table, i2[sl]), y[sl])
+
+    def batch_iterator(self, train_mode=True):
+        """(dataloader.py:686-739)"""
+        self.load_data()
+        mode = 'train' if train_mode else 'dev'
+        num_pairs = len(self.frame_pairs[mode][2])
+        num_batches = num_pairs // self.batch_size
+        if num_batches == 0:
+            num_batches = 1
+        if mode == 'dev' or self.max_batches_per_epoch is None:
+            batch_ids = range(num_batches)
+            if self.randomize_dataset:
+                self.frame_pairs[mode] = self._shuffle(self.frame_pairs[mode])
+        else:
+            if self.batch_position >= num_batches:
+                if self.randomize_dataset:
+                    self.frame_pairs[mode] = self._shuffle(self.frame_pairs[mode])
+                self.batch_position = 0
+            batch_ids = range(self.batch_position,
+                              min(self.batch_position + self.max_batches_per_epoch,
+                                  num_batches))
+            self.batch_position += self.max_batches_per_epoch
+        for i in batch_ids:
+            yield self.load_batch(slice(i * self.batch_size,
+                                        i * self.batch_size + self.batch_size), mode)

@@ -1,0 +1,84 @@
+"""Embedders on MI355X: the class surface of abnet3/embedder.py.
+
+Mirrors (file:line relative to the reference checkout)
+  EmbedderBuilder   abnet3/embedder.py:19-50
+  EmbedderSiamese   abnet3/embedder.py:53-100
+The eval-mode forward of the first tower runs through abn_tower_forward.  The
+reference reads/writes h5features files (third-party, absent from this image):
+embed() uses that package when it is importable, and embed_features() is the
+same loop over in-memory arrays.
+"""
+import numpy as np
+import torch
+
+
+class EmbedderBuilder:
+    """Generic Embedder class for ABnet3 (abnet3/embedder.py:19-50)."""
+
+    def __init__(self, network=None, network_path=None, feature_path=None,
+                 output_path=None, cuda=True, batch_size=5000):
+        if network is None:
+            raise ValueError("network is None.")
+        self.network = network
+        self.network_path = network_path
+        self.feature_path = feature_path
+        self.output_path = output_path
+        self.cuda = cuda
+        self.batch_size = batch_size
+
+    def embed(self):
+        raise NotImplementedError('Unimplemented embed for class:',
+                                  self.__class__.__name__)
+
+
+class EmbedderSiamese(EmbedderBuilder):
+    """Embedder class for siamese network on monotask (abnet3/embedder.py:53-100)."""
+
+    def __init__(self, *args, **kwargs):
+        super(EmbedderSiamese, self).__init__(*args, **kwargs)
+
+    def embed_features(self, feats):
+        """The reference's per-utterance loop (embedder.py:80-96) over a list of
+        [T, D] arrays; returns the list of [T, output_dim] float32 embeddings."""
+        self.network.eval()
+        self.network.cuda()
+        embeddings = []
+        with torch.no_grad():
+            for feat in feats:
+                if feat.dtype != np.float32:
+                    feat = feat.astype(np.float32)
+                if len(feat) == 0:
+                    embeddings.append(np.zeros((0, self.network.output_dim), np.float32))
+                    continue
+                n_batches = len(feat) // self.batch_size + 1
+                outputs = []
+                for b_feat in np.array_split(feat, n_batches):
+                    if len(b_feat) == 0:
+                        continue
+                    x = torch.from_numpy(np.ascontiguousarray(b_feat)).cuda()
+                    emb = self.network.forward_once(x)   # first output of network(x, x)
+                    outputs.append(emb.cpu().numpy())
+                embeddings.append(np.vstack(outputs))
+        return embeddings
+
+    def embed(self):
+        """Embed method to embed features based on a saved network."""
+        if self.network_path is not None:
+            self.network.load_network(self.network_path)
+        print("Done loading network weights")
+        try:
+            import h5features
+        except ImportError:
+            raise ImportError('EmbedderSiamese.embed() reads and writes h5features '
+                              'files like the reference; the h5features package is '
+                              'not installed. Use embed_features() on in-memory arrays.')
+        with h5features.Reader(self.feature_path, 'features') as fh:
+            features = fh.read()
+        items = features.items()
+        times = features.labels()
+        feats = features.features()
+        print("Done loading input feature file")
+        embeddings = self.embed_features(feats)
+        data = h5features.Data(items, times, embeddings, check=True)
+        with h5features.Writer(self.output_path) as fh:
+            fh.write(data, 'features')

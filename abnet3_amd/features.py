@@ -1,0 +1,132 @@
+"""Feature extraction on MI355X: the hot-path part of abnet3/features.py.
+
+Mirrors (file:line relative to the reference checkout)
+  FeaturesGenerator.do_fbank      abnet3/features.py:99-114   -> abn_fbank
+  FeaturesGenerator.stack_fbanks  abnet3/features.py:135-159  -> abn_stack_frames
+The reference delegates the filterbank arithmetic to the third-party
+spectral.Spectral (absent, unpinned); the definition implemented by the kernel
+is written down in oracle/features_np.py.  The h5features file pipeline
+(features.py:161-203, :299-404) is I/O orchestration and out of scope.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+LOWERF = 133.3333
+UPPERF = 6855.4976
+
+
+def _mel(f):
+    return 2595.0 * np.log10(1.0 + f / 700.0)
+
+
+def _melinv(m):
+    return 700.0 * (np.power(10.0, m / 2595.0) - 1.0)
+
+
+def mel_filterbank(fs, nfft=1024, nfilt=40, lowerf=LOWERF, upperf=UPPERF):
+    """Triangular mel bank [nfft/2+1, nfilt] (host, built once per sampling
+    rate): edges equally spaced on the mel scale between lowerf and upperf,
+    rounded to DFT bins, height 2 / (width in Hz)."""
+    if upperf > fs / 2:
+        raise ValueError('Upper frequency %f exceeds Nyquist %f' % (upperf, fs / 2))
+    bank = np.zeros((nfft // 2 + 1, nfilt), dtype=np.float64)
+    dfreq = float(fs) / nfft
+    lo, hi = _mel(lowerf), _mel(upperf)
+    edges = _melinv(lo + (hi - lo) / (nfilt + 1) * np.arange(nfilt + 2, dtype=np.float64))
+    bins = [int(round(e / dfreq)) for e in edges]
+    for w in range(nfilt):
+        left, center, right = bins[w], bins[w + 1], bins[w + 2]
+        height = 2.0 / ((right - left) * dfreq)
+        for k in range(left + 1, center):
+            bank[k, w] = (k - left) * height / (center - left)
+        if center > left:
+            bank[center, w] = height
+        for k in range(center + 1, right):
+            bank[k, w] = (k - right) * height / (center - right)
+    return bank
+
+
+class FeaturesGenerator:
+    """Filterbank front end (abnet3/features.py:18-98 constructor surface kept
+    for the hot-path arguments)."""
+
+    def __init__(self, files=None, output_path=None, method='fbanks', n_filters=40,
+                 save=True, load_mean_variance_path=None, save_mean_variance_path=None,
+                 vad_file=None, normalization=True, norm_per_file=False,
+                 norm_per_channel=False, stack=True, nframes=7, deltas=False,
+                 deltasdeltas=False, run='once'):
+        if deltas or deltasdeltas:
+            raise NotImplementedError('deltas are not on the accelerated path')
+        self.files = files
+        self.output_path = output_path
+        self.method = method
+        self.n_filters = n_filters
+        self.stack = stack
+        self.nframes = nframes
+        self.deltas = deltas
+        self.deltasdeltas = deltasdeltas
+        self.run = run
+        self._tables = {}
+
+    def whoami(self):
+        return {'params': self.__dict__, 'class_name': self.__class__.__name__}
+
+    def _table(self, fs, wlen, nfft, device):
+        key = (fs, wlen, nfft, self.n_filters, str(device))
+        if key not in self._tables:
+            win = torch.from_numpy(np.hamming(wlen).astype(np.float32)).to(device)
+            bank = torch.from_numpy(
+                mel_filterbank(fs, nfft, self.n_filters).astype(np.float32)).to(device)
+            self._tables[key] = (win, bank)
+        return self._tables[key]
+
+    def fbank_from_samples(self, sound, srate, alpha=0.97, frate=100, wlen=0.025,
+                           nfft=1024):
+        """Log mel energies [T, n_filters] float32 (device tensor) from int16 or
+        float mono samples (numpy array or device tensor)."""
+        lib = _lib.load()
+        if isinstance(sound, torch.Tensor):
+            s = sound
+        else:
+            sound = np.ascontiguousarray(sound)
+            if sound.dtype != np.int16:
+                sound = sound.astype(np.float32)
+            s = torch.from_numpy(sound)
+        s = s.cuda().contiguous()
+        if s.dtype not in (torch.int16, torch.float32):
+            s = s.float()
+        wl = int(wlen * srate)
+        fshift = float(srate) / frate
+        nfr = int(s.numel() / fshift + 1)
+        win, bank = self._table(srate, wl, nfft, s.device)
+        out = torch.empty(nfr, self.n_filters, dtype=torch.float32, device=s.device)
+        _lib.check(lib.abn_fbank(_lib.ptr(s), int(s.dtype == torch.int16), s.numel(), wl,
+                                 fshift, nfft, self.n_filters, alpha, _lib.ptr(win),
+                                 _lib.ptr(bank), nfr, _lib.ptr(out), _lib.stream()),
+                   'abn_fbank')
+        return out
+
+    def do_fbank(self, fname):
+        """Compute standard filterbanks from a wav file (features.py:99-114)."""
+        from scipy.io import wavfile
+        srate, sound = wavfile.read(fname)
+        return self.fbank_from_samples(sound, srate).cpu().numpy()
+
+    def stack_fbanks(self, features, nframes=7):
+        """Each frame becomes the concatenation of its nframes//2 previous and
+        next frames, zero padded at the edges (features.py:135-159).  numpy in
+        -> numpy out, device tensor in -> device tensor out."""
+        assert nframes % 2 == 1, 'number of stacked frames must be odd'
+        lib = _lib.load()
+        is_np = not isinstance(features, torch.Tensor)
+        f = torch.from_numpy(np.ascontiguousarray(features)) if is_np else features
+        dtype = f.dtype
+        f = f.cuda().float().contiguous()
+        T, D = f.shape
+        out = torch.empty(T, D * nframes, dtype=torch.float32, device=f.device)
+        _lib.check(lib.abn_stack_frames(_lib.ptr(f), T, D, nframes, _lib.ptr(out),
+                                        _lib.stream()), 'abn_stack_frames')
+        out = out.to(dtype)
+        return out.cpu().numpy() if is_np else out

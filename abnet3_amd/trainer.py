@@ -1,0 +1,321 @@
+"""Trainers on MI355X: the class surface of abnet3/trainer.py.
+
+Mirrors (file:line relative to the reference checkout)
+  TrainerBuilder   abnet3/trainer.py:32-201  (same kwargs, defaults, early
+                   stopping, best-model saving, whoami)
+  TrainerSiamese   abnet3/trainer.py:203-256 (give_batch_to_network,
+                   optimize_model)
+Differences, all on purpose:
+  * the optimizer is one fused HIP kernel over the network's flat parameter
+    buffer with torch.optim's update rules (FlatOptimizer);
+  * per-batch losses are accumulated on the device in fp64 and read back once
+    per epoch (the reference syncs every batch at trainer.py:242,248);
+  * under torch.distributed (one process per GPU) the flat gradient bucket is
+    all-reduced over RCCL between backward and step, and batches are sharded
+    round-robin over ranks;
+  * tensorboardX is optional (absent in this image): scalars then only go to
+    train_losses / dev_losses.
+"""
+import copy
+import os
+import pickle
+import time
+import warnings
+from pathlib import Path
+
+import torch
+import torch.optim as optim
+
+from . import _lib, parallel
+from .model import NetworkBuilder
+
+try:                                        # pragma: no cover
+    from tensorboardX import SummaryWriter
+except Exception:                           # noqa: the package is optional here
+    class SummaryWriter(object):
+        def __init__(self, log_dir=None):
+            self.log_dir = log_dir
+
+        def add_scalar(self, *args, **kwargs):
+            pass
+
+
+class FlatOptimizer(object):
+    """torch.optim.{SGD,Adadelta,Adam,Adagrad,RMSprop} semantics (torch's default
+    hyper-parameters, abnet3/trainer.py:68-87) as ONE kernel launch over the
+    network's flat parameter / gradient buffers (abn_optimizer_step)."""
+
+    HP = {  # kind: (hp0, hp1, eps)
+        'sgd': (None, 0.0, 0.0),
+        'adadelta': (0.9, 0.0, 1e-6),
+        'adam': (0.9, 0.999, 1e-8),
+        'adagrad': (0.0, 0.0, 1e-10),
+        'RMSprop': (0.99, 0.0, 1e-8),
+    }
+
+    def __init__(self, network, kind, lr, momentum=0.9):
+        assert kind in self.HP
+        self.network = network
+        self.kind = kind
+        self.lr = float(lr)
+        self.momentum = float(momentum if momentum is not None else 0.0)
+        self.step_count = 0
+        self.grad_scale = 1.0
+        self._flat = None
+        self._s1 = self._s2 = None
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.network.parameters():
+            p.grad = None
+
+    def _state(self):
+        flat = self.network.flat_parameters()
+        if self._flat is None or self._flat.data_ptr() != flat.data_ptr():
+            if self.step_count > 0:
+                raise RuntimeError('abnet3_amd: the network was moved after the '
+                                   'optimizer took its first step')
+            self._flat = flat
+            self._s1 = torch.zeros_like(flat)
+            self._s2 = torch.zeros_like(flat)
+        return flat
+
+    def step(self):
+        lib = _lib.load()
+        flat = self._state()
+        grad = self.network.flat_grad()
+        _lib.require_device(flat, grad)
+        self.step_count += 1
+        hp0, hp1, eps = self.HP[self.kind]
+        if self.kind == 'sgd':
+            hp0 = self.momentum
+        _lib.check(lib.abn_optimizer_step(
+            _lib.OPT[self.kind], _lib.ptr(flat), _lib.ptr(grad), _lib.ptr(self._s1),
+            _lib.ptr(self._s2), flat.numel(), self.lr, hp0, hp1, eps, self.step_count,
+            float(self.grad_scale), _lib.stream()), 'abn_optimizer_step')
+
+    def state_dict(self):
+        return {'kind': self.kind, 'lr': self.lr, 'momentum': self.momentum,
+                'step': self.step_count, 's1': self._s1, 's2': self._s2}
+
+
+class TrainerBuilder:
+    """Generic Trainer class for ABnet3 (abnet3/trainer.py:32-201)."""
+
+    def __init__(self, network=None, loss=None,
+                 num_epochs=200, patience=20,
+                 optimizer_type='sgd', lr=0.001, momentum=0.9, cuda=True,
+                 seed=0, dataloader=None, log_dir=None,
+                 feature_generator=None,
+                 checkpoints=False):
+        self.network = network
+        self.loss = loss
+        self.num_epochs = num_epochs
+        self.patience = patience
+        self.lr = lr
+        self.momentum = momentum
+        self.best_epoch = 0
+        self.seed = seed
+        self.cuda = cuda
+        self.statistics_training = {}
+        self.dataloader = dataloader
+        self.feature_generator = feature_generator
+        self.checkpoints = checkpoints
+        self.rank, self.world_size = parallel.world()
+
+        if not cuda:
+            warnings.warn('abnet3_amd has no CPU path: cuda=False is ignored and '
+                          'the trainer runs on the MI355X')
+        self.cuda = True
+        self.loss.cuda()
+        self.network.cuda()
+
+        if log_dir is None:
+            self.log_dir = Path('./runs/%s' % time.strftime('%m-%d-%Hh%M-%S'))
+        else:
+            self.log_dir = Path(log_dir) / ('%s' % time.strftime('%m-%d-%Hh%M-%S'))
+
+        assert optimizer_type in ('sgd', 'adadelta', 'adam', 'adagrad',
+                                  'RMSprop', 'LBFGS')
+        if optimizer_type == 'LBFGS':
+            # like the reference: constructed, but .step() needs a closure the
+            # reference loop never passes (trainer.py:240)
+            self.optimizer = optim.LBFGS(self.network.parameters(), lr=self.lr)
+        else:
+            self.optimizer = FlatOptimizer(self.network, optimizer_type, self.lr,
+                                           self.momentum)
+        if self.world_size > 1:
+            parallel.broadcast_parameters(self.network.flat_parameters())
+
+    def params(self):
+        params = copy.copy(self.__dict__)
+        del params['dataloader']
+        del params['feature_generator']
+
+    def whoami(self):
+        whoami = {
+            'params': self.params(),
+            'network': self.network.whoami(),
+            'loss': self.loss.whoami(),
+            'class_name': self.__class__.__name__,
+            'dataloader': self.dataloader.whoami()
+        }
+        if self.feature_generator is not None:
+            whoami['feature_generator'] = self.feature_generator.whoami()
+        return whoami
+
+    def save_whoami(self):
+        info = {'class_name': self.__class__.__name__,
+                'network_class': self.network.__class__.__name__,
+                'loss_class': self.loss.__class__.__name__,
+                'dataloader': self.dataloader.whoami()
+                if hasattr(self.dataloader, 'whoami') else None}
+        pickle.dump(info, open(self.network.output_path + '.params', "wb"))
+
+    def optimize_model(self, do_training=True):
+        raise NotImplementedError('Unimplemented optimize_model for class:',
+                                  self.__class__.__name__)
+
+    def train(self):
+        """Train method to train the model (abnet3/trainer.py:117-173)."""
+        self.patience_dev = 0
+        self.best_dev = None
+
+        self.train_losses = []
+        self.dev_losses = []
+        self.num_batches_train = 0
+        self.num_batches_dev = 0
+        master = self.rank == 0
+
+        self.network.eval()
+        if master:
+            self.network.save_network()
+
+        train_writer = SummaryWriter(log_dir=str(self.log_dir / 'train_loss'))
+        dev_writer = SummaryWriter(log_dir=str(self.log_dir / 'dev_loss'))
+
+        _ = self.optimize_model(do_training=False)
+        train_writer.add_scalar('loss', self.train_losses[-1], 0)
+        dev_writer.add_scalar('loss', self.dev_losses[-1], 0)
+
+        if self.checkpoints and master:
+            self.network.save_network(epoch=0)
+
+        for key in self.statistics_training.keys():
+            self.statistics_training[key] = 0
+
+        for epoch in range(self.num_epochs):
+            dev_loss = self.optimize_model(do_training=True)
+
+            train_writer.add_scalar('loss', self.train_losses[-1], epoch + 1)
+            dev_writer.add_scalar('loss', self.dev_losses[-1], epoch + 1)
+
+            if self.best_dev is None or dev_loss < self.best_dev:
+                self.best_dev = dev_loss
+                self.patience_dev = 0
+                if master:
+                    print('Saving best model so far, ' +
+                          'epoch {}... '.format(epoch + 1), end='', flush=True)
+                    if self.checkpoints:
+                        self.network.save_network(epoch=epoch + 1)
+                    self.network.save_network()
+                    self.save_whoami()
+                    print("Done.")
+                self.best_epoch = epoch
+            else:
+                self.patience_dev += 1
+                if self.patience_dev > self.patience:
+                    if master:
+                        print("No improvements after {} iterations, "
+                              "stopping now".format(self.patience))
+                        print('Finished Training')
+                    break
+
+        if master:
+            print('Saving best checkpoint network')
+
+    def plot_summary_statistics(self):
+        print(" ***** Statistics for the training step ***** ")
+        for key in self.statistics_training.keys():
+            stats = self.statistics_training[key]
+            print(" Number of {} pairs seen: {} \t\t".format(key, stats))
+
+    def pretty_print_losses(self, train_loss, dev_loss):
+        if self.rank == 0:
+            print("  training loss:\t\t{:.6f}".format(train_loss))
+            print("  dev loss:\t\t\t{:.6f}".format(dev_loss))
+
+
+class TrainerSiamese(TrainerBuilder):
+    """Siamese Trainer class for ABnet3 (abnet3/trainer.py:203-256)."""
+
+    def __init__(self, *args, **kwargs):
+        super(TrainerSiamese, self).__init__(*args, **kwargs)
+        assert isinstance(self.network, NetworkBuilder)
+
+    def give_batch_to_network(self, batch):
+        """Feeds one (X1, X2, y) batch to the network and returns the loss to
+        optimize (abnet3/trainer.py:211-224)."""
+        X_batch1, X_batch2, y_batch = batch
+        X_batch1 = X_batch1.cuda(non_blocking=True)
+        X_batch2 = X_batch2.cuda(non_blocking=True)
+        y_batch = y_batch.cuda(non_blocking=True)
+        emb_batch1, emb_batch2 = self.network(X_batch1, X_batch2)
+        return self.loss(emb_batch1, emb_batch2, y_batch)
+
+    def train_step(self, batch, do_training=True):
+        """The five statements of the reference's inner loop
+        (abnet3/trainer.py:236-240) plus the data-parallel gradient exchange.
+        Returns the (device) loss of the batch; never synchronises."""
+        if do_training:
+            loss_value = self.give_batch_to_network(batch)
+            self.optimizer.zero_grad()
+            loss_value.backward()
+            if self.world_size > 1:
+                self.optimizer.grad_scale = parallel.all_reduce_gradients(
+                    self.network.flat_grad(), getattr(self.loss, 'avg', False))
+            self.optimizer.step()
+        else:
+            with torch.no_grad():
+                loss_value = self.give_batch_to_network(batch)
+            self.optimizer.zero_grad()
+        return loss_value.detach()
+
+    def _batches(self, train_mode):
+        it = self.dataloader.batch_iterator(train_mode=train_mode)
+        if self.world_size > 1 and not getattr(self.dataloader, 'shards_itself', False):
+            it = parallel.shard_batches(it, self.rank, self.world_size)
+        return it
+
+    def optimize_model(self, do_training=True):
+        """Optimization model step for the Siamese network
+        (abnet3/trainer.py:226-256)."""
+        dev_ = self.network.flat_parameters().device
+        train_loss = torch.zeros((), dtype=torch.float64, device=dev_)
+        dev_loss = torch.zeros((), dtype=torch.float64, device=dev_)
+        num_batches_train = 0
+        num_batches_dev = 0
+        self.network.train()
+        for minibatch in self._batches(True):
+            train_loss += self.train_step(minibatch, do_training).double()
+            num_batches_train += 1
+
+        self.network.eval()
+        with torch.no_grad():
+            for minibatch in self._batches(False):
+                num_batches_dev += 1
+                dev_loss += self.give_batch_to_network(minibatch).double()
+
+        sums = torch.stack([train_loss, dev_loss])
+        counts = torch.tensor([num_batches_train, num_batches_dev], dtype=torch.float64,
+                              device=dev_)
+        if self.world_size > 1:
+            torch.distributed.all_reduce(sums)
+            torch.distributed.all_reduce(counts)
+        train_loss, dev_loss = [float(v) for v in sums.cpu()]      # one sync per epoch
+        num_batches_train, num_batches_dev = [max(float(v), 1.0) for v in counts.cpu()]
+
+        self.train_losses.append(train_loss / num_batches_train)
+        self.dev_losses.append(dev_loss / num_batches_dev)
+        self.pretty_print_losses(train_loss / num_batches_train,
+                                 dev_loss / num_batches_dev)
+        return dev_loss

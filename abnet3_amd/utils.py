@@ -1,0 +1,195 @@
+"""Host helpers + HIP front ends for the batch-production side of the hot path.
+
+Mirrors (file:line relative to the reference checkout)
+  cosine_distance     abnet3/utils.py:40-60     -> abn_cosine_distance
+  get_dtw_alignment   abnet3/utils.py:147-153   -> abn_dtw_batched (1 pair)
+  dtw_align_batch     (new) the same for a whole batch of token pairs at once
+  Features_Accessor   abnet3/utils.py:118-145   host slicing semantics
+  read_dataset / group_pairs / read_pairs   abnet3/utils.py:156-208
+  print_token         abnet3/utils.py:101-105   (pairs-file number format)
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def print_token(tok):
+    """Pretty print token for batches (abnet3/utils.py:101-105)."""
+    return "{0} {1:.2f} {2:.2f}".format(tok[0], tok[1], tok[2])
+
+
+def read_dataset(dataset_file):
+    """[(file1, start1, end1, f2, s2, e2, pair_type), ...] (utils.py:156-173)."""
+    with open(dataset_file, 'r') as fh:
+        lines = fh.readlines()
+    pairs = []
+    for line in lines:
+        tokens = line.strip().split(" ")
+        assert len(tokens) == 7
+        f1, s1, e1, f2, s2, e2, pair_type = tokens
+        s1, e1, s2, e2 = float(s1), float(e1), float(s2), float(e2)
+        assert pair_type in ['same', 'diff'], \
+            'Unsupported pair type {0}'.format(pair_type)
+        pairs.append((f1, s1, e1, f2, s2, e2, pair_type))
+    return pairs
+
+
+def write_dataset(dataset_file, pairs):
+    """The sampler's output format (abnet3/sampler.py:697-742): one line per
+    word pair, times printed %.2f."""
+    with open(dataset_file, 'w') as fh:
+        for f1, s1, e1, f2, s2, e2, pair_type in pairs:
+            fh.write('%s %s %s\n' % (print_token((f1, s1, e1)),
+                                     print_token((f2, s2, e2)), pair_type))
+
+
+def group_pairs(pairs):
+    """{'same': [...], 'diff': [...]} (abnet3/utils.py:176-192)."""
+    grouped_pairs = {'same': [], 'diff': []}
+    for f1, s1, e1, f2, s2, e2, pair_type in pairs:
+        assert pair_type in grouped_pairs, \
+            'Unsupported pair type {0}'.format(pair_type)
+        grouped_pairs[pair_type].append((f1, s1, e1, f2, s2, e2))
+    return grouped_pairs
+
+
+def read_pairs(pair_file):
+    return group_pairs(read_dataset(pair_file))
+
+
+def cast_features(features, target_type=np.float32):
+    for item in features:
+        features[item] = features[item].astype(target_type)
+    return features
+
+
+class Features_Accessor(object):
+    """Time-window -> frame slice with BOTH ends inclusive (utils.py:118-145)."""
+
+    def __init__(self, times, features):
+        self.times = times
+        if features[list(features.keys())[0]].dtype == np.float32:
+            self.features = features
+        else:
+            self.features = cast_features(features)
+
+    @staticmethod
+    def get_indices_between(time, start, end):
+        return np.where(np.logical_and(time >= start, time <= end))[0]
+
+    @staticmethod
+    def get_features_between(feature, time, start, end):
+        return feature[Features_Accessor.get_indices_between(time, start, end), :]
+
+    def _name(self, f):
+        filename = f.encode('UTF-8')
+        if filename not in self.times:
+            filename = f
+        return filename
+
+    def get(self, f, on, off):
+        filename = self._name(f)
+        return self.get_features_between(self.features[filename],
+                                         self.times[filename], on, off)
+
+    def get_between_frames(self, f, frame_on, frame_off):
+        return self.features[self._name(f)][frame_on:frame_off]
+
+
+def _as_device_f32(a):
+    if isinstance(a, torch.Tensor):
+        t = a
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    if t.dtype != torch.float32:
+        raise AssertionError('features must be float32 (abnet3/utils.py:41-42)')
+    return t.cuda().contiguous()
+
+
+def cosine_distance(x, y):
+    """Angular distance matrix arccos(cos)/pi, float64 [N, M] (utils.py:40-60),
+    computed on the MI355X.  Raises AssertionError, like the reference's
+    `assert np.all(d >= 0)`, when an entry is NaN (cos rounded above 1)."""
+    x = np.asarray(x) if not isinstance(x, torch.Tensor) else x
+    y = np.asarray(y) if not isinstance(y, torch.Tensor) else y
+    if not isinstance(x, torch.Tensor) and x.dtype == np.float64:
+        assert y.dtype == np.float64
+        x, y = x.astype(np.float32), y.astype(np.float32)   # device math is fp32
+    lib = _lib.load()
+    xd, yd = _as_device_f32(x), _as_device_f32(y)
+    N, M, D = xd.shape[0], yd.shape[0], xd.shape[1]
+    assert yd.shape[1] == D
+    d = torch.empty(N, M, dtype=torch.float64, device=xd.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=xd.device)
+    _lib.check(lib.abn_cosine_distance(_lib.ptr(xd), N, _lib.ptr(yd), M, D, _lib.ptr(d),
+                                       _lib.ptr(bad), _lib.stream()), 'abn_cosine_distance')
+    assert int(bad.item()) == 0, 'cosine_distance produced NaN / negative entries'
+    return d.cpu().numpy()
+
+
+class DtwBatchResult(object):
+    """Device-resident result of dtw_align_batch."""
+
+    def __init__(self, path1, path2, path_len, total_cost):
+        self.path1, self.path2 = path1, path2          # int32 [P, stride] (device)
+        self.path_len = path_len                       # int32 [P] (device); 0 = dropped
+        self.total_cost = total_cost                   # float64 [P] (device)
+
+    def to_lists(self):
+        ln = self.path_len.cpu().numpy()
+        p1 = self.path1.cpu().numpy()
+        p2 = self.path2.cpu().numpy()
+        return [(p1[i, :ln[i]].copy(), p2[i, :ln[i]].copy()) if ln[i] > 0 else None
+                for i in range(len(ln))]
+
+
+def dtw_align_batch(feats1, off1, n1, feats2, off2, n2):
+    """Aligns pair p = rows [off1[p], off1[p]+n1[p]) of feats1 with rows
+    [off2[p], off2[p]+n2[p]) of feats2 for all p in one launch sequence.
+
+    feats1/feats2: [rows, D] float32 device tensors (the same tensor may be
+    passed twice).  off*/n*: host int arrays.  Returns DtwBatchResult."""
+    lib = _lib.load()
+    _lib.require_device(feats1, feats2)
+    off1 = np.ascontiguousarray(off1, dtype=np.int64)
+    off2 = np.ascontiguousarray(off2, dtype=np.int64)
+    n1 = np.ascontiguousarray(n1, dtype=np.int32)
+    n2 = np.ascontiguousarray(n2, dtype=np.int32)
+    P = len(n1)
+    dev = feats1.device
+    stride = int(max(1, (n1.astype(np.int64) + n2).max() - 1)) if P else 1
+    path1 = torch.empty(P, stride, dtype=torch.int32, device=dev)
+    path2 = torch.empty(P, stride, dtype=torch.int32, device=dev)
+    plen = torch.zeros(P, dtype=torch.int32, device=dev)
+    cost = torch.zeros(P, dtype=torch.float64, device=dev)
+    if P == 0:
+        return DtwBatchResult(path1, path2, plen, cost)
+    vp = ctypes.c_void_p
+    a = lambda arr: arr.ctypes.data_as(vp)
+    ws_bytes = lib.abn_dtw_ws_bytes(a(n1), a(n2), P, feats1.shape[0], feats2.shape[0])
+    hs_bytes = lib.abn_dtw_host_stage_bytes(a(n1), a(n2), P)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    host_stage = torch.empty(hs_bytes, dtype=torch.uint8).pin_memory()
+    _lib.check(lib.abn_dtw_batched(
+        _lib.ptr(feats1), feats1.shape[0], _lib.ptr(feats2), feats2.shape[0],
+        a(off1), a(n1), a(off2), a(n2), P, feats1.shape[1], _lib.ptr(path1),
+        _lib.ptr(path2), _lib.ptr(plen), stride, _lib.ptr(cost), _lib.ptr(ws), ws_bytes,
+        vp(host_stage.data_ptr()), hs_bytes, _lib.stream()), 'abn_dtw_batched')
+    res = DtwBatchResult(path1, path2, plen, cost)
+    res._keepalive = (ws, host_stage)        # until the stream has consumed them
+    return res
+
+
+def get_dtw_alignment(feat1, feat2):
+    """(path1, path2) for one token pair (abnet3/utils.py:147-153).  Raises
+    AssertionError when the reference's cosine_distance would (NaN distance)."""
+    f1, f2 = _as_device_f32(feat1), _as_device_f32(feat2)
+    res = dtw_align_batch(f1, [0], [f1.shape[0]], f2, [0], [f2.shape[0]])
+    out = res.to_lists()[0]
+    assert out is not None, 'cosine_distance produced NaN / negative entries'
+    path1, path2 = out
+    assert len(path1) == len(path2)
+    return path1, path2

@@ -15,8 +15,9 @@ parameter names come from) and IS the definition the HIP kernel is tested
 against:
   frames:   nfr = int(len(sig)/fshift + 1), fshift = fs/frate, frame t starts
             at round(t*fshift), wlen = int(0.025*fs) samples, zero-padded tail
-  pre-emph: y[i] = x[i] - alpha*x[i-1] inside the frame; for i=0 the previous
-            sample of the signal (0 before the first sample)
+  pre-emph: y[i] = x[i] - alpha*x[i-1] over the zero-padded frame; the history
+            of its first sample is the previous sample of the signal (0 before
+            the first one), and the first padded sample still sees -alpha*last
   window:   numpy.hamming(wlen) (symmetric)
   power:    |rfft(frame, nfft)|^2, nfft=1024 -> 513 bins
   mel bank: 40 triangular filters between lowerf=133.3333 Hz and
@@ -101,21 +102,12 @@ def fbank(sig, fs, nfilt=40, alpha=0.97, frate=100, wlen=0.025, nfft=1024,
     filt = mel_filterbank(fs, nfft, nfilt)
     nfr = frame_count(len(sig), fs, frate)
     out = np.zeros((nfr, nfilt), dtype=np.float32)
-    padded = np.concatenate((sig, np.zeros(wl + 1)))
+    # the signal extended by zeros on both sides: x~[-1] = 0, x~[len...] = 0
+    ext = np.concatenate(([0.0], sig, np.zeros(wl + 1)))
     for t in range(nfr):
         start = int(round(t * fshift))
-        if start >= len(sig):
-            frame = np.zeros(wl)
-            prev = np.zeros(wl)
-        else:
-            frame = padded[start:start + wl].copy()
-            # samples past the end of the signal are zero, and so is the
-            # pre-emphasis history there
-            valid = max(0, min(wl, len(sig) - start))
-            frame[valid:] = 0.0
-            prev = np.empty(wl)
-            prev[0] = sig[start - 1] if start > 0 else 0.0
-            prev[1:] = frame[:-1]
+        frame = ext[start + 1:start + 1 + wl]
+        prev = ext[start:start + wl]
         pre = ((frame - alpha * prev) * win).astype(dtype)
         spec = np.fft.rfft(pre.astype(np.float64), nfft)
         power = (spec.real * spec.real + spec.imag * spec.imag).astype(dtype)

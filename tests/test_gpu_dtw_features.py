@@ -1,0 +1,208 @@
+"""Parity of the HIP DTW / distance / gather / stacking / filterbank kernels
+(through the C-ABI) with the C / numpy oracle and the golden vectors.
+DTW path indices must be BIT-EXACT.  Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def synth_pairs(rng, P, lo=5, hi=90, D=40, warp=True):
+    n1 = rng.integers(lo, hi, P).astype(np.int32)
+    n2 = rng.integers(lo, hi, P).astype(np.int32)
+    f1 = rng.standard_normal((int(n1.sum()), D)).astype(np.float32)
+    o1 = np.concatenate(([0], np.cumsum(n1)[:-1])).astype(np.int64)
+    o2 = np.concatenate(([0], np.cumsum(n2)[:-1])).astype(np.int64)
+    f2 = rng.standard_normal((int(n2.sum()), D)).astype(np.float32)
+    if warp:    # second token = time-warped copy of the first + noise
+        for p in range(P):
+            src = np.rint(np.linspace(0, n1[p] - 1, n2[p])).astype(int)
+            f2[o2[p]:o2[p] + n2[p]] = f1[o1[p] + src] + 0.1 * f2[o2[p]:o2[p] + n2[p]]
+    return f1, o1, n1, f2, o2, n2
+
+
+@pytest.mark.parametrize('name', ['f32', 'one', 'zero', 'near'])
+def test_cosine_distance_matches_reference_and_oracle(name):
+    from abnet3_amd.utils import cosine_distance
+    from oracle import dtw_oracle as O
+    g = load_golden('cosdist.npz')
+    d = cosine_distance(g[name + '.x'], g[name + '.y'])
+    assert d.dtype == np.float64
+    assert (d == O.cosine_distance(g[name + '.x'], g[name + '.y'])).all()      # bit-exact
+    ref = g[name + '.d']
+    assert np.abs(np.cos(np.pi * d) - np.cos(np.pi * ref)).max() < 5e-7
+
+
+def test_cosine_distance_nan_pair_is_refused():
+    from abnet3_amd.utils import cosine_distance, get_dtw_alignment
+    g = load_golden('cosdist.npz')
+    with pytest.raises(AssertionError):
+        cosine_distance(g['pos.x'], g['pos.y'])
+    with pytest.raises(AssertionError):       # the loader's try/except then drops the pair
+        get_dtw_alignment(g['pos.x'], g['pos.y'])
+
+
+@pytest.mark.parametrize('D', [40, 280, 13])
+def test_dtw_paths_bit_exact_vs_oracle(D):
+    from abnet3_amd.utils import dtw_align_batch
+    from oracle import dtw_oracle as O
+    rng = np.random.default_rng(D)
+    f1, o1, n1, f2, o2, n2 = synth_pairs(rng, 96, D=D)
+    # edge cases: 1-frame tokens, a long one, an exact tile multiple
+    n1[0], n2[0] = 1, 1
+    n1[1], n2[1] = 1, 40
+    n1[2], n2[2] = 64, 64
+    res = dtw_align_batch(torch.from_numpy(f1).cuda(), o1, n1, torch.from_numpy(f2).cuda(), o2, n2)
+    got = res.to_lists()
+    cost = res.total_cost.cpu().numpy()
+    for p in range(len(n1)):
+        a = f1[o1[p]:o1[p] + n1[p]]
+        b = f2[o2[p]:o2[p] + n2[p]]
+        d = O.cosine_distance(a, b)
+        p1, p2 = O.dtw_path(d)
+        assert got[p] is not None
+        assert (got[p][0] == p1).all() and (got[p][1] == p2).all(), p
+        assert cost[p] == O.dtw_cost(d), p                        # float64 DP: bit-exact too
+
+
+def test_dtw_ties_and_long_tokens():
+    from abnet3_amd.utils import dtw_align_batch
+    from oracle import dtw_oracle as O
+    rng = np.random.default_rng(5)
+    # quantised features => many exactly equal distances => tie-break matters
+    n1 = np.array([300, 600, 1000, 17, 128], dtype=np.int32)
+    n2 = np.array([280, 590, 50, 1000, 129], dtype=np.int32)
+    f1 = rng.integers(-2, 3, (int(n1.sum()), 8)).astype(np.float32)
+    f2 = rng.integers(-2, 3, (int(n2.sum()), 8)).astype(np.float32)
+    f1[f1.sum(1) == 0] += 1
+    o1 = np.concatenate(([0], np.cumsum(n1)[:-1]))
+    o2 = np.concatenate(([0], np.cumsum(n2)[:-1]))
+    got = dtw_align_batch(torch.from_numpy(f1).cuda(), o1, n1, torch.from_numpy(f2).cuda(), o2, n2).to_lists()
+    for p in range(len(n1)):
+        a, b = f1[o1[p]:o1[p] + n1[p]], f2[o2[p]:o2[p] + n2[p]]
+        try:
+            ref = O.get_dtw_alignment(a, b)
+        except AssertionError:
+            assert got[p] is None
+            continue
+        assert (got[p][0] == ref[0]).all() and (got[p][1] == ref[1]).all(), p
+
+
+def test_dtw_dropped_pair_and_empty_token():
+    from abnet3_amd.utils import dtw_align_batch
+    g = load_golden('cosdist.npz')
+    x, y = g['pos.x'], g['pos.y']            # holds identical rows -> NaN -> dropped
+    f = torch.from_numpy(np.concatenate([x, y])).cuda()
+    res = dtw_align_batch(f, [0, 0, 0], [30, 30, 0], f, [30, 40, 30], [30, 10, 5])
+    ln = res.path_len.cpu().numpy()
+    assert ln[0] == 0 and ln[2] == 0 and ln[1] > 0
+
+
+def test_load_frames_from_pairs_matches_reference_fixture():
+    """G7: OriginalDataLoader.load_frames_from_pairs on the toy batch (the
+    fixture was produced by the reference loader with the oracle DTW)."""
+    from abnet3_amd.dataloader import OriginalDataLoader
+    from abnet3_amd.utils import group_pairs
+    g = load_golden('frames.npz')
+    feats = {k[5:]: v for k, v in g.items() if k.startswith('feat.')}
+    times = {k: np.arange(len(v)) * 0.01 + 0.0025 for k, v in feats.items()}
+
+    def parse(line):
+        t = str(line).split(' ')
+        return (t[0], float(t[1]), float(t[2]), t[3], float(t[4]), float(t[5]), t[6])
+    pairs = [parse(l) for l in g['pairs']]
+    empty = parse(g['pairs_empty'])
+    for align in (0, 1):
+        dl = OriginalDataLoader('unused', 'unused', align_different_words=bool(align))
+        dl.set_data(feats, times)
+        X1, X2, Y = dl.load_frames_from_pairs(group_pairs(pairs + ([] if align else [empty])))
+        assert Y.dtype == np.float64 and X1.dtype == np.float32
+        assert (X1 == g['align%d.X1' % align]).all()
+        assert (X2 == g['align%d.X2' % align]).all()
+        assert (Y == g['align%d.Y' % align]).all()
+
+
+def test_frames_dataloader_batches_and_trainer_epoch(tmp_path):
+    """FramesDataLoader (exact frame-pair batches) driving TrainerSiamese for
+    two epochs: losses finite, decreasing machinery runs, best model saved."""
+    from abnet3_amd.dataloader import FramesDataLoader
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.loss import coscos2
+    from abnet3_amd.trainer import TrainerSiamese
+    rng = np.random.default_rng(3)
+    feats = {'u%d' % i: rng.standard_normal((400, 40)).astype(np.float32) for i in range(4)}
+    times = {k: np.arange(400) * 0.01 + 0.0025 for k in feats}
+    pairs = []
+    for i in range(40):
+        a, b = rng.integers(0, 4, 2)
+        s1, s2 = rng.uniform(0, 3.0, 2).round(2)
+        pairs.append(('u%d' % a, s1, s1 + 0.4, 'u%d' % b, s2, s2 + 0.5, 'same' if i % 2 else 'diff'))
+    dl = FramesDataLoader('unused', 'unused', batch_size=256)
+    dl.set_data(feats, times, pairs[:30], pairs[30:])
+    np.random.seed(0)
+    batches = list(dl.batch_iterator(True))
+    assert all(b[0].shape == (256, 40) and b[0].is_cuda for b in batches)
+    assert batches[0][2].dtype == torch.int64
+    torch.manual_seed(0)
+    net = SiameseNetwork(input_dim=40, num_hidden_layers=1, hidden_dim=64, output_dim=32,
+                         p_dropout=0.0, activation_layer='sigmoid',
+                         output_path=str(tmp_path / 'network'))
+    tr = TrainerSiamese(network=net, loss=coscos2(avg=False), num_epochs=2, patience=5,
+                        optimizer_type='adadelta', lr=0.1, dataloader=dl,
+                        log_dir=str(tmp_path / 'runs'))
+    tr.train()
+    assert len(tr.train_losses) == 3 and np.isfinite(tr.train_losses).all()
+    assert (tmp_path / 'network.pth').exists()
+    sd = torch.load(str(tmp_path / 'network.pth'))
+    assert list(sd.keys()) == ['input_emb.0.weight', 'input_emb.0.bias',
+                               'hidden_layers.0.weight', 'hidden_layers.0.bias',
+                               'output_layer.0.weight', 'output_layer.0.bias']
+
+
+@pytest.mark.parametrize('name', ['t100_n7', 't100_n3', 't5_n7', 't2_n7', 't17_n1'])
+def test_stack_fbanks_matches_reference(name):
+    from abnet3_amd.features import FeaturesGenerator
+    g = load_golden('stack.npz')
+    out = FeaturesGenerator().stack_fbanks(g[name + '.in'], int(g[name + '.n']))
+    assert out.dtype == g[name + '.out'].dtype and (out == g[name + '.out']).all()
+
+
+@pytest.mark.parametrize('fs,n', [(16000, 16000), (16000, 12345), (22050, 3999), (16000, 150)])
+def test_fbank_matches_oracle(fs, n):
+    from abnet3_amd.features import FeaturesGenerator
+    from oracle import features_np as F
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / fs
+    sig = (2000 * np.sin(2 * np.pi * 700 * t) + 900 * np.sin(2 * np.pi * 2300 * t + 1.0)
+           + 200 * rng.standard_normal(n)).astype(np.int16)
+    fg = FeaturesGenerator()
+    fb = fg.fbank_from_samples(sig, fs).cpu().numpy()
+    ref = F.fbank(sig, fs)
+    assert fb.shape == ref.shape == (F.frame_count(n, fs), 40) and fb.dtype == np.float32
+    # log energies ~ 10..25; fp32 FFT against the fp64 definition
+    assert np.abs(fb - ref).max() < 2e-3
+    # float input path and silence floor
+    fbf = fg.fbank_from_samples(sig.astype(np.float32), fs).cpu().numpy()
+    assert np.abs(fbf - fb).max() < 1e-5
+    z = fg.fbank_from_samples(np.zeros(2000, dtype=np.int16), fs).cpu().numpy()
+    assert np.allclose(z, np.log(1e-5))
+
+
+def test_embedder_matches_eval_forward():
+    from abnet3_amd.embedder import EmbedderSiamese
+    from abnet3_amd.model import SiameseNetwork
+    g = load_golden('tower_sig.npz')
+    import ast
+    net = SiameseNetwork(**ast.literal_eval(str(g['kw'])))
+    net.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('p.')})
+    emb = EmbedderSiamese(network=net, network_path=None, feature_path=None, output_path=None,
+                          batch_size=10)
+    out = emb.embed_features([g['x1'], g['x2'].astype(np.float64), g['x1'][:0]])
+    assert np.abs(out[0] - g['eval_e1']).max() < 1e-5 * np.abs(g['eval_e1']).max()
+    assert np.abs(out[1] - g['eval_e2']).max() < 1e-5 * np.abs(g['eval_e2']).max()
+    assert out[2].shape == (0, 50)
+    with pytest.raises(ValueError):
+        EmbedderSiamese(network=None)

@@ -124,7 +124,7 @@ def test_loss_edge_cases(ls, lname, margin, avg):
     assert lv.dim() == 0
     lv.backward()
     ref = float(g[tag + '.loss'])
-    assert abs(float(lv) - ref) <= 1e-5 * abs(ref) + 1e-6
+    assert abs(float(lv.detach()) - ref) <= 1e-5 * abs(ref) + 1e-6
     check_loss_grads(e1.grad.cpu().numpy(), e2.grad.cpu().numpy(),
                      g[tag + '.de1'], g[tag + '.de2'], lname, tag)
 
