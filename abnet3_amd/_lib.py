@@ -32,6 +32,10 @@ SYMBOLS = {
     'abn_tower_forward': (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int, _vp, _vp]),
     'abn_tower_backward': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp,
                                       _i64, _vp, _vp]),
+    'abn_linear_forward': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp, _vp]),
+    'abn_linear_dgrad': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, C.c_int, _vp, _vp]),
+    'abn_linear_wgrad_scratch_floats': (_i64, [_i64, _i64, _i64]),
+    'abn_linear_wgrad': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     'abn_pair_loss_ws_bytes': (_i64, [_i64]),
     'abn_pair_loss': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, C.c_int,
                                  _f32, C.c_int, _vp, _vp, _vp, _vp, _vp]),

@@ -525,4 +525,80 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     return ABN_OK;
 }
 
+
+// ---- single-layer entry points (the same kernels, one Linear at a time) -------
+int abn_linear_forward(const float* x, const float* W, const float* b, int64_t rows, int64_t in_dim,
+                       int64_t out_dim, int act, float* y, void* stream)
+{
+    ABN_REQUIRE(x && W && y, "linear_forward: null pointer");
+    ABN_REQUIRE(rows >= 0 && rows < (1LL << 30) && in_dim >= 1 && out_dim >= 1 && in_dim < (1 << 24) && out_dim < (1 << 24),
+                "linear_forward: bad shape");
+    ABN_REQUIRE(act >= ABN_ACT_NONE && act <= ABN_ACT_TANH, "linear_forward: unsupported activation %d", act);
+    GemmP p = {};
+    p.A = x; p.lda = in_dim;
+    p.B = W; p.ldb = in_dim;
+    p.C = y; p.ldc = out_dim;
+    p.M = (int)rows; p.N = (int)out_dim; p.K = (int)in_dim; p.k_chunk = (int)in_dim;
+    p.bias = b; p.act = act; p.ones_col = -1;
+    p.a_vec = aligned16(x) && (in_dim % 4 == 0);
+    p.b_vec = aligned16(W) && (in_dim % 4 == 0);
+    return launch_gemm<true, true, EPI_FWD>(p, 1, (hipStream_t)stream);
+}
+
+int abn_linear_dgrad(const float* dz, const float* W, int64_t rows, int64_t in_dim, int64_t out_dim,
+                     const float* a_prev, int act_prev, float* dx, void* stream)
+{
+    ABN_REQUIRE(dz && W && dx, "linear_dgrad: null pointer");
+    ABN_REQUIRE(rows >= 0 && rows < (1LL << 30) && in_dim >= 1 && out_dim >= 1 && in_dim < (1 << 24) && out_dim < (1 << 24),
+                "linear_dgrad: bad shape");
+    ABN_REQUIRE(act_prev >= ABN_ACT_NONE && act_prev <= ABN_ACT_TANH, "linear_dgrad: unsupported activation %d", act_prev);
+    GemmP p = {};
+    p.A = dz; p.lda = out_dim;
+    p.B = W; p.ldb = in_dim;
+    p.C = dx; p.ldc = in_dim;
+    p.M = (int)rows; p.N = (int)in_dim; p.K = (int)out_dim; p.k_chunk = (int)out_dim;
+    p.aux = a_prev; p.ldaux = in_dim; p.act = act_prev; p.ones_col = -1;
+    p.a_vec = aligned16(dz) && (out_dim % 4 == 0);
+    p.b_vec = aligned16(W) && (in_dim % 4 == 0);
+    return launch_gemm<true, false, EPI_DGRAD>(p, 1, (hipStream_t)stream);
+}
+
+int64_t abn_linear_wgrad_scratch_floats(int64_t rows, int64_t in_dim, int64_t out_dim)
+{
+    if (rows < 0 || in_dim < 1 || out_dim < 1) return -1;
+    return align_up(out_dim * in_dim + out_dim, 64) * split_count(rows);
+}
+
+int abn_linear_wgrad(const float* dz, const float* a_in, int64_t rows, int64_t in_dim, int64_t out_dim, float* dW,
+                     float* db, float* scratch, int64_t scratch_floats, void* stream)
+{
+    ABN_REQUIRE(dz && a_in && dW && db && scratch, "linear_wgrad: null pointer");
+    ABN_REQUIRE(rows >= 1 && rows < (1LL << 30) && in_dim >= 1 && out_dim >= 1 && in_dim < (1 << 24) && out_dim < (1 << 24),
+                "linear_wgrad: bad shape");
+    const int splits = split_count(rows);
+    const int64_t stride = align_up(out_dim * in_dim + out_dim, 64);
+    if (scratch_floats < stride * splits) { set_error("linear_wgrad: scratch too small"); return ABN_E_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    GemmP p = {};
+    p.A = dz; p.lda = out_dim;
+    p.B = a_in; p.ldb = in_dim;
+    p.C = scratch; p.ldc = in_dim;
+    p.C2 = scratch + out_dim * in_dim;
+    p.slab_stride = stride;
+    p.M = (int)out_dim; p.N = (int)in_dim + 1; p.K = (int)rows;
+    p.k_chunk = (int)align_up((rows + splits - 1) / splits, BK);
+    p.ones_col = (int)in_dim;
+    p.a_vec = aligned16(dz) && (out_dim % 4 == 0);
+    p.b_vec = aligned16(a_in) && (in_dim % 4 == 0);
+    int rc = launch_gemm<false, false, EPI_WGRAD>(p, splits, st);
+    if (rc != ABN_OK) return rc;
+    ReduceTable rt = {};
+    rt.n_layers = 1; rt.splits = splits; rt.slab_stride = stride;
+    rt.off[0] = 0; rt.nW[0] = out_dim * in_dim; rt.nb[0] = out_dim; rt.dW[0] = dW; rt.db[0] = db;
+    rt.total = out_dim * in_dim + out_dim;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(rt.total)), dim3(256), 0, st, scratch, rt);
+    ABN_CHECK_LAUNCH("linear_wgrad");
+    return ABN_OK;
+}
+
 }  // extern "C"

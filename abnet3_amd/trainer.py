@@ -280,6 +280,51 @@ class TrainerSiamese(TrainerBuilder):
             self.optimizer.zero_grad()
         return loss_value.detach()
 
+    def make_graphed_step(self, example_batch, warmup=3):
+        """Captures one whole train step (forward of both towers, loss,
+        backward, optimizer) for batches shaped like `example_batch` into a
+        hipGraph and returns step(batch) -> device loss.  A C2 step is ~15
+        kernel launches of 5-50 us each: replaying one graph removes the
+        per-launch host cost (Python, autograd, ctypes) from the loop.  Under
+        torch.distributed the gradient all-reduce and the optimizer stay
+        outside the graph (fwd + bwd are captured).  Adam's bias correction is
+        host-computed per step, so its optimizer launch also stays outside."""
+        x1, x2, y = [t.cuda().clone() for t in example_batch]
+        opt = self.optimizer
+        capture_opt = (self.world_size == 1 and isinstance(opt, FlatOptimizer)
+                       and opt.kind != 'adam')
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):      # also moves the optimizer past step 1
+                self.train_step((x1, x2, y), True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss_value = self.give_batch_to_network((x1, x2, y))
+            opt.zero_grad()
+            loss_value.backward()
+            if capture_opt:
+                opt.step()
+        static_loss = loss_value.detach()
+
+        def step(batch):
+            x1.copy_(batch[0], non_blocking=True)
+            x2.copy_(batch[1], non_blocking=True)
+            y.copy_(batch[2], non_blocking=True)
+            graph.replay()
+            if capture_opt:
+                opt.step_count += 1
+            else:
+                if self.world_size > 1:
+                    opt.grad_scale = parallel.all_reduce_gradients(
+                        self.network.flat_grad(), getattr(self.loss, 'avg', False))
+                opt.step()
+            return static_loss
+        step.graph = graph
+        return step
+
     def _batches(self, train_mode):
         it = self.dataloader.batch_iterator(train_mode=train_mode)
         if self.world_size > 1 and not getattr(self.dataloader, 'shards_itself', False):

@@ -108,6 +108,21 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
                        const float* ws, float* scratch, int64_t scratch_floats,
                        float* dx, void* stream);
 
+/* One nn.Linear at a time with the same kernels (what abn_tower_* chains):
+ *   forward  y = act(x W^T + b)                       (addmm + activation)
+ *   dgrad    dx = (dz W) * act'(a_prev)  [a_prev NULL: plain dz W]
+ *   wgrad    dW = dz^T a_in, db = colsum(dz); scratch: split-K slabs
+ * x [rows,in], W [out,in], y/dz [rows,out], a_prev/dx/a_in [rows,in]. */
+int abn_linear_forward(const float* x, const float* W, const float* b, int64_t rows,
+                       int64_t in_dim, int64_t out_dim, int act, float* y, void* stream);
+int abn_linear_dgrad(const float* dz, const float* W, int64_t rows, int64_t in_dim,
+                     int64_t out_dim, const float* a_prev, int act_prev, float* dx,
+                     void* stream);
+int64_t abn_linear_wgrad_scratch_floats(int64_t rows, int64_t in_dim, int64_t out_dim);
+int abn_linear_wgrad(const float* dz, const float* a_in, int64_t rows, int64_t in_dim,
+                     int64_t out_dim, float* dW, float* db, float* scratch,
+                     int64_t scratch_floats, void* stream);
+
 /* coscos2.forward / cosmargin.forward fused with their backward,
  * abnet3/loss.py:46-67 and :85-105 (nn.CosineSimilarity(dim=1, eps=1e-6)).
  * loss_out: device scalar (fp32).  de1/de2: [B, D] gradients of the (already
