@@ -54,6 +54,10 @@ struct GemmP {
     int64_t slab_stride;    // WGRAD: floats between split-K slabs of C / C2
     int ones_col;           // WGRAD: column of B that is identically 1, or -1
     int a_vec, b_vec;       // 16-byte global loads allowed for A / B
+    int c_vec;              // 16-byte epilogue accesses allowed (C, bias, aux)
+#ifdef ABN_STAMPS
+    unsigned long long* stamps;   // diagnostic build only: [block][128] s_memtime stamps
+#endif
 };
 
 __device__ __forceinline__ float act_apply(float z, int act)
@@ -86,75 +90,119 @@ struct TileShape {
     static constexpr int per_thread = units / 256;
 };
 
-// Loads this thread's float4 units of one operand tile into registers.
-// mn0: first row(M/N index) of the tile, k0: first k, k_end: exclusive k bound.
+// Global -> register stage of one operand tile, BRANCH-FREE: every lane issues
+// all of its loads unconditionally from clamped (always valid) addresses and
+// nothing consumes the results here, so the loads stay in flight behind the
+// MFMA phase that follows.  Validity is re-derived and applied in tile_commit,
+// after that phase.  (Per-unit `if (m < M)` guards compile to exec-mask
+// branches with a vmcnt(0) at every join: measured 2.6x slower.)
+// mn0: first row (M/N index) of the tile, k0: first k, k_end: exclusive k bound.
+template <int BMN, bool KCONTIG, bool VEC, bool INTERIOR>
+__device__ __forceinline__ void tile_issue(f32x4* r, const float* __restrict__ X, int64_t ld,
+                                           int MN, int mn0, int k0, int k_end)
+{
+    constexpr int PT = TileShape<BMN, KCONTIG>::per_thread;
+    const int t = threadIdx.x;
+    if constexpr (VEC && INTERIOR) {   // whole tile inside the matrix: no clamping at all
+        static_assert(!INTERIOR, "interior tiles go through tile_issue_fast");
+    } else if constexpr (VEC) {  // units are entirely inside or entirely outside the matrix
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int u = t + 256 * i;
+            int m, k;
+            if constexpr (KCONTIG) { m = mn0 + (u >> 3); k = k0 + 4 * (u & 7); }
+            else { constexpr int UPR = BMN / 4; k = k0 + u / UPR; m = mn0 + 4 * (u % UPR); }
+            const bool ok = KCONTIG ? (m < MN && k < k_end) : (k < k_end && m < MN);
+            const int64_t off = KCONTIG ? ((int64_t)m * ld + k) : ((int64_t)k * ld + m);
+            r[i] = *reinterpret_cast<const f32x4*>(X + (ok ? off : 0));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int u = t + 256 * i;
+            int m, k;
+            if constexpr (KCONTIG) { m = mn0 + (u >> 3); k = k0 + 4 * (u & 7); }
+            else { constexpr int UPR = BMN / 4; k = k0 + u / UPR; m = mn0 + 4 * (u % UPR); }
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int me = KCONTIG ? m : m + e, ke = KCONTIG ? k + e : k;
+                const bool ok = me < MN && ke < k_end;
+                const int64_t off = KCONTIG ? ((int64_t)me * ld + ke) : ((int64_t)ke * ld + me);
+                v[e] = X[ok ? off : 0];
+            }
+            r[i] = v;
+        }
+    }
+}
+
+// Interior tiles (the common case): the per-lane element offsets inside the tile
+// never change, so they are computed ONCE (32-bit: the host checks that every
+// operand spans < 2^31 floats) and each k-tile only moves a wave-uniform base
+// pointer -- no 64-bit integer VALU work in the loop (it measured ~1400 cycles
+// per tile when recomputed each time).
 template <int BMN, bool KCONTIG>
-__device__ __forceinline__ void tile_load(f32x4* r,
-                                          const float* __restrict__ X, int64_t ld,
-                                          int MN, int mn0, int k0, int k_end, bool vec,
-                                          int ones_col)
+__device__ __forceinline__ void tile_offsets(uint32_t* voff, int64_t ld)
 {
     constexpr int PT = TileShape<BMN, KCONTIG>::per_thread;
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
         const int u = t + 256 * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (KCONTIG) {
-            const int row = u >> 3, kq = u & 7;
-            const int m = mn0 + row, k = k0 + 4 * kq;
-            if (m < MN) {
-                const float* p = X + (int64_t)m * ld + k;
-                if (vec && k + 3 < k_end) {
-                    v = *reinterpret_cast<const f32x4*>(p);
-                } else {
-                    if (k + 0 < k_end) v.x = p[0];
-                    if (k + 1 < k_end) v.y = p[1];
-                    if (k + 2 < k_end) v.z = p[2];
-                    if (k + 3 < k_end) v.w = p[3];
-                }
-            }
-        } else {
-            constexpr int UPR = BMN / 4;            // units per k row
-            const int kk = u / UPR, mq = u % UPR;
-            const int k = k0 + kk, m = mn0 + 4 * mq;
-            if (k < k_end) {
-                const float* p = X + (int64_t)k * ld + m;
-                if (vec && m + 3 < MN) {
-                    v = *reinterpret_cast<const f32x4*>(p);
-                } else {
-                    if (m + 0 < MN) v.x = p[0];
-                    if (m + 1 < MN) v.y = p[1];
-                    if (m + 2 < MN) v.z = p[2];
-                    if (m + 3 < MN) v.w = p[3];
-                }
-                if (ones_col >= 0) {                // wgrad: bias column of ones
-                    const int d = ones_col - m;
-                    if (d == 0) v.x = 1.0f;
-                    if (d == 1) v.y = 1.0f;
-                    if (d == 2) v.z = 1.0f;
-                    if (d == 3) v.w = 1.0f;
-                }
-            }
-        }
-        r[i] = v;
+        if constexpr (KCONTIG) voff[i] = (uint32_t)((u >> 3) * (uint32_t)ld + 4 * (u & 7));
+        else { constexpr int UPR = BMN / 4; voff[i] = (uint32_t)((u / UPR) * (uint32_t)ld + 4 * (u % UPR)); }
     }
 }
 
 template <int BMN, bool KCONTIG>
-__device__ __forceinline__ void tile_store(const f32x4* r,
-                                           float* __restrict__ lds)
+__device__ __forceinline__ void tile_issue_fast(f32x4* r, const float* __restrict__ base, const uint32_t* voff)
+{
+    constexpr int PT = TileShape<BMN, KCONTIG>::per_thread;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) r[i] = *reinterpret_cast<const f32x4*>(base + voff[i]);
+}
+
+// Register -> LDS stage: zero what lies outside the matrix, synthesise the
+// all-ones bias column of wgrad, store 16 bytes per unit.
+template <int BMN, bool KCONTIG, bool INTERIOR>
+__device__ __forceinline__ void tile_commit(const f32x4* r, float* __restrict__ lds, int MN, int mn0,
+                                            int k0, int k_end, int ones_col)
 {
     constexpr int PT = TileShape<BMN, KCONTIG>::per_thread;
     constexpr int ST = TileShape<BMN, KCONTIG>::stride;
     const int t = threadIdx.x;
+    if constexpr (INTERIOR) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int u = t + 256 * i;
+            int off;
+            if constexpr (KCONTIG) off = (u >> 3) * ST + 4 * (u & 7);
+            else { constexpr int UPR = BMN / 4; off = (u / UPR) * ST + 4 * (u % UPR); }
+            *reinterpret_cast<f32x4*>(lds + off) = r[i];
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
         const int u = t + 256 * i;
-        int off;
-        if constexpr (KCONTIG) off = (u >> 3) * ST + 4 * (u & 7);
-        else { constexpr int UPR = BMN / 4; off = (u / UPR) * ST + 4 * (u % UPR); }
-        *reinterpret_cast<f32x4*>(lds + off) = r[i];
+        int m, k, off;
+        if constexpr (KCONTIG) {
+            m = mn0 + (u >> 3); k = k0 + 4 * (u & 7);
+            off = (u >> 3) * ST + 4 * (u & 7);
+        } else {
+            constexpr int UPR = BMN / 4;
+            k = k0 + u / UPR; m = mn0 + 4 * (u % UPR);
+            off = (u / UPR) * ST + 4 * (u % UPR);
+        }
+        f32x4 v = r[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int me = KCONTIG ? m : m + e, ke = KCONTIG ? k + e : k;
+            float x = (me < MN && ke < k_end) ? v[e] : 0.0f;
+            if (!KCONTIG && me == ones_col && ke < k_end) x = 1.0f;   // ones_col = -1: never
+            v[e] = x;
+        }
+        *reinterpret_cast<f32x4*>(lds + off) = v;
     }
 }
 
@@ -183,9 +231,35 @@ __device__ __forceinline__ int xcd_tile_index(int b, int n)
     return (b & 7) * (n >> 3) + (b >> 3);
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+#ifdef ABN_STAMPS
+// stamps stay in SGPR/LDS-free registers of lane 0 until the end of the kernel
+#define ABN_STAMP()                                                                          \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        unsigned long long t_;                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if (nst < 80) stbuf[nst] = t_;                                                       \
+        ++nst;                                                                               \
+    } while (0)
+#define ABN_STAMP_FLUSH()                                                                    \
+    do {                                                                                     \
+        if (p.stamps && threadIdx.x == 0)                                                    \
+            for (int q_ = 0; q_ < 80; ++q_) p.stamps[(size_t)blockIdx.x * 128 + q_] = q_ < nst ? stbuf[q_] : 0; \
+    } while (0)
+#else
+#define ABN_STAMP() do {} while (0)
+#define ABN_STAMP_FLUSH() do {} while (0)
+#endif
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
 {
+#ifdef ABN_STAMPS
+    int nst = 0;
+    unsigned long long stbuf[80];
+#endif
+    ABN_STAMP();
     static_assert(BM % 64 == 0 && BN % 64 == 0, "tile must split over 2x2 waves of 32x32 MFMAs");
     constexpr int TM = BM / 64, TN = BN / 64;
     using TA = TileShape<BM, A_KC>;
@@ -217,80 +291,167 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
     const int ones = (EPI == EPI_WGRAD) ? p.ones_col : -1;
     // the ones column is synthesised, never read: B really has `ones` columns
     const int nB = (ones >= 0) ? ones : p.N;
+    // wave-uniform "this operand tile lies fully inside the matrix" flags pick a
+    // clamp-free issue and a mask-free commit (the common case: 15 of 16 k-tiles)
+    const bool a_in = VEC && (m0 + BM <= p.M), b_in = VEC && (n0 + BN <= nB);
+    uint32_t voa[TA::per_thread], vob[TB::per_thread];
+    tile_offsets<BM, A_KC>(voa, p.lda);
+    tile_offsets<BN, B_KC>(vob, p.ldb);
+    // element (mn0, k = 0) of each operand; a k-tile adds k0 (K-contig) or k0*ld
+    const float* const a_org = p.A + (A_KC ? (int64_t)m0 * p.lda : (int64_t)m0);
+    const float* const b_org = p.B + (B_KC ? (int64_t)n0 * p.ldb : (int64_t)n0);
+    auto issue = [&](int k0) {
+        const bool k_in = k0 + BK <= ke;
+        if (a_in && k_in) tile_issue_fast<BM, A_KC>(ra, a_org + (A_KC ? (int64_t)k0 : (int64_t)k0 * p.lda), voa);
+        else tile_issue<BM, A_KC, VEC, false>(ra, p.A, p.lda, p.M, m0, k0, ke);
+        if (b_in && k_in) tile_issue_fast<BN, B_KC>(rb, b_org + (B_KC ? (int64_t)k0 : (int64_t)k0 * p.ldb), vob);
+        else tile_issue<BN, B_KC, VEC, false>(rb, p.B, p.ldb, nB, n0, k0, ke);
+    };
+    auto commit = [&](int k0, float* as, float* bs) {
+        const bool k_in = k0 + BK <= ke;
+        if (a_in && k_in) tile_commit<BM, A_KC, true>(ra, as, p.M, m0, k0, ke, -1);
+        else tile_commit<BM, A_KC, false>(ra, as, p.M, m0, k0, ke, -1);
+        if (b_in && k_in) tile_commit<BN, B_KC, true>(rb, bs, nB, n0, k0, ke, ones);
+        else tile_commit<BN, B_KC, false>(rb, bs, nB, n0, k0, ke, ones);
+    };
     if (nkt > 0) {
-        tile_load<BM, A_KC>(ra, p.A, p.lda, p.M, m0, kb, ke, p.a_vec, -1);
-        tile_load<BN, B_KC>(rb, p.B, p.ldb, nB, n0, kb, ke, p.b_vec, ones);
-        tile_store<BM, A_KC>(ra, As);
-        tile_store<BN, B_KC>(rb, Bs);
+        issue(kb);
+        commit(kb, As, Bs);
     }
     __syncthreads();
+    ABN_STAMP();
+
+    auto k_group = [&](const float* as, const float* bs, int g) {
+        f32x4 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, A_KC>(as, wm0 + 32 * i, g, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, B_KC>(bs, wn0 + 32 * j, g, lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    };
+
+    // One global load of the next tile (unit u: A units first, then B units).
+    auto issue_unit = [&](int u, const float* an, const float* bn) {
+        if (u < TA::per_thread) ra[u] = *reinterpret_cast<const f32x4*>(an + voa[u]);
+        else rb[u - TA::per_thread] = *reinterpret_cast<const f32x4*>(bn + vob[u - TA::per_thread]);
+    };
+    constexpr int UNITS = TA::per_thread + TB::per_thread;
+    constexpr int UPG = (UNITS + 1) / 2;         // loads issued behind each of the first two k-groups
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
-        if (more) {
-            tile_load<BM, A_KC>(ra, p.A, p.lda, p.M, m0, kb + (kt + 1) * BK, ke, p.a_vec, -1);
-            tile_load<BN, B_KC>(rb, p.B, p.ldb, nB, n0, kb + (kt + 1) * BK, ke, p.b_vec, ones);
+        const int knext = kb + (kt + 1) * BK;
+        const float* as = As + cur * TA::floats;
+        const float* bs = Bs + cur * TB::floats;
+        // Interior next tile (the common case): its loads are NOT issued in one
+        // burst at the top -- all 8 waves of a CU doing that right after the
+        // barrier queue ~50 KB on the CU's address unit and every wave's MFMA
+        // phase starts 800-1700 cycles late (s_memtime stamps) -- but spread
+        // behind the first two k-groups' MFMAs.  Edge tiles keep the simple order.
+        const bool fast = more && a_in && b_in && (knext + BK <= ke);
+        if (more && !fast) issue(knext);
+        ABN_STAMP();
+        const float* an = a_org + (A_KC ? (int64_t)knext : (int64_t)knext * p.lda);
+        const float* bn = b_org + (B_KC ? (int64_t)knext : (int64_t)knext * p.ldb);
+        // tiles are zero-filled past k_end, so every tile runs all BK/8 groups
+        // (at most 31 wasted k per GEMM) and the loop body stays branch-free
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            k_group(as, bs, g);
+            if (g < 2 && fast) {
+#pragma unroll
+                for (int u = g * UPG; u < (g + 1) * UPG && u < UNITS; ++u) issue_unit(u, an, bn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        const int kvalid = min(BK, ke - (kb + kt * BK));
-        const int ng = (kvalid + 7) >> 3;
-        for (int g = 0; g < ng; ++g) {
-            f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, A_KC>(As + cur * TA::floats, wm0 + 32 * i, g, lane);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, B_KC>(Bs + cur * TB::floats, wn0 + 32 * j, g, lane);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e],
-                                                                        acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            tile_store<BM, A_KC>(ra, As + (cur ^ 1) * TA::floats);
-            tile_store<BN, B_KC>(rb, Bs + (cur ^ 1) * TB::floats);
-        }
+        ABN_STAMP();
+        if (more) commit(knext, As + (cur ^ 1) * TA::floats, Bs + (cur ^ 1) * TB::floats);
+        ABN_STAMP();
         __syncthreads();
+        ABN_STAMP();
     }
 
-    // Epilogue. Accumulator register r of lane l holds
+    // Epilogue.  The accumulators go through LDS (free after the k loop) so that
+    // every global access of the epilogue -- C, the bias, the dgrad's saved
+    // activations -- is a full-row 16-byte access: storing straight from the
+    // MFMA layout (32 lanes x 4 B per row segment) measured 10 us per 16 MB
+    // output, this form ~4.  Accumulator register r of lane l holds
     //   row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31   of its 32x32 block.
-    const int col_l = lane & 31, rsub = 4 * (lane >> 5);
+    constexpr int SST = BN + 4;
+    float* const stage = smem;
+    {
+        const int col_l = lane & 31, rsub = 4 * (lane >> 5);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + 32 * j + col_l;
-        if (n >= p.N) continue;
-        float bias = 0.0f;
-        if constexpr (EPI == EPI_FWD) bias = p.bias ? p.bias[n] : 0.0f;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + rsub;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
+                for (int r = 0; r < 16; ++r)
+                    stage[(wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + rsub) * SST + wn0 + 32 * j + col_l] = acc[i][j][r];
+    }
+    __syncthreads();
+    ABN_STAMP();
+    constexpr int C4 = BN / 4;
+    const int n_plain = (EPI == EPI_WGRAD && p.ones_col >= 0) ? p.ones_col : p.N;   // columns that live in C
+    const int64_t slab = (EPI == EPI_WGRAD) ? (int64_t)blockIdx.y * p.slab_stride : 0;
+#pragma unroll 2
+    for (int u = threadIdx.x; u < BM * C4; u += 256) {
+        const int row = u / C4, c4 = u % C4;
+        const int m = m0 + row, n = n0 + 4 * c4;
+        if (m >= p.M || n >= p.N) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * SST + 4 * c4);
+        if (p.c_vec && n + 3 < n_plain) {
+            if constexpr (EPI == EPI_FWD) {
+                if (p.bias) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    v += bv;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
+            } else if constexpr (EPI == EPI_DGRAD) {
+                if (p.aux) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(p.aux + (int64_t)m * p.ldaux + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= act_grad(av[e], p.act);
+                }
+            }
+            *reinterpret_cast<f32x4*>(p.C + slab + (int64_t)m * p.ldc + n) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ne = n + e;
+                if (ne >= p.N) break;
+                float x = v[e];
                 if constexpr (EPI == EPI_FWD) {
-                    p.C[(int64_t)m * p.ldc + n] = act_apply(v + bias, p.act);
+                    x = act_apply(x + (p.bias ? p.bias[ne] : 0.0f), p.act);
+                    p.C[(int64_t)m * p.ldc + ne] = x;
                 } else if constexpr (EPI == EPI_DGRAD) {
-                    if (p.aux) v *= act_grad(p.aux[(int64_t)m * p.ldaux + n], p.act);
-                    p.C[(int64_t)m * p.ldc + n] = v;
+                    if (p.aux) x *= act_grad(p.aux[(int64_t)m * p.ldaux + ne], p.act);
+                    p.C[(int64_t)m * p.ldc + ne] = x;
                 } else {
-                    const int64_t slab = (int64_t)blockIdx.y * p.slab_stride;
-                    if (n == p.ones_col) p.C2[slab + m] = v;
-                    else p.C[slab + (int64_t)m * p.ldc + n] = v;
+                    if (ne == p.ones_col) p.C2[slab + m] = x;
+                    else p.C[slab + (int64_t)m * p.ldc + ne] = x;
                 }
             }
         }
     }
+    ABN_STAMP();
+    ABN_STAMP_FLUSH();
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC>
 constexpr size_t gemm_lds_bytes()
 {
-    return sizeof(float) * 2 * (TileShape<BM, A_KC>::floats + TileShape<BN, B_KC>::floats);
+    constexpr size_t tiles = sizeof(float) * 2 * (TileShape<BM, A_KC>::floats + TileShape<BN, B_KC>::floats);
+    constexpr size_t stage = sizeof(float) * BM * (BN + 4);       // epilogue staging tile
+    return tiles > stage ? tiles : stage;
 }
 
 }  // namespace abn

@@ -7,6 +7,7 @@
 // and the activation derivative (dgrad) are fused into the GEMM epilogues; the
 // bias gradient rides in the wgrad GEMM as an extra all-ones input column.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -26,12 +27,12 @@ void set_error(const char* fmt, ...)
 // ---------------------------------------------------------------------------
 // GEMM dispatch
 // ---------------------------------------------------------------------------
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
-static void launch_cfg(const GemmP& p, int splits, hipStream_t st)
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC>
+static void launch_one(const GemmP& p, int splits, hipStream_t st)
 {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     constexpr size_t lds = gemm_lds_bytes<BM, BN, A_KC, B_KC>();
-    auto k = gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>;
+    auto k = gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, VEC>;
     static bool attr_set = false;      // > 64 KiB of dynamic LDS needs the opt-in
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -41,29 +42,55 @@ static void launch_cfg(const GemmP& p, int splits, hipStream_t st)
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(256), lds, st, p);
 }
 
+// 16-byte global loads need both operands aligned with leading dimensions that
+// are multiples of 4 floats; anything else takes the element-wise build.
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+static void launch_cfg(const GemmP& p, int splits, hipStream_t st)
+{
+    if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true>(p, splits, st);
+    else launch_one<BM, BN, A_KC, B_KC, EPI, false>(p, splits, st);
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 static int launch_gemm(GemmP p, int splits, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0) return ABN_OK;
     if (p.K <= 0) { set_error("gemm: empty reduction"); return ABN_E_ARG; }
+    {   // in-kernel lane offsets are 32-bit: every operand must span < 2^31 floats
+        const int64_t span_a = (int64_t)(A_KC ? p.M : p.K) * p.lda, span_b = (int64_t)(B_KC ? p.N : p.K) * p.ldb;
+        if (span_a >= (1LL << 31) || span_b >= (1LL << 31)) { set_error("gemm: operand larger than 2^31 floats"); return ABN_E_ARG; }
+    }
     auto tiles = [&](int bm, int bn) {
         return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * splits;
     };
-    // largest tile that still yields ~a workgroup per CU (256 CUs); among the
-    // two rectangular shapes prefer the one wasting less padding.
-    const int64_t want = 192;
+    // Largest tile that still gives every CU (256) two workgroups: a workgroup
+    // is one wave per SIMD, so a second resident workgroup is what covers the
+    // barrier / LDS-refill phases of the first with MFMA work.  Among the two
+    // rectangular shapes prefer the one wasting less padding.
+    const int64_t want = 2 * 256;
+    {
+        const bool slab_ok = (EPI != EPI_WGRAD) || (p.slab_stride % 4 == 0);
+        p.c_vec = aligned16(p.C) && (p.ldc % 4 == 0) && slab_ok && (!p.bias || aligned16(p.bias)) &&
+                  (!p.aux || (aligned16(p.aux) && p.ldaux % 4 == 0));
+    }
+#ifdef ABN_STAMPS
+    p.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
+#endif
+    static const int force = getenv("ABN_GEMM_TILE") ? atoi(getenv("ABN_GEMM_TILE")) : -1;
+    if (force == 0) { launch_cfg<128, 128, A_KC, B_KC, EPI>(p, splits, st); return ABN_OK; }
+    if (force == 1) { launch_cfg<128, 64, A_KC, B_KC, EPI>(p, splits, st); return ABN_OK; }
+    if (force == 2) { launch_cfg<64, 128, A_KC, B_KC, EPI>(p, splits, st); return ABN_OK; }
+    if (force == 3) { launch_cfg<64, 64, A_KC, B_KC, EPI>(p, splits, st); return ABN_OK; }
+    const int64_t pad_a = (int64_t)((p.M + 127) / 128 * 128) * ((p.N + 63) / 64 * 64);
+    const int64_t pad_b = (int64_t)((p.M + 63) / 64 * 64) * ((p.N + 127) / 128 * 128);
     if (p.M > 64 && p.N > 64 && tiles(128, 128) >= want)
         launch_cfg<128, 128, A_KC, B_KC, EPI>(p, splits, st);
-    else {
-        const int64_t pad_a = (int64_t)((p.M + 127) / 128 * 128) * ((p.N + 63) / 64 * 64);
-        const int64_t pad_b = (int64_t)((p.M + 63) / 64 * 64) * ((p.N + 127) / 128 * 128);
-        if (p.M > 64 && tiles(128, 64) >= want && pad_a <= pad_b)
-            launch_cfg<128, 64, A_KC, B_KC, EPI>(p, splits, st);
-        else if (p.N > 64 && tiles(64, 128) >= want)
-            launch_cfg<64, 128, A_KC, B_KC, EPI>(p, splits, st);
-        else
-            launch_cfg<64, 64, A_KC, B_KC, EPI>(p, splits, st);
-    }
+    else if (p.M > 64 && tiles(128, 64) >= want && (pad_a <= pad_b || !(p.N > 64 && tiles(64, 128) >= want)))
+        launch_cfg<128, 64, A_KC, B_KC, EPI>(p, splits, st);
+    else if (p.N > 64 && tiles(64, 128) >= want)
+        launch_cfg<64, 128, A_KC, B_KC, EPI>(p, splits, st);
+    else
+        launch_cfg<64, 64, A_KC, B_KC, EPI>(p, splits, st);
     ABN_CHECK_LAUNCH("gemm_f32");
     return ABN_OK;
 }
