@@ -69,7 +69,7 @@ class _TowerFunction(torch.autograd.Function):
     """One launch sequence for n_calls forward_once calls sharing the weights."""
 
     @staticmethod
-    def forward(ctx, net, n_calls, x1, x2, *params):
+    def forward(ctx, net, n_calls, split, x1, x2, *params):
         lib = _lib.load()
         _lib.require_device(x1, x2, *params)
         if x1.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
@@ -97,14 +97,35 @@ class _TowerFunction(torch.autograd.Function):
         out = ws[off:off + rows * net.output_dim].view(rows, net.output_dim)
         ctx.net, ctx.n_calls, ctx.train = net, n_calls, train
         ctx.have_x2 = x2 is not None
+        ctx.split = split
         ctx.save_for_backward(x1, x2, ws)
+        if split:        # the two towers' embeddings as two outputs (no slice nodes)
+            half = rows // 2
+            return out[:half], out[half:]
         return out
 
     @staticmethod
-    def backward(ctx, d_out):
+    def backward(ctx, *d_outs):
         lib = _lib.load()
         net = ctx.net
         x1, x2, ws = ctx.saved_tensors
+        if ctx.split:
+            d1, d2 = d_outs
+            if d1 is None or d2 is None:
+                z = d1 if d1 is not None else d2
+                d1 = d1 if d1 is not None else torch.zeros_like(z)
+                d2 = d2 if d2 is not None else torch.zeros_like(z)
+            # the pair loss hands back two halves of ONE buffer: take it whole
+            if (d1.is_contiguous() and d2.is_contiguous() and d1._base is not None
+                    and d1._base is d2._base and d1._base.is_contiguous()
+                    and d1._base.numel() == 2 * d1.numel()
+                    and d1.data_ptr() == d1._base.data_ptr()
+                    and d2.data_ptr() == d1.data_ptr() + d1.numel() * 4):
+                d_out = d1._base.view(2 * d1.shape[0], d1.shape[1])
+            else:
+                d_out = torch.cat([d1, d2])
+        else:
+            d_out = d_outs[0]
         if net.batch_norm and not ctx.train:
             raise NotImplementedError(
                 'abnet3_amd: backward through an eval-mode BatchNorm forward is '
@@ -118,7 +139,7 @@ class _TowerFunction(torch.autograd.Function):
         scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
         scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32,
                               device=d_out.device)
-        need_dx = ctx.needs_input_grad[2] or (ctx.have_x2 and ctx.needs_input_grad[3])
+        need_dx = ctx.needs_input_grad[3] or (ctx.have_x2 and ctx.needs_input_grad[4])
         dx = torch.empty(rows, net.input_dim, dtype=torch.float32,
                          device=d_out.device) if need_dx else None
         _lib.check(lib.abn_tower_backward(
@@ -131,7 +152,7 @@ class _TowerFunction(torch.autograd.Function):
                 dx1, dx2 = dx[:rows // 2], dx[rows // 2:]
             else:
                 dx1 = dx
-        return (None, None, dx1, dx2) + tuple(grads)
+        return (None, None, None, dx1, dx2) + tuple(grads)
 
 
 class SiameseNetwork(NetworkBuilder):
@@ -327,26 +348,31 @@ class SiameseNetwork(NetworkBuilder):
                 gi += 2
         return d
 
-    def _run(self, x1, x2):
+    def _run(self, x1, x2, n_calls, split):
         if self.training and self.p_dropout > 0:
             raise NotImplementedError(
                 'abnet3_amd: p_dropout > 0 in train mode is not on the accelerated '
                 'path yet (use p_dropout=0.0, the canonical configuration, '
                 'test/data/buckeye.yaml:50)')
-        n_calls = 2 if x2 is not None else 1
-        return _TowerFunction.apply(self, n_calls, x1, x2, *self.parameters())
+        return _TowerFunction.apply(self, n_calls, split, x1, x2, *self.parameters())
 
     # -- reference surface ---------------------------------------------------
     def forward_once(self, x):
         """Simple forward pass for one instance x (abnet3/model.py:179-186)."""
-        return self._run(x, None)
+        return self._run(x, None, 1, False)
 
     def forward(self, input1, input2):
         """Forward pass through the same network (abnet3/model.py:188-196): both
         towers in one launch sequence, BatchNorm statistics per tower call."""
-        out = self._run(input1, input2)
-        n = input1.shape[0]
-        return out[:n], out[n:]
+        return self._run(input1, input2, 2, True)
+
+    def forward_pair_rows(self, x12):
+        """forward(x12[:B], x12[B:]) for a batch that already sits in one
+        [2B, D] buffer (what a device-side batch builder produces): saves the
+        concatenation copy inside the call."""
+        if x12.shape[0] % 2:
+            raise ValueError('abnet3_amd: forward_pair_rows needs an even number of rows')
+        return self._run(x12, None, 2, True)
 
     def whoami(self):
         return {'params': self.__dict__, 'class_name': self.__class__.__name__}

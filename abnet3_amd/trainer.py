@@ -289,8 +289,16 @@ class TrainerSiamese(TrainerBuilder):
         torch.distributed the gradient all-reduce and the optimizer stay
         outside the graph (fwd + bwd are captured).  Adam's bias correction is
         host-computed per step, so its optimizer launch also stays outside."""
-        x1, x2, y = [t.cuda().clone() for t in example_batch]
+        # static inputs: both towers' rows in ONE [2B, D] buffer
+        B = example_batch[0].shape[0]
+        x12 = torch.cat([example_batch[0].cuda(), example_batch[1].cuda()])
+        x1, x2 = x12[:B], x12[B:]
+        y = example_batch[2].cuda().clone()
         opt = self.optimizer
+
+        def fwd_loss():
+            e1, e2 = self.network.forward_pair_rows(x12)
+            return self.loss(e1, e2, y)
         capture_opt = (self.world_size == 1 and isinstance(opt, FlatOptimizer)
                        and opt.kind != 'adam')
         side = torch.cuda.Stream()
@@ -302,7 +310,7 @@ class TrainerSiamese(TrainerBuilder):
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            loss_value = self.give_batch_to_network((x1, x2, y))
+            loss_value = fwd_loss()
             opt.zero_grad()
             loss_value.backward()
             if capture_opt:

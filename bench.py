@@ -52,7 +52,7 @@ def make_pool(seed, device):
 
 
 def gemm_roofline(torch, reps=50):
-    """Times the dominant kernel -- gemm_f32_kernel<128,128,K-contig,K-contig,FWD>,
+    """Times the dominant kernel -- gemm_f32_kernel<128, 64, true, true, 0, true>,
     launched three times per step (layers 40->500, 500->500, 500->500 over the
     2x4096 tower rows) -- in isolation through the single-layer C-ABI entry,
     with HIP events on the launch stream; reports per-launch averages."""
@@ -87,7 +87,7 @@ def gemm_roofline(torch, reps=50):
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             'traffic': None,
-            'kernel': 'gemm_f32_kernel<128,128,Kcontig,Kcontig,FWD>',
+            'kernel': 'abn::gemm_f32_kernel<128, 64, true, true, 0, true>  (forward: A, B K-contiguous, 16-byte loads)',
             'avg_launch_us': round(avg_s * 1e6, 2),
             'flop_per_launch': flop_per_launch}
 
@@ -125,12 +125,84 @@ def cpu_baseline(torch, budget_s=12.0):
                       'of the reference, %.1f s)' % (n, BATCH, dt)}
 
 
+def synth_dtw_pairs(P, seed, D=40):
+    """SURVEY.md 8d "C4": lengths ~ clip(round(N(300, 60)), 50, 600); the second
+    token of a pair is a time-warped noisy copy of the first."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    n1 = np.clip(np.rint(rng.normal(300, 60, P)), 50, 600).astype(np.int32)
+    n2 = np.clip(np.rint(rng.normal(300, 60, P)), 50, 600).astype(np.int32)
+    o1 = np.concatenate(([0], np.cumsum(n1)[:-1])).astype(np.int64)
+    o2 = np.concatenate(([0], np.cumsum(n2)[:-1])).astype(np.int64)
+    f1 = rng.standard_normal((int(n1.sum()), D), dtype=np.float32)
+    f2 = np.empty((int(n2.sum()), D), dtype=np.float32)
+    noise = rng.standard_normal(f2.shape, dtype=np.float32)
+    for p in range(P):
+        src = np.rint(np.linspace(0, n1[p] - 1, n2[p])).astype(np.int64)
+        f2[o2[p]:o2[p] + n2[p]] = f1[o1[p] + src] + 0.1 * noise[o2[p]:o2[p] + n2[p]]
+    return f1, o1, n1, f2, o2, n2
+
+
+def dtw_bench(torch, P, rank, world, reps=3, cpu_pairs=4000):
+    """BASELINE.json configs[3]: DTW alignment of P synthetic token pairs (40-d,
+    ~300 frames) on this rank's GPU; cells/s = sum(N*M) / wall time of the
+    batched call (distance matrix + DP + traceback; features already in HBM)."""
+    import numpy as np
+    from abnet3_amd.utils import dtw_align_batch
+    f1, o1, n1, f2, o2, n2 = synth_dtw_pairs(P, seed=1000 + rank)
+    cells = int((n1.astype(np.int64) * n2).sum())
+    d1, d2 = torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda()
+    res = dtw_align_batch(d1, o1, n1, d2, o2, n2)          # warm-up (+ allocations)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = dtw_align_batch(d1, o1, n1, d2, o2, n2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        best = dt if best is None else min(best, dt)
+    dropped = int((res.path_len == 0).sum().item())
+    out = {'metric': 'DTW cells/sec (cosine distance + DP + traceback, 40-d, ~300-frame tokens)',
+           'value': round(cells * world / best, 1), 'unit': 'cells/s', 'pairs_per_gpu': P,
+           'cells_per_gpu': cells, 'ms': round(best * 1e3, 3), 'dropped_pairs': dropped,
+           # algorithmic bytes (SURVEY.md 8d): inputs (N+M)*40*4 + paths <= (N+M)*8
+           'roofline': {'bound': 'hbm', 'achieved': round((int((n1.astype(np.int64) + n2).sum()) * 168) / best / 1e9, 2),
+                        'peak': 8000.0, 'unit': 'GB/s', 'traffic': None,
+                        'note': 'dependency/VALU-bound DP: N+M-1 sequential anti-diagonals per pair; '
+                                'the HBM roofline is reported for reference only'}}
+    out['roofline']['frac'] = round(out['roofline']['achieved'] / 8000.0, 5)
+    if rank == 0 and world == 1:
+        from oracle import dtw_oracle
+        q = min(cpu_pairs, P)
+        sub_cells = int((n1[:q].astype(np.int64) * n2[:q]).sum())
+        t0 = time.perf_counter()
+        p1, p2, ln, c = dtw_oracle.dtw_batch(f1, o1[:q], n1[:q], f2, o2[:q], n2[:q], 1200)
+        dt = time.perf_counter() - t0
+        got = res.to_lists()
+        exact = all(got[i] is not None and (got[i][0] == p1[i, :ln[i]]).all() and
+                    (got[i][1] == p2[i, :ln[i]]).all() for i in range(q))
+        out['cpu_baseline'] = {'value': round(sub_cells / dt, 1), 'unit': 'cells/s', 'cores': 1,
+                               'kind': 'port', 'sample': '%d of the %d pairs (%d cells, %.1f s), oracle/dtw.c'
+                               % (q, P, sub_cells, dt)}
+        out['paths_bit_exact_on_sample'] = bool(exact)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtw-pairs', type=int, default=10000,
+                    help='token pairs per GPU for the DTW leg (0 = skip)')
     ap.add_argument('--no-graph', action='store_true',
                     help='launch every step eagerly instead of replaying a hipGraph')
     args = ap.parse_args()
@@ -181,6 +253,8 @@ def main():
         elapsed = float(t.item())
     last_loss = float(loss)
 
+    dtw = dtw_bench(torch, args.dtw_pairs, rank, world) if args.dtw_pairs > 0 else None
+
     if rank == 0:
         value = args.steps * BATCH * world / elapsed
         out = {
@@ -202,6 +276,8 @@ def main():
             cb = cpu_baseline(torch)
             out['cpu_baseline'] = cb
             out['gpu_over_cpu'] = round(value / cb['value'], 1)
+        if dtw is not None:
+            out['dtw'] = dtw
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

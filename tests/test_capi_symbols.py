@@ -1,0 +1,84 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol that
+include/abnet3_hip.h declares; host-side sizing entry points answer sanely.
+No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, 'include', 'abnet3_hip.h')
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(abn_[a-z0-9_]+)\s*\(', text)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from abnet3_amd import build, _lib
+    build.build()                      # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def test_header_declares_what_the_binding_binds(lib):
+    from abnet3_amd import _lib
+    assert set(declared_symbols()) == set(_lib.SYMBOLS), \
+        set(declared_symbols()) ^ set(_lib.SYMBOLS)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    raw = ctypes.CDLL(lib._name)
+    for name in declared_symbols():
+        assert hasattr(raw, name), name
+    assert lib.abn_abi_version() == 1
+
+
+def test_descriptor_layout_matches_header():
+    from abnet3_amd import _lib
+    # 4 x int32 + 17 x int64 + 10 arrays of 16 pointers
+    assert ctypes.sizeof(_lib.TowerDesc) == 16 + 17 * 8 + 10 * 16 * 8
+
+
+def test_host_side_sizing_and_argument_errors(lib):
+    from abnet3_amd import _lib
+    d = _lib.TowerDesc()
+    d.n_layers, d.act, d.last_act, d.batch_norm = 4, 1, 1, 0
+    for i, v in enumerate((40, 500, 500, 500, 100)):
+        d.dims[i] = v
+    for l in range(4):
+        d.W[l] = 0x1000
+        d.b[l] = 0x1000
+    rows = 8192
+    ws = lib.abn_tower_ws_floats(ctypes.byref(d), rows, 2)
+    assert ws >= rows * (40 + 500 * 3 + 100)
+    off = lib.abn_tower_out_offset(ctypes.byref(d), rows, 2)
+    assert 0 < off < ws and off % 64 == 0
+    assert lib.abn_tower_bwd_scratch_floats(ctypes.byref(d), rows) >= 16 * 571600
+    assert lib.abn_tower_ws_floats(ctypes.byref(d), 8191, 2) == -1      # rows % n_calls
+    assert b'divisible' in lib.abn_last_error()
+    d.n_layers = 99
+    assert lib.abn_tower_ws_floats(ctypes.byref(d), rows, 2) == -1
+    assert lib.abn_pair_loss_ws_bytes(4096) == 512 * 8
+    assert lib.abn_linear_wgrad_scratch_floats(8192, 500, 500) == 16 * 250560
+    # argument validation happens before any launch
+    assert lib.abn_pair_loss(None, None, None, 2, 4, 4, 0, 0.5, 1, None, None, None, None, None) == -1
+    assert lib.abn_stack_frames(None, 10, 40, 4, None, None) == -1      # even nframes
+    assert b'odd' in lib.abn_last_error()
+    assert lib.abn_fbank(None, 1, 100, 400, 160.0, 1000, 40, 0.97, None, None, 1, None, None) == -1
+
+
+def test_dtw_workspace_planning(lib):
+    import numpy as np
+    n1 = np.array([300, 50, 0], dtype=np.int32)
+    n2 = np.array([280, 600, 5], dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    ws = lib.abn_dtw_ws_bytes(p(n1), p(n2), 3, 1000, 1000)
+    cells = (300 + 280) * 300 + (50 + 600) * 50
+    assert ws >= cells * 5                     # f32 skewed distances + u8 back-pointers
+    assert lib.abn_dtw_host_stage_bytes(p(n1), p(n2), 3) >= 3 * 40
+    assert lib.abn_dtw_ws_bytes(None, None, 3, 0, 0) == -1
