@@ -85,14 +85,22 @@ struct PairMeta {
 constexpr int TS = 64;       // distance tile
 constexpr int KC = 32;       // k chunk staged in LDS
 
-// row norms: sequential fmaf chain, one thread per row
-__global__ void norm_kernel(const float* __restrict__ f, int64_t rows, int D, float* __restrict__ out)
+// row norms: sequential fmaf chain over k (the oracle's order), one thread per
+// row; 16-byte loads when rows are 16-byte aligned (D % 4 == 0)
+__global__ void norm_kernel(const float* __restrict__ f, int64_t rows, int D, int vec, float* __restrict__ out)
 {
     const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const float* v = f + r * D;
     float s = 0.0f;
-    for (int k = 0; k < D; ++k) s = fmaf(v[k], v[k], s);
+    if (vec) {
+        for (int k = 0; k < D; k += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(v + k);
+            s = fmaf(q.x, q.x, s); s = fmaf(q.y, q.y, s); s = fmaf(q.z, q.z, s); s = fmaf(q.w, q.w, s);
+        }
+    } else {
+        for (int k = 0; k < D; ++k) s = fmaf(v[k], v[k], s);
+    }
     out[r] = sqrtf(s);
 }
 
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
                                                    const PairMeta* __restrict__ meta, const int32_t* __restrict__ tile_pair,
                                                    int D, float* __restrict__ ws, int32_t* __restrict__ bad)
 {
-    __shared__ float xs[TS][KC + 1], ys[TS][KC + 1];
+    __shared__ __attribute__((aligned(16))) float xs[TS][KC + 4], ys[TS][KC + 4];   // rows 16-byte aligned
     __shared__ float tile[TS * TS];
     const int p = tile_pair[blockIdx.x];
     const PairMeta m = meta[p];
@@ -127,16 +135,25 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
             ys[r][k] = yv;
         }
         __syncthreads();
-        for (int k = 0; k < kn; ++k) {
-            float xa[4], yb[4];
+        // the chunk is zero-filled past kn, and fma(0, 0, acc) == acc exactly, so
+        // whole float4 groups can be consumed; k still ascends one at a time
+        for (int k = 0; k < kn; k += 4) {
+            float4 xa[4], yb[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) xa[a] = xs[ty + 16 * a][k];
+            for (int a = 0; a < 4; ++a) xa[a] = *reinterpret_cast<const float4*>(&xs[ty + 16 * a][k]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) yb[b] = ys[tx + 16 * b][k];
+            for (int b = 0; b < 4; ++b) yb[b] = *reinterpret_cast<const float4*>(&ys[tx + 16 * b][k]);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(xa[a], yb[b], acc[a][b]);
+                for (int b = 0; b < 4; ++b) {
+                    float c = acc[a][b];
+                    c = fmaf(xa[a].x, yb[b].x, c);
+                    c = fmaf(xa[a].y, yb[b].y, c);
+                    c = fmaf(xa[a].z, yb[b].z, c);
+                    c = fmaf(xa[a].w, yb[b].w, c);
+                    acc[a][b] = c;
+                }
         }
         __syncthreads();
     }
@@ -175,15 +192,20 @@ constexpr int DP_MAXN = 1024;        // rows a wavefront can sweep (LDS: 3 x 8 K
 // back-pointer codes
 enum { DIR_DIAG = 0, DIR_UP = 1, DIR_LEFT = 2 };
 
+constexpr int DP_SLOTS = DP_MAXN / 64;      // rows a lane can own
+
 __global__ __launch_bounds__(64) void dp_kernel(const PairMeta* __restrict__ meta, const float* __restrict__ ws,
                                                 uint8_t* __restrict__ dirs, const int32_t* __restrict__ bad,
                                                 int32_t* __restrict__ path1, int32_t* __restrict__ path2,
                                                 int32_t* __restrict__ path_len, int64_t path_stride,
-                                                double* __restrict__ total_cost)
+                                                double* __restrict__ total_cost, int lds_rows)
 {
-    // slot i+1 holds row i.  Interior cells only ever read predecessors that
-    // are real cells of the previous two diagonals, so no sentinel is needed.
-    __shared__ double diag[3][DP_MAXN + 1];
+    // Three rotating anti-diagonals of float64 costs; slot i+1 holds row i.
+    // Interior cells only ever read predecessors that are real cells of the
+    // previous two diagonals, so no sentinel is needed.  Sized by the longest
+    // token of the batch (dynamic LDS) so that more pairs fit on a CU.
+    extern __shared__ double diag_mem[];
+    double* const diag0 = diag_mem;
     const int p = blockIdx.x;
     const PairMeta m = meta[p];
     const int N = m.n1, M = m.n2, lane = threadIdx.x;
@@ -193,36 +215,60 @@ __global__ __launch_bounds__(64) void dp_kernel(const PairMeta* __restrict__ met
     }
     const float* S = ws + m.ws_off;
     uint8_t* Dr = dirs + m.ws_off;
+    const int nc = (N + 63) / 64;                 // slots this pair uses (<= DP_SLOTS)
+    // distances of the NEXT diagonal are fetched while the current one is being
+    // relaxed: the DP is a chain of N+M-1 dependent steps and an un-prefetched
+    // global load per step would put its full latency on that chain
+    float nxt[DP_SLOTS];
+    {
+        // diagonal 0 is the single cell (0,0)
+#pragma unroll
+        for (int c = 0; c < DP_SLOTS; ++c) nxt[c] = 0.0f;
+        if (lane == 0) nxt[0] = S[0];
+    }
     // diagonal d holds cells (i, d - i), max(0, d-M+1) <= i <= min(d, N-1)
     for (int d = 0; d < N + M - 1; ++d) {
-        double* cur = diag[d % 3];
-        const double* p1 = diag[(d + 2) % 3];     // diagonal d-1
-        const double* p2 = diag[(d + 1) % 3];     // diagonal d-2
+        double* cur = diag0 + (d % 3) * lds_rows;
+        const double* p1 = diag0 + ((d + 2) % 3) * lds_rows;     // diagonal d-1
+        const double* p2 = diag0 + ((d + 1) % 3) * lds_rows;     // diagonal d-2
         const int ilo = max(0, d - M + 1), ihi = min(d, N - 1);
-        for (int i = ilo + lane; i <= ihi; i += 64) {
-            const int j = d - i;
-            const double dist = (double)S[(int64_t)d * N + i];
-            double best;
-            int dir;
-            if (i == 0 && j == 0) { best = 0.0; dir = DIR_DIAG; }
-            else if (i == 0) { best = p1[i + 1]; dir = DIR_LEFT; }
-            else if (j == 0) { best = p1[i]; dir = DIR_UP; }
-            else {
-                best = p2[i]; dir = DIR_DIAG;                       // (i-1, j-1)
-                const double up = p1[i], left = p1[i + 1];          // (i-1, j), (i, j-1)
-                if (up < best) { best = up; dir = DIR_UP; }
-                if (left < best) { best = left; dir = DIR_LEFT; }
+        float dist[DP_SLOTS];
+#pragma unroll
+        for (int c = 0; c < DP_SLOTS; ++c) dist[c] = nxt[c];
+        if (d + 1 < N + M - 1) {
+            const int nlo = max(0, d + 1 - M + 1), nhi = min(d + 1, N - 1);
+#pragma unroll
+            for (int c = 0; c < DP_SLOTS; ++c) {
+                const int i = nlo + lane + 64 * c;
+                if (c < nc && i <= nhi) nxt[c] = S[(int64_t)(d + 1) * N + i];
             }
-            cur[i + 1] = dist + best;
-            Dr[(int64_t)d * N + i] = (uint8_t)dir;
+        }
+#pragma unroll
+        for (int c = 0; c < DP_SLOTS; ++c) {
+            const int i = ilo + lane + 64 * c;
+            if (c < nc && i <= ihi) {
+                const int j = d - i;
+                double best;
+                int dir;
+                if (i == 0 && j == 0) { best = 0.0; dir = DIR_DIAG; }
+                else if (i == 0) { best = p1[i + 1]; dir = DIR_LEFT; }
+                else if (j == 0) { best = p1[i]; dir = DIR_UP; }
+                else {
+                    best = p2[i]; dir = DIR_DIAG;                       // (i-1, j-1)
+                    const double up = p1[i], left = p1[i + 1];          // (i-1, j), (i, j-1)
+                    if (up < best) { best = up; dir = DIR_UP; }
+                    if (left < best) { best = left; dir = DIR_LEFT; }
+                }
+                cur[i + 1] = (double)dist[c] + best;
+                Dr[(int64_t)d * N + i] = (uint8_t)dir;
+            }
         }
         __syncthreads();
     }
     if (lane == 0) {
-        if (total_cost) total_cost[p] = diag[(N + M - 2) % 3][N];
-        // traceback, written back to front at its final position
+        if (total_cost) total_cost[p] = diag0[((N + M - 2) % 3) * lds_rows + N];
+        // traceback: first pass counts the steps, second writes the path in place
         int i = N - 1, j = M - 1, len = 1;
-        // first pass: length
         while (i > 0 || j > 0) {
             const int dir = Dr[(int64_t)(i + j) * N + i];
             if (dir == DIR_DIAG) { --i; --j; } else if (dir == DIR_UP) --i; else --j;
@@ -364,15 +410,19 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
     }
     float* norm1 = (float*)(base + w.norm1_off);
     float* norm2 = (float*)(base + w.norm2_off);
-    if (rows1 > 0) hipLaunchKernelGGL(norm_kernel, dim3((unsigned)((rows1 + 255) / 256)), dim3(256), 0, st, feats1, rows1, (int)D, norm1);
-    if (rows2 > 0) hipLaunchKernelGGL(norm_kernel, dim3((unsigned)((rows2 + 255) / 256)), dim3(256), 0, st, feats2, rows2, (int)D, norm2);
+    if (rows1 > 0) hipLaunchKernelGGL(norm_kernel, dim3((unsigned)((rows1 + 255) / 256)), dim3(256), 0, st, feats1, rows1, (int)D, (int)(D % 4 == 0 && aligned16(feats1)), norm1);
+    if (rows2 > 0) hipLaunchKernelGGL(norm_kernel, dim3((unsigned)((rows2 + 255) / 256)), dim3(256), 0, st, feats2, rows2, (int)D, (int)(D % 4 == 0 && aligned16(feats2)), norm2);
     if (tiles > 0)
         hipLaunchKernelGGL(dist_kernel, dim3((unsigned)tiles), dim3(256), 0, st, feats1, feats2, norm1, norm2,
                            (const PairMeta*)(base + w.meta_off), (const int32_t*)(base + w.tilepair_off), (int)D,
                            (float*)(base + w.dist_off), (int32_t*)(base + w.bad_off));
-    hipLaunchKernelGGL(dp_kernel, dim3((unsigned)npairs), dim3(64), 0, st, (const PairMeta*)(base + w.meta_off),
-                       (const float*)(base + w.dist_off), (uint8_t*)(base + w.dirs_off),
-                       (const int32_t*)(base + w.bad_off), path1, path2, path_len, path_stride, total_cost);
+    int32_t max_n1 = 1;
+    for (int64_t p = 0; p < npairs; ++p) max_n1 = n1_host[p] > max_n1 ? n1_host[p] : max_n1;
+    const int lds_rows = (int)align_up(max_n1 + 1, 2);
+    hipLaunchKernelGGL(dp_kernel, dim3((unsigned)npairs), dim3(64), (size_t)3 * lds_rows * sizeof(double), st,
+                       (const PairMeta*)(base + w.meta_off), (const float*)(base + w.dist_off),
+                       (uint8_t*)(base + w.dirs_off), (const int32_t*)(base + w.bad_off), path1, path2, path_len,
+                       path_stride, total_cost, lds_rows);
     ABN_CHECK_LAUNCH("dtw");
     return ABN_OK;
 }

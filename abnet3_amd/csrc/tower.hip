@@ -108,7 +108,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ a, const float* __restr
 
 struct ReduceTable {
     int n_layers;
-    int splits;
+    int splits[ABN_MAX_LAYERS];
     int64_t slab_stride;
     int64_t off[ABN_MAX_LAYERS];     // packed offset of [W_l | b_l]
     int64_t nW[ABN_MAX_LAYERS];
@@ -118,18 +118,36 @@ struct ReduceTable {
     int64_t total;
 };
 
-// grad[i] = sum_s slab[s][i] in fixed order (deterministic, unlike atomics)
+// grad[i] = sum_s slab[s][i] in a FIXED order (deterministic, unlike atomics):
+// four interleaved partial sums (s mod 4) so that four loads are in flight,
+// combined as (p0 + p1) + (p2 + p3).  Layer boundaries are 64-float aligned, so
+// a thread's 4 consecutive elements never straddle two layers.
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, ReduceTable t)
 {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < t.total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.0f;
-        for (int k = 0; k < t.splits; ++k) s += slabs[(int64_t)k * t.slab_stride + i];
+    const int64_t n4 = (t.total + 3) / 4;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4;
+         q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = 4 * q;
         int l = 0;
         while (l + 1 < t.n_layers && i >= t.off[l + 1]) ++l;
-        const int64_t j = i - t.off[l];
-        if (j < t.nW[l]) t.dW[l][j] = s;
-        else if (j - t.nW[l] < t.nb[l]) t.db[l][j - t.nW[l]] = s;
+        const int S = t.splits[l];
+        f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, p2 = p0, p3 = p0;
+        const float* src = slabs + i;
+        int k = 0;
+        for (; k + 3 < S; k += 4) {
+            p0 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 0) * t.slab_stride);
+            p1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 1) * t.slab_stride);
+            p2 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 2) * t.slab_stride);
+            p3 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 3) * t.slab_stride);
+        }
+        for (; k < S; ++k) p0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * t.slab_stride);
+        const f32x4 s = (p0 + p1) + (p2 + p3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t j = i + e - t.off[l];
+            if (j < t.nW[l]) t.dW[l][j] = s[e];
+            else if (j - t.nW[l] < t.nb[l]) t.db[l][j - t.nW[l]] = s[e];
+        }
     }
 }
 
@@ -321,7 +339,21 @@ static int check_desc(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
     return ABN_OK;
 }
 
-static int split_count(int64_t rows) { return (int)(rows / 512 < 1 ? 1 : (rows / 512 > 16 ? 16 : rows / 512)); }
+// Split-K factor of one wgrad GEMM (reduction over `rows`): enough slices that
+// the launch has ~2 workgroups per CU, each slice at least 128 rows deep.
+constexpr int MAX_SPLITS = 32;
+static int split_count(int64_t rows, int64_t out_dim, int64_t in_dim)
+{
+    const int64_t n = in_dim + 1;                       // + the bias column
+    const int64_t tm128 = (out_dim + 127) / 128, tm64 = (out_dim + 63) / 64;
+    const int64_t tn128 = (n + 127) / 128, tn64 = (n + 63) / 64;
+    const int64_t est = out_dim > 64 ? tm128 * tn64 : (n > 64 ? tm64 * tn128 : tm64 * tn64);
+    int64_t s = (512 + est - 1) / est;
+    const int64_t by_rows = rows / 128 < 1 ? 1 : rows / 128;
+    if (s > by_rows) s = by_rows;
+    if (s > MAX_SPLITS) s = MAX_SPLITS;
+    return (int)(s < 1 ? 1 : s);
+}
 
 struct BwdLayout {
     int64_t dz[2];
@@ -329,7 +361,7 @@ struct BwdLayout {
     int64_t slabs;
     int64_t slab_stride;
     int64_t off[ABN_MAX_LAYERS];
-    int splits;
+    int splits[ABN_MAX_LAYERS];
     int64_t total;
 };
 
@@ -345,11 +377,15 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
     B.bn_s2 = take(8 * maxw);
     for (int l = 0; l < t->n_layers; ++l) {
         B.off[l] = packed;
-        packed += t->dims[l + 1] * t->dims[l] + t->dims[l + 1];
+        packed += align_up(t->dims[l + 1] * t->dims[l] + t->dims[l + 1], 64);
     }
     B.slab_stride = align_up(packed, 64);
-    B.splits = split_count(rows);
-    B.slabs = take(B.slab_stride * B.splits);
+    int smax = 1;
+    for (int l = 0; l < t->n_layers; ++l) {
+        B.splits[l] = split_count(rows, t->dims[l + 1], t->dims[l]);
+        smax = B.splits[l] > smax ? B.splits[l] : smax;
+    }
+    B.slabs = take(B.slab_stride * smax);
     B.total = o;
     return B;
 }
@@ -500,11 +536,12 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             p.C2 = slabs + B.off[l] + (int64_t)Nout * Kin;
             p.slab_stride = B.slab_stride;
             p.M = Nout; p.N = Kin + 1; p.K = (int)rows;
-            p.k_chunk = (int)align_up((rows + B.splits - 1) / B.splits, BK);
+            p.k_chunk = (int)align_up((rows + B.splits[l] - 1) / B.splits[l], BK);
             p.ones_col = Kin;
             p.a_vec = aligned16(dz) && (Nout % 4 == 0);
             p.b_vec = aligned16(a_in) && (Kin % 4 == 0);
-            rc = launch_gemm<false, false, EPI_WGRAD>(p, B.splits, st);
+            // slices past the end of the reduction write zero slabs (k range empty)
+            rc = launch_gemm<false, false, EPI_WGRAD>(p, B.splits[l], st);
             if (rc != ABN_OK) return rc;
         }
         // dgrad: d a_{l-1} = dz W_l, times act'(a_{l-1}) when no BN sits in between
@@ -537,9 +574,9 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     }
     ReduceTable rt = {};
     rt.n_layers = nl;
-    rt.splits = B.splits;
     rt.slab_stride = B.slab_stride;
     for (int l = 0; l < nl; ++l) {
+        rt.splits[l] = B.splits[l];
         rt.off[l] = B.off[l];
         rt.nW[l] = t->dims[l + 1] * t->dims[l];
         rt.nb[l] = t->dims[l + 1];
@@ -547,7 +584,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
         rt.db[l] = t->db[l];
     }
     rt.total = B.off[nl - 1] + rt.nW[nl - 1] + rt.nb[nl - 1];
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(rt.total)), dim3(256), 0, st, slabs, rt);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, slabs, rt);
     ABN_CHECK_LAUNCH("slab_reduce");
     return ABN_OK;
 }
@@ -593,7 +630,7 @@ int abn_linear_dgrad(const float* dz, const float* W, int64_t rows, int64_t in_d
 int64_t abn_linear_wgrad_scratch_floats(int64_t rows, int64_t in_dim, int64_t out_dim)
 {
     if (rows < 0 || in_dim < 1 || out_dim < 1) return -1;
-    return align_up(out_dim * in_dim + out_dim, 64) * split_count(rows);
+    return align_up(out_dim * in_dim + out_dim, 64) * split_count(rows, out_dim, in_dim);
 }
 
 int abn_linear_wgrad(const float* dz, const float* a_in, int64_t rows, int64_t in_dim, int64_t out_dim, float* dW,
@@ -602,7 +639,7 @@ int abn_linear_wgrad(const float* dz, const float* a_in, int64_t rows, int64_t i
     ABN_REQUIRE(dz && a_in && dW && db && scratch, "linear_wgrad: null pointer");
     ABN_REQUIRE(rows >= 1 && rows < (1LL << 30) && in_dim >= 1 && out_dim >= 1 && in_dim < (1 << 24) && out_dim < (1 << 24),
                 "linear_wgrad: bad shape");
-    const int splits = split_count(rows);
+    const int splits = split_count(rows, out_dim, in_dim);
     const int64_t stride = align_up(out_dim * in_dim + out_dim, 64);
     if (scratch_floats < stride * splits) { set_error("linear_wgrad: scratch too small"); return ABN_E_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
@@ -620,10 +657,10 @@ int abn_linear_wgrad(const float* dz, const float* a_in, int64_t rows, int64_t i
     int rc = launch_gemm<false, false, EPI_WGRAD>(p, splits, st);
     if (rc != ABN_OK) return rc;
     ReduceTable rt = {};
-    rt.n_layers = 1; rt.splits = splits; rt.slab_stride = stride;
+    rt.n_layers = 1; rt.splits[0] = splits; rt.slab_stride = stride;
     rt.off[0] = 0; rt.nW[0] = out_dim * in_dim; rt.nb[0] = out_dim; rt.dW[0] = dW; rt.db[0] = db;
     rt.total = out_dim * in_dim + out_dim;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(rt.total)), dim3(256), 0, st, scratch, rt);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, scratch, rt);
     ABN_CHECK_LAUNCH("linear_wgrad");
     return ABN_OK;
 }
