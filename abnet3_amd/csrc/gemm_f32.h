@@ -45,7 +45,8 @@ struct GemmP {
     const float* B; int64_t ldb;
     float* C; int64_t ldc;
     int M, N, K;
-    int k_chunk;            // split-K: blockIdx.y owns k in [y*k_chunk, +k_chunk)
+    int k_chunk;            // split-K: slice s owns k in [s*k_chunk, +k_chunk)
+    int splits;             // number of k slices (grid = tiles * splits blocks)
     const float* bias;      // FWD: [N] or nullptr
     int act;                // FWD: activation applied; DGRAD: act of `aux`
     const float* aux;       // DGRAD: activation OUTPUT a_prev[M][N] (ld = ldaux)
@@ -270,9 +271,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
 
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int tile = xcd_tile_index(blockIdx.x, tiles_m * tiles_n);
+    // Block -> (tile, k-slice).  Blocks b, b+8, ... share an XCD (its L2).  Without
+    // split-K every XCD gets a contiguous run of tiles (neighbours share A rows).
+    // With split-K an XCD owns whole k-SLICES instead, for all tiles: its L2 then
+    // fetches each operand row of its slices from HBM exactly once (measured
+    // FETCH_SIZE of the 500x500 wgrad: 113 MB tile-major vs 33 MB algorithmic).
+    const int ntiles = tiles_m * tiles_n;
+    int tile, slice;
+    if (p.splits > 1 && (p.splits & 7) == 0) {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, spx = p.splits >> 3;
+        slice = xcd * spx + q / ntiles;
+        tile = q % ntiles;
+    } else if (p.splits > 1) {
+        slice = blockIdx.x / ntiles;
+        tile = blockIdx.x % ntiles;
+    } else {
+        slice = 0;
+        tile = xcd_tile_index(blockIdx.x, ntiles);
+    }
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    const int kb = blockIdx.y * p.k_chunk;
+    const int kb = slice * p.k_chunk;
     const int ke = min(p.K, kb + p.k_chunk);
     const int nkt = (ke - kb + BK - 1) / BK;
 
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
     ABN_STAMP();
     constexpr int C4 = BN / 4;
     const int n_plain = (EPI == EPI_WGRAD && p.ones_col >= 0) ? p.ones_col : p.N;   // columns that live in C
-    const int64_t slab = (EPI == EPI_WGRAD) ? (int64_t)blockIdx.y * p.slab_stride : 0;
+    const int64_t slab = (EPI == EPI_WGRAD) ? (int64_t)slice * p.slab_stride : 0;
 #pragma unroll 2
     for (int u = threadIdx.x; u < BM * C4; u += 256) {
         const int row = u / C4, c4 = u % C4;

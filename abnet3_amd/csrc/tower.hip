@@ -39,7 +39,9 @@ static void launch_one(const GemmP& p, int splits, hipStream_t st)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(256), lds, st, p);
+    GemmP q = p;
+    q.splits = splits;
+    hipLaunchKernelGGL(k, dim3(tiles * splits), dim3(256), lds, st, q);
 }
 
 // 16-byte global loads need both operands aligned with leading dimensions that

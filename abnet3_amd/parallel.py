@@ -33,6 +33,8 @@ def init_from_env(backend=None):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
             torch.cuda.set_device(local)
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend=backend, rank=rank, world_size=ws)
     return rank, ws, local

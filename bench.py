@@ -84,9 +84,20 @@ def gemm_roofline(torch, reps=50):
     avg_s = e0.elapsed_time(e1) * 1e-3 / launches
     flop_per_launch = sum(2.0 * rows * k * n for k, n in shapes) / len(shapes)
     achieved = flop_per_launch / avg_s / 1e12
+    # HBM bytes per launch of this kernel from the TCC counters (FETCH_SIZE x2 per
+    # the gfx950 correction + WRITE_SIZE), collected by tools/collect_traffic.sh
+    # in separate --pmc passes and committed under profiles/
+    traffic = None
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+        for name, v in t.items():
+            if 'gemm_f32_kernel<128, 64, true, true, 0, true>' in name:
+                traffic = round(v['hbm_bytes_per_launch'])
+    except Exception:
+        pass
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            'traffic': None,
+            'traffic': traffic,
             'kernel': 'abn::gemm_f32_kernel<128, 64, true, true, 0, true>  (forward: A, B K-contiguous, 16-byte loads)',
             'avg_launch_us': round(avg_s * 1e6, 2),
             'flop_per_launch': flop_per_launch}
@@ -209,7 +220,10 @@ def main():
 
     import torch
     from abnet3_amd import parallel
-    rank, world, local = parallel.init_from_env('nccl')
+    # backend nccl = RCCL over xGMI; ABN_DIST_BACKEND=gloo lets the multi-process
+    # path be rehearsed on a box with fewer GPUs than ranks
+    rank, world, local = parallel.init_from_env(os.environ.get('ABN_DIST_BACKEND', 'nccl'))
+    local = local % max(1, torch.cuda.device_count())
     if world != args.gpus:
         if args.gpus > 1:
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run '
