@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libabnet3_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LAYERS = 16
 
 ACT = {'none': 0, None: 0, 'sigmoid': 1, 'relu': 2, 'tanh': 3}
@@ -60,7 +60,7 @@ class TowerDesc(C.Structure):
                 ('batch_norm', _i32), ('dims', _i64 * (MAX_LAYERS + 1))] + [
         (name, _vp * MAX_LAYERS)
         for name in ('W', 'b', 'bn_w', 'bn_b', 'bn_rm', 'bn_rv', 'dW', 'db',
-                     'dbn_w', 'dbn_b')]
+                     'dbn_w', 'dbn_b', 'drop_mask')]
 
 
 class HipLibraryError(RuntimeError):

@@ -51,6 +51,8 @@ struct GemmP {
     int act;                // FWD: activation applied; DGRAD: act of `aux`
     const float* aux;       // DGRAD: activation OUTPUT a_prev[M][N] (ld = ldaux)
     int64_t ldaux;
+    const float* mask;      // FWD: dropout multiplier [M][N] (ld = ldc) applied before `act`;
+                            // DGRAD: multiplier of the layer that produced `aux` (ld = ldaux)
     float* C2;              // WGRAD: destination of the ones column (bias grad)
     int64_t slab_stride;    // WGRAD: floats between split-K slabs of C / C2
     int ones_col;           // WGRAD: column of B that is identically 1, or -1
@@ -431,6 +433,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
                     v += bv;
                 }
+                if (p.mask) v *= *reinterpret_cast<const f32x4*>(p.mask + (int64_t)m * p.ldc + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
             } else if constexpr (EPI == EPI_DGRAD) {
@@ -439,6 +442,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] *= act_grad(av[e], p.act);
                 }
+                if (p.mask) v *= *reinterpret_cast<const f32x4*>(p.mask + (int64_t)m * p.ldaux + n);
             }
             *reinterpret_cast<f32x4*>(p.C + slab + (int64_t)m * p.ldc + n) = v;
         } else {
@@ -448,10 +452,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
                 if (ne >= p.N) break;
                 float x = v[e];
                 if constexpr (EPI == EPI_FWD) {
-                    x = act_apply(x + (p.bias ? p.bias[ne] : 0.0f), p.act);
-                    p.C[(int64_t)m * p.ldc + ne] = x;
+                    x += p.bias ? p.bias[ne] : 0.0f;
+                    if (p.mask) x *= p.mask[(int64_t)m * p.ldc + ne];
+                    p.C[(int64_t)m * p.ldc + ne] = act_apply(x, p.act);
                 } else if constexpr (EPI == EPI_DGRAD) {
                     if (p.aux) x *= act_grad(p.aux[(int64_t)m * p.ldaux + ne], p.act);
+                    if (p.mask) x *= p.mask[(int64_t)m * p.ldaux + ne];
                     p.C[(int64_t)m * p.ldc + ne] = x;
                 } else {
                     if (ne == p.ones_col) p.C2[slab + m] = x;

@@ -73,7 +73,8 @@ static int launch_gemm(GemmP p, int splits, hipStream_t st)
     {
         const bool slab_ok = (EPI != EPI_WGRAD) || (p.slab_stride % 4 == 0);
         p.c_vec = aligned16(p.C) && (p.ldc % 4 == 0) && slab_ok && (!p.bias || aligned16(p.bias)) &&
-                  (!p.aux || (aligned16(p.aux) && p.ldaux % 4 == 0));
+                  (!p.aux || (aligned16(p.aux) && p.ldaux % 4 == 0)) &&
+                  (!p.mask || (aligned16(p.mask) && (EPI == EPI_DGRAD ? p.ldaux : p.ldc) % 4 == 0));
     }
 #ifdef ABN_STAMPS
     p.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
@@ -101,11 +102,11 @@ static int launch_gemm(GemmP p, int splits, hipStream_t st)
 // small elementwise / column-reduction kernels
 // ---------------------------------------------------------------------------
 __global__ void act_bwd_kernel(const float* __restrict__ a, const float* __restrict__ da,
-                               float* __restrict__ dz, int64_t n, int act)
+                               const float* __restrict__ mask, float* __restrict__ dz, int64_t n, int act)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
-        dz[i] = da[i] * act_grad(a[i], act);
+        dz[i] = da[i] * act_grad(a[i], act) * (mask ? mask[i] : 1.0f);
 }
 
 struct ReduceTable {
@@ -268,8 +269,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ a, const float* da
                                     const float* __restrict__ xhat, int64_t rows, int64_t rows_per_call,
                                     int C, int act, const float* __restrict__ gamma,
                                     const float* __restrict__ invstd, const float* __restrict__ s1,
-                                    const float* __restrict__ s2, int n_calls, float* dz,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta)
+                                    const float* __restrict__ s2, int n_calls, const float* __restrict__ mask,
+                                    float* dz, float* __restrict__ dgamma, float* __restrict__ dbeta)
 {
     const int64_t n = rows * C;
     const float nf = (float)rows_per_call;
@@ -279,7 +280,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ a, const float* da
         const int64_t g = (i / C) / rows_per_call;
         const float dy = da[i] * act_grad(a[i], act);
         const float k = gamma[c] * invstd[g * C + c] / nf;
-        dz[i] = k * (nf * dy - s1[g * C + c] - xhat[i] * s2[g * C + c]);
+        dz[i] = k * (nf * dy - s1[g * C + c] - xhat[i] * s2[g * C + c]) * (mask ? mask[i] : 1.0f);
         if (i < C && dgamma) {
             float sg = 0.0f, sb = 0.0f;
             for (int q = 0; q < n_calls; ++q) { sg += s2[(int64_t)q * C + c]; sb += s1[(int64_t)q * C + c]; }
@@ -453,6 +454,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         p.B = t->W[l]; p.ldb = K;
         p.M = (int)rows; p.N = N; p.K = K; p.k_chunk = K;
         p.bias = t->b[l];
+        p.mask = train ? t->drop_mask[l] : nullptr;
         p.a_vec = aligned16(in) && (K % 4 == 0);
         p.b_vec = aligned16(t->W[l]) && (K % 4 == 0);
         p.ones_col = -1;
@@ -511,15 +513,15 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
         const float* a = ws + L.a[nl - 1];
         float* dz = scratch + B.dz[cur];
         if (!t->batch_norm) {
-            hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, a, d_out, dz, rows * N,
-                               t->last_act);
+            hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, a, d_out,
+                               t->drop_mask[nl - 1], dz, rows * N, t->last_act);
         } else {
             hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((N + 31) / 32, (int)n_calls), dim3(256), 0, st, a, d_out,
                                ws + L.xhat[nl - 1], rpc, N, t->last_act, scratch + B.bn_s1, scratch + B.bn_s2);
             hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, a, d_out,
                                ws + L.xhat[nl - 1], rows, rpc, N, t->last_act, t->bn_w[nl - 1],
-                               ws + L.invstd[nl - 1], scratch + B.bn_s1, scratch + B.bn_s2, (int)n_calls, dz,
-                               t->dbn_w[nl - 1], t->dbn_b[nl - 1]);
+                               ws + L.invstd[nl - 1], scratch + B.bn_s1, scratch + B.bn_s2, (int)n_calls,
+                               t->drop_mask[nl - 1], dz, t->dbn_w[nl - 1], t->dbn_b[nl - 1]);
         }
         ABN_CHECK_LAUNCH("output-layer dz");
     }
@@ -557,7 +559,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             p.a_vec = aligned16(dz) && (Nout % 4 == 0);
             p.b_vec = aligned16(t->W[l]) && (Kin % 4 == 0);
             p.ones_col = -1;
-            if (l > 0 && !t->batch_norm) { p.aux = ws + L.a[l - 1]; p.ldaux = Kin; p.act = t->act; }
+            if (l > 0 && !t->batch_norm) { p.aux = ws + L.a[l - 1]; p.ldaux = Kin; p.act = t->act; p.mask = t->drop_mask[l - 1]; }
             rc = launch_gemm<true, false, EPI_DGRAD>(p, 1, st);
             if (rc != ABN_OK) return rc;
             if (l > 0 && t->batch_norm) {
@@ -567,8 +569,8 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
                                    dst, ws + L.xhat[l - 1], rpc, Kin, t->act, scratch + B.bn_s1, scratch + B.bn_s2);
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * Kin)), dim3(256), 0, st, a, dst,
                                    ws + L.xhat[l - 1], rows, rpc, Kin, t->act, t->bn_w[l - 1], ws + L.invstd[l - 1],
-                                   scratch + B.bn_s1, scratch + B.bn_s2, (int)n_calls, dst, t->dbn_w[l - 1],
-                                   t->dbn_b[l - 1]);
+                                   scratch + B.bn_s1, scratch + B.bn_s2, (int)n_calls, t->drop_mask[l - 1], dst,
+                                   t->dbn_w[l - 1], t->dbn_b[l - 1]);
                 ABN_CHECK_LAUNCH("batch_norm backward");
             }
             cur ^= 1;

@@ -82,7 +82,8 @@ class _TowerFunction(torch.autograd.Function):
             raise ValueError('abnet3_amd: the two inputs must have the same shape')
         train = bool(net.training)
         rows = x1.shape[0] * (2 if x2 is not None else 1)
-        desc = net._descriptor(with_grads=False)
+        masks = net._draw_dropout_masks(rows, x1.device) if train else None
+        desc = net._descriptor(with_grads=False, masks=masks)
         ws_floats = lib.abn_tower_ws_floats(_lib.C.byref(desc), rows, n_calls)
         if ws_floats < 0:
             _lib.check(-1, 'abn_tower_ws_floats')
@@ -96,6 +97,7 @@ class _TowerFunction(torch.autograd.Function):
         off = lib.abn_tower_out_offset(_lib.C.byref(desc), rows, n_calls)
         out = ws[off:off + rows * net.output_dim].view(rows, net.output_dim)
         ctx.net, ctx.n_calls, ctx.train = net, n_calls, train
+        ctx.masks = masks
         ctx.have_x2 = x2 is not None
         ctx.split = split
         ctx.save_for_backward(x1, x2, ws)
@@ -135,7 +137,7 @@ class _TowerFunction(torch.autograd.Function):
         _lib.require_device(d_out)
         rows = d_out.shape[0]
         grads = net._new_grad_views()
-        desc = net._descriptor(with_grads=True, grad_views=grads)
+        desc = net._descriptor(with_grads=True, grad_views=grads, masks=ctx.masks)
         scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
         scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32,
                               device=d_out.device)
@@ -220,6 +222,7 @@ class SiameseNetwork(NetworkBuilder):
         self._flat = None
         self._last_grad_flat = None
         self._offsets = None
+        self._mask_override = None      # tests: fixed dropout masks
 
     def init_weight_method(self, layer):
         if isinstance(layer, nn.Linear):
@@ -316,7 +319,7 @@ class SiameseNetwork(NetworkBuilder):
         self._last_grad_flat = buf
         return buf
 
-    def _descriptor(self, with_grads, grad_views=None):
+    def _descriptor(self, with_grads, grad_views=None, masks=None):
         self.flat_parameters()
         d = _lib.TowerDesc()
         blocks = self._blocks()
@@ -333,6 +336,8 @@ class SiameseNetwork(NetworkBuilder):
             d.dims[l + 1] = lin.out_features
             d.W[l] = lin.weight.data_ptr()
             d.b[l] = lin.bias.data_ptr()
+            if masks is not None:
+                d.drop_mask[l] = masks[l].data_ptr()
             if with_grads:
                 d.dW[l] = grad_views[gi].data_ptr()
                 d.db[l] = grad_views[gi + 1].data_ptr()
@@ -348,12 +353,25 @@ class SiameseNetwork(NetworkBuilder):
                 gi += 2
         return d
 
+    def _draw_dropout_masks(self, rows, device):
+        """nn.Dropout(p) of every block in train mode (model.py:137,148,157): one
+        [rows, width] multiplier per layer, 0 with probability p else 1/(1-p),
+        drawn with torch's device generator (the reference's CPU stream cannot be
+        reproduced on a GPU; the arithmetic that consumes the mask is what the
+        parity tests pin).  None when p == 0."""
+        if self._mask_override is not None:
+            return self._mask_override
+        p = float(self.p_dropout)
+        if p <= 0.0:
+            return None
+        masks = []
+        for lin, _ in self._blocks():
+            keep = torch.rand(rows, lin.out_features, device=device) >= p
+            masks.append(keep.to(torch.float32).mul_(1.0 / (1.0 - p)) if p < 1.0
+                         else torch.zeros(rows, lin.out_features, device=device))
+        return masks
+
     def _run(self, x1, x2, n_calls, split):
-        if self.training and self.p_dropout > 0:
-            raise NotImplementedError(
-                'abnet3_amd: p_dropout > 0 in train mode is not on the accelerated '
-                'path yet (use p_dropout=0.0, the canonical configuration, '
-                'test/data/buckeye.yaml:50)')
         return _TowerFunction.apply(self, n_calls, split, x1, x2, *self.parameters())
 
     # -- reference surface ---------------------------------------------------

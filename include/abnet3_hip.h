@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 1
+#define ABN_ABI_VERSION 2
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -57,8 +57,8 @@ int abn_abi_version(void);
 const char* abn_last_error(void);          /* host string, thread-local */
 
 /* One SiameseNetwork tower (abnet3/model.py:110-170): n_layers Linear layers
- * dims[0] -> dims[1] -> ... -> dims[n_layers], each followed by Dropout(p=0 on
- * this path), optional BatchNorm1d, and an activation (`act`, or `last_act` for
+ * dims[0] -> dims[1] -> ... -> dims[n_layers], each followed by Dropout (caller-
+ * drawn masks, see drop_mask), optional BatchNorm1d, and an activation (`act`, or `last_act` for
  * the output layer, model.py:161-166).  W[l] is [dims[l+1], dims[l]] row-major
  * exactly as nn.Linear stores it; gradients are written to dW/db/dbn_* (same
  * shapes).  All pointers are device pointers held in this HOST struct. */
@@ -78,6 +78,11 @@ typedef struct abn_tower_desc {
     float* db[ABN_MAX_LAYERS];             /* when only forward is called     */
     float* dbn_w[ABN_MAX_LAYERS];
     float* dbn_b[ABN_MAX_LAYERS];
+    /* nn.Dropout(p) between Linear and BatchNorm/activation (model.py:137,148,157):
+     * per layer a [rows, dims[l+1]] multiplier (0 or 1/(1-p)) drawn by the caller;
+     * NULL = identity (p = 0 or eval mode).  The same masks must be passed to
+     * the backward call. */
+    const float* drop_mask[ABN_MAX_LAYERS];
 } abn_tower_desc;
 
 /* Workspace of one forward call (saved activations for backward), in floats,

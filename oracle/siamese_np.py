@@ -14,7 +14,8 @@ Reference lines restated (all relative to /root/reference):
   abnet3/trainer.py:68-87   optimizer choice (torch.optim defaults)
   abnet3/trainer.py:236-242 zero_grad / backward / step
 The backward pass restates what torch autograd executes for those modules.
-Dropout is restated for p=0 only (identity); p>0 cannot match torch's RNG.
+Dropout takes explicit masks (0 or 1/(1-p)); torch's CPU RNG stream is not
+restated, so p>0 is checked with masks shared between oracle and kernel.
 """
 import numpy as np
 
@@ -87,18 +88,20 @@ def act_bwd(a, da, kind):
     raise ValueError(kind)
 
 
-def tower_forward(params, x, spec, train, update_running=True):
+def tower_forward(params, x, spec, train, update_running=True, masks=None):
     """forward_once (model.py:179-186). Returns (embedding, cache).
 
     BN train mode: batch mean / biased variance over THIS call's rows; running
     stats updated with momentum 0.1 and the unbiased variance, exactly once per
     call (so twice per Siamese forward)."""
     a = np.ascontiguousarray(x, dtype=F32)
-    cache = {'a': [a], 'xhat': [], 'invstd': []}
+    cache = {'a': [a], 'xhat': [], 'invstd': [], 'masks': masks if train else None}
     for l in range(spec.n_layers):
         W = params[spec.lin_keys[l] + '.weight']
         b = params[spec.lin_keys[l] + '.bias']
         z = (a @ W.T + b).astype(F32)
+        if masks is not None and train:      # nn.Dropout between Linear and BN/act
+            z = (z * masks[l]).astype(F32)
         if spec.batch_norm:
             k = spec.bn_keys[l]
             g, beta = params[k + '.weight'], params[k + '.bias']
@@ -148,6 +151,8 @@ def tower_backward(params, cache, dout, spec, grads=None):
             dz = ((g * invstd / n) * (n * dz - dbeta - xhat * dgamma)).astype(F32)
             _acc(grads, k + '.weight', dgamma)
             _acc(grads, k + '.bias', dbeta)
+        if cache.get('masks') is not None:
+            dz = (dz * cache['masks'][l]).astype(F32)
         W = params[spec.lin_keys[l] + '.weight']
         _acc(grads, spec.lin_keys[l] + '.weight', (dz.T @ a_in).astype(F32))
         _acc(grads, spec.lin_keys[l] + '.bias',

@@ -77,11 +77,6 @@ def test_no_cpu_fallback_anywhere():
         cosmargin(margin=1.5)
     assert coscos2().avg is True and cosmargin().margin == 0.5
     assert cosmargin(avg=False).whoami()['class_name'] == 'cosmargin'
-    net.train()
-    dn = SiameseNetwork(input_dim=10, num_hidden_layers=0, hidden_dim=8, output_dim=4,
-                        activation_layer='tanh')        # reference default p_dropout=0.1
-    with pytest.raises(NotImplementedError):
-        dn(x, x)
 
 
 def test_embedder_and_trainer_surface_errors():
