@@ -12,6 +12,7 @@
 
 #include "common.h"
 #include "gemm_f32.h"
+#include "tower_fused.h"
 
 namespace abn {
 
@@ -434,6 +435,45 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
     hipStream_t st = (hipStream_t)stream;
     const Layout L = make_layout(t, rows, n_calls);
     const int64_t rpc = rows / n_calls;
+
+    // Whole tower in one launch when it fits the fused kernel's LDS image
+    // (tower_fused.h): no BatchNorm (its statistics span all rows), widths <= 512
+    // and multiples of 4, 16-byte aligned tensors.  ABN_FUSED=0 forces the
+    // per-layer path (A/B measurements).
+    static const bool fused_enabled = !(getenv("ABN_FUSED") && atoi(getenv("ABN_FUSED")) == 0);
+    bool fusable = fused_enabled && !t->batch_norm && aligned16(x1) && (!x2 || aligned16(x2)) && aligned16(ws);
+    for (int l = 0; l <= t->n_layers && fusable; ++l)
+        fusable = t->dims[l] >= 4 && t->dims[l] <= FUSED_MAXW && t->dims[l] % 4 == 0;
+    for (int l = 0; l < t->n_layers && fusable; ++l)
+        fusable = aligned16(t->W[l]) && (!t->drop_mask[l] || !train || aligned16(t->drop_mask[l]));
+    if (fusable) {
+        FusedFwdP f = {};
+        f.n_layers = t->n_layers;
+        f.rows = (int)rows;
+        f.rows_call = (int)rpc;
+        f.x1 = x1; f.x2 = x2;
+        f.x_copy = x2 ? ws + L.x : nullptr;
+        for (int l = 0; l <= t->n_layers; ++l) f.dims[l] = (int)t->dims[l];
+        for (int l = 0; l < t->n_layers; ++l) {
+            f.act[l] = (l == t->n_layers - 1) ? t->last_act : t->act;
+            f.W[l] = t->W[l]; f.b[l] = t->b[l];
+            f.mask[l] = train ? t->drop_mask[l] : nullptr;
+            f.out[l] = ws + L.a[l];
+        }
+#ifdef ABN_STAMPS
+        f.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
+#endif
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_fused_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(tower_fwd_fused_kernel, dim3((unsigned)((rows + FUSED_ROWS - 1) / FUSED_ROWS)), dim3(256),
+                           FUSED_LDS_BYTES, st, f);
+        ABN_CHECK_LAUNCH("tower_fwd_fused");
+        return ABN_OK;
+    }
 
     const float* in = x1;
     if (x2) {    // the two towers' inputs become one [2B, D] operand
