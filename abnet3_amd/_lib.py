@@ -49,6 +49,9 @@ SYMBOLS = {
     'abn_cosine_distance': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     'abn_gather_rows': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     'abn_stack_frames': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    'abn_mvn_ws_bytes': (_i64, [_i64, _i64]),
+    'abn_mvn_stats': (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp]),
+    'abn_mvn_apply': (C.c_int, [_vp, _i64, _i64, _vp, _vp, C.c_int, _f32, _vp, _vp]),
     'abn_fbank': (C.c_int, [_vp, C.c_int, _i64, _i32, C.c_double, _i32, _i32,
                              _f32, _vp, _vp, _i64, _vp, _vp]),
 }

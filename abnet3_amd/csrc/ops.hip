@@ -80,6 +80,79 @@ __global__ void stack_frames_kernel(const float* __restrict__ in, int64_t T, int
     }
 }
 
+// Mean / variance normalisation, abnet3/features.py:205-244 and :263-297:
+//   mean = np.mean(features, axis), std = np.std(features, axis)   (axis 0 = per
+//   channel, None = whole spectrum), out = (x - mean) / (std + eps).
+// Stage 1: fp64 partial sums of x and x^2 per (row chunk, column).
+__global__ __launch_bounds__(256) void mvn_partial_kernel(const float* __restrict__ x, int64_t T, int D, int64_t rows_per_chunk,
+                                                          double* __restrict__ part)   // [chunks][D][2]
+{
+    __shared__ double s1[8][33], s2[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < T ? r0 + rows_per_chunk : T;
+    double a = 0.0, b = 0.0;
+    if (c < D)
+        for (int64_t r = r0 + ty; r < r1; r += 8) {
+            const double v = x[r * D + c];
+            a += v;
+            b += v * v;
+        }
+    s1[ty][tx] = a;
+    s2[ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && c < D) {
+        for (int k = 1; k < 8; ++k) { a += s1[k][tx]; b += s2[k][tx]; }
+        part[((int64_t)blockIdx.y * D + c) * 2 + 0] = a;
+        part[((int64_t)blockIdx.y * D + c) * 2 + 1] = b;
+    }
+}
+
+// Stage 2 (one block): fixed-order reduction over chunks (and over columns for
+// the whole-spectrum mode); writes mean/std as fp32 [D] (per channel) or [1].
+__global__ __launch_bounds__(256) void mvn_finalize_kernel(const double* __restrict__ part, int chunks, int D, int64_t T,
+                                                           int per_channel, float* __restrict__ mean, float* __restrict__ stdv)
+{
+    __shared__ double cs1[256], cs2[256];
+    double t1 = 0.0, t2 = 0.0;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < chunks; ++k) { a += part[((int64_t)k * D + c) * 2]; b += part[((int64_t)k * D + c) * 2 + 1]; }
+        if (per_channel) {
+            const double m = a / (double)T;
+            double var = b / (double)T - m * m;
+            if (var < 0.0) var = 0.0;
+            mean[c] = (float)m;
+            stdv[c] = (float)sqrt(var);
+        }
+        t1 += a;
+        t2 += b;
+    }
+    if (per_channel) return;
+    cs1[threadIdx.x] = t1;
+    cs2[threadIdx.x] = t2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < 256; ++k) { a += cs1[k]; b += cs2[k]; }
+        const double n = (double)T * (double)D, m = a / n;
+        double var = b / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[0] = (float)m;
+        stdv[0] = (float)sqrt(var);
+    }
+}
+
+__global__ void mvn_apply_kernel(const float* __restrict__ x, int64_t n, int D, const float* __restrict__ mean,
+                                 const float* __restrict__ stdv, int per_channel, float eps, float* __restrict__ out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = per_channel ? (int)(i % D) : 0;
+        out[i] = (x[i] - mean[c]) / (stdv[c] + eps);
+    }
+}
+
 static inline int grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
 }  // namespace abn
@@ -127,6 +200,45 @@ int abn_stack_frames(const float* feats, int64_t T, int64_t D, int32_t nframes, 
     hipLaunchKernelGGL(stack_frames_kernel, dim3(grid_for(T * D * nframes)), dim3(256), 0, (hipStream_t)stream, feats, T,
                        (int)D, (int)nframes, out);
     ABN_CHECK_LAUNCH("stack_frames");
+    return ABN_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int64_t abn_mvn_ws_bytes(int64_t T, int64_t D)
+{
+    if (T < 0 || D < 1) return -1;
+    const int64_t chunks = T / 2048 < 1 ? 1 : (T / 2048 > 512 ? 512 : T / 2048);
+    return chunks * D * 2 * (int64_t)sizeof(double);
+}
+
+int abn_mvn_stats(const float* feats, int64_t T, int64_t D, int per_channel, float* mean, float* stdv, void* ws,
+                  void* stream)
+{
+    ABN_REQUIRE(feats && mean && stdv && ws, "mvn_stats: null pointer");
+    ABN_REQUIRE(T >= 1 && D >= 1 && D < (1 << 20), "mvn_stats: bad shape T=%lld D=%lld", (long long)T, (long long)D);
+    const int64_t chunks = T / 2048 < 1 ? 1 : (T / 2048 > 512 ? 512 : T / 2048);
+    const int64_t rpc = (T + chunks - 1) / chunks;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mvn_partial_kernel, dim3((unsigned)((D + 31) / 32), (unsigned)chunks), dim3(256), 0, st, feats, T,
+                       (int)D, rpc, (double*)ws);
+    hipLaunchKernelGGL(mvn_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, (int)chunks, (int)D, T,
+                       per_channel, mean, stdv);
+    ABN_CHECK_LAUNCH("mvn_stats");
+    return ABN_OK;
+}
+
+int abn_mvn_apply(const float* feats, int64_t T, int64_t D, const float* mean, const float* stdv, int per_channel,
+                  float eps, float* out, void* stream)
+{
+    ABN_REQUIRE(T >= 0 && D >= 1, "mvn_apply: bad shape");
+    if (T == 0) return ABN_OK;
+    ABN_REQUIRE(feats && mean && stdv && out, "mvn_apply: null pointer");
+    hipLaunchKernelGGL(mvn_apply_kernel, dim3(grid_for(T * D)), dim3(256), 0, (hipStream_t)stream, feats, T * D, (int)D,
+                       mean, stdv, per_channel, eps, out);
+    ABN_CHECK_LAUNCH("mvn_apply");
     return ABN_OK;
 }
 

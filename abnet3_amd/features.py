@@ -65,6 +65,12 @@ class FeaturesGenerator:
         self.n_filters = n_filters
         self.stack = stack
         self.nframes = nframes
+        self.normalization = normalization
+        self.norm_per_file = norm_per_file
+        self.norm_per_channel = norm_per_channel
+        self.vad_file = vad_file
+        self.load_mean_variance_path = load_mean_variance_path
+        self.save_mean_variance_path = save_mean_variance_path
         self.deltas = deltas
         self.deltasdeltas = deltasdeltas
         self.run = run
@@ -130,3 +136,77 @@ class FeaturesGenerator:
                                         _lib.stream()), 'abn_stack_frames')
         out = out.to(dtype)
         return out.cpu().numpy() if is_np else out
+
+    # -- mean / variance normalisation (abnet3/features.py:205-297, :322-363) --------
+    def _stats(self, feats_dev):
+        """(mean, std) of a [T, D] device tensor: per channel ([D]) or over the
+        whole spectrum ([1]), np.mean / np.std semantics."""
+        lib = _lib.load()
+        T, D = feats_dev.shape
+        k = D if self.norm_per_channel else 1
+        mean = torch.empty(k, dtype=torch.float32, device=feats_dev.device)
+        std = torch.empty(k, dtype=torch.float32, device=feats_dev.device)
+        ws = torch.empty(lib.abn_mvn_ws_bytes(T, D), dtype=torch.uint8, device=feats_dev.device)
+        _lib.check(lib.abn_mvn_stats(_lib.ptr(feats_dev), T, D, int(bool(self.norm_per_channel)),
+                                     _lib.ptr(mean), _lib.ptr(std), _lib.ptr(ws), _lib.stream()),
+                   'abn_mvn_stats')
+        return mean, std
+
+    def _apply(self, feats_dev, mean, std):
+        lib = _lib.load()
+        T, D = feats_dev.shape
+        out = torch.empty_like(feats_dev)
+        eps = float(np.finfo(np.float32).eps)
+        _lib.check(lib.abn_mvn_apply(_lib.ptr(feats_dev), T, D, _lib.ptr(mean), _lib.ptr(std),
+                                     int(mean.numel() > 1), eps, _lib.ptr(out), _lib.stream()),
+                   'abn_mvn_apply')
+        return out
+
+    @staticmethod
+    def _vad_rows(times, segments):
+        from .utils import Features_Accessor
+        idx = [Features_Accessor.get_indices_between(times, s, e) for s, e in segments]
+        return np.concatenate(idx) if idx else np.zeros(0, dtype=np.int64)
+
+    def normalize_features(self, features, times=None, vad=None, params=None):
+        """In-memory form of normalize() (features.py:345-363): `features` is
+        {utt: [T, D] float32}; `vad` {utt: [[start, end], ...]} restricts the
+        frames the statistics are computed on (needs `times`); `params`
+        {'mean', 'variance'} skips the statistics (load_mean_variance).
+        Returns ({utt: normalised array}, stats) where stats is (mean, std) for
+        the global mode or [(utt, mean, std), ...] per file."""
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+        if self.norm_per_file:
+            out, stats = {}, []
+            for f, x in features.items():
+                xd = dev(x)
+                sd = xd
+                if vad is not None and str(f) in vad:
+                    rows = self._vad_rows(times[f], vad[str(f)])
+                    sd = xd[torch.from_numpy(rows).cuda()]
+                mean, std = self._stats(sd)
+                out[f] = self._apply(xd, mean, std).cpu().numpy()
+                stats.append((f, mean.cpu().numpy(), std.cpu().numpy()))
+            return out, stats
+        names = list(features.keys())
+        if params is not None:
+            mean = dev(np.atleast_1d(params['mean']))
+            std = dev(np.atleast_1d(params['variance']))
+        else:
+            parts = []
+            for f in names:
+                x = features[f]
+                if vad is not None and str(f) in vad:
+                    x = x[self._vad_rows(times[f], vad[str(f)])]
+                parts.append(x)
+            mean, std = self._stats(dev(np.vstack(parts)))
+        out = {f: self._apply(dev(features[f]), mean, std).cpu().numpy() for f in names}
+        return out, (mean.cpu().numpy() if mean.numel() > 1 else float(mean.cpu()[0]),
+                     std.cpu().numpy() if std.numel() > 1 else float(std.cpu()[0]))
+
+    def save_mean_variance(self, mean, variance, output_file):
+        np.savetxt(output_file, np.vstack((mean, variance)))
+
+    def load_mean_variance(self, file_path):
+        mean_var = np.loadtxt(file_path)
+        return {'mean': mean_var[0], 'variance': mean_var[1]}

@@ -183,6 +183,17 @@ int abn_gather_rows(const float* table, const int64_t* idx, int64_t n, int64_t D
 int abn_stack_frames(const float* feats, int64_t T, int64_t D, int32_t nframes,
                      float* out, void* stream);
 
+/* FeaturesGenerator.mean_variance_normalisation / mean_var_norm_per_file,
+ * abnet3/features.py:205-244, :263-297: mean = np.mean, std = np.std over axis 0
+ * (per_channel: [D] outputs) or over everything (whole spectrum: [1] outputs),
+ * then out = (x - mean) / (std + eps).  ws: abn_mvn_ws_bytes(T, D) bytes. */
+int64_t abn_mvn_ws_bytes(int64_t T, int64_t D);
+int abn_mvn_stats(const float* feats, int64_t T, int64_t D, int per_channel,
+                  float* mean, float* stdv, void* ws, void* stream);
+int abn_mvn_apply(const float* feats, int64_t T, int64_t D, const float* mean,
+                  const float* stdv, int per_channel, float eps, float* out,
+                  void* stream);
+
 /* FeaturesGenerator.do_fbank, abnet3/features.py:99-114 (-> third-party
  * spectral.Spectral): int16 or fp32 mono samples -> [nframes, nfilt] log mel
  * energies.  melbank: [nfft/2+1, nfilt] fp32 weights (host side builds it,

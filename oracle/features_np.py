@@ -114,3 +114,19 @@ def fbank(sig, fs, nfilt=40, alpha=0.97, frate=100, wlen=0.025, nfft=1024,
         e = np.dot(power.astype(np.float64), filt)
         out[t] = np.log(np.clip(e, FLOOR, np.inf)).astype(np.float32)
     return out
+
+
+def mvn(features, per_channel, stats_on=None, params=None):
+    """abnet3/features.py:216-244 (and :283-293 per file): mean = np.mean,
+    std = np.std over axis 0 (per channel) or None (whole spectrum) of
+    `stats_on` (default: the features themselves, e.g. the VAD-filtered frames),
+    out = (features - mean) / (std + finfo.eps).  Pinned by the reference's own
+    use of numpy for this arithmetic (test/test_features.py:37-281)."""
+    axis = 0 if per_channel else None
+    ref = features if stats_on is None else stats_on
+    if params is not None:
+        mean, std = params['mean'], params['variance']
+    else:
+        mean, std = np.mean(ref, axis=axis), np.std(ref, axis=axis)
+    eps = np.finfo(features.dtype).eps
+    return (features - mean) / (std + eps), mean, std

@@ -206,3 +206,45 @@ def test_embedder_matches_eval_forward():
     assert out[2].shape == (0, 50)
     with pytest.raises(ValueError):
         EmbedderSiamese(network=None)
+
+
+@pytest.mark.parametrize('per_channel', [True, False])
+@pytest.mark.parametrize('per_file', [True, False])
+def test_mean_variance_normalisation(per_channel, per_file):
+    """features.py:205-297: global / per-file, per-channel / whole-spectrum,
+    with and without VAD, against the numpy expressions the reference uses."""
+    from abnet3_amd.features import FeaturesGenerator
+    from oracle import features_np as F
+    rng = np.random.default_rng(9)
+    feats = {'a': (rng.standard_normal((700, 40)) * 3 + 12).astype(np.float32),
+             'b': (rng.standard_normal((5000, 40)) * 2 + 9).astype(np.float32),
+             'c': np.full((30, 40), 4.0, dtype=np.float32)}          # constant: std = 0 -> eps matters
+    times = {k: np.arange(len(v)) * 0.01 + 0.0025 for k, v in feats.items()}
+    vad = {'a': [[0.5, 2.0], [3.0, 4.5]], 'b': [[10.0, 30.0]]}
+    fg = FeaturesGenerator(norm_per_file=per_file, norm_per_channel=per_channel)
+    for use_vad in (False, True):
+        out, stats = fg.normalize_features(feats, times, vad if use_vad else None)
+        if per_file:
+            for f, x in feats.items():
+                sel = x
+                if use_vad and f in vad:
+                    sel = x[FeaturesGenerator._vad_rows(times[f], vad[f])]
+                ref, m, s = F.mvn(x, per_channel, stats_on=sel)
+                # constant file: ref is 0/eps-scaled noise; compare with an absolute bound there
+                tol = 2e-5 * max(1.0, np.abs(ref).max())
+                assert np.abs(out[f] - ref).max() <= tol, (f, use_vad)
+        else:
+            parts = [x[FeaturesGenerator._vad_rows(times[f], vad[f])] if (use_vad and f in vad) else x
+                     for f, x in feats.items()]
+            allf = np.vstack(parts)
+            for f, x in feats.items():
+                ref, m, s = F.mvn(x, per_channel, stats_on=allf)
+                assert np.abs(out[f] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (f, use_vad)
+            assert np.allclose(stats[0], np.mean(allf, axis=0 if per_channel else None), rtol=1e-5)
+            assert np.allclose(stats[1], np.std(allf, axis=0 if per_channel else None), rtol=1e-5)
+    if not per_file:       # load_mean_variance path
+        params = {'mean': np.full(40, 10.0) if per_channel else 10.0,
+                  'variance': np.full(40, 2.0) if per_channel else 2.0}
+        out, _ = fg.normalize_features(feats, params={k: np.asarray(v, dtype=np.float32) for k, v in params.items()})
+        ref = (feats['a'] - 10.0) / (2.0 + np.finfo(np.float32).eps)
+        assert np.abs(out['a'] - ref).max() < 1e-5
