@@ -1,6 +1,8 @@
 """Parity of the HIP DTW / distance / gather / stacking / filterbank kernels
 (through the C-ABI) with the C / numpy oracle and the golden vectors.
 DTW path indices must be BIT-EXACT.  Needs an MI355X: run with -m gpu."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -248,3 +250,21 @@ def test_mean_variance_normalisation(per_channel, per_file):
         out, _ = fg.normalize_features(feats, params={k: np.asarray(v, dtype=np.float32) for k, v in params.items()})
         ref = (feats['a'] - 10.0) / (2.0 + np.finfo(np.float32).eps)
         assert np.abs(out['a'] - ref).max() < 1e-5
+
+
+def test_end_to_end_pipeline_trains(tmp_path, monkeypatch):
+    """BASELINE.json configs[4] in miniature: fbank -> normalise -> stack -> DTW
+    pair mining -> Siamese training -> embedding; the loss must go down."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('e2e', os.path.join(root, 'examples', 'end_to_end.py'))
+    e2e = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(e2e)
+    monkeypatch.setattr(sys, 'argv', ['end_to_end.py', '--utts', '12', '--words', '6', '--pairs', '120',
+                                      '--epochs', '4', '--hidden', '128', '--batch', '1024',
+                                      '--out', str(tmp_path / 'e2e')])
+    trainer, emb = e2e.main()
+    assert len(trainer.train_losses) == 5 and np.isfinite(trainer.train_losses).all()
+    assert trainer.train_losses[-1] < trainer.train_losses[0]
+    assert emb[0].shape[1] == 100 and np.isfinite(emb[0]).all()
