@@ -17,7 +17,8 @@
  *   diagonal, up (i-1), left (j-1) wins a tie; path returned start -> end.
  * cosine_distance IS pinned (tests/golden/cosdist.npz, from the reference) to
  * a tolerance; its float32 arithmetic is fixed here operation by operation
- * (sequential fmaf dot products, own acosf) so that CPU and GPU agree bitwise.
+ * (sequential fmaf dot products, reciprocal norms, a division-free acos) so
+ * that CPU and GPU agree bitwise.
  *
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off)
  */
@@ -26,48 +27,27 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* acos in pure float32 arithmetic: the published fdlibm e_acosf.c rational
- * approximation, written so every operation is a single IEEE-754 binary32
- * add/mul/div/sqrt in a fixed order (no fused contraction).  */
-static float oracle_acos_r(float z)
-{
-    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f,
-                pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
-    float p = z * (pS0 + z * (pS1 + z * pS2));
-    float q = 1.0f + z * qS1;
-    return p / q;
-}
-
+/* acos in pure float32 arithmetic, division-free: Abramowitz & Stegun 4.4.46,
+ *   acos(x) = sqrt(1 - x) * (a0 + a1 x + ... + a7 x^7),  0 <= x <= 1, |err| <= 2e-8,
+ * and acos(-x) = pi - acos(x).  Every operation is one IEEE-754 binary32 fma /
+ * add / mul / sqrt in a fixed order (Horner with fmaf), so the GPU kernel
+ * reproduces it bit for bit.  (An earlier revision used fdlibm's rational form;
+ * its three divisions per cell dominated the GPU distance kernel.) */
 float abn_oracle_acosf(float x)
 {
-    const float pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
-    float ax = fabsf(x);
-    if (!(ax < 1.0f)) {              /* |x| >= 1 or NaN */
-        if (x == 1.0f) return 0.0f;
-        if (x == -1.0f) return 2.0f * pio2_hi + 0x1p-120f;
-        return NAN;                  /* utils.py:59 then trips its assert */
-    }
-    if (ax < 0.5f) {
-        if (ax <= 0x1p-26f) return pio2_hi + 0x1p-120f;
-        return pio2_hi - (x - (pio2_lo - x * oracle_acos_r(x * x)));
-    }
-    if (x < 0.0f) {
-        float z = (1.0f + x) * 0.5f;
-        float s = sqrtf(z);
-        float w = oracle_acos_r(z) * s - pio2_lo;
-        return 2.0f * (pio2_hi - (s + w));
-    } else {
-        float z = (1.0f - x) * 0.5f;
-        float s = sqrtf(z);
-        uint32_t bits;
-        memcpy(&bits, &s, 4);
-        bits &= 0xfffff000u;
-        float df;
-        memcpy(&df, &bits, 4);
-        float c = (z - df * df) / (s + df);
-        float w = oracle_acos_r(z) * s + c;
-        return 2.0f * (df + w);
-    }
+    const float pi_f = 3.14159274101257324f;
+    const float ax = fabsf(x);
+    if (!(ax <= 1.0f)) return NAN;       /* |x| > 1 or NaN: utils.py:59 then trips its assert */
+    float p = -0.0012624911f;
+    p = fmaf(p, ax, 0.0066700901f);
+    p = fmaf(p, ax, -0.0170881256f);
+    p = fmaf(p, ax, 0.0308918810f);
+    p = fmaf(p, ax, -0.0501743046f);
+    p = fmaf(p, ax, 0.0889789874f);
+    p = fmaf(p, ax, -0.2145988016f);
+    p = fmaf(p, ax, 1.5707963050f);
+    const float r = sqrtf(1.0f - ax) * p;
+    return x < 0.0f ? pi_f - r : r;
 }
 
 static float row_norm(const float* v, int64_t D)
@@ -78,13 +58,16 @@ static float row_norm(const float* v, int64_t D)
 }
 
 /* utils.py:40-60 for float32 inputs. d is N x M row-major float64.
+ *   cos = (dot * (1/|x|)) * (1/|y|)   (reciprocal norms once per row; the
+ *                                      reference divides by the outer product),
+ *   d   = acos(cos) * float32(1/pi)   (the reference divides by pi).
  * Returns 0, or 1 if any entry is NaN / negative (the reference's
  * `assert np.all(d >= 0)` then raises and the caller drops the pair,
  * dataloader.py:188-191). */
 int abn_oracle_cosine_distance_f32(const float* x, int64_t N, const float* y,
                                    int64_t M, int64_t D, double* d)
 {
-    const float pi_f = 3.14159274101257324f;     /* float32(np.pi) */
+    const float inv_pi_f = 0.318309873342514038f;     /* float32(1/pi) */
     float* nx = (float*)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1));
     float* ny = (float*)malloc(sizeof(float) * (size_t)(M > 0 ? M : 1));
     int bad = 0;
@@ -99,8 +82,8 @@ int abn_oracle_cosine_distance_f32(const float* x, int64_t N, const float* y,
                 float dot = 0.0f;
                 for (int64_t k = 0; k < D; ++k)
                     dot = fmaf(x[i * D + k], y[j * D + k], dot);
-                float c = dot / (nx[i] * ny[j]);
-                v = abn_oracle_acosf(c) / pi_f;
+                const float c = (dot * (1.0f / nx[i])) * (1.0f / ny[j]);
+                v = abn_oracle_acosf(c) * inv_pi_f;
             }
             if (!(v >= 0.0f)) bad = 1;
             d[i * M + j] = (double)v;

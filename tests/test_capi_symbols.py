@@ -78,7 +78,9 @@ def test_dtw_workspace_planning(lib):
     n2 = np.array([280, 600, 5], dtype=np.int32)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     ws = lib.abn_dtw_ws_bytes(p(n1), p(n2), 3, 1000, 1000)
-    cells = (300 + 280) * 300 + (50 + 600) * 50
-    assert ws >= cells * 5                     # f32 skewed distances + u8 back-pointers
-    assert lib.abn_dtw_host_stage_bytes(p(n1), p(n2), 3) >= 3 * 40
+    # per pair: ceil((n1+n2-1)/4) diagonal groups x 64 lanes x rows-per-lane; a float4 of
+    # distances and one byte of packed back-pointers per row and group
+    rows = 145 * 64 * 5 + 163 * 64 * 1
+    assert rows * 17 <= ws <= rows * 17 + 16 * 256 + 2 * 4000
+    assert lib.abn_dtw_host_stage_bytes(p(n1), p(n2), 3) >= 3 * 56 + 3 * 4
     assert lib.abn_dtw_ws_bytes(None, None, 3, 0, 0) == -1
