@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libabnet3_hip.so')
+# ABNET3_HIP_LIB points at another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get('ABNET3_HIP_LIB') or os.path.join(HERE, 'lib', 'libabnet3_hip.so')
 ABI_VERSION = 2
 MAX_LAYERS = 16
 

@@ -7,13 +7,14 @@
 // abnet3/dataloader.py:166-261 and :617-671.
 //
 // Three kernels per batch:
-//  1. dist_kernel   64x64 tiles of the angular distance matrix, x / y rows
-//                   staged through LDS in 32-wide k chunks, 4x4 cells per
-//                   thread.  Every cell's dot product is ONE sequential fmaf
-//                   chain over k (and acos is an explicit float32 routine), so
-//                   the values are bit-identical to the C oracle; the file is
-//                   compiled with -ffp-contract=off.  The matrix is written in
-//                   the layout the DP reads with 16-byte coalesced loads:
+//  1. dist_kernel   64x64 tiles of the angular distance matrix, one 32x32 quadrant
+//                   per wavefront on the float32 matrix cores: the MFMA
+//                   accumulates every cell as one sequential fused chain over k,
+//                   exactly the oracle's fmaf loop, and acos is an explicit
+//                   float32 routine, so the values are bit-identical to the C
+//                   oracle (the file is compiled with -ffp-contract=off).  The
+//                   matrix is written in the layout the DP reads with 16-byte
+//                   coalesced loads:
 //                     S4[g][phys(i)][e] = dist(i, 4g + e - i)
 //                   i.e. one float4 holds row i's cells on the four
 //                   anti-diagonals of group g, and phys(i) = (i % SL)*64 + i/SL
@@ -36,16 +37,33 @@
 // parallelism comes from running thousands of pairs side by side, longest first.
 #include "common.h"
 #include <algorithm>
+#include <mutex>
+#include <vector>
+#include <type_traits>
 
 namespace abn {
 
+// Correctly rounded float32 sqrt for x in {0} U [2^-24, 1] -- every value 1 - |c| can
+// take: v_rsq_f32 plus one Markstein step.  tools/sqrt_exact_probe.hip checks it
+// against (float)sqrt((double)x) for ALL 201 326 593 floats of that range on gfx950
+// (0 mismatches), so it equals the oracle's sqrtf bit for bit at a third of the
+// instructions of the general routine (no denormal scaling, no one-ulp fix-up).
+__device__ __forceinline__ float sqrt_unit(float x)
+{
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float s = x * r, h = 0.5f * r;
+    const float e = fmaf(-s, s, x);
+    const float q = fmaf(e, h, s);
+    return x > 0.0f ? q : 0.0f;                       // also turns the NaN of a negative argument into 0
+}
+
 // ---- float32 acos, operation for operation the oracle's (oracle/dtw.c):
-// division-free Abramowitz & Stegun 4.4.46, Horner with explicit fmaf ---------
+// division-free Abramowitz & Stegun 4.4.46, Horner with explicit fmaf.  Written
+// without branches (every lane runs the same straight line; selects at the end).
 __device__ __forceinline__ float acos_f32(float x)
 {
     const float pi_f = 3.14159274101257324f;
     const float ax = fabsf(x);
-    if (!(ax <= 1.0f)) return __builtin_nanf("");
     float p = -0.0012624911f;
     p = fmaf(p, ax, 0.0066700901f);
     p = fmaf(p, ax, -0.0170881256f);
@@ -54,18 +72,24 @@ __device__ __forceinline__ float acos_f32(float x)
     p = fmaf(p, ax, 0.0889789874f);
     p = fmaf(p, ax, -0.2145988016f);
     p = fmaf(p, ax, 1.5707963050f);
-    const float r = sqrtf(1.0f - ax) * p;
-    return x < 0.0f ? pi_f - r : r;
+    const float r = sqrt_unit(1.0f - ax) * p;
+    const float v = x < 0.0f ? pi_f - r : r;
+    return ax <= 1.0f ? v : __builtin_nanf("");     // |x| > 1 (rounding) or NaN -> NaN, the pair is dropped
 }
 
-// inx / iny are 1/|x|, 1/|y| (+inf for a zero row)
+// inx / iny are 1/|x|, 1/|y| (+inf for a zero row).  ZERO_ROWS = false is the
+// fast path for tiles that hold no zero row.
+template <bool ZERO_ROWS = true>
 __device__ __forceinline__ float angular_distance(float dot, float inx, float iny)
 {
     const float inv_pi_f = 0.318309873342514038f;
-    const bool zx = __builtin_isinf(inx), zy = __builtin_isinf(iny);
-    if (zx && zy) return 0.0f;                        // utils.py:57-58
-    if (zx || zy) return 1.0f;                        // utils.py:55-56
-    return acos_f32((dot * inx) * iny) * inv_pi_f;
+    float v = acos_f32((dot * inx) * iny) * inv_pi_f;
+    if (ZERO_ROWS) {
+        const bool zx = __builtin_isinf(inx), zy = __builtin_isinf(iny);
+        v = (zx || zy) ? 1.0f : v;                    // utils.py:55-56
+        v = (zx && zy) ? 0.0f : v;                    // utils.py:57-58
+    }
+    return v;
 }
 
 struct PairMeta {
@@ -80,117 +104,142 @@ struct PairMeta {
 };
 
 constexpr int TS = 64;       // distance tile
-constexpr int KC = 32;       // k chunk staged in LDS
 
-// reciprocal row norms 1/sqrt(sum x^2): sequential fmaf chain over k (the
-// oracle's order), one thread per row; 16-byte loads when D % 4 == 0
-__global__ void norm_kernel(const float* __restrict__ f, int64_t rows, int D, int vec, float* __restrict__ out)
+// tile id -> pair id table, filled on the device from the per-pair tile ranges
+__global__ void expand_tiles_kernel(const PairMeta* __restrict__ meta, int npairs, int32_t* __restrict__ tile_pair)
 {
-    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const float* v = f + r * D;
-    float s = 0.0f;
-    if (vec) {
-        for (int k = 0; k < D; k += 4) {
-            const float4 q = *reinterpret_cast<const float4*>(v + k);
-            s = fmaf(q.x, q.x, s); s = fmaf(q.y, q.y, s); s = fmaf(q.z, q.z, s); s = fmaf(q.w, q.w, s);
-        }
-    } else {
-        for (int k = 0; k < D; ++k) s = fmaf(v[k], v[k], s);
-    }
-    out[r] = 1.0f / sqrtf(s);
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    const PairMeta m = meta[p];
+    const int tm = (m.n1 + TS - 1) / TS, tn = (m.n2 + TS - 1) / TS;
+    for (int t = 0; t < tm * tn; ++t) tile_pair[m.tile0 + t] = p;
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int TSP = TS + 4;  // padded tile row: float4 rows of the MFMA layout land on distinct LDS banks
+constexpr int KC = 40;       // k chunk staged in LDS (the 40-d filterbank frame in one piece)
+constexpr int KCP = KC + 4;  // padded: 16-byte row reads of 8 consecutive rows hit 32 distinct banks
+
+// One 64x64 tile of a pair's distance matrix per workgroup, one 32x32 quadrant
+// per wavefront.  The dot products run on the matrix cores: a float32 MFMA
+// (v_mfma_f32_32x32x2_f32, k = 2s + lane/32) accumulates each cell as ONE
+// sequential fused chain over k, bit-identical to the oracle's fmaf loop
+// (tools/mfma_exact_probe.hip: 0 mismatches in 204 800 cells), which leaves the
+// vector ALU to the acos epilogue -- the part that bounds this kernel.
+// Rows are staged through LDS with coalesced 16-byte loads (a token's rows are
+// contiguous), and the tile's row norms are recomputed from the staged rows (40
+// fmas per row: cheaper than a separate pass over the corpus).  A = rows of y (j), B = rows of x (i): a lane then holds one i and runs of four
+// consecutive j, which go to LDS as float4s and leave in DP order.
 __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ feats1, const float* __restrict__ feats2,
-                                                   const float* __restrict__ norm1, const float* __restrict__ norm2,
                                                    const PairMeta* __restrict__ meta, const int32_t* __restrict__ tile_pair,
-                                                   int D, float* __restrict__ ws, int32_t* __restrict__ bad)
+                                                   int D, int vec, float* __restrict__ ws, int32_t* __restrict__ bad)
 {
-    __shared__ __attribute__((aligned(16))) float xs[TS][KC + 4], ys[TS][KC + 4];   // rows 16-byte aligned
-    __shared__ float tile[TS * TS];
+    // x / y row chunks [64][KC] for the MFMA loop; the finished tile reuses the space
+    __shared__ __attribute__((aligned(16))) float smem[2 * TS * KCP];
+    __shared__ float inx_s[TS], iny_s[TS];
+    static_assert(2 * TS * KCP >= TS * TSP, "the distance tile must fit in the staging buffers");
+    float (*xs)[KCP] = reinterpret_cast<float (*)[KCP]>(smem);
+    float (*ys)[KCP] = reinterpret_cast<float (*)[KCP]>(smem + TS * KCP);
+    float* tile = smem;
     const int p = tile_pair[blockIdx.x];
     const PairMeta m = meta[p];
     const int t = blockIdx.x - m.tile0;
     const int i0 = (t / m.tiles_n) * TS, j0 = (t % m.tiles_n) * TS;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 16 threads, 4x4 cells each
-    float acc[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int ib = 32 * (wave >> 1), jb = 32 * (wave & 1);        // this wave's quadrant
+    // rows past the token end are clamped: their cells are computed and discarded
+    const float* xbase = feats1 + m.off1 * D;
+    const float* ybase = feats2 + m.off2 * D;
+    f32x16 acc;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
-
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+    float nsum = 0.0f;                            // waves 0 / 1: sum of squares of x / y row `lane`
     for (int k0 = 0; k0 < D; k0 += KC) {
         const int kn = min(KC, D - k0);
-        for (int u = threadIdx.x; u < TS * KC; u += 256) {
-            const int r = u / KC, k = u % KC;
-            float xv = 0.0f, yv = 0.0f;
-            if (k < kn) {
-                if (i0 + r < m.n1) xv = feats1[(m.off1 + i0 + r) * D + k0 + k];
-                if (j0 + r < m.n2) yv = feats2[(m.off2 + j0 + r) * D + k0 + k];
+        if (vec) {                                // 16-byte loads; a token's rows are contiguous in memory
+            for (int u = threadIdx.x; u < 2 * TS * (KC / 4); u += 256) {
+                const int which = u >= TS * (KC / 4), v = u - which * TS * (KC / 4);
+                const int row = v / (KC / 4), c4 = (v % (KC / 4)) * 4;
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c4 < kn) {
+                    const float* src = which ? ybase + (int64_t)min(j0 + row, m.n2 - 1) * D : xbase + (int64_t)min(i0 + row, m.n1 - 1) * D;
+                    q = *reinterpret_cast<const float4*>(src + k0 + c4);
+                }
+                *reinterpret_cast<float4*>(which ? &ys[row][c4] : &xs[row][c4]) = q;
             }
-            xs[r][k] = xv;
-            ys[r][k] = yv;
+        } else {
+            for (int u = threadIdx.x; u < 2 * TS * KC; u += 256) {
+                const int which = u >= TS * KC, v = u - which * TS * KC;
+                const int row = v / KC, c = v % KC;
+                float q = 0.0f;
+                if (c < kn) q = which ? ybase[(int64_t)min(j0 + row, m.n2 - 1) * D + k0 + c] : xbase[(int64_t)min(i0 + row, m.n1 - 1) * D + k0 + c];
+                (which ? ys : xs)[row][c] = q;
+            }
         }
         __syncthreads();
         // the chunk is zero-filled past kn, and fma(0, 0, acc) == acc exactly, so
         // whole float4 groups can be consumed; k still ascends one at a time
+        if (wave < 2) {                           // the tile's 64 + 64 row norms, same sequential chain as the oracle
+            const float* row = wave == 0 ? xs[lane] : ys[lane];
+            for (int k = 0; k < kn; k += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(row + k);
+                nsum = fmaf(q.x, q.x, nsum); nsum = fmaf(q.y, q.y, nsum); nsum = fmaf(q.z, q.z, nsum); nsum = fmaf(q.w, q.w, nsum);
+            }
+        }
         for (int k = 0; k < kn; k += 4) {
-            float4 xa[4], yb[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) xa[a] = *reinterpret_cast<const float4*>(&xs[ty + 16 * a][k]);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) yb[b] = *reinterpret_cast<const float4*>(&ys[tx + 16 * b][k]);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    float c = acc[a][b];
-                    c = fmaf(xa[a].x, yb[b].x, c);
-                    c = fmaf(xa[a].y, yb[b].y, c);
-                    c = fmaf(xa[a].z, yb[b].z, c);
-                    c = fmaf(xa[a].w, yb[b].w, c);
-                    acc[a][b] = c;
-                }
+            const float4 yq = *reinterpret_cast<const float4*>(&ys[jb + r][k]);
+            const float4 xq = *reinterpret_cast<const float4*>(&xs[ib + r][k]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? yq.y : yq.x, h ? xq.y : xq.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? yq.w : yq.z, h ? xq.w : xq.z, acc, 0, 0, 0);
         }
         __syncthreads();
     }
+    if (wave < 2) (wave == 0 ? inx_s : iny_s)[lane] = 1.0f / sqrtf(nsum);
+    __syncthreads();                              // reciprocal norms are staged
+    const int i = i0 + ib + r;
+    const float inx = inx_s[ib + r];
+    // zero rows (reciprocal norm = inf) are rare: tiles without one skip their handling
+    const bool zero_rows = __any(__builtin_isinf(inx_s[lane]) || __builtin_isinf(iny_s[lane]));
     bool any_bad = false;
+    auto epilogue = [&](auto zr) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int i = i0 + ty + 16 * a;
-        const float nx = i < m.n1 ? norm1[m.off1 + i] : 1.0f;          // reciprocal norms
+        for (int qg = 0; qg < 4; ++qg) {
+            const int jl = jb + 8 * qg + 4 * h;   // MFMA rows 8*qg + 4*h + (0..3)
+            float v[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int j = j0 + tx + 16 * b;
-            float v = 0.0f;
-            if (i < m.n1 && j < m.n2) {
-                v = angular_distance(acc[a][b], nx, norm2[m.off2 + j]);
-                if (!(v >= 0.0f)) any_bad = true;      // utils.py:59 assert
+            for (int e = 0; e < 4; ++e) {
+                const float d = angular_distance<decltype(zr)::value>(acc[4 * qg + e], inx, iny_s[jl + e]);
+                const bool valid = i < m.n1 && j0 + jl + e < m.n2;
+                any_bad |= valid && !(d >= 0.0f);     // utils.py:59 assert
+                v[e] = valid ? d : 0.0f;
             }
-            tile[(ty + 16 * a) * TS + tx + 16 * b] = v;
+            *reinterpret_cast<float4*>(&tile[(ib + r) * TSP + jl]) = make_float4(v[0], v[1], v[2], v[3]);
         }
-    }
+    };
+    if (zero_rows) epilogue(std::true_type{}); else epilogue(std::false_type{});
     if (any_bad) atomicOr(&bad[p], 1);
     __syncthreads();
     // write-out in DP order: one float4 = row i on the four diagonals of group g
     // (cells j = 4g - i .. 4g - i + 3); a wave takes one group, lanes take rows
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int SL = m.slots;
-    const int i = i0 + lane;
-    const int iend = min(i0 + TS, m.n1) - 1, jend = min(j0 + TS, m.n2) - 1;
-    const int64_t gstride = (int64_t)64 * SL;                     // float4s per group
-    float4* S4 = reinterpret_cast<float4*>(ws + m.ws_off) + (i % SL) * 64 + i / SL;
-    for (int g = ((i0 + j0) >> 2) + wave; g <= ((iend + jend) >> 2); g += 4) {
-        const int jl = 4 * g - i - j0;                            // tile column of element 0
-        if (i > iend || jl + 3 < 0 || jl > jend - j0) continue;
-        float* dst = reinterpret_cast<float*>(S4 + g * gstride);
-        const float* src = &tile[lane * TS + jl];
-        if (jl >= 0 && jl + 3 <= jend - j0) {
-            *reinterpret_cast<float4*>(dst) = make_float4(src[0], src[1], src[2], src[3]);
-        } else {
+    {
+        const int SL = m.slots;
+        const int i = i0 + lane;
+        const int iend = min(i0 + TS, m.n1) - 1, jend = min(j0 + TS, m.n2) - 1;
+        const int64_t gstride = (int64_t)64 * SL;                 // float4s per group
+        float4* S4 = reinterpret_cast<float4*>(ws + m.ws_off) + (i % SL) * 64 + i / SL;
+        for (int g = ((i0 + j0) >> 2) + wave; g <= ((iend + jend) >> 2); g += 4) {
+            const int jl = 4 * g - i - j0;                        // tile column of element 0
+            if (i > iend || jl + 3 < 0 || jl > jend - j0) continue;
+            float* dst = reinterpret_cast<float*>(S4 + g * gstride);
+            const float* src = &tile[lane * TSP + jl];
+            if (jl >= 0 && jl + 3 <= jend - j0) {
+                *reinterpret_cast<float4*>(dst) = make_float4(src[0], src[1], src[2], src[3]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (jl + e >= 0 && jl + e <= jend - j0) dst[e] = src[e];
+                for (int e = 0; e < 4; ++e)
+                    if (jl + e >= 0 && jl + e <= jend - j0) dst[e] = src[e];
+            }
         }
     }
 }
@@ -199,6 +248,7 @@ constexpr int DP_MAXN = 1024;        // longest first token a wavefront can swee
 constexpr int DP_CLASSES[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};      // rows per lane the DP is instantiated for
 constexpr int DP_NCLASSES = sizeof(DP_CLASSES) / sizeof(int);
 constexpr int WIN = 16;              // traceback window: 16 groups (64 diagonals) x 64 rows
+constexpr int DP_WAVES = 4;          // pairs (wavefronts) per DP workgroup
 
 // back-pointer codes
 enum { DIR_DIAG = 0, DIR_UP = 1, DIR_LEFT = 2 };
@@ -211,20 +261,33 @@ static inline int dp_class_of(int n1)
     return DP_NCLASSES - 1;
 }
 
+// LDS hand-off inside ONE wavefront: its LDS operations complete in order, so draining
+// them (and keeping the compiler from moving accesses across) is all that is needed
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // lane l receives lane l-1's value (lane 0: lane 63's)
 __device__ __forceinline__ double rotate_up(double v, int src_lane) { return __shfl(v, src_lane, 64); }
 
 template <int SL>
-__global__ __launch_bounds__(64) void dp_kernel(const PairMeta* __restrict__ meta, const int32_t* __restrict__ order,
-                                                float* __restrict__ ws, uint8_t* __restrict__ dirs,
+__global__ __launch_bounds__(64 * DP_WAVES) void dp_kernel(const PairMeta* __restrict__ meta, const int32_t* __restrict__ order,
+                                                int npairs, float* __restrict__ ws, uint8_t* __restrict__ dirs,
                                                 const int32_t* __restrict__ bad, int32_t* __restrict__ path1,
                                                 int32_t* __restrict__ path2, int32_t* __restrict__ path_len,
                                                 int64_t path_stride, double* __restrict__ total_cost)
 {
-    __shared__ uint8_t win[WIN][64];
-    const int p = order[blockIdx.x];
+    // DP_WAVES independent pairs per workgroup, one per wavefront (so the waves land on
+    // different SIMDs); nothing below synchronises across waves
+    __shared__ uint8_t win_all[DP_WAVES][WIN][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x * DP_WAVES + wave >= npairs) return;
+    uint8_t (*win)[64] = win_all[wave];
+    const int p = order[blockIdx.x * DP_WAVES + wave];
     const PairMeta m = meta[p];
-    const int N = m.n1, M = m.n2, lane = threadIdx.x;
+    const int N = m.n1, M = m.n2;
     if (N <= 0 || M <= 0 || bad[p]) {
         if (lane == 0) { path_len[p] = 0; if (total_cost) total_cost[p] = 0.0; }
         return;
@@ -239,8 +302,15 @@ __global__ __launch_bounds__(64) void dp_kernel(const PairMeta* __restrict__ met
 #pragma unroll
     for (int c = 0; c < SL; ++c) {
         p1[c] = INF; p2[c] = INF;
-        nxt[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + c < N) nxt[c] = S4[c * 64];
+        nxt[c] = S4[c * 64];                      // rows >= N are allocated (never written, never used)
+    }
+    bool row_ok[SL];
+#pragma unroll
+    for (int c = 0; c < SL; ++c) {
+        row_ok[c] = row0 + c < N;
+        // consume the first group here: otherwise the loop header inherits "loads pending" from
+        // this edge and waits for ALL memory operations, the back-pointer stores included, every trip
+        asm volatile("" ::"v"(nxt[c].x), "v"(nxt[c].y), "v"(nxt[c].z), "v"(nxt[c].w));
     }
     const int src = (lane + 63) & 63;
     // group g holds diagonals 4g .. 4g+3; diagonal d holds cells (i, d - i)
@@ -248,10 +318,12 @@ __global__ __launch_bounds__(64) void dp_kernel(const PairMeta* __restrict__ met
         float4 cur[SL];
 #pragma unroll
         for (int c = 0; c < SL; ++c) cur[c] = nxt[c];
-        if (g + 1 < G) {
+        {   // prefetch the next group a whole group (four steps) ahead.  Unconditional (the
+            // last iteration re-reads its own group): a guard equal to the loop condition
+            // lets the compiler sink the loads into the latch, right in front of their use.
+            const int gn = min(g + 1, G - 1);
 #pragma unroll
-            for (int c = 0; c < SL; ++c)
-                if (row0 + c < N) nxt[c] = S4[(g + 1) * GS + c * 64];
+            for (int c = 0; c < SL; ++c) nxt[c] = S4[gn * GS + c * 64];
         }
         uint32_t bits[SL];
 #pragma unroll
@@ -267,23 +339,23 @@ __global__ __launch_bounds__(64) void dp_kernel(const PairMeta* __restrict__ met
                 const double up = c ? p1[c - 1] : rot1;       // (i-1, j)   on diagonal d-1
                 const double dg = c ? p2[c - 1] : rot2;       // (i-1, j-1) on diagonal d-2
                 const double left = p1[c];                    // (i, j-1)   on diagonal d-1
-                double best = dg;
-                uint32_t dir = DIR_DIAG;
-                if (up < best) { best = up; dir = DIR_UP; }
-                if (left < best) { best = left; dir = DIR_LEFT; }
+                // straight-line selects (no divergent branches): first minimum in the order diag, up, left
+                const bool take_up = up < dg;
+                const double b1 = take_up ? up : dg;
+                const bool take_left = left < b1;
+                const double best = take_left ? left : b1;
+                const uint32_t dir = take_left ? (uint32_t)DIR_LEFT : take_up ? (uint32_t)DIR_UP : (uint32_t)DIR_DIAG;
                 const float dist = e == 0 ? cur[c].x : e == 1 ? cur[c].y : e == 2 ? cur[c].z : cur[c].w;
                 const double cost = (double)dist + best;
-                const int i = row0 + c, j = d - i;
-                p2[c] = p1[c];
-                if (i < N && j >= 0 && j < M) {   // rows never reached keep +inf: that is the boundary condition
-                    p1[c] = cost;
-                    bits[c] |= dir << (2 * e);
-                }
+                // cell (row0 + c, d - row0 - c) exists?  rows never reached keep +inf: that is the boundary condition
+                const bool on = row_ok[c] && (uint32_t)(d - row0 - c) < (uint32_t)M;
+                p2[c] = left;
+                p1[c] = on ? cost : left;
+                bits[c] |= on ? dir << (2 * e) : 0u;
             }
         }
 #pragma unroll
-        for (int c = 0; c < SL; ++c)
-            if (row0 + c < N) Dr[g * GS + c * 64 + lane] = (uint8_t)bits[c];
+        for (int c = 0; c < SL; ++c) Dr[g * GS + c * 64 + lane] = (uint8_t)bits[c];
     }
     if (total_cost) {                             // p1 of row N-1 still holds cell (N-1, M-1)
         double last = 0.0;
@@ -308,7 +380,7 @@ __global__ __launch_bounds__(64) void dp_kernel(const PairMeta* __restrict__ met
             const int gq = gh - q;
             win[q][lane] = (r >= 0 && gq >= 0) ? Dr[gq * GS + phys] : (uint8_t)0;
         }
-        __syncthreads();
+        wave_lds_sync();
         if (lane == 0) {
             while ((i > 0 || j > 0) && i >= rlo && ((i + j) >> 2) > gh - WIN) {
                 const int d = i + j;
@@ -322,7 +394,7 @@ __global__ __launch_bounds__(64) void dp_kernel(const PairMeta* __restrict__ met
         i = __shfl(i, 0, 64);
         j = __shfl(j, 0, 64);
         k = __shfl(k, 0, 64);
-        __syncthreads();
+        wave_lds_sync();
     }
     __threadfence();                              // lane 0's stores are visible to the whole wave
     const int len = k + 1;
@@ -356,13 +428,40 @@ __global__ void dist_plain_kernel(const float* __restrict__ x, int N, const floa
 }
 
 struct WsPlan {
-    int64_t meta_off, tilepair_off, order_off, norm1_off, norm2_off, bad_off, dist_off, dirs_off, total;
+    int64_t meta_off, tilepair_off, order_off, bad_off, dist_off, dirs_off, total;
     int64_t total_tiles, dist_floats;
 };
 
 }  // namespace abn
 
 using namespace abn;
+
+// Side streams for the DP size classes, one set per device, created on first use.
+constexpr int N_SIDE = 3;
+struct SideStreams {
+    std::mutex mu;              // the fork / join events are shared by all callers
+    hipStream_t s[N_SIDE];
+    hipEvent_t fork, join[N_SIDE];
+    bool ok = false;
+};
+static SideStreams* side_streams()
+{
+    static SideStreams per_device[16];
+    static std::mutex init_mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStreams& ss = per_device[dev];
+    std::lock_guard<std::mutex> g(init_mu);
+    if (!ss.ok) {
+        bool good = hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess;
+        for (int q = 0; q < N_SIDE && good; ++q)
+            good = hipStreamCreateWithFlags(&ss.s[q], hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&ss.join[q], hipEventDisableTiming) == hipSuccess;
+        if (!good) { (void)hipGetLastError(); return nullptr; }
+        ss.ok = true;
+    }
+    return &ss;
+}
 
 // S4 rows of one pair: groups x 64 x SL (float4s for the distances, bytes for the back-pointers)
 static inline int64_t pair_rows(int64_t a, int64_t b)
@@ -371,7 +470,7 @@ static inline int64_t pair_rows(int64_t a, int64_t b)
     return ((a + b - 1 + 3) / 4) * 64 * DP_CLASSES[dp_class_of((int)a)];
 }
 
-// Workspace: [PairMeta x P][tile->pair x tiles][order x P][norms][bad x P][S4 dist f32][dirs u8]
+// Workspace: [PairMeta x P][tile->pair x tiles][order x P][bad x P][S4 dist f32][dirs u8]
 static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P, int64_t rows1, int64_t rows2)
 {
     WsPlan w;
@@ -386,8 +485,6 @@ static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P, int64_t r
     w.meta_off = take(P * (int64_t)sizeof(PairMeta));
     w.tilepair_off = take(tiles * 4);
     w.order_off = take(P * 4);
-    w.norm1_off = take(rows1 * 4);
-    w.norm2_off = take(rows2 * 4);
     w.bad_off = take(P * 4);
     w.dist_off = take(rows * 16);
     w.dirs_off = take(rows);
@@ -408,7 +505,8 @@ extern "C" int64_t abn_dtw_host_stage_bytes(const int32_t* n1_host, const int32_
 {
     if (!n1_host || !n2_host || npairs < 0) return -1;
     const WsPlan w = plan_ws(n1_host, n2_host, npairs, 0, 0);
-    return align_up(npairs * (int64_t)sizeof(PairMeta), 256) + align_up(w.total_tiles * 4, 256) + align_up(npairs * 4, 256);
+    (void)w;
+    return align_up(npairs * (int64_t)sizeof(PairMeta), 256) + align_up(npairs * 4, 256);
 }
 
 extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* feats2, int64_t rows2,
@@ -437,14 +535,12 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
     const WsPlan w = plan_ws(n1_host, n2_host, npairs, rows1, rows2);
     if (ws_bytes < w.total) { set_error("dtw: workspace too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)w.total); return ABN_E_WORKSPACE; }
     const int64_t meta_bytes = align_up(npairs * (int64_t)sizeof(PairMeta), 256);
-    const int64_t tp_bytes = align_up(w.total_tiles * 4, 256);
-    if (host_stage_bytes < meta_bytes + tp_bytes + align_up(npairs * 4, 256)) { set_error("dtw: host staging buffer too small"); return ABN_E_WORKSPACE; }
+    if (host_stage_bytes < meta_bytes + align_up(npairs * 4, 256)) { set_error("dtw: host staging buffer too small"); return ABN_E_WORKSPACE; }
 
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)ws;
     PairMeta* hm = (PairMeta*)host_stage;
-    int32_t* htp = (int32_t*)((char*)host_stage + meta_bytes);
-    int32_t* hord = (int32_t*)((char*)host_stage + meta_bytes + tp_bytes);
+    int32_t* hord = (int32_t*)((char*)host_stage + meta_bytes);
     int64_t tiles = 0, rows = 0;
     int64_t class_count[DP_NCLASSES] = {};
     for (int64_t p = 0; p < npairs; ++p) {
@@ -459,50 +555,92 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
         hm[p].tiles_n = (int32_t)(tn > 0 ? tn : 1);
         hm[p].slots = DP_CLASSES[cls];
         hm[p].groups = (int32_t)((a + b - 1 + 3) / 4);
-        for (int64_t t = 0; t < tm * tn; ++t) htp[tiles + t] = (int32_t)p;
         tiles += tm * tn;
         rows += pair_rows(a, b);
         ++class_count[cls];
-        hord[p] = (int32_t)p;
     }
-    // DP launch order: by size class, longest sweep first inside a class (the short ones fill the tail)
-    std::sort(hord, hord + npairs, [&](int32_t x, int32_t y) {
-        const int cx = dp_class_of(n1_host[x]), cy = dp_class_of(n1_host[y]);
-        if (cx != cy) return cx < cy;
-        const int64_t lx = (int64_t)n1_host[x] + n2_host[x], ly = (int64_t)n1_host[y] + n2_host[y];
-        return lx != ly ? lx > ly : x < y;
-    });
+    // DP launch order: by size class, longest sweep first inside a class (the short ones fill
+    // the tail).  One integer key per pair: class | inverted length | index.
+    {
+        std::vector<uint64_t> keys((size_t)npairs);
+        for (int64_t p = 0; p < npairs; ++p) {
+            const uint64_t len = (uint64_t)n1_host[p] + (uint64_t)n2_host[p];
+            keys[p] = ((uint64_t)dp_class_of(n1_host[p]) << 58) | ((((uint64_t)1 << 26) - 1 - std::min<uint64_t>(len, (1u << 26) - 1)) << 32) |
+                      (uint64_t)p;
+        }
+        std::sort(keys.begin(), keys.end());
+        for (int64_t p = 0; p < npairs; ++p) hord[p] = (int32_t)(keys[p] & 0xffffffffu);
+    }
     if (hipMemcpyAsync(base + w.meta_off, hm, npairs * sizeof(PairMeta), hipMemcpyHostToDevice, st) != hipSuccess ||
-        (tiles > 0 && hipMemcpyAsync(base + w.tilepair_off, htp, tiles * 4, hipMemcpyHostToDevice, st) != hipSuccess) ||
         hipMemcpyAsync(base + w.order_off, hord, npairs * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemsetAsync(base + w.bad_off, 0, npairs * 4, st) != hipSuccess) {
         set_error("dtw: metadata upload failed");
         return ABN_E_LAUNCH;
     }
-    float* norm1 = (float*)(base + w.norm1_off);
-    float* norm2 = (float*)(base + w.norm2_off);
-    if (rows1 > 0) hipLaunchKernelGGL(norm_kernel, dim3((unsigned)((rows1 + 255) / 256)), dim3(256), 0, st, feats1, rows1, (int)D, (int)(D % 4 == 0 && aligned16(feats1)), norm1);
-    if (rows2 > 0) hipLaunchKernelGGL(norm_kernel, dim3((unsigned)((rows2 + 255) / 256)), dim3(256), 0, st, feats2, rows2, (int)D, (int)(D % 4 == 0 && aligned16(feats2)), norm2);
-    if (tiles > 0)
-        hipLaunchKernelGGL(dist_kernel, dim3((unsigned)tiles), dim3(256), 0, st, feats1, feats2, norm1, norm2,
+    if (tiles > 0) {
+        hipLaunchKernelGGL(expand_tiles_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
+                           (const PairMeta*)(base + w.meta_off), (int)npairs, (int32_t*)(base + w.tilepair_off));
+        hipLaunchKernelGGL(dist_kernel, dim3((unsigned)tiles), dim3(256), 0, st, feats1, feats2,
                            (const PairMeta*)(base + w.meta_off), (const int32_t*)(base + w.tilepair_off), (int)D,
-                           (float*)(base + w.dist_off), (int32_t*)(base + w.bad_off));
+                           (int)(D % 4 == 0 && aligned16(feats1) && aligned16(feats2)), (float*)(base + w.dist_off),
+                           (int32_t*)(base + w.bad_off));
+    }
     const PairMeta* dm = (const PairMeta*)(base + w.meta_off);
     const int32_t* dord = (const int32_t*)(base + w.order_off);
     float* dd = (float*)(base + w.dist_off);
     uint8_t* dr = (uint8_t*)(base + w.dirs_off);
     const int32_t* db = (const int32_t*)(base + w.bad_off);
-    int64_t first = 0;
-#define ABN_DP_CLASS(C)                                                                                                 \
-    if (class_count[C] > 0) {                                                                                           \
-        hipLaunchKernelGGL((dp_kernel<DP_CLASSES[C]>), dim3((unsigned)class_count[C]), dim3(64), 0, st, dm, dord + first, \
-                           dd, dr, db, path1, path2, path_len, path_stride, total_cost);                                \
-        first += class_count[C];                                                                                        \
+    // The size classes are independent: fork them over side streams so that the
+    // short tail of one class overlaps the others (joined back into `st` below).
+    int64_t first[DP_NCLASSES], acc_first = 0;
+    int by_work[DP_NCLASSES], nclasses = 0;
+    for (int c = 0; c < DP_NCLASSES; ++c) {
+        first[c] = acc_first;
+        acc_first += class_count[c];
+        if (class_count[c] > 0) by_work[nclasses++] = c;
     }
-    ABN_DP_CLASS(0) ABN_DP_CLASS(1) ABN_DP_CLASS(2) ABN_DP_CLASS(3) ABN_DP_CLASS(4)
-    ABN_DP_CLASS(5) ABN_DP_CLASS(6) ABN_DP_CLASS(7) ABN_DP_CLASS(8) ABN_DP_CLASS(9)
-#undef ABN_DP_CLASS
-    static_assert(DP_NCLASSES == 10, "one ABN_DP_CLASS line per size class");
+    std::sort(by_work, by_work + nclasses, [&](int x, int y) {
+        return class_count[x] * DP_CLASSES[x] > class_count[y] * DP_CLASSES[y];
+    });
+    SideStreams* side = nclasses > 1 ? side_streams() : nullptr;
+    std::unique_lock<std::mutex> guard;
+    if (side) {
+        guard = std::unique_lock<std::mutex>(side->mu);
+        if (hipEventRecord(side->fork, st) != hipSuccess) side = nullptr;
+    }
+    bool used[N_SIDE] = {};
+    for (int k = 0; k < nclasses; ++k) {
+        const int c = by_work[k];
+        hipStream_t cs = st;
+        if (side && k % (N_SIDE + 1) != 0) {
+            const int q = k % (N_SIDE + 1) - 1;
+            if (!used[q] && hipStreamWaitEvent(side->s[q], side->fork, 0) != hipSuccess) {
+                set_error("dtw: side stream fork failed");
+                return ABN_E_LAUNCH;
+            }
+            used[q] = true;
+            cs = side->s[q];
+        }
+        const dim3 grid((unsigned)((class_count[c] + DP_WAVES - 1) / DP_WAVES));
+        const int32_t* ord = dord + first[c];
+#define ABN_DP_CASE(C)                                                                                                   \
+    case C:                                                                                                              \
+        hipLaunchKernelGGL((dp_kernel<DP_CLASSES[C]>), grid, dim3(64 * DP_WAVES), 0, cs, dm, ord, (int)class_count[c], dd, dr, \
+                           db, path1, path2, path_len, path_stride, total_cost);                                         \
+        break;
+        switch (c) {
+            ABN_DP_CASE(0) ABN_DP_CASE(1) ABN_DP_CASE(2) ABN_DP_CASE(3) ABN_DP_CASE(4)
+            ABN_DP_CASE(5) ABN_DP_CASE(6) ABN_DP_CASE(7) ABN_DP_CASE(8) ABN_DP_CASE(9)
+        }
+#undef ABN_DP_CASE
+    }
+    static_assert(DP_NCLASSES == 10, "one ABN_DP_CASE per size class");
+    for (int q = 0; q < N_SIDE; ++q)
+        if (used[q] && (hipEventRecord(side->join[q], side->s[q]) != hipSuccess ||
+                        hipStreamWaitEvent(st, side->join[q], 0) != hipSuccess)) {
+            set_error("dtw: side stream join failed");
+            return ABN_E_LAUNCH;
+        }
     ABN_CHECK_LAUNCH("dtw");
     return ABN_OK;
 }
