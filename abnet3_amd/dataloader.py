@@ -22,7 +22,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .utils import (Features_Accessor, dtw_align_batch, group_pairs, read_dataset)
+from .utils import (Features_Accessor, dtw_align_batch, group_pairs, read_dataset,
+                    read_spkid_file)
 
 
 class DataLoader:
@@ -205,12 +206,25 @@ class OriginalDataLoader(DataLoader):
                 self.align_pairs(group_pairs(self.pairs[mode])['same'])
 
     # -- batches ---------------------------------------------------------------
-    def frames_from_pairs_device(self, pairs, seed=0, frames=False):
+    def same_speaker(self, fid2spk, f1, f2):
+        """+1 / -1 speaker label of a word pair.  The reference compares the two
+        speaker STRINGS with `is` (dataloader.py:197,237): under CPython that is
+        true when both tokens come from the same file (the same dict value), or
+        when the ids are equal one-character strings (interned) -- two files of
+        one multi-character speaker count as DIFFERENT speakers.  speaker_match =
+        'identity' (default) reproduces that; 'equal' compares the ids."""
+        a, b = fid2spk[f1], fid2spk[f2]
+        if getattr(self, 'speaker_match', 'identity') == 'equal':
+            return a == b
+        return f1 == f2 or (a == b and len(a) <= 1)
+
+    def frames_from_pairs_device(self, pairs, seed=0, frames=False, fid2spk=None):
         """load_frames_from_pairs (dataloader.py:166-261) producing device
-        tensors: X1, X2 float32 [n, D], y float64 [n]."""
+        tensors: X1, X2 float32 [n, D], y float64 [n]; with fid2spk (the
+        multitask loader) X1, X2, y_spk, y_phn."""
         self.align_pairs(pairs['same'], frames)
         dev = self.features.table.device
-        idx1, idx2, ys = [], [], []
+        idx1, idx2, ys, ys_spk = [], [], [], []
         for f1, s1, e1, f2, s2, e2 in pairs['same']:
             if (s1 > e1) or (s2 > e2):
                 continue
@@ -220,6 +234,10 @@ class OriginalDataLoader(DataLoader):
             self.statistics_training['SameType'] += 1
             idx1.append(al[0]); idx2.append(al[1])
             ys.append(np.ones(len(al[0])))
+            if fid2spk:
+                same = self.same_speaker(fid2spk, f1, f2)
+                ys_spk.append((1 if same else -1) * np.ones(len(al[0])))
+                self.statistics_training['SameTypeSameSpk' if same else 'SameTypeDiffSpk'] += 1
         for f1, s1, e1, f2, s2, e2 in pairs['diff']:
             if (s1 > e1) or (s2 > e2):
                 continue
@@ -243,6 +261,10 @@ class OriginalDataLoader(DataLoader):
             idx2.append(torch.from_numpy(w2.astype(np.int64)).to(dev))
             ys.append(-1 * np.ones(min(n1, n2)))
             self.statistics_training['DiffType'] += 1
+            if fid2spk:
+                same = self.same_speaker(fid2spk, f1, f2)
+                ys_spk.append((1 if same else -1) * np.ones(min(n1, n2)))
+                self.statistics_training['DiffTypeSameSpk' if same else 'DiffTypeDiffSpk'] += 1
         if not idx1:
             raise ValueError('need at least one array to concatenate')
         i1, i2 = torch.cat(idx1), torch.cat(idx2)
@@ -252,14 +274,18 @@ class OriginalDataLoader(DataLoader):
         ind_d = torch.from_numpy(ind).to(dev)
         X1 = gather_rows(self.features.table, i1[ind_d])
         X2 = gather_rows(self.features.table, i2[ind_d])
+        if fid2spk:
+            y_spk = np.concatenate(ys_spk)
+            assert len(y) == len(y_spk), 'not same number of labels...'
+            return (X1, X2, torch.from_numpy(y_spk[ind]).to(dev),
+                    torch.from_numpy(y[ind]).to(dev))
         return X1, X2, torch.from_numpy(y[ind]).to(dev)
 
     def load_frames_from_pairs(self, pairs, seed=0, fid2spk=None, frames=False):
-        """numpy front end with the reference's return types."""
-        if fid2spk:
-            raise NotImplementedError('speaker labels belong to MultiTaskDataLoader')
-        X1, X2, y = self.frames_from_pairs_device(pairs, seed, frames)
-        return X1.cpu().numpy(), X2.cpu().numpy(), y.cpu().numpy()
+        """numpy front end with the reference's return types: (X1, X2, y), or
+        (X1, X2, y_spk, y_phn) when a speaker mapping is given."""
+        out = self.frames_from_pairs_device(pairs, seed, frames, fid2spk)
+        return tuple(t.cpu().numpy() for t in out)
 
     def batch_iterator(self, train_mode=True):
         """Iterator over (X1, X2, y) batches of `batch_size` WORD pairs
@@ -403,3 +429,37 @@ class FramesDataLoader(OriginalDataLoader):
         for i in batch_ids:
             yield self.load_batch(slice(i * self.batch_size,
                                         i * self.batch_size + self.batch_size), mode)
+
+
+class MultiTaskDataLoader(OriginalDataLoader):
+    """Batches (X1, X2, y_spk, y_phn) for the multitask siamese network
+    (abnet3/dataloader.py:742-792).  fid2spk_file: lines "<file id> <speaker id>".
+    speaker_match: see OriginalDataLoader.same_speaker."""
+
+    def __init__(self, pairs_path, features_path, fid2spk_file=None,
+                 speaker_match='identity', **kwargs):
+        super().__init__(pairs_path, features_path, **kwargs)
+        assert speaker_match in ('identity', 'equal')
+        self.fid2spk_file = fid2spk_file
+        self.speaker_match = speaker_match
+
+    def batch_iterator(self, train_mode=True):
+        self.load_data()
+        mode = 'train' if train_mode else 'dev'
+        pairs = self.pairs[mode]
+        num_pairs = len(pairs)
+        batches = [pairs[idx:idx + self.batch_size]
+                   for idx in range(0, num_pairs, self.batch_size)]
+        num_batches = len(batches)
+        fid2spk = read_spkid_file(self.fid2spk_file)
+        if self.num_max_minibatches < num_batches:
+            selected_batches = np.random.choice(range(num_batches),
+                                                self.num_max_minibatches,
+                                                replace=False)
+        else:
+            selected_batches = np.random.permutation(range(num_batches))
+        self.align_pairs([p[:6] for b in selected_batches for p in batches[b]
+                          if p[6] == 'same'])
+        for idx in selected_batches:
+            yield self.frames_from_pairs_device(group_pairs(batches[idx]), fid2spk=fid2spk)
+

@@ -3,6 +3,7 @@
 Mirrors (file:line relative to the reference checkout)
   EmbedderBuilder   abnet3/embedder.py:19-50
   EmbedderSiamese   abnet3/embedder.py:53-100
+  EmbedderSiameseMultitask  abnet3/embedder.py:103-148
 The eval-mode forward of the first tower runs through abn_tower_forward.  The
 reference reads/writes h5features files (third-party, absent from this image):
 embed() uses that package when it is importable, and embed_features() is the
@@ -82,3 +83,57 @@ class EmbedderSiamese(EmbedderBuilder):
         data = h5features.Data(items, times, embeddings, check=True)
         with h5features.Writer(self.output_path) as fh:
             fh.write(data, 'features')
+
+
+class EmbedderSiameseMultitask(EmbedderBuilder):
+    """Embedder class for siamese network on multitask
+    (abnet3/embedder.py:103-148): every utterance goes through the network whole
+    (no batch_size chunking in the reference) and yields a speaker and a phone
+    embedding; embed() writes <output_path>.spk and <output_path>.phn."""
+
+    def __init__(self, *args, **kwargs):
+        super(EmbedderSiameseMultitask, self).__init__(*args, **kwargs)
+
+    def embed_features(self, feats):
+        """([T, out] speaker embeddings], [[T, out] phone embeddings]) for a list
+        of [T, D] arrays (the loop of embedder.py:130-140)."""
+        self.network.eval()
+        self.network.cuda()
+        embeddings_spk, embeddings_phn = [], []
+        with torch.no_grad():
+            for feat in feats:
+                if feat.dtype != np.float32:
+                    feat = feat.astype(np.float32)
+                if len(feat) == 0:
+                    empty = np.zeros((0, self.network.output_dim), np.float32)
+                    embeddings_spk.append(empty)
+                    embeddings_phn.append(empty.copy())
+                    continue
+                x = torch.from_numpy(np.ascontiguousarray(feat)).cuda()
+                emb_spk, emb_phn = self.network.forward_once(x)   # network(x, x)[:2]
+                embeddings_spk.append(emb_spk.cpu().numpy())
+                embeddings_phn.append(emb_phn.cpu().numpy())
+        return embeddings_spk, embeddings_phn
+
+    def embed(self):
+        if self.network_path is not None:
+            self.network.load_network(self.network_path)
+        try:
+            import h5features
+        except ImportError:
+            raise ImportError('EmbedderSiameseMultitask.embed() reads and writes '
+                              'h5features files like the reference; the h5features '
+                              'package is not installed. Use embed_features().')
+        with h5features.Reader(self.feature_path, 'features') as fh:
+            features = fh.read()
+        items = features.items()
+        times = features.labels()
+        feats = features.features()
+        embeddings_spk, embeddings_phn = self.embed_features(feats)
+        data_spk = h5features.Data(items, times, embeddings_spk, check=True)
+        data_phn = h5features.Data(items, times, embeddings_phn, check=True)
+        with h5features.Writer(self.output_path + '.spk') as fh:
+            fh.write(data_spk, 'features')
+        with h5features.Writer(self.output_path + '.phn') as fh:
+            fh.write(data_phn, 'features')
+

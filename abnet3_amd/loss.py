@@ -4,6 +4,7 @@ Mirrors (file:line relative to the reference checkout)
   LossBuilder   abnet3/loss.py:15-34
   coscos2       abnet3/loss.py:37-67
   cosmargin     abnet3/loss.py:70-105
+  weighted_loss_multi  abnet3/loss.py:140-182
 forward(input1, input2, y) returns a 0-dim tensor with .backward(); the
 arithmetic (cosine similarity with eps=1e-6, per-label transform, sum, /N) and
 its gradient run fused in one kernel (abn_pair_loss).
@@ -92,3 +93,33 @@ class cosmargin(LossBuilder):
     def forward(self, input1, input2, y, avg=True):
         # like the reference, the `avg` ARGUMENT is ignored (loss.py:103)
         return _pair_loss(input1, input2, y, 'cosmargin', self.margin, self.avg)
+
+
+class weighted_loss_multi(LossBuilder):
+    """Weighted loss for multi-task training based on two pair losses
+    (abnet3/loss.py:140-182): weight*loss_spk + (1 - weight)*loss_phn.
+
+    Parameters
+    ----------
+    loss_phn, loss_spk : abnet3_amd.loss functions (coscos2 / cosmargin)
+    weight : float
+        variable between 0 and 1, to weight one or the other task.
+    """
+
+    def __init__(self, avg=True, loss_phn=None, loss_spk=None,
+                 weight=0.5, *args, **kwargs):
+        super(weighted_loss_multi, self).__init__(*args, **kwargs)
+        assert type(weight) is float
+        assert (weight >= 0 and weight <= 1)
+        self.weight = weight
+        self.avg = avg
+        self.loss_phn = loss_phn
+        self.loss_spk = loss_spk
+
+    def forward(self, emb_spk1, emb_phn1, emb_spk2, emb_phn2,
+                y_spk, y_phn):
+        output_spk = self.loss_spk(emb_spk1, emb_spk2, y_spk)
+        output_phn = self.loss_phn(emb_phn1, emb_phn2, y_phn)
+        output = self.weight * output_spk + (1.0 - self.weight) * output_phn
+        return output
+

@@ -65,25 +65,117 @@ class NetworkBuilder(nn.Module):
                                   self.__class__.__name__)
 
 
+class _Segment(object):
+    """A run of [Linear, Dropout, (BatchNorm1d), act] blocks executed by one
+    abn_tower_forward / abn_tower_backward launch sequence: the whole
+    SiameseNetwork, or the trunk / one head of a SiameseMultitaskNetwork."""
+
+    def __init__(self, net, blocks, first_block, act, last_act, batch_norm):
+        self.net = net
+        self.blocks = blocks                  # [(Linear, BatchNorm1d | None)]
+        self.first_block = first_block        # index into the network's dropout masks
+        self.act, self.last_act = act, last_act
+        self.batch_norm = bool(batch_norm)
+        self.input_dim = blocks[0][0].in_features
+        self.output_dim = blocks[-1][0].out_features
+        self.params = []
+        for lin, bn in blocks:
+            self.params += [lin.weight, lin.bias]
+            if bn is not None:
+                self.params += [bn.weight, bn.bias]
+
+    def bn_modules(self):
+        return [bn for _, bn in self.blocks if bn is not None]
+
+    def masks_of(self, all_masks):
+        if all_masks is None:
+            return None
+        return all_masks[self.first_block:self.first_block + len(self.blocks)]
+
+    def descriptor(self, with_grads, grad_views=None, masks=None):
+        self.net.flat_parameters()
+        d = _lib.TowerDesc()
+        d.n_layers = len(self.blocks)
+        d.act = _lib.ACT[self.act]
+        if self.last_act not in _lib.ACT:
+            raise NotImplementedError('abnet3_amd: last_non_linearity=%r is not on '
+                                      'the accelerated path' % (self.last_act,))
+        d.last_act = _lib.ACT[self.last_act]
+        d.batch_norm = int(self.batch_norm)
+        d.dims[0] = self.input_dim
+        gi = 0
+        for l, (lin, bn) in enumerate(self.blocks):
+            d.dims[l + 1] = lin.out_features
+            d.W[l] = lin.weight.data_ptr()
+            d.b[l] = lin.bias.data_ptr()
+            if masks is not None:
+                d.drop_mask[l] = masks[l].data_ptr()
+            if with_grads:
+                d.dW[l] = grad_views[gi].data_ptr()
+                d.db[l] = grad_views[gi + 1].data_ptr()
+            gi += 2
+            if bn is not None:
+                d.bn_w[l] = bn.weight.data_ptr()
+                d.bn_b[l] = bn.bias.data_ptr()
+                d.bn_rm[l] = bn.running_mean.data_ptr()
+                d.bn_rv[l] = bn.running_var.data_ptr()
+                if with_grads:
+                    d.dbn_w[l] = grad_views[gi].data_ptr()
+                    d.dbn_b[l] = grad_views[gi + 1].data_ptr()
+                gi += 2
+        return d
+
+
+class _GradPass(object):
+    """The flat gradient buffer of ONE backward pass, shared by the segments of a
+    network: a fresh buffer per forward (caching allocator: no memset, no sync).
+    autograd takes the per-parameter views as p.grad without copying, so after one
+    backward the whole gradient sits in one buffer laid out like the flat
+    parameters.  A segment that runs backward a second time (retain_graph) gets a
+    private buffer, and autograd adds it into the first as for any other module."""
+
+    def __init__(self, net):
+        self.net = net
+        self.buf = None
+        self.used = set()
+
+    def views(self, seg):
+        net = self.net
+        net.flat_parameters()
+        if self.buf is None or id(seg) in self.used:
+            buf = torch.empty_like(net._flat)
+            if self.buf is None:
+                self.buf = buf
+                net._last_grad_flat = buf
+        else:
+            buf = self.buf
+        self.used.add(id(seg))
+        return [buf[net._offset_of[id(p)]:net._offset_of[id(p)] + p.numel()].view(p.shape)
+                for p in seg.params]
+
+
 class _TowerFunction(torch.autograd.Function):
-    """One launch sequence for n_calls forward_once calls sharing the weights."""
+    """One launch sequence for n_calls forward_once calls of one segment."""
 
     @staticmethod
-    def forward(ctx, net, n_calls, split, x1, x2, *params):
+    def forward(ctx, seg, grad_pass, all_masks, n_calls, split, x1, x2, *params):
         lib = _lib.load()
+        net = seg.net
         _lib.require_device(x1, x2, *params)
         if x1.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
             raise TypeError('abnet3_amd: features must be float32 (the reference '
                             'casts them, abnet3/utils.py:228-235)')
-        if x1.dim() != 2 or x1.shape[1] != net.input_dim:
+        if x1.dim() != 2 or x1.shape[1] != seg.input_dim:
             raise ValueError('abnet3_amd: expected input of shape [n, %d], got %s'
-                             % (net.input_dim, tuple(x1.shape)))
+                             % (seg.input_dim, tuple(x1.shape)))
         if x2 is not None and x2.shape != x1.shape:
             raise ValueError('abnet3_amd: the two inputs must have the same shape')
+        x1 = x1.contiguous()
+        x2 = x2.contiguous() if x2 is not None else None
         train = bool(net.training)
         rows = x1.shape[0] * (2 if x2 is not None else 1)
-        masks = net._draw_dropout_masks(rows, x1.device) if train else None
-        desc = net._descriptor(with_grads=False, masks=masks)
+        masks = seg.masks_of(all_masks) if train else None
+        desc = seg.descriptor(with_grads=False, masks=masks)
         ws_floats = lib.abn_tower_ws_floats(_lib.C.byref(desc), rows, n_calls)
         if ws_floats < 0:
             _lib.check(-1, 'abn_tower_ws_floats')
@@ -91,12 +183,12 @@ class _TowerFunction(torch.autograd.Function):
         _lib.check(lib.abn_tower_forward(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2),
                                          rows, n_calls, int(train), _lib.ptr(ws),
                                          _lib.stream()), 'abn_tower_forward')
-        if train and net.batch_norm:
-            for bn in net._bn_modules():
+        if train and seg.batch_norm:
+            for bn in seg.bn_modules():
                 bn.num_batches_tracked += n_calls
         off = lib.abn_tower_out_offset(_lib.C.byref(desc), rows, n_calls)
-        out = ws[off:off + rows * net.output_dim].view(rows, net.output_dim)
-        ctx.net, ctx.n_calls, ctx.train = net, n_calls, train
+        out = ws[off:off + rows * seg.output_dim].view(rows, seg.output_dim)
+        ctx.seg, ctx.grad_pass, ctx.n_calls, ctx.train = seg, grad_pass, n_calls, train
         ctx.masks = masks
         ctx.have_x2 = x2 is not None
         ctx.split = split
@@ -109,7 +201,7 @@ class _TowerFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *d_outs):
         lib = _lib.load()
-        net = ctx.net
+        seg = ctx.seg
         x1, x2, ws = ctx.saved_tensors
         if ctx.split:
             d1, d2 = d_outs
@@ -128,7 +220,7 @@ class _TowerFunction(torch.autograd.Function):
                 d_out = torch.cat([d1, d2])
         else:
             d_out = d_outs[0]
-        if net.batch_norm and not ctx.train:
+        if seg.batch_norm and not ctx.train:
             raise NotImplementedError(
                 'abnet3_amd: backward through an eval-mode BatchNorm forward is '
                 'not on the accelerated path (the reference trains in train mode, '
@@ -136,13 +228,13 @@ class _TowerFunction(torch.autograd.Function):
         d_out = d_out.contiguous()
         _lib.require_device(d_out)
         rows = d_out.shape[0]
-        grads = net._new_grad_views()
-        desc = net._descriptor(with_grads=True, grad_views=grads, masks=ctx.masks)
+        grads = ctx.grad_pass.views(seg)
+        desc = seg.descriptor(with_grads=True, grad_views=grads, masks=ctx.masks)
         scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
         scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32,
                               device=d_out.device)
-        need_dx = ctx.needs_input_grad[3] or (ctx.have_x2 and ctx.needs_input_grad[4])
-        dx = torch.empty(rows, net.input_dim, dtype=torch.float32,
+        need_dx = ctx.needs_input_grad[5] or (ctx.have_x2 and ctx.needs_input_grad[6])
+        dx = torch.empty(rows, seg.input_dim, dtype=torch.float32,
                          device=d_out.device) if need_dx else None
         _lib.check(lib.abn_tower_backward(
             _lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(d_out), rows,
@@ -154,10 +246,145 @@ class _TowerFunction(torch.autograd.Function):
                 dx1, dx2 = dx[:rows // 2], dx[rows // 2:]
             else:
                 dx1 = dx
-        return (None, None, None, dx1, dx2) + tuple(grads)
+        return (None, None, None, None, None, dx1, dx2) + tuple(grads)
 
 
-class SiameseNetwork(NetworkBuilder):
+def _blocks_of(*sequentials):
+    """[(Linear, BatchNorm1d | None)] of nn.Sequentials in forward order."""
+    out = []
+    for seq in sequentials:
+        lin = None
+        for m in seq:
+            if isinstance(m, nn.Linear):
+                if lin is not None:
+                    out.append((lin, None))
+                lin = m
+            elif isinstance(m, nn.BatchNorm1d):
+                out.append((lin, m))
+                lin = None
+        if lin is not None:
+            out.append((lin, None))
+    return out
+
+
+class _HipNetwork(NetworkBuilder):
+    """What the HIP-backed networks share: the flat parameter / gradient buffers
+    (one optimizer launch and one RCCL all-reduce per step instead of one per
+    tensor), dropout masks and the segment launcher.  Subclasses provide
+    _segments() and the reference's constructor / forward surface."""
+
+    def _init_hip_state(self):
+        self._flat = None
+        self._last_grad_flat = None
+        self._offsets = None
+        self._offset_of = None
+        self._segs = None
+        self._mask_override = None      # tests: fixed dropout masks, one per live block
+
+    def _segments(self):
+        raise NotImplementedError
+
+    def _segment_list(self):
+        if self._segs is None:
+            self._segs = self._segments()
+        return self._segs
+
+    def _blocks(self):
+        return [b for seg in self._segment_list() for b in seg.blocks]
+
+    def _bn_modules(self):
+        return [bn for _, bn in self._blocks() if bn is not None]
+
+    def live_parameters(self):
+        """The parameters forward() uses (all of them, except the never-called
+        branches of a SiameseMultitaskNetwork), in nn.Module.parameters() order:
+        what the flat buffers hold and the optimizer updates."""
+        return [p for seg in self._segment_list() for p in seg.params]
+
+    def flatten_parameters(self):
+        """Re-homes every live parameter into one flat fp32 buffer (gradients come
+        back in a buffer of the same layout).  Called lazily; redone automatically
+        when .cuda()/.to() replaced the storages."""
+        params = self.live_parameters()
+        dev = params[0].device
+        offs, o = [], 0
+        for p in params:
+            offs.append(o)
+            o += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        flat = torch.zeros(o, dtype=torch.float32, device=dev)
+        for p, off in zip(params, offs):
+            flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + p.numel()].view(p.shape)
+        self._flat = flat
+        self._offsets = offs
+        self._offset_of = {id(p): off for p, off in zip(params, offs)}
+        return flat
+
+    def _is_flat(self):
+        if self._flat is None:
+            return False
+        base = self._flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * off
+                   for p, off in zip(self.live_parameters(), self._offsets))
+
+    def flat_parameters(self):
+        if not self._is_flat():
+            self.flatten_parameters()
+        return self._flat
+
+    def grads_in_flat_buffer(self):
+        """True when every live p.grad IS its view of one flat gradient buffer."""
+        buf = getattr(self, '_last_grad_flat', None)
+        if buf is None or not self._is_flat():
+            return False
+        base = buf.data_ptr()
+        return all(p.grad is not None and p.grad.data_ptr() == base + 4 * off
+                   for p, off in zip(self.live_parameters(), self._offsets))
+
+    def flat_grad(self):
+        """The gradient of all live parameters as one flat fp32 buffer laid out
+        like flat_parameters() (the all-reduce bucket).  Zero-copy after a single
+        backward; otherwise p.grad tensors are packed into a new buffer."""
+        if self.grads_in_flat_buffer():
+            return self._last_grad_flat
+        self.flat_parameters()
+        buf = torch.zeros_like(self._flat)
+        for p, off in zip(self.live_parameters(), self._offsets):
+            if p.grad is not None:
+                buf[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                p.grad = buf[off:off + p.numel()].view(p.shape)
+        self._last_grad_flat = buf
+        return buf
+
+    def _draw_dropout_masks(self, rows, device):
+        """nn.Dropout(p) of every block in train mode (model.py:137,148,157): one
+        [rows, width] multiplier per layer, 0 with probability p else 1/(1-p),
+        drawn with torch's device generator (the reference's CPU stream cannot be
+        reproduced on a GPU; the arithmetic that consumes the mask is what the
+        parity tests pin).  None when p == 0."""
+        if self._mask_override is not None:
+            return self._mask_override
+        p = float(self.p_dropout)
+        if p <= 0.0:
+            return None
+        masks = []
+        for lin, _ in self._blocks():
+            keep = torch.rand(rows, lin.out_features, device=device) >= p
+            masks.append(keep.to(torch.float32).mul_(1.0 / (1.0 - p)) if p < 1.0
+                         else torch.zeros(rows, lin.out_features, device=device))
+        return masks
+
+    def _run(self, seg, grad_pass, masks, x1, x2, n_calls, split):
+        return _TowerFunction.apply(seg, grad_pass, masks, n_calls, split, x1, x2, *seg.params)
+
+    def whoami(self):
+        return {'params': self.__dict__, 'class_name': self.__class__.__name__}
+
+    def load_network(self, network_path=None):
+        self.load_state_dict(torch.load(network_path))
+
+
+class SiameseNetwork(_HipNetwork):
     """Siamese neural network Architecture (abnet3/model.py:82-208).
 
     Parameters: see the reference docstring; identical names and defaults.
@@ -219,10 +446,7 @@ class SiameseNetwork(NetworkBuilder):
         self.output_layer = nn.Sequential(*output_layer)
         self.output_path = output_path
         self.apply(self.init_weight_method)
-        self._flat = None
-        self._last_grad_flat = None
-        self._offsets = None
-        self._mask_override = None      # tests: fixed dropout masks
+        self._init_hip_state()
 
     def init_weight_method(self, layer):
         if isinstance(layer, nn.Linear):
@@ -232,157 +456,25 @@ class SiameseNetwork(NetworkBuilder):
             layer.bias.data.fill_(0.0)
 
     # -- HIP plumbing ------------------------------------------------------
-    def _blocks(self):
-        """[(Linear, BatchNorm1d | None)] in forward order."""
-        out = []
-        for seq in (self.input_emb, self.hidden_layers, self.output_layer):
-            lin = None
-            for m in seq:
-                if isinstance(m, nn.Linear):
-                    if lin is not None:
-                        out.append((lin, None))
-                    lin = m
-                elif isinstance(m, nn.BatchNorm1d):
-                    out.append((lin, m))
-                    lin = None
-            if lin is not None:
-                out.append((lin, None))
-        return out
+    def _segments(self):
+        return [_Segment(self, _blocks_of(self.input_emb, self.hidden_layers, self.output_layer),
+                         0, self.activation_layer, self._last_act, self.batch_norm)]
 
-    def _bn_modules(self):
-        return [bn for _, bn in self._blocks() if bn is not None]
-
-    def flatten_parameters(self):
-        """Re-homes every parameter into one flat fp32 buffer (gradients come
-        back in a buffer of the same layout): one optimizer launch and one RCCL
-        all-reduce per step instead of one per tensor.  Called lazily; redone
-        automatically when .cuda()/.to() replaced the storages."""
-        params = list(self.parameters())
-        dev = params[0].device
-        offs, o = [], 0
-        for p in params:
-            offs.append(o)
-            o += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
-        flat = torch.zeros(o, dtype=torch.float32, device=dev)
-        for p, off in zip(params, offs):
-            flat[off:off + p.numel()].copy_(p.data.reshape(-1))
-            p.data = flat[off:off + p.numel()].view(p.shape)
-        self._flat = flat
-        self._offsets = offs
-        return flat
-
-    def _is_flat(self):
-        if self._flat is None:
-            return False
-        base = self._flat.data_ptr()
-        return all(p.data_ptr() == base + 4 * off
-                   for p, off in zip(self.parameters(), self._offsets))
-
-    def flat_parameters(self):
-        if not self._is_flat():
-            self.flatten_parameters()
-        return self._flat
-
-    def _new_grad_views(self):
-        """A fresh flat gradient buffer per backward (caching allocator: no
-        memset, no sync) and its per-parameter views.  autograd takes the views
-        as p.grad without copying, so after one backward the whole gradient sits
-        in ONE buffer; a second backward before zero_grad() gets its own buffer
-        and autograd adds it into the first, as for any other module."""
-        self.flat_parameters()
-        buf = torch.empty_like(self._flat)
-        self._last_grad_flat = buf
-        return [buf[off:off + p.numel()].view(p.shape)
-                for p, off in zip(self.parameters(), self._offsets)]
-
-    def grads_in_flat_buffer(self):
-        """True when every p.grad IS its view of one flat gradient buffer."""
-        buf = getattr(self, '_last_grad_flat', None)
-        if buf is None or not self._is_flat():
-            return False
-        base = buf.data_ptr()
-        return all(p.grad is not None and p.grad.data_ptr() == base + 4 * off
-                   for p, off in zip(self.parameters(), self._offsets))
-
-    def flat_grad(self):
-        """The gradient of all parameters as one flat fp32 buffer laid out like
-        flat_parameters() (the all-reduce bucket).  Zero-copy after a single
-        backward; otherwise p.grad tensors are packed into a new buffer."""
-        if self.grads_in_flat_buffer():
-            return self._last_grad_flat
-        self.flat_parameters()
-        buf = torch.zeros_like(self._flat)
-        for p, off in zip(self.parameters(), self._offsets):
-            if p.grad is not None:
-                buf[off:off + p.numel()].copy_(p.grad.reshape(-1))
-                p.grad = buf[off:off + p.numel()].view(p.shape)
-        self._last_grad_flat = buf
-        return buf
-
-    def _descriptor(self, with_grads, grad_views=None, masks=None):
-        self.flat_parameters()
-        d = _lib.TowerDesc()
-        blocks = self._blocks()
-        d.n_layers = len(blocks)
-        d.act = _lib.ACT[self.activation_layer]
-        if self._last_act not in _lib.ACT:
-            raise NotImplementedError('abnet3_amd: last_non_linearity=%r is not on '
-                                      'the accelerated path' % (self._last_act,))
-        d.last_act = _lib.ACT[self._last_act]
-        d.batch_norm = int(bool(self.batch_norm))
-        d.dims[0] = self.input_dim
-        gi = 0
-        for l, (lin, bn) in enumerate(blocks):
-            d.dims[l + 1] = lin.out_features
-            d.W[l] = lin.weight.data_ptr()
-            d.b[l] = lin.bias.data_ptr()
-            if masks is not None:
-                d.drop_mask[l] = masks[l].data_ptr()
-            if with_grads:
-                d.dW[l] = grad_views[gi].data_ptr()
-                d.db[l] = grad_views[gi + 1].data_ptr()
-            gi += 2
-            if bn is not None:
-                d.bn_w[l] = bn.weight.data_ptr()
-                d.bn_b[l] = bn.bias.data_ptr()
-                d.bn_rm[l] = bn.running_mean.data_ptr()
-                d.bn_rv[l] = bn.running_var.data_ptr()
-                if with_grads:
-                    d.dbn_w[l] = grad_views[gi].data_ptr()
-                    d.dbn_b[l] = grad_views[gi + 1].data_ptr()
-                gi += 2
-        return d
-
-    def _draw_dropout_masks(self, rows, device):
-        """nn.Dropout(p) of every block in train mode (model.py:137,148,157): one
-        [rows, width] multiplier per layer, 0 with probability p else 1/(1-p),
-        drawn with torch's device generator (the reference's CPU stream cannot be
-        reproduced on a GPU; the arithmetic that consumes the mask is what the
-        parity tests pin).  None when p == 0."""
-        if self._mask_override is not None:
-            return self._mask_override
-        p = float(self.p_dropout)
-        if p <= 0.0:
-            return None
-        masks = []
-        for lin, _ in self._blocks():
-            keep = torch.rand(rows, lin.out_features, device=device) >= p
-            masks.append(keep.to(torch.float32).mul_(1.0 / (1.0 - p)) if p < 1.0
-                         else torch.zeros(rows, lin.out_features, device=device))
-        return masks
-
-    def _run(self, x1, x2, n_calls, split):
-        return _TowerFunction.apply(self, n_calls, split, x1, x2, *self.parameters())
+    def _run_tower(self, x1, x2, n_calls, split):
+        seg = self._segment_list()[0]
+        rows = x1.shape[0] * (2 if x2 is not None else 1)
+        masks = self._draw_dropout_masks(rows, x1.device) if self.training else None
+        return self._run(seg, _GradPass(self), masks, x1, x2, n_calls, split)
 
     # -- reference surface ---------------------------------------------------
     def forward_once(self, x):
         """Simple forward pass for one instance x (abnet3/model.py:179-186)."""
-        return self._run(x, None, 1, False)
+        return self._run_tower(x, None, 1, False)
 
     def forward(self, input1, input2):
         """Forward pass through the same network (abnet3/model.py:188-196): both
         towers in one launch sequence, BatchNorm statistics per tower call."""
-        return self._run(input1, input2, 2, True)
+        return self._run_tower(input1, input2, 2, True)
 
     def forward_pair_rows(self, x12):
         """forward(x12[:B], x12[B:]) for a batch that already sits in one
@@ -390,7 +482,7 @@ class SiameseNetwork(NetworkBuilder):
         concatenation copy inside the call."""
         if x12.shape[0] % 2:
             raise ValueError('abnet3_amd: forward_pair_rows needs an even number of rows')
-        return self._run(x12, None, 2, True)
+        return self._run_tower(x12, None, 2, True)
 
     def whoami(self):
         return {'params': self.__dict__, 'class_name': self.__class__.__name__}
@@ -400,3 +492,115 @@ class SiameseNetwork(NetworkBuilder):
 
     def load_network(self, network_path=None):
         self.load_state_dict(torch.load(network_path))
+
+
+class SiameseMultitaskNetwork(_HipNetwork):
+    """Siamese network for multi-task speaker and speech representation
+    (abnet3/model.py:211-376): input_emb and hidden_layers_shared feed BOTH
+    output_layer_spk and output_layer_phn.  hidden_layers_spk / hidden_layers_phn
+    are built and initialised as in the reference (same state_dict keys, same RNG
+    consumption) but, as in the reference's forward_once (model.py:337-345),
+    never called: they get no gradient and no optimizer update.
+
+    Three launch sequences per forward: the trunk over both towers' rows, then
+    each one-layer head over the trunk's output; autograd adds the two heads'
+    gradients into the trunk's."""
+
+    def __init__(self, input_dim=None, num_hidden_layers_shared=None,
+                 num_hidden_layers_spk=None,
+                 num_hidden_layers_phn=None,
+                 hidden_dim=None,
+                 output_dim=None, p_dropout=0.1, batch_norm=False,
+                 type_init='xavier_uni', activation_layer=None,
+                 output_path=None):
+        super(SiameseMultitaskNetwork, self).__init__()
+        assert activation_layer in ('relu', 'sigmoid', 'tanh')
+        assert type_init in ('xavier_uni', 'xavier_normal', 'orthogonal')
+        assert type(input_dim) == int, 'input dim should be int'
+        assert type(hidden_dim) == int, 'hidden dim should be int'
+        assert type(num_hidden_layers_shared) == int
+        assert type(num_hidden_layers_spk) == int
+        assert type(num_hidden_layers_phn) == int
+        assert type(output_dim) == int, 'output dim should be int'
+        assert num_hidden_layers_shared + 1 <= _lib.MAX_LAYERS, 'too many layers'
+
+        self.input_dim = input_dim
+        self.num_hidden_layers_shared = num_hidden_layers_shared
+        self.num_hidden_layers_spk = num_hidden_layers_spk
+        self.num_hidden_layers_phn = num_hidden_layers_phn
+        self.hidden_dim = hidden_dim
+        self.output_dim = output_dim
+        self.activation_layer = activation_layer
+        self.batch_norm = batch_norm
+        self.type_init = type_init
+        self.p_dropout = p_dropout
+
+        activation = activation_functions[activation_layer]
+
+        def block(n_in, n_out):
+            layers = [nn.Linear(n_in, n_out), nn.Dropout(p=p_dropout)]
+            if self.batch_norm:
+                layers.append(nn.BatchNorm1d(n_out))
+            layers.append(activation())
+            return layers
+
+        def stack(n):
+            layers = []
+            for idx in range(n):
+                layers += block(hidden_dim, hidden_dim)
+            return layers
+
+        # construction order of the reference: input, shared, spk, phn, then the
+        # two output layers (every nn.Linear draws its default init from the RNG)
+        self.input_emb = nn.Sequential(*block(input_dim, hidden_dim))
+        shared = stack(self.num_hidden_layers_shared)
+        spk = stack(self.num_hidden_layers_spk)
+        phn = stack(self.num_hidden_layers_phn)
+        self.hidden_layers_shared = nn.Sequential(*shared)
+        self.hidden_layers_spk = nn.Sequential(*spk)
+        self.hidden_layers_phn = nn.Sequential(*phn)
+        self.output_layer_spk = nn.Sequential(*block(hidden_dim, output_dim))
+        self.output_layer_phn = nn.Sequential(*block(hidden_dim, output_dim))
+
+        self.output_path = output_path
+        self.apply(self.init_weight_method)
+        self._init_hip_state()
+
+    def init_weight_method(self, layer):
+        if isinstance(layer, nn.Linear):
+            init_func = init_functions[self.type_init]
+            init_func(layer.weight.data,
+                      gain=nn.init.calculate_gain(self.activation_layer))
+            layer.bias.data.fill_(0.0)
+
+    def _segments(self):
+        act, bn = self.activation_layer, self.batch_norm
+        trunk = _blocks_of(self.input_emb, self.hidden_layers_shared)
+        return [_Segment(self, trunk, 0, act, act, bn),
+                _Segment(self, _blocks_of(self.output_layer_spk), len(trunk), act, act, bn),
+                _Segment(self, _blocks_of(self.output_layer_phn), len(trunk) + 1, act, act, bn)]
+
+    def _forward(self, x1, x2):
+        trunk, head_spk, head_phn = self._segment_list()
+        n_calls = 1 if x2 is None else 2
+        rows = x1.shape[0] * n_calls
+        gp = _GradPass(self)
+        masks = self._draw_dropout_masks(rows, x1.device) if self.training else None
+        h = self._run(trunk, gp, masks, x1, x2, n_calls, False)
+        split = x2 is not None
+        return (self._run(head_spk, gp, masks, h, None, n_calls, split),
+                self._run(head_phn, gp, masks, h, None, n_calls, split))
+
+    def forward_once(self, x):
+        """(output_spk, output_phn) for one instance x (abnet3/model.py:337-345)."""
+        return self._forward(x, None)
+
+    def forward(self, input1, input2):
+        """(spk1, phn1, spk2, phn2) (abnet3/model.py:347-356): both towers in one
+        launch sequence per segment, BatchNorm statistics per tower call."""
+        (spk1, spk2), (phn1, phn2) = self._forward(input1, input2)
+        return spk1, phn1, spk2, phn2
+
+    def save_network(self, epoch=''):
+        torch.save(self.state_dict(), self.output_path + epoch + '.pth')
+

@@ -5,6 +5,7 @@ Mirrors (file:line relative to the reference checkout)
                    stopping, best-model saving, whoami)
   TrainerSiamese   abnet3/trainer.py:203-256 (give_batch_to_network,
                    optimize_model)
+  TrainerSiameseMultitask  abnet3/trainer.py:259-279
 Differences, all on purpose:
   * the optimizer is one fused HIP kernel over the network's flat parameter
     buffer with torch.optim's update rules (FlatOptimizer);
@@ -27,7 +28,7 @@ import torch
 import torch.optim as optim
 
 from . import _lib, parallel
-from .model import NetworkBuilder
+from .model import NetworkBuilder, SiameseMultitaskNetwork
 
 try:                                        # pragma: no cover
     from tensorboardX import SummaryWriter
@@ -262,6 +263,11 @@ class TrainerSiamese(TrainerBuilder):
         emb_batch1, emb_batch2 = self.network(X_batch1, X_batch2)
         return self.loss(emb_batch1, emb_batch2, y_batch)
 
+    def _loss_is_mean(self):
+        """Data-parallel gradient exchange: a mean loss averages over ranks, a
+        summed loss sums."""
+        return bool(getattr(self.loss, 'avg', False))
+
     def train_step(self, batch, do_training=True):
         """The five statements of the reference's inner loop
         (abnet3/trainer.py:236-240) plus the data-parallel gradient exchange.
@@ -272,7 +278,7 @@ class TrainerSiamese(TrainerBuilder):
             loss_value.backward()
             if self.world_size > 1:
                 self.optimizer.grad_scale = parallel.all_reduce_gradients(
-                    self.network.flat_grad(), getattr(self.loss, 'avg', False))
+                    self.network.flat_grad(), self._loss_is_mean())
             self.optimizer.step()
         else:
             with torch.no_grad():
@@ -289,23 +295,15 @@ class TrainerSiamese(TrainerBuilder):
         torch.distributed the gradient all-reduce and the optimizer stay
         outside the graph (fwd + bwd are captured).  Adam's bias correction is
         host-computed per step, so its optimizer launch also stays outside."""
-        # static inputs: both towers' rows in ONE [2B, D] buffer
-        B = example_batch[0].shape[0]
-        x12 = torch.cat([example_batch[0].cuda(), example_batch[1].cuda()])
-        x1, x2 = x12[:B], x12[B:]
-        y = example_batch[2].cuda().clone()
+        static, fwd_loss = self._graph_inputs(example_batch)
         opt = self.optimizer
-
-        def fwd_loss():
-            e1, e2 = self.network.forward_pair_rows(x12)
-            return self.loss(e1, e2, y)
         capture_opt = (self.world_size == 1 and isinstance(opt, FlatOptimizer)
                        and opt.kind != 'adam')
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):      # also moves the optimizer past step 1
-                self.train_step((x1, x2, y), True)
+                self.train_step(tuple(static), True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -318,20 +316,33 @@ class TrainerSiamese(TrainerBuilder):
         static_loss = loss_value.detach()
 
         def step(batch):
-            x1.copy_(batch[0], non_blocking=True)
-            x2.copy_(batch[1], non_blocking=True)
-            y.copy_(batch[2], non_blocking=True)
+            for dst, src in zip(static, batch):
+                dst.copy_(src, non_blocking=True)
             graph.replay()
             if capture_opt:
                 opt.step_count += 1
             else:
                 if self.world_size > 1:
                     opt.grad_scale = parallel.all_reduce_gradients(
-                        self.network.flat_grad(), getattr(self.loss, 'avg', False))
+                        self.network.flat_grad(), self._loss_is_mean())
                 opt.step()
             return static_loss
         step.graph = graph
         return step
+
+    def _graph_inputs(self, example_batch):
+        """Static device tensors a captured step reads its batch from, and the
+        forward+loss closure over them.  Both towers' rows sit in ONE [2B, D]
+        buffer (saves the concatenation inside the network call)."""
+        B = example_batch[0].shape[0]
+        x12 = torch.cat([example_batch[0].cuda(), example_batch[1].cuda()])
+        x1, x2 = x12[:B], x12[B:]
+        y = example_batch[2].cuda().clone()
+
+        def fwd_loss():
+            e1, e2 = self.network.forward_pair_rows(x12)
+            return self.loss(e1, e2, y)
+        return [x1, x2, y], fwd_loss
 
     def _batches(self, train_mode):
         it = self.dataloader.batch_iterator(train_mode=train_mode)
@@ -372,3 +383,37 @@ class TrainerSiamese(TrainerBuilder):
         self.pretty_print_losses(train_loss / num_batches_train,
                                  dev_loss / num_batches_dev)
         return dev_loss
+
+
+class TrainerSiameseMultitask(TrainerSiamese):
+    """Siamese Trainer class for ABnet3 for multi task phn and spk
+    (abnet3/trainer.py:259-279): batches are (X1, X2, y_spk, y_phn)."""
+
+    def __init__(self, *args, **kwargs):
+        super(TrainerSiameseMultitask, self).__init__(*args, **kwargs)
+        assert type(self.network) == SiameseMultitaskNetwork
+
+    def give_batch_to_network(self, batch):
+        X_batch1, X_batch2, y_spk_batch, y_phn_batch = batch
+        X_batch1 = X_batch1.cuda(non_blocking=True)
+        X_batch2 = X_batch2.cuda(non_blocking=True)
+        y_spk_batch = y_spk_batch.cuda(non_blocking=True)
+        y_phn_batch = y_phn_batch.cuda(non_blocking=True)
+        emb_spk1, emb_phn1, emb_spk2, emb_phn2 = self.network(X_batch1, X_batch2)
+        return self.loss(emb_spk1, emb_phn1, emb_spk2, emb_phn2,
+                         y_spk_batch, y_phn_batch)
+
+    def _loss_is_mean(self):
+        spk = bool(getattr(self.loss.loss_spk, 'avg', False))
+        phn = bool(getattr(self.loss.loss_phn, 'avg', False))
+        if spk != phn:
+            raise NotImplementedError(
+                'abnet3_amd: data-parallel multitask training needs both base losses '
+                'to agree on avg (one summed and one averaged loss cannot share one '
+                'all-reduce scale)')
+        return spk
+
+    def _graph_inputs(self, example_batch):
+        static = [t.cuda().clone() for t in example_batch]
+        return static, lambda: self.give_batch_to_network(tuple(static))
+

@@ -21,6 +21,18 @@ def print_token(tok):
     return "{0} {1:.2f} {2:.2f}".format(tok[0], tok[1], tok[2])
 
 
+def read_spkid_file(spkid_file):
+    """{file id: speaker id} from lines "<fid> <spkid>" (abnet3/utils.py:23-31)."""
+    with open(spkid_file, 'r') as fh:
+        lines = fh.readlines()
+    spk = {}
+    for line in lines:
+        fid, spkid = line.strip().split(" ")
+        assert not (fid in spk)
+        spk[fid] = spkid
+    return spk
+
+
 def read_dataset(dataset_file):
     """[(file1, start1, end1, f2, s2, e2, pair_type), ...] (utils.py:156-173)."""
     with open(dataset_file, 'r') as fh:

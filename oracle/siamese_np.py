@@ -13,6 +13,10 @@ Reference lines restated (all relative to /root/reference):
   abnet3/loss.py:85-105     cosmargin
   abnet3/trainer.py:68-87   optimizer choice (torch.optim defaults)
   abnet3/trainer.py:236-242 zero_grad / backward / step
+  abnet3/model.py:211-376   SiameseMultitaskNetwork (shared trunk, two output heads;
+                            hidden_layers_spk / _phn are built but never called)
+  abnet3/loss.py:140-182    weighted_loss_multi
+  abnet3/trainer.py:259-279 TrainerSiameseMultitask.give_batch_to_network
 The backward pass restates what torch autograd executes for those modules.
 Dropout takes explicit masks (0 or 1/(1-p)); torch's CPU RNG stream is not
 restated, so p>0 is checked with masks shared between oracle and kernel.
@@ -132,8 +136,10 @@ def tower_forward(params, x, spec, train, update_running=True, masks=None):
     return a, cache
 
 
-def tower_backward(params, cache, dout, spec, grads=None):
-    """Autograd of forward_once in train mode; accumulates into `grads`."""
+def tower_backward(params, cache, dout, spec, grads=None, return_dx=False):
+    """Autograd of forward_once in train mode; accumulates into `grads`.
+    return_dx: also return the gradient w.r.t. the tower's input (needed when the
+    tower is a head sitting on a shared trunk)."""
     if grads is None:
         grads = {}
     da = np.ascontiguousarray(dout, dtype=F32)
@@ -157,8 +163,10 @@ def tower_backward(params, cache, dout, spec, grads=None):
         _acc(grads, spec.lin_keys[l] + '.weight', (dz.T @ a_in).astype(F32))
         _acc(grads, spec.lin_keys[l] + '.bias',
              dz.sum(axis=0, dtype=np.float64).astype(F32))
-        if l > 0:
+        if l > 0 or return_dx:
             da = (dz @ W).astype(F32)
+    if return_dx:
+        return grads, da
     return grads
 
 
@@ -290,3 +298,85 @@ def train_step(params, x1, x2, y, spec, opt, kind='coscos2', margin=0.5,
         tower_backward(params, c2, de2, spec, grads)
         opt.step(params, grads, spec.param_keys())
     return loss, grads, (e1, e2)
+
+
+# ---- multitask (model.py:211-376, loss.py:140-182, trainer.py:259-279) ------------
+
+class _Stack(object):
+    """A run of [Linear, Dropout, (BN), act] blocks with explicit state_dict keys:
+    the interface tower_forward / tower_backward need."""
+
+    def __init__(self, dims, lin_keys, bn_keys, act, batch_norm):
+        self.dims = dims
+        self.n_layers = len(dims) - 1
+        self.act = self.last_act = act
+        self.batch_norm = bool(batch_norm)
+        self.lin_keys, self.bn_keys = lin_keys, bn_keys
+
+    def layer_act(self, l):
+        return self.act
+
+
+class MultitaskSpec(object):
+    """SiameseMultitaskNetwork: input_emb + hidden_layers_shared feed BOTH
+    output_layer_spk and output_layer_phn (forward_once, model.py:337-345).
+    hidden_layers_spk / hidden_layers_phn hold parameters that forward never
+    uses: they receive no gradient and no optimizer update."""
+
+    def __init__(self, input_dim, num_hidden_layers_shared, num_hidden_layers_spk,
+                 num_hidden_layers_phn, hidden_dim, output_dim, activation_layer,
+                 batch_norm=False):
+        stride = 4 if batch_norm else 3
+        H = hidden_dim
+        self.batch_norm = bool(batch_norm)
+        self.trunk = _Stack(
+            [input_dim] + [H] * (num_hidden_layers_shared + 1),
+            ['input_emb.0'] + ['hidden_layers_shared.%d' % (stride * i)
+                               for i in range(num_hidden_layers_shared)],
+            ['input_emb.2'] + ['hidden_layers_shared.%d' % (stride * i + 2)
+                               for i in range(num_hidden_layers_shared)],
+            activation_layer, batch_norm)
+        self.head_spk = _Stack([H, output_dim], ['output_layer_spk.0'], ['output_layer_spk.2'],
+                               activation_layer, batch_norm)
+        self.head_phn = _Stack([H, output_dim], ['output_layer_phn.0'], ['output_layer_phn.2'],
+                               activation_layer, batch_norm)
+        self.dead = (['hidden_layers_spk.%d' % (stride * i) for i in range(num_hidden_layers_spk)]
+                     + ['hidden_layers_phn.%d' % (stride * i) for i in range(num_hidden_layers_phn)])
+
+    def live_param_keys(self):
+        keys = []
+        for st in (self.trunk, self.head_spk, self.head_phn):
+            for l in range(st.n_layers):
+                keys += [st.lin_keys[l] + '.weight', st.lin_keys[l] + '.bias']
+                if st.batch_norm:
+                    keys += [st.bn_keys[l] + '.weight', st.bn_keys[l] + '.bias']
+        return keys
+
+
+def multitask_forward_once(params, x, spec, train):
+    h, ct = tower_forward(params, x, spec.trunk, train)
+    es, cs = tower_forward(params, h, spec.head_spk, train)
+    ep, cp = tower_forward(params, h, spec.head_phn, train)
+    return es, ep, (ct, cs, cp)
+
+
+def multitask_train_step(params, x1, x2, y_spk, y_phn, spec, opt, weight,
+                         spk=('coscos2', 0.5, True), phn=('coscos2', 0.5, True),
+                         do_training=True):
+    """One batch of TrainerSiameseMultitask: loss = w*L_spk + (1-w)*L_phn
+    (loss.py:178-181); spk / phn = (kind, margin, avg) of the two base losses."""
+    s1, p1, c1 = multitask_forward_once(params, x1, spec, True)
+    s2, p2, c2 = multitask_forward_once(params, x2, spec, True)
+    ls, ds1, ds2, _ = pair_loss(s1, s2, y_spk, *spk)
+    lp, dp1, dp2, _ = pair_loss(p1, p2, y_phn, *phn)
+    w = F32(weight)
+    loss = F32(w * F32(ls) + (F32(1.0) - w) * F32(lp))
+    grads = {}
+    if do_training:
+        for (ct, cs, cp), ds, dp in ((c1, ds1, dp1), (c2, ds2, dp2)):
+            _, dh_s = tower_backward(params, cs, (w * ds).astype(F32), spec.head_spk, grads, True)
+            _, dh_p = tower_backward(params, cp, ((F32(1.0) - w) * dp).astype(F32), spec.head_phn,
+                                     grads, True)
+            tower_backward(params, ct, (dh_s + dh_p).astype(F32), spec.trunk, grads)
+        opt.step(params, grads, spec.live_param_keys())
+    return loss, grads, (s1, p1, s2, p2)

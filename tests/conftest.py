@@ -39,7 +39,7 @@ def is_pre_bn_bias(k, batch_norm):
     if not batch_norm or not k.endswith('.bias'):
         return False
     parts = k.split('.')
-    return int(parts[1]) % 4 == 0 if parts[0] == 'hidden_layers' else parts[1] == '0'
+    return int(parts[1]) % 4 == 0 if parts[0].startswith('hidden_layers') else parts[1] == '0'
 
 
 def check_params(mine, ref, keys, batch_norm, tol=1e-5):

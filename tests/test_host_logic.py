@@ -144,3 +144,56 @@ def test_reference_is_never_needed_at_run_time():
                 text = open(os.path.join(dirpath, f)).read()
                 assert '/root/reference' not in text, f
                 assert 'import oracle' not in text and 'from oracle' not in text, f
+
+
+def test_multitask_surface_host_side(tmp_path):
+    """SiameseMultitaskNetwork / weighted_loss_multi / same_speaker: everything
+    that needs no GPU."""
+    import ast
+    from conftest import load_golden
+    from abnet3_amd._lib import HipLibraryError
+    from abnet3_amd.model import SiameseMultitaskNetwork, NetworkBuilder
+    from abnet3_amd.loss import weighted_loss_multi, coscos2, cosmargin
+    from abnet3_amd.dataloader import OriginalDataLoader, MultiTaskDataLoader
+    g = load_golden('multitask_relu_bn.npz')
+    kw = ast.literal_eval(str(g['kw']))
+    torch.manual_seed(5)
+    net = SiameseMultitaskNetwork(output_path=str(tmp_path / 'mt'), **kw)
+    assert isinstance(net, NetworkBuilder)
+    sd = net.state_dict()
+    assert sorted(sd) == sorted(k[2:] for k in g if k.startswith('p.'))
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), g['p.' + k]), k      # reference init from the same seed
+    # the branches forward never calls stay out of the flat bucket
+    live = net.live_parameters()
+    dead = [p for k, p in net.named_parameters() if k.startswith(('hidden_layers_spk', 'hidden_layers_phn'))]
+    assert dead and not any(any(p is q for q in live) for p in dead)
+    assert len(live) + len(dead) == len(list(net.parameters()))
+    flat = net.flat_parameters()
+    assert net._is_flat() and flat.numel() == sum((p.numel() + 63) // 64 * 64 for p in live)
+    for k, v in net.state_dict().items():
+        assert np.array_equal(v.numpy(), g['p.' + k]), k
+    net.save_network()
+    other = SiameseMultitaskNetwork(**kw)
+    other.load_network(str(tmp_path / 'mt.pth'))
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), other.state_dict().values()))
+    with pytest.raises(HipLibraryError):
+        net(torch.randn(3, 40), torch.randn(3, 40))
+    with pytest.raises(AssertionError):
+        SiameseMultitaskNetwork(**dict(kw, num_hidden_layers_spk=None))
+    with pytest.raises(AssertionError):
+        SiameseMultitaskNetwork(**dict(kw, activation_layer='softmax'))
+
+    with pytest.raises(AssertionError):
+        weighted_loss_multi(loss_spk=coscos2(), loss_phn=coscos2(), weight=1)      # int, not float
+    with pytest.raises(AssertionError):
+        weighted_loss_multi(loss_spk=coscos2(), loss_phn=coscos2(), weight=1.5)
+    w = weighted_loss_multi(loss_spk=coscos2(avg=False), loss_phn=cosmargin())
+    assert w.weight == 0.5 and w.avg is True and w.whoami()['class_name'] == 'weighted_loss_multi'
+
+    dl = OriginalDataLoader('p', 'f')
+    spk = {'u0': 'alice', 'u1': ''.join(['ali', 'ce']), 'u2': 'b', 'u3': 'b'}
+    assert dl.same_speaker(spk, 'u0', 'u0') and not dl.same_speaker(spk, 'u0', 'u1')
+    assert dl.same_speaker(spk, 'u2', 'u3') and not dl.same_speaker(spk, 'u1', 'u2')
+    ml = MultiTaskDataLoader('p', 'f', fid2spk_file='x', speaker_match='equal')
+    assert ml.same_speaker(spk, 'u0', 'u1') and not ml.same_speaker(spk, 'u0', 'u2')

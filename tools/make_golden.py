@@ -18,6 +18,9 @@ Fixture sets:
   G6 stack        FeaturesGenerator.stack_fbanks
   G7 frames       OriginalDataLoader.load_frames_from_pairs (needs the oracle DTW
                   monkey-patched in as get_dtw_alignment; third-party dtw absent)
+  G8 multitask_*  SiameseMultitaskNetwork + weighted_loss_multi: forward (eval,
+                  train), every gradient, params after 3 steps; and the speaker
+                  labels of load_frames_from_pairs(fid2spk=...)
 
 usage: python tools/make_golden.py [--only G1,G3]
 """
@@ -389,8 +392,108 @@ def g7_frames(abnet3):
     np.savez_compressed(os.path.join(OUT, 'frames.npz'), **out)
 
 
+def g8_multitask(abnet3):
+    """G8: SiameseMultitaskNetwork (model.py:211-376) + weighted_loss_multi
+    (loss.py:140-182), re-enacting TrainerSiameseMultitask.give_batch_to_network
+    (trainer.py:259-279) and trainer.py:236-242."""
+    import torch
+    cases = {
+        'sig': dict(activation_layer='sigmoid', batch_norm=False, num_hidden_layers_shared=1,
+                    num_hidden_layers_spk=1, num_hidden_layers_phn=0),
+        'relu_bn': dict(activation_layer='relu', batch_norm=True, num_hidden_layers_shared=2,
+                        num_hidden_layers_spk=0, num_hidden_layers_phn=1),
+        'tanh0': dict(activation_layer='tanh', batch_norm=False, num_hidden_layers_shared=0,
+                      num_hidden_layers_spk=0, num_hidden_layers_phn=0),
+    }
+    for name, extra in cases.items():
+        kw = dict(input_dim=40, hidden_dim=64, output_dim=24, p_dropout=0.0,
+                  type_init='xavier_uni')
+        kw.update(extra)
+        x1, x2, y_spk = make_inputs(48, 40, 3)
+        np.random.seed(11)
+        y_phn = np.random.choice([1, -1], 48)
+        out = {'x1': x1.numpy(), 'x2': x2.numpy(), 'y_spk': y_spk, 'y_phn': y_phn,
+               'kw': np.array(repr(kw))}
+        torch.manual_seed(5)
+        net = abnet3.model.SiameseMultitaskNetwork(**kw)
+        out.update(sd_to_np(net))
+        net.eval()
+        with torch.no_grad():
+            s1, p1, s2, p2 = net(x1, x2)
+        for k, v in (('spk1', s1), ('phn1', p1), ('spk2', s2), ('phn2', p2)):
+            out['eval_' + k] = v.numpy()
+        for oname, weight in (('sgd', 0.3), ('adadelta', 0.5), ('adam', 1.0)):
+            torch.manual_seed(5)
+            net = abnet3.model.SiameseMultitaskNetwork(**kw)
+            loss_mod = abnet3.loss.weighted_loss_multi(
+                loss_spk=abnet3.loss.coscos2(avg=False),
+                loss_phn=abnet3.loss.cosmargin(avg=True, margin=0.4), weight=weight)
+            opt = OPTIMS[oname](torch, net.parameters())
+            net.train()
+            tag = '%s.w%g' % (oname, weight)
+            losses = []
+            for s in range(3):
+                emb = net(x1, x2)
+                lv = loss_mod(emb[0], emb[1], emb[2], emb[3], torch.from_numpy(y_spk),
+                              torch.from_numpy(y_phn))
+                opt.zero_grad()
+                lv.backward()
+                if s == 0:
+                    for k, p in net.named_parameters():
+                        # dead branches (hidden_layers_spk / _phn) get no gradient at all
+                        out['%s.grad0.%s' % (tag, k)] = (
+                            p.grad.detach().numpy().copy() if p.grad is not None
+                            else np.zeros(0, dtype=np.float32))
+                    for k, v in zip(('spk1', 'phn1', 'spk2', 'phn2'), emb):
+                        out['%s.%s_0' % (tag, k)] = v.detach().numpy().copy()
+                opt.step()
+                losses.append(float(lv.detach()))
+            out['%s.losses' % tag] = np.array(losses, dtype=np.float64)
+            for k, v in net.state_dict().items():
+                out['%s.after.%s' % (tag, k)] = v.detach().numpy().copy()
+        np.savez_compressed(os.path.join(OUT, 'multitask_%s.npz' % name), **out)
+
+    # speaker labels of the multitask loader (dataloader.py:195-201,235-241): the
+    # reference compares the speaker strings with `is`
+    sys.path.insert(0, REPO)
+    from oracle import dtw_oracle
+    rng = np.random.default_rng(8)
+    feats = {'u%d' % i: rng.standard_normal((n, 40)).astype(np.float32)
+             for i, n in enumerate((80, 60, 75))}
+    times = {k: (np.arange(len(v)) * 0.01 + 0.0025) for k, v in feats.items()}
+    acc = abnet3.utils.Features_Accessor(times, feats)
+
+    def oracle_align(f1, f2):
+        d = abnet3.utils.cosine_distance(f1, f2)
+        a, b = dtw_oracle.dtw_path(d)
+        return list(a), list(b)
+
+    abnet3.dataloader.get_dtw_alignment = oracle_align
+    import tempfile
+    with tempfile.NamedTemporaryFile('w', suffix='.spk', delete=False) as fh:
+        fh.write('u0 alice\nu1 alice\nu2 b\n')
+        spk_path = fh.name
+    fid2spk = abnet3.utils.read_spkid_file(spk_path)
+    os.unlink(spk_path)
+    pairs = [('u0', 0.10, 0.40, 'u1', 0.05, 0.33, 'same'),    # same speaker name, two files
+             ('u0', 0.12, 0.30, 'u0', 0.41, 0.66, 'same'),    # same file
+             ('u1', 0.20, 0.45, 'u2', 0.10, 0.31, 'diff'),
+             ('u2', 0.05, 0.22, 'u2', 0.40, 0.61, 'diff')]
+    out = {'pairs': np.array([' '.join(map(str, q)) for q in pairs]),
+           'spk_file': np.array('u0 alice\nu1 alice\nu2 b\n')}
+    for k, v in feats.items():
+        out['feat.' + k] = v
+    dl = abnet3.dataloader.OriginalDataLoader('unused', 'unused', align_different_words=False)
+    dl.features = acc
+    X1, X2, y_spk, y_phn = dl.load_frames_from_pairs(abnet3.utils.group_pairs(pairs),
+                                                     fid2spk=fid2spk)
+    out['X1'], out['X2'], out['y_spk'], out['y_phn'] = X1, X2, y_spk, y_phn
+    np.savez_compressed(os.path.join(OUT, 'multitask_frames.npz'), **out)
+
+
 ALL = {'G1': g1_tower, 'G2': g2_train_c1, 'G3': g3_loss_edge,
-       'G4': g4_train_mid, 'G5': g5_cosdist, 'G6': g6_stack, 'G7': g7_frames}
+       'G4': g4_train_mid, 'G5': g5_cosdist, 'G6': g6_stack, 'G7': g7_frames,
+       'G8': g8_multitask}
 
 
 def main():
