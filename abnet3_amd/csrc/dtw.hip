@@ -437,7 +437,7 @@ struct WsPlan {
 using namespace abn;
 
 // Side streams for the DP size classes, one set per device, created on first use.
-constexpr int N_SIDE = 3;
+constexpr int N_SIDE = 4;
 struct SideStreams {
     std::mutex mu;              // the fork / join events are shared by all callers
     hipStream_t s[N_SIDE];
@@ -599,9 +599,10 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
         acc_first += class_count[c];
         if (class_count[c] > 0) by_work[nclasses++] = c;
     }
-    std::sort(by_work, by_work + nclasses, [&](int x, int y) {
-        return class_count[x] * DP_CLASSES[x] > class_count[y] * DP_CLASSES[y];
-    });
+    // A class with few pairs is latency-bound (one wavefront sweeps a pair; its time grows
+    // with rows-per-lane x steps), so the widest classes start first, each on its own
+    // stream; the narrow, fast ones queue up behind them.
+    std::sort(by_work, by_work + nclasses, [&](int x, int y) { return x > y; });
     SideStreams* side = nclasses > 1 ? side_streams() : nullptr;
     std::unique_lock<std::mutex> guard;
     if (side) {
