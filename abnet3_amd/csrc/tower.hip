@@ -469,7 +469,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES);
             attr_set = true;
         }
-        hipLaunchKernelGGL(tower_fwd_fused_kernel, dim3((unsigned)((rows + FUSED_ROWS - 1) / FUSED_ROWS)), dim3(256),
+        hipLaunchKernelGGL(tower_fwd_fused_kernel, dim3((unsigned)((rows + FUSED_ROWS - 1) / FUSED_ROWS)), dim3(FUSED_NT),
                            FUSED_LDS_BYTES, st, f);
         ABN_CHECK_LAUNCH("tower_fwd_fused");
         return ABN_OK;

@@ -11,7 +11,7 @@
 //                                conflicts for the MFMA A-fragment column reads)
 //        Wst[wave][3][32*BPW][16]  per-WAVE ring of weight tiles filled by LDS-DMA
 //
-//   wave w owns output columns  w*32*BPW .. +32*BPW  (BPW = 1, 2 or 4 MFMA blocks)
+//   8 waves; wave w owns output columns  w*32*BPW .. +32*BPW  (BPW = 1 or 2 MFMA blocks)
 //   k-loop: 16-deep tiles; the wave's own weight slice W[cols][k0..k0+16) comes in
 //   by global_load_lds_dwordx4, two tiles ahead of the MFMAs (L2 latency under
 //   this load is ~1.6 us).  The weight ring is private to the wave, so the k-loop
@@ -38,8 +38,11 @@ constexpr int FUSED_MAXW = 512;                 // widest layer the LDS image ho
 constexpr int FUSED_XS = 512;                   // row stride of X (swizzled chunks)
 constexpr int FUSED_BK = 16;                    // k-tile of the weight ring
 constexpr int FUSED_STAGES = 3;                 // ring depth: two tiles in flight
-constexpr int FUSED_WTILE = 128 * FUSED_BK;     // floats of one weight stage of one wave (BPW = 4)
-constexpr size_t FUSED_LDS_BYTES = sizeof(float) * (FUSED_ROWS * FUSED_XS + 4 * FUSED_STAGES * FUSED_WTILE);
+constexpr int FUSED_WAVES = 8;                  // two wavefronts per SIMD: one's LDS / DMA waits hide behind the other's MFMAs
+constexpr int FUSED_NT = 64 * FUSED_WAVES;
+constexpr int FUSED_MAXBPW = FUSED_MAXW / 32 / FUSED_WAVES;      // 2 MFMA column blocks per wave at the widest layer
+constexpr int FUSED_WTILE = 32 * FUSED_MAXBPW * FUSED_BK;        // floats of one weight stage of one wave
+constexpr size_t FUSED_LDS_BYTES = sizeof(float) * (FUSED_ROWS * FUSED_XS + FUSED_WAVES * FUSED_STAGES * FUSED_WTILE);
 static_assert(FUSED_LDS_BYTES <= 160 * 1024, "fused tower image must fit the 160 KiB LDS");
 
 struct FusedFwdP {
@@ -74,7 +77,10 @@ __device__ __forceinline__ int x_off(int row, int k)
 
 // One layer for one workgroup.  X holds the input rows (zero beyond K up to the
 // next multiple of 32); on return it holds this layer's output the same way.
-template <int BPW>
+// KS = 2 (narrow layers, at most 4 column blocks): waves 4..7 take the second half of
+// K for the same columns as waves 0..3 and hand their partial sums over through LDS,
+// so that every SIMD still runs two wavefronts.
+template <int BPW, int KS>
 __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __restrict__ X,
                                             float* __restrict__ Wst, int wave, int lane, int row0)
 {
@@ -83,8 +89,11 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
     const int K = p.dims[l], N = p.dims[l + 1];
     const float* __restrict__ W = p.W[l];
     const int rl = lane & 31, h = lane >> 5;
-    const int nkt = (K + 31) / 32 * 2;           // 16-deep tiles over K padded to 32 (X is zero there)
-    const int col0 = wave * CW;
+    const int nkt_all = (K + 31) / 32 * 2;       // 16-deep tiles over K padded to 32 (X is zero there)
+    const int khalf = KS == 2 ? wave / (FUSED_WAVES / 2) : 0;
+    const int kt_first = KS == 2 ? khalf * (nkt_all / 2) : 0;
+    const int nkt = KS == 2 ? nkt_all / 2 : nkt_all;                     // tiles this wave sweeps (nkt_all is even)
+    const int col0 = (KS == 2 ? wave % (FUSED_WAVES / 2) : wave) * CW;
 
     f32x16 acc[BPW];
 #pragma unroll
@@ -108,7 +117,7 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
     const int kc_lane = 4 * ((lane & 3) ^ ((lane >> 3) & 3));      // (n >> 1) & 3 == (lane >> 3) & 3
     auto dma = [&](int kt, int stage) {
         float* dst = Wst + stage * FUSED_WTILE;
-        int gk = kt * FUSED_BK + kc_lane;
+        int gk = (kt_first + kt) * FUSED_BK + kc_lane;
         gk = gk <= K - 4 ? gk : K - 4;
         const float* src = W + gk;
 #pragma unroll
@@ -118,8 +127,11 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
                 (__attribute__((address_space(3))) void*)(dst + 256 * i), 16, 0, 0);
     };
     FSTAMP(1 + 3 * l);
+    const int npad = (N + 31) / 32 * 32;
+    const bool active = col0 < npad;              // narrow layers leave the upper waves without columns
+    if (active) {
     dma(0, 0);
-    dma(1, 1);                                    // nkt >= 2 always
+    if (nkt > 1) dma(1, 1);
     // lane-invariant parts of the fragment addresses
     const float* const xrow = X + rl * FUSED_XS;
     const int xsw = rl & 7;
@@ -148,8 +160,7 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
         // tile kt has landed when at most the NEXT tile's DMAs are outstanding
         // (vmcnt retires in order; older activation stores drain first)
         if (kt + 1 < nkt) {
-            if constexpr (BPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if constexpr (BPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -157,7 +168,7 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
         // stage (kt+2)%3 == (kt-1)%3 was read during tile kt-1: free now
         if (kt + 2 < nkt) dma(kt + 2, (kt + 2) % FUSED_STAGES);
         const float* ws = Wst + (kt % FUSED_STAGES) * FUSED_WTILE;
-        const int k0 = kt * FUSED_BK;
+        const int k0 = (kt_first + kt) * FUSED_BK;
         // with one wave per SIMD nothing but the wave itself hides LDS latency:
         // the second k-group's fragments are read before the first group's MFMAs
         f32x4 fa0, fa1, fb0[BPW], fb1[BPW];
@@ -166,12 +177,21 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
         mfmas(fa0, fb0);
         mfmas(fa1, fb1);
     }
+    }
+    if (KS == 2 && active && khalf == 1) {         // partial sums of the upper K half -> this wave's (idle) ring
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Wst[r * 64 + lane] = acc[0][r];
+    }
     FSTAMP(2 + 3 * l);
     __syncthreads();                               // every wave is done reading X
+    if (KS == 2 && active && khalf == 0) {
+        const float* part = Wst + (FUSED_WAVES / 2) * FUSED_STAGES * FUSED_WTILE;   // wave + 4's ring
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] += part[r * 64 + lane];
+    }
     // epilogue: bias, dropout mask, activation -> X (input of the next layer),
     // zero up to the next multiple of 32 (the next layer's k padding)
     const int act = p.act[l];
-    const int npad = (N + 31) / 32 * 32;
     const float* __restrict__ mask = p.mask[l];
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
@@ -179,7 +199,7 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
         const bool live = col < N;
         const int colc = live ? col : 0;
         const float bias = p.b[l] ? p.b[l][colc] : 0.0f;
-        if (col < npad) {                       // one branch per 32-column block, not per element
+        if (col < npad && khalf == 0) {         // one branch per 32-column block, not per element
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -199,7 +219,7 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
     // 16 bytes per lane; asynchronous: nobody waits for these stores
     float* __restrict__ out = p.out[l];
     const int n4 = N / 4;
-    for (int i = threadIdx.x; i < FUSED_ROWS * n4; i += 256) {
+    for (int i = threadIdx.x; i < FUSED_ROWS * n4; i += FUSED_NT) {
         const int r = i / n4, c = 4 * (i % n4);
         if (row0 + r < p.rows)
             *reinterpret_cast<f32x4*>(out + (int64_t)(row0 + r) * N + c) =
@@ -207,7 +227,7 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
     }
 }
 
-__global__ __launch_bounds__(256) void tower_fwd_fused_kernel(FusedFwdP p)
+__global__ __launch_bounds__(FUSED_NT) void tower_fwd_fused_kernel(FusedFwdP p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const X = smem;
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(256) void tower_fwd_fused_kernel(FusedFwdP p)
     FSTAMP(0);
 
     // input rows -> X (zero padded), + the concatenated copy for the backward
-    for (int i = threadIdx.x; i < FUSED_ROWS * (FUSED_XS / 4); i += 256) {
+    for (int i = threadIdx.x; i < FUSED_ROWS * (FUSED_XS / 4); i += FUSED_NT) {
         const int r = i / (FUSED_XS / 4), c = 4 * (i % (FUSED_XS / 4));
         const int gr = row0 + r;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -234,9 +254,9 @@ __global__ __launch_bounds__(256) void tower_fwd_fused_kernel(FusedFwdP p)
 
     for (int l = 0; l < p.n_layers; ++l) {
         const int N = p.dims[l + 1];
-        if (N > 256) fused_layer<4>(p, l, X, Wst, wave, lane, row0);
-        else if (N > 128) fused_layer<2>(p, l, X, Wst, wave, lane, row0);
-        else fused_layer<1>(p, l, X, Wst, wave, lane, row0);
+        if (N > 32 * FUSED_WAVES) fused_layer<2, 1>(p, l, X, Wst, wave, lane, row0);
+        else if (N > 16 * FUSED_WAVES) fused_layer<1, 1>(p, l, X, Wst, wave, lane, row0);
+        else fused_layer<1, 2>(p, l, X, Wst, wave, lane, row0);
     }
     FSTAMP(1 + 3 * p.n_layers);
 }

@@ -15,6 +15,23 @@ import torch.nn as nn
 from . import _lib
 
 
+_UNIT = {}        # device -> 0-dim tensor holding 1.0, never written again
+
+
+def unit_grad(device):
+    """The gradient seed d loss / d loss = 1 as a cached device tensor.  A trainer
+    that starts backward with it (torch.autograd.backward(loss, unit_grad(dev)))
+    saves autograd's ones_like fill, and the pair loss recognises it by address and
+    hands its stored gradient back without the multiply by 1."""
+    key = torch.device(device)
+    if key.type == 'cuda' and key.index is None:
+        key = torch.device('cuda', torch.cuda.current_device())
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones((), dtype=torch.float32, device=key)
+    return t
+
+
 class _PairLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e1, e2, y, kind, margin, avg):
@@ -46,7 +63,10 @@ class _PairLossFunction(torch.autograd.Function):
         if de is None:
             return None, None, None, None, None, None
         # d loss / d e was produced with the forward; chain the incoming scalar
-        de = de * g
+        # (unless it is the cached unit seed, identified by its address)
+        unit = _UNIT.get(g.device)
+        if unit is None or g.data_ptr() != unit.data_ptr():
+            de = de * g
         return de[0], de[1], None, None, None, None
 
 

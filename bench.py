@@ -288,10 +288,12 @@ def main():
     pool = make_pool(seed=rank, device=dev)    # rank r sees its own pairs
     net.train()
     stepper = trainer.make_graphed_step(pool[0]) if not args.no_graph else None
+    # what a device-side batch builder hands over: each batch as one packed blob
+    packed = [trainer.pack_batch(b) for b in pool] if stepper is not None else None
 
     def step(i):
         if stepper is not None:
-            return stepper(pool[i % POOL])
+            return stepper(packed[i % POOL])
         return trainer.train_step(pool[i % POOL], True)
 
     for i in range(args.warmup):

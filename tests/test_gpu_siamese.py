@@ -329,3 +329,38 @@ def test_reference_style_update_all_weights_with_default_dropout():
             opt.step()
             for a, b in zip(before, net.parameters()):
                 assert (a != b).any(), name
+
+
+def test_graphed_step_equals_eager_step():
+    """make_graphed_step (hipGraph replay, tuple batches and pack_batch blobs) takes
+    the same steps as the eager TrainerSiamese.train_step, which the golden tests pin."""
+    import abnet3_amd.loss as L
+    from abnet3_amd.trainer import TrainerSiamese
+    g = load_golden('train_mid_bn0.npz')
+    rng = np.random.default_rng(3)
+    batches = [(dev(rng.standard_normal((96, 40)).astype(np.float32)),
+                dev(rng.standard_normal((96, 40)).astype(np.float32)),
+                dev(rng.choice([1.0, -1.0], 96))) for _ in range(3)]
+    results = []
+    for mode in ('eager', 'graph', 'graph_packed'):
+        net, _ = cuda_net(g)
+        net.output_path = '/tmp/abn_graph_test'
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta',
+                            lr=0.1, dataloader=None, log_dir='/tmp/abn_runs')
+        net.train()
+        losses = []
+        if mode == 'eager':
+            for s in range(2):                      # the warm-up steps of the graphed variants
+                tr.train_step(batches[0], True)
+            for s in range(6):
+                losses.append(float(tr.train_step(batches[s % 3], True)))
+        else:
+            step = tr.make_graphed_step(batches[0], warmup=2)
+            feed = [tr.pack_batch(b) for b in batches] if mode == 'graph_packed' else batches
+            for s in range(6):
+                losses.append(float(step(feed[s % 3])))
+        results.append((losses, {k: p.detach().cpu().numpy().copy() for k, p in net.named_parameters()}))
+    for losses, params in results[1:]:
+        assert np.allclose(losses, results[0][0], rtol=1e-6, atol=0)
+        for k, v in params.items():           # (the flat buffer's alignment gaps hold no parameters)
+            assert rel_err(v, results[0][1][k]) < 1e-6, k
