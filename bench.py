@@ -51,56 +51,109 @@ def make_pool(seed, device):
     return pool
 
 
-def gemm_roofline(torch, reps=50):
-    """Times the dominant kernel -- gemm_f32_kernel<128, 64, true, true, 0, true>,
-    launched three times per step (layers 40->500, 500->500, 500->500 over the
-    2x4096 tower rows) -- in isolation through the single-layer C-ABI entry,
-    with HIP events on the launch stream; reports per-launch averages."""
-    from abnet3_amd import _lib
-    lib = _lib.load()
-    dev = 'cuda'
-    rows = 2 * BATCH
-    shapes = [(40, 500), (500, 500), (500, 500)]
-    bufs = []
-    for k, n in shapes:
-        bufs.append((torch.randn(rows, k, device=dev), torch.randn(n, k, device=dev) * 0.05,
-                     torch.zeros(n, device=dev), torch.empty(rows, n, device=dev)))
+FUSED_KERNEL = 'abn::tower_fwd_fused_kernel(abn::FusedFwdP)'
+DGRAD_KERNEL = 'void abn::gemm_f32_kernel<128, 64, true, false, 1, true>(abn::GemmP)'
+WGRAD_KERNEL = 'void abn::gemm_f32_kernel<128, 64, false, false, 2, true>(abn::GemmP)'
 
-    def run_all():
-        for (k, n), (x, w, b, y) in zip(shapes, bufs):
-            _lib.check(lib.abn_linear_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), rows, k, n,
-                                              _lib.ACT['sigmoid'], _lib.ptr(y), _lib.stream()),
-                       'abn_linear_forward')
-    for _ in range(10):
-        run_all()
+
+def _time_launches(torch, fn, reps):
+    """Average GPU time of one fn() (a fixed launch sequence): `reps` calls are
+    captured into ONE hipGraph, so the HIP events around its replays (recorded on
+    the stream the graph -- and in the step, the C-ABI calls -- launch on) see the
+    kernels back to back, as the rocprofv3 kernel trace does, not the host's
+    launch gaps."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            fn()
+    graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        run_all()
+    for _ in range(4):
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    launches = reps * len(shapes)
-    avg_s = e0.elapsed_time(e1) * 1e-3 / launches
-    flop_per_launch = sum(2.0 * rows * k * n for k, n in shapes) / len(shapes)
-    achieved = flop_per_launch / avg_s / 1e12
-    # HBM bytes per launch of this kernel from the TCC counters (FETCH_SIZE x2 per
-    # the gfx950 correction + WRITE_SIZE), collected by tools/collect_traffic.sh
-    # in separate --pmc passes and committed under profiles/
-    traffic = None
+    return e0.elapsed_time(e1) * 1e-3 / (4 * reps)
+
+
+def _traffic(kernel):
+    """HBM bytes per launch from the TCC counters (FETCH_SIZE x2 per the gfx950
+    correction + WRITE_SIZE), collected by tools/collect_traffic.sh in separate
+    --pmc passes and committed under profiles/."""
     try:
         t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
         for name, v in t.items():
-            if 'gemm_f32_kernel<128, 64, true, true, 0, true>' in name:
-                traffic = round(v['hbm_bytes_per_launch'])
+            if kernel in name:
+                return round(v['hbm_bytes_per_launch'])
     except Exception:
         pass
-    return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
-            'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            'traffic': traffic,
-            'kernel': 'abn::gemm_f32_kernel<128, 64, true, true, 0, true>  (forward: A, B K-contiguous, 16-byte loads)',
-            'avg_launch_us': round(avg_s * 1e6, 2),
-            'flop_per_launch': flop_per_launch}
+    return None
+
+
+def tower_roofline(torch, net, reps=20):
+    """The dominant kernel of the step: tower_fwd_fused_kernel, ONE launch for the
+    forward of both towers (2 x 4096 rows through 40->500->500->500->100, about 30 %
+    of the step).  Timed with HIP events on the launch stream around the same
+    call the step makes (abn_tower_forward, train mode, activations stored for the
+    backward); algorithmic FLOPs per launch = 2 * rows * sum(in*out) (SURVEY.md 8d:
+    570 000 MAC per tower row)."""
+    from abnet3_amd import _lib
+    rows = 2 * BATCH
+    x12 = torch.randn(rows, 40, device='cuda')
+    net.train()
+
+    def fwd():
+        with torch.no_grad():
+            net.forward_pair_rows(x12)
+    avg_s = _time_launches(torch, fwd, reps)
+    flop = 2.0 * rows * (40 * 500 + 2 * 500 * 500 + 500 * 100)
+    achieved = flop / avg_s / 1e12
+    out = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
+           'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+           'traffic': _traffic('tower_fwd_fused_kernel'),
+           'kernel': FUSED_KERNEL + '  (whole forward of both towers in one launch)',
+           'avg_launch_us': round(avg_s * 1e6, 2), 'flop_per_launch': flop}
+    # the backward's two GEMM kernels at the step's own shapes, through the single-layer entries
+    lib = _lib.load()
+    others = []
+    shapes = [(500, 100), (500, 500), (500, 500)]          # dgrad: no input-layer dgrad
+    bufs = [(torch.randn(rows, n, device='cuda'), torch.randn(n, k, device='cuda') * 0.05,
+             torch.rand(rows, k, device='cuda'), torch.empty(rows, k, device='cuda')) for k, n in shapes]
+
+    def dgrad():
+        for (k, n), (dz, w, a, dx) in zip(shapes, bufs):
+            _lib.check(lib.abn_linear_dgrad(_lib.ptr(dz), _lib.ptr(w), rows, k, n, _lib.ptr(a),
+                                            _lib.ACT['sigmoid'], _lib.ptr(dx), _lib.stream()), 'abn_linear_dgrad')
+    t = _time_launches(torch, dgrad, reps) / len(shapes)
+    fl = sum(2.0 * rows * k * n for k, n in shapes) / len(shapes)
+    others.append({'kernel': DGRAD_KERNEL + '  (dgrad, fused activation derivative; 3 launches per step)',
+                   'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                   'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl, 'traffic': _traffic(DGRAD_KERNEL)})
+    k, n = 500, 500
+    dz, a = torch.randn(rows, n, device='cuda'), torch.rand(rows, k, device='cuda')
+    dW, db = torch.empty(n, k, device='cuda'), torch.empty(n, device='cuda')
+    sc_n = lib.abn_linear_wgrad_scratch_floats(rows, k, n)
+    sc = torch.empty(sc_n, device='cuda')
+
+    def wgrad():
+        _lib.check(lib.abn_linear_wgrad(_lib.ptr(dz), _lib.ptr(a), rows, k, n, _lib.ptr(dW), _lib.ptr(db),
+                                        _lib.ptr(sc), sc_n, _lib.stream()), 'abn_linear_wgrad')
+    t = _time_launches(torch, wgrad, reps)
+    fl = 2.0 * rows * k * n
+    others.append({'kernel': WGRAD_KERNEL + '  (wgrad 500x500, split-K; the time includes its slab reduction)',
+                   'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                   'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl, 'traffic': _traffic(WGRAD_KERNEL)})
+    out['backward_kernels'] = others
+    return out
 
 
 def cpu_baseline(torch, budget_s=12.0):
@@ -333,7 +386,7 @@ def main():
             'tflops_whole_step': round(value * FLOP_PER_PAIR / 1e12, 2),
             'last_loss': last_loss,
         }
-        out['roofline'] = gemm_roofline(torch)
+        out['roofline'] = tower_roofline(torch, net)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(torch)
             out['cpu_baseline'] = cb

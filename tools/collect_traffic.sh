@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of the dominant GEMM kernel from the TCC counters, collected as
+# HBM traffic of the step kernels (fused forward, dgrad, wgrad, ...) from the TCC counters, collected as
 # MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc
 # passes (3 + 2 TCC slots), kernel-trace only.  Run on the GPU box:
 #   tools/collect_traffic.sh gpurun_out/traffic
