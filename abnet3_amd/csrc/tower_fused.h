@@ -178,7 +178,34 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
         mfmas(fa1, fb1);
     }
     }
-    if (KS == 2 && active && khalf == 1) {         // partial sums of the upper K half -> this wave's (idle) ring
+    // epilogue: bias, dropout mask, activation -> X (input of the next layer), zero up to
+    // the next multiple of 32 (the next layer's k padding).  The waves leave the k-loop
+    // a few thousand cycles apart (each streams its own weights), so everything that
+    // does not touch X -- bias, mask, activation, in registers -- runs BEFORE the
+    // barrier, in the time the wave would otherwise spend waiting for the slowest one.
+    const int act = p.act[l];
+    const float* __restrict__ mask = p.mask[l];
+    auto finish = [&]() {
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int col = col0 + 32 * j + rl;
+            const int colc = col < N ? col : 0;
+            const float bias = p.b[l] ? p.b[l][colc] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[j][r] + bias;
+                if (mask) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int gr = min(row0 + row, p.rows - 1);
+                    v *= mask[(int64_t)gr * N + colc];
+                }
+                acc[j][r] = act_apply(v, act);
+            }
+        }
+    };
+    if (KS == 1) {
+        if (active) finish();
+    } else if (active && khalf == 1) {             // partial sums of the upper K half -> this wave's (idle) ring
 #pragma unroll
         for (int r = 0; r < 16; ++r) Wst[r * 64 + lane] = acc[0][r];
     }
@@ -188,28 +215,17 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
         const float* part = Wst + (FUSED_WAVES / 2) * FUSED_STAGES * FUSED_WTILE;   // wave + 4's ring
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] += part[r * 64 + lane];
+        finish();
     }
-    // epilogue: bias, dropout mask, activation -> X (input of the next layer),
-    // zero up to the next multiple of 32 (the next layer's k padding)
-    const int act = p.act[l];
-    const float* __restrict__ mask = p.mask[l];
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
         const int col = col0 + 32 * j + rl;
-        const bool live = col < N;
-        const int colc = live ? col : 0;
-        const float bias = p.b[l] ? p.b[l][colc] : 0.0f;
         if (col < npad && khalf == 0) {         // one branch per 32-column block, not per element
+            const bool live = col < N;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                float v = acc[j][r] + bias;
-                if (mask) {
-                    const int gr = min(row0 + row, p.rows - 1);
-                    v *= mask[(int64_t)gr * N + colc];
-                }
-                v = act_apply(v, act);
-                X[x_off(row, col)] = live ? v : 0.0f;
+                X[x_off(row, col)] = live ? acc[j][r] : 0.0f;
             }
         }
     }
