@@ -375,6 +375,14 @@ class _HipNetwork(NetworkBuilder):
         return masks
 
     def _run(self, seg, grad_pass, masks, x1, x2, n_calls, split):
+        if x1.shape[0] == 0:
+            # nn.Linear on zero rows gives zero rows (and nothing to launch)
+            _lib.require_device(x1)
+            if x1.dim() != 2 or x1.shape[1] != seg.input_dim:
+                raise ValueError('abnet3_amd: expected input of shape [n, %d], got %s'
+                                 % (seg.input_dim, tuple(x1.shape)))
+            empty = x1.new_zeros((0, seg.output_dim))
+            return (empty, empty.clone()) if split else empty
         return _TowerFunction.apply(seg, grad_pass, masks, n_calls, split, x1, x2, *seg.params)
 
     def whoami(self):
