@@ -205,6 +205,72 @@ int abn_stack_frames(const float* feats, int64_t T, int64_t D, int32_t nframes, 
 
 }  // extern "C"
 
+namespace abn {
+
+// last_non_linearity = 'softmax' (abnet3/model.py:161-166: nn.Softmax() on a 2-D
+// input = softmax over each row).  One wavefront per row; max-shifted like ATen.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ z, int64_t rows, int n,
+                                                           float* __restrict__ out)
+{
+    const int64_t row = blockIdx.x * 4LL + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* zr = z + row * n;
+    float m = -INFINITY;
+    for (int c = lane; c < n; c += 64) m = fmaxf(m, zr[c]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float s = 0.0f;
+    for (int c = lane; c < n; c += 64) s += expf(zr[c] - m);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    float* orow = out + row * n;
+    for (int c = lane; c < n; c += 64) orow[c] = expf(zr[c] - m) / s;
+}
+
+// dz = a * (da - sum_c(da * a)) per row
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ a, const float* __restrict__ da,
+                                                               int64_t rows, int n, float* __restrict__ dz)
+{
+    const int64_t row = blockIdx.x * 4LL + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* ar = a + row * n;
+    const float* dr = da + row * n;
+    double s = 0.0;
+    for (int c = lane; c < n; c += 64) s += (double)dr[c] * (double)ar[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float sf = (float)s;
+    float* zr = dz + row * n;
+    for (int c = lane; c < n; c += 64) zr[c] = ar[c] * (dr[c] - sf);
+}
+
+}  // namespace abn
+
+extern "C" {
+
+int abn_softmax_rows(const float* z, int64_t rows, int64_t n, float* out, void* stream)
+{
+    ABN_REQUIRE(rows >= 0 && n >= 1 && n < (1 << 24), "softmax_rows: bad shape");
+    if (rows == 0) return ABN_OK;
+    ABN_REQUIRE(z && out, "softmax_rows: null pointer");
+    hipLaunchKernelGGL(abn::softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, rows,
+                       (int)n, out);
+    ABN_CHECK_LAUNCH("softmax_rows");
+    return ABN_OK;
+}
+
+int abn_softmax_rows_backward(const float* a, const float* da, int64_t rows, int64_t n, float* dz, void* stream)
+{
+    ABN_REQUIRE(rows >= 0 && n >= 1 && n < (1 << 24), "softmax_rows_backward: bad shape");
+    if (rows == 0) return ABN_OK;
+    ABN_REQUIRE(a && da && dz, "softmax_rows_backward: null pointer");
+    hipLaunchKernelGGL(abn::softmax_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a,
+                       da, rows, (int)n, dz);
+    ABN_CHECK_LAUNCH("softmax_rows_backward");
+    return ABN_OK;
+}
+
+}  // extern "C"
+
 extern "C" {
 
 int64_t abn_mvn_ws_bytes(int64_t T, int64_t D)

@@ -249,6 +249,33 @@ class _TowerFunction(torch.autograd.Function):
         return (None, None, None, None, None, dx1, dx2) + tuple(grads)
 
 
+class _SoftmaxRows(torch.autograd.Function):
+    """nn.Softmax() over the rows of a [n, width] matrix (the 'softmax' choice of
+    last_non_linearity, abnet3/model.py:161-166): abn_softmax_rows and its autograd."""
+
+    @staticmethod
+    def forward(ctx, z):
+        lib = _lib.load()
+        z = z.contiguous()
+        _lib.require_device(z)
+        out = torch.empty_like(z)
+        _lib.check(lib.abn_softmax_rows(_lib.ptr(z), z.shape[0], z.shape[1], _lib.ptr(out),
+                                        _lib.stream()), 'abn_softmax_rows')
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, da):
+        lib = _lib.load()
+        (a,) = ctx.saved_tensors
+        da = da.contiguous()
+        dz = torch.empty_like(da)
+        _lib.check(lib.abn_softmax_rows_backward(_lib.ptr(a), _lib.ptr(da), a.shape[0], a.shape[1],
+                                                 _lib.ptr(dz), _lib.stream()),
+                   'abn_softmax_rows_backward')
+        return dz
+
+
 def _blocks_of(*sequentials):
     """[(Linear, BatchNorm1d | None)] of nn.Sequentials in forward order."""
     out = []
@@ -465,14 +492,20 @@ class SiameseNetwork(_HipNetwork):
 
     # -- HIP plumbing ------------------------------------------------------
     def _segments(self):
+        # a row-wise softmax cannot ride in a GEMM epilogue: the tower ends linear
+        # and abn_softmax_rows follows
+        last = 'none' if self._last_act == 'softmax' else self._last_act
         return [_Segment(self, _blocks_of(self.input_emb, self.hidden_layers, self.output_layer),
-                         0, self.activation_layer, self._last_act, self.batch_norm)]
+                         0, self.activation_layer, last, self.batch_norm)]
 
     def _run_tower(self, x1, x2, n_calls, split):
         seg = self._segment_list()[0]
         rows = x1.shape[0] * (2 if x2 is not None else 1)
         masks = self._draw_dropout_masks(rows, x1.device) if self.training else None
-        return self._run(seg, _GradPass(self), masks, x1, x2, n_calls, split)
+        out = self._run(seg, _GradPass(self), masks, x1, x2, n_calls, split)
+        if self._last_act == 'softmax':
+            out = tuple(_SoftmaxRows.apply(o) for o in out) if split else _SoftmaxRows.apply(out)
+        return out
 
     # -- reference surface ---------------------------------------------------
     def forward_once(self, x):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 2
+#define ABN_ABI_VERSION 3
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -174,6 +174,13 @@ int abn_dtw_batched(const float* feats1, int64_t rows1, const float* feats2,
 /* The distance matrix alone (utils.py:40-60), one pair, float64 [N, M] out. */
 int abn_cosine_distance(const float* x, int64_t N, const float* y, int64_t M,
                         int64_t D, double* d, int32_t* bad_flag, void* stream);
+
+/* last_non_linearity='softmax' (abnet3/model.py:161-166: nn.Softmax() after the output
+ * layer's Linear/Dropout/BatchNorm = softmax over each row of a [rows, n] matrix), and
+ * its autograd: dz = a * (da - sum_c(da * a)).  out may alias z; dz may alias da. */
+int abn_softmax_rows(const float* z, int64_t rows, int64_t n, float* out, void* stream);
+int abn_softmax_rows_backward(const float* a, const float* da, int64_t rows, int64_t n,
+                              float* dz, void* stream);
 
 /* X[path] gathers of abnet3/dataloader.py:204-205, :673-684: out[i] = table[idx[i]] */
 int abn_gather_rows(const float* table, const int64_t* idx, int64_t n, int64_t D,

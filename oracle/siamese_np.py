@@ -76,6 +76,9 @@ def act_fwd(z, kind):
         return np.tanh(z).astype(F32)
     if kind == 'none':
         return z
+    if kind == 'softmax':      # nn.Softmax() on a 2-D input: over each row (model.py:161-166)
+        e = np.exp((z - z.max(axis=1, keepdims=True)).astype(F32)).astype(F32)
+        return (e / e.sum(axis=1, keepdims=True, dtype=F32)).astype(F32)
     raise ValueError(kind)
 
 
@@ -89,6 +92,9 @@ def act_bwd(a, da, kind):
         return (da * (F32(1) - a * a)).astype(F32)
     if kind == 'none':
         return da
+    if kind == 'softmax':
+        dot = (da.astype(np.float64) * a).sum(axis=1, keepdims=True)
+        return (a * (da - dot.astype(F32))).astype(F32)
     raise ValueError(kind)
 
 

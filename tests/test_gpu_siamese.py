@@ -37,7 +37,8 @@ def test_library_is_the_hip_one():
     assert torch.cuda.is_available()
 
 
-@pytest.mark.parametrize('name', ['sig', 'sig_bn', 'relu_bn', 'tanh', 'sig_lin', 'relu_h2'])
+@pytest.mark.parametrize('name', ['sig', 'sig_bn', 'relu_bn', 'tanh', 'sig_lin', 'relu_h2',
+                                  'tanh_softmax', 'relu_bn_softmax'])
 def test_tower_forward_matches_reference(name):
     g = load_golden('tower_%s.npz' % name)
     net, kw = cuda_net(g)
@@ -60,6 +61,26 @@ def test_tower_forward_matches_reference(name):
             assert rel_err(sd[k[6:]].cpu().numpy(), v) < TOL, k
         if k.startswith('after.') and 'num_batches_tracked' in k:
             assert int(sd[k[6:]]) == int(v) == 2
+
+
+@pytest.mark.parametrize('name', ['tanh_softmax', 'relu_bn_softmax'])
+def test_softmax_head_gradients(name):
+    """last_non_linearity='softmax' (model.py:161-166): abn_softmax_rows after the
+    linear-ended tower, and its backward, against the reference's autograd."""
+    import abnet3_amd.loss as L
+    g = load_golden('tower_%s.npz' % name)
+    net, kw = cuda_net(g)
+    net.train()
+    e1, e2 = net(dev(g['x1']), dev(g['x2']))
+    assert np.allclose(e1.detach().sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+    lv = L.cosmargin(avg=True)(e1, e2, dev(g['y']))
+    lv.backward()
+    ref = float(g['loss'])
+    assert abs(float(lv.detach()) - ref) <= 1e-5 * abs(ref)
+    keys = [k for k, _ in net.named_parameters()]
+    grads = {k: p.grad.cpu().numpy() for k, p in net.named_parameters()}
+    check_grads(grads, {k: g['grad.' + k] for k in keys}, keys, bool(kw['batch_norm']), tol=5e-5)
+    assert net.grads_in_flat_buffer()
 
 
 OPT = {'sgd': lambda p: torch.optim.SGD(p, lr=0.001, momentum=0.9),

@@ -26,7 +26,7 @@ def params_from(g, prefix='p.'):
 
 
 @pytest.mark.parametrize('name', ['sig', 'sig_bn', 'relu_bn', 'tanh', 'sig_lin',
-                                  'relu_h2'])
+                                  'relu_h2', 'tanh_softmax', 'relu_bn_softmax'])
 def test_tower_forward_matches_reference(name):
     g = load_golden('tower_%s.npz' % name)
     spec, _ = spec_from(g)
@@ -44,6 +44,21 @@ def test_tower_forward_matches_reference(name):
             assert rel_err(p[k], v) < TOL, k
         if 'num_batches_tracked' in k:
             assert int(p[k]) == int(v) == 2      # one update per tower call
+
+
+@pytest.mark.parametrize('name', ['tanh_softmax', 'relu_bn_softmax'])
+def test_softmax_head_gradients(name):
+    """last_non_linearity='softmax' (model.py:161-166): loss and every parameter
+    gradient through the row softmax, cosmargin(avg=True)."""
+    g = load_golden('tower_%s.npz' % name)
+    spec, _ = spec_from(g)
+    assert spec.last_act == 'softmax'
+    p = params_from(g)
+    loss, grads, _ = O.train_step(p, g['x1'], g['x2'], g['y'], spec, O.Optimizer('sgd', 0.0),
+                                  kind='cosmargin', avg=True)
+    assert abs(loss - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    check_grads(grads, {k: g['grad.' + k] for k in spec.param_keys()}, spec.param_keys(),
+                spec.batch_norm, tol=5e-5)
 
 
 CASES_C1 = [(l, a, o) for l in ('coscos2', 'cosmargin') for a in (1, 0)

@@ -100,6 +100,10 @@ def g1_tower(abnet3):
                         last_non_linearity=None),
         'relu_h2': dict(activation_layer='relu', batch_norm=False,
                         num_hidden_layers=2),
+        'tanh_softmax': dict(activation_layer='tanh', batch_norm=False,
+                             last_non_linearity='softmax'),
+        'relu_bn_softmax': dict(activation_layer='relu', batch_norm=True,
+                                last_non_linearity='softmax'),
     }
     for name, extra in cases.items():
         kw = dict(input_dim=40, num_hidden_layers=0, hidden_dim=100,
@@ -118,6 +122,15 @@ def g1_tower(abnet3):
             e1, e2 = net(x1, x2)
         out['train_e1'], out['train_e2'] = e1.numpy(), e2.numpy()
         out.update(sd_to_np(net, 'after.'))   # BN running stats after 2 calls
+        if 'softmax' in name:                 # + one backward through the softmax head
+            net = build_net(abnet3, 0, **kw)
+            net.train()
+            e1, e2 = net(x1, x2)
+            lv = abnet3.loss.cosmargin(avg=True)(e1, e2, torch.from_numpy(y))
+            lv.backward()
+            out['loss'] = np.float64(lv.detach())
+            for k, p in net.named_parameters():
+                out['grad.' + k] = p.grad.detach().numpy().copy()
         out['kw'] = np.array(repr(kw))
         np.savez_compressed(os.path.join(OUT, 'tower_%s.npz' % name), **out)
 
