@@ -268,3 +268,45 @@ def test_end_to_end_pipeline_trains(tmp_path, monkeypatch):
     assert len(trainer.train_losses) == 5 and np.isfinite(trainer.train_losses).all()
     assert trainer.train_losses[-1] < trainer.train_losses[0]
     assert emb[0].shape[1] == 100 and np.isfinite(emb[0]).all()
+
+
+def test_dtw_full_size_properties():
+    """BASELINE.json configs[3] at full size (10 000 pairs, ~300 frames, 9e8 cells)
+    through properties that need no per-cell oracle: every path starts at (0, 0),
+    ends at (N-1, M-1), advances by (1,0) / (0,1) / (1,1), has a length in
+    [max(N, M), N+M-1]; the accumulated cost equals the sum of the distances along
+    the returned path; aligning (y, x) costs the same as (x, y); and a sample of
+    pairs is bit-identical to the C oracle."""
+    import bench
+    from abnet3_amd.utils import dtw_align_batch, cosine_distance
+    from oracle import dtw_oracle as O
+    P = 10000
+    f1, o1, n1, f2, o2, n2 = bench.synth_dtw_pairs(P, seed=1234)
+    d1, d2 = torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda()
+    res = dtw_align_batch(d1, o1, n1, d2, o2, n2)
+    L = res.path_len.long()
+    assert int((L == 0).sum()) == 0
+    n1t, n2t = torch.from_numpy(n1).cuda().long(), torch.from_numpy(n2).cuda().long()
+    p1, p2 = res.path1.long(), res.path2.long()
+    stride = p1.shape[1]
+    ar = torch.arange(P, device='cuda')
+    assert bool((p1[:, 0] == 0).all() and (p2[:, 0] == 0).all())
+    assert bool((p1[ar, L - 1] == n1t - 1).all() and (p2[ar, L - 1] == n2t - 1).all())
+    assert bool((L >= torch.maximum(n1t, n2t)).all() and (L <= n1t + n2t - 1).all())
+    inside = torch.arange(1, stride, device='cuda')[None, :] < L[:, None]
+    s1, s2 = (p1[:, 1:] - p1[:, :-1])[inside], (p2[:, 1:] - p2[:, :-1])[inside]
+    assert bool(((s1 == 0) | (s1 == 1)).all() and ((s2 == 0) | (s2 == 1)).all() and ((s1 + s2) >= 1).all())
+    cost = res.total_cost.cpu().numpy()
+    got = None
+    rng = np.random.default_rng(0)
+    for p in rng.choice(P, 12, replace=False):
+        a, b = f1[o1[p]:o1[p] + n1[p]], f2[o2[p]:o2[p] + n2[p]]
+        d = cosine_distance(a, b)                       # HIP distance matrix, float64 [N, M]
+        i, j = p1[p, :L[p]].cpu().numpy(), p2[p, :L[p]].cpu().numpy()
+        assert cost[p] == d[i, j].sum()                 # exact: float64 sums of float32 distances
+        od = O.cosine_distance(a, b)
+        q1, q2 = O.dtw_path(od)
+        assert np.array_equal(i, q1) and np.array_equal(j, q2) and cost[p] == O.dtw_cost(od)
+    # symmetry: swap the roles of the two tokens for the first 2000 pairs
+    sw = dtw_align_batch(d2, o2[:2000], n2[:2000], d1, o1[:2000], n1[:2000])
+    assert np.allclose(sw.total_cost.cpu().numpy(), cost[:2000], rtol=1e-6, atol=0)
