@@ -13,11 +13,12 @@ import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ABNET3_HIP_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get('ABNET3_HIP_LIB') or os.path.join(HERE, 'lib', 'libabnet3_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LAYERS = 16
 
 ACT = {'none': 0, None: 0, 'sigmoid': 1, 'relu': 2, 'tanh': 3}
 LOSS = {'coscos2': 0, 'cosmargin': 1}
+PRECISION = {'fp32': 0, 'bf16': 1}
 OPT = {'sgd': 0, 'adadelta': 1, 'adam': 2, 'adagrad': 3, 'RMSprop': 4}
 Y_DTYPE = {torch.int8: 0, torch.int32: 1, torch.int64: 2, torch.float32: 3,
            torch.float64: 4}
@@ -66,7 +67,7 @@ class TowerDesc(C.Structure):
                 ('batch_norm', _i32), ('dims', _i64 * (MAX_LAYERS + 1))] + [
         (name, _vp * MAX_LAYERS)
         for name in ('W', 'b', 'bn_w', 'bn_b', 'bn_rm', 'bn_rv', 'dW', 'db',
-                     'dbn_w', 'dbn_b', 'drop_mask')]
+                     'dbn_w', 'dbn_b', 'drop_mask')] + [('precision', _i32), ('reserved_', _i32)]
 
 
 class HipLibraryError(RuntimeError):

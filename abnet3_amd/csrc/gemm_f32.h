@@ -58,6 +58,7 @@ struct GemmP {
     int ones_col;           // WGRAD: column of B that is identically 1, or -1
     int a_vec, b_vec;       // 16-byte global loads allowed for A / B
     int c_vec;              // 16-byte epilogue accesses allowed (C, bias, aux)
+    int bf16;               // throughput mode: operands rounded to bf16 at fragment time (fp32 accumulate)
 #ifdef ABN_STAMPS
     unsigned long long* stamps;   // diagnostic build only: [block][128] s_memtime stamps
 #endif
@@ -219,6 +220,19 @@ __device__ __forceinline__ void tile_commit(const f32x4* r, float* __restrict__ 
     }
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Two fp32 fragments (k-groups g, g+1: 8 k values per lane) -> one bf16 MFMA operand
+// (v_cvt_pk_bf16_f32, round to nearest even).  Which k a lane holds does not matter as
+// long as A and B agree: the 32x32x16 MFMA sums over all 16 (lane-half, slot) positions.
+__device__ __forceinline__ bf16x8 pack_bf16(const f32x4& a, const f32x4& b)
+{
+    bf16x8 r;
+    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+    r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+    return r;
+}
+
 // Fragment of one 32-row MFMA operand block for k-group g (8 k values):
 // element e is the operand of MFMA step (g,e); k = 8g + 4*(lane>>5) + e.
 template <int BMN, bool KCONTIG>
@@ -265,7 +279,12 @@ __device__ __forceinline__ int xcd_tile_index(int b, int n)
 #define ABN_STAMP_FLUSH() do {} while (0)
 #endif
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC>
+// BF16 = the opt-in throughput mode: same tiles, loaders, LDS image (fp32) and
+// epilogues; only the inner product changes -- pairs of k-groups are rounded to bf16
+// and fed to v_mfma_f32_32x32x16_bf16 (fp32 accumulate), 2 MFMAs of 32 cycles per
+// 32-deep tile and block instead of 16 of 64.  NOT the parity path (~3 significant
+// digits); the kernel is then bound by its global -> LDS traffic, not by the MFMA.
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC, bool BF16 = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
 {
 #ifdef ABN_STAMPS
@@ -366,6 +385,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     };
 
+    auto k_group_bf16 = [&](const float* as, const float* bs, int g2) {
+        bf16x8 pa[TM], pb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            pa[i] = pack_bf16(frag_read<BM, A_KC>(as, wm0 + 32 * i, 2 * g2, lane),
+                              frag_read<BM, A_KC>(as, wm0 + 32 * i, 2 * g2 + 1, lane));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            pb[j] = pack_bf16(frag_read<BN, B_KC>(bs, wn0 + 32 * j, 2 * g2, lane),
+                              frag_read<BN, B_KC>(bs, wn0 + 32 * j, 2 * g2 + 1, lane));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i], pb[j], acc[i][j], 0, 0, 0);
+    };
+
     // One global load of the next tile (unit u: A units first, then B units).
     auto issue_unit = [&](int u, const float* an, const float* bn) {
         if (u < TA::per_thread) ra[u] = *reinterpret_cast<const f32x4*>(an + voa[u]);
@@ -392,6 +428,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
         const float* bn = b_org + (B_KC ? (int64_t)knext : (int64_t)knext * p.ldb);
         // tiles are zero-filled past k_end, so every tile runs all BK/8 groups
         // (at most 31 wasted k per GEMM) and the loop body stays branch-free
+        if constexpr (BF16) {
+#pragma unroll
+            for (int g2 = 0; g2 < BK / 16; ++g2) {
+                k_group_bf16(as, bs, g2);
+                if (fast) {
+#pragma unroll
+                    for (int u = g2 * UPG; u < (g2 + 1) * UPG && u < UNITS; ++u) issue_unit(u, an, bn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             k_group(as, bs, g);
@@ -400,6 +447,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
                 for (int u = g * UPG; u < (g + 1) * UPG && u < UNITS; ++u) issue_unit(u, an, bn);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         ABN_STAMP();
         if (more) commit(knext, As + (cur ^ 1) * TA::floats, Bs + (cur ^ 1) * TB::floats);

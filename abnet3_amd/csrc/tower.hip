@@ -28,12 +28,12 @@ void set_error(const char* fmt, ...)
 // ---------------------------------------------------------------------------
 // GEMM dispatch
 // ---------------------------------------------------------------------------
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC, bool BF16>
 static void launch_one(const GemmP& p, int splits, hipStream_t st)
 {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     constexpr size_t lds = gemm_lds_bytes<BM, BN, A_KC, B_KC>();
-    auto k = gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, VEC>;
+    auto k = gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, VEC, BF16>;
     static bool attr_set = false;      // > 64 KiB of dynamic LDS needs the opt-in
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -50,8 +50,13 @@ static void launch_one(const GemmP& p, int splits, hipStream_t st)
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
 static void launch_cfg(const GemmP& p, int splits, hipStream_t st)
 {
-    if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true>(p, splits, st);
-    else launch_one<BM, BN, A_KC, B_KC, EPI, false>(p, splits, st);
+    if (p.bf16) {                         // throughput mode (abn_tower_desc.precision = 1)
+        if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true, true>(p, splits, st);
+        else launch_one<BM, BN, A_KC, B_KC, EPI, false, true>(p, splits, st);
+        return;
+    }
+    if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true, false>(p, splits, st);
+    else launch_one<BM, BN, A_KC, B_KC, EPI, false, false>(p, splits, st);
 }
 
 template <bool A_KC, bool B_KC, int EPI>
@@ -328,6 +333,7 @@ static int check_desc(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
 {
     ABN_REQUIRE(t != nullptr, "tower: null descriptor");
     ABN_REQUIRE(t->n_layers >= 1 && t->n_layers <= ABN_MAX_LAYERS, "tower: n_layers=%d out of range", t->n_layers);
+    ABN_REQUIRE(t->precision == 0 || t->precision == 1, "tower: precision=%d (0 = fp32, 1 = bf16 operands)", t->precision);
     ABN_REQUIRE(rows >= 0 && n_calls >= 1 && rows % n_calls == 0, "tower: rows=%lld not divisible by n_calls=%lld",
                 (long long)rows, (long long)n_calls);
     for (int l = 0; l <= t->n_layers; ++l)
@@ -451,6 +457,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         f.n_layers = t->n_layers;
         f.rows = (int)rows;
         f.rows_call = (int)rpc;
+        f.bf16 = t->precision == 1;
         f.x1 = x1; f.x2 = x2;
         f.x_copy = x2 ? ws + L.x : nullptr;
         for (int l = 0; l <= t->n_layers; ++l) f.dims[l] = (int)t->dims[l];
@@ -465,12 +472,15 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
 #endif
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_fused_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_fused_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_fused_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES);
             attr_set = true;
         }
-        hipLaunchKernelGGL(tower_fwd_fused_kernel, dim3((unsigned)((rows + FUSED_ROWS - 1) / FUSED_ROWS)), dim3(FUSED_NT),
-                           FUSED_LDS_BYTES, st, f);
+        const dim3 fgrid((unsigned)((rows + FUSED_ROWS - 1) / FUSED_ROWS));
+        if (f.bf16) hipLaunchKernelGGL(tower_fwd_fused_kernel<true>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
+        else hipLaunchKernelGGL(tower_fwd_fused_kernel<false>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
         ABN_CHECK_LAUNCH("tower_fwd_fused");
         return ABN_OK;
     }
@@ -498,6 +508,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         p.a_vec = aligned16(in) && (K % 4 == 0);
         p.b_vec = aligned16(t->W[l]) && (K % 4 == 0);
         p.ones_col = -1;
+        p.bf16 = t->precision == 1;
         if (!t->batch_norm) {
             p.C = a; p.ldc = N; p.act = act;
             rc = launch_gemm<true, true, EPI_FWD>(p, 1, st);
@@ -582,6 +593,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             p.M = Nout; p.N = Kin + 1; p.K = (int)rows;
             p.k_chunk = (int)align_up((rows + B.splits[l] - 1) / B.splits[l], BK);
             p.ones_col = Kin;
+            p.bf16 = t->precision == 1;
             p.a_vec = aligned16(dz) && (Nout % 4 == 0);
             p.b_vec = aligned16(a_in) && (Kin % 4 == 0);
             // slices past the end of the reduction write zero slabs (k range empty)
@@ -599,6 +611,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             p.a_vec = aligned16(dz) && (Nout % 4 == 0);
             p.b_vec = aligned16(t->W[l]) && (Kin % 4 == 0);
             p.ones_col = -1;
+            p.bf16 = t->precision == 1;
             if (l > 0 && !t->batch_norm) { p.aux = ws + L.a[l - 1]; p.ldaux = Kin; p.act = t->act; p.mask = t->drop_mask[l - 1]; }
             rc = launch_gemm<true, false, EPI_DGRAD>(p, 1, st);
             if (rc != ABN_OK) return rc;

@@ -49,6 +49,7 @@ struct FusedFwdP {
     int n_layers;
     int rows;                      // total rows (both towers)
     int rows_call;                 // rows per forward_once call (x1 | x2 split)
+    int bf16;                      // throughput mode: operands rounded to bf16 at fragment time
     int dims[ABN_MAX_LAYERS + 1];
     int act[ABN_MAX_LAYERS];
     const float* x1;
@@ -80,7 +81,7 @@ __device__ __forceinline__ int x_off(int row, int k)
 // KS = 2 (narrow layers, at most 4 column blocks): waves 4..7 take the second half of
 // K for the same columns as waves 0..3 and hand their partial sums over through LDS,
 // so that every SIMD still runs two wavefronts.
-template <int BPW, int KS>
+template <int BPW, int KS, bool BF16>
 __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __restrict__ X,
                                             float* __restrict__ Wst, int wave, int lane, int row0)
 {
@@ -174,8 +175,15 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
         f32x4 fa0, fa1, fb0[BPW], fb1[BPW];
         load_frags(fa0, fb0, ws, k0, 0);
         load_frags(fa1, fb1, ws, k0, 1);
-        mfmas(fa0, fb0);
-        mfmas(fa1, fb1);
+        if constexpr (BF16) {                     // one 16-deep bf16 MFMA per column block and tile
+            const bf16x8 pa = pack_bf16(fa0, fa1);
+#pragma unroll
+            for (int j = 0; j < BPW; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, pack_bf16(fb0[j], fb1[j]), acc[j], 0, 0, 0);
+        } else {
+            mfmas(fa0, fb0);
+            mfmas(fa1, fb1);
+        }
     }
     }
     // epilogue: bias, dropout mask, activation -> X (input of the next layer), zero up to
@@ -243,6 +251,7 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
     }
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(FUSED_NT) void tower_fwd_fused_kernel(FusedFwdP p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -270,9 +279,9 @@ __global__ __launch_bounds__(FUSED_NT) void tower_fwd_fused_kernel(FusedFwdP p)
 
     for (int l = 0; l < p.n_layers; ++l) {
         const int N = p.dims[l + 1];
-        if (N > 32 * FUSED_WAVES) fused_layer<2, 1>(p, l, X, Wst, wave, lane, row0);
-        else if (N > 16 * FUSED_WAVES) fused_layer<1, 1>(p, l, X, Wst, wave, lane, row0);
-        else fused_layer<1, 2>(p, l, X, Wst, wave, lane, row0);
+        if (N > 32 * FUSED_WAVES) fused_layer<2, 1, BF16>(p, l, X, Wst, wave, lane, row0);
+        else if (N > 16 * FUSED_WAVES) fused_layer<1, 1, BF16>(p, l, X, Wst, wave, lane, row0);
+        else fused_layer<1, 2, BF16>(p, l, X, Wst, wave, lane, row0);
     }
     FSTAMP(1 + 3 * p.n_layers);
 }

@@ -11,6 +11,8 @@ arithmetic of forward_once / forward and of their autograd runs in
 libabnet3_hip.so (abn_tower_forward / abn_tower_backward).  There is no CPU
 path: calling the network with CPU tensors raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -102,6 +104,7 @@ class _Segment(object):
                                       'the accelerated path' % (self.last_act,))
         d.last_act = _lib.ACT[self.last_act]
         d.batch_norm = int(self.batch_norm)
+        d.precision = _lib.PRECISION[self.net.precision]
         d.dims[0] = self.input_dim
         gi = 0
         for l, (lin, bn) in enumerate(self.blocks):
@@ -307,6 +310,10 @@ class _HipNetwork(NetworkBuilder):
         self._offset_of = None
         self._segs = None
         self._mask_override = None      # tests: fixed dropout masks, one per live block
+        # 'fp32' = the parity path (exact-fp32 MFMA); 'bf16' = opt-in throughput mode:
+        # matrix operands rounded to bf16 inside the GEMMs, fp32 accumulation and storage
+        self.precision = os.environ.get('ABNET3_PRECISION', 'fp32')
+        assert self.precision in _lib.PRECISION, self.precision
 
     def _segments(self):
         raise NotImplementedError

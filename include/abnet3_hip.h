@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 3
+#define ABN_ABI_VERSION 4
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -83,6 +83,11 @@ typedef struct abn_tower_desc {
      * NULL = identity (p = 0 or eval mode).  The same masks must be passed to
      * the backward call. */
     const float* drop_mask[ABN_MAX_LAYERS];
+    /* 0 = fp32 on the exact-fp32 MFMA (the parity path, default); 1 = throughput mode:
+     * matrix operands rounded to bf16 at fragment time, fp32 accumulation, everything
+     * else (storage, BatchNorm, loss, optimizer) still fp32.  NOT within the 1e-5 bar. */
+    int32_t precision;
+    int32_t reserved_;
 } abn_tower_desc;
 
 /* Workspace of one forward call (saved activations for backward), in floats,

@@ -385,3 +385,44 @@ def test_graphed_step_equals_eager_step():
         assert np.allclose(losses, results[0][0], rtol=1e-6, atol=0)
         for k, v in params.items():           # (the flat buffer's alignment gaps hold no parameters)
             assert rel_err(v, results[0][1][k]) < 1e-6, k
+
+
+@pytest.mark.parametrize('fixture,bn', [('train_c2_bn0.npz', False), ('train_mid_bn1.npz', True)])
+def test_bf16_throughput_mode_tracks_fp32(fixture, bn):
+    """precision='bf16' (opt-in, NOT the parity path): operands of every tower GEMM are
+    rounded to bf16, accumulation stays fp32.  It must stay within bf16's ~3 significant
+    digits of the fp32 path in the forward, and train to the same loss curve."""
+    import copy
+    import abnet3_amd.loss as L
+    g = load_golden(fixture)
+    net32, kw = cuda_net(g, seed=2 if 'c2' in fixture else None, prefix=None if 'c2' in fixture else 'p.')
+    net16 = copy.deepcopy(net32)
+    net16.precision = 'bf16'
+    assert net32.precision == 'fp32'
+    rng = np.random.default_rng(1)
+    B = 256
+    x1 = dev(rng.standard_normal((B, kw['input_dim'])).astype(np.float32))
+    x2 = dev(rng.standard_normal((B, kw['input_dim'])).astype(np.float32))
+    y = dev(rng.choice([1, -1], B))
+    for net in (net32, net16):
+        net.eval()
+    with torch.no_grad():
+        a, b = net32.forward_once(x1), net16.forward_once(x1)
+    err = rel_err(b.cpu().numpy(), a.cpu().numpy())
+    assert 1e-6 < err < 3e-2, err                  # different arithmetic, same function
+    curves = []
+    for net in (net32, net16):
+        net.train()
+        opt = torch.optim.Adadelta(net.parameters(), lr=0.1)
+        loss_mod = L.coscos2(avg=True)
+        losses = []
+        for s in range(8):
+            e1, e2 = net(x1, x2)
+            lv = loss_mod(e1, e2, y)
+            opt.zero_grad()
+            lv.backward()
+            opt.step()
+            losses.append(float(lv.detach()))
+        curves.append(losses)
+    assert np.allclose(curves[0], curves[1], rtol=3e-2), curves
+    assert curves[1][-1] <= curves[1][0]           # (a sigmoid tower at its initialisation barely moves)
