@@ -313,16 +313,19 @@ class TrainerSiamese(TrainerBuilder):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):      # also moves the optimizer past step 1
-                self.train_step(tuple(static), True)
+                warmup_loss = self.train_step(tuple(static), True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
+        steps_before = getattr(opt, 'step_count', 0)
         with torch.cuda.graph(graph):
             loss_value = fwd_loss()
             opt.zero_grad()
             self._backward(loss_value)
             if capture_opt:
                 opt.step()
+        if capture_opt:
+            opt.step_count = steps_before        # capturing recorded the launch, it did not run it
         static_loss = loss_value.detach()
 
         blob = getattr(self, '_static_blob', None)
@@ -344,7 +347,36 @@ class TrainerSiamese(TrainerBuilder):
                 opt.step()
             return static_loss
         step.graph = graph
+        step.warmup_loss = warmup_loss
+        step.flat_ptr = self.network.flat_parameters().data_ptr()
         return step
+
+    # shapes a captured step exists for / how often a shape was seen
+    GRAPH_AFTER = 3          # capture once a batch shape has come up this often
+    MAX_GRAPHS = 4
+
+    def train_step_auto(self, batch):
+        """train_step for an epoch loop: batches whose shape keeps recurring (the
+        FramesDataLoader's fixed `batch_size` frame pairs) are served by a captured
+        hipGraph from their GRAPH_AFTER-th occurrence on -- small batches are
+        otherwise bound by the host's per-launch cost, not by the GPU; every other
+        batch takes the eager path.  self.graph_steps = False disables it."""
+        if not getattr(self, 'graph_steps', True) or not isinstance(self.optimizer, FlatOptimizer):
+            return self.train_step(batch, True)
+        if not hasattr(self, '_graphs'):
+            self._graphs, self._shape_seen = {}, {}
+        key = tuple((tuple(t.shape), str(t.dtype)) for t in batch)
+        step = self._graphs.get(key)
+        if step is not None:
+            if step.flat_ptr == self.network.flat_parameters().data_ptr() and self.network.training:
+                return step(batch)
+            del self._graphs[key]                # parameters were re-homed: the graph is stale
+        n = self._shape_seen[key] = self._shape_seen.get(key, 0) + 1
+        if n < self.GRAPH_AFTER or len(self._graphs) >= self.MAX_GRAPHS or batch[0].shape[0] == 0:
+            return self.train_step(batch, True)
+        step = self.make_graphed_step(batch, warmup=1)   # its one warm-up step IS this batch's step
+        self._graphs[key] = step
+        return step.warmup_loss
 
     @staticmethod
     def _packed_layout(B, D, y):
@@ -400,7 +432,10 @@ class TrainerSiamese(TrainerBuilder):
         num_batches_dev = 0
         self.network.train()
         for minibatch in self._batches(True):
-            train_loss += self.train_step(minibatch, do_training).double()
+            if do_training:
+                train_loss += self.train_step_auto(minibatch).double()
+            else:
+                train_loss += self.train_step(minibatch, False).double()
             num_batches_train += 1
 
         self.network.eval()

@@ -426,3 +426,69 @@ def test_bf16_throughput_mode_tracks_fp32(fixture, bn):
         curves.append(losses)
     assert np.allclose(curves[0], curves[1], rtol=3e-2), curves
     assert curves[1][-1] <= curves[1][0]           # (a sigmoid tower at its initialisation barely moves)
+
+
+class _ListLoader(object):
+    """Minimal dataloader contract the trainer consumes (dataloader.py:263-312)."""
+
+    def __init__(self, train, dev_batches):
+        self.train, self.dev = train, dev_batches
+
+    def batch_iterator(self, train_mode=True):
+        return iter(self.train if train_mode else self.dev)
+
+    def whoami(self):
+        return {'class_name': 'ListLoader'}
+
+
+def test_epoch_loop_auto_graph_equals_eager():
+    """optimize_model serves recurring batch shapes from a captured hipGraph
+    (train_step_auto): same losses and parameters as the all-eager loop, odd-shaped
+    batches in between included."""
+    import abnet3_amd.loss as L
+    from abnet3_amd.trainer import TrainerSiamese
+    g = load_golden('train_mid_bn1.npz')
+    rng = np.random.default_rng(5)
+
+    def batch(n):
+        return (dev(rng.standard_normal((n, 40)).astype(np.float32)),
+                dev(rng.standard_normal((n, 40)).astype(np.float32)), dev(rng.choice([1.0, -1.0], n)))
+    train = [batch(64) for _ in range(4)] + [batch(37)] + [batch(64) for _ in range(5)] + [batch(21)]
+    devb = [batch(64), batch(30)]
+    out = []
+    for graph_steps in (False, True):
+        net, _ = cuda_net(g)
+        net.output_path = '/tmp/abn_auto_graph'
+        tr = TrainerSiamese(network=net, loss=L.cosmargin(avg=True), optimizer_type='sgd', lr=0.01,
+                            momentum=0.9, dataloader=_ListLoader(train, devb), log_dir='/tmp/abn_runs')
+        tr.graph_steps = graph_steps
+        tr.train_losses, tr.dev_losses = [], []
+        for _ in range(2):
+            tr.optimize_model(do_training=True)
+        assert (len(getattr(tr, '_graphs', {})) == 1) == graph_steps
+        out.append((tr.train_losses, tr.dev_losses,
+                    {k: p.detach().cpu().numpy().copy() for k, p in net.state_dict().items()}))
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-6) and np.allclose(out[0][1], out[1][1], rtol=1e-6)
+    for k, v in out[1][2].items():
+        assert rel_err(v, out[0][2][k]) < 1e-6, k          # BatchNorm running stats and counters included
+
+
+def test_auto_graph_redraws_dropout_masks():
+    """Dropout masks are drawn by torch's device generator inside the captured step:
+    every replay must see fresh masks."""
+    import abnet3_amd.loss as L
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.trainer import TrainerSiamese
+    torch.manual_seed(0)
+    net = SiameseNetwork(input_dim=40, num_hidden_layers=1, hidden_dim=64, output_dim=32,
+                         p_dropout=0.3, activation_layer='tanh', output_path='/tmp/abn_drop').cuda()
+    tr = TrainerSiamese(network=net, loss=L.coscos2(avg=True), optimizer_type='sgd', lr=0.0,
+                        dataloader=None, log_dir='/tmp/abn_runs')
+    rng = np.random.default_rng(0)
+    b = (dev(rng.standard_normal((128, 40)).astype(np.float32)),
+         dev(rng.standard_normal((128, 40)).astype(np.float32)), dev(rng.choice([1.0, -1.0], 128)))
+    net.train()
+    losses = [float(tr.train_step_auto(b)) for _ in range(8)]      # lr = 0: only the masks change
+    assert len(tr._graphs) == 1
+    assert len(set(losses[3:])) == len(losses[3:]), losses
+    assert all(np.isfinite(losses))
