@@ -446,8 +446,15 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
     // (tower_fused.h): no BatchNorm (its statistics span all rows), widths <= 512
     // and multiples of 4, 16-byte aligned tensors.  ABN_FUSED=0 forces the
     // per-layer path (A/B measurements).
-    static const bool fused_enabled = !(getenv("ABN_FUSED") && atoi(getenv("ABN_FUSED")) == 0);
-    bool fusable = fused_enabled && !t->batch_norm && aligned16(x1) && (!x2 || aligned16(x2)) && aligned16(ws);
+    // (both switches are read per call: tests flip them inside one process)
+    const bool fused_enabled = !(getenv("ABN_FUSED") && atoi(getenv("ABN_FUSED")) == 0);
+    // A fused workgroup walks its 32 rows through every layer in ~110 us whatever the
+    // batch: it only pays once there are workgroups for most CUs.  Below that the
+    // per-layer GEMMs (tiles over rows AND columns) are faster (measured: 4096 rows 91 vs
+    // 116 us, 1024 rows 64 vs 107 us; 8192 rows 145 vs 131 us).
+    const int64_t fused_min_rows = getenv("ABN_FUSED_MIN_ROWS") ? atoll(getenv("ABN_FUSED_MIN_ROWS")) : 6144;
+    bool fusable = fused_enabled && rows >= fused_min_rows && !t->batch_norm && aligned16(x1) && (!x2 || aligned16(x2)) &&
+                   aligned16(ws);
     for (int l = 0; l <= t->n_layers && fusable; ++l)
         fusable = t->dims[l] >= 4 && t->dims[l] <= FUSED_MAXW && t->dims[l] % 4 == 0;
     for (int l = 0; l < t->n_layers && fusable; ++l)

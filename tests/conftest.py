@@ -14,6 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 
 
+@pytest.fixture(params=['per_layer', 'fused'])
+def forward_path(request, monkeypatch):
+    """Runs a test once on the per-layer GEMM forward and once on the fused
+    whole-tower kernel (which the library picks by itself only from 6144 rows up)."""
+    monkeypatch.setenv('ABN_FUSED_MIN_ROWS', '0' if request.param == 'fused' else '1000000000')
+    return request.param
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 

@@ -61,7 +61,7 @@ def test_odd_widths_and_ragged_rows(act, bn):
 
 
 @pytest.mark.parametrize('B', [1, 2, 63, 65, 130])
-def test_row_counts_around_tile_edges(B):
+def test_row_counts_around_tile_edges(B, forward_path):
     run_case(dict(input_dim=40, num_hidden_layers=1, hidden_dim=72, output_dim=36,
                   activation_layer='tanh', batch_norm=False), B=B, seed=B, loss_kind='cosmargin', avg=True)
 

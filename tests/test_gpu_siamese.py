@@ -39,7 +39,7 @@ def test_library_is_the_hip_one():
 
 @pytest.mark.parametrize('name', ['sig', 'sig_bn', 'relu_bn', 'tanh', 'sig_lin', 'relu_h2',
                                   'tanh_softmax', 'relu_bn_softmax'])
-def test_tower_forward_matches_reference(name):
+def test_tower_forward_matches_reference(name, forward_path):
     g = load_golden('tower_%s.npz' % name)
     net, kw = cuda_net(g)
     x1, x2 = dev(g['x1']), dev(g['x2'])
@@ -96,7 +96,7 @@ CASES_C1 = [(l, a, o) for l in ('coscos2', 'cosmargin') for a in (1, 0)
 
 @pytest.mark.parametrize('bn', [0, 1])
 @pytest.mark.parametrize('lname,avg,oname', CASES_C1)
-def test_c1_grads_and_three_steps(bn, lname, avg, oname):
+def test_c1_grads_and_three_steps(bn, lname, avg, oname, forward_path):
     """C1 = 40->100->50, B=32 (BASELINE.json configs[0]); the statements of
     trainer.py:236-242 with torch.optim driving the HIP network's parameters."""
     import abnet3_amd.loss as L
@@ -270,7 +270,7 @@ def test_cpu_tensors_fail_loudly():
 
 
 @pytest.mark.parametrize('bn', [False, True])
-def test_dropout_masks_forward_backward_vs_oracle(bn):
+def test_dropout_masks_forward_backward_vs_oracle(bn, forward_path):
     """nn.Dropout(p) sits between Linear and BatchNorm/activation
     (model.py:137,148,157).  torch's CPU RNG stream cannot be reproduced on the
     device, so the ARITHMETIC is pinned with masks shared by oracle and kernel,
