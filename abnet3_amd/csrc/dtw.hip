@@ -365,7 +365,12 @@ __global__ __launch_bounds__(64 * DP_WAVES) void dp_kernel(const PairMeta* __res
         last = __shfl(last, (N - 1) / SL, 64);
         if (lane == 0) total_cost[p] = last;
     }
-    __threadfence();                              // back-pointers are in L2 before anyone reads them
+    // The back-pointers were stored by THIS wavefront and are read back by it: its stores
+    // only have to be complete (the vector L1 is write-through, and no line of this region
+    // was ever loaded before).  An agent-scope fence would write the XCD's whole L2 back
+    // -- per pair -- and made short pairs several times slower.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
 
     // traceback.  The distances are dead now: their region takes the reversed path.
     int32_t* tmp = reinterpret_cast<int32_t*>(ws + m.ws_off);
@@ -396,7 +401,10 @@ __global__ __launch_bounds__(64 * DP_WAVES) void dp_kernel(const PairMeta* __res
         k = __shfl(k, 0, 64);
         wave_lds_sync();
     }
-    __threadfence();                              // lane 0's stores are visible to the whole wave
+    // lane 0's stores are complete; the loads below bypass the L1 (which may still hold
+    // the distances that lived in these lines)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
     const int len = k + 1;
     int32_t* o1 = path1 + (int64_t)p * path_stride;
     int32_t* o2 = path2 + (int64_t)p * path_stride;
