@@ -130,9 +130,17 @@ constexpr int KCP = KC + 4;  // padded: 16-byte row reads of 8 consecutive rows 
 // contiguous), and the tile's row norms are recomputed from the staged rows (40
 // fmas per row: cheaper than a separate pass over the corpus).  A = rows of y (j), B = rows of x (i): a lane then holds one i and runs of four
 // consecutive j, which go to LDS as float4s and leave in DP order.
+#ifdef ABN_DIST_STAMPS      // diagnostic build only (tools/dist_stamps.py): cycles per phase, summed over blocks
+__device__ unsigned long long g_dist_cycles[8];
+#define DSTAMP() do { if (threadIdx.x == 0) tk[nk++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DSTAMP() do {} while (0)
+#endif
+
 __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ feats1, const float* __restrict__ feats2,
                                                    const PairMeta* __restrict__ meta, const int32_t* __restrict__ tile_pair,
-                                                   int D, int vec, float* __restrict__ ws, int32_t* __restrict__ bad)
+                                                   int ntiles, int D, int vec, float* __restrict__ ws,
+                                                   int32_t* __restrict__ bad)
 {
     // x / y row chunks [64][KC] for the MFMA loop; the finished tile reuses the space
     __shared__ __attribute__((aligned(16))) float smem[2 * TS * KCP];
@@ -141,9 +149,20 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
     float (*xs)[KCP] = reinterpret_cast<float (*)[KCP]>(smem);
     float (*ys)[KCP] = reinterpret_cast<float (*)[KCP]>(smem + TS * KCP);
     float* tile = smem;
-    const int p = tile_pair[blockIdx.x];
+#ifdef ABN_DIST_STAMPS
+    unsigned long long tk[8];
+    int nk = 0;
+#endif
+    DSTAMP();
+    // XCD-aware order: workgroups b, b+8, b+16, ... share an XCD and its L2, so XCD x takes
+    // the contiguous tile range [x*G/8, (x+1)*G/8): the tiles of one pair (consecutive ids)
+    // then run on ONE XCD and re-read their x / y rows from its L2 instead of HBM
+    // (round-robin order: 4.4 GB fetched for 1 GB of features).
+    const int tile_id = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (tile_id >= ntiles) return;
+    const int p = tile_pair[tile_id];
     const PairMeta m = meta[p];
-    const int t = blockIdx.x - m.tile0;
+    const int t = tile_id - m.tile0;
     const int i0 = (t / m.tiles_n) * TS, j0 = (t % m.tiles_n) * TS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -178,6 +197,7 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
             }
         }
         __syncthreads();
+        DSTAMP();                                 // (D <= KC: one trip) operands staged
         // the chunk is zero-filled past kn, and fma(0, 0, acc) == acc exactly, so
         // whole float4 groups can be consumed; k still ascends one at a time
         if (wave < 2) {                           // the tile's 64 + 64 row norms, same sequential chain as the oracle
@@ -195,8 +215,10 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
         }
         __syncthreads();
     }
+    DSTAMP();                                     // norms + MFMA + barrier
     if (wave < 2) (wave == 0 ? inx_s : iny_s)[lane] = 1.0f / sqrtf(nsum);
     __syncthreads();                              // reciprocal norms are staged
+    DSTAMP();
     const int i = i0 + ib + r;
     const float inx = inx_s[ib + r];
     // zero rows (reciprocal norm = inf) are rare: tiles without one skip their handling
@@ -220,6 +242,7 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
     if (zero_rows) epilogue(std::true_type{}); else epilogue(std::false_type{});
     if (any_bad) atomicOr(&bad[p], 1);
     __syncthreads();
+    DSTAMP();                                     // acos epilogue
     // write-out in DP order: one float4 = row i on the four diagonals of group g
     // (cells j = 4g - i .. 4g - i + 3); a wave takes one group, lanes take rows
     {
@@ -242,6 +265,13 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
             }
         }
     }
+    DSTAMP();                                     // write-out issued
+#ifdef ABN_DIST_STAMPS
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < nk && q < 8; ++q) atomicAdd(&g_dist_cycles[q], tk[q] - tk[q - 1]);
+        atomicAdd(&g_dist_cycles[0], 1ull);
+    }
+#endif
 }
 
 constexpr int DP_MAXN = 1024;        // longest first token a wavefront can sweep (16 rows per lane)
@@ -502,6 +532,13 @@ static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P, int64_t r
     return w;
 }
 
+#ifdef ABN_DIST_STAMPS
+extern "C" int abn_debug_dist_cycles(unsigned long long* out8)
+{
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(abn::g_dist_cycles), 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int64_t abn_dtw_ws_bytes(const int32_t* n1_host, const int32_t* n2_host, int64_t npairs,
                                          int64_t rows1, int64_t rows2)
 {
@@ -588,8 +625,8 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
     if (tiles > 0) {
         hipLaunchKernelGGL(expand_tiles_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
                            (const PairMeta*)(base + w.meta_off), (int)npairs, (int32_t*)(base + w.tilepair_off));
-        hipLaunchKernelGGL(dist_kernel, dim3((unsigned)tiles), dim3(256), 0, st, feats1, feats2,
-                           (const PairMeta*)(base + w.meta_off), (const int32_t*)(base + w.tilepair_off), (int)D,
+        hipLaunchKernelGGL(dist_kernel, dim3((unsigned)align_up(tiles, 8)), dim3(256), 0, st, feats1, feats2,
+                           (const PairMeta*)(base + w.meta_off), (const int32_t*)(base + w.tilepair_off), (int)tiles, (int)D,
                            (int)(D % 4 == 0 && aligned16(feats1) && aligned16(feats2)), (float*)(base + w.dist_off),
                            (int32_t*)(base + w.bad_off));
     }
