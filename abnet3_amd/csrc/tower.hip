@@ -163,37 +163,94 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, ReduceTable 
 constexpr float BN_EPS = 1e-5f;
 constexpr float BN_MOMENTUM = 0.1f;
 
-// per (call, column): batch mean and 1/sqrt(biased var + eps) over the call's
-// rows.  32 columns x 8 row-lanes per block; fp64 accumulation.
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int64_t rows_per_call,
-                                                       int C, float* __restrict__ mean,
-                                                       float* __restrict__ invstd,
-                                                       float* __restrict__ var_out)
+// BatchNorm column reductions run in two deterministic stages over many workgroups
+// (the first version used 32 workgroups for the whole matrix: 150-300 us per layer).
+// Stage 1: a workgroup sums `chunk_rows` rows of one forward_once call for 64 columns
+// (64 consecutive columns per row: 256-byte segments; 4 row lanes; fp64 accumulators)
+// and writes its partial sums; stage 2 adds the chunks of a column in a fixed order.
+constexpr int BN_MAX_CHUNKS = 128;
+static inline int bn_chunks(int64_t rows_per_call)
 {
-    __shared__ double s1[8][33], s2[8][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + tx, g = blockIdx.y;
-    const float* zg = z + (int64_t)g * rows_per_call * C;
-    double a = 0.0, b = 0.0;
+    const int64_t c = (rows_per_call + 63) / 64;
+    return (int)(c < 1 ? 1 : (c > BN_MAX_CHUNKS ? BN_MAX_CHUNKS : c));
+}
+static inline int64_t bn_chunk_rows(int64_t rows_per_call) { return (rows_per_call + bn_chunks(rows_per_call) - 1) / bn_chunks(rows_per_call); }
+
+// partial layout: part[((g * nchunks + chunk) * 2 + which) * C + c]
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ z /* fwd: z; bwd: da */,
+                                                         const float* __restrict__ a, const float* __restrict__ xhat,
+                                                         int64_t rows_per_call, int C, int64_t chunk_rows, int act,
+                                                         double* __restrict__ part)
+{
+    __shared__ double s1[4][64], s2[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx, chunk = blockIdx.y, g = blockIdx.z;
+    const int64_t r0 = chunk * chunk_rows, r1 = min(r0 + chunk_rows, rows_per_call);
+    const int64_t base = (int64_t)g * rows_per_call * C;
+    double u = 0.0, v = 0.0;
     if (c < C)
-        for (int64_t r = ty; r < rows_per_call; r += 8) {
-            const double v = zg[r * C + c];
-            a += v;
-            b += v * v;
+        for (int64_t r = r0 + ty; r < r1; r += 4) {
+            const int64_t i = base + r * C + c;
+            if (BWD) {     // s1 = sum dy, s2 = sum dy * xhat with dy = da * act'(a)
+                const double dy = (double)(z[i] * act_grad(a[i], act));
+                u += dy;
+                v += dy * xhat[i];
+            } else {       // s1 = sum z, s2 = sum z^2
+                const double x = z[i];
+                u += x;
+                v += x * x;
+            }
         }
-    s1[ty][tx] = a;
-    s2[ty][tx] = b;
+    s1[ty][tx] = u;
+    s2[ty][tx] = v;
     __syncthreads();
     if (ty == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { a += s1[k][tx]; b += s2[k][tx]; }
-        const double n = (double)rows_per_call;
-        const double m = a / n;
-        double var = b / n - m * m;
-        if (var < 0.0) var = 0.0;
-        mean[(int64_t)g * C + c] = (float)m;
-        var_out[(int64_t)g * C + c] = (float)var;
-        invstd[(int64_t)g * C + c] = 1.0f / sqrtf((float)var + BN_EPS);
+        for (int k = 1; k < 4; ++k) { u += s1[k][tx]; v += s2[k][tx]; }
+        double* dst = part + ((int64_t)(g * gridDim.y + chunk) * 2) * C;
+        dst[c] = u;
+        dst[C + c] = v;
     }
+}
+
+// forward: batch mean, biased variance, 1/sqrt(var + eps) per (call, column)
+__global__ void bn_stats_finish_kernel(const double* __restrict__ part, int nchunks, int64_t rows_per_call, int C,
+                                       int n_calls, float* __restrict__ mean, float* __restrict__ invstd,
+                                       float* __restrict__ var_out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_calls * C) return;
+    const int g = idx / C, c = idx % C;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+        const double* src = part + ((int64_t)(g * nchunks + k) * 2) * C;
+        a += src[c];
+        b += src[C + c];
+    }
+    const double n = (double)rows_per_call;
+    const double m = a / n;
+    double var = b / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[idx] = (float)m;
+    var_out[idx] = (float)var;
+    invstd[idx] = 1.0f / sqrtf((float)var + BN_EPS);
+}
+
+// backward: s1 = sum dy, s2 = sum dy * xhat per (call, column)
+__global__ void bn_bwd_finish_kernel(const double* __restrict__ part, int nchunks, int C, int n_calls,
+                                     float* __restrict__ s1o, float* __restrict__ s2o)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_calls * C) return;
+    const int g = idx / C, c = idx % C;
+    double u = 0.0, v = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+        const double* src = part + ((int64_t)(g * nchunks + k) * 2) * C;
+        u += src[c];
+        v += src[C + c];
+    }
+    s1o[idx] = (float)u;
+    s2o[idx] = (float)v;
 }
 
 // running stats: one momentum update per forward_once call, in call order
@@ -242,34 +299,6 @@ __global__ void bn_apply_kernel(const float* z /* may alias xhat */, int64_t row
     }
 }
 
-// per (call, column): s1 = sum dy, s2 = sum dy*xhat with dy = da * act'(a)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ a, const float* __restrict__ da,
-                                                            const float* __restrict__ xhat, int64_t rows_per_call,
-                                                            int C, int act, float* __restrict__ s1o,
-                                                            float* __restrict__ s2o)
-{
-    __shared__ double s1[8][33], s2[8][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + tx, g = blockIdx.y;
-    const int64_t base = (int64_t)g * rows_per_call * C;
-    double u = 0.0, v = 0.0;
-    if (c < C)
-        for (int64_t r = ty; r < rows_per_call; r += 8) {
-            const int64_t i = base + r * C + c;
-            const double dy = (double)(da[i] * act_grad(a[i], act));
-            u += dy;
-            v += dy * xhat[i];
-        }
-    s1[ty][tx] = u;
-    s2[ty][tx] = v;
-    __syncthreads();
-    if (ty == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { u += s1[k][tx]; v += s2[k][tx]; }
-        s1o[(int64_t)g * C + c] = (float)u;
-        s2o[(int64_t)g * C + c] = (float)v;
-    }
-}
-
 // dz = gamma*invstd/n * (n*dy - s1 - xhat*s2); also dgamma = sum_g s2, dbeta = sum_g s1
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ a, const float* da,   // da may alias dz
                                     const float* __restrict__ xhat, int64_t rows, int64_t rows_per_call,
@@ -304,6 +333,7 @@ struct Layout {
     int64_t a[ABN_MAX_LAYERS];           // post-activation outputs
     int64_t xhat[ABN_MAX_LAYERS];        // BN only (z is produced here, then normalised in place)
     int64_t mean[ABN_MAX_LAYERS], invstd[ABN_MAX_LAYERS], var[ABN_MAX_LAYERS];
+    int64_t bn_part;                     // BN only: stage-1 partial sums (doubles), shared by the layers
     int64_t total;
 };
 
@@ -324,6 +354,12 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
         } else {
             L.xhat[l] = L.mean[l] = L.invstd[l] = L.var[l] = -1;
         }
+    }
+    L.bn_part = -1;
+    if (t->batch_norm) {
+        int64_t maxw = 0;
+        for (int l = 1; l <= t->n_layers; ++l) maxw = t->dims[l] > maxw ? t->dims[l] : maxw;
+        L.bn_part = take(2 * n_calls * bn_chunks(rows / n_calls) * 2 * maxw);      // doubles = 2 floats each
     }
     L.total = o;
     return L;
@@ -368,6 +404,7 @@ static int split_count(int64_t rows, int64_t out_dim, int64_t in_dim)
 struct BwdLayout {
     int64_t dz[2];
     int64_t bn_s1, bn_s2;
+    int64_t bn_part;                 // stage-1 partial sums of the BatchNorm backward (doubles)
     int64_t slabs;
     int64_t slab_stride;
     int64_t off[ABN_MAX_LAYERS];
@@ -385,6 +422,7 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
     B.dz[1] = take(rows * maxw);
     B.bn_s1 = take(8 * maxw);
     B.bn_s2 = take(8 * maxw);
+    B.bn_part = take(2 * 8 * BN_MAX_CHUNKS * 2 * maxw);
     for (int l = 0; l < t->n_layers; ++l) {
         B.off[l] = packed;
         packed += align_up(t->dims[l + 1] * t->dims[l] + t->dims[l + 1], 64);
@@ -526,8 +564,12 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
             rc = launch_gemm<true, true, EPI_FWD>(p, 1, st);
             if (rc != ABN_OK) return rc;
             if (train) {
-                hipLaunchKernelGGL(bn_stats_kernel, dim3((N + 31) / 32, (int)n_calls), dim3(256), 0, st, z, rpc, N,
-                                   ws + L.mean[l], ws + L.invstd[l], ws + L.var[l]);
+                const int nch = bn_chunks(rpc);
+                double* part = reinterpret_cast<double*>(ws + L.bn_part);
+                hipLaunchKernelGGL(bn_partial_kernel<false>, dim3((N + 63) / 64, nch, (int)n_calls), dim3(256), 0, st, z,
+                                   nullptr, nullptr, rpc, N, bn_chunk_rows(rpc), 0, part);
+                hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((unsigned)((n_calls * N + 255) / 256)), dim3(256), 0, st,
+                                   part, nch, rpc, N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l]);
                 hipLaunchKernelGGL(bn_running_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws + L.mean[l],
                                    ws + L.var[l], N, (int)n_calls, rpc, t->bn_rm[l], t->bn_rv[l]);
             }
@@ -574,8 +616,12 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, a, d_out,
                                t->drop_mask[nl - 1], dz, rows * N, t->last_act);
         } else {
-            hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((N + 31) / 32, (int)n_calls), dim3(256), 0, st, a, d_out,
-                               ws + L.xhat[nl - 1], rpc, N, t->last_act, scratch + B.bn_s1, scratch + B.bn_s2);
+            const int nch = bn_chunks(rpc);
+            double* part = reinterpret_cast<double*>(scratch + B.bn_part);
+            hipLaunchKernelGGL(bn_partial_kernel<true>, dim3((N + 63) / 64, nch, (int)n_calls), dim3(256), 0, st, d_out, a,
+                               ws + L.xhat[nl - 1], rpc, N, bn_chunk_rows(rpc), t->last_act, part);
+            hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((n_calls * N + 255) / 256)), dim3(256), 0, st, part,
+                               nch, N, (int)n_calls, scratch + B.bn_s1, scratch + B.bn_s2);
             hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, a, d_out,
                                ws + L.xhat[nl - 1], rows, rpc, N, t->last_act, t->bn_w[nl - 1],
                                ws + L.invstd[nl - 1], scratch + B.bn_s1, scratch + B.bn_s2, (int)n_calls,
@@ -625,8 +671,12 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             if (l > 0 && t->batch_norm) {
                 // dst holds d a_{l-1}; turn it into d z_{l-1} through act' and BN
                 const float* a = ws + L.a[l - 1];
-                hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((Kin + 31) / 32, (int)n_calls), dim3(256), 0, st, a,
-                                   dst, ws + L.xhat[l - 1], rpc, Kin, t->act, scratch + B.bn_s1, scratch + B.bn_s2);
+                const int nch = bn_chunks(rpc);
+                double* part = reinterpret_cast<double*>(scratch + B.bn_part);
+                hipLaunchKernelGGL(bn_partial_kernel<true>, dim3((Kin + 63) / 64, nch, (int)n_calls), dim3(256), 0, st,
+                                   dst, a, ws + L.xhat[l - 1], rpc, Kin, bn_chunk_rows(rpc), t->act, part);
+                hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((n_calls * Kin + 255) / 256)), dim3(256), 0, st,
+                                   part, nch, Kin, (int)n_calls, scratch + B.bn_s1, scratch + B.bn_s2);
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * Kin)), dim3(256), 0, st, a, dst,
                                    ws + L.xhat[l - 1], rows, rpc, Kin, t->act, t->bn_w[l - 1], ws + L.invstd[l - 1],
                                    scratch + B.bn_s1, scratch + B.bn_s2, (int)n_calls, t->drop_mask[l - 1], dst,

@@ -207,6 +207,44 @@ def synth_dtw_pairs(P, seed, D=40):
     return f1, o1, n1, f2, o2, n2
 
 
+def variants_bench(torch, pool, args, rank, world):
+    """SURVEY.md 8d also lists the C2 step with BatchNorm on, and with the trainer's
+    class-default optimizer SGD(0.001, 0.9): same workload, shorter runs, reported
+    beside the headline (canonical: no BatchNorm, Adadelta(0.1))."""
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.loss import coscos2
+    from abnet3_amd.trainer import TrainerSiamese
+    out = {}
+    for name, bn, opt, lr in (('batch_norm_adadelta', True, 'adadelta', 0.1), ('no_bn_sgd', False, 'sgd', 0.001)):
+        torch.manual_seed(0)
+        net = SiameseNetwork(output_path='/tmp/abnet3_bench_v%d' % rank, **dict(C2, batch_norm=bn))
+        tr = TrainerSiamese(network=net, loss=coscos2(avg=False), optimizer_type=opt, lr=lr,
+                            dataloader=None, log_dir='/tmp/abnet3_bench_runs')
+        net.train()
+        stepper = tr.make_graphed_step(pool[0])
+        packed = [tr.pack_batch(b) for b in pool]
+        steps = max(20, args.steps // 4)
+        for i in range(10):
+            stepper(packed[i % POOL])
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            stepper(packed[i % POOL])
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=pool[0][0].device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        out[name] = {'value': round(steps * BATCH * world / elapsed, 1), 'unit': 'frame-pairs/s',
+                     'ms_per_step': round(elapsed / steps * 1e3, 4), 'steps': steps}
+    return out
+
+
 def bf16_mode_bench(torch, trainer, net, pool, args, world):
     """BASELINE.json configs[1] names bf16: the same C2 step with the tower GEMMs'
     operands rounded to bf16 (fp32 accumulate / storage / loss / optimizer;
@@ -408,6 +446,7 @@ def main():
     last_loss = float(loss)
 
     bf16 = bf16_mode_bench(torch, trainer, net, pool, args, world) if not args.no_graph else None
+    variants = variants_bench(torch, pool, args, rank, world) if not args.no_graph else None
     dtw = dtw_bench(torch, args.dtw_pairs, rank, world) if args.dtw_pairs > 0 else None
 
     if rank == 0:
@@ -433,6 +472,8 @@ def main():
             out['gpu_over_cpu'] = round(value / cb['value'], 1)
         if bf16 is not None:
             out['bf16_throughput_mode'] = bf16
+        if variants is not None:
+            out['f32_variants'] = variants
         if dtw is not None:
             out['dtw'] = dtw
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,15 @@
+"""Eager C2 train steps with BatchNorm on, for a kernel trace."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from abnet3_amd.model import SiameseNetwork
+from abnet3_amd.loss import coscos2
+from abnet3_amd.trainer import TrainerSiamese
+torch.manual_seed(0)
+net = SiameseNetwork(output_path='/tmp/abn_bn', **dict(bench.C2, batch_norm=True))
+tr = TrainerSiamese(network=net, loss=coscos2(avg=False), optimizer_type='adadelta', lr=0.1, dataloader=None, log_dir='/tmp/abn_runs')
+pool = bench.make_pool(seed=0, device=torch.device('cuda'))
+net.train()
+for i in range(12):
+    tr.train_step(pool[i % len(pool)], True)
+torch.cuda.synchronize()
