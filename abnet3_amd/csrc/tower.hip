@@ -213,27 +213,38 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
-// forward: batch mean, biased variance, 1/sqrt(var + eps) per (call, column)
+// forward, one thread per column: batch mean, biased variance, 1/sqrt(var + eps) of
+// every call, then the running statistics -- one momentum update per forward_once call,
+// in call order (the reference updates twice per Siamese forward)
 __global__ void bn_stats_finish_kernel(const double* __restrict__ part, int nchunks, int64_t rows_per_call, int C,
                                        int n_calls, float* __restrict__ mean, float* __restrict__ invstd,
-                                       float* __restrict__ var_out)
+                                       float* __restrict__ var_out, float* __restrict__ rm, float* __restrict__ rv)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_calls * C) return;
-    const int g = idx / C, c = idx % C;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-        const double* src = part + ((int64_t)(g * nchunks + k) * 2) * C;
-        a += src[c];
-        b += src[C + c];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float m_run = rm[c], v_run = rv[c];
+    const float unb = rows_per_call > 1 ? (float)((double)rows_per_call / (double)(rows_per_call - 1)) : 1.0f;
+    for (int g = 0; g < n_calls; ++g) {
+        double a = 0.0, b = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < nchunks; ++k) {       // fixed order; the loads are independent
+            const double* src = part + ((int64_t)(g * nchunks + k) * 2) * C;
+            a += src[c];
+            b += src[C + c];
+        }
+        const double n = (double)rows_per_call;
+        const double m = a / n;
+        double var = b / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const int64_t idx = (int64_t)g * C + c;
+        mean[idx] = (float)m;
+        var_out[idx] = (float)var;
+        invstd[idx] = 1.0f / sqrtf((float)var + BN_EPS);
+        m_run = (1.0f - BN_MOMENTUM) * m_run + BN_MOMENTUM * (float)m;
+        v_run = (1.0f - BN_MOMENTUM) * v_run + BN_MOMENTUM * ((float)var * unb);
     }
-    const double n = (double)rows_per_call;
-    const double m = a / n;
-    double var = b / n - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[idx] = (float)m;
-    var_out[idx] = (float)var;
-    invstd[idx] = 1.0f / sqrtf((float)var + BN_EPS);
+    rm[c] = m_run;
+    rv[c] = v_run;
 }
 
 // backward: s1 = sum dy, s2 = sum dy * xhat per (call, column)
@@ -244,6 +255,7 @@ __global__ void bn_bwd_finish_kernel(const double* __restrict__ part, int nchunk
     if (idx >= n_calls * C) return;
     const int g = idx / C, c = idx % C;
     double u = 0.0, v = 0.0;
+#pragma unroll 8
     for (int k = 0; k < nchunks; ++k) {
         const double* src = part + ((int64_t)(g * nchunks + k) * 2) * C;
         u += src[c];
@@ -251,24 +263,6 @@ __global__ void bn_bwd_finish_kernel(const double* __restrict__ part, int nchunk
     }
     s1o[idx] = (float)u;
     s2o[idx] = (float)v;
-}
-
-// running stats: one momentum update per forward_once call, in call order
-// (the reference updates twice per Siamese forward)
-__global__ void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var,
-                                  int C, int n_calls, int64_t rows_per_call,
-                                  float* __restrict__ rm, float* __restrict__ rv)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float m = rm[c], v = rv[c];
-    const float unb = rows_per_call > 1 ? (float)((double)rows_per_call / (double)(rows_per_call - 1)) : 1.0f;
-    for (int g = 0; g < n_calls; ++g) {
-        m = (1.0f - BN_MOMENTUM) * m + BN_MOMENTUM * mean[(int64_t)g * C + c];
-        v = (1.0f - BN_MOMENTUM) * v + BN_MOMENTUM * (var[(int64_t)g * C + c] * unb);
-    }
-    rm[c] = m;
-    rv[c] = v;
 }
 
 // xhat = (z - mean) * invstd ; a = act(gamma * xhat + beta).  train: per-call
@@ -568,10 +562,9 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 double* part = reinterpret_cast<double*>(ws + L.bn_part);
                 hipLaunchKernelGGL(bn_partial_kernel<false>, dim3((N + 63) / 64, nch, (int)n_calls), dim3(256), 0, st, z,
                                    nullptr, nullptr, rpc, N, bn_chunk_rows(rpc), 0, part);
-                hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((unsigned)((n_calls * N + 255) / 256)), dim3(256), 0, st,
-                                   part, nch, rpc, N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l]);
-                hipLaunchKernelGGL(bn_running_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws + L.mean[l],
-                                   ws + L.var[l], N, (int)n_calls, rpc, t->bn_rm[l], t->bn_rv[l]);
+                hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, part, nch, rpc,
+                                   N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l], t->bn_rm[l],
+                                   t->bn_rv[l]);
             }
             hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, z, rows, rpc, N,
                                ws + L.mean[l], ws + L.invstd[l], t->bn_rm[l], t->bn_rv[l], train, t->bn_w[l],
@@ -620,7 +613,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             double* part = reinterpret_cast<double*>(scratch + B.bn_part);
             hipLaunchKernelGGL(bn_partial_kernel<true>, dim3((N + 63) / 64, nch, (int)n_calls), dim3(256), 0, st, d_out, a,
                                ws + L.xhat[nl - 1], rpc, N, bn_chunk_rows(rpc), t->last_act, part);
-            hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((n_calls * N + 255) / 256)), dim3(256), 0, st, part,
+            hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((n_calls * N + 63) / 64)), dim3(64), 0, st, part,
                                nch, N, (int)n_calls, scratch + B.bn_s1, scratch + B.bn_s2);
             hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, a, d_out,
                                ws + L.xhat[nl - 1], rows, rpc, N, t->last_act, t->bn_w[nl - 1],
@@ -675,7 +668,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
                 double* part = reinterpret_cast<double*>(scratch + B.bn_part);
                 hipLaunchKernelGGL(bn_partial_kernel<true>, dim3((Kin + 63) / 64, nch, (int)n_calls), dim3(256), 0, st,
                                    dst, a, ws + L.xhat[l - 1], rpc, Kin, bn_chunk_rows(rpc), t->act, part);
-                hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((n_calls * Kin + 255) / 256)), dim3(256), 0, st,
+                hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((n_calls * Kin + 63) / 64)), dim3(64), 0, st,
                                    part, nch, Kin, (int)n_calls, scratch + B.bn_s1, scratch + B.bn_s2);
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * Kin)), dim3(256), 0, st, a, dst,
                                    ws + L.xhat[l - 1], rows, rpc, Kin, t->act, t->bn_w[l - 1], ws + L.invstd[l - 1],

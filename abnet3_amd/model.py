@@ -186,9 +186,8 @@ class _TowerFunction(torch.autograd.Function):
         _lib.check(lib.abn_tower_forward(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2),
                                          rows, n_calls, int(train), _lib.ptr(ws),
                                          _lib.stream()), 'abn_tower_forward')
-        if train and seg.batch_norm:
-            for bn in seg.bn_modules():
-                bn.num_batches_tracked += n_calls
+        if train and seg.batch_norm:        # one launch for all the counters
+            torch._foreach_add_([bn.num_batches_tracked for bn in seg.bn_modules()], n_calls)
         off = lib.abn_tower_out_offset(_lib.C.byref(desc), rows, n_calls)
         out = ws[off:off + rows * seg.output_dim].view(rows, seg.output_dim)
         ctx.seg, ctx.grad_pass, ctx.n_calls, ctx.train = seg, grad_pass, n_calls, train
