@@ -38,29 +38,37 @@ class EmbedderSiamese(EmbedderBuilder):
     def __init__(self, *args, **kwargs):
         super(EmbedderSiamese, self).__init__(*args, **kwargs)
 
+    # rows per forward launch: utterances are concatenated up to this many frames
+    ROWS_PER_LAUNCH = 65536
+
     def embed_features(self, feats):
-        """The reference's per-utterance loop (embedder.py:80-96) over a list of
-        [T, D] arrays; returns the list of [T, output_dim] float32 embeddings."""
+        """What the reference's per-utterance loop (embedder.py:80-96) computes, for a
+        list of [T, D] arrays: the list of [T, output_dim] float32 embeddings.
+
+        In eval mode every output row depends on its own input row only (BatchNorm
+        uses the running statistics), so the utterances are concatenated into
+        launches of up to ROWS_PER_LAUNCH frames instead of one (or several
+        `batch_size` chunks) per utterance: same values, far fewer launches and
+        host<->device copies."""
         self.network.eval()
         self.network.cuda()
-        embeddings = []
+        feats = [f if f.dtype == np.float32 else f.astype(np.float32) for f in feats]
+        lengths = [len(f) for f in feats]
+        out_dim = self.network.output_dim
+        total = int(sum(lengths))
+        if total == 0:
+            return [np.zeros((0, out_dim), np.float32) for _ in feats]
+        allrows = np.concatenate([f for f in feats if len(f)], axis=0)
+        emb = np.empty((total, out_dim), np.float32)
         with torch.no_grad():
-            for feat in feats:
-                if feat.dtype != np.float32:
-                    feat = feat.astype(np.float32)
-                if len(feat) == 0:
-                    embeddings.append(np.zeros((0, self.network.output_dim), np.float32))
-                    continue
-                n_batches = len(feat) // self.batch_size + 1
-                outputs = []
-                for b_feat in np.array_split(feat, n_batches):
-                    if len(b_feat) == 0:
-                        continue
-                    x = torch.from_numpy(np.ascontiguousarray(b_feat)).cuda()
-                    emb = self.network.forward_once(x)   # first output of network(x, x)
-                    outputs.append(emb.cpu().numpy())
-                embeddings.append(np.vstack(outputs))
-        return embeddings
+            for r0 in range(0, total, self.ROWS_PER_LAUNCH):
+                x = torch.from_numpy(np.ascontiguousarray(allrows[r0:r0 + self.ROWS_PER_LAUNCH])).cuda()
+                emb[r0:r0 + len(x)] = self.network.forward_once(x).cpu().numpy()   # first output of network(x, x)
+        out, o = [], 0
+        for n in lengths:
+            out.append(emb[o:o + n])
+            o += n
+        return out
 
     def embed(self):
         """Embed method to embed features based on a saved network."""
@@ -94,26 +102,37 @@ class EmbedderSiameseMultitask(EmbedderBuilder):
     def __init__(self, *args, **kwargs):
         super(EmbedderSiameseMultitask, self).__init__(*args, **kwargs)
 
+    ROWS_PER_LAUNCH = 65536
+
     def embed_features(self, feats):
-        """([T, out] speaker embeddings], [[T, out] phone embeddings]) for a list
-        of [T, D] arrays (the loop of embedder.py:130-140)."""
+        """([[T, out] speaker embeddings], [[T, out] phone embeddings]) for a list of
+        [T, D] arrays (the loop of embedder.py:130-140); utterances are concatenated
+        into launches of up to ROWS_PER_LAUNCH frames (rows are independent in eval
+        mode, see EmbedderSiamese.embed_features)."""
         self.network.eval()
         self.network.cuda()
-        embeddings_spk, embeddings_phn = [], []
+        feats = [f if f.dtype == np.float32 else f.astype(np.float32) for f in feats]
+        lengths = [len(f) for f in feats]
+        out_dim = self.network.output_dim
+        total = int(sum(lengths))
+        if total == 0:
+            empty = [np.zeros((0, out_dim), np.float32) for _ in feats]
+            return empty, [e.copy() for e in empty]
+        allrows = np.concatenate([f for f in feats if len(f)], axis=0)
+        spk = np.empty((total, out_dim), np.float32)
+        phn = np.empty((total, out_dim), np.float32)
         with torch.no_grad():
-            for feat in feats:
-                if feat.dtype != np.float32:
-                    feat = feat.astype(np.float32)
-                if len(feat) == 0:
-                    empty = np.zeros((0, self.network.output_dim), np.float32)
-                    embeddings_spk.append(empty)
-                    embeddings_phn.append(empty.copy())
-                    continue
-                x = torch.from_numpy(np.ascontiguousarray(feat)).cuda()
-                emb_spk, emb_phn = self.network.forward_once(x)   # network(x, x)[:2]
-                embeddings_spk.append(emb_spk.cpu().numpy())
-                embeddings_phn.append(emb_phn.cpu().numpy())
-        return embeddings_spk, embeddings_phn
+            for r0 in range(0, total, self.ROWS_PER_LAUNCH):
+                x = torch.from_numpy(np.ascontiguousarray(allrows[r0:r0 + self.ROWS_PER_LAUNCH])).cuda()
+                emb_spk, emb_phn = self.network.forward_once(x)      # network(x, x)[:2]
+                spk[r0:r0 + len(x)] = emb_spk.cpu().numpy()
+                phn[r0:r0 + len(x)] = emb_phn.cpu().numpy()
+        out_spk, out_phn, o = [], [], 0
+        for n in lengths:
+            out_spk.append(spk[o:o + n])
+            out_phn.append(phn[o:o + n])
+            o += n
+        return out_spk, out_phn
 
     def embed(self):
         if self.network_path is not None:
