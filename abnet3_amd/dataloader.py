@@ -163,15 +163,16 @@ class OriginalDataLoader(DataLoader):
         """DTW-aligns every not-yet-cached 'same' pair in ONE batched GPU call
         (get_dtw_alignment, dataloader.py:189).  Dropped pairs (NaN distance,
         dataloader.py:188-191) are cached as None."""
-        todo = []
+        todo, queued = [], set()
         for p in same_pairs:
             key = tuple(p) + (frames,)
-            if key in self._align or key in todo:
+            if key in self._align or key in queued:
                 continue
             f1, s1, e1, f2, s2, e2 = p
             if (s1 > e1) or (s2 > e2):
                 continue
             todo.append(key)
+            queued.add(key)
         if not todo:
             return
         o1, n1, o2, n2 = [], [], [], []
@@ -225,6 +226,7 @@ class OriginalDataLoader(DataLoader):
         self.align_pairs(pairs['same'], frames)
         dev = self.features.table.device
         idx1, idx2, ys, ys_spk = [], [], [], []
+        d1, d2 = [], []                       # diff pairs: host index arrays, ONE upload per batch
         for f1, s1, e1, f2, s2, e2 in pairs['same']:
             if (s1 > e1) or (s2 > e2):
                 continue
@@ -257,14 +259,19 @@ class OriginalDataLoader(DataLoader):
                 m = min(n1, n2)
                 w1 = a0 + np.arange(m)
                 w2 = b0 + np.arange(m)
-            idx1.append(torch.from_numpy(w1.astype(np.int64)).to(dev))
-            idx2.append(torch.from_numpy(w2.astype(np.int64)).to(dev))
+            d1.append(w1.astype(np.int64))
+            d2.append(w2.astype(np.int64))
             ys.append(-1 * np.ones(min(n1, n2)))
             self.statistics_training['DiffType'] += 1
             if fid2spk:
                 same = self.same_speaker(fid2spk, f1, f2)
                 ys_spk.append((1 if same else -1) * np.ones(min(n1, n2)))
                 self.statistics_training['DiffTypeSameSpk' if same else 'DiffTypeDiffSpk'] += 1
+        if d1:                                # after the same pairs, like the reference's vstack order
+            both = torch.from_numpy(np.concatenate(d1 + d2)).to(dev)
+            n_d = both.numel() // 2
+            idx1.append(both[:n_d])
+            idx2.append(both[n_d:])
         if not idx1:
             raise ValueError('need at least one array to concatenate')
         i1, i2 = torch.cat(idx1), torch.cat(idx2)
@@ -377,15 +384,20 @@ class FramesDataLoader(OriginalDataLoader):
             i1.append(al[0]); i2.append(al[1])
             ys.append(np.ones(len(al[0]), dtype=np.int64))
             self.statistics_training['SameType'] += 1
+        d1, d2 = [], []                       # diff pairs: host index ranges, one upload for all
         for f1, s1, e1, f2, s2, e2 in pairs['diff']:
             if (s1 > e1) or (s2 > e2):
                 continue
             (a0, n1), (b0, n2) = self.features.token(f1, s1, e1), self.features.token(f2, s2, e2)
             m = min(n1, n2)
-            i1.append(torch.arange(a0, a0 + m, device=dev))
-            i2.append(torch.arange(b0, b0 + m, device=dev))
+            d1.append(np.arange(a0, a0 + m, dtype=np.int64))
+            d2.append(np.arange(b0, b0 + m, dtype=np.int64))
             ys.append(-np.ones(m, dtype=np.int64))
             self.statistics_training['DiffType'] += 1
+        if d1:
+            both = torch.from_numpy(np.concatenate(d1 + d2)).to(dev)
+            i1.append(both[:both.numel() // 2])
+            i2.append(both[both.numel() // 2:])
         if not i1:
             z = torch.zeros(0, dtype=torch.int64, device=dev)
             return z, z, z

@@ -48,8 +48,8 @@ class EmbedderSiamese(EmbedderBuilder):
         In eval mode every output row depends on its own input row only (BatchNorm
         uses the running statistics), so the utterances are concatenated into
         launches of up to ROWS_PER_LAUNCH frames instead of one (or several
-        `batch_size` chunks) per utterance: same values, far fewer launches and
-        host<->device copies."""
+        `batch_size` chunks) per utterance: the same values up to fp32 summation order
+        (large launches take the fused kernel), far fewer launches and copies."""
         self.network.eval()
         self.network.cuda()
         feats = [f if f.dtype == np.float32 else f.astype(np.float32) for f in feats]
