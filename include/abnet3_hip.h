@@ -164,7 +164,11 @@ int abn_optimizer_step(int kind, float* params, const float* grads, float* state
  * stream has passed this call).  path1/path2: [npairs, path_stride] int32
  * (device), the path from (0,0) to (n1-1,n2-1); path_len[p] = 0 marks a pair
  * the reference would have dropped (NaN distance, abnet3/dataloader.py:188-191).
- * total_cost (device, [npairs] f64) may be NULL.  n1[p] <= 1024. */
+ * total_cost (device, [npairs] f64) may be NULL.  n1[p] <= 1024.
+ * The size classes of the DP run on library-owned side streams, forked from and joined
+ * back into `stream` with events (no host synchronisation; capturable).  rows1 / rows2
+ * bound the offsets (checked); abn_dtw_ws_bytes ignores them since ABI 3 (the row norms
+ * are recomputed per tile) but keeps the arguments. */
 int64_t abn_dtw_ws_bytes(const int32_t* n1_host, const int32_t* n2_host,
                          int64_t npairs, int64_t rows1, int64_t rows2);
 int64_t abn_dtw_host_stage_bytes(const int32_t* n1_host, const int32_t* n2_host,
