@@ -34,11 +34,14 @@ static void launch_one(const GemmP& p, int splits, hipStream_t st)
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     constexpr size_t lds = gemm_lds_bytes<BM, BN, A_KC, B_KC>();
     auto k = gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, VEC, BF16>;
-    static bool attr_set = false;      // > 64 KiB of dynamic LDS needs the opt-in
-    if (!attr_set) {
+    static bool attr_set[16] = {};     // > 64 KiB of dynamic LDS needs the opt-in, once per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = (dev >= 0 && dev < 16) ? dev : 0;
+    if (!attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     GemmP q = p;
     q.splits = splits;
@@ -509,13 +512,16 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
 #ifdef ABN_STAMPS
         f.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
 #endif
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[16] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev = (dev >= 0 && dev < 16) ? dev : 0;
+        if (!attr_set[dev]) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_fused_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_fused_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES);
-            attr_set = true;
+            attr_set[dev] = true;
         }
         const dim3 fgrid((unsigned)((rows + FUSED_ROWS - 1) / FUSED_ROWS));
         if (f.bf16) hipLaunchKernelGGL(tower_fwd_fused_kernel<true>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
