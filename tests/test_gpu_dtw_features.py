@@ -310,3 +310,52 @@ def test_dtw_full_size_properties():
     # symmetry: swap the roles of the two tokens for the first 2000 pairs
     sw = dtw_align_batch(d2, o2[:2000], n2[:2000], d1, o1[:2000], n1[:2000])
     assert np.allclose(sw.total_cost.cpu().numpy(), cost[:2000], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_dtw_randomised_shapes_bit_exact(seed):
+    """Random feature widths (also odd, also < 4), token lengths 1..200, repeated rows
+    (exact ties in the DP), zero rows (distance 1 / 0 rules) and tiny / huge scales:
+    paths and accumulated costs bit-identical to the C oracle for every pair."""
+    from abnet3_amd.utils import dtw_align_batch
+    from oracle import dtw_oracle as O
+    rng = np.random.default_rng(100 + seed)
+    D = int(rng.choice([1, 3, 4, 13, 40, 47]))
+    P = 60
+    n1 = rng.integers(1, 200, P).astype(np.int32)
+    n2 = rng.integers(1, 200, P).astype(np.int32)
+    o1 = np.concatenate(([0], np.cumsum(n1)[:-1])).astype(np.int64)
+    o2 = np.concatenate(([0], np.cumsum(n2)[:-1])).astype(np.int64)
+    f1 = rng.standard_normal((int(n1.sum()), D)).astype(np.float32)
+    f2 = rng.standard_normal((int(n2.sum()), D)).astype(np.float32)
+    for p in range(P):
+        a, b = f1[o1[p]:o1[p] + n1[p]], f2[o2[p]:o2[p] + n2[p]]
+        kind = p % 6
+        if kind == 1 and n1[p] > 3:            # runs of identical frames: ties
+            a[1:n1[p] // 2] = a[0]
+        elif kind == 2 and n2[p] > 2:          # a zero row on one side
+            b[n2[p] // 2] = 0.0
+        elif kind == 3:                        # zero rows on both sides
+            a[0] = 0.0
+            b[-1] = 0.0
+        elif kind == 4:                        # scale must not matter to the path's validity
+            a *= np.float32(1e-6)
+            b *= np.float32(3e5)
+        elif kind == 5 and n2[p] > 1:          # y a copy of x's frames: zero-distance cells
+            b[:] = a[rng.integers(0, n1[p], n2[p])]
+    res = dtw_align_batch(torch.from_numpy(f1).cuda(), o1, n1, torch.from_numpy(f2).cuda(), o2, n2)
+    got = res.to_lists()
+    cost = res.total_cost.cpu().numpy()
+    dropped = 0
+    for p in range(P):
+        try:
+            d = O.cosine_distance(f1[o1[p]:o1[p] + n1[p]], f2[o2[p]:o2[p] + n2[p]])
+        except AssertionError:                 # cos rounded above 1 -> NaN: utils.py:59 asserts and
+            assert got[p] is None, p           # the loader drops the pair; the oracle says the same
+            dropped += 1
+            continue
+        q1, q2 = O.dtw_path(d)
+        assert got[p] is not None, p
+        assert np.array_equal(got[p][0], q1) and np.array_equal(got[p][1], q2), (p, D)
+        assert cost[p] == O.dtw_cost(d), p
+    assert dropped < P // 2
