@@ -32,29 +32,35 @@ def unit_grad(device):
     return t
 
 
+def _pair_loss_raw(e1, e2, y, kind, margin, avg, need_grad):
+    """abn_pair_loss: (0-dim loss, [2, B, D] gradient of the loss w.r.t. (e1, e2) or None)."""
+    lib = _lib.load()
+    _lib.require_device(e1, e2, y)
+    if e1.dtype != torch.float32 or e2.dtype != torch.float32:
+        raise TypeError('abnet3_amd: embeddings must be float32')
+    if y.dtype not in _lib.Y_DTYPE:
+        raise TypeError('abnet3_amd: unsupported label dtype %s' % y.dtype)
+    B, D = e1.shape
+    if y.numel() != B:
+        raise ValueError('abnet3_amd: %d labels for %d pairs' % (y.numel(), B))
+    e1, e2, y = e1.contiguous(), e2.contiguous(), y.contiguous()
+    loss = torch.empty((), dtype=torch.float32, device=e1.device)
+    de = torch.empty(2, B, D, dtype=torch.float32, device=e1.device) if need_grad else None
+    ws = torch.empty(lib.abn_pair_loss_ws_bytes(B), dtype=torch.uint8, device=e1.device)
+    _lib.check(lib.abn_pair_loss(
+        _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(y), _lib.Y_DTYPE[y.dtype], B, D,
+        _lib.LOSS[kind], float(margin), int(bool(avg)), _lib.ptr(loss),
+        _lib.ptr(de[0]) if need_grad else None,
+        _lib.ptr(de[1]) if need_grad else None, _lib.ptr(ws), _lib.stream()),
+        'abn_pair_loss')
+    return loss, de
+
+
 class _PairLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e1, e2, y, kind, margin, avg):
-        lib = _lib.load()
-        _lib.require_device(e1, e2, y)
-        if e1.dtype != torch.float32 or e2.dtype != torch.float32:
-            raise TypeError('abnet3_amd: embeddings must be float32')
-        if y.dtype not in _lib.Y_DTYPE:
-            raise TypeError('abnet3_amd: unsupported label dtype %s' % y.dtype)
-        B, D = e1.shape
-        if y.numel() != B:
-            raise ValueError('abnet3_amd: %d labels for %d pairs' % (y.numel(), B))
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        loss = torch.empty((), dtype=torch.float32, device=e1.device)
-        de = torch.empty(2, B, D, dtype=torch.float32, device=e1.device) if need_grad else None
-        ws = torch.empty(lib.abn_pair_loss_ws_bytes(B), dtype=torch.uint8, device=e1.device)
-        _lib.check(lib.abn_pair_loss(
-            _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(y), _lib.Y_DTYPE[y.dtype], B, D,
-            _lib.LOSS[kind], float(margin), int(bool(avg)), _lib.ptr(loss),
-            _lib.ptr(de[0]) if need_grad else None,
-            _lib.ptr(de[1]) if need_grad else None, _lib.ptr(ws), _lib.stream()),
-            'abn_pair_loss')
-        ctx.de = de
+        loss, ctx.de = _pair_loss_raw(e1, e2, y, kind, margin, avg, need_grad)
         return loss
 
     @staticmethod
@@ -100,6 +106,12 @@ class coscos2(LossBuilder):
     def forward(self, input1, input2, y):
         return _pair_loss(input1, input2, y, 'coscos2', 0.0, self.avg)
 
+    def value_and_grad(self, input1, input2, y):
+        """(loss, [2, B, D] gradient w.r.t. (input1, input2)) without autograd: what
+        forward(...).backward() yields, for a trainer that drives the kernels itself."""
+        assert input1.size() == input2.size(), 'Input not the same size'
+        return _pair_loss_raw(input1, input2, y, 'coscos2', 0.0, self.avg, True)
+
 
 class cosmargin(LossBuilder):
     """cosmargin Loss function (abnet3/loss.py:70-105); margin in [0, 1]."""
@@ -113,6 +125,10 @@ class cosmargin(LossBuilder):
     def forward(self, input1, input2, y, avg=True):
         # like the reference, the `avg` ARGUMENT is ignored (loss.py:103)
         return _pair_loss(input1, input2, y, 'cosmargin', self.margin, self.avg)
+
+    def value_and_grad(self, input1, input2, y):
+        assert input1.size() == input2.size(), 'Input not the same size'
+        return _pair_loss_raw(input1, input2, y, 'cosmargin', self.margin, self.avg, True)
 
 
 class weighted_loss_multi(LossBuilder):

@@ -89,13 +89,33 @@ class _Segment(object):
     def bn_modules(self):
         return [bn for _, bn in self.blocks if bn is not None]
 
+    def offsets(self):
+        """Float offsets of self.params in the network's flat buffers (the live
+        parameters are the segments' parameters, concatenated in segment order)."""
+        net = self.net
+        first = 0
+        for seg in net._segment_list():
+            if seg is self:
+                break
+            first += len(seg.params)
+        return net._offsets[first:first + len(self.params)]
+
     def masks_of(self, all_masks):
         if all_masks is None:
             return None
         return all_masks[self.first_block:self.first_block + len(self.blocks)]
 
-    def descriptor(self, with_grads, grad_views=None, masks=None):
-        self.net.flat_parameters()
+    def _template(self):
+        """The descriptor with everything but gradient and mask pointers filled in,
+        rebuilt only when the parameters were re-homed (a step calls this three
+        times; filling ~100 ctypes fields each time was a quarter of the eager
+        step's host cost)."""
+        net = self.net
+        net.flat_parameters()
+        key = (net._flat.data_ptr(), net._generation, net.precision)
+        cached = getattr(self, '_desc_cache', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
         d = _lib.TowerDesc()
         d.n_layers = len(self.blocks)
         d.act = _lib.ACT[self.act]
@@ -104,28 +124,41 @@ class _Segment(object):
                                       'the accelerated path' % (self.last_act,))
         d.last_act = _lib.ACT[self.last_act]
         d.batch_norm = int(self.batch_norm)
-        d.precision = _lib.PRECISION[self.net.precision]
+        d.precision = _lib.PRECISION[net.precision]
         d.dims[0] = self.input_dim
+        grad_slots = []                      # (field, layer, float offset in the flat buffers)
+        offs = self.offsets()                # in the order of self.params
         gi = 0
         for l, (lin, bn) in enumerate(self.blocks):
             d.dims[l + 1] = lin.out_features
             d.W[l] = lin.weight.data_ptr()
             d.b[l] = lin.bias.data_ptr()
-            if masks is not None:
-                d.drop_mask[l] = masks[l].data_ptr()
-            if with_grads:
-                d.dW[l] = grad_views[gi].data_ptr()
-                d.db[l] = grad_views[gi + 1].data_ptr()
+            grad_slots += [('dW', l, offs[gi]), ('db', l, offs[gi + 1])]
             gi += 2
             if bn is not None:
                 d.bn_w[l] = bn.weight.data_ptr()
                 d.bn_b[l] = bn.bias.data_ptr()
                 d.bn_rm[l] = bn.running_mean.data_ptr()
                 d.bn_rv[l] = bn.running_var.data_ptr()
-                if with_grads:
-                    d.dbn_w[l] = grad_views[gi].data_ptr()
-                    d.dbn_b[l] = grad_views[gi + 1].data_ptr()
+                grad_slots += [('dbn_w', l, offs[gi]), ('dbn_b', l, offs[gi + 1])]
                 gi += 2
+        self._desc_cache = (key, d, grad_slots)
+        return d
+
+    def descriptor(self, with_grads, grad_buf=None, masks=None):
+        """abn_tower_desc for one call.  grad_buf: the flat gradient buffer of this
+        backward pass (gradients land at the parameters' offsets in it)."""
+        tmpl = self._template()
+        if not with_grads and masks is None:
+            return tmpl                        # read-only for the library
+        d = _lib.TowerDesc.from_buffer_copy(tmpl)
+        if masks is not None:
+            for l, m in enumerate(masks):
+                d.drop_mask[l] = m.data_ptr()
+        if with_grads:
+            base = grad_buf.data_ptr()
+            for field, l, off in self._desc_cache[2]:
+                getattr(d, field)[l] = base + 4 * off
         return d
 
 
@@ -143,6 +176,7 @@ class _GradPass(object):
         self.used = set()
 
     def views(self, seg):
+        """(flat gradient buffer, its per-parameter views for `seg`)."""
         net = self.net
         net.flat_parameters()
         if self.buf is None or id(seg) in self.used:
@@ -153,8 +187,79 @@ class _GradPass(object):
         else:
             buf = self.buf
         self.used.add(id(seg))
-        return [buf[net._offset_of[id(p)]:net._offset_of[id(p)] + p.numel()].view(p.shape)
-                for p in seg.params]
+        specs = getattr(seg, '_view_specs', None)
+        if specs is None or specs[0] != net._flat.data_ptr():
+            specs = seg._view_specs = (net._flat.data_ptr(),
+                                       [(tuple(p.shape), tuple(p.stride()), off)
+                                        for p, off in zip(seg.params, seg.offsets())])
+        return buf, [buf.as_strided(shape, stride, off) for shape, stride, off in specs[1]]
+
+
+class _Saved(object):
+    """What a segment's forward leaves for its backward."""
+    __slots__ = ('x1', 'x2', 'ws', 'masks', 'n_calls', 'train', 'rows')
+
+
+def _segment_forward(seg, all_masks, n_calls, x1, x2):
+    """Raw forward of one segment (no autograd): the launch sequence of
+    abn_tower_forward.  Returns ([rows, out] embeddings as a view of the workspace,
+    _Saved)."""
+    lib = _lib.load()
+    net = seg.net
+    _lib.require_device(x1, x2)
+    if x1.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
+        raise TypeError('abnet3_amd: features must be float32 (the reference '
+                        'casts them, abnet3/utils.py:228-235)')
+    if x1.dim() != 2 or x1.shape[1] != seg.input_dim:
+        raise ValueError('abnet3_amd: expected input of shape [n, %d], got %s'
+                         % (seg.input_dim, tuple(x1.shape)))
+    if x2 is not None and x2.shape != x1.shape:
+        raise ValueError('abnet3_amd: the two inputs must have the same shape')
+    x1 = x1.contiguous()
+    x2 = x2.contiguous() if x2 is not None else None
+    train = bool(net.training)
+    rows = x1.shape[0] * (2 if x2 is not None else 1)
+    masks = seg.masks_of(all_masks) if train else None
+    desc = seg.descriptor(with_grads=False, masks=masks)
+    ws_floats = lib.abn_tower_ws_floats(_lib.C.byref(desc), rows, n_calls)
+    if ws_floats < 0:
+        _lib.check(-1, 'abn_tower_ws_floats')
+    ws = torch.empty(max(ws_floats, 1), dtype=torch.float32, device=x1.device)
+    _lib.check(lib.abn_tower_forward(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2),
+                                     rows, n_calls, int(train), _lib.ptr(ws),
+                                     _lib.stream()), 'abn_tower_forward')
+    if train and seg.batch_norm:        # one launch for all the counters
+        torch._foreach_add_([bn.num_batches_tracked for bn in seg.bn_modules()], n_calls)
+    off = lib.abn_tower_out_offset(_lib.C.byref(desc), rows, n_calls)
+    out = ws[off:off + rows * seg.output_dim].view(rows, seg.output_dim)
+    sv = _Saved()
+    sv.x1, sv.x2, sv.ws, sv.masks, sv.n_calls, sv.train, sv.rows = x1, x2, ws, masks, n_calls, train, rows
+    return out, sv
+
+
+def _segment_backward(seg, sv, d_out, grad_pass, need_dx):
+    """Raw backward of one segment: abn_tower_backward into the pass's flat gradient
+    buffer.  Returns (per-parameter gradient views, dx or None)."""
+    lib = _lib.load()
+    if seg.batch_norm and not sv.train:
+        raise NotImplementedError(
+            'abnet3_amd: backward through an eval-mode BatchNorm forward is '
+            'not on the accelerated path (the reference trains in train mode, '
+            'abnet3/trainer.py:234)')
+    d_out = d_out.contiguous()
+    _lib.require_device(d_out)
+    rows = d_out.shape[0]
+    grad_buf, grads = grad_pass.views(seg)
+    desc = seg.descriptor(with_grads=True, grad_buf=grad_buf, masks=sv.masks)
+    scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
+    scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32, device=d_out.device)
+    dx = torch.empty(rows, seg.input_dim, dtype=torch.float32,
+                     device=d_out.device) if need_dx else None
+    _lib.check(lib.abn_tower_backward(
+        _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(d_out), rows,
+        sv.n_calls, _lib.ptr(sv.ws), _lib.ptr(scratch), scratch_floats,
+        _lib.ptr(dx), _lib.stream()), 'abn_tower_backward')
+    return grads, dx
 
 
 class _TowerFunction(torch.autograd.Function):
@@ -162,49 +267,19 @@ class _TowerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, seg, grad_pass, all_masks, n_calls, split, x1, x2, *params):
-        lib = _lib.load()
-        net = seg.net
-        _lib.require_device(x1, x2, *params)
-        if x1.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
-            raise TypeError('abnet3_amd: features must be float32 (the reference '
-                            'casts them, abnet3/utils.py:228-235)')
-        if x1.dim() != 2 or x1.shape[1] != seg.input_dim:
-            raise ValueError('abnet3_amd: expected input of shape [n, %d], got %s'
-                             % (seg.input_dim, tuple(x1.shape)))
-        if x2 is not None and x2.shape != x1.shape:
-            raise ValueError('abnet3_amd: the two inputs must have the same shape')
-        x1 = x1.contiguous()
-        x2 = x2.contiguous() if x2 is not None else None
-        train = bool(net.training)
-        rows = x1.shape[0] * (2 if x2 is not None else 1)
-        masks = seg.masks_of(all_masks) if train else None
-        desc = seg.descriptor(with_grads=False, masks=masks)
-        ws_floats = lib.abn_tower_ws_floats(_lib.C.byref(desc), rows, n_calls)
-        if ws_floats < 0:
-            _lib.check(-1, 'abn_tower_ws_floats')
-        ws = torch.empty(max(ws_floats, 1), dtype=torch.float32, device=x1.device)
-        _lib.check(lib.abn_tower_forward(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2),
-                                         rows, n_calls, int(train), _lib.ptr(ws),
-                                         _lib.stream()), 'abn_tower_forward')
-        if train and seg.batch_norm:        # one launch for all the counters
-            torch._foreach_add_([bn.num_batches_tracked for bn in seg.bn_modules()], n_calls)
-        off = lib.abn_tower_out_offset(_lib.C.byref(desc), rows, n_calls)
-        out = ws[off:off + rows * seg.output_dim].view(rows, seg.output_dim)
-        ctx.seg, ctx.grad_pass, ctx.n_calls, ctx.train = seg, grad_pass, n_calls, train
-        ctx.masks = masks
+        _lib.require_device(*params)
+        out, sv = _segment_forward(seg, all_masks, n_calls, x1, x2)
+        ctx.seg, ctx.grad_pass, ctx.sv = seg, grad_pass, sv
         ctx.have_x2 = x2 is not None
         ctx.split = split
-        ctx.save_for_backward(x1, x2, ws)
         if split:        # the two towers' embeddings as two outputs (no slice nodes)
-            half = rows // 2
+            half = sv.rows // 2
             return out[:half], out[half:]
         return out
 
     @staticmethod
     def backward(ctx, *d_outs):
-        lib = _lib.load()
         seg = ctx.seg
-        x1, x2, ws = ctx.saved_tensors
         if ctx.split:
             d1, d2 = d_outs
             if d1 is None or d2 is None:
@@ -222,28 +297,11 @@ class _TowerFunction(torch.autograd.Function):
                 d_out = torch.cat([d1, d2])
         else:
             d_out = d_outs[0]
-        if seg.batch_norm and not ctx.train:
-            raise NotImplementedError(
-                'abnet3_amd: backward through an eval-mode BatchNorm forward is '
-                'not on the accelerated path (the reference trains in train mode, '
-                'abnet3/trainer.py:234)')
-        d_out = d_out.contiguous()
-        _lib.require_device(d_out)
-        rows = d_out.shape[0]
-        grads = ctx.grad_pass.views(seg)
-        desc = seg.descriptor(with_grads=True, grad_views=grads, masks=ctx.masks)
-        scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
-        scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32,
-                              device=d_out.device)
         need_dx = ctx.needs_input_grad[5] or (ctx.have_x2 and ctx.needs_input_grad[6])
-        dx = torch.empty(rows, seg.input_dim, dtype=torch.float32,
-                         device=d_out.device) if need_dx else None
-        _lib.check(lib.abn_tower_backward(
-            _lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(d_out), rows,
-            ctx.n_calls, _lib.ptr(ws), _lib.ptr(scratch), scratch_floats,
-            _lib.ptr(dx), _lib.stream()), 'abn_tower_backward')
+        grads, dx = _segment_backward(seg, ctx.sv, d_out, ctx.grad_pass, need_dx)
         dx1 = dx2 = None
         if need_dx:
+            rows = d_out.shape[0]
             if ctx.have_x2:
                 dx1, dx2 = dx[:rows // 2], dx[rows // 2:]
             else:
@@ -306,9 +364,10 @@ class _HipNetwork(NetworkBuilder):
         self._flat = None
         self._last_grad_flat = None
         self._offsets = None
-        self._offset_of = None
         self._segs = None
         self._mask_override = None      # tests: fixed dropout masks, one per live block
+        self._generation = getattr(self, '_generation', 0)
+        self._live_cache = None
         # 'fp32' = the parity path (exact-fp32 MFMA); 'bf16' = opt-in throughput mode:
         # matrix operands rounded to bf16 inside the GEMMs, fp32 accumulation and storage
         self.precision = os.environ.get('ABNET3_PRECISION', 'fp32')
@@ -350,15 +409,29 @@ class _HipNetwork(NetworkBuilder):
             p.data = flat[off:off + p.numel()].view(p.shape)
         self._flat = flat
         self._offsets = offs
-        self._offset_of = {id(p): off for p, off in zip(params, offs)}
+        self._live_cache = params
         return flat
 
-    def _is_flat(self):
+    def _apply(self, fn, *args, **kwargs):
+        # .cuda() / .to() / .float() replace the parameter storages: the flat buffer
+        # and every cached descriptor are stale afterwards
+        out = super(_HipNetwork, self)._apply(fn, *args, **kwargs)
+        self._flat = None
+        self._generation = getattr(self, '_generation', 0) + 1
+        return out
+
+    def _is_flat(self, full=False):
+        """Are the live parameters views of self._flat?  _apply() invalidates the
+        buffer itself; the per-call check looks at the first and the last parameter
+        only (someone re-assigning p.data by hand), `full` at all of them."""
         if self._flat is None:
             return False
         base = self._flat.data_ptr()
-        return all(p.data_ptr() == base + 4 * off
-                   for p, off in zip(self.live_parameters(), self._offsets))
+        params = self._live_cache
+        if full:
+            return all(p.data_ptr() == base + 4 * off for p, off in zip(params, self._offsets))
+        return (params[0].data_ptr() == base + 4 * self._offsets[0] and
+                params[-1].data_ptr() == base + 4 * self._offsets[-1])
 
     def flat_parameters(self):
         if not self._is_flat():
@@ -519,6 +592,31 @@ class SiameseNetwork(_HipNetwork):
         if self._last_act == 'softmax':
             out = tuple(_SoftmaxRows.apply(o) for o in out) if split else _SoftmaxRows.apply(out)
         return out
+
+    # -- autograd-free training path (TrainerSiamese.train_step) -------------------
+    def direct_ok(self):
+        return self._last_act != 'softmax'
+
+    def direct_forward(self, x1, x2):
+        """forward(x1, x2) in the current mode without building an autograd graph:
+        ([2B, out] embeddings of both towers, state for direct_backward).  Dispatching
+        one backward through torch's autograd engine costs ~150 us of host time per
+        step (worker-thread hand-off, graph bookkeeping) -- more than the GPU needs
+        for a reference-sized batch -- and the trainer knows the graph anyway."""
+        seg = self._segment_list()[0]
+        rows = 2 * x1.shape[0]
+        masks = self._draw_dropout_masks(rows, x1.device) if self.training else None
+        out, sv = _segment_forward(seg, masks, 2, x1, x2)
+        return out, (seg, sv, _GradPass(self))
+
+    def direct_backward(self, state, d_out):
+        """Backward of direct_forward: gradients of every parameter land in a fresh
+        flat buffer and are installed as p.grad (views), exactly what autograd's
+        backward leaves behind."""
+        seg, sv, grad_pass = state
+        grads, _ = _segment_backward(seg, sv, d_out, grad_pass, False)
+        for p, g in zip(seg.params, grads):
+            p.grad = g
 
     # -- reference surface ---------------------------------------------------
     def forward_once(self, x):

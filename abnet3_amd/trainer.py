@@ -71,6 +71,8 @@ class FlatOptimizer(object):
             p.grad = None
 
     def _state(self):
+        if not self.network._is_flat(full=True):
+            self.network.flatten_parameters()
         flat = self.network.flat_parameters()
         if self._flat is None or self._flat.data_ptr() != flat.data_ptr():
             if self.step_count > 0:
@@ -264,6 +266,22 @@ class TrainerSiamese(TrainerBuilder):
         emb_batch1, emb_batch2 = self.network(X_batch1, X_batch2)
         return self.loss(emb_batch1, emb_batch2, y_batch)
 
+    def _direct_ok(self):
+        """The autograd-free step applies to the plain Siamese case: our network and
+        pair losses, the fused optimizer, the unmodified give_batch_to_network."""
+        if not getattr(self, 'direct_steps', True):
+            return False
+        ok = getattr(self, '_direct_cache', None)
+        if ok is None:
+            from .loss import coscos2, cosmargin
+            from .model import SiameseNetwork
+            ok = self._direct_cache = (
+                type(self.network) is SiameseNetwork and self.network.direct_ok()
+                and type(self.loss) in (coscos2, cosmargin)
+                and isinstance(self.optimizer, FlatOptimizer)
+                and type(self).give_batch_to_network is TrainerSiamese.give_batch_to_network)
+        return ok
+
     @staticmethod
     def _backward(loss_value):
         """loss.backward() (abnet3/trainer.py:239) seeded with the cached unit
@@ -282,7 +300,23 @@ class TrainerSiamese(TrainerBuilder):
         """The five statements of the reference's inner loop
         (abnet3/trainer.py:236-240) plus the data-parallel gradient exchange.
         Returns the (device) loss of the batch; never synchronises."""
-        if do_training:
+        if do_training and batch[0].shape[0] > 0 and self._direct_ok():
+            # the five statements with the trainer driving the kernels itself: forward,
+            # fused loss + its gradient, backward -- no autograd graph, no engine
+            X_batch1, X_batch2, y_batch = batch
+            X_batch1 = X_batch1.cuda(non_blocking=True)
+            X_batch2 = X_batch2.cuda(non_blocking=True)
+            y_batch = y_batch.cuda(non_blocking=True)
+            emb, state = self.network.direct_forward(X_batch1, X_batch2)
+            n = X_batch1.shape[0]
+            loss_value, de = self.loss.value_and_grad(emb[:n], emb[n:], y_batch)
+            self.optimizer.zero_grad()
+            self.network.direct_backward(state, de.view(2 * n, -1))
+            if self.world_size > 1:
+                self.optimizer.grad_scale = parallel.all_reduce_gradients(
+                    self.network.flat_grad(), self._loss_is_mean())
+            self.optimizer.step()
+        elif do_training:
             loss_value = self.give_batch_to_network(batch)
             self.optimizer.zero_grad()
             self._backward(loss_value)
