@@ -488,6 +488,7 @@ def test_auto_graph_redraws_dropout_masks():
     b = (dev(rng.standard_normal((128, 40)).astype(np.float32)),
          dev(rng.standard_normal((128, 40)).astype(np.float32)), dev(rng.choice([1.0, -1.0], 128)))
     net.train()
+    tr.graph_steps = True
     losses = [float(tr.train_step_auto(b)) for _ in range(8)]      # lr = 0: only the masks change
     assert len(tr._graphs) == 1
     assert len(set(losses[3:])) == len(losses[3:]), losses
