@@ -207,6 +207,18 @@ def synth_dtw_pairs(P, seed, D=40):
     return f1, o1, n1, f2, o2, n2
 
 
+def make_stepper(trainer, pool, use_graph):
+    """step(i) for batch i of the pool.  Default: TrainerSiamese.train_step, which drives
+    the kernels itself (no autograd, no graph, no input copy).  --graph replays a captured
+    hipGraph instead (fed by packed batch blobs): it needs one device copy per step and is
+    ~3 % slower at this size; it pays for batches small enough to be launch-bound."""
+    if not use_graph:
+        return lambda i: trainer.train_step(pool[i % POOL], True)
+    stepper = trainer.make_graphed_step(pool[0])
+    packed = [trainer.pack_batch(b) for b in pool]
+    return lambda i: stepper(packed[i % POOL])
+
+
 def variants_bench(torch, pool, args, rank, world):
     """SURVEY.md 8d also lists the C2 step with BatchNorm on, and with the trainer's
     class-default optimizer SGD(0.001, 0.9): same workload, shorter runs, reported
@@ -221,17 +233,16 @@ def variants_bench(torch, pool, args, rank, world):
         tr = TrainerSiamese(network=net, loss=coscos2(avg=False), optimizer_type=opt, lr=lr,
                             dataloader=None, log_dir='/tmp/abnet3_bench_runs')
         net.train()
-        stepper = tr.make_graphed_step(pool[0])
-        packed = [tr.pack_batch(b) for b in pool]
+        step = make_stepper(tr, pool, args.graph)
         steps = max(20, args.steps // 4)
         for i in range(10):
-            stepper(packed[i % POOL])
+            step(i)
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            stepper(packed[i % POOL])
+            step(i)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -258,17 +269,16 @@ def bf16_mode_bench(torch, trainer, net, pool, args, world):
         got = net.forward_once(x1)
     err = float((got - ref).abs().max() / ref.abs().max())
     net.train()
-    stepper = trainer.make_graphed_step(pool[0])
-    packed = [trainer.pack_batch(b) for b in pool]
+    step = make_stepper(trainer, pool, args.graph)
     steps = max(20, args.steps // 2)
     for i in range(10):
-        stepper(packed[i % POOL])
+        step(i)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        stepper(packed[i % POOL])
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -390,8 +400,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtw-pairs', type=int, default=10000,
                     help='token pairs per GPU for the DTW leg (0 = skip)')
-    ap.add_argument('--no-graph', action='store_true',
-                    help='launch every step eagerly instead of replaying a hipGraph')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay a captured hipGraph per step instead of the eager direct step')
+    ap.add_argument('--no-graph', action='store_true', help='(default; kept for old command lines)')
     args = ap.parse_args()
 
     import torch
@@ -417,14 +428,7 @@ def main():
                              lr=0.1, dataloader=None, log_dir='/tmp/abnet3_bench_runs')
     pool = make_pool(seed=rank, device=dev)    # rank r sees its own pairs
     net.train()
-    stepper = trainer.make_graphed_step(pool[0]) if not args.no_graph else None
-    # what a device-side batch builder hands over: each batch as one packed blob
-    packed = [trainer.pack_batch(b) for b in pool] if stepper is not None else None
-
-    def step(i):
-        if stepper is not None:
-            return stepper(packed[i % POOL])
-        return trainer.train_step(pool[i % POOL], True)
+    step = make_stepper(trainer, pool, args.graph)
 
     for i in range(args.warmup):
         step(i)
@@ -445,8 +449,8 @@ def main():
         elapsed = float(t.item())
     last_loss = float(loss)
 
-    bf16 = bf16_mode_bench(torch, trainer, net, pool, args, world) if not args.no_graph else None
-    variants = variants_bench(torch, pool, args, rank, world) if not args.no_graph else None
+    bf16 = bf16_mode_bench(torch, trainer, net, pool, args, world)
+    variants = variants_bench(torch, pool, args, rank, world)
     dtw = dtw_bench(torch, args.dtw_pairs, rank, world) if args.dtw_pairs > 0 else None
 
     if rank == 0:
@@ -461,7 +465,7 @@ def main():
             'config': {'workload': 'C2: SiameseNetwork 40->500x2->100 sigmoid, coscos2(avg=False), '
                                    'Adadelta(0.1), 4096 frame pairs per GPU per step, 40-d N(0,1) frames',
                        'pairs_per_gpu': BATCH, 'global_pairs': BATCH * world,
-                       'parallelism': 'dp%d' % world, 'graph_replay': stepper is not None},
+                       'parallelism': 'dp%d' % world, 'graph_replay': bool(args.graph)},
             'tflops_whole_step': round(value * FLOP_PER_PAIR / 1e12, 2),
             'last_loss': last_loss,
         }
