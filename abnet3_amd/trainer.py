@@ -18,7 +18,6 @@ Differences, all on purpose:
     train_losses / dev_losses.
 """
 import copy
-import os
 import pickle
 import time
 import warnings
