@@ -272,7 +272,7 @@ __device__ __forceinline__ int xcd_tile_index(int b, int n)
 #define ABN_STAMP_FLUSH()                                                                    \
     do {                                                                                     \
         if (p.stamps && threadIdx.x == 0)                                                    \
-            for (int q_ = 0; q_ < 80; ++q_) p.stamps[(size_t)blockIdx.x * 128 + q_] = q_ < nst ? stbuf[q_] : 0; \
+            for (int q_ = 0; q_ < 80; ++q_) p.stamps[(size_t)block_id * 128 + q_] = q_ < nst ? stbuf[q_] : 0; \
     } while (0)
 #else
 #define ABN_STAMP() do {} while (0)
@@ -285,7 +285,7 @@ __device__ __forceinline__ int xcd_tile_index(int b, int n)
 // 32-deep tile and block instead of 16 of 64.  NOT the parity path (~3 significant
 // digits); the kernel is then bound by its global -> LDS traffic, not by the MFMA.
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC, bool BF16 = false>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
+__device__ __forceinline__ void gemm_body(const GemmP& p, const int block_id)
 {
 #ifdef ABN_STAMPS
     int nst = 0;
@@ -310,15 +310,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
     const int ntiles = tiles_m * tiles_n;
     int tile, slice;
     if (p.splits > 1 && (p.splits & 7) == 0) {
-        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, spx = p.splits >> 3;
+        const int xcd = block_id & 7, q = block_id >> 3, spx = p.splits >> 3;
         slice = xcd * spx + q / ntiles;
         tile = q % ntiles;
     } else if (p.splits > 1) {
-        slice = blockIdx.x / ntiles;
-        tile = blockIdx.x % ntiles;
+        slice = block_id / ntiles;
+        tile = block_id % ntiles;
     } else {
         slice = 0;
-        tile = xcd_tile_index(blockIdx.x, ntiles);
+        tile = xcd_tile_index(block_id, ntiles);
     }
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int kb = slice * p.k_chunk;
@@ -526,6 +526,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
     }
     ABN_STAMP();
     ABN_STAMP_FLUSH();
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC, bool BF16 = false>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
+{
+    gemm_body<BM, BN, A_KC, B_KC, EPI, VEC, BF16>(p, (int)blockIdx.x);
+}
+
+// One launch for the two GEMMs of a backward layer, which both consume dz_l and are
+// independent of each other: workgroups [0, n0) are the wgrad (dW_l = dz_l^T a_{l-1},
+// split-K slabs), the rest the dgrad (d a_{l-1} = dz_l W_l).  Launched back to back, the
+// second kernel cannot start before the first one's last workgroup has drained its
+// epilogue; in one grid its workgroups take over the CUs as they free up.  n0 must be a
+// multiple of 8 so that the XCD-affine tile maps of both parts still see `b & 7` = XCD.
+template <int WM, int WN, bool BF16>
+__global__ __launch_bounds__(256) void gemm_bwd_pair_kernel(GemmP pw, int n0, GemmP pd)
+{
+    if ((int)blockIdx.x < n0) gemm_body<WM, WN, false, false, EPI_WGRAD, true, BF16>(pw, (int)blockIdx.x);
+    else gemm_body<128, 64, true, false, EPI_DGRAD, true, BF16>(pd, (int)blockIdx.x - n0);
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC>

@@ -62,14 +62,17 @@ static void launch_cfg(const GemmP& p, int splits, hipStream_t st)
     else launch_one<BM, BN, A_KC, B_KC, EPI, false, false>(p, splits, st);
 }
 
+// Checks, epilogue vectorisation flag and tile choice of one GEMM.  Returns the tile
+// code (0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64), -1 for "nothing to do", or a
+// negative ABN_E_* error shifted by -100.
 template <bool A_KC, bool B_KC, int EPI>
-static int launch_gemm(GemmP p, int splits, hipStream_t st)
+static int prepare_gemm(GemmP& p, int splits)
 {
-    if (p.M <= 0 || p.N <= 0) return ABN_OK;
-    if (p.K <= 0) { set_error("gemm: empty reduction"); return ABN_E_ARG; }
+    if (p.M <= 0 || p.N <= 0) return -1;
+    if (p.K <= 0) { set_error("gemm: empty reduction"); return -100 + ABN_E_ARG; }
     {   // in-kernel lane offsets are 32-bit: every operand must span < 2^31 floats
         const int64_t span_a = (int64_t)(A_KC ? p.M : p.K) * p.lda, span_b = (int64_t)(B_KC ? p.N : p.K) * p.ldb;
-        if (span_a >= (1LL << 31) || span_b >= (1LL << 31)) { set_error("gemm: operand larger than 2^31 floats"); return ABN_E_ARG; }
+        if (span_a >= (1LL << 31) || span_b >= (1LL << 31)) { set_error("gemm: operand larger than 2^31 floats"); return -100 + ABN_E_ARG; }
     }
     auto tiles = [&](int bm, int bn) {
         return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * splits;
@@ -85,26 +88,81 @@ static int launch_gemm(GemmP p, int splits, hipStream_t st)
                   (!p.aux || (aligned16(p.aux) && p.ldaux % 4 == 0)) &&
                   (!p.mask || (aligned16(p.mask) && (EPI == EPI_DGRAD ? p.ldaux : p.ldc) % 4 == 0));
     }
+    p.splits = splits;
 #ifdef ABN_STAMPS
     p.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
 #endif
     static const int force = getenv("ABN_GEMM_TILE") ? atoi(getenv("ABN_GEMM_TILE")) : -1;
-    if (force == 0) { launch_cfg<128, 128, A_KC, B_KC, EPI>(p, splits, st); return ABN_OK; }
-    if (force == 1) { launch_cfg<128, 64, A_KC, B_KC, EPI>(p, splits, st); return ABN_OK; }
-    if (force == 2) { launch_cfg<64, 128, A_KC, B_KC, EPI>(p, splits, st); return ABN_OK; }
-    if (force == 3) { launch_cfg<64, 64, A_KC, B_KC, EPI>(p, splits, st); return ABN_OK; }
+    if (force >= 0 && force <= 3) return force;
     const int64_t pad_a = (int64_t)((p.M + 127) / 128 * 128) * ((p.N + 63) / 64 * 64);
     const int64_t pad_b = (int64_t)((p.M + 63) / 64 * 64) * ((p.N + 127) / 128 * 128);
-    if (p.M > 64 && p.N > 64 && tiles(128, 128) >= want)
-        launch_cfg<128, 128, A_KC, B_KC, EPI>(p, splits, st);
-    else if (p.M > 64 && tiles(128, 64) >= want && (pad_a <= pad_b || !(p.N > 64 && tiles(64, 128) >= want)))
-        launch_cfg<128, 64, A_KC, B_KC, EPI>(p, splits, st);
-    else if (p.N > 64 && tiles(64, 128) >= want)
-        launch_cfg<64, 128, A_KC, B_KC, EPI>(p, splits, st);
-    else
-        launch_cfg<64, 64, A_KC, B_KC, EPI>(p, splits, st);
+    if (p.M > 64 && p.N > 64 && tiles(128, 128) >= want) return 0;
+    if (p.M > 64 && tiles(128, 64) >= want && (pad_a <= pad_b || !(p.N > 64 && tiles(64, 128) >= want))) return 1;
+    if (p.N > 64 && tiles(64, 128) >= want) return 2;
+    return 3;
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+static int launch_gemm(GemmP p, int splits, hipStream_t st)
+{
+    const int tile = prepare_gemm<A_KC, B_KC, EPI>(p, splits);
+    if (tile == -1) return ABN_OK;
+    if (tile < -1) return tile + 100;
+    if (tile == 0) launch_cfg<128, 128, A_KC, B_KC, EPI>(p, splits, st);
+    else if (tile == 1) launch_cfg<128, 64, A_KC, B_KC, EPI>(p, splits, st);
+    else if (tile == 2) launch_cfg<64, 128, A_KC, B_KC, EPI>(p, splits, st);
+    else launch_cfg<64, 64, A_KC, B_KC, EPI>(p, splits, st);
     ABN_CHECK_LAUNCH("gemm_f32");
     return ABN_OK;
+}
+
+// wgrad + dgrad of one backward layer in ONE grid (gemm_bwd_pair_kernel) when both take
+// their usual vectorised instantiations; otherwise two launches.
+template <int WM, int WN, bool BF16>
+static void launch_pair_one(const GemmP& pw, int n0, const GemmP& pd, int n1, hipStream_t st)
+{
+    constexpr size_t lw = gemm_lds_bytes<WM, WN, false, false>(), ld = gemm_lds_bytes<128, 64, true, false>();
+    constexpr size_t lds = lw > ld ? lw : ld;
+    auto k = gemm_bwd_pair_kernel<WM, WN, BF16>;
+    static bool attr_set[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = (dev >= 0 && dev < 16) ? dev : 0;
+    if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(k, dim3(n0 + n1), dim3(256), lds, st, pw, n0, pd);
+}
+
+static int launch_bwd_pair(GemmP pw, int splits, GemmP pd, hipStream_t st)
+{
+    static const bool enabled = !(getenv("ABN_BWD_PAIR") && atoi(getenv("ABN_BWD_PAIR")) == 0);
+    const int tw = prepare_gemm<false, false, EPI_WGRAD>(pw, splits);
+    const int td = prepare_gemm<true, false, EPI_DGRAD>(pd, 1);
+    if (tw < -1) return tw + 100;
+    if (td < -1) return td + 100;
+    const bool vec = pw.a_vec && pw.b_vec && pd.a_vec && pd.b_vec;
+    const bool same_prec = pw.bf16 == pd.bf16;
+    if (enabled && vec && same_prec && td == 1 && (tw == 1 || tw == 3)) {
+        const int wm = tw == 1 ? 128 : 64;
+        const int n0 = ((pw.M + wm - 1) / wm) * ((pw.N + 63) / 64) * splits;
+        const int n1 = ((pd.M + 127) / 128) * ((pd.N + 63) / 64);
+        if (n0 % 8 == 0) {
+            if (tw == 1) {
+                if (pw.bf16) launch_pair_one<128, 64, true>(pw, n0, pd, n1, st);
+                else launch_pair_one<128, 64, false>(pw, n0, pd, n1, st);
+            } else {
+                if (pw.bf16) launch_pair_one<64, 64, true>(pw, n0, pd, n1, st);
+                else launch_pair_one<64, 64, false>(pw, n0, pd, n1, st);
+            }
+            ABN_CHECK_LAUNCH("gemm_bwd_pair");
+            return ABN_OK;
+        }
+    }
+    int rc = launch_gemm<false, false, EPI_WGRAD>(pw, splits, st);
+    if (rc != ABN_OK) return rc;
+    return launch_gemm<true, false, EPI_DGRAD>(pd, 1, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -635,24 +693,25 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
         const float* dz = scratch + B.dz[cur];
         const float* a_in = (l == 0) ? xin : ws + L.a[l - 1];
         // wgrad: dW[Nout, Kin] (+ db via the ones column) = dz^T a_in, split over rows
-        {
-            GemmP p = {};
-            p.A = dz; p.lda = Nout;
-            p.B = a_in; p.ldb = Kin;
-            p.C = slabs + B.off[l]; p.ldc = Kin;
-            p.C2 = slabs + B.off[l] + (int64_t)Nout * Kin;
-            p.slab_stride = B.slab_stride;
-            p.M = Nout; p.N = Kin + 1; p.K = (int)rows;
-            p.k_chunk = (int)align_up((rows + B.splits[l] - 1) / B.splits[l], BK);
-            p.ones_col = Kin;
-            p.bf16 = t->precision == 1;
-            p.a_vec = aligned16(dz) && (Nout % 4 == 0);
-            p.b_vec = aligned16(a_in) && (Kin % 4 == 0);
-            // slices past the end of the reduction write zero slabs (k range empty)
-            rc = launch_gemm<false, false, EPI_WGRAD>(p, B.splits[l], st);
+        GemmP pw = {};
+        pw.A = dz; pw.lda = Nout;
+        pw.B = a_in; pw.ldb = Kin;
+        pw.C = slabs + B.off[l]; pw.ldc = Kin;
+        pw.C2 = slabs + B.off[l] + (int64_t)Nout * Kin;
+        pw.slab_stride = B.slab_stride;
+        pw.M = Nout; pw.N = Kin + 1; pw.K = (int)rows;
+        pw.k_chunk = (int)align_up((rows + B.splits[l] - 1) / B.splits[l], BK);
+        pw.ones_col = Kin;
+        pw.bf16 = t->precision == 1;
+        pw.a_vec = aligned16(dz) && (Nout % 4 == 0);
+        pw.b_vec = aligned16(a_in) && (Kin % 4 == 0);
+        // slices past the end of the reduction write zero slabs (k range empty)
+        if (!(l > 0 || dx)) {
+            rc = launch_gemm<false, false, EPI_WGRAD>(pw, B.splits[l], st);
             if (rc != ABN_OK) return rc;
         }
-        // dgrad: d a_{l-1} = dz W_l, times act'(a_{l-1}) when no BN sits in between
+        // dgrad: d a_{l-1} = dz W_l, times act'(a_{l-1}) when no BN sits in between.  Both
+        // GEMMs read dz only: they go out as one grid (launch_bwd_pair).
         if (l > 0 || dx) {
             float* dst = (l == 0) ? dx : scratch + B.dz[cur ^ 1];
             GemmP p = {};
@@ -665,7 +724,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             p.ones_col = -1;
             p.bf16 = t->precision == 1;
             if (l > 0 && !t->batch_norm) { p.aux = ws + L.a[l - 1]; p.ldaux = Kin; p.act = t->act; p.mask = t->drop_mask[l - 1]; }
-            rc = launch_gemm<true, false, EPI_DGRAD>(p, 1, st);
+            rc = launch_bwd_pair(pw, B.splits[l], p, st);
             if (rc != ABN_OK) return rc;
             if (l > 0 && t->batch_norm) {
                 // dst holds d a_{l-1}; turn it into d z_{l-1} through act' and BN

@@ -51,9 +51,7 @@ def make_pool(seed, device):
     return pool
 
 
-FUSED_KERNEL = 'abn::tower_fwd_fused_kernel(abn::FusedFwdP)'
-DGRAD_KERNEL = 'void abn::gemm_f32_kernel<128, 64, true, false, 1, true>(abn::GemmP)'
-WGRAD_KERNEL = 'void abn::gemm_f32_kernel<128, 64, false, false, 2, true>(abn::GemmP)'
+FUSED_KERNEL = 'void abn::tower_fwd_fused_kernel<false>(abn::FusedFwdP)'
 
 
 def _time_launches(torch, fn, reps):
@@ -122,37 +120,22 @@ def tower_roofline(torch, net, reps=20):
            'traffic': _traffic('tower_fwd_fused_kernel'),
            'kernel': FUSED_KERNEL + '  (whole forward of both towers in one launch)',
            'avg_launch_us': round(avg_s * 1e6, 2), 'flop_per_launch': flop}
-    # the backward's two GEMM kernels at the step's own shapes, through the single-layer entries
-    lib = _lib.load()
-    others = []
-    shapes = [(500, 100), (500, 500), (500, 500)]          # dgrad: no input-layer dgrad
-    bufs = [(torch.randn(rows, n, device='cuda'), torch.randn(n, k, device='cuda') * 0.05,
-             torch.rand(rows, k, device='cuda'), torch.empty(rows, k, device='cuda')) for k, n in shapes]
+    # the backward of the same step: act', three (wgrad + dgrad) grids, the input layer's
+    # wgrad, the slab reduction -- timed as one sequence through abn_tower_backward
+    net.train()
+    emb, state = net.direct_forward(x12[:BATCH].contiguous(), x12[BATCH:].contiguous())
+    d_out = torch.randn_like(emb) * 1e-3
 
-    def dgrad():
-        for (k, n), (dz, w, a, dx) in zip(shapes, bufs):
-            _lib.check(lib.abn_linear_dgrad(_lib.ptr(dz), _lib.ptr(w), rows, k, n, _lib.ptr(a),
-                                            _lib.ACT['sigmoid'], _lib.ptr(dx), _lib.stream()), 'abn_linear_dgrad')
-    t = _time_launches(torch, dgrad, reps) / len(shapes)
-    fl = sum(2.0 * rows * k * n for k, n in shapes) / len(shapes)
-    others.append({'kernel': DGRAD_KERNEL + '  (dgrad, fused activation derivative; 3 launches per step)',
-                   'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                   'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl, 'traffic': _traffic(DGRAD_KERNEL)})
-    k, n = 500, 500
-    dz, a = torch.randn(rows, n, device='cuda'), torch.rand(rows, k, device='cuda')
-    dW, db = torch.empty(n, k, device='cuda'), torch.empty(n, device='cuda')
-    sc_n = lib.abn_linear_wgrad_scratch_floats(rows, k, n)
-    sc = torch.empty(sc_n, device='cuda')
-
-    def wgrad():
-        _lib.check(lib.abn_linear_wgrad(_lib.ptr(dz), _lib.ptr(a), rows, k, n, _lib.ptr(dW), _lib.ptr(db),
-                                        _lib.ptr(sc), sc_n, _lib.stream()), 'abn_linear_wgrad')
-    t = _time_launches(torch, wgrad, reps)
-    fl = 2.0 * rows * k * n
-    others.append({'kernel': WGRAD_KERNEL + '  (wgrad 500x500, split-K; the time includes its slab reduction)',
-                   'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                   'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl, 'traffic': _traffic(WGRAD_KERNEL)})
-    out['backward_kernels'] = others
+    def bwd():
+        net.direct_backward(state, d_out)
+    t = _time_launches(torch, bwd, reps)
+    fl = 2.0 * rows * (2 * (40 * 500 + 2 * 500 * 500 + 500 * 100) - 40 * 500)      # wgrad everywhere, no dgrad into the input
+    out['backward'] = {
+        'kernels': 'abn::gemm_bwd_pair_kernel<128, 64, false> x2 + <64, 64, false> x1 (wgrad + dgrad of a layer in one '
+                   'grid), gemm_f32_kernel<64, 64, false, false, 2, ...> (input-layer wgrad), act_bwd, slab_reduce',
+        'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+        'avg_sequence_us': round(t * 1e6, 2), 'flop_per_sequence': fl,
+        'traffic_pair_kernel': _traffic('gemm_bwd_pair_kernel<128, 64, false>')}
     return out
 
 
