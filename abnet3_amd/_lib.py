@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ABNET3_HIP_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get('ABNET3_HIP_LIB') or os.path.join(HERE, 'lib', 'libabnet3_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LAYERS = 16
 
 ACT = {'none': 0, None: 0, 'sigmoid': 1, 'relu': 2, 'tanh': 3}
@@ -38,6 +38,7 @@ SYMBOLS = {
     'abn_linear_dgrad': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, C.c_int, _vp, _vp]),
     'abn_linear_wgrad_scratch_floats': (_i64, [_i64, _i64, _i64]),
     'abn_linear_wgrad': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    'abn_linear_backward': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp]),
     'abn_softmax_rows': (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     'abn_softmax_rows_backward': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     'abn_pair_loss_ws_bytes': (_i64, [_i64]),

@@ -837,4 +837,49 @@ int abn_linear_wgrad(const float* dz, const float* a_in, int64_t rows, int64_t i
     return ABN_OK;
 }
 
+// dgrad + wgrad of one nn.Linear as the tower backward issues them: ONE grid
+// (gemm_bwd_pair_kernel) when both take their vectorised instantiations, then the slab
+// reduction.  a_in doubles as a_prev (the layer's input IS the previous activation).
+int abn_linear_backward(const float* dz, const float* W, const float* a_in, int64_t rows, int64_t in_dim,
+                        int64_t out_dim, int act_prev, float* dW, float* db, float* dx, float* scratch,
+                        int64_t scratch_floats, void* stream)
+{
+    ABN_REQUIRE(dz && W && a_in && dW && db && dx && scratch, "linear_backward: null pointer");
+    ABN_REQUIRE(rows >= 1 && rows < (1LL << 30) && in_dim >= 1 && out_dim >= 1 && in_dim < (1 << 24) && out_dim < (1 << 24),
+                "linear_backward: bad shape");
+    ABN_REQUIRE(act_prev >= ABN_ACT_NONE && act_prev <= ABN_ACT_TANH, "linear_backward: unsupported activation %d", act_prev);
+    const int splits = split_count(rows, out_dim, in_dim);
+    const int64_t stride = align_up(out_dim * in_dim + out_dim, 64);
+    if (scratch_floats < stride * splits) { set_error("linear_backward: scratch too small"); return ABN_E_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    GemmP pw = {};
+    pw.A = dz; pw.lda = out_dim;
+    pw.B = a_in; pw.ldb = in_dim;
+    pw.C = scratch; pw.ldc = in_dim;
+    pw.C2 = scratch + out_dim * in_dim;
+    pw.slab_stride = stride;
+    pw.M = (int)out_dim; pw.N = (int)in_dim + 1; pw.K = (int)rows;
+    pw.k_chunk = (int)align_up((rows + splits - 1) / splits, BK);
+    pw.ones_col = (int)in_dim;
+    pw.a_vec = aligned16(dz) && (out_dim % 4 == 0);
+    pw.b_vec = aligned16(a_in) && (in_dim % 4 == 0);
+    GemmP pd = {};
+    pd.A = dz; pd.lda = out_dim;
+    pd.B = W; pd.ldb = in_dim;
+    pd.C = dx; pd.ldc = in_dim;
+    pd.M = (int)rows; pd.N = (int)in_dim; pd.K = (int)out_dim; pd.k_chunk = (int)out_dim;
+    pd.aux = act_prev == ABN_ACT_NONE ? nullptr : a_in; pd.ldaux = in_dim; pd.act = act_prev; pd.ones_col = -1;
+    pd.a_vec = aligned16(dz) && (out_dim % 4 == 0);
+    pd.b_vec = aligned16(W) && (in_dim % 4 == 0);
+    int rc = launch_bwd_pair(pw, splits, pd, st);
+    if (rc != ABN_OK) return rc;
+    ReduceTable rt = {};
+    rt.n_layers = 1; rt.splits[0] = splits; rt.slab_stride = stride;
+    rt.off[0] = 0; rt.nW[0] = out_dim * in_dim; rt.nb[0] = out_dim; rt.dW[0] = dW; rt.db[0] = db;
+    rt.total = out_dim * in_dim + out_dim;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, scratch, rt);
+    ABN_CHECK_LAUNCH("linear_backward");
+    return ABN_OK;
+}
+
 }  // extern "C"

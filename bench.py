@@ -52,6 +52,7 @@ def make_pool(seed, device):
 
 
 FUSED_KERNEL = 'void abn::tower_fwd_fused_kernel<false>(abn::FusedFwdP)'
+PAIR_KERNEL = 'void abn::gemm_bwd_pair_kernel<128, 64, false>(abn::GemmP, int, abn::GemmP)'
 
 
 def _time_launches(torch, fn, reps):
@@ -98,31 +99,53 @@ def _traffic(kernel):
 
 
 def tower_roofline(torch, net, reps=20):
-    """The dominant kernel of the step: tower_fwd_fused_kernel, ONE launch for the
-    forward of both towers (2 x 4096 rows through 40->500->500->500->100, about 30 %
-    of the step).  Timed with HIP events on the launch stream around the same
-    call the step makes (abn_tower_forward, train mode, activations stored for the
-    backward); algorithmic FLOPs per launch = 2 * rows * sum(in*out) (SURVEY.md 8d:
-    570 000 MAC per tower row)."""
+    """The dominant kernel of the step by time: gemm_bwd_pair_kernel<128, 64, false> --
+    the wgrad and the dgrad of a 500x500 layer over the 2 x 4096 tower rows in ONE grid,
+    two launches per step (a third of the step).  Timed live through abn_linear_backward
+    (the single-layer entry that issues exactly what the tower backward issues: that grid,
+    then the layer's slab reduction), `reps` calls captured into one hipGraph and bracketed
+    by HIP events on the launch stream; the slab reduction's own time, measured the same
+    way through abn_linear_wgrad minus abn_linear_backward's GEMM, is reported beside it.
+    Algorithmic FLOPs per launch: 2 GEMMs x 2 * 8192 * 500 * 500 (+ the bias column).
+    The whole-forward kernel and the whole backward sequence follow as further entries."""
     from abnet3_amd import _lib
-    rows = 2 * BATCH
+    lib = _lib.load()
+    rows, k, n = 2 * BATCH, 500, 500
+    dz, a = torch.randn(rows, n, device='cuda'), torch.rand(rows, k, device='cuda')
+    W = torch.randn(n, k, device='cuda') * 0.05
+    dW, db, dx = torch.empty(n, k, device='cuda'), torch.empty(n, device='cuda'), torch.empty(rows, k, device='cuda')
+    sc_n = lib.abn_linear_wgrad_scratch_floats(rows, k, n)
+    sc = torch.empty(sc_n, device='cuda')
+
+    def pair():
+        _lib.check(lib.abn_linear_backward(_lib.ptr(dz), _lib.ptr(W), _lib.ptr(a), rows, k, n, _lib.ACT['sigmoid'],
+                                           _lib.ptr(dW), _lib.ptr(db), _lib.ptr(dx), _lib.ptr(sc), sc_n,
+                                           _lib.stream()), 'abn_linear_backward')
+    t_pair = _time_launches(torch, pair, reps)
+    flop = 2.0 * rows * k * n + 2.0 * rows * (k + 1) * n
+    achieved = flop / t_pair / 1e12
+    out = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
+           'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+           'traffic': _traffic('gemm_bwd_pair_kernel<128, 64, false>'),
+           'kernel': PAIR_KERNEL + '  (wgrad + dgrad of a 500x500 layer in one grid; avg_launch_us also '
+                     'holds the layer\'s ~5 us slab reduction and the dispatch gaps, so the fraction is a lower bound)',
+           'avg_launch_us': round(t_pair * 1e6, 2), 'flop_per_launch': flop}
+
+    # the whole forward of both towers, one launch (the largest single launch of the step)
     x12 = torch.randn(rows, 40, device='cuda')
     net.train()
 
     def fwd():
         with torch.no_grad():
             net.forward_pair_rows(x12)
-    avg_s = _time_launches(torch, fwd, reps)
-    flop = 2.0 * rows * (40 * 500 + 2 * 500 * 500 + 500 * 100)
-    achieved = flop / avg_s / 1e12
-    out = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
-           'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-           'traffic': _traffic('tower_fwd_fused_kernel'),
-           'kernel': FUSED_KERNEL + '  (whole forward of both towers in one launch)',
-           'avg_launch_us': round(avg_s * 1e6, 2), 'flop_per_launch': flop}
+    t = _time_launches(torch, fwd, reps)
+    fl = 2.0 * rows * (40 * 500 + 2 * 500 * 500 + 500 * 100)
+    out['forward'] = {'kernel': FUSED_KERNEL + '  (whole forward of both towers in one launch)',
+                      'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                      'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl,
+                      'traffic': _traffic('tower_fwd_fused_kernel')}
     # the backward of the same step: act', three (wgrad + dgrad) grids, the input layer's
     # wgrad, the slab reduction -- timed as one sequence through abn_tower_backward
-    net.train()
     emb, state = net.direct_forward(x12[:BATCH].contiguous(), x12[BATCH:].contiguous())
     d_out = torch.randn_like(emb) * 1e-3
 
@@ -131,11 +154,10 @@ def tower_roofline(torch, net, reps=20):
     t = _time_launches(torch, bwd, reps)
     fl = 2.0 * rows * (2 * (40 * 500 + 2 * 500 * 500 + 500 * 100) - 40 * 500)      # wgrad everywhere, no dgrad into the input
     out['backward'] = {
-        'kernels': 'abn::gemm_bwd_pair_kernel<128, 64, false> x2 + <64, 64, false> x1 (wgrad + dgrad of a layer in one '
-                   'grid), gemm_f32_kernel<64, 64, false, false, 2, ...> (input-layer wgrad), act_bwd, slab_reduce',
+        'kernels': 'gemm_bwd_pair_kernel<128, 64, false> x2 + <64, 64, false> x1, gemm_f32_kernel<64, 64, false, false, 2, ...> '
+                   '(input-layer wgrad), act_bwd, slab_reduce',
         'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-        'avg_sequence_us': round(t * 1e6, 2), 'flop_per_sequence': fl,
-        'traffic_pair_kernel': _traffic('gemm_bwd_pair_kernel<128, 64, false>')}
+        'avg_sequence_us': round(t * 1e6, 2), 'flop_per_sequence': fl}
     return out
 
 

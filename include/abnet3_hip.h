@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 4
+#define ABN_ABI_VERSION 5
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -132,6 +132,15 @@ int64_t abn_linear_wgrad_scratch_floats(int64_t rows, int64_t in_dim, int64_t ou
 int abn_linear_wgrad(const float* dz, const float* a_in, int64_t rows, int64_t in_dim,
                      int64_t out_dim, float* dW, float* db, float* scratch,
                      int64_t scratch_floats, void* stream);
+/* dgrad + wgrad of one nn.Linear the way abn_tower_backward issues them: both read dz
+ * only, so they go out as ONE grid (the dgrad's workgroups take over the CUs as the
+ * wgrad's retire), followed by the slab reduction.  a_in [rows,in] is the layer's input =
+ * the previous activation (act_prev = 0: no activation derivative).  scratch as for
+ * abn_linear_wgrad. */
+int abn_linear_backward(const float* dz, const float* W, const float* a_in, int64_t rows,
+                        int64_t in_dim, int64_t out_dim, int act_prev, float* dW,
+                        float* db, float* dx, float* scratch, int64_t scratch_floats,
+                        void* stream);
 
 /* coscos2.forward / cosmargin.forward fused with their backward,
  * abnet3/loss.py:46-67 and :85-105 (nn.CosineSimilarity(dim=1, eps=1e-6)).

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
     raw = ctypes.CDLL(lib._name)
     for name in declared_symbols():
         assert hasattr(raw, name), name
-    assert lib.abn_abi_version() == 4
+    assert lib.abn_abi_version() == 5
 
 
 def test_descriptor_layout_matches_header():

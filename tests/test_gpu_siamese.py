@@ -527,3 +527,33 @@ def test_direct_step_equals_autograd_step(fixture, opt):
         assert rel_err(v, out[0][1][k]) < 1e-6, k
     for k, v in out[1][2].items():
         assert rel_err(v, out[0][2][k], floor=1e-12) < 1e-6, k
+
+
+@pytest.mark.parametrize('rows,k,n,act', [(8192, 500, 500, 'sigmoid'), (200, 40, 72, 'tanh'), (1000, 500, 100, 'none')])
+def test_linear_backward_entry_matches_the_two_single_gemm_entries(rows, k, n, act):
+    """abn_linear_backward (wgrad + dgrad of one Linear as ONE grid, the way the tower
+    backward issues them) against abn_linear_wgrad + abn_linear_dgrad, and those against
+    float64 matmuls."""
+    from abnet3_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(rows)
+    dz = dev(rng.standard_normal((rows, n)).astype(np.float32))
+    W = dev((rng.standard_normal((n, k)) * 0.05).astype(np.float32))
+    a = dev(rng.uniform(0.05, 0.95, (rows, k)).astype(np.float32))
+    code = _lib.ACT[act]
+    sc_n = lib.abn_linear_wgrad_scratch_floats(rows, k, n)
+    sc = torch.empty(sc_n, device='cuda')
+    dW1, db1, dx1 = torch.empty(n, k, device='cuda'), torch.empty(n, device='cuda'), torch.empty(rows, k, device='cuda')
+    dW2, db2, dx2 = torch.empty_like(dW1), torch.empty_like(db1), torch.empty_like(dx1)
+    _lib.check(lib.abn_linear_backward(_lib.ptr(dz), _lib.ptr(W), _lib.ptr(a), rows, k, n, code, _lib.ptr(dW1),
+                                       _lib.ptr(db1), _lib.ptr(dx1), _lib.ptr(sc), sc_n, _lib.stream()), 'bwd')
+    _lib.check(lib.abn_linear_wgrad(_lib.ptr(dz), _lib.ptr(a), rows, k, n, _lib.ptr(dW2), _lib.ptr(db2),
+                                    _lib.ptr(sc), sc_n, _lib.stream()), 'w')
+    _lib.check(lib.abn_linear_dgrad(_lib.ptr(dz), _lib.ptr(W), rows, k, n, _lib.ptr(a) if code else None, code,
+                                    _lib.ptr(dx2), _lib.stream()), 'd')
+    assert torch.equal(dW1, dW2) and torch.equal(db1, db2) and torch.equal(dx1, dx2)   # same kernels bodies
+    dz64, a64, W64 = dz.double().cpu().numpy(), a.double().cpu().numpy(), W.double().cpu().numpy()
+    grad = {'sigmoid': a64 * (1 - a64), 'tanh': 1 - a64 * a64, 'none': np.ones_like(a64)}[act]
+    assert rel_err(dW1.cpu().numpy(), dz64.T @ a64) < 1e-5
+    assert rel_err(db1.cpu().numpy(), dz64.sum(0)) < 1e-5
+    assert rel_err(dx1.cpu().numpy(), (dz64 @ W64) * grad) < 1e-5
