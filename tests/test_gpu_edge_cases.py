@@ -91,3 +91,20 @@ def test_empty_batch_is_refused_or_empty():
         e = net.forward_once(x)
     assert e.shape == (0, 8)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_tower_configurations(seed, forward_path):
+    """Random depth / widths (multiples of 4 or not) / activation / BatchNorm / output
+    head / batch size / loss, forward + loss + every gradient against the numpy oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    act = str(rng.choice(['sigmoid', 'tanh', 'relu']))
+    hidden = int(rng.choice([8, 30, 64, 100, 257]))
+    kw = dict(input_dim=int(rng.choice([5, 16, 40, 77])), num_hidden_layers=int(rng.integers(0, 4)),
+              hidden_dim=hidden, output_dim=int(rng.choice([3, 20, 64])), activation_layer=act,
+              batch_norm=bool(rng.integers(0, 2)))
+    if rng.integers(0, 3) == 0:
+        kw['last_non_linearity'] = None
+    B = int(rng.integers(2, 150))
+    run_case(kw, B=B, seed=seed, loss_kind=str(rng.choice(['coscos2', 'cosmargin'])), avg=bool(rng.integers(0, 2)),
+             tol=3e-5)
