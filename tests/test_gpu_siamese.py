@@ -190,7 +190,7 @@ def test_mid_width_against_oracle_and_reference(bn):
     ol, og, (oe1, oe2) = O.train_step(p, g['x1.0'], g['x2.0'], g['y.0'], spec,
                                       O.Optimizer('sgd', 0.0), avg=False)
     assert rel_err(e1.detach().cpu().numpy(), oe1) < TOL
-    assert abs(float(lv) - ol) <= 1e-5 * abs(ol)
+    assert abs(float(lv.detach()) - ol) <= 1e-5 * abs(ol)
     grads = {k: q.grad.cpu().numpy() for k, q in net.named_parameters()}
     # tight against the oracle (fp64 loss gradient on both sides) ...
     check_grads(grads, og, keys, bool(bn), tol=5e-5)
