@@ -467,17 +467,18 @@ class TrainerSiamese(TrainerBuilder):
         num_batches_dev = 0
         self.network.train()
         for minibatch in self._batches(True):
+            # fp64 accumulator += fp32 loss in ONE launch (add_ promotes the operand)
             if do_training:
-                train_loss += self.train_step_auto(minibatch).double()
+                train_loss.add_(self.train_step_auto(minibatch))
             else:
-                train_loss += self.train_step(minibatch, False).double()
+                train_loss.add_(self.train_step(minibatch, False))
             num_batches_train += 1
 
         self.network.eval()
         with torch.no_grad():
             for minibatch in self._batches(False):
                 num_batches_dev += 1
-                dev_loss += self.give_batch_to_network(minibatch).double()
+                dev_loss.add_(self.give_batch_to_network(minibatch))
 
         sums = torch.stack([train_loss, dev_loss])
         counts = torch.tensor([num_batches_train, num_batches_dev], dtype=torch.float64,
