@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ABNET3_HIP_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get('ABNET3_HIP_LIB') or os.path.join(HERE, 'lib', 'libabnet3_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LAYERS = 16
 
 ACT = {'none': 0, None: 0, 'sigmoid': 1, 'relu': 2, 'tanh': 3}
@@ -52,6 +52,8 @@ SYMBOLS = {
                                    _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp,
                                    _i64, _vp]),
     'abn_cosine_distance': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
+    'abn_cosine_distance_f64': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
+    'abn_arccos_f32': (C.c_int, [_vp, _i64, _vp, _vp]),
     'abn_gather_rows': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     'abn_stack_frames': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
     'abn_mvn_ws_bytes': (_i64, [_i64, _i64]),

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'lib', 'obj')
 LIB = os.path.join(HERE, 'lib', 'libabnet3_hip.so')
 SOURCES = ['tower.hip', 'loss.hip', 'ops.hip', 'dtw.hip', 'fbank.hip']
-HEADERS = ['common.h', 'gemm_f32.h', os.path.join('..', '..', 'include', 'abnet3_hip.h')]
+HEADERS = sorted(h for h in os.listdir(CSRC) if h.endswith('.h')) + [os.path.join('..', '..', 'include', 'abnet3_hip.h')]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall',
          '-Wno-unused-function']
 # translation units whose float arithmetic must be identical on CPU and GPU

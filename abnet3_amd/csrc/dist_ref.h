@@ -1,0 +1,134 @@
+// dist_ref.h -- the reference's angular distance (abnet3/utils.py:40-60), float32,
+// operation for operation as numpy + libm evaluate it on the plain path (see
+// oracle/dtw.c, which tests/golden/cosdist_libm.npz pins to the reference bit for bit):
+//
+//   x2 = np.sqrt(np.sum(x ** 2, axis=1))   squares rounded, numpy's pairwise summation
+//   d  = np.dot(x, y.T) / np.outer(x2, y2) one fma chain over k (the callers' MFMA /
+//                                          fmaf loops), norms multiplied, ONE division
+//   d  = arccos(d) / np.pi                 glibc's acosf (fdlibm e_acosf.c), / float32(pi)
+//
+// Every translation unit that includes this file is compiled with -ffp-contract=off:
+// a*b + c below is a rounded product followed by a rounded sum unless it is written
+// fmaf().  Division and square root are the compiler's correctly rounded ones (HIP's
+// default -fhip-fp32-correctly-rounded-divide-sqrt).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace abn {
+
+__device__ __forceinline__ float bits_f32(uint32_t u) { return __uint_as_float(u); }
+
+// np.sum(v ** 2) over n <= 128 consecutive floats: 8 interleaved partial sums, combined
+// as a tree, then the tail (numpy/core/src/umath/loops_utils.h.src, pairwise sum)
+__device__ __forceinline__ float sumsq_block(const float* __restrict__ v, int n)
+{
+    if (n < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < n; ++i) res += v[i] * v[i];
+        return res;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = v[j] * v[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += v[i + j] * v[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += v[i] * v[i];
+    return res;
+}
+
+// the whole recursion (n > 128 splits at n/2 rounded down to a multiple of 8), written
+// with an explicit stack: depth <= 16 covers every D the ABI accepts (< 2^20)
+__device__ inline float sumsq_numpy(const float* __restrict__ v, int n)
+{
+    if (n <= 128) return sumsq_block(v, n);
+    int off[20], len[20], state[20];
+    float left[20];
+    int sp = 0;
+    off[0] = 0; len[0] = n; state[0] = 0;
+    float ret = 0.0f;
+    while (sp >= 0) {
+        if (len[sp] <= 128) {
+            ret = sumsq_block(v + off[sp], len[sp]);
+            --sp;
+            continue;
+        }
+        int n2 = len[sp] / 2;
+        n2 -= n2 % 8;
+        if (state[sp] == 0) {              // descend into the left half
+            state[sp] = 1;
+            off[sp + 1] = off[sp]; len[sp + 1] = n2; state[sp + 1] = 0;
+            ++sp;
+        } else if (state[sp] == 1) {       // left done: keep it, descend right
+            left[sp] = ret;
+            state[sp] = 2;
+            off[sp + 1] = off[sp] + n2; len[sp + 1] = len[sp] - n2; state[sp + 1] = 0;
+            ++sp;
+        } else {
+            ret = left[sp] + ret;
+            --sp;
+        }
+    }
+    return ret;
+}
+
+__device__ __forceinline__ float row_norm_numpy(const float* __restrict__ v, int n) { return sqrtf(sumsq_numpy(v, n)); }
+
+// glibc 2.35 __ieee754_acosf, straight-line for the common |x| < 0.5 case with
+// wave-uniform detours for the other two ranges (a wave whose lanes all sit in
+// |x| < 0.5 -- most of a distance tile of unrelated frames -- never pays for them).
+__device__ __forceinline__ float acosf_ref(float x)
+{
+    const float one = 1.0f;
+    const float pi = bits_f32(0x40490fdau), pio2_hi = bits_f32(0x3fc90fdau), pio2_lo = bits_f32(0x33a22168u);
+    const float pS0 = bits_f32(0x3e2aaaabu), pS1 = -bits_f32(0x3ea6b090u), pS2 = bits_f32(0x3e4e0aa8u),
+                pS3 = -bits_f32(0x3d241146u), pS4 = bits_f32(0x3a4f7f04u), pS5 = bits_f32(0x3811ef08u);
+    const float qS1 = -bits_f32(0x4019d139u), qS2 = bits_f32(0x4001572du), qS3 = -bits_f32(0x3f303361u),
+                qS4 = bits_f32(0x3d9dc62eu);
+    const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
+    const float ax = __uint_as_float(ix);
+    const bool small = ix < 0x3f000000u;
+    // x < -0.5: z = (1 + x) / 2 = (1 - |x|) / 2, the same operation
+    const float z = small ? x * x : (one - ax) * 0.5f;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    float res = pio2_hi - (x - (pio2_lo - x * r));
+    if (__any(!small)) {
+        const float s = sqrtf(z);
+        const float wn = r * s - pio2_lo;
+        const float neg = pi - 2.0f * (s + wn);
+        float big = neg;
+        const bool posb = !small && (int32_t)hx >= 0;
+        if (__any(posb)) {
+            const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
+            const float c = (z - df * df) / (s + df);
+            const float wp = r * s + c;
+            big = posb ? 2.0f * (df + wp) : neg;
+        }
+        res = small ? res : big;
+    }
+    res = ix <= 0x32800000u ? pio2_hi + pio2_lo : res;
+    res = ix == 0x3f800000u ? ((int32_t)hx > 0 ? 0.0f : pi + 2.0f * pio2_lo) : res;
+    return ix > 0x3f800000u ? __builtin_nanf("") : res;       // |x| > 1 (rounding) or NaN: the pair is dropped
+}
+
+// one cell of cosine_distance: dot = the fma chain x.y, nx / ny = the row norms
+// (utils.py:46-58; a zero-norm row is at distance 1 from everything, 0 from another zero row)
+template <bool ZERO_ROWS = true>
+__device__ __forceinline__ float angular_distance_ref(float dot, float nx, float ny)
+{
+    const float pi_f = bits_f32(0x40490fdbu);                  // float32(np.pi)
+    float v = acosf_ref(dot / (nx * ny)) / pi_f;
+    if (ZERO_ROWS) {
+        const bool zx = nx == 0.0f, zy = ny == 0.0f;
+        v = (zx || zy) ? 1.0f : v;
+        v = (zx && zy) ? 0.0f : v;
+    }
+    return v;
+}
+
+}  // namespace abn

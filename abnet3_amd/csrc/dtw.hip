@@ -10,9 +10,13 @@
 //  1. dist_kernel   64x64 tiles of the angular distance matrix, one 32x32 quadrant
 //                   per wavefront on the float32 matrix cores: the MFMA
 //                   accumulates every cell as one sequential fused chain over k,
-//                   exactly the oracle's fmaf loop, and acos is an explicit
-//                   float32 routine, so the values are bit-identical to the C
-//                   oracle (the file is compiled with -ffp-contract=off).  The
+//                   exactly the oracle's fmaf loop (= what sgemm computes behind
+//                   the reference's np.dot), and the rest of the cell -- norms in
+//                   numpy's summation order, one division, glibc's acosf, / pi --
+//                   follows the reference's statements operation by operation
+//                   (dist_ref.h), so the values are bit-identical to the C oracle
+//                   and to the reference's own output (tests/golden/cosdist_libm.npz;
+//                   the file is compiled with -ffp-contract=off).  The
 //                   matrix is written in the layout the DP reads with 16-byte
 //                   coalesced loads:
 //                     S4[g][phys(i)][e] = dist(i, 4g + e - i)
@@ -36,61 +40,13 @@
 // The DP is dependency-bound (N+M-1 sequential steps per pair), not HBM-bound:
 // parallelism comes from running thousands of pairs side by side, longest first.
 #include "common.h"
+#include "dist_ref.h"
 #include <algorithm>
 #include <mutex>
 #include <vector>
 #include <type_traits>
 
 namespace abn {
-
-// Correctly rounded float32 sqrt for x in {0} U [2^-24, 1] -- every value 1 - |c| can
-// take: v_rsq_f32 plus one Markstein step.  tools/sqrt_exact_probe.hip checks it
-// against (float)sqrt((double)x) for ALL 201 326 593 floats of that range on gfx950
-// (0 mismatches), so it equals the oracle's sqrtf bit for bit at a third of the
-// instructions of the general routine (no denormal scaling, no one-ulp fix-up).
-__device__ __forceinline__ float sqrt_unit(float x)
-{
-    const float r = __builtin_amdgcn_rsqf(x);
-    const float s = x * r, h = 0.5f * r;
-    const float e = fmaf(-s, s, x);
-    const float q = fmaf(e, h, s);
-    return x > 0.0f ? q : 0.0f;                       // also turns the NaN of a negative argument into 0
-}
-
-// ---- float32 acos, operation for operation the oracle's (oracle/dtw.c):
-// division-free Abramowitz & Stegun 4.4.46, Horner with explicit fmaf.  Written
-// without branches (every lane runs the same straight line; selects at the end).
-__device__ __forceinline__ float acos_f32(float x)
-{
-    const float pi_f = 3.14159274101257324f;
-    const float ax = fabsf(x);
-    float p = -0.0012624911f;
-    p = fmaf(p, ax, 0.0066700901f);
-    p = fmaf(p, ax, -0.0170881256f);
-    p = fmaf(p, ax, 0.0308918810f);
-    p = fmaf(p, ax, -0.0501743046f);
-    p = fmaf(p, ax, 0.0889789874f);
-    p = fmaf(p, ax, -0.2145988016f);
-    p = fmaf(p, ax, 1.5707963050f);
-    const float r = sqrt_unit(1.0f - ax) * p;
-    const float v = x < 0.0f ? pi_f - r : r;
-    return ax <= 1.0f ? v : __builtin_nanf("");     // |x| > 1 (rounding) or NaN -> NaN, the pair is dropped
-}
-
-// inx / iny are 1/|x|, 1/|y| (+inf for a zero row).  ZERO_ROWS = false is the
-// fast path for tiles that hold no zero row.
-template <bool ZERO_ROWS = true>
-__device__ __forceinline__ float angular_distance(float dot, float inx, float iny)
-{
-    const float inv_pi_f = 0.318309873342514038f;
-    float v = acos_f32((dot * inx) * iny) * inv_pi_f;
-    if (ZERO_ROWS) {
-        const bool zx = __builtin_isinf(inx), zy = __builtin_isinf(iny);
-        v = (zx || zy) ? 1.0f : v;                    // utils.py:55-56
-        v = (zx && zy) ? 0.0f : v;                    // utils.py:57-58
-    }
-    return v;
-}
 
 struct PairMeta {
     int64_t off1, off2;      // first row of each token in feats1 / feats2
@@ -144,7 +100,7 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
 {
     // x / y row chunks [64][KC] for the MFMA loop; the finished tile reuses the space
     __shared__ __attribute__((aligned(16))) float smem[2 * TS * KCP];
-    __shared__ float inx_s[TS], iny_s[TS];
+    __shared__ float nx_s[TS], ny_s[TS];
     static_assert(2 * TS * KCP >= TS * TSP, "the distance tile must fit in the staging buffers");
     float (*xs)[KCP] = reinterpret_cast<float (*)[KCP]>(smem);
     float (*ys)[KCP] = reinterpret_cast<float (*)[KCP]>(smem + TS * KCP);
@@ -173,7 +129,6 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-    float nsum = 0.0f;                            // waves 0 / 1: sum of squares of x / y row `lane`
     for (int k0 = 0; k0 < D; k0 += KC) {
         const int kn = min(KC, D - k0);
         if (vec) {                                // 16-byte loads; a token's rows are contiguous in memory
@@ -200,13 +155,9 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
         DSTAMP();                                 // (D <= KC: one trip) operands staged
         // the chunk is zero-filled past kn, and fma(0, 0, acc) == acc exactly, so
         // whole float4 groups can be consumed; k still ascends one at a time
-        if (wave < 2) {                           // the tile's 64 + 64 row norms, same sequential chain as the oracle
-            const float* row = wave == 0 ? xs[lane] : ys[lane];
-            for (int k = 0; k < kn; k += 4) {
-                const float4 q = *reinterpret_cast<const float4*>(row + k);
-                nsum = fmaf(q.x, q.x, nsum); nsum = fmaf(q.y, q.y, nsum); nsum = fmaf(q.z, q.z, nsum); nsum = fmaf(q.w, q.w, nsum);
-            }
-        }
+        // the tile's 64 + 64 row norms, np.sqrt(np.sum(x ** 2, axis=1)) in numpy's pairwise
+        // order: from the staged rows when a frame fits one chunk (the 40-d case), else below
+        if (wave < 2 && D <= KC) (wave == 0 ? nx_s : ny_s)[lane] = row_norm_numpy(wave == 0 ? xs[lane] : ys[lane], D);
         for (int k = 0; k < kn; k += 4) {
             const float4 yq = *reinterpret_cast<const float4*>(&ys[jb + r][k]);
             const float4 xq = *reinterpret_cast<const float4*>(&xs[ib + r][k]);
@@ -216,13 +167,15 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
         __syncthreads();
     }
     DSTAMP();                                     // norms + MFMA + barrier
-    if (wave < 2) (wave == 0 ? inx_s : iny_s)[lane] = 1.0f / sqrtf(nsum);
-    __syncthreads();                              // reciprocal norms are staged
+    if (wave < 2 && D > KC)                       // wide frames: the summation order spans the chunks, read the row itself
+        (wave == 0 ? nx_s : ny_s)[lane] = wave == 0 ? row_norm_numpy(xbase + (int64_t)min(i0 + lane, m.n1 - 1) * D, D)
+                                                      : row_norm_numpy(ybase + (int64_t)min(j0 + lane, m.n2 - 1) * D, D);
+    __syncthreads();                              // the norms are staged
     DSTAMP();
     const int i = i0 + ib + r;
-    const float inx = inx_s[ib + r];
-    // zero rows (reciprocal norm = inf) are rare: tiles without one skip their handling
-    const bool zero_rows = __any(__builtin_isinf(inx_s[lane]) || __builtin_isinf(iny_s[lane]));
+    const float nx = nx_s[ib + r];
+    // zero rows are rare: tiles without one skip their handling
+    const bool zero_rows = __any(nx_s[lane] == 0.0f || ny_s[lane] == 0.0f);
     bool any_bad = false;
     auto epilogue = [&](auto zr) {
 #pragma unroll
@@ -231,7 +184,7 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ fea
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float d = angular_distance<decltype(zr)::value>(acc[4 * qg + e], inx, iny_s[jl + e]);
+                const float d = angular_distance_ref<decltype(zr)::value>(acc[4 * qg + e], nx, ny_s[jl + e]);
                 const bool valid = i < m.n1 && j0 + jl + e < m.n2;
                 any_bad |= valid && !(d >= 0.0f);     // utils.py:59 assert
                 v[e] = valid ? d : 0.0f;
@@ -454,15 +407,43 @@ __global__ void dist_plain_kernel(const float* __restrict__ x, int N, const floa
     const int i = (int)(idx / M), j = (int)(idx % M);
     const float* a = x + (int64_t)i * D;
     const float* b = y + (int64_t)j * D;
-    float dot = 0.0f, sa = 0.0f, sb = 0.0f;
-    for (int k = 0; k < D; ++k) {
-        dot = fmaf(a[k], b[k], dot);
-        sa = fmaf(a[k], a[k], sa);
-        sb = fmaf(b[k], b[k], sb);
-    }
-    const float v = angular_distance(dot, 1.0f / sqrtf(sa), 1.0f / sqrtf(sb));
+    float dot = 0.0f;
+    for (int k = 0; k < D; ++k) dot = fmaf(a[k], b[k], dot);
+    const float v = angular_distance_ref(dot, row_norm_numpy(a, D), row_norm_numpy(b, D));
     if (!(v >= 0.0f) && bad) atomicOr(bad, 1);
     d[idx] = (double)v;
+}
+
+// float64 inputs: the reference computes in the input precision (utils.py:41-42).  The
+// same statements in double; arccos is the device library's (within a few ulp of libm's).
+__global__ void dist_plain_f64_kernel(const double* __restrict__ x, int N, const double* __restrict__ y, int M, int D,
+                                      double* __restrict__ d, int32_t* __restrict__ bad)
+{
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * M) return;
+    const int i = (int)(idx / M), j = (int)(idx % M);
+    const double* a = x + (int64_t)i * D;
+    const double* b = y + (int64_t)j * D;
+    double dot = 0.0, sa = 0.0, sb = 0.0;
+    for (int k = 0; k < D; ++k) {
+        dot = fma(a[k], b[k], dot);
+        sa += a[k] * a[k];
+        sb += b[k] * b[k];
+    }
+    const double na = sqrt(sa), nb = sqrt(sb);
+    double v = acos(dot / (na * nb)) / 3.14159265358979323846;
+    if (na == 0.0 || nb == 0.0) v = 1.0;
+    if (na == 0.0 && nb == 0.0) v = 0.0;
+    if (!(v >= 0.0) && bad) atomicOr(bad, 1);
+    d[idx] = v;
+}
+
+// acosf_ref over an array: lets the tests compare the device routine with libm's acosf
+// argument by argument (all 2^31 of them, tools/acosf_gpu_exhaustive.py)
+__global__ void arccos_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = acosf_ref(x[i]);
 }
 
 struct WsPlan {
@@ -702,5 +683,30 @@ extern "C" int abn_cosine_distance(const float* x, int64_t N, const float* y, in
     hipLaunchKernelGGL(dist_plain_kernel, dim3((unsigned)((N * M + 255) / 256)), dim3(256), 0, st, x, (int)N, y, (int)M,
                        (int)D, d, bad_flag);
     ABN_CHECK_LAUNCH("cosine_distance");
+    return ABN_OK;
+}
+
+extern "C" int abn_cosine_distance_f64(const double* x, int64_t N, const double* y, int64_t M, int64_t D, double* d,
+                                       int32_t* bad_flag, void* stream)
+{
+    ABN_REQUIRE(N >= 0 && M >= 0 && D >= 1 && N * M < (1LL << 40), "cosine_distance_f64: bad shape");
+    if (N * M == 0) return ABN_OK;
+    ABN_REQUIRE(x && y && d, "cosine_distance_f64: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (bad_flag && hipMemsetAsync(bad_flag, 0, 4, st) != hipSuccess) { set_error("cosine_distance_f64: memset failed"); return ABN_E_LAUNCH; }
+    hipLaunchKernelGGL(dist_plain_f64_kernel, dim3((unsigned)((N * M + 255) / 256)), dim3(256), 0, st, x, (int)N, y,
+                       (int)M, (int)D, d, bad_flag);
+    ABN_CHECK_LAUNCH("cosine_distance_f64");
+    return ABN_OK;
+}
+
+extern "C" int abn_arccos_f32(const float* x, int64_t n, float* out, void* stream)
+{
+    ABN_REQUIRE(n >= 0, "arccos_f32: negative length");
+    if (n == 0) return ABN_OK;
+    ABN_REQUIRE(x && out, "arccos_f32: null pointer");
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(arccos_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    ABN_CHECK_LAUNCH("arccos_f32");
     return ABN_OK;
 }

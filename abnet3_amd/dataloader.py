@@ -21,7 +21,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, parallel
 from .utils import (Features_Accessor, dtw_align_batch, group_pairs, read_dataset,
                     read_spkid_file)
 
@@ -159,22 +159,15 @@ class OriginalDataLoader(DataLoader):
     def _token(self, f, s, e, frames):
         return self.features.token_frames(f, s, e) if frames else self.features.token(f, s, e)
 
-    def align_pairs(self, same_pairs, frames=False):
-        """DTW-aligns every not-yet-cached 'same' pair in ONE batched GPU call
-        (get_dtw_alignment, dataloader.py:189).  Dropped pairs (NaN distance,
-        dataloader.py:188-191) are cached as None."""
-        todo, queued = [], set()
-        for p in same_pairs:
-            key = tuple(p) + (frames,)
-            if key in self._align or key in queued:
-                continue
-            f1, s1, e1, f2, s2, e2 = p
-            if (s1 > e1) or (s2 > e2):
-                continue
-            todo.append(key)
-            queued.add(key)
-        if not todo:
-            return
+    # cells (sum of n1*n2) one batched DTW call may cover: bounds the call's workspace
+    # and its [pairs, stride] path arrays whatever the size of the dataset
+    ALIGN_CELL_BUDGET = 1 << 30
+
+    shards_itself = True          # see parallel.py: the trainer must not shard again
+
+    def _align_chunk(self, todo):
+        """One batched DTW call for the keys in `todo`: (path lengths on the host,
+        flat global-row index tensors g1, g2 on the device, concatenated in order)."""
         o1, n1, o2, n2 = [], [], [], []
         for f1, s1, e1, f2, s2, e2, fr in todo:
             a, b = self._token(f1, s1, e1, fr), self._token(f2, s2, e2, fr)
@@ -187,15 +180,67 @@ class OriginalDataLoader(DataLoader):
         mask = torch.arange(stride, device=dev)[None, :] < res.path_len[:, None]
         g1 = (res.path1.long() + torch.tensor(o1, device=dev)[:, None])[mask]
         g2 = (res.path2.long() + torch.tensor(o2, device=dev)[:, None])[mask]
-        start = 0
-        for key, ln in zip(todo, lens):
-            if ln == 0:
-                # an empty token or a NaN distance: the reference's try/except
-                # drops the pair (dataloader.py:188-191)
-                self._align[key] = None
-            else:
-                self._align[key] = (g1[start:start + ln], g2[start:start + ln])
-            start += int(ln)
+        return lens, g1, g2
+
+    def align_pairs(self, same_pairs, frames=False, exchange=False):
+        """DTW-aligns every not-yet-cached 'same' pair in batched GPU calls
+        (get_dtw_alignment, dataloader.py:189), at most ALIGN_CELL_BUDGET cells per
+        call.  Dropped pairs (NaN distance, dataloader.py:188-191) are cached as None.
+        exchange=True under torch.distributed: the pairs are split over the ranks
+        (pair k goes to rank k % R), each rank aligns its share and the index lists
+        are all-gathered, so that every rank ends up with every alignment."""
+        todo, queued = [], set()
+        for p in same_pairs:
+            key = tuple(p) + (frames,)
+            if key in self._align or key in queued:
+                continue
+            f1, s1, e1, f2, s2, e2 = p
+            if (s1 > e1) or (s2 > e2):
+                continue
+            todo.append(key)
+            queued.add(key)
+        if not todo:             # (the same list on every rank: nobody waits in a collective)
+            return
+        rank, ws = parallel.world()
+        exchange = exchange and ws > 1
+        mine = todo[rank::ws] if exchange else todo
+        lens_all, g1_all, g2_all = [], [], []
+        chunk, cells = [], 0
+        for key in mine + [None]:
+            if key is not None:
+                f1, s1, e1, f2, s2, e2, fr = key
+                c = self._token(f1, s1, e1, fr)[1] * self._token(f2, s2, e2, fr)[1]
+                if not chunk or cells + c <= self.ALIGN_CELL_BUDGET:
+                    chunk.append(key)
+                    cells += c
+                    continue
+            if chunk:
+                lens, g1, g2 = self._align_chunk(chunk)
+                lens_all.append(lens); g1_all.append(g1); g2_all.append(g2)
+            chunk, cells = ([key], c) if key is not None else ([], 0)
+        dev = self.features.table.device
+        empty = torch.zeros(0, dtype=torch.int64, device=dev)
+        lens = np.concatenate(lens_all) if lens_all else np.zeros(0, dtype=np.int32)
+        g1 = torch.cat(g1_all) if g1_all else empty
+        g2 = torch.cat(g2_all) if g2_all else empty
+        if exchange:
+            lens_r = parallel.all_gather_varlen(torch.from_numpy(lens.astype(np.int64)))
+            g1_r = parallel.all_gather_varlen(g1)
+            g2_r = parallel.all_gather_varlen(g2)
+            shares = [(todo[r::ws], lens_r[r].cpu().numpy(), g1_r[r], g2_r[r]) for r in range(ws)]
+        else:
+            shares = [(mine, lens, g1, g2)]
+        for keys, lens, g1, g2 in shares:
+            start = 0
+            for key, ln in zip(keys, lens):
+                ln = int(ln)
+                if ln == 0:
+                    # an empty token or a NaN distance: the reference's try/except
+                    # drops the pair (dataloader.py:188-191)
+                    self._align[key] = None
+                else:
+                    self._align[key] = (g1[start:start + ln], g2[start:start + ln])
+                start += ln
 
     def prefetch_alignments(self):
         """Aligns every 'same' pair of the train and dev sets up front, in one
@@ -204,7 +249,7 @@ class OriginalDataLoader(DataLoader):
         self.load_data()
         for mode in ('train', 'dev'):
             if self.pairs[mode]:
-                self.align_pairs(group_pairs(self.pairs[mode])['same'])
+                self.align_pairs(group_pairs(self.pairs[mode])['same'], exchange=True)
 
     # -- batches ---------------------------------------------------------------
     def same_speaker(self, fid2spk, f1, f2):
@@ -302,17 +347,11 @@ class OriginalDataLoader(DataLoader):
         pairs = self.pairs[mode]
         num_pairs = len(pairs)
         if self.shuffle_between_epochs:
-            random.shuffle(pairs)
+            self._shuffle_pairs(pairs)
         batches = [pairs[idx:idx + self.batch_size]
                    for idx in range(0, num_pairs, self.batch_size)]
-        num_batches = len(batches)
-        if self.num_max_minibatches < num_batches:
-            selected_batches = np.random.choice(range(num_batches),
-                                                self.num_max_minibatches,
-                                                replace=False)
-        else:
-            selected_batches = np.random.permutation(range(num_batches))
-        # one batched DTW launch for everything this epoch will touch
+        selected_batches = self._select_batches(len(batches), train_mode)
+        # one batched DTW launch for everything this epoch will touch ON THIS RANK
         self.align_pairs([p[:6] for b in selected_batches for p in batches[b]
                           if p[6] == 'same'])
         for batch_id in selected_batches:
@@ -320,6 +359,35 @@ class OriginalDataLoader(DataLoader):
             if self.tcl > 0:
                 batch = self.add_tcl_to_batch(batch)
             yield batch
+
+    @staticmethod
+    def _shuffle_pairs(pairs):
+        """random.shuffle(pairs) (dataloader.py:276-277); under torch.distributed the
+        permutation is rank 0's, whatever the other ranks' `random` state is."""
+        if parallel.world()[1] == 1:
+            random.shuffle(pairs)
+            return
+        perm = list(range(len(pairs)))
+        random.shuffle(perm)                     # same draws as shuffling the list itself
+        perm = parallel.broadcast_array(perm)
+        pairs[:] = [pairs[i] for i in perm]
+
+    def _select_batches(self, num_batches, train_mode):
+        """The epoch's batch ids in visiting order (dataloader.py:291-299).  Under
+        torch.distributed rank 0's draw is broadcast and rank r keeps ids r, r+R, ...
+        of it: disjoint, together complete (train: up to R-1 batches at the end are
+        left out so that every rank takes the same number of steps)."""
+        if self.num_max_minibatches < num_batches:
+            selected_batches = np.random.choice(range(num_batches),
+                                                self.num_max_minibatches,
+                                                replace=False)
+        else:
+            selected_batches = np.random.permutation(range(num_batches))
+        rank, ws = parallel.world()
+        if ws > 1:
+            selected_batches = parallel.broadcast_array(selected_batches)
+            selected_batches = parallel.shard_ids(selected_batches, rank, ws, equal=train_mode)
+        return selected_batches
 
     def add_tcl_to_batch(self, batch):
         X1, X2, Y = batch
@@ -372,7 +440,7 @@ class FramesDataLoader(OriginalDataLoader):
         """The frame-pair dataset (global row of frame 1, of frame 2, +-1) for
         all word pairs (dataloader.py:617-671), shuffled once."""
         pairs = group_pairs(pairs)
-        self.align_pairs(pairs['same'])
+        self.align_pairs(pairs['same'], exchange=True)     # DTW work split over the ranks
         dev = self.features.table.device
         i1, i2, ys = [], [], []
         for f1, s1, e1, f2, s2, e2 in pairs['same']:
@@ -409,7 +477,9 @@ class FramesDataLoader(OriginalDataLoader):
     def _shuffle(fp):
         # np.random.shuffle(list) and np.random.permutation(n) draw the same
         # permutation from the same global state (dataloader.py:670)
-        perm = torch.from_numpy(np.random.permutation(len(fp[2]))).to(fp[2].device)
+        # (under torch.distributed every rank applies rank 0's permutation)
+        perm = parallel.broadcast_array(np.random.permutation(len(fp[2])))
+        perm = torch.from_numpy(perm).to(fp[2].device)
         return fp[0][perm], fp[1][perm], fp[2][perm]
 
     def load_batch(self, sl, mode):
@@ -438,6 +508,9 @@ class FramesDataLoader(OriginalDataLoader):
                               min(self.batch_position + self.max_batches_per_epoch,
                                   num_batches))
             self.batch_position += self.max_batches_per_epoch
+        rank, ws = parallel.world()
+        if ws > 1:       # rank r gathers batches r, r+R, ... of the epoch's (shared) order
+            batch_ids = parallel.shard_ids(list(batch_ids), rank, ws, equal=train_mode)
         for i in batch_ids:
             yield self.load_batch(slice(i * self.batch_size,
                                         i * self.batch_size + self.batch_size), mode)
@@ -462,14 +535,8 @@ class MultiTaskDataLoader(OriginalDataLoader):
         num_pairs = len(pairs)
         batches = [pairs[idx:idx + self.batch_size]
                    for idx in range(0, num_pairs, self.batch_size)]
-        num_batches = len(batches)
         fid2spk = read_spkid_file(self.fid2spk_file)
-        if self.num_max_minibatches < num_batches:
-            selected_batches = np.random.choice(range(num_batches),
-                                                self.num_max_minibatches,
-                                                replace=False)
-        else:
-            selected_batches = np.random.permutation(range(num_batches))
+        selected_batches = self._select_batches(len(batches), train_mode)
         self.align_pairs([p[:6] for b in selected_batches for p in batches[b]
                           if p[6] == 'same'])
         for idx in selected_batches:

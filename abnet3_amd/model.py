@@ -206,6 +206,10 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2):
     _Saved)."""
     lib = _lib.load()
     net = seg.net
+    # the reference takes strided inputs (a column slice of stacked features):
+    # make them dense first, then insist on the device
+    x1 = x1.contiguous()
+    x2 = x2.contiguous() if x2 is not None else None
     _lib.require_device(x1, x2)
     if x1.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
         raise TypeError('abnet3_amd: features must be float32 (the reference '
@@ -215,8 +219,6 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2):
                          % (seg.input_dim, tuple(x1.shape)))
     if x2 is not None and x2.shape != x1.shape:
         raise ValueError('abnet3_amd: the two inputs must have the same shape')
-    x1 = x1.contiguous()
-    x2 = x2.contiguous() if x2 is not None else None
     train = bool(net.training)
     rows = x1.shape[0] * (2 if x2 is not None else 1)
     masks = seg.masks_of(all_masks) if train else None
@@ -267,7 +269,11 @@ class _TowerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, seg, grad_pass, all_masks, n_calls, split, x1, x2, *params):
-        _lib.require_device(*params)
+        # parameters are views of the flat buffer (dense by construction); only the
+        # device is checked here
+        for p_ in params:
+            if not p_.is_cuda:
+                _lib.require_device(p_)
         out, sv = _segment_forward(seg, all_masks, n_calls, x1, x2)
         ctx.seg, ctx.grad_pass, ctx.sv = seg, grad_pass, sv
         ctx.have_x2 = x2 is not None
@@ -416,6 +422,12 @@ class _HipNetwork(NetworkBuilder):
         # .cuda() / .to() / .float() replace the parameter storages: the flat buffer
         # and every cached descriptor are stale afterwards
         out = super(_HipNetwork, self)._apply(fn, *args, **kwargs)
+        # a no-op move (.cuda() on a network that already lives there, as the embedders
+        # do between epochs) leaves every parameter a view of the flat buffer: keep it,
+        # the optimizer state and captured graphs hang on its address
+        if getattr(self, '_flat', None) is not None and self._live_cache is not None \
+                and self._flat.device == self._live_cache[0].device and self._is_flat(full=True):
+            return out
         self._flat = None
         self._generation = getattr(self, '_generation', 0) + 1
         return out
@@ -498,8 +510,19 @@ class _HipNetwork(NetworkBuilder):
             return (empty, empty.clone()) if split else empty
         return _TowerFunction.apply(seg, grad_pass, masks, n_calls, split, x1, x2, *seg.params)
 
+    # HIP plumbing kept in __dict__ next to the reference's attributes: device
+    # buffers, ctypes descriptors and caches -- not part of the description of the
+    # network and not picklable
+    _HIP_STATE = ('_flat', '_last_grad_flat', '_offsets', '_segs', '_mask_override',
+                  '_generation', '_live_cache')
+
     def whoami(self):
-        return {'params': self.__dict__, 'class_name': self.__class__.__name__}
+        """Output description for the neural network and all parameters
+        (abnet3/model.py:198-202: {'params': self.__dict__, 'class_name'}), minus the
+        HIP plumbing, so that TrainerBuilder.save_whoami can pickle it as the
+        reference does (abnet3/trainer.py:106-108)."""
+        params = {k: v for k, v in self.__dict__.items() if k not in self._HIP_STATE}
+        return {'params': params, 'class_name': self.__class__.__name__}
 
     def load_network(self, network_path=None):
         self.load_state_dict(torch.load(network_path))
@@ -635,9 +658,6 @@ class SiameseNetwork(_HipNetwork):
         if x12.shape[0] % 2:
             raise ValueError('abnet3_amd: forward_pair_rows needs an even number of rows')
         return self._run_tower(x12, None, 2, True)
-
-    def whoami(self):
-        return {'params': self.__dict__, 'class_name': self.__class__.__name__}
 
     def save_network(self, epoch=''):
         torch.save(self.state_dict(), self.output_path + str(epoch) + '.pth')

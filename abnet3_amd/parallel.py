@@ -7,11 +7,22 @@ backward and optimizer step (abnet3/trainer.py:239 -> :240).  The bucket is ONE
 contiguous buffer (SiameseNetwork.flat_grad()), i.e. one small-message
 collective (2.29 MB for C2) instead of eight.
 
+Producer side ("each rank runs its own DTW mining"): the loaders
+shard themselves (`shards_itself`).  Every decision that involves a random draw
+-- which word-pair batches an epoch visits and in which order, the shuffle of
+the frame-pair list -- is taken on rank 0 and broadcast, so all ranks cut ONE
+order into disjoint pieces whatever their local RNG state is; each rank then
+aligns (DTW) and gathers only its own batches.  A frame-pair dataset that is
+aligned once (FramesDataLoader) splits the alignment work over the ranks and
+exchanges the resulting index lists (all_gather_varlen).
+
 torch.distributed's "nccl" backend IS RCCL on ROCm; "gloo" is used by the CPU
-tests of this file's logic.
+tests of this file's logic (and by the two-ranks-on-one-GPU parity test).
 """
 import os
+import random
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -40,6 +51,20 @@ def init_from_env(backend=None):
     return rank, ws, local
 
 
+def _comm_device():
+    """Where small control messages live: RCCL moves device memory only."""
+    if dist.get_backend() == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def seed_all(seed):
+    """Same `random` / numpy global RNG state on every rank (the loaders draw from
+    both; the reference never seeds them, abnet3/trainer.py:36-87 only stores `seed`)."""
+    random.seed(seed)
+    np.random.seed(seed)
+
+
 def all_reduce_gradients(flat_grad, loss_is_mean):
     """SUM-reduces the flat gradient bucket in place over all ranks.
 
@@ -53,10 +78,24 @@ def all_reduce_gradients(flat_grad, loss_is_mean):
     return 1.0 / ws if loss_is_mean else 1.0
 
 
-def shard_batches(iterator, rank, ws):
-    """Round-robin shard of a batch iterator: rank r takes batches r, r+ws, ...
-    Only complete groups of `ws` batches are used, so every rank performs the
-    same number of steps (the all-reduce is a collective)."""
+def shard_ids(ids, rank, ws, equal):
+    """Rank r's share ids[r], ids[r+ws], ... of ONE order known to all ranks.
+    equal=True keeps complete groups of `ws` only, so that every rank takes the
+    same number of steps (the gradient all-reduce is a collective); equal=False
+    keeps the tail (evaluation: sums and counts are all-reduced afterwards)."""
+    if ws == 1:
+        return ids
+    n = len(ids)
+    if equal:
+        n = n // ws * ws
+    return ids[rank:n:ws]
+
+
+def shard_batches(iterator, rank, ws, drop_tail=True):
+    """Round-robin shard of a batch iterator for loaders that do not shard
+    themselves: rank r takes batches r, r+ws, ...  With drop_tail only complete
+    groups of `ws` batches are used (train: same number of steps on every rank);
+    without it rank r also gets its batch of the incomplete last group (dev)."""
     if ws == 1:
         for b in iterator:
             yield b
@@ -67,9 +106,41 @@ def shard_batches(iterator, rank, ws):
         if len(group) == ws:
             yield group[rank]
             group = []
+    if not drop_tail and rank < len(group):
+        yield group[rank]
 
 
 def broadcast_parameters(flat_params, src=0):
     _, ws = world()
     if ws > 1:
         dist.broadcast(flat_params, src=src)
+
+
+def broadcast_array(arr, src=0):
+    """int64 numpy array, same length on every rank -> rank `src`'s values."""
+    _, ws = world()
+    arr = np.ascontiguousarray(arr, dtype=np.int64)
+    if ws == 1 or arr.size == 0:
+        return arr
+    t = torch.from_numpy(arr.copy()).to(_comm_device())
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+def all_gather_varlen(t):
+    """1-d tensors of rank-dependent length -> list of every rank's tensor (on t's
+    device), in rank order."""
+    rank, ws = world()
+    if ws == 1:
+        return [t]
+    dev = _comm_device()
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
+    lens = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(lens, n)
+    lens = [int(v.item()) for v in lens]
+    cap = max(max(lens), 1)
+    mine = torch.zeros(cap, dtype=t.dtype, device=dev)
+    mine[:t.numel()] = t.to(dev)
+    parts = [torch.empty_like(mine) for _ in range(ws)]
+    dist.all_gather(parts, mine)
+    return [p[:n_].to(t.device) for p, n_ in zip(parts, lens)]

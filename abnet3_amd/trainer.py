@@ -148,6 +148,9 @@ class TrainerBuilder:
                                            self.momentum)
         if self.world_size > 1:
             parallel.broadcast_parameters(self.network.flat_parameters())
+            # one RNG state on all ranks to start from; what an epoch visits is
+            # broadcast from rank 0 anyway (parallel.py, the loaders' batch_iterator)
+            parallel.seed_all(self.seed)
 
     def params(self):
         params = copy.copy(self.__dict__)
@@ -167,12 +170,11 @@ class TrainerBuilder:
         return whoami
 
     def save_whoami(self):
-        info = {'class_name': self.__class__.__name__,
-                'network_class': self.network.__class__.__name__,
-                'loss_class': self.loss.__class__.__name__,
-                'dataloader': self.dataloader.whoami()
-                if hasattr(self.dataloader, 'whoami') else None}
-        pickle.dump(info, open(self.network.output_path + '.params', "wb"))
+        """Pickles whoami() next to the network, as the reference does
+        (abnet3/trainer.py:106-108); the networks' whoami() leaves their HIP
+        plumbing out, everything else is the reference's dictionary."""
+        with open(self.network.output_path + '.params', "wb") as fh:
+            pickle.dump(self.whoami(), fh)
 
     def optimize_model(self, do_training=True):
         raise NotImplementedError('Unimplemented optimize_model for class:',
@@ -360,6 +362,14 @@ class TrainerSiamese(TrainerBuilder):
         if capture_opt:
             opt.step_count = steps_before        # capturing recorded the launch, it did not run it
         static_loss = loss_value.detach()
+        # The replayed backward writes into the buffers THIS capture allocated.  An
+        # eager step in between (another batch shape, train_step_auto) re-points
+        # p.grad / _last_grad_flat at its own buffer; every replay therefore puts the
+        # captured gradient tensors back before anything reads flat_grad().
+        net = self.network
+        live = list(net.live_parameters()) if hasattr(net, 'live_parameters') else list(net.parameters())
+        captured_grads = [p.grad for p in live]
+        captured_flat = getattr(net, '_last_grad_flat', None)
 
         blob = getattr(self, '_static_blob', None)
         self._static_blob = None
@@ -371,6 +381,10 @@ class TrainerSiamese(TrainerBuilder):
                 for dst, src in zip(static, batch):
                     dst.copy_(src, non_blocking=True)
             graph.replay()
+            for p, g in zip(live, captured_grads):
+                p.grad = g
+            if captured_flat is not None:
+                net._last_grad_flat = captured_flat
             if capture_opt:
                 opt.step_count += 1
             else:
@@ -454,7 +468,10 @@ class TrainerSiamese(TrainerBuilder):
     def _batches(self, train_mode):
         it = self.dataloader.batch_iterator(train_mode=train_mode)
         if self.world_size > 1 and not getattr(self.dataloader, 'shards_itself', False):
-            it = parallel.shard_batches(it, self.rank, self.world_size)
+            # a foreign loader: every rank iterates everything and keeps its share.  The
+            # train pass needs the same number of steps on every rank (the all-reduce is
+            # a collective); the dev pass keeps its tail (sums / counts are reduced later)
+            it = parallel.shard_batches(it, self.rank, self.world_size, drop_tail=train_mode)
         return it
 
     def optimize_model(self, do_training=True):

@@ -123,21 +123,28 @@ def _as_device_f32(a):
 
 def cosine_distance(x, y):
     """Angular distance matrix arccos(cos)/pi, float64 [N, M] (utils.py:40-60),
-    computed on the MI355X.  Raises AssertionError, like the reference's
-    `assert np.all(d >= 0)`, when an entry is NaN (cos rounded above 1)."""
+    computed on the MI355X in the precision of the inputs, as the reference does
+    (both float32 -- the hot path -- or both float64, utils.py:41-42).  Raises
+    AssertionError, like the reference's `assert np.all(d >= 0)`, when an entry is NaN
+    (cos rounded above 1)."""
     x = np.asarray(x) if not isinstance(x, torch.Tensor) else x
     y = np.asarray(y) if not isinstance(y, torch.Tensor) else y
-    if not isinstance(x, torch.Tensor) and x.dtype == np.float64:
-        assert y.dtype == np.float64
-        x, y = x.astype(np.float32), y.astype(np.float32)   # device math is fp32
+    f64 = torch.float64 if isinstance(x, torch.Tensor) else np.float64
+    f32 = torch.float32 if isinstance(x, torch.Tensor) else np.float32
+    assert (x.dtype == f64 and y.dtype == f64) or (x.dtype == f32 and y.dtype == f32)
     lib = _lib.load()
-    xd, yd = _as_device_f32(x), _as_device_f32(y)
+    if x.dtype == f64:
+        xd = (x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))).cuda().contiguous()
+        yd = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y))).cuda().contiguous()
+        fn, what = lib.abn_cosine_distance_f64, 'abn_cosine_distance_f64'
+    else:
+        xd, yd = _as_device_f32(x), _as_device_f32(y)
+        fn, what = lib.abn_cosine_distance, 'abn_cosine_distance'
     N, M, D = xd.shape[0], yd.shape[0], xd.shape[1]
     assert yd.shape[1] == D
     d = torch.empty(N, M, dtype=torch.float64, device=xd.device)
     bad = torch.zeros(1, dtype=torch.int32, device=xd.device)
-    _lib.check(lib.abn_cosine_distance(_lib.ptr(xd), N, _lib.ptr(yd), M, D, _lib.ptr(d),
-                                       _lib.ptr(bad), _lib.stream()), 'abn_cosine_distance')
+    _lib.check(fn(_lib.ptr(xd), N, _lib.ptr(yd), M, D, _lib.ptr(d), _lib.ptr(bad), _lib.stream()), what)
     assert int(bad.item()) == 0, 'cosine_distance produced NaN / negative entries'
     return d.cpu().numpy()
 

@@ -435,6 +435,14 @@ def main():
     net.train()
     step = make_stepper(trainer, pool, args.graph)
 
+    # untimed, and independent of --warmup: let clocks, allocator and code caches settle
+    # (a short `--steps 20 --warmup 5` run otherwise times the first 8 ms after start-up)
+    t_settle, i = time.perf_counter(), 0
+    while time.perf_counter() - t_settle < 0.5:
+        for _ in range(32):
+            step(i)
+            i += 1
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     if world > 1:

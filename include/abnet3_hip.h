@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 5
+#define ABN_ABI_VERSION 6
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -189,9 +189,24 @@ int abn_dtw_batched(const float* feats1, int64_t rows1, const float* feats2,
                     int64_t path_stride, double* total_cost, void* ws,
                     int64_t ws_bytes, void* host_stage, int64_t host_stage_bytes,
                     void* stream);
-/* The distance matrix alone (utils.py:40-60), one pair, float64 [N, M] out. */
+/* The distance matrix alone (utils.py:40-60), one pair, float64 [N, M] out.  The
+ * reference computes in the precision of its inputs (utils.py:41-42: both float32 or
+ * both float64): abn_cosine_distance is the float32 arithmetic of the hot path (the
+ * same cell function as abn_dtw_batched: numpy's norm summation order, one fma chain
+ * per dot product, one division, glibc's acosf, / float32(pi) -- bit-identical to the
+ * reference's output on its plain numpy/libm path), abn_cosine_distance_f64 the same
+ * statements in double.  *bad_flag (device int32, may be NULL) is set when an entry is
+ * NaN or negative -- the reference's `assert np.all(d >= 0)` (utils.py:59). */
 int abn_cosine_distance(const float* x, int64_t N, const float* y, int64_t M,
                         int64_t D, double* d, int32_t* bad_flag, void* stream);
+int abn_cosine_distance_f64(const double* x, int64_t N, const double* y, int64_t M,
+                            int64_t D, double* d, int32_t* bad_flag, void* stream);
+
+/* np.arccos on float32 as the reference's cosine_distance evaluates it on numpy's plain
+ * path (utils.py:50,53: scipy.arccos = np.arccos = libm acosf): out[i] = acosf(x[i]),
+ * bit-identical to glibc 2.35's acosf for every float32 argument (NaN outside [-1, 1]).
+ * The cell function of abn_dtw_batched / abn_cosine_distance, exposed for verification. */
+int abn_arccos_f32(const float* x, int64_t n, float* out, void* stream);
 
 /* last_non_linearity='softmax' (abnet3/model.py:161-166: nn.Softmax() after the output
  * layer's Linear/Dropout/BatchNorm = softmax over each row of a [rows, n] matrix), and

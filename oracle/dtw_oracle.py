@@ -2,8 +2,9 @@
 
 Restates abnet3/utils.py:40-60 (cosine_distance) and :147-153
 (get_dtw_alignment).  The DP's parity is UNPINNED (third-party dtw.DTW absent
-from /root/reference; see dtw.c header); cosine_distance is pinned by
-tests/golden/cosdist.npz.
+from /root/reference; see dtw.c header); cosine_distance is pinned bit for bit by
+tests/golden/cosdist_libm.npz (reference outputs, numpy on its libm path) and to
+2e-7 by tests/golden/cosdist.npz (numpy on its SVML path).
 """
 import ctypes
 import os
@@ -34,6 +35,13 @@ def lib():
         L.abn_oracle_cosine_distance_f32.restype = c.c_int
         L.abn_oracle_cosine_distance_f32.argtypes = [
             c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_int64, c.c_void_p]
+        L.abn_oracle_cosine_distance_f64.restype = c.c_int
+        L.abn_oracle_cosine_distance_f64.argtypes = [
+            c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_int64, c.c_void_p]
+        L.abn_oracle_row_norm.restype = c.c_float
+        L.abn_oracle_row_norm.argtypes = [c.c_void_p, c.c_int64]
+        L.abn_oracle_acosf_vs_libm.restype = c.c_int64
+        L.abn_oracle_acosf_vs_libm.argtypes = [c.c_uint32, c.c_uint32, c.c_uint32, c.c_void_p]
         L.abn_oracle_dtw.restype = c.c_int64
         L.abn_oracle_dtw.argtypes = [c.c_void_p, c.c_int64, c.c_int64,
                                      c.c_void_p, c.c_void_p, c.c_void_p]
@@ -48,16 +56,37 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def cosine_distance(x, y):
-    """float32 [N,D], [M,D] -> float64 [N,M]; raises AssertionError like
-    utils.py:59 when an entry is NaN/negative."""
-    x = np.ascontiguousarray(x, dtype=np.float32)
-    y = np.ascontiguousarray(y, dtype=np.float32)
+def cosine_distance(x, y, check=True):
+    """[N,D], [M,D] (both float32 or both float64, utils.py:41-42) -> float64 [N,M],
+    computed in the input precision; raises AssertionError like utils.py:59 when an
+    entry is NaN/negative (check=False returns the matrix and the flag instead)."""
+    x, y = np.asarray(x), np.asarray(y)
+    assert (x.dtype == np.float64 and y.dtype == np.float64) or (
+        x.dtype == np.float32 and y.dtype == np.float32)
+    x, y = np.ascontiguousarray(x), np.ascontiguousarray(y)
     d = np.empty((x.shape[0], y.shape[0]), dtype=np.float64)
-    bad = lib().abn_oracle_cosine_distance_f32(_p(x), x.shape[0], _p(y),
-                                               y.shape[0], x.shape[1], _p(d))
+    fn = (lib().abn_oracle_cosine_distance_f32 if x.dtype == np.float32
+          else lib().abn_oracle_cosine_distance_f64)
+    bad = fn(_p(x), x.shape[0], _p(y), y.shape[0], x.shape[1], _p(d))
+    if not check:
+        return d, bool(bad)
     assert not bad, 'cosine_distance produced NaN / negative entries'
     return d
+
+
+def row_norms(x):
+    """np.sqrt(np.sum(x ** 2, axis=1)) for float32 rows, numpy's summation order."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return np.array([lib().abn_oracle_row_norm(_p(x[i:i + 1]), x.shape[1])
+                     for i in range(x.shape[0])], dtype=np.float32)
+
+
+def acosf_vs_libm(lo_bits, hi_bits, step=1):
+    """(# of float32 bit patterns in [lo, hi] (stride `step`) where the restated acosf
+    differs from this machine's libm, first such pattern)."""
+    first = ctypes.c_uint32(0)
+    n = lib().abn_oracle_acosf_vs_libm(lo_bits, hi_bits, step, ctypes.byref(first))
+    return int(n), int(first.value)
 
 
 def dtw_path(d):

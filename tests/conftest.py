@@ -10,8 +10,48 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+DP_JOB = {}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    # tests/test_gpu_dp.py needs two data-parallel ranks as FRESH processes.  A process
+    # that has initialised the GPU must not exec another program on these boxes, so the
+    # ranks are started HERE, before this (pytest) process has touched the card
+    # (torch.cuda.device_count() does not initialise it); the test joins them later.
+    expr = config.getoption('markexpr', default='') or ''
+    if 'gpu' in expr and 'not gpu' not in expr and os.environ.get('ABN_SKIP_DP_WORKERS') != '1':
+        try:
+            import torch
+            have_gpu = torch.cuda.device_count() > 0
+        except Exception:
+            have_gpu = False
+        if have_gpu:
+            import subprocess
+            import tempfile
+            out = os.path.join(tempfile.mkdtemp(prefix='abn_dp_'), 'res')
+            port = str(_free_port())
+            procs = []
+            for r in range(2):
+                log = open(out + '.rank%d.log' % r, 'w')
+                procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'),
+                                               str(r), '2', port, out], stdout=log, stderr=subprocess.STDOUT))
+            DP_JOB.update(procs=procs, out=out)
+
+
+def pytest_unconfigure(config):
+    for p in DP_JOB.get('procs', []):
+        if p.poll() is None:
+            p.kill()
 
 
 @pytest.fixture(params=['per_layer', 'fused'])

@@ -1,0 +1,97 @@
+"""One data-parallel rank of tests/test_gpu_dp.py: started as a FRESH process (by
+conftest.py, before the pytest process has touched the GPU), ranks share GPU 0 and
+talk over gloo -- the code path of an 8-GPU RCCL job with another transport.
+
+    python tests/dp_worker.py RANK WORLD PORT OUT_PREFIX
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import ast
+    import numpy as np
+    import torch
+    from abnet3_amd import parallel
+    import abnet3_amd.loss as L
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.trainer import TrainerSiamese
+    from abnet3_amd.dataloader import FramesDataLoader, OriginalDataLoader
+    from conftest import load_golden
+    parallel.init_from_env('gloo')
+    res = {}
+
+    # --- (1) the HIP trainer under a process group: each rank steps on its half of a
+    # 2B batch; the test compares with one process on the whole batch
+    g = load_golden('train_mid_bn0.npz')
+    kw = ast.literal_eval(str(g['kw']))
+    rng = np.random.default_rng(123)
+    B2 = 192
+    x1 = rng.standard_normal((B2, 40)).astype(np.float32)
+    x2 = rng.standard_normal((B2, 40)).astype(np.float32)
+    y = rng.choice([1.0, -1.0], B2)
+    half = B2 // world
+    sl = slice(rank * half, rank * half + half)
+    for avg in (False, True):
+        for oname, lr in (('adadelta', 0.1), ('sgd', 0.01)):
+            net = SiameseNetwork(output_path='/tmp/abn_dp_%d' % rank, **kw)
+            sd = {k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith('p.')}
+            if rank != 0:          # only rank 0 holds the real weights: the trainer must broadcast them
+                sd = {k: torch.zeros_like(v) for k, v in sd.items()}
+            net.load_state_dict(sd)
+            tr = TrainerSiamese(network=net, loss=L.coscos2(avg=avg), optimizer_type=oname, lr=lr,
+                                dataloader=None, log_dir='/tmp/abn_runs_dp')
+            assert tr.world_size == world
+            net.train()
+            batch = (torch.from_numpy(x1[sl]).cuda(), torch.from_numpy(x2[sl]).cuda(), torch.from_numpy(y[sl]).cuda())
+            losses = [float(tr.train_step(batch, True)) for _ in range(3)]
+            tag = 'avg%d.%s' % (int(avg), oname)
+            res[tag + '.losses'] = np.array(losses)
+            for k, p in net.named_parameters():
+                res[tag + '.p.' + k] = p.detach().cpu().numpy()
+
+    # --- (2) loaders shard themselves: disjoint, complete, one shared order
+    gl = load_golden('frames_loader.npz')
+    feats = {k[5:]: v for k, v in gl.items() if k.startswith('feat.')}
+    times = {k: np.arange(len(v)) * 0.01 + 0.0025 for k, v in feats.items()}
+
+    def parse(line):
+        t = str(line).split(' ')
+        return (t[0], float(t[1]), float(t[2]), t[3], float(t[4]), float(t[5]), t[6])
+    train = [parse(l) for l in gl['train_pairs']]
+    devp = [parse(l) for l in gl['dev_pairs']]
+    np.random.seed(1000 + rank)            # ranks start from DIFFERENT RNG states on purpose
+    dl = FramesDataLoader('unused', 'unused', batch_size=25)
+    dl.set_data(feats, times, train, devp)
+    for ep, mode in enumerate('TTD'):
+        ys, xs = [], []
+        for a, b, c in dl.batch_iterator(train_mode=(mode == 'T')):
+            xs.append(np.concatenate([a.cpu().numpy(), b.cpu().numpy()], axis=1))
+            ys.append(c.cpu().numpy())
+        res['frames.ep%d.x' % ep] = np.stack(xs) if xs else np.zeros((0, 25, 80), np.float32)
+        res['frames.ep%d.y' % ep] = np.stack(ys) if ys else np.zeros((0, 25), np.int64)
+    np.random.seed(2000 + rank)
+    ol = OriginalDataLoader('unused', 'unused', batch_size=2)
+    ol.set_data(feats, times, train, devp)
+    for ep, mode in enumerate('TD'):
+        sizes, firsts = [], []
+        for a, b, c in ol.batch_iterator(train_mode=(mode == 'T')):
+            sizes.append(len(c))
+            firsts.append(a[0].cpu().numpy())
+        res['words.ep%d.sizes' % ep] = np.array(sizes)
+        res['words.ep%d.first' % ep] = np.stack(firsts) if firsts else np.zeros((0, 40), np.float32)
+    np.savez(out + '.rank%d.npz' % rank, **res)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    print('dp worker %d done' % rank, flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -34,6 +34,23 @@ def _worker(rank, world, port, out):
     # round-robin sharding: same number of batches on every rank, disjoint
     mine = list(parallel.shard_batches(iter(range(7)), rank, world))
     ok &= mine == [rank, rank + world, rank + 2 * world]
+    # evaluation keeps the incomplete last group: rank 0 also gets batch 6
+    tail = list(parallel.shard_batches(iter(range(7)), rank, world, drop_tail=False))
+    ok &= tail == [rank, rank + world, rank + 2 * world] + ([6] if rank == 0 else [])
+    ids = np.arange(7)
+    ok &= list(parallel.shard_ids(ids, rank, world, equal=True)) == [rank, rank + 2, rank + 4]
+    ok &= list(parallel.shard_ids(ids, rank, world, equal=False)) == list(range(rank, 7, 2))
+    # rank 0's draw wins, whatever the local RNG state
+    np.random.seed(100 + rank)
+    perm = parallel.broadcast_array(np.random.permutation(11))
+    np.random.seed(100)
+    ok &= (perm == np.random.permutation(11)).all()
+    # variable-length exchange (the split DTW alignment's index lists)
+    parts = parallel.all_gather_varlen(torch.arange(3 + 4 * rank) + 100 * rank)
+    ok &= len(parts) == world and all(
+        torch.equal(parts[r], torch.arange(3 + 4 * r) + 100 * r) for r in range(world))
+    empty = parallel.all_gather_varlen(torch.zeros(0, dtype=torch.int64))
+    ok &= all(p.numel() == 0 for p in empty)
     flat = torch.full((64,), float(rank))
     parallel.broadcast_parameters(flat, src=0)
     ok &= bool((flat == 0).all())
@@ -66,3 +83,6 @@ def test_single_process_defaults():
     g = torch.ones(4)
     assert parallel.all_reduce_gradients(g, True) == 1.0 and bool((g == 1).all())
     assert list(parallel.shard_batches(iter(range(3)), 0, 1)) == [0, 1, 2]
+    assert list(parallel.shard_ids(np.arange(5), 0, 1, equal=True)) == [0, 1, 2, 3, 4]
+    assert (parallel.broadcast_array([3, 1, 2]) == [3, 1, 2]).all()
+    assert len(parallel.all_gather_varlen(torch.arange(4))) == 1

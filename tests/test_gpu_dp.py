@@ -1,0 +1,116 @@
+"""Data parallelism on real hardware without an 8-GPU node: two ranks (fresh processes
+started by conftest.py, sharing GPU 0, gloo transport) run the HIP trainer and the
+self-sharding loaders; this process computes what ONE process does with the whole
+batch / the whole epoch and compares.  Needs an MI355X: run with -m gpu."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+import conftest
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ranks():
+    job = conftest.DP_JOB
+    if not job:
+        pytest.skip('the data-parallel workers were not started (run with -m gpu on a GPU box)')
+    for r, p in enumerate(job['procs']):
+        try:
+            rc = p.wait(timeout=600)
+        except Exception:
+            p.kill()
+            rc = -9
+        log = open(job['out'] + '.rank%d.log' % r).read()
+        assert rc == 0, 'rank %d failed (%s):\n%s' % (r, rc, log[-3000:])
+    return [dict(np.load(job['out'] + '.rank%d.npz' % r)) for r in range(2)]
+
+
+@pytest.mark.parametrize('avg', [False, True])
+@pytest.mark.parametrize('oname,lr', [('adadelta', 0.1), ('sgd', 0.01)])
+def test_two_ranks_equal_one_process_on_the_full_batch(ranks, avg, oname, lr):
+    """avg=False: SUM all-reduce, no scaling; avg=True: each rank's loss is a mean over
+    its half, the reduced gradient is scaled by 1/2 inside the optimizer kernel.  After
+    3 steps both ranks hold the parameters of a single process stepping on all 192 pairs
+    (no BatchNorm: per-replica statistics would differ)."""
+    import abnet3_amd.loss as L
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.trainer import TrainerSiamese
+    g = load_golden('train_mid_bn0.npz')
+    kw = ast.literal_eval(str(g['kw']))
+    rng = np.random.default_rng(123)
+    x1 = rng.standard_normal((192, 40)).astype(np.float32)
+    x2 = rng.standard_normal((192, 40)).astype(np.float32)
+    y = rng.choice([1.0, -1.0], 192)
+    net = SiameseNetwork(output_path='/tmp/abn_dp_single', **kw)
+    net.load_state_dict({k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith('p.')})
+    tr = TrainerSiamese(network=net, loss=L.coscos2(avg=avg), optimizer_type=oname, lr=lr,
+                        dataloader=None, log_dir='/tmp/abn_runs_dp')
+    assert tr.world_size == 1
+    net.train()
+    batch = (torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), torch.from_numpy(y).cuda())
+    losses = [float(tr.train_step(batch, True)) for _ in range(3)]
+    tag = 'avg%d.%s' % (int(avg), oname)
+    both = [r[tag + '.losses'] for r in ranks]
+    total = (both[0] + both[1]) * (0.5 if avg else 1.0)
+    assert np.allclose(total, losses, rtol=2e-6), (total, losses)
+    for k, p in net.named_parameters():
+        mine = p.detach().cpu().numpy()
+        for r in ranks:
+            assert rel_err(r[tag + '.p.' + k], mine) < 1e-6, (k, rel_err(r[tag + '.p.' + k], mine))
+        assert (ranks[0][tag + '.p.' + k] == ranks[1][tag + '.p.' + k]).all()     # replicas stay bit-identical
+
+
+def _corpus():
+    gl = load_golden('frames_loader.npz')
+    feats = {k[5:]: v for k, v in gl.items() if k.startswith('feat.')}
+    times = {k: np.arange(len(v)) * 0.01 + 0.0025 for k, v in feats.items()}
+
+    def parse(line):
+        t = str(line).split(' ')
+        return (t[0], float(t[1]), float(t[2]), t[3], float(t[4]), float(t[5]), t[6])
+    return feats, times, [parse(l) for l in gl['train_pairs']], [parse(l) for l in gl['dev_pairs']]
+
+
+def test_frames_loader_shards_one_order_disjoint_and_complete(ranks):
+    """Ranks start from different numpy RNG states; rank 0's shuffles are broadcast, the
+    DTW work is split (each rank aligns every other 'same' pair and the index lists are
+    all-gathered), rank r takes batches r, r+2, ...  Interleaving the two ranks' batches
+    must give exactly the single-process epoch run from rank 0's seed."""
+    from abnet3_amd.dataloader import FramesDataLoader
+    feats, times, train, devp = _corpus()
+    np.random.seed(1000)
+    dl = FramesDataLoader('unused', 'unused', batch_size=25)
+    dl.set_data(feats, times, train, devp)
+    for ep, mode in enumerate('TTD'):
+        ref = [(np.concatenate([a.cpu().numpy(), b.cpu().numpy()], axis=1), c.cpu().numpy())
+               for a, b, c in dl.batch_iterator(train_mode=(mode == 'T'))]
+        n = [len(r['frames.ep%d.y' % ep]) for r in ranks]
+        if mode == 'T':
+            assert n[0] == n[1] == len(ref) // 2              # same number of steps on every rank
+        else:
+            assert n[0] + n[1] == len(ref)                    # the dev pass keeps its tail
+        for i in range(n[0] + n[1]):
+            r, k = i % 2, i // 2
+            assert (ranks[r]['frames.ep%d.y' % ep][k] == ref[i][1]).all(), (ep, i)
+            assert (ranks[r]['frames.ep%d.x' % ep][k] == ref[i][0]).all(), (ep, i)
+
+
+def test_word_pair_loader_shards_batches_by_rank(ranks):
+    from abnet3_amd.dataloader import OriginalDataLoader
+    feats, times, train, devp = _corpus()
+    np.random.seed(2000)
+    ol = OriginalDataLoader('unused', 'unused', batch_size=2)
+    ol.set_data(feats, times, train, devp)
+    for ep, mode in enumerate('TD'):
+        ref = [(len(c), a[0].cpu().numpy()) for a, b, c in ol.batch_iterator(train_mode=(mode == 'T'))]
+        n = [len(r['words.ep%d.sizes' % ep]) for r in ranks]
+        assert (n[0] == n[1] == len(ref) // 2) if mode == 'T' else (n[0] + n[1] == len(ref))
+        for i in range(n[0] + n[1]):
+            r, k = i % 2, i // 2
+            assert ranks[r]['words.ep%d.sizes' % ep][k] == ref[i][0]
+            assert (ranks[r]['words.ep%d.first' % ep][k] == ref[i][1]).all()

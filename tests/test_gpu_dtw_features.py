@@ -34,8 +34,88 @@ def test_cosine_distance_matches_reference_and_oracle(name):
     d = cosine_distance(g[name + '.x'], g[name + '.y'])
     assert d.dtype == np.float64
     assert (d == O.cosine_distance(g[name + '.x'], g[name + '.y'])).all()      # bit-exact
+    # this fixture was produced with numpy's AVX512 dispatch (SVML arccos, OpenBLAS's
+    # small-matrix sgemm): comparable to a few ulp of the cosine only
     ref = g[name + '.d']
     assert np.abs(np.cos(np.pi * d) - np.cos(np.pi * ref)).max() < 6e-7
+
+
+@pytest.mark.parametrize('name', ['big', 'bigpos', 'bigzero', 'bigdup', 'wide'])
+def test_cosine_distance_bit_exact_vs_reference_libm_path(name):
+    """G5L: outputs of the reference's cosine_distance on numpy's plain-libm path
+    (regular sgemm kernel): the HIP distance reproduces every cell bit for bit."""
+    from abnet3_amd.utils import cosine_distance
+    g = load_golden('cosdist_libm.npz')
+    if (name + '.dropped') in g:
+        with pytest.raises(AssertionError):
+            cosine_distance(g[name + '.x'], g[name + '.y'])
+        return
+    d = cosine_distance(g[name + '.x'], g[name + '.y'])
+    d32 = d.astype(np.float32)
+    assert (d32.astype(np.float64) == d).all()
+    assert (d32.view(np.uint32) == g[name + '.d32'].view(np.uint32)).all()
+
+
+def test_drop_decisions_agree_with_reference_pair_by_pair():
+    """48 near-duplicate token pairs through abn_dtw_batched (the tiled MFMA distance):
+    path_len == 0 exactly for the pairs the reference's cosine_distance refuses, and the
+    standalone distance of every kept pair equals the reference's, bit for bit."""
+    import hashlib
+    from abnet3_amd.utils import cosine_distance, dtw_align_batch
+    from test_oracle_dtw_features import _near_duplicate_pair
+    g = load_golden('cosdist_libm.npz')
+    drop, sha = g['near.dropped'], g['near.sha256']
+    xs, ys = zip(*[_near_duplicate_pair(p) for p in range(len(drop))])
+    f1 = torch.from_numpy(np.concatenate(xs)).cuda()
+    f2 = torch.from_numpy(np.concatenate(ys)).cuda()
+    n = np.array([len(x) for x in xs], dtype=np.int32)
+    off = np.concatenate(([0], np.cumsum(n)[:-1]))
+    res = dtw_align_batch(f1, off, n, f2, off, n)
+    ln = res.path_len.cpu().numpy()
+    assert ((ln == 0) == drop).all(), np.nonzero((ln == 0) != drop)[0]
+    for p in np.nonzero(~drop)[0]:
+        d = cosine_distance(xs[p], ys[p])
+        assert hashlib.sha256(d.astype(np.float32).tobytes()).hexdigest() == str(sha[p]), p
+
+
+def test_cosine_distance_float64_inputs():
+    """utils.py:41-42: float64 inputs are computed in float64 (G5 `f64`); mixed
+    precisions are refused like in the reference."""
+    from abnet3_amd.utils import cosine_distance
+    g = load_golden('cosdist.npz')
+    d = cosine_distance(g['f64.x'], g['f64.y'])
+    assert d.dtype == np.float64
+    assert np.abs(d - g['f64.d']).max() < 2e-15
+    with pytest.raises(AssertionError):
+        cosine_distance(g['f64.x'], g['f64.y'].astype(np.float32))
+
+
+def test_device_arccos_equals_libm_acosf():
+    """abn_arccos_f32 (the cell function's acosf) against the oracle's restatement of
+    glibc's acosf -- itself compared with libm for every float32 -- on every 61st
+    float32 of [-1, 1], all of the three range boundaries, and arguments outside."""
+    from abnet3_amd import _lib
+    from oracle import dtw_oracle as O
+    lib = _lib.load()
+    L = O.lib()
+    bits = np.concatenate([np.arange(0, 0x3f800100, 61, dtype=np.int64),
+                           np.arange(0x3effff00, 0x3f000100, dtype=np.int64),
+                           np.arange(0x3f7ffe00, 0x3f800100, dtype=np.int64),
+                           np.arange(0x32700000, 0x32900000, 997, dtype=np.int64)])
+    bits = np.concatenate([bits, bits + 0x80000000]).astype(np.uint32)
+    x = bits.view(np.float32)
+    xd = torch.from_numpy(x.copy()).cuda()
+    out = torch.empty_like(xd)
+    _lib.check(lib.abn_arccos_f32(_lib.ptr(xd), xd.numel(), _lib.ptr(out), _lib.stream()), 'abn_arccos_f32')
+    got = out.cpu().numpy()
+    import ctypes
+    L.abn_oracle_acosf_array.restype = None
+    L.abn_oracle_acosf_array.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    ref = np.empty_like(x)
+    L.abn_oracle_acosf_array(x.ctypes.data_as(ctypes.c_void_p), len(x), ref.ctypes.data_as(ctypes.c_void_p))
+    nan = np.isnan(ref)
+    assert (np.isnan(got) == nan).all()
+    assert (got.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all()
 
 
 def test_cosine_distance_nan_pair_is_refused():

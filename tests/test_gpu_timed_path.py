@@ -1,0 +1,219 @@
+"""The path bench.py times -- TrainerSiamese.train_step (autograd-free forward / fused
+loss+gradient / backward / abn_optimizer_step) and make_graphed_step -- against the
+numbers the REFERENCE produced (tests/golden, tools/make_golden.py): every
+optimizer_type of abnet3/trainer.py:68-87 on C1, and the C2 configuration of
+BASELINE.json (five Adadelta steps, full-tensor gradient checksums).
+Needs an MI355X: run with -m gpu."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, check_grads, check_params
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def cuda_net(g, seed=None, prefix='p.'):
+    from abnet3_amd.model import SiameseNetwork
+    kw = ast.literal_eval(str(g['kw']))
+    if seed is not None:
+        torch.manual_seed(seed)
+    net = SiameseNetwork(output_path='/tmp/abn_timed_path', **kw)
+    if prefix is not None:
+        net.load_state_dict({k[len(prefix):]: torch.from_numpy(v.copy()) for k, v in g.items()
+                             if k.startswith(prefix)})
+    return net.cuda(), kw
+
+
+def trainer(net, lname, avg, oname):
+    import abnet3_amd.loss as L
+    from abnet3_amd.trainer import TrainerSiamese, FlatOptimizer
+    lr = {'sgd': 0.001, 'adadelta': 0.1, 'adam': 0.001, 'adagrad': 0.001, 'RMSprop': 0.001}[oname]
+    tr = TrainerSiamese(network=net, loss=getattr(L, lname)(avg=bool(avg)), optimizer_type=oname, lr=lr,
+                        momentum=0.9, dataloader=None, log_dir='/tmp/abn_runs')
+    assert isinstance(tr.optimizer, FlatOptimizer) and tr._direct_ok()
+    return tr
+
+
+CASES_C1 = [(l, a, o) for l in ('coscos2', 'cosmargin') for a in (1, 0)
+            for o in ('sgd', 'adadelta')] + \
+           [('coscos2', 0, o) for o in ('adam', 'adagrad', 'RMSprop')]
+
+
+@pytest.mark.parametrize('bn', [0, 1])
+@pytest.mark.parametrize('lname,avg,oname', CASES_C1)
+@pytest.mark.parametrize('mode', ['eager', 'graph'])
+def test_c1_train_step_all_optimizers_vs_reference(bn, lname, avg, oname, mode):
+    """G2 (C1 = 40->100->50, B=32): three steps of the direct path + abn_optimizer_step
+    (sgd, adadelta, adam, adagrad, RMSprop) -- eager and replayed from a hipGraph --
+    against the reference's losses, first-step gradients and parameters after 3 steps."""
+    g = load_golden('train_c1_bn%d.npz' % bn)
+    net, kw = cuda_net(g)
+    tr = trainer(net, lname, avg, oname)
+    batch = (dev(g['x1']), dev(g['x2']), dev(g['y']))
+    tag = '%s.avg%d.%s' % (lname, avg, oname)
+    keys = [k for k, _ in net.named_parameters()]
+    net.train()
+    if mode == 'eager':
+        losses = [float(tr.train_step(batch, True))]
+        grads = {k: p.grad.cpu().numpy().copy() for k, p in net.named_parameters()}
+        check_grads(grads, {k: g['%s.grad0.%s' % (tag, k)] for k in keys}, keys, bool(bn))
+        assert net.grads_in_flat_buffer()
+        losses += [float(tr.train_step(batch, True)) for _ in range(2)]
+    else:
+        step = tr.make_graphed_step(batch, warmup=1)        # its warm-up step is step 1
+        losses = [float(step.warmup_loss)] + [float(step(batch)) for _ in range(2)]
+    assert tr.optimizer.step_count == 3
+    assert np.allclose(losses, g[tag + '.losses'], rtol=1e-5, atol=1e-6), (losses, g[tag + '.losses'])
+    params = {k: p.detach().cpu().numpy() for k, p in net.named_parameters()}
+    check_params(params, {k: g['%s.after.%s' % (tag, k)] for k in keys}, keys, bool(bn),
+                 1e-5 if oname in ('sgd', 'adadelta') else 3e-4)
+
+
+@pytest.mark.parametrize('bn', [0, 1])
+@pytest.mark.parametrize('mode', ['eager', 'graph'])
+def test_c2_timed_step_five_adadelta_steps_vs_reference(bn, mode):
+    """BASELINE.json configs[1] (40->500x2->100, coscos2(avg=False), B=4096, Adadelta 0.1)
+    through the stepper bench.py times.  Losses of 5 steps at 2e-5, full-tensor checksums
+    of the first-step gradients (`gchk`: sum, sum|.|, max|.|) and of the parameters after
+    the 5 steps (`after_chk`), all produced by the reference (tools/make_golden.py g4)."""
+    from oracle import torch_ref
+    g = load_golden('train_c2_bn%d.npz' % bn)
+    net, kw = cuda_net(g, seed=2, prefix=None)
+    for k, v in net.state_dict().items():
+        v = v.double().cpu()
+        assert np.allclose([float(v.sum()), float(v.abs().sum())], g['chk.' + k], rtol=1e-9), k
+    tr = trainer(net, 'coscos2', 0, 'adadelta')
+    batches = []
+    for s in range(2):
+        x1, x2, y = torch_ref.make_inputs(4096, 40, 20 + s)
+        batches.append((x1.cuda(), x2.cuda(), torch.from_numpy(y).cuda()))
+    net.train()
+
+    def check_first_gradient():
+        gmax = max(float(g['gchk.' + k][2]) for k, _ in net.named_parameters())
+        for k, q in net.named_parameters():
+            gg = q.grad.double().cpu()
+            ref_sum, ref_abs, ref_max = [float(v) for v in g['gchk.' + k]]
+            pre_bn_bias = bn and k.endswith('bias') and (k.endswith('.0.bias') or int(k.split('.')[1]) % 4 == 0)
+            if pre_bn_bias:        # mathematically zero, rounding noise on both sides
+                assert float(gg.abs().max()) <= 1e-4 * gmax, k
+                continue
+            # the reference's own fp32 gradient is 1e-5 .. 1.1e-4 away from an fp64
+            # evaluation at this initialisation: 3e-4 of the
+            # tensor's mass, and of its largest entry
+            assert abs(float(gg.abs().sum()) - ref_abs) <= 3e-4 * ref_abs, k
+            assert abs(float(gg.sum()) - ref_sum) <= 3e-4 * ref_abs, k
+            assert abs(float(gg.abs().max()) - ref_max) <= 3e-4 * max(ref_max, 1e-2 * gmax), k
+            assert rel_err(q.grad.cpu().numpy().reshape(q.shape[0], -1)[:4], g['grow.' + k], 1e-6) < 3e-4, k
+
+    if mode == 'eager':
+        losses = []
+        for s in range(5):
+            losses.append(float(tr.train_step(batches[s % 2], True)))
+            if s == 0:
+                check_first_gradient()
+    else:
+        step = tr.make_graphed_step(batches[0], warmup=1)     # its warm-up step is step 1
+        losses = [float(step.warmup_loss)] + [float(step(batches[s % 2])) for s in range(1, 5)]
+    assert np.allclose(losses, g['losses'], rtol=2e-5), (losses, g['losses'])
+    for k, v in net.state_dict().items():
+        if 'num_batches' in k or (bn and k.endswith('bias')) or 'running_mean' in k:
+            continue
+        v = v.double().cpu()
+        assert np.allclose([float(v.sum()), float(v.abs().sum())], g['after_chk.' + k],
+                           rtol=1e-4, atol=1e-3), k
+
+
+class _ListLoader(object):
+    def __init__(self, train, dev_batches):
+        self.train, self.dev = train, dev_batches
+
+    def batch_iterator(self, train_mode=True):
+        return iter(self.train if train_mode else self.dev)
+
+    def whoami(self):
+        return {'class_name': 'ListLoader'}
+
+
+@pytest.mark.parametrize('oname', ['adam', 'adadelta'])
+def test_auto_graph_with_interleaved_eager_steps_uses_fresh_gradients(oname):
+    """A replayed step whose optimizer launch is NOT captured (Adam: host-side bias
+    correction) must step on the gradient the replay just wrote, even when eager steps
+    of other batch shapes ran in between and re-pointed p.grad at their own buffer."""
+    import abnet3_amd.loss as L
+    from abnet3_amd.trainer import TrainerSiamese
+    g = load_golden('train_mid_bn0.npz')
+    rng = np.random.default_rng(17)
+
+    def batch(n):
+        return (dev(rng.standard_normal((n, 40)).astype(np.float32)),
+                dev(rng.standard_normal((n, 40)).astype(np.float32)), dev(rng.choice([1.0, -1.0], n)))
+    train = [batch(64) for _ in range(4)] + [batch(37)] + [batch(64), batch(21), batch(64), batch(64)]
+    out = []
+    for graph_steps in (False, True):
+        net, _ = cuda_net(g)
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=True), optimizer_type=oname, lr=0.01,
+                            dataloader=_ListLoader(train, [batch(30)]), log_dir='/tmp/abn_runs')
+        tr.graph_steps = graph_steps
+        tr.train_losses, tr.dev_losses = [], []
+        for _ in range(2):
+            tr.optimize_model(do_training=True)
+        assert (len(getattr(tr, '_graphs', {})) == 1) == graph_steps
+        out.append((tr.train_losses, {k: p.detach().cpu().numpy().copy() for k, p in net.state_dict().items()}))
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-6)
+    for k, v in out[1][1].items():
+        assert rel_err(v, out[0][1][k]) < 1e-6, k
+
+
+def test_save_whoami_pickles_the_reference_dictionary(tmp_path):
+    """TrainerBuilder.save_whoami (abnet3/trainer.py:106-108) pickles whoami(): the
+    network / loss / dataloader descriptions under the reference's keys."""
+    import pickle
+    import abnet3_amd.loss as L
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.trainer import TrainerSiamese
+    net = SiameseNetwork(input_dim=40, num_hidden_layers=1, hidden_dim=32, output_dim=16, p_dropout=0.0,
+                         activation_layer='sigmoid', output_path=str(tmp_path / 'network'))
+    tr = TrainerSiamese(network=net, loss=L.cosmargin(avg=False, margin=0.4), optimizer_type='adadelta', lr=0.1,
+                        dataloader=_ListLoader([], []), log_dir=str(tmp_path / 'runs'))
+    x = torch.randn(8, 40).cuda()
+    tr.train_step((x, x.flip(0), torch.ones(8).cuda()), True)          # HIP state exists by now
+    tr.save_whoami()
+    with open(str(tmp_path / 'network') + '.params', 'rb') as fh:
+        info = pickle.load(fh)
+    assert set(info) == {'params', 'network', 'loss', 'class_name', 'dataloader'}
+    assert info['class_name'] == 'TrainerSiamese' and info['network']['class_name'] == 'SiameseNetwork'
+    assert info['loss']['class_name'] == 'cosmargin' and info['loss']['params']['margin'] == 0.4
+    p = info['network']['params']
+    assert p['input_dim'] == 40 and p['hidden_dim'] == 32 and p['activation_layer'] == 'sigmoid'
+    assert not any(k in p for k in SiameseNetwork._HIP_STATE)
+    # the network still steps after having described itself, and a no-op .cuda() keeps
+    # the flat buffer (and with it the optimizer state) in place
+    flat_before = net.flat_parameters().data_ptr()
+    net.cuda()
+    assert net.flat_parameters().data_ptr() == flat_before
+    tr.train_step((x, x.flip(0), torch.ones(8).cuda()), True)
+
+
+def test_strided_inputs_are_accepted():
+    """The reference takes any tensor nn.Linear takes, e.g. a column slice of stacked
+    features (non-contiguous)."""
+    from abnet3_amd.model import SiameseNetwork
+    torch.manual_seed(0)
+    net = SiameseNetwork(input_dim=40, num_hidden_layers=0, hidden_dim=24, output_dim=8, p_dropout=0.0,
+                         activation_layer='tanh').cuda().eval()
+    wide = torch.randn(33, 280).cuda()
+    sl = wide[:, 120:160]
+    assert not sl.is_contiguous()
+    with torch.no_grad():
+        a = net.forward_once(sl)
+        b = net.forward_once(sl.contiguous())
+    assert torch.equal(a, b)

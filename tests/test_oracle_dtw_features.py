@@ -34,13 +34,87 @@ def test_cosine_distance_zero_rows_and_nan_drop():
         D.cosine_distance(g['pos.x'], g['pos.y'])
 
 
-def test_acosf_accuracy():
+def test_acosf_restatement_equals_libm():
+    """oracle/dtw.c restates glibc's acosf operation by operation; here every 257th
+    float32 of [-1, 1] and of a band outside (tools/acosf_exhaustive.py runs ALL of
+    them: 0 mismatches on this image's glibc 2.35)."""
+    for lo, hi in ((0x00000000, 0x3f800100), (0x80000000, 0xbf800100),
+                   (0x3effff00, 0x3f000100), (0x3f7fff00, 0x3f800000)):
+        n, first = D.acosf_vs_libm(lo, hi, 257 if hi - lo > 0x10000 else 1)
+        assert n == 0, hex(first)
     L = D.lib()
-    xs = np.concatenate([np.linspace(-1, 1, 20001), [1e-9, -1e-9, 0.5, -0.5, 0.49999997, 1.0, -1.0]])
+    xs = np.concatenate([np.linspace(-1, 1, 2001), [1e-9, -1e-9, 0.5, -0.5, 0.49999997, 1.0, -1.0]])
     got = np.array([L.abn_oracle_acosf(float(np.float32(x))) for x in xs])
     ref = np.arccos(xs.astype(np.float32).astype(np.float64))
-    assert np.abs(got - ref).max() < 5e-7        # < 2 float32 ulps of pi/2 (A&S 4.4.46 in binary32)
-    assert np.isnan(L.abn_oracle_acosf(1.0000001))
+    assert np.abs(got - ref).max() < 3e-7
+    assert np.isnan(L.abn_oracle_acosf(1.0000001)) and np.isnan(L.abn_oracle_acosf(-1.0000001))
+
+
+@pytest.mark.parametrize('Dm', [1, 3, 7, 8, 9, 13, 39, 40, 41, 127, 128, 129, 200, 280, 1000])
+def test_row_norms_follow_numpy_summation_order(Dm):
+    """x2 = np.sqrt(np.sum(x ** 2, axis=1)) (utils.py:43-44): numpy sums pairwise, and
+    the order changes the last bit in most rows -- the restatement must reproduce
+    numpy's own result exactly (numpy is the arbiter of its summation order)."""
+    rng = np.random.default_rng(Dm)
+    x = rng.standard_normal((64, Dm)).astype(np.float32)
+    assert (D.row_norms(x) == np.sqrt(np.sum(x ** 2, axis=1))).all()
+
+
+def _near_duplicate_pair(p):
+    # the generator of tools/make_golden.py (near_duplicate_pair), restated
+    rng = np.random.default_rng(5000 + p)
+    n = 176
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    if p % 3 == 2:
+        x = np.abs(x)
+    eps = [0.0, 3e-4, 6e-4, 8e-4, 1e-3, 1.3e-3, 2e-3, 4e-3][p % 8]
+    y = (x + np.float32(eps) * rng.standard_normal((n, 40)).astype(np.float32)).astype(np.float32)
+    if p % 16 >= 8:
+        y = (y * np.float32(1.0 + 0.37 * (p % 5))).astype(np.float32)
+    return x, y
+
+
+@pytest.mark.parametrize('name', ['big', 'bigpos', 'bigzero', 'bigdup', 'wide'])
+def test_cosine_distance_bit_exact_vs_reference_on_libm_path(name):
+    """G5L: the reference's cosine_distance run with numpy on its plain-libm path, on
+    matrices that take OpenBLAS's regular sgemm kernel: every cell bit for bit."""
+    g = load_golden('cosdist_libm.npz')
+    d, bad = D.cosine_distance(g[name + '.x'], g[name + '.y'], check=False)
+    ref = g[name + '.d32']
+    if (name + '.dropped') in g:
+        assert bad                      # the reference raised AssertionError
+        return
+    assert not bad
+    d32 = d.astype(np.float32)
+    assert (d32.astype(np.float64) == d).all()
+    assert (d32.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def test_drop_decisions_agree_with_reference_pair_by_pair():
+    """48 near-duplicate token pairs: which ones the reference drops (cos rounds above 1
+    -> arccos NaN -> AssertionError, utils.py:59, dataloader.py:188-191) and, for the
+    kept ones, every distance bit (sha256 of the float32 matrix)."""
+    import hashlib
+    g = load_golden('cosdist_libm.npz')
+    drop, sha = g['near.dropped'], g['near.sha256']
+    assert 10 < drop.sum() < len(drop) - 10
+    for p in range(len(drop)):
+        x, y = _near_duplicate_pair(p)
+        assert [float(x.astype(np.float64).sum()), float(y.astype(np.float64).sum())] == list(g['near.in_chk'][p])
+        d, bad = D.cosine_distance(x, y, check=False)
+        assert bad == bool(drop[p]), p
+        if not bad:
+            assert hashlib.sha256(d.astype(np.float32).tobytes()).hexdigest() == str(sha[p]), p
+
+
+def test_cosine_distance_float64_inputs():
+    """utils.py:41-42: float64 inputs are computed in float64 (G5 `f64`)."""
+    g = load_golden('cosdist.npz')
+    d = D.cosine_distance(g['f64.x'], g['f64.y'])
+    assert d.dtype == np.float64
+    assert np.abs(d - g['f64.d']).max() < 1e-15
+    with pytest.raises(AssertionError):
+        D.cosine_distance(g['f64.x'], g['f64.y'].astype(np.float32))
 
 
 def test_dtw_c_matches_python_restatement():

@@ -21,6 +21,15 @@ Fixture sets:
   G8 multitask_*  SiameseMultitaskNetwork + weighted_loss_multi: forward (eval,
                   train), every gradient, params after 3 steps; and the speaker
                   labels of load_frames_from_pairs(fid2spk=...)
+  G5L cosdist_libm  abnet3.utils.cosine_distance with numpy on its plain-libm path
+                  (NPY_DISABLE_CPU_FEATURES drops numpy's AVX512/SVML arccos; the
+                  generator re-runs itself in a child process with that variable) on
+                  matrices large enough for OpenBLAS's regular sgemm kernel: what the
+                  oracle and the HIP kernel reproduce bit for bit, plus the per-pair
+                  drop decisions (AssertionError) for near-duplicate tokens
+  G9 frames_loader  FramesDataLoader.load_all_frames / load_batch / batch_iterator
+                  (shuffles, batch slicing, max_batches_per_epoch wrap-around) and
+                  OriginalDataLoader.add_tcl_to_batch / temporal_coherence_loss
 
 usage: python tools/make_golden.py [--only G1,G3]
 """
@@ -504,9 +513,162 @@ def g8_multitask(abnet3):
     np.savez_compressed(os.path.join(OUT, 'multitask_frames.npz'), **out)
 
 
+NO_AVX512 = 'AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL'
+
+
+def near_duplicate_pair(p):
+    """Token pair p of the drop-decision set: 176 x 40 frames (M*N*K > 10^6, the
+    regular sgemm kernel), the second token = the first plus noise of a size that
+    puts cos(x_i, y_i) within a few ulp of 1.  Regenerated from the seed by the tests
+    (numpy's PCG64 stream); `in_chk` in the fixture guards against a drifted stream."""
+    rng = np.random.default_rng(5000 + p)
+    n = 176
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    if p % 3 == 2:
+        x = np.abs(x)                            # filterbank-like: all cosines > 0.5
+    eps = [0.0, 3e-4, 6e-4, 8e-4, 1e-3, 1.3e-3, 2e-3, 4e-3][p % 8]
+    y = (x + np.float32(eps) * rng.standard_normal((n, 40)).astype(np.float32)).astype(np.float32)
+    if p % 16 >= 8:
+        y = (y * np.float32(1.0 + 0.37 * (p % 5))).astype(np.float32)   # same direction, other norm
+    return x, y
+
+
+def g5l_cosdist_libm(abnet3):
+    """G5L: cosine_distance on numpy's libm path (see the module docstring)."""
+    import hashlib
+    if os.environ.get('NPY_DISABLE_CPU_FEATURES') != NO_AVX512:
+        import subprocess
+        env = dict(os.environ, NPY_DISABLE_CPU_FEATURES=NO_AVX512)
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), '--only', 'G5L'], env=env)
+        return
+    rng = np.random.default_rng(55)
+    out = {}
+    cases = {}
+    cases['big'] = (rng.standard_normal((300, 40)).astype(np.float32),
+                    rng.standard_normal((280, 40)).astype(np.float32))
+    pos = np.abs(rng.standard_normal((530, 40))).astype(np.float32)
+    cases['bigpos'] = (pos[:260], pos[260:])
+    z = rng.standard_normal((290, 40)).astype(np.float32)
+    w = rng.standard_normal((270, 40)).astype(np.float32)
+    z[5] = 0; z[77] = 0; w[0] = 0; w[200] = 0
+    cases['bigzero'] = (z, w)
+    z2, w2 = z.copy(), w.copy()
+    w2[13] = -2.0 * z2[13]                          # cos = -1 up to rounding
+    w2[14] = 0.5 * z2[14]                           # cos = +1 up to rounding
+    cases['bigdup'] = (z2, w2)
+    wide = rng.standard_normal((190, 280)).astype(np.float32)   # stacked 7 x 40 features
+    cases['wide'] = (wide[:100], wide[100:])
+    for name, (x, y) in cases.items():
+        out[name + '.x'], out[name + '.y'] = x, y
+        try:
+            d = abnet3.utils.cosine_distance(x, y)
+            d32 = d.astype(np.float32)
+            assert (d32.astype(np.float64) == d).all()      # float32 values in a float64 container
+            out[name + '.d32'] = d32
+        except AssertionError:
+            out[name + '.d32'] = np.zeros((0, 0), dtype=np.float32)
+            out[name + '.dropped'] = np.array(True)
+    P = 48
+    dropped, hashes, in_chk = [], [], []
+    for p in range(P):
+        x, y = near_duplicate_pair(p)
+        in_chk.append([float(x.astype(np.float64).sum()), float(y.astype(np.float64).sum())])
+        try:
+            d = abnet3.utils.cosine_distance(x, y)
+            dropped.append(False)
+            hashes.append(hashlib.sha256(d.astype(np.float32).tobytes()).hexdigest())
+        except AssertionError:
+            dropped.append(True)
+            hashes.append('')
+    out['near.dropped'] = np.array(dropped)
+    out['near.sha256'] = np.array(hashes)
+    out['near.in_chk'] = np.array(in_chk)
+    print('   near-duplicate pairs dropped by the reference: %d of %d' % (sum(dropped), P))
+    np.savez_compressed(os.path.join(OUT, 'cosdist_libm.npz'), **out)
+
+
+def g9_frames_loader(abnet3):
+    """G9: FramesDataLoader (dataloader.py:580-739) and the temporal coherence pairs
+    of OriginalDataLoader (:314-352), with a fake accessor and the build's oracle DTW
+    standing in for the absent third-party dtw.DTW (as in G7)."""
+    import random
+    sys.path.insert(0, REPO)
+    from oracle import dtw_oracle
+    rng = np.random.default_rng(9)
+    feats = {'u%d' % i: rng.standard_normal((n, 40)).astype(np.float32)
+             for i, n in enumerate((90, 70, 120, 64, 100))}
+    times = {k: (np.arange(len(v)) * 0.01 + 0.0025) for k, v in feats.items()}
+
+    def oracle_align(f1, f2):
+        d = abnet3.utils.cosine_distance(f1, f2)
+        p1, p2 = dtw_oracle.dtw_path(d)
+        return list(p1), list(p2)
+
+    abnet3.dataloader.get_dtw_alignment = oracle_align
+    train = [('u0', 0.10, 0.42, 'u1', 0.05, 0.31, 'same'),
+             ('u2', 0.50, 0.93, 'u3', 0.11, 0.37, 'same'),
+             ('u0', 0.33, 0.61, 'u2', 0.70, 1.05, 'diff'),
+             ('u1', 0.20, 0.21, 'u3', 0.30, 0.46, 'diff'),   # 1-frame token
+             ('u3', 0.40, 0.30, 'u1', 0.10, 0.20, 'same'),   # s > e: skipped
+             ('u1', 0.02, 0.29, 'u4', 0.31, 0.64, 'same'),
+             ('u4', 0.05, 0.44, 'u2', 0.15, 0.50, 'same'),
+             ('u4', 0.60, 0.95, 'u0', 0.45, 0.85, 'diff'),
+             ('u3', 0.02, 0.30, 'u4', 0.50, 0.80, 'diff')]
+    dev = [('u0', 0.50, 0.80, 'u3', 0.20, 0.52, 'same'),
+           ('u1', 0.30, 0.55, 'u2', 0.20, 0.41, 'diff'),
+           ('u2', 0.02, 0.33, 'u4', 0.20, 0.49, 'same')]
+    out = {'train_pairs': np.array([' '.join(map(str, p)) for p in train]),
+           'dev_pairs': np.array([' '.join(map(str, p)) for p in dev])}
+    for k, v in feats.items():
+        out['feat.' + k] = v
+
+    cases = {   # name: (ctor kwargs, numpy seed, sequence of epochs: T(rain) / D(ev))
+        'full': (dict(batch_size=50, randomize_dataset=True), 9, 'TTDT'),
+        'norand': (dict(batch_size=64, randomize_dataset=False), 10, 'TDT'),
+        'sub': (dict(batch_size=40, randomize_dataset=True, max_batches_per_epoch=2), 11, 'TTTDTTT'),
+        'tiny': (dict(batch_size=5000, randomize_dataset=True), 12, 'TD'),   # fewer pairs than one batch
+    }
+    for name, (kw, seed, epochs) in cases.items():
+        acc = abnet3.utils.Features_Accessor(dict(times), {k: v.copy() for k, v in feats.items()})
+        dl = abnet3.dataloader.FramesDataLoader('unused', 'unused', **kw)
+        dl.features = acc
+        dl.pairs = {'train': list(train), 'dev': list(dev)}
+        np.random.seed(seed)
+        X1s, X2s, Ys, sizes, nb = [], [], [], [], []
+        for mode in epochs:
+            n = 0
+            for X1, X2, y in dl.batch_iterator(train_mode=(mode == 'T')):
+                X1s.append(X1.numpy()); X2s.append(X2.numpy()); Ys.append(y.numpy())
+                sizes.append(len(y))
+                n += 1
+            nb.append(n)
+        out[name + '.kw'] = np.array(repr(kw))
+        out[name + '.seed'] = np.array(seed)
+        out[name + '.epochs'] = np.array(epochs)
+        out[name + '.X1'] = np.vstack(X1s)
+        out[name + '.X2'] = np.vstack(X2s)
+        out[name + '.y'] = np.concatenate(Ys)
+        out[name + '.sizes'] = np.array(sizes)
+        out[name + '.batches_per_epoch'] = np.array(nb)
+        out[name + '.n_frame_pairs'] = np.array([len(dl.frame_pairs['train']), len(dl.frame_pairs['dev'])])
+
+    # temporal coherence pairs added to a word-pair batch (tcl = 0.3)
+    acc = abnet3.utils.Features_Accessor(dict(times), {k: v.copy() for k, v in feats.items()})
+    dl = abnet3.dataloader.OriginalDataLoader('unused', 'unused', tcl=0.3)
+    dl.features = acc
+    dl.train_files = ['u0', 'u2', 'u3', 'u4']       # explicit order (the reference builds it from a set)
+    batch = dl.load_frames_from_pairs(abnet3.utils.group_pairs(train[:4]))
+    random.seed(4)
+    X1, X2, Y = dl.add_tcl_to_batch(batch)
+    out['tcl.train_files'] = np.array(dl.train_files)
+    out['tcl.n_before'] = np.array(len(batch[2]))
+    out['tcl.X1'], out['tcl.X2'], out['tcl.Y'] = X1, X2, Y
+    np.savez_compressed(os.path.join(OUT, 'frames_loader.npz'), **out)
+
+
 ALL = {'G1': g1_tower, 'G2': g2_train_c1, 'G3': g3_loss_edge,
        'G4': g4_train_mid, 'G5': g5_cosdist, 'G6': g6_stack, 'G7': g7_frames,
-       'G8': g8_multitask}
+       'G8': g8_multitask, 'G5L': g5l_cosdist_libm, 'G9': g9_frames_loader}
 
 
 def main():
