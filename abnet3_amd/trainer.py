@@ -18,6 +18,7 @@ Differences, all on purpose:
     train_losses / dev_losses.
 """
 import copy
+import gc
 import pickle
 import time
 import warnings
@@ -353,12 +354,23 @@ class TrainerSiamese(TrainerBuilder):
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         steps_before = getattr(opt, 'step_count', 0)
-        with torch.cuda.graph(graph):
-            loss_value = fwd_loss()
-            opt.zero_grad()
-            self._backward(loss_value)
-            if capture_opt:
-                opt.step()
+        # No cyclic garbage collection while the stream is capturing: a collector run
+        # started by the allocations below may finalise an OLD trainer's CUDAGraph (its
+        # step closure and the trainer reference each other), whose destructor frees
+        # device memory -- not permitted during capture, and fatal inside a destructor.
+        # torch.cuda.graph() collects once before it begins capturing.
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(graph):
+                loss_value = fwd_loss()
+                opt.zero_grad()
+                self._backward(loss_value)
+                if capture_opt:
+                    opt.step()
+        finally:
+            if gc_was_enabled:
+                gc.enable()
         if capture_opt:
             opt.step_count = steps_before        # capturing recorded the launch, it did not run it
         static_loss = loss_value.detach()

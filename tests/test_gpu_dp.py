@@ -61,7 +61,10 @@ def test_two_ranks_equal_one_process_on_the_full_batch(ranks, avg, oname, lr):
     for k, p in net.named_parameters():
         mine = p.detach().cpu().numpy()
         for r in ranks:
-            assert rel_err(r[tag + '.p.' + k], mine) < 1e-6, (k, rel_err(r[tag + '.p.' + k], mine))
+            # 1e-6 of the tensor's scale; the biases start at zero and are still ~1e-5
+            # after three steps, so they are judged against the weights' scale (0.05)
+            e = rel_err(r[tag + '.p.' + k], mine, floor=0.05)
+            assert e < 1e-6, (k, e)
         assert (ranks[0][tag + '.p.' + k] == ranks[1][tag + '.p.' + k]).all()     # replicas stay bit-identical
 
 
