@@ -42,9 +42,8 @@ __device__ __forceinline__ float sumsq_block(const float* __restrict__ v, int n)
 
 // the whole recursion (n > 128 splits at n/2 rounded down to a multiple of 8), written
 // with an explicit stack: depth <= 16 covers every D the ABI accepts (< 2^20)
-__device__ inline float sumsq_numpy(const float* __restrict__ v, int n)
+__device__ __noinline__ float sumsq_numpy_split(const float* __restrict__ v, int n)
 {
-    if (n <= 128) return sumsq_block(v, n);
     int off[20], len[20], state[20];
     float left[20];
     int sp = 0;
@@ -73,6 +72,11 @@ __device__ inline float sumsq_numpy(const float* __restrict__ v, int n)
         }
     }
     return ret;
+}
+
+__device__ __forceinline__ float sumsq_numpy(const float* __restrict__ v, int n)
+{
+    return n <= 128 ? sumsq_block(v, n) : sumsq_numpy_split(v, n);      // (the stack of the split form lives in scratch)
 }
 
 __device__ __forceinline__ float row_norm_numpy(const float* __restrict__ v, int n) { return sqrtf(sumsq_numpy(v, n)); }

@@ -51,351 +51,326 @@ namespace abn {
 struct PairMeta {
     int64_t off1, off2;      // first row of each token in feats1 / feats2
     int32_t n1, n2;
-    int64_t ws_off;          // float offset of this pair's S4 region
-    int64_t dir_off;         // byte offset of this pair's packed back-pointers
-    int32_t tile0;           // first tile id of this pair (dist kernel)
-    int32_t tiles_n;         // tiles along j
-    int32_t slots;           // SL: rows per DP lane (the pair's size class)
-    int32_t groups;          // ceil((n1 + n2 - 1) / 4) groups of four anti-diagonals
+    int64_t dir_off;         // dword offset of this pair's packed back-pointers
+    int64_t tmp_off;         // int32 offset of this pair's reversed-path scratch
+    int32_t nbands;          // ceil(n1 / 32): bands of 32 rows
+    int32_t nrounds;         // ceil((n2 + 31) / 32): 32-diagonal rounds per band
 };
 
-constexpr int TS = 64;       // distance tile
-
-// tile id -> pair id table, filled on the device from the per-pair tile ranges
-__global__ void expand_tiles_kernel(const PairMeta* __restrict__ meta, int npairs, int32_t* __restrict__ tile_pair)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npairs) return;
-    const PairMeta m = meta[p];
-    const int tm = (m.n1 + TS - 1) / TS, tn = (m.n2 + TS - 1) / TS;
-    for (int t = 0; t < tm * tn; ++t) tile_pair[m.tile0 + t] = p;
-}
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int TSP = TS + 4;  // padded tile row: float4 rows of the MFMA layout land on distinct LDS banks
-constexpr int KC = 40;       // k chunk staged in LDS (the 40-d filterbank frame in one piece)
-constexpr int KCP = KC + 4;  // padded: 16-byte row reads of 8 consecutive rows hit 32 distinct banks
-
-// One 64x64 tile of a pair's distance matrix per workgroup, one 32x32 quadrant
-// per wavefront.  The dot products run on the matrix cores: a float32 MFMA
-// (v_mfma_f32_32x32x2_f32, k = 2s + lane/32) accumulates each cell as ONE
-// sequential fused chain over k, bit-identical to the oracle's fmaf loop
-// (tools/mfma_exact_probe.hip: 0 mismatches in 204 800 cells), which leaves the
-// vector ALU to the acos epilogue -- the part that bounds this kernel.
-// Rows are staged through LDS with coalesced 16-byte loads (a token's rows are
-// contiguous), and the tile's row norms are recomputed from the staged rows (40
-// fmas per row: cheaper than a separate pass over the corpus).  A = rows of y (j), B = rows of x (i): a lane then holds one i and runs of four
-// consecutive j, which go to LDS as float4s and leave in DP order.
-#ifdef ABN_DIST_STAMPS      // diagnostic build only (tools/dist_stamps.py): cycles per phase, summed over blocks
-__device__ unsigned long long g_dist_cycles[8];
-#define DSTAMP() do { if (threadIdx.x == 0) tk[nk++] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define DSTAMP() do {} while (0)
-#endif
-
-__global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ feats1, const float* __restrict__ feats2,
-                                                   const PairMeta* __restrict__ meta, const int32_t* __restrict__ tile_pair,
-                                                   int ntiles, int D, int vec, float* __restrict__ ws,
-                                                   int32_t* __restrict__ bad)
-{
-    // x / y row chunks [64][KC] for the MFMA loop; the finished tile reuses the space
-    __shared__ __attribute__((aligned(16))) float smem[2 * TS * KCP];
-    __shared__ float nx_s[TS], ny_s[TS];
-    static_assert(2 * TS * KCP >= TS * TSP, "the distance tile must fit in the staging buffers");
-    float (*xs)[KCP] = reinterpret_cast<float (*)[KCP]>(smem);
-    float (*ys)[KCP] = reinterpret_cast<float (*)[KCP]>(smem + TS * KCP);
-    float* tile = smem;
-#ifdef ABN_DIST_STAMPS
-    unsigned long long tk[8];
-    int nk = 0;
-#endif
-    DSTAMP();
-    // XCD-aware order: workgroups b, b+8, b+16, ... share an XCD and its L2, so XCD x takes
-    // the contiguous tile range [x*G/8, (x+1)*G/8): the tiles of one pair (consecutive ids)
-    // then run on ONE XCD and re-read their x / y rows from its L2 instead of HBM
-    // (round-robin order: 4.4 GB fetched for 1 GB of features).
-    const int tile_id = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    if (tile_id >= ntiles) return;
-    const int p = tile_pair[tile_id];
-    const PairMeta m = meta[p];
-    const int t = tile_id - m.tile0;
-    const int i0 = (t / m.tiles_n) * TS, j0 = (t % m.tiles_n) * TS;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int ib = 32 * (wave >> 1), jb = 32 * (wave & 1);        // this wave's quadrant
-    // rows past the token end are clamped: their cells are computed and discarded
-    const float* xbase = feats1 + m.off1 * D;
-    const float* ybase = feats2 + m.off2 * D;
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-    for (int k0 = 0; k0 < D; k0 += KC) {
-        const int kn = min(KC, D - k0);
-        if (vec) {                                // 16-byte loads; a token's rows are contiguous in memory
-            for (int u = threadIdx.x; u < 2 * TS * (KC / 4); u += 256) {
-                const int which = u >= TS * (KC / 4), v = u - which * TS * (KC / 4);
-                const int row = v / (KC / 4), c4 = (v % (KC / 4)) * 4;
-                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c4 < kn) {
-                    const float* src = which ? ybase + (int64_t)min(j0 + row, m.n2 - 1) * D : xbase + (int64_t)min(i0 + row, m.n1 - 1) * D;
-                    q = *reinterpret_cast<const float4*>(src + k0 + c4);
-                }
-                *reinterpret_cast<float4*>(which ? &ys[row][c4] : &xs[row][c4]) = q;
-            }
-        } else {
-            for (int u = threadIdx.x; u < 2 * TS * KC; u += 256) {
-                const int which = u >= TS * KC, v = u - which * TS * KC;
-                const int row = v / KC, c = v % KC;
-                float q = 0.0f;
-                if (c < kn) q = which ? ybase[(int64_t)min(j0 + row, m.n2 - 1) * D + k0 + c] : xbase[(int64_t)min(i0 + row, m.n1 - 1) * D + k0 + c];
-                (which ? ys : xs)[row][c] = q;
-            }
-        }
-        __syncthreads();
-        DSTAMP();                                 // (D <= KC: one trip) operands staged
-        // the chunk is zero-filled past kn, and fma(0, 0, acc) == acc exactly, so
-        // whole float4 groups can be consumed; k still ascends one at a time
-        // the tile's 64 + 64 row norms, np.sqrt(np.sum(x ** 2, axis=1)) in numpy's pairwise
-        // order: from the staged rows when a frame fits one chunk (the 40-d case), else below
-        if (wave < 2 && D <= KC) (wave == 0 ? nx_s : ny_s)[lane] = row_norm_numpy(wave == 0 ? xs[lane] : ys[lane], D);
-        for (int k = 0; k < kn; k += 4) {
-            const float4 yq = *reinterpret_cast<const float4*>(&ys[jb + r][k]);
-            const float4 xq = *reinterpret_cast<const float4*>(&xs[ib + r][k]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? yq.y : yq.x, h ? xq.y : xq.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? yq.w : yq.z, h ? xq.w : xq.z, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    DSTAMP();                                     // norms + MFMA + barrier
-    if (wave < 2 && D > KC)                       // wide frames: the summation order spans the chunks, read the row itself
-        (wave == 0 ? nx_s : ny_s)[lane] = wave == 0 ? row_norm_numpy(xbase + (int64_t)min(i0 + lane, m.n1 - 1) * D, D)
-                                                      : row_norm_numpy(ybase + (int64_t)min(j0 + lane, m.n2 - 1) * D, D);
-    __syncthreads();                              // the norms are staged
-    DSTAMP();
-    const int i = i0 + ib + r;
-    const float nx = nx_s[ib + r];
-    // zero rows are rare: tiles without one skip their handling
-    const bool zero_rows = __any(nx_s[lane] == 0.0f || ny_s[lane] == 0.0f);
-    bool any_bad = false;
-    auto epilogue = [&](auto zr) {
-#pragma unroll
-        for (int qg = 0; qg < 4; ++qg) {
-            const int jl = jb + 8 * qg + 4 * h;   // MFMA rows 8*qg + 4*h + (0..3)
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = angular_distance_ref<decltype(zr)::value>(acc[4 * qg + e], nx, ny_s[jl + e]);
-                const bool valid = i < m.n1 && j0 + jl + e < m.n2;
-                any_bad |= valid && !(d >= 0.0f);     // utils.py:59 assert
-                v[e] = valid ? d : 0.0f;
-            }
-            *reinterpret_cast<float4*>(&tile[(ib + r) * TSP + jl]) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    };
-    if (zero_rows) epilogue(std::true_type{}); else epilogue(std::false_type{});
-    if (any_bad) atomicOr(&bad[p], 1);
-    __syncthreads();
-    DSTAMP();                                     // acos epilogue
-    // write-out in DP order: one float4 = row i on the four diagonals of group g
-    // (cells j = 4g - i .. 4g - i + 3); a wave takes one group, lanes take rows
-    {
-        const int SL = m.slots;
-        const int i = i0 + lane;
-        const int iend = min(i0 + TS, m.n1) - 1, jend = min(j0 + TS, m.n2) - 1;
-        const int64_t gstride = (int64_t)64 * SL;                 // float4s per group
-        float4* S4 = reinterpret_cast<float4*>(ws + m.ws_off) + (i % SL) * 64 + i / SL;
-        for (int g = ((i0 + j0) >> 2) + wave; g <= ((iend + jend) >> 2); g += 4) {
-            const int jl = 4 * g - i - j0;                        // tile column of element 0
-            if (i > iend || jl + 3 < 0 || jl > jend - j0) continue;
-            float* dst = reinterpret_cast<float*>(S4 + g * gstride);
-            const float* src = &tile[lane * TSP + jl];
-            if (jl >= 0 && jl + 3 <= jend - j0) {
-                *reinterpret_cast<float4*>(dst) = make_float4(src[0], src[1], src[2], src[3]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (jl + e >= 0 && jl + e <= jend - j0) dst[e] = src[e];
-            }
-        }
-    }
-    DSTAMP();                                     // write-out issued
-#ifdef ABN_DIST_STAMPS
-    if (threadIdx.x == 0) {
-        for (int q = 1; q < nk && q < 8; ++q) atomicAdd(&g_dist_cycles[q], tk[q] - tk[q - 1]);
-        atomicAdd(&g_dist_cycles[0], 1ull);
-    }
-#endif
-}
-
-constexpr int DP_MAXN = 1024;        // longest first token a wavefront can sweep (16 rows per lane)
-constexpr int DP_CLASSES[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};      // rows per lane the DP is instantiated for
-constexpr int DP_NCLASSES = sizeof(DP_CLASSES) / sizeof(int);
-constexpr int WIN = 16;              // traceback window: 16 groups (64 diagonals) x 64 rows
-constexpr int DP_WAVES = 4;          // pairs (wavefronts) per DP workgroup
+constexpr int BAND = 32;     // rows of token 1 a lane-half sweeps at once (one row per lane)
+constexpr int KCH = 40;      // k processed per MFMA chain segment (the 40-d filterbank frame in one piece)
+constexpr int KST = KCH / 2; // v_mfma_f32_32x32x2_f32 steps per segment
 
 // back-pointer codes
 enum { DIR_DIAG = 0, DIR_UP = 1, DIR_LEFT = 2 };
 
-static inline int dp_class_of(int n1)
+struct DtwP {
+    const float* feats1;
+    const float* feats2;
+    const PairMeta* meta;
+    const int32_t* order;        // work queue: pair ids, largest first
+    int32_t* counter;            // next queue position (zeroed by the host call)
+    int32_t npairs;
+    int32_t D;
+    uint32_t* dirs;              // 2-bit back-pointers, 16 diagonals per dword: [pair][band][16-diag group][32 rows]
+    double* bound;               // band boundary rows: [slot][2][mcap] accumulated costs of a band's last row
+    int64_t mcap;
+    int32_t* bad;                // [pair] set when a distance is NaN / negative (utils.py:59)
+    double* total_cost;          // [pair] or NULL
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// lane l receives lane l-1's value (lanes 0 and 32 are overridden by the caller)
+__device__ __forceinline__ double wave_shr1(double v)
 {
-    const int need = (std::max(n1, 1) + 63) / 64;
-    for (int c = 0; c < DP_NCLASSES; ++c)
-        if (DP_CLASSES[c] >= need) return c;
-    return DP_NCLASSES - 1;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);      // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
 
-// LDS hand-off inside ONE wavefront: its LDS operations complete in order, so draining
-// them (and keeping the compiler from moving accesses across) is all that is needed
+__device__ __forceinline__ int64_t readlane64(int64_t v, int l)
+{
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// LDS hand-off inside ONE wavefront: its LDS operations complete in order, so keeping the
+// compiler from moving accesses across is all that is needed
 __device__ __forceinline__ void wave_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
 
-// lane l receives lane l-1's value (lane 0: lane 63's)
-__device__ __forceinline__ double rotate_up(double v, int src_lane) { return __shfl(v, src_lane, 64); }
-
-template <int SL>
-__global__ __launch_bounds__(64 * DP_WAVES) void dp_kernel(const PairMeta* __restrict__ meta, const int32_t* __restrict__ order,
-                                                int npairs, float* __restrict__ ws, uint8_t* __restrict__ dirs,
-                                                const int32_t* __restrict__ bad, int32_t* __restrict__ path1,
-                                                int32_t* __restrict__ path2, int32_t* __restrict__ path_len,
-                                                int64_t path_stride, double* __restrict__ total_cost)
+// MFMA operand fragment of one row for k in [k0, k0 + 40): element t = row[k0 + 2t + h]
+// (h = lane / 32), zero past D -- fma(0, 0, acc) == acc exactly, so padding never shows
+template <bool VEC>
+__device__ __forceinline__ void load_frag(float* __restrict__ f, const float* __restrict__ row, int k0, int D, int h)
 {
-    // DP_WAVES independent pairs per workgroup, one per wavefront (so the waves land on
-    // different SIMDs); nothing below synchronises across waves
-    __shared__ uint8_t win_all[DP_WAVES][WIN][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if ((int)blockIdx.x * DP_WAVES + wave >= npairs) return;
-    uint8_t (*win)[64] = win_all[wave];
-    const int p = order[blockIdx.x * DP_WAVES + wave];
-    const PairMeta m = meta[p];
-    const int N = m.n1, M = m.n2;
-    if (N <= 0 || M <= 0 || bad[p]) {
-        if (lane == 0) { path_len[p] = 0; if (total_cost) total_cost[p] = 0.0; }
-        return;
-    }
-    constexpr int64_t GS = 64 * SL;               // rows (float4s / bytes) per group
-    const float4* S4 = reinterpret_cast<const float4*>(ws + m.ws_off) + lane;
-    uint8_t* Dr = dirs + m.dir_off;
-    const int G = m.groups, row0 = lane * SL;
-    const double INF = __builtin_inf();
-    double p1[SL], p2[SL];                        // rows row0 + c on diagonals d-1, d-2
-    float4 nxt[SL];
+    if (VEC) {
 #pragma unroll
-    for (int c = 0; c < SL; ++c) {
-        p1[c] = INF; p2[c] = INF;
-        nxt[c] = S4[c * 64];                      // rows >= N are allocated (never written, never used)
-    }
-    bool row_ok[SL];
-#pragma unroll
-    for (int c = 0; c < SL; ++c) {
-        row_ok[c] = row0 + c < N;
-        // consume the first group here: otherwise the loop header inherits "loads pending" from
-        // this edge and waits for ALL memory operations, the back-pointer stores included, every trip
-        asm volatile("" ::"v"(nxt[c].x), "v"(nxt[c].y), "v"(nxt[c].z), "v"(nxt[c].w));
-    }
-    const int src = (lane + 63) & 63;
-    // group g holds diagonals 4g .. 4g+3; diagonal d holds cells (i, d - i)
-    for (int g = 0; g < G; ++g) {
-        float4 cur[SL];
-#pragma unroll
-        for (int c = 0; c < SL; ++c) cur[c] = nxt[c];
-        {   // prefetch the next group a whole group (four steps) ahead.  Unconditional (the
-            // last iteration re-reads its own group): a guard equal to the loop condition
-            // lets the compiler sink the loads into the latch, right in front of their use.
-            const int gn = min(g + 1, G - 1);
-#pragma unroll
-            for (int c = 0; c < SL; ++c) nxt[c] = S4[gn * GS + c * 64];
+        for (int q = 0; q < KST / 2; ++q) {
+            const int k = k0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < D) v = *reinterpret_cast<const float4*>(row + k);          // D % 4 == 0 on this path
+            f[2 * q] = h ? v.y : v.x;
+            f[2 * q + 1] = h ? v.w : v.z;
         }
-        uint32_t bits[SL];
+    } else {
 #pragma unroll
-        for (int c = 0; c < SL; ++c) bits[c] = 0u;
+        for (int t = 0; t < KST; ++t) {
+            const int k = k0 + 2 * t + h;
+            f[t] = k < D ? row[k] : 0.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The whole alignment of a pair in one kernel, the cost matrix never leaves the CU:
+//
+//  * one wavefront per workgroup; its two lane-halves are two independent SLOTS, each
+//    sweeping one token pair at a time (pairs come from a work queue, largest first);
+//  * a slot walks its pair in BANDS of 32 rows of token 1 (one row per lane) and, inside a
+//    band, in ROUNDS of 32 anti-diagonals.  A round first PRODUCES the 32 x 32 block of
+//    distances of the next 32 columns -- 20 v_mfma_f32_32x32x2_f32 on the fp32 matrix
+//    cores (one sequential fma chain per cell = the reference's sgemm), then the
+//    reference's division / acosf / pi per cell on all 64 lanes (dist_ref.h) -- and drops
+//    it into a 64-diagonal ring in LDS, diagonal-major (row = (i + j) & 63, column = row
+//    of the band: conflict-free both ways).  Then the slot's 32 lanes SWEEP 32
+//    anti-diagonals of float64 costs: cost = d + min(diag, up, left), first minimum in
+//    that order wins; the previous two diagonals live in registers, the neighbour row
+//    comes over a DPP wave shift, the row above the band (the previous band's last row)
+//    through a small LDS window of a per-slot scratch row;
+//  * HBM sees the features once per band (L2), 2 bits per cell of back-pointers
+//    (16 diagonals per dword, [band][group][row]: 128-byte stores) and the band boundary
+//    rows: ~0.3 B per cell.  Tokens of any length.
+//
+// The produce phase is throughput code on all 64 lanes, the sweep a dependency chain on
+// 32 + 32: co-resident wavefronts (8 per CU at this LDS footprint) interleave the two.
+// ---------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(64) void dtw_fused_kernel(DtwP P)
+{
+    __shared__ __attribute__((aligned(16))) float ring[2][64][BAND];
+    __shared__ __attribute__((aligned(16))) float ny_s[2][BAND];
+    __shared__ double top_s[2][BAND];
+    __shared__ double bot_s[2][2 * BAND];
+    const int lane = threadIdx.x, half = lane >> 5, n = lane & 31;
+    const int D = P.D;
+    const double INF = __builtin_inf();
+    const int slot = 2 * (int)blockIdx.x + half;
+    double* const bnd = P.bound + (int64_t)slot * 2 * P.mcap;
+
+    // slot state, uniform inside a lane-half
+    int pair = -1, N = 0, M = 0, nbands = 0, nrounds = 0, band = 0, u = 0;
+    int64_t xoff = 0, yoff = 0, dir_off = 0;
+    bool exhausted = false;
+    // sweep state, per lane (= per row of the band)
+    double p1 = INF, p2 = INF, topprev = INF;
+    float xf[2][KST];                      // x fragments of both slots' bands (D <= 40: loaded once per band)
+    float nx[2] = {0.0f, 0.0f};
+    int anybad[2] = {0, 0};
+
+    for (;;) {
+        // ---- work queue: a slot without a pair takes the next one
+        {
+            const bool need = pair < 0 && !exhausted;
+            int idx = -1;
+            if (need && n == 0) idx = atomicAdd(P.counter, 1);
+            idx = __shfl(idx, half * 32);
+            if (need) {
+                if (idx < P.npairs) {
+                    pair = P.order[idx];
+                    const PairMeta m = P.meta[pair];
+                    N = m.n1; M = m.n2; nbands = m.nbands; nrounds = m.nrounds;
+                    xoff = m.off1 * D; yoff = m.off2 * D; dir_off = m.dir_off;
+                    band = 0; u = 0;
+                    p1 = INF; p2 = INF; topprev = 0.0;       // the virtual cell (-1, -1) costs 0
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (!__any(pair >= 0)) break;
+        const bool active = pair >= 0;
+        const int i0 = band * BAND, j0 = u * BAND;
+
+        // the band's boundary row above: this round's 32 columns of the previous band's last row
+        double topv = INF;
+        if (active && band > 0 && j0 + n < M)
+            topv = __hip_atomic_load(&bnd[(int64_t)((band & 1) ^ 1) * P.mcap + j0 + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+        // ---- produce: distances of columns j0 .. j0+31 for both slots, all 64 lanes
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int d = 4 * g + e;
-            // row row0 - 1: the previous lane's last row; row -1 is +inf except the virtual (-1,-1) = 0
-            double rot1 = rotate_up(p1[SL - 1], src), rot2 = rotate_up(p2[SL - 1], src);
-            if (lane == 0) { rot1 = INF; rot2 = d == 0 ? 0.0 : INF; }
+        for (int q = 0; q < 2; ++q) {
+            const int src = 32 * q;
+            const int q_pair = __builtin_amdgcn_readlane(pair, src);
+            const int qM = __builtin_amdgcn_readlane(M, src), qN = __builtin_amdgcn_readlane(N, src);
+            const int qj0 = __builtin_amdgcn_readlane(j0, src), qi0 = __builtin_amdgcn_readlane(i0, src);
+            const int qu = __builtin_amdgcn_readlane(u, src);
+            if (q_pair < 0 || qj0 >= qM) continue;                         // wave-uniform
+            const float* xb = P.feats1 + readlane64(xoff, src);
+            const float* yb = P.feats2 + readlane64(yoff, src);
+            const float* xrow = xb + (int64_t)min(qi0 + n, qN - 1) * D;    // rows past the token end are clamped:
+            const float* yrow = yb + (int64_t)min(qj0 + n, qM - 1) * D;    // their cells are computed and never used
+            if (qu == 0) nx[q] = row_norm_numpy(xrow, D);                  // np.sqrt(np.sum(x ** 2, axis=1)), numpy's order
+            if (half == 0) ny_s[q][n] = row_norm_numpy(yrow, D);
+            f32x16 acc;
 #pragma unroll
-            for (int c = SL - 1; c >= 0; --c) {   // descending: p1[c-1], p2[c-1] still hold the old diagonals
-                const double up = c ? p1[c - 1] : rot1;       // (i-1, j)   on diagonal d-1
-                const double dg = c ? p2[c - 1] : rot2;       // (i-1, j-1) on diagonal d-2
-                const double left = p1[c];                    // (i, j-1)   on diagonal d-1
-                // straight-line selects (no divergent branches): first minimum in the order diag, up, left
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int k0 = 0; k0 < D; k0 += KCH) {
+                float yf[KST];
+                if (D > KCH || qu == 0) load_frag<VEC>(xf[q], xrow, k0, D, half);
+                load_frag<VEC>(yf, yrow, k0, D, half);
+#pragma unroll
+                for (int t = 0; t < KST; ++t)                               // A = token 2 rows (j), B = token 1 rows (i)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[t], xf[q][t], acc, 0, 0, 0);
+            }
+            wave_lds_sync();                                               // ny_s is staged
+            // accumulator r of lane (n, h) is cell (row i0 + n, column j0 + m), m = (r & 3) + 8 (r >> 2) + 4 h
+            const float nxl = nx[q];
+            const bool zero_rows = __any(nxl == 0.0f || ny_s[q][n] == 0.0f);
+            const bool rowok = qi0 + n < qN;
+            bool bad = false;
+            auto epilogue = [&](auto zr) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 ny4 = *reinterpret_cast<const float4*>(&ny_s[q][8 * g + 4 * half]);
+                    const float nyv[4] = {ny4.x, ny4.y, ny4.z, ny4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = 8 * g + 4 * half + e;
+                        const float d = angular_distance_ref<decltype(zr)::value>(acc[4 * g + e], nxl, nyv[e]);
+                        bad |= rowok && qj0 + m < qM && !(d >= 0.0f);      // utils.py:59 assert
+                        ring[q][(qj0 + m + n) & 63][n] = d;
+                    }
+                }
+            };
+            if (zero_rows) epilogue(std::true_type{}); else epilogue(std::false_type{});
+            anybad[q] |= __any(bad) ? 1 : 0;
+        }
+        // boundary window: the row above the band for this round's 32 diagonals
+        top_s[half][n] = topv;
+        wave_lds_sync();
+
+        // ---- sweep: 32 anti-diagonals; lane n owns row i0 + n, at diagonal s its column is s - n
+        {
+            const float* rg = &ring[half][(u & 1) * BAND][n];             // diagonal 32 u + e lives in ring row (32 u + e) & 63
+            const int sbase = j0;                                          // band-local diagonal of step 0
+            const bool rowok = active && i0 + n < N;
+            const bool feed_next = active && band + 1 < nbands;             // the last row feeds the next band
+            const bool last_lane = n == BAND - 1 && feed_next;
+            uint32_t* dptr = P.dirs + dir_off + ((int64_t)(band * 2 * nrounds + 2 * u) * BAND + n);
+            for (int e16 = 0; e16 < BAND; e16 += 16) {
+            uint32_t bits = 0u;
+#pragma unroll
+            for (int ee = 0; ee < 16; ++ee) {
+                const int e = e16 + ee;
+                const int j = sbase + e - n;
+                const float dist = rg[e * BAND];
+                const double topc = top_s[half][e];
+                double up = wave_shr1(p1), dg = wave_shr1(p2);
+                if (n == 0) { up = topc; dg = topprev; topprev = topc; }
+                const double left = p1;
+                // straight-line selects: first minimum in the order diag, up, left
                 const bool take_up = up < dg;
                 const double b1 = take_up ? up : dg;
                 const bool take_left = left < b1;
                 const double best = take_left ? left : b1;
                 const uint32_t dir = take_left ? (uint32_t)DIR_LEFT : take_up ? (uint32_t)DIR_UP : (uint32_t)DIR_DIAG;
-                const float dist = e == 0 ? cur[c].x : e == 1 ? cur[c].y : e == 2 ? cur[c].z : cur[c].w;
                 const double cost = (double)dist + best;
-                // cell (row0 + c, d - row0 - c) exists?  rows never reached keep +inf: that is the boundary condition
-                const bool on = row_ok[c] && (uint32_t)(d - row0 - c) < (uint32_t)M;
-                p2[c] = left;
-                p1[c] = on ? cost : left;
-                bits[c] |= on ? dir << (2 * e) : 0u;
+                const bool on = rowok && (uint32_t)j < (uint32_t)M;
+                p2 = left;
+                p1 = on ? cost : left;                                     // past the row's end the last cost stays put
+                bits |= on ? dir << (2 * ee) : 0u;
+                if (last_lane && on) bot_s[half][j & 63] = cost;
+            }
+            if (active) dptr[(e16 >> 4) * BAND] = bits;
+            }
+            wave_lds_sync();
+            // the band's last row, for the band below: block u-1 of 32 columns is complete now
+            if (feed_next) {
+                double* dst = bnd + (int64_t)(band & 1) * P.mcap;
+                if (u >= 1) {
+                    const int j = (u - 1) * BAND + n;
+                    if (j < M) __hip_atomic_store(&dst[j], bot_s[half][j & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (u == nrounds - 1) {
+                    const int j = u * BAND + n;
+                    if (j < M) __hip_atomic_store(&dst[j], bot_s[half][j & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
-#pragma unroll
-        for (int c = 0; c < SL; ++c) Dr[g * GS + c * 64 + lane] = (uint8_t)bits[c];
-    }
-    if (total_cost) {                             // p1 of row N-1 still holds cell (N-1, M-1)
-        double last = 0.0;
-#pragma unroll
-        for (int c = 0; c < SL; ++c)
-            if (c == (N - 1) % SL) last = p1[c];
-        last = __shfl(last, (N - 1) / SL, 64);
-        if (lane == 0) total_cost[p] = last;
-    }
-    // The back-pointers were stored by THIS wavefront and are read back by it: its stores
-    // only have to be complete (the vector L1 is write-through, and no line of this region
-    // was ever loaded before).  An agent-scope fence would write the XCD's whole L2 back
-    // -- per pair -- and made short pairs several times slower.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
 
-    // traceback.  The distances are dead now: their region takes the reversed path.
-    int32_t* tmp = reinterpret_cast<int32_t*>(ws + m.ws_off);
-    int i = N - 1, j = M - 1, k = 0;
-    if (lane == 0) { tmp[0] = i; tmp[1] = j; }
-    while (i > 0 || j > 0) {                      // wave-uniform
-        const int gh = (i + j) >> 2, rlo = i - 63;
-        const int r = rlo + lane;
-        const int phys = r >= 0 ? (r % SL) * 64 + r / SL : 0;
-#pragma unroll
-        for (int q = 0; q < WIN; ++q) {
-            const int gq = gh - q;
-            win[q][lane] = (r >= 0 && gq >= 0) ? Dr[gq * GS + phys] : (uint8_t)0;
-        }
-        wave_lds_sync();
-        if (lane == 0) {
-            while ((i > 0 || j > 0) && i >= rlo && ((i + j) >> 2) > gh - WIN) {
-                const int d = i + j;
-                const int dir = (win[gh - (d >> 2)][i - rlo] >> (2 * (d & 3))) & 3;
-                if (dir == DIR_DIAG) { --i; --j; } else if (dir == DIR_UP) --i; else --j;
-                ++k;
-                tmp[2 * k] = i;
-                tmp[2 * k + 1] = j;
+        // ---- advance the slot
+        if (active) {
+            ++u;
+            if (u == nrounds) {
+                u = 0;
+                ++band;
+                if (band == nbands) {
+                    // lane (N-1) % 32 still holds cost(N-1, M-1)
+                    if (P.total_cost && n == ((N - 1) & 31)) P.total_cost[pair] = p1;
+                    if (n == 0 && (half ? anybad[1] : anybad[0])) P.bad[pair] = 1;
+                    pair = -1;
+                }
+                p1 = INF; p2 = INF; topprev = INF;
             }
         }
-        i = __shfl(i, 0, 64);
-        j = __shfl(j, 0, 64);
-        k = __shfl(k, 0, 64);
-        wave_lds_sync();
+        // The boundary row of a finished band is re-read by this same wavefront: its stores are
+        // write-through (sc1) and only have to be complete; the loads bypass the L1 (sc1).  An
+        // agent-scope release would write the XCD's whole L2 back, once per band.
+        if (__any(active && u == 0)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+        // a slot that finished its pair: its bad flag starts afresh with the next pair
+        if (__builtin_amdgcn_readlane(pair, 0) < 0) anybad[0] = 0;
+        if (__builtin_amdgcn_readlane(pair, 32) < 0) anybad[1] = 0;
     }
-    // lane 0's stores are complete; the loads below bypass the L1 (which may still hold
-    // the distances that lived in these lines)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
+}
+
+// Walks the back-pointers of one pair from (N-1, M-1) to (0, 0) and writes the path start -> end.
+// One thread per pair: the walk is a chain of dependent 4-byte loads (L1 / L2 hits: a step moves
+// at most one row and two diagonals), a few hundred steps.
+__global__ void dtw_traceback_kernel(const PairMeta* __restrict__ meta, int npairs, const uint32_t* __restrict__ dirs,
+                                     const int32_t* __restrict__ bad, int32_t* __restrict__ tmp,
+                                     int32_t* __restrict__ path1, int32_t* __restrict__ path2,
+                                     int32_t* __restrict__ path_len, int64_t path_stride, double* __restrict__ total_cost)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    const PairMeta m = meta[p];
+    const int N = m.n1, M = m.n2;
+    if (N <= 0 || M <= 0 || bad[p]) {
+        path_len[p] = 0;
+        if (total_cost) total_cost[p] = 0.0;
+        return;
+    }
+    const uint32_t* dp = dirs + m.dir_off;
+    int32_t* t = tmp + m.tmp_off;
+    const int nsg = 2 * m.nrounds;
+    int i = N - 1, j = M - 1, k = 0;
+    t[0] = i; t[1] = j;
+    while (i > 0 || j > 0) {
+        const int b = i >> 5, r = i & 31, s = j + r;
+        const uint32_t w = dp[(int64_t)(b * nsg + (s >> 4)) * BAND + r];
+        const int dir = (w >> (2 * (s & 15))) & 3;
+        if (dir == DIR_DIAG) { --i; --j; } else if (dir == DIR_UP) --i; else --j;
+        ++k;
+        t[2 * k] = i;
+        t[2 * k + 1] = j;
+    }
     const int len = k + 1;
     int32_t* o1 = path1 + (int64_t)p * path_stride;
     int32_t* o2 = path2 + (int64_t)p * path_stride;
-    for (int t = lane; t < len; t += 64) {
-        o1[t] = __hip_atomic_load(&tmp[2 * (len - 1 - t)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        o2[t] = __hip_atomic_load(&tmp[2 * (len - 1 - t) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q = 0; q < len; ++q) {
+        o1[q] = t[2 * (len - 1 - q)];
+        o2[q] = t[2 * (len - 1 - q) + 1];
     }
-    if (lane == 0) path_len[p] = len;
+    path_len[p] = len;
 }
 
 // plain [N, M] float64 distance matrix of one pair (abn_cosine_distance)
@@ -447,91 +422,60 @@ __global__ void arccos_kernel(const float* __restrict__ x, int64_t n, float* __r
 }
 
 struct WsPlan {
-    int64_t meta_off, tilepair_off, order_off, bad_off, dist_off, dirs_off, total;
-    int64_t total_tiles, dist_floats;
+    int64_t meta_off, order_off, bad_off, counter_off, dirs_off, bound_off, tmp_off, total;
+    int64_t mcap;
+    int32_t nwg;
 };
 
 }  // namespace abn
 
 using namespace abn;
 
-// Side streams for the DP size classes, one set per device, created on first use.
-constexpr int N_SIDE = 4;
-struct SideStreams {
-    std::mutex mu;              // the fork / join events are shared by all callers
-    hipStream_t s[N_SIDE];
-    hipEvent_t fork, join[N_SIDE];
-    bool ok = false;
-};
-static SideStreams* side_streams()
-{
-    static SideStreams per_device[16];
-    static std::mutex init_mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideStreams& ss = per_device[dev];
-    std::lock_guard<std::mutex> g(init_mu);
-    if (!ss.ok) {
-        bool good = hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess;
-        for (int q = 0; q < N_SIDE && good; ++q)
-            good = hipStreamCreateWithFlags(&ss.s[q], hipStreamNonBlocking) == hipSuccess &&
-                   hipEventCreateWithFlags(&ss.join[q], hipEventDisableTiming) == hipSuccess;
-        if (!good) { (void)hipGetLastError(); return nullptr; }
-        ss.ok = true;
-    }
-    return &ss;
-}
-
-// S4 rows of one pair: groups x 64 x SL (float4s for the distances, bytes for the back-pointers)
-static inline int64_t pair_rows(int64_t a, int64_t b)
-{
-    if (a <= 0 || b <= 0) return 0;
-    return ((a + b - 1 + 3) / 4) * 64 * DP_CLASSES[dp_class_of((int)a)];
-}
-
-// Workspace: [PairMeta x P][tile->pair x tiles][order x P][bad x P][S4 dist f32][dirs u8]
-static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P, int64_t rows1, int64_t rows2)
+// Workspace: [PairMeta x P][order x P][bad x P][queue counter][back-pointers][boundary rows][reversed paths]
+static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P)
 {
     WsPlan w;
-    int64_t tiles = 0, rows = 0;
+    int64_t dwords = 0, tmp = 0, mmax = 1;
     for (int64_t p = 0; p < P; ++p) {
         const int64_t a = n1[p] > 0 ? n1[p] : 0, b = n2[p] > 0 ? n2[p] : 0;
-        tiles += ((a + TS - 1) / TS) * ((b + TS - 1) / TS);
-        rows += pair_rows(a, b);
+        if (a > 0 && b > 0) {
+            dwords += ((a + BAND - 1) / BAND) * 2 * ((b + 2 * BAND - 1) / BAND) * BAND;
+            tmp += 2 * (a + b);
+            mmax = b > mmax ? b : mmax;
+        }
     }
+    w.mcap = align_up(mmax, 32);
+    // persistent grid: one wavefront per workgroup, two pairs in flight per wavefront, up to 9
+    // wavefronts per CU (LDS); fewer when the boundary rows of that many slots would outgrow 256 MiB
+    int64_t nwg = (P + 1) / 2;
+    if (nwg > 256 * 9) nwg = 256 * 9;
+    const int64_t cap = (256LL << 20) / (4 * w.mcap * 8);
+    if (nwg > cap) nwg = cap < 1 ? 1 : cap;
+    if (nwg < 1) nwg = 1;
+    w.nwg = (int32_t)nwg;
     int64_t o = 0;
     auto take = [&](int64_t bytes) { int64_t r = o; o += align_up(bytes, 256); return r; };
     w.meta_off = take(P * (int64_t)sizeof(PairMeta));
-    w.tilepair_off = take(tiles * 4);
     w.order_off = take(P * 4);
     w.bad_off = take(P * 4);
-    w.dist_off = take(rows * 16);
-    w.dirs_off = take(rows);
+    w.counter_off = take(4);
+    w.dirs_off = take(dwords * 4);
+    w.bound_off = take(2 * nwg * 2 * w.mcap * 8);
+    w.tmp_off = take(tmp * 4);
     w.total = o;
-    w.total_tiles = tiles;
-    w.dist_floats = rows * 4;
     return w;
 }
-
-#ifdef ABN_DIST_STAMPS
-extern "C" int abn_debug_dist_cycles(unsigned long long* out8)
-{
-    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(abn::g_dist_cycles), 64) == hipSuccess ? 0 : -1;
-}
-#endif
 
 extern "C" int64_t abn_dtw_ws_bytes(const int32_t* n1_host, const int32_t* n2_host, int64_t npairs,
                                          int64_t rows1, int64_t rows2)
 {
     if (!n1_host || !n2_host || npairs < 0 || rows1 < 0 || rows2 < 0) return -1;
-    return plan_ws(n1_host, n2_host, npairs, rows1, rows2).total;
+    return plan_ws(n1_host, n2_host, npairs).total;
 }
 
 extern "C" int64_t abn_dtw_host_stage_bytes(const int32_t* n1_host, const int32_t* n2_host, int64_t npairs)
 {
     if (!n1_host || !n2_host || npairs < 0) return -1;
-    const WsPlan w = plan_ws(n1_host, n2_host, npairs, 0, 0);
-    (void)w;
     return align_up(npairs * (int64_t)sizeof(PairMeta), 256) + align_up(npairs * 4, 256);
 }
 
@@ -542,23 +486,24 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
                                     void* ws, int64_t ws_bytes, void* host_stage, int64_t host_stage_bytes,
                                     void* stream)
 {
-    ABN_REQUIRE(npairs >= 0 && D >= 1 && D < (1 << 20), "dtw: bad npairs/D");
+    ABN_REQUIRE(npairs >= 0 && npairs < (1LL << 31) && D >= 1 && D < (1 << 20), "dtw: bad npairs/D");
     if (npairs == 0) return ABN_OK;
     ABN_REQUIRE(feats1 && feats2 && off1_host && n1_host && off2_host && n2_host && path1 && path2 && path_len && ws &&
                     host_stage,
                 "dtw: null pointer");
-    int32_t maxlen = 0;
+    int64_t maxlen = 0;
     for (int64_t p = 0; p < npairs; ++p) {
         ABN_REQUIRE(n1_host[p] >= 0 && n2_host[p] >= 0, "dtw: negative token length at pair %lld", (long long)p);
-        ABN_REQUIRE(n1_host[p] <= DP_MAXN, "dtw: token of %d frames exceeds the %d-frame limit", n1_host[p], DP_MAXN);
         ABN_REQUIRE(off1_host[p] >= 0 && off1_host[p] + n1_host[p] <= rows1 && off2_host[p] >= 0 &&
                         off2_host[p] + n2_host[p] <= rows2,
                     "dtw: pair %lld reads outside the feature arrays", (long long)p);
-        const int32_t need = n1_host[p] + n2_host[p] - 1;
+        const int64_t need = (int64_t)n1_host[p] + n2_host[p] - 1;
         maxlen = need > maxlen ? need : maxlen;
     }
-    ABN_REQUIRE(path_stride >= maxlen, "dtw: path_stride %lld < longest possible path %d", (long long)path_stride, maxlen);
-    const WsPlan w = plan_ws(n1_host, n2_host, npairs, rows1, rows2);
+    ABN_REQUIRE(path_stride >= maxlen, "dtw: path_stride %lld < longest possible path %lld", (long long)path_stride,
+                (long long)maxlen);
+    ABN_REQUIRE(rows1 * D < (1LL << 62) && rows2 * D < (1LL << 62), "dtw: feature array too large");
+    const WsPlan w = plan_ws(n1_host, n2_host, npairs);
     if (ws_bytes < w.total) { set_error("dtw: workspace too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)w.total); return ABN_E_WORKSPACE; }
     const int64_t meta_bytes = align_up(npairs * (int64_t)sizeof(PairMeta), 256);
     if (host_stage_bytes < meta_bytes + align_up(npairs * 4, 256)) { set_error("dtw: host staging buffer too small"); return ABN_E_WORKSPACE; }
@@ -567,107 +512,63 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
     char* base = (char*)ws;
     PairMeta* hm = (PairMeta*)host_stage;
     int32_t* hord = (int32_t*)((char*)host_stage + meta_bytes);
-    int64_t tiles = 0, rows = 0;
-    int64_t class_count[DP_NCLASSES] = {};
+    int64_t dwords = 0, tmp = 0;
     for (int64_t p = 0; p < npairs; ++p) {
         const int64_t a = n1_host[p], b = n2_host[p];
-        const int64_t tm = (a + TS - 1) / TS, tn = (b + TS - 1) / TS;
-        const int cls = dp_class_of((int)a);
         hm[p].off1 = off1_host[p]; hm[p].off2 = off2_host[p];
         hm[p].n1 = (int32_t)a; hm[p].n2 = (int32_t)b;
-        hm[p].ws_off = rows * 4;
-        hm[p].dir_off = rows;
-        hm[p].tile0 = (int32_t)tiles;
-        hm[p].tiles_n = (int32_t)(tn > 0 ? tn : 1);
-        hm[p].slots = DP_CLASSES[cls];
-        hm[p].groups = (int32_t)((a + b - 1 + 3) / 4);
-        tiles += tm * tn;
-        rows += pair_rows(a, b);
-        ++class_count[cls];
+        hm[p].dir_off = dwords;
+        hm[p].tmp_off = tmp;
+        hm[p].nbands = (int32_t)((a + BAND - 1) / BAND);
+        hm[p].nrounds = (int32_t)((b + 2 * BAND - 1) / BAND);
+        if (a > 0 && b > 0) {
+            dwords += (int64_t)hm[p].nbands * 2 * hm[p].nrounds * BAND;
+            tmp += 2 * (a + b);
+        }
     }
-    // DP launch order: by size class, longest sweep first inside a class (the short ones fill
-    // the tail).  One integer key per pair: class | inverted length | index.
+    // Work queue: largest pairs first (the short ones fill the tail), empty pairs never queued.
+    int64_t nq = 0;
     {
-        std::vector<uint64_t> keys((size_t)npairs);
+        std::vector<uint64_t> keys;
+        keys.reserve((size_t)npairs);
         for (int64_t p = 0; p < npairs; ++p) {
-            const uint64_t len = (uint64_t)n1_host[p] + (uint64_t)n2_host[p];
-            keys[p] = ((uint64_t)dp_class_of(n1_host[p]) << 58) | ((((uint64_t)1 << 26) - 1 - std::min<uint64_t>(len, (1u << 26) - 1)) << 32) |
-                      (uint64_t)p;
+            if (n1_host[p] <= 0 || n2_host[p] <= 0) continue;
+            const uint64_t work = (uint64_t)hm[p].nbands * (uint64_t)hm[p].nrounds;       // rounds the pair needs
+            keys.push_back(((~std::min<uint64_t>(work, 0xffffffffu) & 0xffffffffu) << 32) | (uint64_t)p);
         }
         std::sort(keys.begin(), keys.end());
-        for (int64_t p = 0; p < npairs; ++p) hord[p] = (int32_t)(keys[p] & 0xffffffffu);
+        nq = (int64_t)keys.size();
+        for (int64_t q = 0; q < nq; ++q) hord[q] = (int32_t)(keys[q] & 0xffffffffu);
     }
     if (hipMemcpyAsync(base + w.meta_off, hm, npairs * sizeof(PairMeta), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(base + w.order_off, hord, npairs * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemsetAsync(base + w.bad_off, 0, npairs * 4, st) != hipSuccess) {
+        (nq > 0 && hipMemcpyAsync(base + w.order_off, hord, nq * 4, hipMemcpyHostToDevice, st) != hipSuccess) ||
+        hipMemsetAsync(base + w.bad_off, 0, (size_t)(w.counter_off + 256 - w.bad_off), st) != hipSuccess) {
         set_error("dtw: metadata upload failed");
         return ABN_E_LAUNCH;
     }
-    if (tiles > 0) {
-        hipLaunchKernelGGL(expand_tiles_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
-                           (const PairMeta*)(base + w.meta_off), (int)npairs, (int32_t*)(base + w.tilepair_off));
-        hipLaunchKernelGGL(dist_kernel, dim3((unsigned)align_up(tiles, 8)), dim3(256), 0, st, feats1, feats2,
-                           (const PairMeta*)(base + w.meta_off), (const int32_t*)(base + w.tilepair_off), (int)tiles, (int)D,
-                           (int)(D % 4 == 0 && aligned16(feats1) && aligned16(feats2)), (float*)(base + w.dist_off),
-                           (int32_t*)(base + w.bad_off));
-    }
     const PairMeta* dm = (const PairMeta*)(base + w.meta_off);
-    const int32_t* dord = (const int32_t*)(base + w.order_off);
-    float* dd = (float*)(base + w.dist_off);
-    uint8_t* dr = (uint8_t*)(base + w.dirs_off);
-    const int32_t* db = (const int32_t*)(base + w.bad_off);
-    // The size classes are independent: fork them over side streams so that the
-    // short tail of one class overlaps the others (joined back into `st` below).
-    int64_t first[DP_NCLASSES], acc_first = 0;
-    int by_work[DP_NCLASSES], nclasses = 0;
-    for (int c = 0; c < DP_NCLASSES; ++c) {
-        first[c] = acc_first;
-        acc_first += class_count[c];
-        if (class_count[c] > 0) by_work[nclasses++] = c;
+    if (nq > 0) {
+        DtwP P = {};
+        P.feats1 = feats1; P.feats2 = feats2;
+        P.meta = dm;
+        P.order = (const int32_t*)(base + w.order_off);
+        P.counter = (int32_t*)(base + w.counter_off);
+        P.npairs = (int32_t)nq;
+        P.D = (int32_t)D;
+        P.dirs = (uint32_t*)(base + w.dirs_off);
+        P.bound = (double*)(base + w.bound_off);
+        P.mcap = w.mcap;
+        P.bad = (int32_t*)(base + w.bad_off);
+        P.total_cost = total_cost;
+        int64_t nwg = (nq + 1) / 2;
+        if (nwg > w.nwg) nwg = w.nwg;
+        const bool vec = D % 4 == 0 && aligned16(feats1) && aligned16(feats2);
+        if (vec) hipLaunchKernelGGL(dtw_fused_kernel<true>, dim3((unsigned)nwg), dim3(64), 0, st, P);
+        else hipLaunchKernelGGL(dtw_fused_kernel<false>, dim3((unsigned)nwg), dim3(64), 0, st, P);
     }
-    // A class with few pairs is latency-bound (one wavefront sweeps a pair; its time grows
-    // with rows-per-lane x steps), so the widest classes start first, each on its own
-    // stream; the narrow, fast ones queue up behind them.
-    std::sort(by_work, by_work + nclasses, [&](int x, int y) { return x > y; });
-    SideStreams* side = nclasses > 1 ? side_streams() : nullptr;
-    std::unique_lock<std::mutex> guard;
-    if (side) {
-        guard = std::unique_lock<std::mutex>(side->mu);
-        if (hipEventRecord(side->fork, st) != hipSuccess) side = nullptr;
-    }
-    bool used[N_SIDE] = {};
-    for (int k = 0; k < nclasses; ++k) {
-        const int c = by_work[k];
-        hipStream_t cs = st;
-        if (side && k % (N_SIDE + 1) != 0) {
-            const int q = k % (N_SIDE + 1) - 1;
-            if (!used[q] && hipStreamWaitEvent(side->s[q], side->fork, 0) != hipSuccess) {
-                set_error("dtw: side stream fork failed");
-                return ABN_E_LAUNCH;
-            }
-            used[q] = true;
-            cs = side->s[q];
-        }
-        const dim3 grid((unsigned)((class_count[c] + DP_WAVES - 1) / DP_WAVES));
-        const int32_t* ord = dord + first[c];
-#define ABN_DP_CASE(C)                                                                                                   \
-    case C:                                                                                                              \
-        hipLaunchKernelGGL((dp_kernel<DP_CLASSES[C]>), grid, dim3(64 * DP_WAVES), 0, cs, dm, ord, (int)class_count[c], dd, dr, \
-                           db, path1, path2, path_len, path_stride, total_cost);                                         \
-        break;
-        switch (c) {
-            ABN_DP_CASE(0) ABN_DP_CASE(1) ABN_DP_CASE(2) ABN_DP_CASE(3) ABN_DP_CASE(4)
-            ABN_DP_CASE(5) ABN_DP_CASE(6) ABN_DP_CASE(7) ABN_DP_CASE(8) ABN_DP_CASE(9)
-        }
-#undef ABN_DP_CASE
-    }
-    static_assert(DP_NCLASSES == 10, "one ABN_DP_CASE per size class");
-    for (int q = 0; q < N_SIDE; ++q)
-        if (used[q] && (hipEventRecord(side->join[q], side->s[q]) != hipSuccess ||
-                        hipStreamWaitEvent(st, side->join[q], 0) != hipSuccess)) {
-            set_error("dtw: side stream join failed");
-            return ABN_E_LAUNCH;
-        }
+    hipLaunchKernelGGL(dtw_traceback_kernel, dim3((unsigned)((npairs + 63) / 64)), dim3(64), 0, st, dm, (int)npairs,
+                       (const uint32_t*)(base + w.dirs_off), (const int32_t*)(base + w.bad_off),
+                       (int32_t*)(base + w.tmp_off), path1, path2, path_len, path_stride, total_cost);
     ABN_CHECK_LAUNCH("dtw");
     return ABN_OK;
 }
