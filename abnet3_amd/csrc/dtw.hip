@@ -39,6 +39,8 @@
 //                   window), and all lanes finally reverse the path into place.
 // The DP is dependency-bound (N+M-1 sequential steps per pair), not HBM-bound:
 // parallelism comes from running thousands of pairs side by side, longest first.
+#include <stdlib.h>
+
 #include "common.h"
 #include "dist_ref.h"
 #include <algorithm>
@@ -127,6 +129,37 @@ __device__ __forceinline__ void load_frag(float* __restrict__ f, const float* __
     }
 }
 
+// np.sum(v ** 2) for 40 floats held as ten float4: numpy's order for n = 40 (8 partial sums
+// over 5 passes, then the tree)
+__device__ __forceinline__ float sumsq40(const float4* v)
+{
+    float r[8];
+    r[0] = v[0].x * v[0].x; r[1] = v[0].y * v[0].y; r[2] = v[0].z * v[0].z; r[3] = v[0].w * v[0].w;
+    r[4] = v[1].x * v[1].x; r[5] = v[1].y * v[1].y; r[6] = v[1].z * v[1].z; r[7] = v[1].w * v[1].w;
+#pragma unroll
+    for (int c = 1; c < 5; ++c) {
+        r[0] += v[2 * c].x * v[2 * c].x; r[1] += v[2 * c].y * v[2 * c].y;
+        r[2] += v[2 * c].z * v[2 * c].z; r[3] += v[2 * c].w * v[2 * c].w;
+        r[4] += v[2 * c + 1].x * v[2 * c + 1].x; r[5] += v[2 * c + 1].y * v[2 * c + 1].y;
+        r[6] += v[2 * c + 1].z * v[2 * c + 1].z; r[7] += v[2 * c + 1].w * v[2 * c + 1].w;
+    }
+    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
+// one 40-float row -> MFMA fragment (element t = row[2t + h]) and its norm, from ONE set of loads
+__device__ __forceinline__ float load_row40(float* __restrict__ f, const float* __restrict__ row, int h)
+{
+    float4 v[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) v[q] = *reinterpret_cast<const float4*>(row + 4 * q);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        f[2 * q] = h ? v[q].y : v[q].x;
+        f[2 * q + 1] = h ? v[q].w : v[q].z;
+    }
+    return sqrtf(sumsq40(v));
+}
+
 // ---------------------------------------------------------------------------------------
 // The whole alignment of a pair in one kernel, the cost matrix never leaves the CU:
 //
@@ -150,8 +183,8 @@ __device__ __forceinline__ void load_frag(float* __restrict__ f, const float* __
 // The produce phase is throughput code on all 64 lanes, the sweep a dependency chain on
 // 32 + 32: co-resident wavefronts (8 per CU at this LDS footprint) interleave the two.
 // ---------------------------------------------------------------------------------------
-template <bool VEC>
-__global__ __launch_bounds__(64) void dtw_fused_kernel(DtwP P)
+template <bool VEC, bool F40>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void dtw_fused_kernel(DtwP P)
 {
     __shared__ __attribute__((aligned(16))) float ring[2][64][BAND];
     __shared__ __attribute__((aligned(16))) float ny_s[2][BAND];
@@ -203,37 +236,70 @@ __global__ __launch_bounds__(64) void dtw_fused_kernel(DtwP P)
             topv = __hip_atomic_load(&bnd[(int64_t)((band & 1) ^ 1) * P.mcap + j0 + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         // ---- produce: distances of columns j0 .. j0+31 for both slots, all 64 lanes
+        int q_pair[2], qM[2], qN[2], qj0[2], qi0[2];
+        bool have[2];
+        f32x16 acc[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int src = 32 * q;
-            const int q_pair = __builtin_amdgcn_readlane(pair, src);
-            const int qM = __builtin_amdgcn_readlane(M, src), qN = __builtin_amdgcn_readlane(N, src);
-            const int qj0 = __builtin_amdgcn_readlane(j0, src), qi0 = __builtin_amdgcn_readlane(i0, src);
-            const int qu = __builtin_amdgcn_readlane(u, src);
-            if (q_pair < 0 || qj0 >= qM) continue;                         // wave-uniform
-            const float* xb = P.feats1 + readlane64(xoff, src);
-            const float* yb = P.feats2 + readlane64(yoff, src);
-            const float* xrow = xb + (int64_t)min(qi0 + n, qN - 1) * D;    // rows past the token end are clamped:
-            const float* yrow = yb + (int64_t)min(qj0 + n, qM - 1) * D;    // their cells are computed and never used
-            if (qu == 0) nx[q] = row_norm_numpy(xrow, D);                  // np.sqrt(np.sum(x ** 2, axis=1)), numpy's order
-            if (half == 0) ny_s[q][n] = row_norm_numpy(yrow, D);
-            f32x16 acc;
+            q_pair[q] = __builtin_amdgcn_readlane(pair, src);
+            qM[q] = __builtin_amdgcn_readlane(M, src); qN[q] = __builtin_amdgcn_readlane(N, src);
+            qj0[q] = __builtin_amdgcn_readlane(j0, src); qi0[q] = __builtin_amdgcn_readlane(i0, src);
+            have[q] = q_pair[q] >= 0 && qj0[q] < qM[q];                     // wave-uniform
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            for (int k0 = 0; k0 < D; k0 += KCH) {
-                float yf[KST];
-                if (D > KCH || qu == 0) load_frag<VEC>(xf[q], xrow, k0, D, half);
-                load_frag<VEC>(yf, yrow, k0, D, half);
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+        }
+        if (F40) {
+            // one MFMA chain segment per cell: rows -> fragments + norms from one set of loads,
+            // then the two slots' chains interleaved on the matrix pipe
+            float yf[2][KST];
 #pragma unroll
-                for (int t = 0; t < KST; ++t)                               // A = token 2 rows (j), B = token 1 rows (i)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[t], xf[q][t], acc, 0, 0, 0);
+            for (int q = 0; q < 2; ++q) {
+                if (!have[q]) continue;
+                const float* xrow = P.feats1 + readlane64(xoff, 32 * q) + (int64_t)min(qi0[q] + n, qN[q] - 1) * D;
+                const float* yrow = P.feats2 + readlane64(yoff, 32 * q) + (int64_t)min(qj0[q] + n, qM[q] - 1) * D;
+                const float ny = load_row40(yf[q], yrow, half);
+                if (half == 0) ny_s[q][n] = ny;
+                __builtin_amdgcn_sched_barrier(0);          // one row's ten float4 in flight at a time (registers)
+                if (qj0[q] == 0) nx[q] = load_row40(xf[q], xrow, half);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            wave_lds_sync();                                               // ny_s is staged
+#pragma unroll
+            for (int t = 0; t < KST; ++t) {                                 // A = token 2 rows (j), B = token 1 rows (i)
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[0][t], xf[0][t], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[1][t], xf[1][t], acc[1], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (!have[q]) continue;
+                const float* xrow = P.feats1 + readlane64(xoff, 32 * q) + (int64_t)min(qi0[q] + n, qN[q] - 1) * D;   // rows past the token
+                const float* yrow = P.feats2 + readlane64(yoff, 32 * q) + (int64_t)min(qj0[q] + n, qM[q] - 1) * D;   // end are clamped
+                if (qj0[q] == 0) nx[q] = row_norm_numpy(xrow, D);           // np.sqrt(np.sum(x ** 2, axis=1)), numpy's order
+                if (half == 0) ny_s[q][n] = row_norm_numpy(yrow, D);
+                for (int k0 = 0; k0 < D; k0 += KCH) {
+                    float yf[KST];
+                    if (D > KCH || qj0[q] == 0) load_frag<VEC>(xf[q], xrow, k0, D, half);
+                    load_frag<VEC>(yf, yrow, k0, D, half);
+#ifndef ABN_EXP_NOMFMA
+#pragma unroll
+                    for (int t = 0; t < KST; ++t)
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[t], xf[q][t], acc[q], 0, 0, 0);
+#endif
+                }
+            }
+        }
+        wave_lds_sync();                                                   // ny_s is staged
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!have[q]) continue;
             // accumulator r of lane (n, h) is cell (row i0 + n, column j0 + m), m = (r & 3) + 8 (r >> 2) + 4 h
             const float nxl = nx[q];
             const bool zero_rows = __any(nxl == 0.0f || ny_s[q][n] == 0.0f);
-            const bool rowok = qi0 + n < qN;
+            const bool rowok = qi0[q] + n < qN[q];
             bool bad = false;
+            float* rw = &ring[q][0][n];
+            const int rbase = (qj0[q] & 32) + n + 4 * half;                 // ring row of accumulator 0
             auto epilogue = [&](auto zr) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -242,9 +308,13 @@ __global__ __launch_bounds__(64) void dtw_fused_kernel(DtwP P)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int m = 8 * g + 4 * half + e;
-                        const float d = angular_distance_ref<decltype(zr)::value>(acc[4 * g + e], nxl, nyv[e]);
-                        bad |= rowok && qj0 + m < qM && !(d >= 0.0f);      // utils.py:59 assert
-                        ring[q][(qj0 + m + n) & 63][n] = d;
+#ifndef ABN_EXP_NOEPI
+                        const float d = angular_distance_ref<decltype(zr)::value>(acc[q][4 * g + e], nxl, nyv[e]);
+#else
+                        const float d = fabsf(acc[q][4 * g + e] * nxl * nyv[e]) * 1e-3f;
+#endif
+                        bad |= rowok && qj0[q] + m < qM[q] && !(d >= 0.0f);  // utils.py:59 assert
+                        rw[((rbase + 8 * g + e) & 63) * BAND] = d;
                     }
                 }
             };
@@ -263,7 +333,11 @@ __global__ __launch_bounds__(64) void dtw_fused_kernel(DtwP P)
             const bool feed_next = active && band + 1 < nbands;             // the last row feeds the next band
             const bool last_lane = n == BAND - 1 && feed_next;
             uint32_t* dptr = P.dirs + dir_off + ((int64_t)(band * 2 * nrounds + 2 * u) * BAND + n);
+#ifdef ABN_EXP_NODP
+            for (int e16 = 0; e16 < 0; e16 += 16) {
+#else
             for (int e16 = 0; e16 < BAND; e16 += 16) {
+#endif
             uint32_t bits = 0u;
 #pragma unroll
             for (int ee = 0; ee < 16; ++ee) {
@@ -563,8 +637,10 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
         int64_t nwg = (nq + 1) / 2;
         if (nwg > w.nwg) nwg = w.nwg;
         const bool vec = D % 4 == 0 && aligned16(feats1) && aligned16(feats2);
-        if (vec) hipLaunchKernelGGL(dtw_fused_kernel<true>, dim3((unsigned)nwg), dim3(64), 0, st, P);
-        else hipLaunchKernelGGL(dtw_fused_kernel<false>, dim3((unsigned)nwg), dim3(64), 0, st, P);
+        static const bool pipelined = !(getenv("ABN_DTW_F40") && atoi(getenv("ABN_DTW_F40")) == 0);     // A/B switch of the 40-d specialisation
+        if (vec && D == KCH && pipelined) hipLaunchKernelGGL((dtw_fused_kernel<true, true>), dim3((unsigned)nwg), dim3(64), 0, st, P);
+        else if (vec) hipLaunchKernelGGL((dtw_fused_kernel<true, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);
+        else hipLaunchKernelGGL((dtw_fused_kernel<false, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);
     }
     hipLaunchKernelGGL(dtw_traceback_kernel, dim3((unsigned)((npairs + 63) / 64)), dim3(64), 0, st, dm, (int)npairs,
                        (const uint32_t*)(base + w.dirs_off), (const int32_t*)(base + w.bad_off),
