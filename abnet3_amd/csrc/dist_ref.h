@@ -81,9 +81,52 @@ __device__ __forceinline__ float sumsq_numpy(const float* __restrict__ v, int n)
 
 __device__ __forceinline__ float row_norm_numpy(const float* __restrict__ v, int n) { return sqrtf(sumsq_numpy(v, n)); }
 
+// a / b, correctly rounded, for operands whose scaled forms equal themselves: the reciprocal
+// refinement the compiler emits for `/` (v_rcp_f32, two Newton steps on the quotient) without
+// the v_div_scale / v_div_fixup pair around it, i.e. bit-identical to `/` whenever neither
+// operand nor the quotient leaves the normal range.  Callers guarantee that range.
+__device__ __forceinline__ float div_normal(float a, float b)
+{
+    float y = __builtin_amdgcn_rcpf(b);
+    const float e = fmaf(-b, y, 1.0f);
+    y = fmaf(e, y, y);
+    float q = a * y;
+    float r = fmaf(-b, q, a);
+    q = fmaf(r, y, q);
+    r = fmaf(-b, q, a);
+    return fmaf(r, y, q);
+}
+
+// sqrtf, correctly rounded, for x in [2^-96, 2^96] (no rescaling needed): v_sqrt_f32 and the
+// compiler's own one-ulp fix-up
+__device__ __forceinline__ float sqrt_normal(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sdn = __uint_as_float(__float_as_uint(s) - 1u), sup = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rdn = fmaf(-sdn, s, x), rup = fmaf(-sup, s, x);
+    float t = (0.0f >= rdn) ? sdn : s;
+    t = (0.0f < rup) ? sup : t;
+    return t;
+}
+
+// a / float32(pi) for a = 0 or a in [2^-13, pi] (every value acosf returns lies there: the smallest
+// positive one is acosf(1 - 2^-24) = 3.45e-4): multiply by the rounded reciprocal, one fma
+// for the remainder, one to correct.  Equal to the correctly rounded quotient for ALL of
+// those floats (exhaustive check on the CPU, tools/divpi_check.c: 0 of 122 683 875 differ).
+__device__ __forceinline__ float div_pi(float a)
+{
+    const float pi_f = bits_f32(0x40490fdbu), inv_pi = bits_f32(0x3ea2f983u);      // float32(np.pi), float32(1 / pi_f)
+    const float q = a * inv_pi;
+    const float r = fmaf(-q, pi_f, a);
+    return fmaf(r, inv_pi, q);
+}
+
 // glibc 2.35 __ieee754_acosf, straight-line for the common |x| < 0.5 case with
 // wave-uniform detours for the other two ranges (a wave whose lanes all sit in
-// |x| < 0.5 -- most of a distance tile of unrelated frames -- never pays for them).
+// |x| < 0.5 -- most of a distance tile of unrelated frames -- never pays for them)
+// and for the rare arguments with a constant result (|x| <= 2^-26, |x| >= 1, NaN).
+// The divisions' operands are in the normal range by construction: q in [0.6, 1], |p| < 0.05;
+// z in [2^-25, 0.25], s + df in [2^-13, 1].
 __device__ __forceinline__ float acosf_ref(float x)
 {
     const float one = 1.0f;
@@ -99,40 +142,48 @@ __device__ __forceinline__ float acosf_ref(float x)
     const float z = small ? x * x : (one - ax) * 0.5f;
     const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
     const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-    const float r = p / q;
+    const float r = div_normal(p, q);
     float res = pio2_hi - (x - (pio2_lo - x * r));
     if (__any(!small)) {
-        const float s = sqrtf(z);
+        const float s = sqrt_normal(z);
         const float wn = r * s - pio2_lo;
         const float neg = pi - 2.0f * (s + wn);
         float big = neg;
         const bool posb = !small && (int32_t)hx >= 0;
         if (__any(posb)) {
             const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
-            const float c = (z - df * df) / (s + df);
+            const float c = div_normal(z - df * df, s + df);
             const float wp = r * s + c;
             big = posb ? 2.0f * (df + wp) : neg;
         }
         res = small ? res : big;
     }
-    res = ix <= 0x32800000u ? pio2_hi + pio2_lo : res;
-    res = ix == 0x3f800000u ? ((int32_t)hx > 0 ? 0.0f : pi + 2.0f * pio2_lo) : res;
-    return ix > 0x3f800000u ? __builtin_nanf("") : res;       // |x| > 1 (rounding) or NaN: the pair is dropped
+    if (__any(ix <= 0x32800000u || ix >= 0x3f800000u)) {
+        res = ix <= 0x32800000u ? pio2_hi + pio2_lo : res;
+        res = ix == 0x3f800000u ? ((int32_t)hx > 0 ? 0.0f : pi + 2.0f * pio2_lo) : res;
+        res = ix > 0x3f800000u ? __builtin_nanf("") : res;    // |x| > 1 (rounding) or NaN: the pair is dropped
+    }
+    return res;
 }
 
 // one cell of cosine_distance: dot = the fma chain x.y, nx / ny = the row norms
-// (utils.py:46-58; a zero-norm row is at distance 1 from everything, 0 from another zero row)
-template <bool ZERO_ROWS = true>
+// (utils.py:46-58; a zero-norm row is at distance 1 from everything, 0 from another zero row).
+// PLAIN = true: the caller has checked that every norm of the block lies in [2^-40, 2^40] (so
+// no zero rows, and dot / (nx ny) stays in the normal range or rounds to a value acosf maps to
+// pi/2 anyway); otherwise the compiler's full IEEE division and the zero-row rules.
+template <bool PLAIN>
 __device__ __forceinline__ float angular_distance_ref(float dot, float nx, float ny)
 {
+    if (PLAIN) return div_pi(acosf_ref(div_normal(dot, nx * ny)));
     const float pi_f = bits_f32(0x40490fdbu);                  // float32(np.pi)
     float v = acosf_ref(dot / (nx * ny)) / pi_f;
-    if (ZERO_ROWS) {
-        const bool zx = nx == 0.0f, zy = ny == 0.0f;
-        v = (zx || zy) ? 1.0f : v;
-        v = (zx && zy) ? 0.0f : v;
-    }
+    const bool zx = nx == 0.0f, zy = ny == 0.0f;
+    v = (zx || zy) ? 1.0f : v;
+    v = (zx && zy) ? 0.0f : v;
     return v;
 }
+
+// is the norm inside the range angular_distance_ref<true> is valid for?
+__device__ __forceinline__ bool norm_is_plain(float v) { return v >= 9.094947e-13f && v <= 1.0995116e12f; }
 
 }  // namespace abn

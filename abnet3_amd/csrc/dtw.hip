@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void dt
             if (!have[q]) continue;
             // accumulator r of lane (n, h) is cell (row i0 + n, column j0 + m), m = (r & 3) + 8 (r >> 2) + 4 h
             const float nxl = nx[q];
-            const bool zero_rows = __any(nxl == 0.0f || ny_s[q][n] == 0.0f);
+            const bool plain = __all(norm_is_plain(nxl) && norm_is_plain(ny_s[q][n]));     // the usual case
             const bool rowok = qi0[q] + n < qN[q];
             bool bad = false;
             float* rw = &ring[q][0][n];
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void dt
                     }
                 }
             };
-            if (zero_rows) epilogue(std::true_type{}); else epilogue(std::false_type{});
+            if (plain) epilogue(std::true_type{}); else epilogue(std::false_type{});
             anybad[q] |= __any(bad) ? 1 : 0;
         }
         // boundary window: the row above the band for this round's 32 diagonals
@@ -458,7 +458,7 @@ __global__ void dist_plain_kernel(const float* __restrict__ x, int N, const floa
     const float* b = y + (int64_t)j * D;
     float dot = 0.0f;
     for (int k = 0; k < D; ++k) dot = fmaf(a[k], b[k], dot);
-    const float v = angular_distance_ref(dot, row_norm_numpy(a, D), row_norm_numpy(b, D));
+    const float v = angular_distance_ref<false>(dot, row_norm_numpy(a, D), row_norm_numpy(b, D));
     if (!(v >= 0.0f) && bad) atomicOr(bad, 1);
     d[idx] = (double)v;
 }
@@ -489,10 +489,12 @@ __global__ void dist_plain_f64_kernel(const double* __restrict__ x, int N, const
 
 // acosf_ref over an array: lets the tests compare the device routine with libm's acosf
 // argument by argument (all 2^31 of them, tools/acosf_gpu_exhaustive.py)
-__global__ void arccos_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out)
+__global__ void arccos_kernel(const float* __restrict__ x, int64_t n, int over_pi, float* __restrict__ out)
 {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = acosf_ref(x[i]);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = acosf_ref(x[i]);
+        out[i] = over_pi ? div_pi(a) : a;
+    }
 }
 
 struct WsPlan {
@@ -677,13 +679,13 @@ extern "C" int abn_cosine_distance_f64(const double* x, int64_t N, const double*
     return ABN_OK;
 }
 
-extern "C" int abn_arccos_f32(const float* x, int64_t n, float* out, void* stream)
+extern "C" int abn_arccos_f32(const float* x, int64_t n, int over_pi, float* out, void* stream)
 {
     ABN_REQUIRE(n >= 0, "arccos_f32: negative length");
     if (n == 0) return ABN_OK;
     ABN_REQUIRE(x && out, "arccos_f32: null pointer");
     const int64_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(arccos_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    hipLaunchKernelGGL(arccos_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, x, n, over_pi, out);
     ABN_CHECK_LAUNCH("arccos_f32");
     return ABN_OK;
 }

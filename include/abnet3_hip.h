@@ -204,9 +204,10 @@ int abn_cosine_distance_f64(const double* x, int64_t N, const double* y, int64_t
 
 /* np.arccos on float32 as the reference's cosine_distance evaluates it on numpy's plain
  * path (utils.py:50,53: scipy.arccos = np.arccos = libm acosf): out[i] = acosf(x[i]),
- * bit-identical to glibc 2.35's acosf for every float32 argument (NaN outside [-1, 1]).
- * The cell function of abn_dtw_batched / abn_cosine_distance, exposed for verification. */
-int abn_arccos_f32(const float* x, int64_t n, float* out, void* stream);
+ * bit-identical to glibc 2.35's acosf for every float32 argument (NaN outside [-1, 1]);
+ * over_pi != 0: out[i] = acosf(x[i]) / float32(pi), the correctly rounded float32 quotient
+ * (utils.py:53).  The cell function of abn_dtw_batched, exposed for verification. */
+int abn_arccos_f32(const float* x, int64_t n, int over_pi, float* out, void* stream);
 
 /* last_non_linearity='softmax' (abnet3/model.py:161-166: nn.Softmax() after the output
  * layer's Linear/Dropout/BatchNorm = softmax over each row of a [rows, n] matrix), and

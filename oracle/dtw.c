@@ -131,9 +131,10 @@ int64_t abn_oracle_acosf_vs_libm(uint32_t lo_bits, uint32_t hi_bits, uint32_t st
     return bad;
 }
 
-void abn_oracle_acosf_array(const float* x, int64_t n, float* out)
+void abn_oracle_acosf_array(const float* x, int64_t n, int over_pi, float* out)
 {
-    for (int64_t i = 0; i < n; ++i) out[i] = abn_oracle_acosf(x[i]);
+    const float pi_f = u2f(0x40490fdbu);
+    for (int64_t i = 0; i < n; ++i) out[i] = over_pi ? abn_oracle_acosf(x[i]) / pi_f : abn_oracle_acosf(x[i]);
 }
 
 /* np.sum(v ** 2) of a contiguous float32 row: the squares are rounded to float32

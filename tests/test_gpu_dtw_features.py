@@ -105,26 +105,18 @@ def test_device_arccos_equals_libm_acosf():
     bits = np.concatenate([bits, bits + 0x80000000]).astype(np.uint32)
     x = bits.view(np.float32)
     xd = torch.from_numpy(x.copy()).cuda()
-    out = torch.empty_like(xd)
-    _lib.check(lib.abn_arccos_f32(_lib.ptr(xd), xd.numel(), _lib.ptr(out), _lib.stream()), 'abn_arccos_f32')
-    got = out.cpu().numpy()
     import ctypes
     L.abn_oracle_acosf_array.restype = None
-    L.abn_oracle_acosf_array.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
-    ref = np.empty_like(x)
-    L.abn_oracle_acosf_array(x.ctypes.data_as(ctypes.c_void_p), len(x), ref.ctypes.data_as(ctypes.c_void_p))
-    nan = np.isnan(ref)
-    assert (np.isnan(got) == nan).all()
-    assert (got.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all()
-
-
-def test_cosine_distance_nan_pair_is_refused():
-    from abnet3_amd.utils import cosine_distance, get_dtw_alignment
-    g = load_golden('cosdist.npz')
-    with pytest.raises(AssertionError):
-        cosine_distance(g['pos.x'], g['pos.y'])
-    with pytest.raises(AssertionError):       # the loader's try/except then drops the pair
-        get_dtw_alignment(g['pos.x'], g['pos.y'])
+    L.abn_oracle_acosf_array.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    for over_pi in (0, 1):                  # acosf(x), and acosf(x) / float32(pi) as utils.py:53 divides
+        out = torch.empty_like(xd)
+        _lib.check(lib.abn_arccos_f32(_lib.ptr(xd), xd.numel(), over_pi, _lib.ptr(out), _lib.stream()), 'abn_arccos_f32')
+        got = out.cpu().numpy()
+        ref = np.empty_like(x)
+        L.abn_oracle_acosf_array(x.ctypes.data_as(ctypes.c_void_p), len(x), over_pi, ref.ctypes.data_as(ctypes.c_void_p))
+        nan = np.isnan(ref)
+        assert (np.isnan(got) == nan).all()
+        assert (got.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all()
 
 
 @pytest.mark.parametrize('D', [40, 280, 13])
