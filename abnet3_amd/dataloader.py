@@ -175,9 +175,8 @@ class OriginalDataLoader(DataLoader):
         table = self.features.table
         res = dtw_align_batch(table, o1, n1, table, o2, n2)
         lens = res.path_len.cpu().numpy()
-        stride = res.path1.shape[1]
         dev = table.device
-        mask = torch.arange(stride, device=dev)[None, :] < res.path_len[:, None]
+        mask = res.mask()
         g1 = (res.path1.long() + torch.tensor(o1, device=dev)[:, None])[mask]
         g2 = (res.path2.long() + torch.tensor(o2, device=dev)[:, None])[mask]
         return lens, g1, g2

@@ -150,18 +150,26 @@ def cosine_distance(x, y):
 
 
 class DtwBatchResult(object):
-    """Device-resident result of dtw_align_batch."""
+    """Device-resident result of dtw_align_batch.  Path p is RIGHT-ALIGNED in row p of
+    path1 / path2: entries [stride - path_len[p], stride), in forward order (see
+    include/abnet3_hip.h, abn_dtw_batched)."""
 
     def __init__(self, path1, path2, path_len, total_cost):
         self.path1, self.path2 = path1, path2          # int32 [P, stride] (device)
         self.path_len = path_len                       # int32 [P] (device); 0 = dropped
         self.total_cost = total_cost                   # float64 [P] (device)
 
+    def mask(self):
+        """bool [P, stride]: the entries that belong to a path."""
+        stride = self.path1.shape[1]
+        return torch.arange(stride, device=self.path1.device)[None, :] >= (stride - self.path_len)[:, None]
+
     def to_lists(self):
         ln = self.path_len.cpu().numpy()
         p1 = self.path1.cpu().numpy()
         p2 = self.path2.cpu().numpy()
-        return [(p1[i, :ln[i]].copy(), p2[i, :ln[i]].copy()) if ln[i] > 0 else None
+        st = p1.shape[1]
+        return [(p1[i, st - ln[i]:].copy(), p2[i, st - ln[i]:].copy()) if ln[i] > 0 else None
                 for i in range(len(ln))]
 
 

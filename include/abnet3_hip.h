@@ -11,9 +11,12 @@
  * Conventions
  *  - extern "C", plain pointers and sizes, no torch / C++ types.
  *  - Every pointer named in a signature is a DEVICE pointer unless the comment
- *    says "host".  The caller owns all buffers; the library never allocates,
- *    frees or synchronises (graph-capturable), and keeps no global state apart
- *    from a thread-local error string.
+ *    says "host".  The caller owns all buffers; the library never allocates device
+ *    memory, frees or synchronises (graph-capturable).  Process state it keeps: a
+ *    thread-local error string, per-kernel "attribute already set" flags (dynamic LDS
+ *    opt-in, set once per device), and the A/B switches it reads from the environment
+ *    (ABN_FUSED, ABN_FUSED_MIN_ROWS, ABN_GEMM_TILE, ABN_BWD_PAIR, ABN_DTW_F40: kernel
+ *    choice only, never results beyond fp32 summation order).  No streams, no events.
  *  - Row-major contiguous fp32 tensors; sizes are int64_t; `stream` is a
  *    hipStream_t passed as void* (NULL = the null stream).
  *  - Return value: 0 = ok, negative = error (ABN_E_*); abn_last_error() gives
@@ -170,14 +173,18 @@ int abn_optimizer_step(int kind, float* params, const float* grads, float* state
  * HOST arrays -- token boundaries come from the pairs file, host data in the
  * reference too -- which the call stages into `ws` through `host_stage` (a
  * caller-owned host buffer, ideally pinned, that must stay untouched until the
- * stream has passed this call).  path1/path2: [npairs, path_stride] int32
- * (device), the path from (0,0) to (n1-1,n2-1); path_len[p] = 0 marks a pair
- * the reference would have dropped (NaN distance, abnet3/dataloader.py:188-191).
- * total_cost (device, [npairs] f64) may be NULL.  n1[p] <= 1024.
- * The size classes of the DP run on library-owned side streams, forked from and joined
- * back into `stream` with events (no host synchronisation; capturable).  rows1 / rows2
- * bound the offsets (checked); abn_dtw_ws_bytes ignores them since ABI 3 (the row norms
- * are recomputed per tile) but keeps the arguments. */
+ * stream has passed this call).  path1/path2: [npairs, path_stride] int32 (device);
+ * the path of pair p, from (0,0) to (n1-1,n2-1), is RIGHT-ALIGNED in its row: entries
+ * [path_stride - path_len[p], path_stride), in forward order (the traceback walks from the
+ * end and writes each cell where it belongs; the rest of the row is not touched).
+ * path_len[p] = 0 marks a pair the reference would have dropped (NaN distance,
+ * abnet3/dataloader.py:188-191) or an empty token.  total_cost (device, [npairs] f64) may be
+ * NULL.  Tokens of any length.  path_stride >= max(n1 + n2 - 1).
+ * One fused kernel per call (distances on the fp32 matrix cores, the reference's division /
+ * acosf / pi per cell, float64 dynamic programme, 2-bit back-pointers) plus a traceback
+ * kernel, all on `stream`: no library-owned streams, events or other global state.  The cost
+ * matrix is never materialised: the workspace holds ~0.26 B per cell (back-pointers) plus
+ * per-workgroup boundary rows.  rows1 / rows2 bound the offsets (checked). */
 int64_t abn_dtw_ws_bytes(const int32_t* n1_host, const int32_t* n2_host,
                          int64_t npairs, int64_t rows1, int64_t rows2);
 int64_t abn_dtw_host_stage_bytes(const int32_t* n1_host, const int32_t* n2_host,

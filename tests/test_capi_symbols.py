@@ -81,12 +81,11 @@ def test_dtw_workspace_planning(lib):
     ws = lib.abn_dtw_ws_bytes(p(n1), p(n2), 3, 1000, 1000)
     # the cost matrix is never materialised: per (padded) cell only 2 bits of back-pointers
     # -- bands of 32 rows x ceil((n2 + 31) / 32) rounds of 32 diagonals, 16 diagonals to a
-    # dword per row -- plus the reversed-path scratch (2 int32 per possible step), the
-    # band boundary rows of the two slots of each of the 2 workgroups, and metadata
+    # dword per row -- plus the band boundary rows of the two slots of each of the 2
+    # workgroups, and metadata
     dirs = (10 * 10 + 2 * 20) * 32 * 2 * 4
-    paths = (2 * (300 + 280) + 2 * (50 + 600)) * 4
     bound = 4 * 2 * 608 * 8
-    assert dirs + paths + bound <= ws <= dirs + paths + bound + 8 * 256 + 3 * 64
+    assert dirs + bound <= ws <= dirs + bound + 8 * 256 + 3 * 64
     assert ws < 1.0 * (300 * 280 + 50 * 600)            # under 1 B per cell even for two pairs (the matrix alone was 4.25 B / cell)
     assert lib.abn_dtw_host_stage_bytes(p(n1), p(n2), 3) >= 3 * 56 + 3 * 4
     assert lib.abn_dtw_ws_bytes(None, None, 3, 0, 0) == -1

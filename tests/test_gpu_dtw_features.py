@@ -362,10 +362,11 @@ def test_dtw_full_size_properties():
     p1, p2 = res.path1.long(), res.path2.long()
     stride = p1.shape[1]
     ar = torch.arange(P, device='cuda')
-    assert bool((p1[:, 0] == 0).all() and (p2[:, 0] == 0).all())
-    assert bool((p1[ar, L - 1] == n1t - 1).all() and (p2[ar, L - 1] == n2t - 1).all())
+    # paths are right-aligned in their rows: entries [stride - L, stride)
+    assert bool((p1[ar, stride - L] == 0).all() and (p2[ar, stride - L] == 0).all())
+    assert bool((p1[:, -1] == n1t - 1).all() and (p2[:, -1] == n2t - 1).all())
     assert bool((L >= torch.maximum(n1t, n2t)).all() and (L <= n1t + n2t - 1).all())
-    inside = torch.arange(1, stride, device='cuda')[None, :] < L[:, None]
+    inside = res.mask()[:, :-1]                 # steps between two path entries
     s1, s2 = (p1[:, 1:] - p1[:, :-1])[inside], (p2[:, 1:] - p2[:, :-1])[inside]
     assert bool(((s1 == 0) | (s1 == 1)).all() and ((s2 == 0) | (s2 == 1)).all() and ((s1 + s2) >= 1).all())
     cost = res.total_cost.cpu().numpy()
@@ -374,7 +375,7 @@ def test_dtw_full_size_properties():
     for p in rng.choice(P, 12, replace=False):
         a, b = f1[o1[p]:o1[p] + n1[p]], f2[o2[p]:o2[p] + n2[p]]
         d = cosine_distance(a, b)                       # HIP distance matrix, float64 [N, M]
-        i, j = p1[p, :L[p]].cpu().numpy(), p2[p, :L[p]].cpu().numpy()
+        i, j = p1[p, stride - L[p]:].cpu().numpy(), p2[p, stride - L[p]:].cpu().numpy()
         assert cost[p] == d[i, j].sum()                 # exact: float64 sums of float32 distances
         od = O.cosine_distance(a, b)
         q1, q2 = O.dtw_path(od)
