@@ -421,22 +421,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void dt
 // Walks the back-pointers of the pairs from (N-1, M-1) to (0, 0).  The k-th cell visited is the
 // k-th from the END of the path, so the path is written right-aligned into its output row --
 // entries [path_stride - len, path_stride) -- in forward order, with no second pass.
-// One thread per pair; the walk is a chain of dependent 4-byte loads (L1 / L2 hits: a step moves
-// at most one row and two diagonals).
-__global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __restrict__ meta, int npairs,
-                                                           const uint32_t* __restrict__ dirs, const int32_t* __restrict__ bad,
+// One thread per pair.  The walk is a chain of dependent loads, so a thread fetches a WINDOW at
+// a time -- the 8 rows at and above its position, the current 16-diagonal group and the one
+// before it: two runs of 8 consecutive dwords, 16 independent loads -- into its private strip
+// of LDS and takes 8 to 17 steps from there at LDS latency.
+constexpr int TB_ROWS = 8;
+__global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __restrict__ meta, const int32_t* __restrict__ order,
+                                                           int npairs, const uint32_t* __restrict__ dirs,
+                                                           const int32_t* __restrict__ bad,
                                                            int32_t* __restrict__ path1, int32_t* __restrict__ path2,
                                                            int32_t* __restrict__ path_len, int64_t path_stride,
                                                            double* __restrict__ total_cost)
 {
-    const int p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= npairs) return;
+    __shared__ uint32_t win[2 * TB_ROWS][64];            // [group offset * 8 + row offset][thread]: conflict-free
+    const int lane = threadIdx.x;
+    if ((int)(blockIdx.x * 64 + lane) >= npairs) return;
+    // queue order (pairs of similar size side by side): the threads of a wavefront walk paths of
+    // similar length.  Empty pairs are not in the queue: their path_len was zeroed by the call.
+    const int p = order[blockIdx.x * 64 + lane];
     const PairMeta m = meta[p];
     const int N = m.n1, M = m.n2;
-    if (N <= 0 || M <= 0 || bad[p]) {
-        path_len[p] = 0;
+    if (bad[p]) {
         if (total_cost) total_cost[p] = 0.0;
-        return;
+        return;                                       // path_len[p] stays 0: the pair is dropped
     }
     const uint32_t* dp = dirs + m.dir_off;
     const int nsg = 2 * m.nrounds;
@@ -445,13 +452,31 @@ __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __res
     int i = N - 1, j = M - 1, k = 0;
     o1[0] = i; o2[0] = j;
     while (i > 0 || j > 0) {
-        const int b = i >> 5, r = i & 31, s = j + r;
-        const uint32_t w = dp[(int64_t)(b * nsg + (s >> 4)) * BAND + r];
-        const int dir = (w >> (2 * (s & 15))) & 3;
-        if (dir == DIR_DIAG) { --i; --j; } else if (dir == DIR_UP) --i; else --j;
-        ++k;
-        o1[-k] = i;
-        o2[-k] = j;
+        const int b = i >> 5, r = i & 31, g = (j + r) >> 4;
+        const int rlo = max(r - (TB_ROWS - 1), 0);
+        const uint32_t* src = dp + (int64_t)(b * nsg + g) * BAND + rlo;     // rows rlo .. rlo+7 <= 31 exist in every band
+        uint32_t w0[TB_ROWS], w1[TB_ROWS];
+#pragma unroll
+        for (int q = 0; q < TB_ROWS; ++q) {
+            w0[q] = src[q];
+            w1[q] = g > 0 ? src[q - BAND] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < TB_ROWS; ++q) {
+            win[q][lane] = w0[q];
+            win[TB_ROWS + q][lane] = w1[q];
+        }
+        // the window holds rows rlo .. r of this band on diagonals 16 (g-1) .. 16 g + 15
+        while (i > 0 || j > 0) {
+            const int rr = i & 31, s = j + rr;
+            if ((i >> 5) != b || rr < rlo || (s >> 4) < g - 1) break;
+            const uint32_t w = win[(g - (s >> 4)) * TB_ROWS + (rr - rlo)][lane];
+            const int dir = (w >> (2 * (s & 15))) & 3;
+            if (dir == DIR_DIAG) { --i; --j; } else if (dir == DIR_UP) --i; else --j;
+            ++k;
+            o1[-k] = i;
+            o2[-k] = j;
+        }
     }
     path_len[p] = k + 1;
 }
@@ -629,6 +654,12 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
         set_error("dtw: metadata upload failed");
         return ABN_E_LAUNCH;
     }
+    // dropped and empty pairs keep path_len = 0, total_cost = 0
+    if (hipMemsetAsync(path_len, 0, (size_t)npairs * 4, st) != hipSuccess ||
+        (total_cost && hipMemsetAsync(total_cost, 0, (size_t)npairs * 8, st) != hipSuccess)) {
+        set_error("dtw: clearing the outputs failed");
+        return ABN_E_LAUNCH;
+    }
     const PairMeta* dm = (const PairMeta*)(base + w.meta_off);
     if (nq > 0) {
         DtwP P = {};
@@ -651,9 +682,10 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
         else if (vec) hipLaunchKernelGGL((dtw_fused_kernel<true, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);
         else hipLaunchKernelGGL((dtw_fused_kernel<false, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);
     }
-    hipLaunchKernelGGL(dtw_traceback_kernel, dim3((unsigned)((npairs + 63) / 64)), dim3(64), 0, st, dm, (int)npairs,
-                       (const uint32_t*)(base + w.dirs_off), (const int32_t*)(base + w.bad_off), path1, path2, path_len,
-                       path_stride, total_cost);
+    if (nq > 0)
+        hipLaunchKernelGGL(dtw_traceback_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, dm,
+                           (const int32_t*)(base + w.order_off), (int)nq, (const uint32_t*)(base + w.dirs_off),
+                           (const int32_t*)(base + w.bad_off), path1, path2, path_len, path_stride, total_cost);
     ABN_CHECK_LAUNCH("dtw");
     return ABN_OK;
 }
