@@ -418,6 +418,280 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void dt
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Producer / consumer form of the same algorithm for 40-value frames (the hot case): a
+// workgroup is TWO wavefronts sharing two slots.
+//   wave 0 (producer)  rows -> fragments + norms, 2 x 20 MFMAs, the reference's distance per
+//                      cell on all 64 lanes: throughput code, ~170 registers, no DP state;
+//   wave 1 (consumer)  the two slots' float64 sweeps (32 lanes each): a dependency chain,
+//                      ~60 registers, plus boundary rows and back-pointer stores.
+// The producer works one block AHEAD: while the consumer sweeps round t it computes the block
+// of round t+1.  A block's 63 anti-diagonals fall into the ring half the consumer is NOT
+// reading (its first 32 diagonals: written at once) and the half it IS reading (the other 31:
+// held in registers until the consumer has finished the round -- barrier A -- then written,
+// barrier B).  Ring rows are counted by a per-slot round counter that never resets, so the
+// halves alternate across band and pair changes too.  The producer also drives the slots'
+// schedule (next block / next band / next pair from the queue) and publishes one descriptor
+// per slot and round through LDS.  Twice the wavefronts per CU at the same LDS footprint:
+// the producers keep the vector ALU fed while the consumers wait on their chains.
+// ---------------------------------------------------------------------------------------
+#ifdef ABN_DTW_STAMPS         // diagnostic build only (tools/dtw_stamps.py): cycles per phase, summed over workgroups
+__device__ unsigned long long g_dtw_cycles[16];
+#define PSTAMP(k) do { if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_dtw_cycles[k], t_ - tlast); tlast = t_; } } while (0)
+#else
+#define PSTAMP(k) do {} while (0)
+#endif
+
+struct RoundDesc {            // what a slot does in one round (LDS; written by the producer)
+    int32_t pair;             // -1: slot idle
+    int32_t N, M, nbands, nrounds, band, u;
+    int32_t v;                // the slot's running round counter (ring phase)
+    int64_t xoff, yoff, dir_off;
+};
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void dtw_pc_kernel(DtwP P)
+{
+    __shared__ __attribute__((aligned(16))) float ring[2][64][BAND];
+    __shared__ __attribute__((aligned(16))) float ny_s[2][BAND];
+    __shared__ double top_s[2][BAND];
+    __shared__ double bot_s[2][2 * BAND];
+    __shared__ RoundDesc desc[2][2];                   // [round parity][slot]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, n = lane & 31;
+    const int D = P.D;
+
+    if (wave == 0) {
+        // =========================== producer ===========================
+        bool exhausted = false;
+        auto fetch = [&](RoundDesc& d) {               // next pair of the queue (wave-uniform values)
+            d.pair = -1;
+            if (exhausted) return;
+            int idx = 0;
+            if (lane == 0) idx = atomicAdd(P.counter, 1);
+            idx = __builtin_amdgcn_readfirstlane(idx);
+            if (idx >= P.npairs) { exhausted = true; return; }
+            const int p = __builtin_amdgcn_readfirstlane(P.order[idx]);
+            const PairMeta* m = P.meta + p;
+            d.pair = p;
+            d.N = __builtin_amdgcn_readfirstlane(m->n1); d.M = __builtin_amdgcn_readfirstlane(m->n2);
+            d.nbands = __builtin_amdgcn_readfirstlane(m->nbands); d.nrounds = __builtin_amdgcn_readfirstlane(m->nrounds);
+            d.xoff = readlane64(m->off1, 0) * D; d.yoff = readlane64(m->off2, 0) * D; d.dir_off = readlane64(m->dir_off, 0);
+            d.band = 0; d.u = 0;
+        };
+        RoundDesc cur[2];                              // the block being produced (scalar registers)
+        uint32_t orbits[2] = {0u, 0u};                 // OR of the distances' bit patterns: >= 0x7f800000 iff one is NaN
+        float dreg[2][16];
+
+        // block of `cur[q]`: loads, MFMA, distances into dreg[q].  One slot at a time and the band's
+        // rows re-read every round (they are L1 / L2 hot): the kernel has to fit 128 registers so
+        // that four wavefronts share a SIMD.
+        auto produce = [&](bool have0, bool have1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (!(q ? have1 : have0)) continue;
+                const RoundDesc& d = cur[q];
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                float nxl, ny;
+                {
+                    float xf[KST], yf[KST];
+                    const float* yrow = P.feats2 + d.yoff + (int64_t)min(d.u * BAND + n, d.M - 1) * D;
+                    ny = load_row40(yf, yrow, half);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float* xrow = P.feats1 + d.xoff + (int64_t)min(d.band * BAND + n, d.N - 1) * D;
+                    nxl = load_row40(xf, xrow, half);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < KST; ++t)                           // A = token 2 rows (j), B = token 1 rows (i)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[t], xf[t], acc, 0, 0, 0);
+                }
+                if (half == 0) ny_s[q][n] = ny;
+                wave_lds_sync();                                           // ny_s (this wave's own writes)
+                const bool plain = __all(norm_is_plain(nxl) && norm_is_plain(ny));
+                uint32_t ob = 0u;
+                auto epilogue = [&](auto pl) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float4 ny4 = *reinterpret_cast<const float4*>(&ny_s[q][8 * g + 4 * half]);
+                        const float nyv[4] = {ny4.x, ny4.y, ny4.z, ny4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float dv = angular_distance_ref<decltype(pl)::value>(acc[4 * g + e], nxl, nyv[e]);
+                            ob |= __float_as_uint(dv);          // padded rows / columns repeat real ones: no masking needed
+                            dreg[q][4 * g + e] = dv;
+                        }
+                    }
+                };
+                if (plain) epilogue(std::true_type{}); else epilogue(std::false_type{});
+                orbits[q] |= ob;
+            }
+        };
+        // accumulator c of lane (n, h) is column m = (c & 3) + 8 (c >> 2) + 4 h of the block: diagonal m + n
+        auto write_ring = [&](int q, bool late) {
+            const int v = cur[q].v;
+            float* rw = &ring[q][0][n];
+            const int base = ((v & 1) * BAND) + n + 4 * half;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int mo = (c & 3) + 8 * (c >> 2);
+                const int dg = n + 4 * half + mo;                           // diagonal inside the block, 0 .. 62
+                if ((dg >= BAND) == late) rw[((base + mo) & 63) * BAND] = dreg[q][c];
+            }
+        };
+        auto finish_pair_flags = [&](int q) {          // the block just produced was the pair's last one
+            const RoundDesc& d = cur[q];
+            const bool last_block = d.band + 1 == d.nbands && (d.u + 1) * BAND >= d.M;
+            if (last_block) {
+                const bool isbad = __any(orbits[q] >= 0x7f800000u);
+                if (isbad && lane == 0) P.bad[d.pair] = 1;                  // utils.py:59: NaN (or negative) distance
+                orbits[q] = 0u;
+            }
+        };
+
+        // prologue: first pairs, their first blocks, complete in the ring before the consumer starts
+        fetch(cur[0]); cur[0].v = 0;
+        fetch(cur[1]); cur[1].v = 0;
+        if (lane == 0) { desc[0][0] = cur[0]; desc[0][1] = cur[1]; }
+        {
+            const bool h0 = cur[0].pair >= 0, h1 = cur[1].pair >= 0;
+            produce(h0, h1);
+            if (h0) { write_ring(0, false); write_ring(0, true); finish_pair_flags(0); }
+            if (h1) { write_ring(1, false); write_ring(1, true); finish_pair_flags(1); }
+        }
+        __syncthreads();                                                    // barrier B of "round -1"
+
+#ifdef ABN_DTW_STAMPS
+        unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+        for (int t = 0;; ++t) {
+            if (cur[0].pair < 0 && cur[1].pair < 0) break;                  // = desc[t & 1]: the consumer sees the same
+            PSTAMP(0);
+            // next round of each slot
+            bool have[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                RoundDesc& d = cur[q];
+                if (d.pair >= 0) {
+                    const int v = d.v + 1;
+                    if (d.u + 1 < d.nrounds) d.u = d.u + 1;
+                    else if (d.band + 1 < d.nbands) { d.band = d.band + 1; d.u = 0; }
+                    else fetch(d);
+                    d.v = v;
+                }
+                have[q] = d.pair >= 0 && d.u * BAND < d.M;
+            }
+            if (lane == 0) { desc[(t + 1) & 1][0] = cur[0]; desc[(t + 1) & 1][1] = cur[1]; }
+            PSTAMP(1);
+            produce(have[0], have[1]);
+            PSTAMP(2);
+            if (have[0]) write_ring(0, false);
+            if (have[1]) write_ring(1, false);
+            PSTAMP(3);
+            __syncthreads();                                                // A: the consumer has finished round t
+            PSTAMP(4);
+            if (have[0]) { write_ring(0, true); finish_pair_flags(0); }
+            if (have[1]) { write_ring(1, true); finish_pair_flags(1); }
+            __syncthreads();                                                // B: round t+1 is complete in the ring
+            PSTAMP(5);
+        }
+    } else {
+        // =========================== consumer ===========================
+        const double INF = __builtin_inf();
+        double* const bnd = P.bound + (int64_t)(2 * (int)blockIdx.x + half) * 2 * P.mcap;
+        double p1 = INF, p2 = INF, topprev = INF;
+        int prev_pair = -1;
+        __syncthreads();                                                    // B of "round -1": first blocks are in the ring
+#ifdef ABN_DTW_STAMPS
+        unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+        for (int t = 0;; ++t) {
+            const RoundDesc* dd = desc[t & 1];
+            if (dd[0].pair < 0 && dd[1].pair < 0) break;
+            PSTAMP(8);
+            const RoundDesc& d = dd[half];
+            const int pair = d.pair, N = d.N, M = d.M, nbands = d.nbands, nrounds = d.nrounds, band = d.band, u = d.u, v = d.v;
+            const bool active = pair >= 0;
+            if (active && u == 0) {                      // a band starts: fresh diagonals
+                p1 = INF; p2 = INF;
+                topprev = (band == 0) ? 0.0 : INF;       // a pair starts from the virtual cell (-1, -1)
+            }
+            const int i0 = band * BAND, j0 = u * BAND;
+            double topv = INF;
+            if (active && band > 0 && j0 + n < M)
+                topv = __hip_atomic_load(&bnd[(int64_t)((band & 1) ^ 1) * P.mcap + j0 + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            top_s[half][n] = topv;
+            wave_lds_sync();
+            PSTAMP(9);
+            {
+                const float* rg = &ring[half][(v & 1) * BAND][n];
+                const bool rowok = active && i0 + n < N;
+                const bool feed_next = active && band + 1 < nbands;
+                const bool last_lane = n == BAND - 1 && feed_next;
+                uint32_t* dptr = P.dirs + d.dir_off + ((int64_t)(band * 2 * nrounds + 2 * u) * BAND + n);
+                for (int e16 = 0; e16 < BAND; e16 += 16) {
+                    uint32_t bits = 0u;
+#pragma unroll
+                    for (int ee = 0; ee < 16; ++ee) {
+                        const int e = e16 + ee;
+                        const int j = j0 + e - n;
+                        const float dist = rg[e * BAND];
+                        const double topc = top_s[half][e];
+                        double up = wave_shr1(p1), dg = wave_shr1(p2);
+                        if (n == 0) { up = topc; dg = topprev; topprev = topc; }
+                        const double left = p1;
+                        const bool take_up = up < dg;
+                        const double b1 = take_up ? up : dg;
+                        const bool take_left = left < b1;
+                        const double best = take_left ? left : b1;
+                        const uint32_t dir = take_left ? (uint32_t)DIR_LEFT : take_up ? (uint32_t)DIR_UP : (uint32_t)DIR_DIAG;
+                        const double cost = (double)dist + best;
+                        const bool on = rowok && (uint32_t)j < (uint32_t)M;
+                        p2 = left;
+                        p1 = on ? cost : left;
+                        bits |= on ? dir << (2 * ee) : 0u;
+                        if (last_lane && on) bot_s[half][j & 63] = cost;
+                    }
+                    if (active) dptr[(e16 >> 4) * BAND] = bits;
+                }
+                wave_lds_sync();
+                if (feed_next) {
+                    double* dst = bnd + (int64_t)(band & 1) * P.mcap;
+                    if (u >= 1) {
+                        const int j = (u - 1) * BAND + n;
+                        if (j < M) __hip_atomic_store(&dst[j], bot_s[half][j & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (u == nrounds - 1) {
+                        const int j = u * BAND + n;
+                        if (j < M) __hip_atomic_store(&dst[j], bot_s[half][j & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (active && u + 1 == nrounds && band + 1 == nbands && P.total_cost && n == ((N - 1) & 31))
+                    P.total_cost[pair] = p1;             // lane (N-1) % 32 holds cost(N-1, M-1)
+            }
+            // a finished band's boundary row is re-read by this wavefront: write-through stores that
+            // only have to be complete; the loads bypass the L1
+            if (__any(active && u + 1 == nrounds)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+            PSTAMP(10);
+            __syncthreads();                                                // A
+            PSTAMP(11);
+            __syncthreads();                                                // B
+            PSTAMP(12);
+        }
+    }
+}
+
+#ifdef ABN_DTW_STAMPS
+extern "C" int abn_debug_dtw_cycles(unsigned long long* out16, int reset)
+{
+    if (reset) { unsigned long long z[16] = {}; return hipMemcpyToSymbol(HIP_SYMBOL(abn::g_dtw_cycles), z, 128) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(abn::g_dtw_cycles), 128) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // Walks the back-pointers of the pairs from (N-1, M-1) to (0, 0).  The k-th cell visited is the
 // k-th from the END of the path, so the path is written right-aligned into its output row --
 // entries [path_stride - len, path_stride) -- in forward order, with no second pass.
@@ -678,7 +952,9 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
         if (nwg > w.nwg) nwg = w.nwg;
         const bool vec = D % 4 == 0 && aligned16(feats1) && aligned16(feats2);
         static const bool pipelined = !(getenv("ABN_DTW_F40") && atoi(getenv("ABN_DTW_F40")) == 0);     // A/B switch of the 40-d specialisation
-        if (vec && D == KCH && pipelined) hipLaunchKernelGGL((dtw_fused_kernel<true, true>), dim3((unsigned)nwg), dim3(64), 0, st, P);
+        static const bool pc = !(getenv("ABN_DTW_PC") && atoi(getenv("ABN_DTW_PC")) == 0);                // A/B switch: producer / consumer form
+        if (vec && D == KCH && pc) hipLaunchKernelGGL(dtw_pc_kernel, dim3((unsigned)nwg), dim3(128), 0, st, P);
+        else if (vec && D == KCH && pipelined) hipLaunchKernelGGL((dtw_fused_kernel<true, true>), dim3((unsigned)nwg), dim3(64), 0, st, P);
         else if (vec) hipLaunchKernelGGL((dtw_fused_kernel<true, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);
         else hipLaunchKernelGGL((dtw_fused_kernel<false, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);
     }
