@@ -222,6 +222,30 @@ __device__ __forceinline__ void tile_commit(const f32x4* r, float* __restrict__ 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// bf16 x 3: an fp32 value as the sum of three bf16 values (8 + 8 + 8 significant bits):
+//   hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid)     (both differences exact in fp32)
+// A product x y is then summed from the six bf16 products whose weight reaches 2^-16 of it,
+//   x y ~ hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi       (each one exact in the fp32 accumulator's
+//                                                                  input, dropped terms <= 3 * 2^-24 |x y|),
+// on v_mfma_f32_32x32x16_bf16: 6 MFMAs of 32 cycles per 16 k and block instead of 8 of 64.
+// The result differs from the exact-fp32 MFMA chain like one fp32 summation order from another
+// (~1e-7 relative), far inside the 1e-5 parity bar -- it is NOT bit-identical to it.
+struct bf16x8x3 { bf16x8 hi, mid, lo; };
+__device__ __forceinline__ bf16x8x3 split_bf16x3(const f32x4& a, const f32x4& b)
+{
+    bf16x8x3 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float v = i < 4 ? a[i] : b[i - 4];
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        r.hi[i] = h; r.mid[i] = m; r.lo[i] = (__bf16)r2;
+    }
+    return r;
+}
+
 // Two fp32 fragments (k-groups g, g+1: 8 k values per lane) -> one bf16 MFMA operand
 // (v_cvt_pk_bf16_f32, round to nearest even).  Which k a lane holds does not matter as
 // long as A and B agree: the 32x32x16 MFMA sums over all 16 (lane-half, slot) positions.
@@ -284,7 +308,7 @@ __device__ __forceinline__ int xcd_tile_index(int b, int n)
 // and fed to v_mfma_f32_32x32x16_bf16 (fp32 accumulate), 2 MFMAs of 32 cycles per
 // 32-deep tile and block instead of 16 of 64.  NOT the parity path (~3 significant
 // digits); the kernel is then bound by its global -> LDS traffic, not by the MFMA.
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC, bool BF16 = false>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC, int BF16 = 0>
 __device__ __forceinline__ void gemm_body(const GemmP& p, const int block_id)
 {
 #ifdef ABN_STAMPS
@@ -386,6 +410,28 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int block_id)
     };
 
     auto k_group_bf16 = [&](const float* as, const float* bs, int g2) {
+        if constexpr (BF16 == 2) {               // bf16 x 3: fp32-grade products from six bf16 MFMAs
+            bf16x8x3 pa[TM], pb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                pa[i] = split_bf16x3(frag_read<BM, A_KC>(as, wm0 + 32 * i, 2 * g2, lane),
+                                     frag_read<BM, A_KC>(as, wm0 + 32 * i, 2 * g2 + 1, lane));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                pb[j] = split_bf16x3(frag_read<BN, B_KC>(bs, wn0 + 32 * j, 2 * g2, lane),
+                                     frag_read<BN, B_KC>(bs, wn0 + 32 * j, 2 * g2 + 1, lane));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {   // small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].lo, pb[j].hi, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].hi, pb[j].lo, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].mid, pb[j].mid, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].mid, pb[j].hi, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].hi, pb[j].mid, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].hi, pb[j].hi, acc[i][j], 0, 0, 0);
+                }
+        } else {
         bf16x8 pa[TM], pb[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -400,6 +446,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int block_id)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i], pb[j], acc[i][j], 0, 0, 0);
+        }
     };
 
     // One global load of the next tile (unit u: A units first, then B units).
@@ -528,7 +575,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int block_id)
     ABN_STAMP_FLUSH();
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC, bool BF16 = false>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC, int BF16 = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
 {
     gemm_body<BM, BN, A_KC, B_KC, EPI, VEC, BF16>(p, (int)blockIdx.x);
@@ -540,7 +587,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p)
 // second kernel cannot start before the first one's last workgroup has drained its
 // epilogue; in one grid its workgroups take over the CUs as they free up.  n0 must be a
 // multiple of 8 so that the XCD-affine tile maps of both parts still see `b & 7` = XCD.
-template <int WM, int WN, bool BF16>
+template <int WM, int WN, int BF16>
 __global__ __launch_bounds__(256) void gemm_bwd_pair_kernel(GemmP pw, int n0, GemmP pd)
 {
     if ((int)blockIdx.x < n0) gemm_body<WM, WN, false, false, EPI_WGRAD, true, BF16>(pw, (int)blockIdx.x);

@@ -28,7 +28,7 @@ void set_error(const char* fmt, ...)
 // ---------------------------------------------------------------------------
 // GEMM dispatch
 // ---------------------------------------------------------------------------
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC, bool BF16>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC, int BF16>
 static void launch_one(const GemmP& p, int splits, hipStream_t st)
 {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -53,13 +53,18 @@ static void launch_one(const GemmP& p, int splits, hipStream_t st)
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
 static void launch_cfg(const GemmP& p, int splits, hipStream_t st)
 {
-    if (p.bf16) {                         // throughput mode (abn_tower_desc.precision = 1)
-        if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true, true>(p, splits, st);
-        else launch_one<BM, BN, A_KC, B_KC, EPI, false, true>(p, splits, st);
+    if (p.bf16 == 1) {                    // throughput mode (abn_tower_desc.precision = 1)
+        if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true, 1>(p, splits, st);
+        else launch_one<BM, BN, A_KC, B_KC, EPI, false, 1>(p, splits, st);
         return;
     }
-    if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true, false>(p, splits, st);
-    else launch_one<BM, BN, A_KC, B_KC, EPI, false, false>(p, splits, st);
+    if (p.bf16 == 2) {                    // bf16 x 3 (abn_tower_desc.precision = 2): fp32-grade products on the bf16 matrix cores
+        if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true, 2>(p, splits, st);
+        else launch_one<BM, BN, A_KC, B_KC, EPI, false, 2>(p, splits, st);
+        return;
+    }
+    if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true, 0>(p, splits, st);
+    else launch_one<BM, BN, A_KC, B_KC, EPI, false, 0>(p, splits, st);
 }
 
 // Checks, epilogue vectorisation flag and tile choice of one GEMM.  Returns the tile
@@ -118,7 +123,7 @@ static int launch_gemm(GemmP p, int splits, hipStream_t st)
 
 // wgrad + dgrad of one backward layer in ONE grid (gemm_bwd_pair_kernel) when both take
 // their usual vectorised instantiations; otherwise two launches.
-template <int WM, int WN, bool BF16>
+template <int WM, int WN, int BF16>
 static void launch_pair_one(const GemmP& pw, int n0, const GemmP& pd, int n1, hipStream_t st)
 {
     constexpr size_t lw = gemm_lds_bytes<WM, WN, false, false>(), ld = gemm_lds_bytes<128, 64, true, false>();
@@ -150,11 +155,13 @@ static int launch_bwd_pair(GemmP pw, int splits, GemmP pd, hipStream_t st)
         const int n1 = ((pd.M + 127) / 128) * ((pd.N + 63) / 64);
         if (n0 % 8 == 0) {
             if (tw == 1) {
-                if (pw.bf16) launch_pair_one<128, 64, true>(pw, n0, pd, n1, st);
-                else launch_pair_one<128, 64, false>(pw, n0, pd, n1, st);
+                if (pw.bf16 == 1) launch_pair_one<128, 64, 1>(pw, n0, pd, n1, st);
+                else if (pw.bf16 == 2) launch_pair_one<128, 64, 2>(pw, n0, pd, n1, st);
+                else launch_pair_one<128, 64, 0>(pw, n0, pd, n1, st);
             } else {
-                if (pw.bf16) launch_pair_one<64, 64, true>(pw, n0, pd, n1, st);
-                else launch_pair_one<64, 64, false>(pw, n0, pd, n1, st);
+                if (pw.bf16 == 1) launch_pair_one<64, 64, 1>(pw, n0, pd, n1, st);
+                else if (pw.bf16 == 2) launch_pair_one<64, 64, 2>(pw, n0, pd, n1, st);
+                else launch_pair_one<64, 64, 0>(pw, n0, pd, n1, st);
             }
             ABN_CHECK_LAUNCH("gemm_bwd_pair");
             return ABN_OK;
@@ -424,7 +431,7 @@ static int check_desc(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
 {
     ABN_REQUIRE(t != nullptr, "tower: null descriptor");
     ABN_REQUIRE(t->n_layers >= 1 && t->n_layers <= ABN_MAX_LAYERS, "tower: n_layers=%d out of range", t->n_layers);
-    ABN_REQUIRE(t->precision == 0 || t->precision == 1, "tower: precision=%d (0 = fp32, 1 = bf16 operands)", t->precision);
+    ABN_REQUIRE(t->precision >= 0 && t->precision <= 2, "tower: precision=%d (0 = fp32, 1 = bf16 operands, 2 = bf16 x 3)", t->precision);
     ABN_REQUIRE(rows >= 0 && n_calls >= 1 && rows % n_calls == 0, "tower: rows=%lld not divisible by n_calls=%lld",
                 (long long)rows, (long long)n_calls);
     for (int l = 0; l <= t->n_layers; ++l)
@@ -557,7 +564,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         f.n_layers = t->n_layers;
         f.rows = (int)rows;
         f.rows_call = (int)rpc;
-        f.bf16 = t->precision == 1;
+        f.bf16 = t->precision;
         f.x1 = x1; f.x2 = x2;
         f.x_copy = x2 ? ws + L.x : nullptr;
         for (int l = 0; l <= t->n_layers; ++l) f.dims[l] = (int)t->dims[l];
@@ -575,15 +582,18 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         (void)hipGetDevice(&dev);
         dev = (dev >= 0 && dev < 16) ? dev : 0;
         if (!attr_set[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_fused_kernel<false>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_fused_kernel<0>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_fused_kernel<true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_fused_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_fused_kernel<2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES);
             attr_set[dev] = true;
         }
         const dim3 fgrid((unsigned)((rows + FUSED_ROWS - 1) / FUSED_ROWS));
-        if (f.bf16) hipLaunchKernelGGL(tower_fwd_fused_kernel<true>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
-        else hipLaunchKernelGGL(tower_fwd_fused_kernel<false>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
+        if (f.bf16 == 1) hipLaunchKernelGGL(tower_fwd_fused_kernel<1>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
+        else if (f.bf16 == 2) hipLaunchKernelGGL(tower_fwd_fused_kernel<2>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
+        else hipLaunchKernelGGL(tower_fwd_fused_kernel<0>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
         ABN_CHECK_LAUNCH("tower_fwd_fused");
         return ABN_OK;
     }
@@ -611,7 +621,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         p.a_vec = aligned16(in) && (K % 4 == 0);
         p.b_vec = aligned16(t->W[l]) && (K % 4 == 0);
         p.ones_col = -1;
-        p.bf16 = t->precision == 1;
+        p.bf16 = t->precision;
         if (!t->batch_norm) {
             p.C = a; p.ldc = N; p.act = act;
             rc = launch_gemm<true, true, EPI_FWD>(p, 1, st);
@@ -702,7 +712,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
         pw.M = Nout; pw.N = Kin + 1; pw.K = (int)rows;
         pw.k_chunk = (int)align_up((rows + B.splits[l] - 1) / B.splits[l], BK);
         pw.ones_col = Kin;
-        pw.bf16 = t->precision == 1;
+        pw.bf16 = t->precision;
         pw.a_vec = aligned16(dz) && (Nout % 4 == 0);
         pw.b_vec = aligned16(a_in) && (Kin % 4 == 0);
         // slices past the end of the reduction write zero slabs (k range empty)
@@ -722,7 +732,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             p.a_vec = aligned16(dz) && (Nout % 4 == 0);
             p.b_vec = aligned16(t->W[l]) && (Kin % 4 == 0);
             p.ones_col = -1;
-            p.bf16 = t->precision == 1;
+            p.bf16 = t->precision;
             if (l > 0 && !t->batch_norm) { p.aux = ws + L.a[l - 1]; p.ldaux = Kin; p.act = t->act; p.mask = t->drop_mask[l - 1]; }
             rc = launch_bwd_pair(pw, B.splits[l], p, st);
             if (rc != ABN_OK) return rc;

@@ -81,7 +81,7 @@ __device__ __forceinline__ int x_off(int row, int k)
 // KS = 2 (narrow layers, at most 4 column blocks): waves 4..7 take the second half of
 // K for the same columns as waves 0..3 and hand their partial sums over through LDS,
 // so that every SIMD still runs two wavefronts.
-template <int BPW, int KS, bool BF16>
+template <int BPW, int KS, int BF16>
 __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __restrict__ X,
                                             float* __restrict__ Wst, int wave, int lane, int row0)
 {
@@ -175,7 +175,19 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
         f32x4 fa0, fa1, fb0[BPW], fb1[BPW];
         load_frags(fa0, fb0, ws, k0, 0);
         load_frags(fa1, fb1, ws, k0, 1);
-        if constexpr (BF16) {                     // one 16-deep bf16 MFMA per column block and tile
+        if constexpr (BF16 == 2) {                // bf16 x 3 (gemm_f32.h): six bf16 MFMAs per column block and tile
+            const bf16x8x3 pa = split_bf16x3(fa0, fa1);
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) {
+                const bf16x8x3 pb = split_bf16x3(fb0[j], fb1[j]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.lo, pb.hi, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.hi, pb.lo, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.mid, pb.mid, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.mid, pb.hi, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.hi, pb.mid, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.hi, pb.hi, acc[j], 0, 0, 0);
+            }
+        } else if constexpr (BF16 == 1) {         // one 16-deep bf16 MFMA per column block and tile
             const bf16x8 pa = pack_bf16(fa0, fa1);
 #pragma unroll
             for (int j = 0; j < BPW; ++j)
@@ -251,7 +263,7 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
     }
 }
 
-template <bool BF16>
+template <int BF16>
 __global__ __launch_bounds__(FUSED_NT) void tower_fwd_fused_kernel(FusedFwdP p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
