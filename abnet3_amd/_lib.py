@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ABNET3_HIP_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get('ABNET3_HIP_LIB') or os.path.join(HERE, 'lib', 'libabnet3_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LAYERS = 16
 
 ACT = {'none': 0, None: 0, 'sigmoid': 1, 'relu': 2, 'tanh': 3}
@@ -60,7 +60,8 @@ SYMBOLS = {
     'abn_mvn_stats': (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp]),
     'abn_mvn_apply': (C.c_int, [_vp, _i64, _i64, _vp, _vp, C.c_int, _f32, _vp, _vp]),
     'abn_fbank': (C.c_int, [_vp, C.c_int, _i64, _i32, C.c_double, _i32, _i32,
-                             _f32, _vp, _vp, _i64, _vp, _vp]),
+                             _f32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'abn_deltas': (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
 }
 
 

@@ -90,13 +90,202 @@ __global__ __launch_bounds__(256) void fbank_kernel(const void* __restrict__ sam
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// nfft = 1024 (the reference's call, features.py:108): ONE WAVEFRONT per frame, persistent.
+//   * the real frame x[0..1023] (wlen non-zero samples, zero padded) is taken as 512 complex
+//     points z[m] = x[2m] + i x[2m+1]; a 512-point complex FFT and one split pass give the
+//     513 bins of rfft(x, 1024): half the butterflies of the complex FFT of x;
+//   * 512 = 8 x 8 x 8: three radix-8 Stockham passes, one 8-point DFT per lane and pass in
+//     registers; the passes exchange data through a wave-private 4 KB strip of LDS (a
+//     wavefront's LDS operations are ordered: no workgroup barrier anywhere);
+//   * every twiddle a lane ever needs depends on the lane only: 7 + 7 for the passes and 4
+//     for the split, computed ONCE per wavefront (sincospif) and kept in registers while the
+//     wavefront walks its frames;
+//   * the mel projection is sparse: lane f owns filter f and sums its own band of bins
+//     [band[2f], band[2f+1]] (a triangle spans 4 .. 70 bins; the dense form read 513 x 40).
+// HBM traffic stays the algorithmic 2 B per new sample + 160 B per frame; the mel table
+// (82 KB) and the window live in L2 / L1.
+// ---------------------------------------------------------------------------------------
+struct cf { float x, y; };
+__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf mul_mi(cf a) { return {a.y, -a.x}; }            // a * (-i)
+
+// forward 8-point DFT in place (natural order in, natural order out)
+__device__ __forceinline__ void dft8(cf* v)
+{
+    const float h = 0.70710678118654752f;
+    // even part: v0 v2 v4 v6, odd part: v1 v3 v5 v7 (4-point DFTs)
+    cf e0 = cadd(v[0], v[4]), e1 = csub(v[0], v[4]), e2 = cadd(v[2], v[6]), e3 = mul_mi(csub(v[2], v[6]));
+    cf o0 = cadd(v[1], v[5]), o1 = csub(v[1], v[5]), o2 = cadd(v[3], v[7]), o3 = mul_mi(csub(v[3], v[7]));
+    cf E0 = cadd(e0, e2), E2 = csub(e0, e2), E1 = cadd(e1, e3), E3 = csub(e1, e3);
+    cf O0 = cadd(o0, o2), O2 = csub(o0, o2), O1 = cadd(o1, o3), O3 = csub(o1, o3);
+    // odd part times w8^k: w8 = (1 - i) / sqrt 2, w8^2 = -i, w8^3 = (-1 - i) / sqrt 2
+    O1 = {h * (O1.x + O1.y), h * (O1.y - O1.x)};
+    O2 = mul_mi(O2);
+    O3 = {h * (O3.y - O3.x), -h * (O3.x + O3.y)};
+    v[0] = cadd(E0, O0); v[4] = csub(E0, O0);
+    v[1] = cadd(E1, O1); v[5] = csub(E1, O1);
+    v[2] = cadd(E2, O2); v[6] = csub(E2, O2);
+    v[3] = cadd(E3, O3); v[7] = csub(E3, O3);
+}
+
+constexpr int FB_WAVES = 4;            // wavefronts (frames in flight) per workgroup
+
+__global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __restrict__ samples, int is_i16,
+                                                                  int64_t nsamples, int wlen, double fshift, int nfilt,
+                                                                  float alpha, const float* __restrict__ window,
+                                                                  const float* __restrict__ melbank,
+                                                                  const int32_t* __restrict__ band, int64_t nframes,
+                                                                  float* __restrict__ out)
+{
+    __shared__ cf zbuf[FB_WAVES][512];
+    __shared__ float pw[FB_WAVES][516];
+    const int wave = threadIdx.x >> 6, j = threadIdx.x & 63;
+    cf* const z = zbuf[wave];
+    float* const power = pw[wave];
+
+    // lane-only twiddles: pass 1 (sub-transform size 8): angle -2 pi r (j & 7) / 64; pass 2: -2 pi r j / 512
+    cf tw1[8], tw2[8], tws[4];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+        float sn, cs;
+        sincospif(-2.0f * (float)(r * (j & 7)) / 64.0f, &sn, &cs);
+        tw1[r] = {cs, sn};
+        sincospif(-2.0f * (float)(r * j) / 512.0f, &sn, &cs);
+        tw2[r] = {cs, sn};
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {          // split pass: e^{-2 pi i k / 1024}, k = j + 64 q
+        float sn, cs;
+        sincospif(-2.0f * (float)(j + 64 * q) / 1024.0f, &sn, &cs);
+        tws[q] = {cs, sn};
+    }
+    // this lane's filter: its band of bins
+    const int blo = j < nfilt ? band[2 * j] : 1, bhi = j < nfilt ? band[2 * j + 1] : 0;
+    // window taps of the samples this lane touches: elements m = j + 64 r, samples 2m, 2m+1
+    float w0[8], w1[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n0 = 2 * (j + 64 * r);
+        w0[r] = n0 < wlen ? window[n0] : 0.0f;
+        w1[r] = n0 + 1 < wlen ? window[n0 + 1] : 0.0f;
+    }
+    const int nwaves = gridDim.x * FB_WAVES;
+    for (int64_t frame = (int64_t)blockIdx.x * FB_WAVES + wave; frame < nframes; frame += nwaves) {
+        const int64_t start = (int64_t)rint((double)frame * fshift);
+        cf v[8];
+        // pre-emphasis over the zero-padded frame: y[n] = x[n] - alpha x[n-1] (x = 0 outside the signal)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n0 = 2 * (j + 64 * r);
+            float a = 0.0f, b = 0.0f, c = 0.0f;                  // x[n0 - 1], x[n0], x[n0 + 1]
+            if (n0 < wlen) {                                      // wave-uniform for whole r beyond the window? no: per lane
+                const int64_t i = start + n0;
+                if (is_i16) {
+                    const int16_t* sp = (const int16_t*)samples;
+                    a = (i - 1 >= 0 && i - 1 < nsamples) ? (float)sp[i - 1] : 0.0f;
+                    b = (i >= 0 && i < nsamples) ? (float)sp[i] : 0.0f;
+                    c = (i + 1 < nsamples) ? (float)sp[i + 1] : 0.0f;
+                } else {
+                    const float* sp = (const float*)samples;
+                    a = (i - 1 >= 0 && i - 1 < nsamples) ? sp[i - 1] : 0.0f;
+                    b = (i >= 0 && i < nsamples) ? sp[i] : 0.0f;
+                    c = (i + 1 < nsamples) ? sp[i + 1] : 0.0f;
+                }
+            }
+            v[r] = {(b - alpha * a) * w0[r], (c - alpha * b) * w1[r]};
+        }
+        // pass 0 (sub-transform size 1): no twiddles; outputs to 8 j + r
+        dft8(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) z[8 * j + r] = v[r];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // pass 1 (size 8): k = j & 7; outputs to ((j - k) << 3) + k + 8 r
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = z[j + 64 * r];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw1[r]);
+        dft8(v);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int k = j & 7, j0 = ((j - k) << 3) + k;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) z[j0 + 8 * r] = v[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // pass 2 (size 64): k = j; outputs to j + 64 r: natural order
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = z[j + 64 * r];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw2[r]);
+        dft8(v);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) z[j + 64 * r] = v[r];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // split: X[k] = (Z[k] + conj Z[512-k]) / 2 - i e^{-2 pi i k / 1024} (Z[k] - conj Z[512-k]) / 2, and its mirror
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = j + 64 * q;                              // 0 .. 255
+            const cf a = z[k], b = z[(512 - k) & 511];
+            const cf s = {0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};        // (Z[k] + conj Z[N-k]) / 2
+            const cf d = {0.5f * (a.x - b.x), 0.5f * (a.y + b.y)};        // (Z[k] - conj Z[N-k]) / 2
+            const cf t = cmul(tws[q], d);                                 // w d ; -i w d = (t.y, -t.x)
+            const cf xk = {s.x + t.y, s.y - t.x};
+            // mirror bin 512 - k: conj(s) - (-i) conj(w) ... = conj(s) + i conj(w d) -> (s.x - t.y, -s.y - t.x)
+            const cf xm = {s.x - t.y, -s.y - t.x};
+            power[k] = xk.x * xk.x + xk.y * xk.y;
+            power[512 - k] = xm.x * xm.x + xm.y * xm.y;            // k = 0: bin 512 = (Re Z0 - Im Z0)^2
+        }
+        if (j == 0) {                                              // bin 256: its own mirror, w = -i
+            const cf a = z[256];
+            power[256] = a.x * a.x + a.y * a.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // mel projection + log
+        float e = 0.0f;
+        for (int k = blo; k <= bhi; ++k) e = fmaf(power[k], melbank[(int64_t)k * nfilt + j], e);
+        if (j < nfilt) out[frame * nfilt + j] = logf(fmaxf(e, FB_FLOOR));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// regression deltas over time (spectral's _deltas: a 9-tap slope filter, sum_n n x[t+n] / 60, the
+// edges padded with copies of frame 1 and frame T-2): out[t][c]
+__global__ void deltas_kernel(const float* __restrict__ x, int64_t T, int D, float* __restrict__ out)
+{
+    const int64_t n = T * D;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / D;
+        const int c = (int)(i - t * D);
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 1; k <= 4; ++k) {
+            int64_t tp = t + k, tm = t - k;
+            tp = tp >= T ? (T >= 2 ? T - 2 : 0) : tp;
+            tm = tm < 0 ? (T >= 2 ? 1 : 0) : tm;
+            acc += (float)k * (x[tp * D + c] - x[tm * D + c]);
+        }
+        out[i] = acc / 60.0f;
+    }
+}
+
 }  // namespace abn
 
 using namespace abn;
 
 extern "C" int abn_fbank(const void* samples, int sample_is_i16, int64_t nsamples, int32_t wlen, double fshift,
                          int32_t nfft, int32_t nfilt, float alpha, const float* window, const float* melbank,
-                         int64_t nframes, float* out, void* stream)
+                         const int32_t* band, int64_t nframes, float* out, void* stream)
 {
     ABN_REQUIRE(nframes >= 0 && nsamples >= 0, "fbank: negative sizes");
     if (nframes == 0) return ABN_OK;
@@ -105,10 +294,33 @@ extern "C" int abn_fbank(const void* samples, int sample_is_i16, int64_t nsample
     ABN_REQUIRE(wlen >= 1 && wlen <= nfft, "fbank: wlen=%d must be in [1, nfft]", wlen);
     ABN_REQUIRE(nfilt >= 1 && nfilt <= FB_MAX_FILT, "fbank: nfilt=%d out of range", nfilt);
     ABN_REQUIRE(fshift > 0.0, "fbank: frame shift must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    if (nfft == 1024 && nfilt <= 64 && band) {
+        // persistent: enough wavefronts to fill the chip, each walks frames wave, wave + W, ...
+        int64_t wgs = (nframes + FB_WAVES - 1) / FB_WAVES;
+        if (wgs > 256 * 6) wgs = 256 * 6;
+        hipLaunchKernelGGL(fbank1024_kernel, dim3((unsigned)wgs), dim3(64 * FB_WAVES), 0, st, samples, sample_is_i16, nsamples,
+                           (int)wlen, fshift, (int)nfilt, alpha, window, melbank, band, nframes, out);
+        ABN_CHECK_LAUNCH("fbank1024");
+        return ABN_OK;
+    }
     int log2n = 0;
     while ((1 << log2n) < nfft) ++log2n;
-    hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)nframes), dim3(256), 0, (hipStream_t)stream, samples, sample_is_i16,
+    hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)nframes), dim3(256), 0, st, samples, sample_is_i16,
                        nsamples, (int)wlen, fshift, (int)nfft, log2n, (int)nfilt, alpha, window, melbank, out);
     ABN_CHECK_LAUNCH("fbank");
+    return ABN_OK;
+}
+
+extern "C" int abn_deltas(const float* feats, int64_t T, int64_t D, float* out, void* stream)
+{
+    ABN_REQUIRE(T >= 0 && D >= 1 && D < (1 << 24), "deltas: bad shape");
+    if (T == 0) return ABN_OK;
+    ABN_REQUIRE(feats && out && feats != out, "deltas: null or aliased pointer");
+    const int64_t n = T * D;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(deltas_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, feats,
+                       T, (int)D, out);
+    ABN_CHECK_LAUNCH("deltas");
     return ABN_OK;
 }

@@ -57,8 +57,6 @@ class FeaturesGenerator:
                  vad_file=None, normalization=True, norm_per_file=False,
                  norm_per_channel=False, stack=True, nframes=7, deltas=False,
                  deltasdeltas=False, run='once'):
-        if deltas or deltasdeltas:
-            raise NotImplementedError('deltas are not on the accelerated path')
         self.files = files
         self.output_path = output_path
         self.method = method
@@ -83,15 +81,32 @@ class FeaturesGenerator:
         key = (fs, wlen, nfft, self.n_filters, str(device))
         if key not in self._tables:
             win = torch.from_numpy(np.hamming(wlen).astype(np.float32)).to(device)
-            bank = torch.from_numpy(
-                mel_filterbank(fs, nfft, self.n_filters).astype(np.float32)).to(device)
-            self._tables[key] = (win, bank)
+            bank64 = mel_filterbank(fs, nfft, self.n_filters)
+            bank = torch.from_numpy(bank64.astype(np.float32)).to(device)
+            # first / last bin with a non-zero weight of every filter (the sparse projection)
+            band = np.zeros((self.n_filters, 2), dtype=np.int32)
+            for f in range(self.n_filters):
+                nz = np.nonzero(bank64[:, f])[0]
+                band[f] = (nz[0], nz[-1]) if len(nz) else (1, 0)
+            self._tables[key] = (win, bank, torch.from_numpy(band).to(device))
         return self._tables[key]
+
+    def deltas_of(self, feats):
+        """Regression deltas of a [T, D] device tensor (spectral's do_deltas): slope over +-4
+        frames, edges padded with frame 1 / frame T-2 (oracle/features_np.py)."""
+        lib = _lib.load()
+        feats = feats.contiguous()
+        out = torch.empty_like(feats)
+        _lib.check(lib.abn_deltas(_lib.ptr(feats), feats.shape[0], feats.shape[1], _lib.ptr(out),
+                                  _lib.stream()), 'abn_deltas')
+        return out
 
     def fbank_from_samples(self, sound, srate, alpha=0.97, frate=100, wlen=0.025,
                            nfft=1024):
         """Log mel energies [T, n_filters] float32 (device tensor) from int16 or
-        float mono samples (numpy array or device tensor)."""
+        float mono samples (numpy array or device tensor); with deltas / deltasdeltas
+        (features.py:110-111) the slopes are appended as further columns:
+        [T, n_filters * (1 + deltas + deltasdeltas)]."""
         lib = _lib.load()
         if isinstance(sound, torch.Tensor):
             s = sound
@@ -106,12 +121,18 @@ class FeaturesGenerator:
         wl = int(wlen * srate)
         fshift = float(srate) / frate
         nfr = int(s.numel() / fshift + 1)
-        win, bank = self._table(srate, wl, nfft, s.device)
+        win, bank, band = self._table(srate, wl, nfft, s.device)
         out = torch.empty(nfr, self.n_filters, dtype=torch.float32, device=s.device)
         _lib.check(lib.abn_fbank(_lib.ptr(s), int(s.dtype == torch.int16), s.numel(), wl,
                                  fshift, nfft, self.n_filters, alpha, _lib.ptr(win),
-                                 _lib.ptr(bank), nfr, _lib.ptr(out), _lib.stream()),
+                                 _lib.ptr(bank), _lib.ptr(band), nfr, _lib.ptr(out), _lib.stream()),
                    'abn_fbank')
+        if self.deltas or self.deltasdeltas:
+            d1 = self.deltas_of(out)
+            cols = [out] + ([d1] if self.deltas else [])
+            if self.deltasdeltas:
+                cols.append(self.deltas_of(d1))
+            out = torch.cat(cols, dim=1)
         return out
 
     def do_fbank(self, fname):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 6
+#define ABN_ABI_VERSION 7
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -245,11 +245,20 @@ int abn_mvn_apply(const float* feats, int64_t T, int64_t D, const float* mean,
 /* FeaturesGenerator.do_fbank, abnet3/features.py:99-114 (-> third-party
  * spectral.Spectral): int16 or fp32 mono samples -> [nframes, nfilt] log mel
  * energies.  melbank: [nfft/2+1, nfilt] fp32 weights (host side builds it,
- * abnet3_amd/features.py), window: [wlen] fp32. */
+ * abnet3_amd/features.py), window: [wlen] fp32.  band: [nfilt][2] int32 (device), first and
+ * last bin with a non-zero weight of every filter; with it (and nfft = 1024, the
+ * reference's value, nfilt <= 64) a frame is one wavefront's real-input FFT and a sparse mel
+ * projection; NULL selects the general (any power-of-two nfft, dense projection) kernel. */
 int abn_fbank(const void* samples, int sample_is_i16, int64_t nsamples,
               int32_t wlen, double fshift, int32_t nfft, int32_t nfilt,
-              float alpha, const float* window, const float* melbank,
+              float alpha, const float* window, const float* melbank, const int32_t* band,
               int64_t nframes, float* out, void* stream);
+
+/* do_deltas / do_deltasdeltas of the same call (abnet3/features.py:110-111 -> spectral):
+ * the slope over +-4 frames, out[t] = sum_{n=1..4} n (x[t+n] - x[t-n]) / 60, the sequence
+ * padded with copies of frame 1 in front and of frame T-2 behind.  Apply twice for the
+ * second-order deltas.  feats, out: [T, D] fp32, distinct buffers. */
+int abn_deltas(const float* feats, int64_t T, int64_t D, float* out, void* stream);
 
 #ifdef __cplusplus
 }

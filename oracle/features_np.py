@@ -116,6 +116,35 @@ def fbank(sig, fs, nfilt=40, alpha=0.97, frate=100, wlen=0.025, nfft=1024,
     return out
 
 
+def deltas(x):
+    """do_deltas of the Spectral call (features.py:110): the package's regression deltas --
+    a 9-tap slope filter, delta[t] = sum_{n=1..4} n (x[t+n] - x[t-n]) / 60 (60 = 2 sum n^2),
+    the sequence padded with 4 copies of frame 1 in front and 4 copies of frame T-2 behind
+    (the package pads with its second and second-to-last frames).  PARITY UNPINNED like the
+    rest of the filterbank arithmetic; second-order deltas are deltas(deltas(x))."""
+    x = np.asarray(x, dtype=np.float64)
+    T = x.shape[0]
+    first = x[1] if T >= 2 else x[0]
+    last = x[T - 2] if T >= 2 else x[0]
+    g = np.vstack([np.tile(first, (4, 1)), x, np.tile(last, (4, 1))])
+    out = np.zeros_like(x)
+    for n in range(1, 5):
+        out += n * (g[4 + n:4 + n + T] - g[4 - n:4 - n + T])
+    return (out / 60.0).astype(np.float32)
+
+
+def fbank_with_deltas(sig, fs, do_deltas=True, do_deltasdeltas=True, **kw):
+    """[T, nfilt * (1 + deltas + deltasdeltas)]: static energies, then the slopes."""
+    fb = fbank(sig, fs, **kw)
+    cols = [fb]
+    d1 = deltas(fb)
+    if do_deltas:
+        cols.append(d1)
+    if do_deltasdeltas:
+        cols.append(deltas(d1))
+    return np.hstack(cols).astype(np.float32)
+
+
 def mvn(features, per_channel, stats_on=None, params=None):
     """abnet3/features.py:216-244 (and :283-293 per file): mean = np.mean,
     std = np.std over axis 0 (per channel) or None (whole spectrum) of

@@ -70,7 +70,7 @@ def test_host_side_sizing_and_argument_errors(lib):
     assert lib.abn_pair_loss(None, None, None, 2, 4, 4, 0, 0.5, 1, None, None, None, None, None) == -1
     assert lib.abn_stack_frames(None, 10, 40, 4, None, None) == -1      # even nframes
     assert b'odd' in lib.abn_last_error()
-    assert lib.abn_fbank(None, 1, 100, 400, 160.0, 1000, 40, 0.97, None, None, 1, None, None) == -1
+    assert lib.abn_fbank(None, 1, 100, 400, 160.0, 1000, 40, 0.97, None, None, None, 1, None, None) == -1
 
 
 def test_dtw_workspace_planning(lib):

@@ -256,13 +256,38 @@ def test_fbank_matches_oracle(fs, n):
     fb = fg.fbank_from_samples(sig, fs).cpu().numpy()
     ref = F.fbank(sig, fs)
     assert fb.shape == ref.shape == (F.frame_count(n, fs), 40) and fb.dtype == np.float32
-    # log energies ~ 10..25; fp32 FFT against the fp64 definition
-    assert np.abs(fb - ref).max() < 2e-3
+    # log energies ~ 10..25; fp32 FFT against the fp64 definition: 5e-5 absolute
+    assert np.abs(fb - ref).max() < 5e-5, np.abs(fb - ref).max()
     # float input path and silence floor
     fbf = fg.fbank_from_samples(sig.astype(np.float32), fs).cpu().numpy()
     assert np.abs(fbf - fb).max() < 1e-5
     z = fg.fbank_from_samples(np.zeros(2000, dtype=np.int16), fs).cpu().numpy()
     assert np.allclose(z, np.log(1e-5))
+
+
+def test_fbank_general_kernel_and_deltas():
+    """nfft != 1024 takes the general kernel; deltas / deltasdeltas (features.py:110-111)
+    append the 9-tap regression slopes of oracle/features_np.py as further columns."""
+    from abnet3_amd.features import FeaturesGenerator
+    from oracle import features_np as F
+    fs, n = 16000, 9000
+    rng = np.random.default_rng(4)
+    t = np.arange(n) / fs
+    sig = (1500 * np.sin(2 * np.pi * 440 * t) + 300 * rng.standard_normal(n)).astype(np.int16)
+    fg = FeaturesGenerator()
+    for nfft in (512, 2048):
+        fb = fg.fbank_from_samples(sig, fs, nfft=nfft).cpu().numpy()
+        assert np.abs(fb - F.fbank(sig, fs, nfft=nfft)).max() < 2e-4
+    for d, dd in ((True, False), (True, True), (False, True)):
+        fg = FeaturesGenerator(deltas=d, deltasdeltas=dd)
+        got = fg.fbank_from_samples(sig, fs).cpu().numpy()
+        ref = F.fbank_with_deltas(sig, fs, do_deltas=d, do_deltasdeltas=dd)
+        assert got.shape == ref.shape == (F.frame_count(n, fs), 40 * (1 + d + dd))
+        assert np.abs(got - ref).max() < 5e-5
+    # two-frame and one-frame inputs: the padding rule needs no neighbour that does not exist
+    for m in (1, 170):
+        short = fg.fbank_from_samples(sig[:m], fs).cpu().numpy()
+        assert np.abs(short - F.fbank_with_deltas(sig[:m], fs, do_deltas=False, do_deltasdeltas=True)).max() < 5e-5
 
 
 def test_embedder_matches_eval_forward():

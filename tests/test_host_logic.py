@@ -131,8 +131,8 @@ def test_mel_filterbank_equals_oracle_definition():
         assert np.abs(mel_filterbank(fs) - F.mel_filterbank(fs)).max() < 1e-15
     with pytest.raises(ValueError):
         mel_filterbank(8000)
-    with pytest.raises(NotImplementedError):
-        FeaturesGenerator(deltas=True)
+    fg = FeaturesGenerator(deltas=True, deltasdeltas=True)     # accepted like in the reference (features.py:110-111)
+    assert fg.deltas and fg.deltasdeltas
 
 
 def test_reference_is_never_needed_at_run_time():

@@ -201,3 +201,19 @@ def test_fbank_shape_and_sanity():
     # float32 pipeline stays close to the float64 definition
     fb32 = F.fbank(sig, fs, dtype=np.float32)
     assert np.abs(fb32 - fb).max() < 1e-4
+
+
+def test_deltas_definition():
+    """9-tap regression slope: exact on a linear ramp away from the edges, zero on a
+    constant, the padding uses frame 1 / frame T-2."""
+    T, Dm = 30, 3
+    ramp = np.arange(T, dtype=np.float32)[:, None] * np.array([1.0, -2.0, 0.5], dtype=np.float32)
+    d = F.deltas(ramp)
+    assert np.allclose(d[4:-4], [1.0, -2.0, 0.5], atol=1e-6)
+    assert np.allclose(F.deltas(np.ones((10, 2), dtype=np.float32)), 0.0)
+    x = np.random.default_rng(0).standard_normal((12, 2)).astype(np.float32)
+    d = F.deltas(x)
+    manual0 = sum(n * (x[n] - x[1]) for n in range(1, 5)) / 60.0       # t = 0: every x[t-n] is the pad = x[1]
+    assert np.allclose(d[0], manual0, atol=1e-6)
+    dd = F.fbank_with_deltas(np.zeros(4000, dtype=np.int16), 16000)
+    assert dd.shape == (26, 120) and np.allclose(dd[:, 40:], 0.0)
