@@ -132,6 +132,7 @@ __device__ __forceinline__ void dft8(cf* v)
 }
 
 constexpr int FB_WAVES = 4;            // wavefronts (frames in flight) per workgroup
+constexpr int FB_SPARSE_MAX = 2048;    // floats of LDS for the filters' non-zero weights (40 mel triangles: ~1000)
 
 __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __restrict__ samples, int is_i16,
                                                                   int64_t nsamples, int wlen, double fshift, int nfilt,
@@ -142,6 +143,8 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
 {
     __shared__ cf zbuf[FB_WAVES][512];
     __shared__ float pw[FB_WAVES][516];
+    __shared__ float sw[FB_SPARSE_MAX];          // the filters' non-zero weights, filter after filter
+    __shared__ int swoff[65];
     const int wave = threadIdx.x >> 6, j = threadIdx.x & 63;
     cf* const z = zbuf[wave];
     float* const power = pw[wave];
@@ -162,8 +165,20 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
         sincospif(-2.0f * (float)(j + 64 * q) / 1024.0f, &sn, &cs);
         tws[q] = {cs, sn};
     }
-    // this lane's filter: its band of bins
+    // this lane's filter: its band of bins; the band's weights go to LDS once per workgroup
     const int blo = j < nfilt ? band[2 * j] : 1, bhi = j < nfilt ? band[2 * j + 1] : 0;
+    if (wave == 0) {
+        int off = 0;
+        for (int f = 0; f < j && f < nfilt; ++f) off += max(band[2 * f + 1] - band[2 * f] + 1, 0);
+        swoff[j] = off;
+        if (j == 63) swoff[64] = 0;
+        const int width = max(bhi - blo + 1, 0);
+        if (off + width <= FB_SPARSE_MAX)
+            for (int i = 0; i < width; ++i) sw[off + i] = melbank[(int64_t)(blo + i) * nfilt + j];
+    }
+    __syncthreads();
+    const int myoff = swoff[j];
+    const bool sparse_ok = __all(myoff + max(bhi - blo + 1, 0) <= FB_SPARSE_MAX);
     // window taps of the samples this lane touches: elements m = j + 64 r, samples 2m, 2m+1
     float w0[8], w1[8];
 #pragma unroll
@@ -252,7 +267,21 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
         __builtin_amdgcn_wave_barrier();
         // mel projection + log
         float e = 0.0f;
-        for (int k = blo; k <= bhi; ++k) e = fmaf(power[k], melbank[(int64_t)k * nfilt + j], e);
+        if (sparse_ok) {                               // four independent partial sums: the LDS reads pipeline
+            const float* pk = power + blo;
+            const float* wk = sw + myoff;
+            const int width = bhi - blo + 1;
+            float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+            int i = 0;
+            for (; i + 3 < width; i += 4) {
+                e0 = fmaf(pk[i], wk[i], e0); e1 = fmaf(pk[i + 1], wk[i + 1], e1);
+                e2 = fmaf(pk[i + 2], wk[i + 2], e2); e3 = fmaf(pk[i + 3], wk[i + 3], e3);
+            }
+            for (; i < width; ++i) e0 = fmaf(pk[i], wk[i], e0);
+            e = (e0 + e1) + (e2 + e3);
+        } else {
+            for (int k = blo; k <= bhi; ++k) e = fmaf(power[k], melbank[(int64_t)k * nfilt + j], e);
+        }
         if (j < nfilt) out[frame * nfilt + j] = logf(fmaxf(e, FB_FLOOR));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
