@@ -44,6 +44,8 @@ SYMBOLS = {
     'abn_pair_loss_ws_bytes': (_i64, [_i64]),
     'abn_pair_loss': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, C.c_int,
                                  _f32, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    'abn_pair_loss_dz': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, C.c_int, _f32, C.c_int, C.c_int,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'abn_optimizer_step': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _f32,
                                       _f32, _f32, _f32, _i64, _f32, _vp]),
     'abn_dtw_ws_bytes': (_i64, [_vp, _vp, _i64, _i64, _i64]),
@@ -71,7 +73,7 @@ class TowerDesc(C.Structure):
                 ('batch_norm', _i32), ('dims', _i64 * (MAX_LAYERS + 1))] + [
         (name, _vp * MAX_LAYERS)
         for name in ('W', 'b', 'bn_w', 'bn_b', 'bn_rm', 'bn_rv', 'dW', 'db',
-                     'dbn_w', 'dbn_b', 'drop_mask')] + [('precision', _i32), ('reserved_', _i32)]
+                     'dbn_w', 'dbn_b', 'drop_mask')] + [('precision', _i32), ('d_out_is_dz', _i32)]
 
 
 class HipLibraryError(RuntimeError):

@@ -12,6 +12,7 @@
 // d cos/d e is a difference of nearly equal terms, which fp32 evaluates with
 // 1e-4 relative noise (see DESIGN.md "parity").
 #include "common.h"
+#include "gemm_f32.h"      // act_grad
 
 namespace abn {
 
@@ -44,9 +45,14 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
                                                         const void* __restrict__ y, int y_dtype, int64_t B, int D,
                                                         int kind, double margin, double scale,
                                                         float* __restrict__ de1, float* __restrict__ de2,
-                                                        double* __restrict__ partial)
+                                                        int act, const float* __restrict__ mask1,
+                                                        const float* __restrict__ mask2,
+                                                        double* __restrict__ partial, unsigned* __restrict__ counter,
+                                                        float* __restrict__ loss_out)
 {
     __shared__ double row_term[ROWS_PER_BLOCK];
+    __shared__ double sh[256];
+    __shared__ int is_last;
     const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + sub;
     double term = 0.0;
@@ -106,14 +112,27 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
                     o1.y = (float)(v.y * inv - u.y * k1); o2.y = (float)(u.y * inv - v.y * k2);
                     o1.z = (float)(v.z * inv - u.z * k1); o2.z = (float)(u.z * inv - v.z * k2);
                     o1.w = (float)(v.w * inv - u.w * k1); o2.w = (float)(u.w * inv - v.w * k2);
+                    if (act != ACT_NONE) {      // d loss / d z of the layer that produced e = act(z): what act_bwd_kernel computes
+                        o1.x *= act_grad(u.x, act); o1.y *= act_grad(u.y, act); o1.z *= act_grad(u.z, act); o1.w *= act_grad(u.w, act);
+                        o2.x *= act_grad(v.x, act); o2.y *= act_grad(v.y, act); o2.z *= act_grad(v.z, act); o2.w *= act_grad(v.w, act);
+                    }
+                    if (mask1) {
+                        const float4 m1 = reinterpret_cast<const float4*>(mask1 + row * D)[c];
+                        const float4 m2 = reinterpret_cast<const float4*>(mask2 + row * D)[c];
+                        o1.x *= m1.x; o1.y *= m1.y; o1.z *= m1.z; o1.w *= m1.w;
+                        o2.x *= m2.x; o2.y *= m2.y; o2.z *= m2.z; o2.w *= m2.w;
+                    }
                     reinterpret_cast<float4*>(g1)[c] = o1;
                     reinterpret_cast<float4*>(g2)[c] = o2;
                 }
             } else {
                 for (int c = l; c < D; c += 32) {
                     const double u = a[c], v = b[c];
-                    g1[c] = (float)(v * inv - u * k1);
-                    g2[c] = (float)(u * inv - v * k2);
+                    float q1 = (float)(v * inv - u * k1), q2 = (float)(u * inv - v * k2);
+                    if (act != ACT_NONE) { q1 *= act_grad(a[c], act); q2 *= act_grad(b[c], act); }
+                    if (mask1) { q1 *= mask1[row * D + c]; q2 *= mask2[row * D + c]; }
+                    g1[c] = q1;
+                    g2[c] = q2;
                 }
             }
         }
@@ -124,24 +143,29 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
         double s = 0.0;
 #pragma unroll
         for (int i = 0; i < ROWS_PER_BLOCK; ++i) s += row_term[i];
-        partial[blockIdx.x] = s;
+        // write-through store, then the ticket: the workgroup that draws the last ticket sums
+        // all partials in a FIXED order (deterministic, unlike an atomic sum) -- the second
+        // launch this used to take
+        __hip_atomic_store(&partial[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = ticket == gridDim.x - 1;
     }
-}
-
-// fixed-order sum of the per-block partials (deterministic)
-__global__ __launch_bounds__(256) void pair_loss_final_kernel(const double* __restrict__ partial, int64_t n, double scale,
-                                                              float* __restrict__ loss_out)
-{
-    __shared__ double sh[256];
+    __syncthreads();
+    if (!is_last) return;
+    const int64_t n = gridDim.x;
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += partial[i];
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *loss_out = (float)(sh[0] * scale);
+    if (threadIdx.x == 0) {
+        *loss_out = (float)(sh[0] * scale);
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next call
+    }
 }
 
 }  // namespace abn
@@ -153,11 +177,12 @@ extern "C" {
 int64_t abn_pair_loss_ws_bytes(int64_t B)
 {
     const int64_t blocks = (B + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    return (blocks < 1 ? 1 : blocks) * (int64_t)sizeof(double);
+    return 8 + (blocks < 1 ? 1 : blocks) * (int64_t)sizeof(double);       // the ticket counter, then the partial sums
 }
 
-int abn_pair_loss(const float* e1, const float* e2, const void* y, int y_dtype, int64_t B, int64_t D, int kind,
-                  float margin, int avg, float* loss_out, float* de1, float* de2, void* ws, void* stream)
+static int pair_loss_impl(const float* e1, const float* e2, const void* y, int y_dtype, int64_t B, int64_t D, int kind,
+                          float margin, int avg, float* loss_out, float* de1, float* de2, int act, const float* mask1,
+                          const float* mask2, void* ws, void* stream)
 {
     ABN_REQUIRE(e1 && e2 && y && loss_out && ws, "pair_loss: null pointer");
     ABN_REQUIRE((de1 == nullptr) == (de2 == nullptr), "pair_loss: de1/de2 must both be given or both be NULL");
@@ -165,20 +190,38 @@ int abn_pair_loss(const float* e1, const float* e2, const void* y, int y_dtype, 
     ABN_REQUIRE(kind == ABN_LOSS_COSCOS2 || kind == ABN_LOSS_COSMARGIN, "pair_loss: unknown loss kind %d", kind);
     ABN_REQUIRE(y_dtype >= ABN_Y_I8 && y_dtype <= ABN_Y_F64, "pair_loss: unknown label dtype %d", y_dtype);
     ABN_REQUIRE(!(kind == ABN_LOSS_COSMARGIN) || (margin >= 0.0f && margin <= 1.0f), "pair_loss: margin outside [0,1]");
+    ABN_REQUIRE(act >= ABN_ACT_NONE && act <= ABN_ACT_TANH, "pair_loss: unsupported activation %d", act);
+    ABN_REQUIRE((mask1 == nullptr) == (mask2 == nullptr), "pair_loss: mask1/mask2 must both be given or both be NULL");
     hipStream_t st = (hipStream_t)stream;
     const int64_t blocks = (B + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     const double scale = avg ? 1.0 / (double)B : 1.0;
-    const bool vec = (D % 4 == 0) && aligned16(e1) && aligned16(e2) && (!de1 || (aligned16(de1) && aligned16(de2)));
-    double* partial = (double*)ws;
+    const bool vec = (D % 4 == 0) && aligned16(e1) && aligned16(e2) && (!de1 || (aligned16(de1) && aligned16(de2))) &&
+                     (!mask1 || (aligned16(mask1) && aligned16(mask2)));
+    unsigned* counter = (unsigned*)ws;                       // first 8 bytes: the ticket counter (fixed place whatever B is)
+    double* partial = (double*)((char*)ws + 8);
     if (vec)
         hipLaunchKernelGGL(pair_loss_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, e1, e2, y, y_dtype, B,
-                           (int)D, kind, (double)margin, scale, de1, de2, partial);
+                           (int)D, kind, (double)margin, scale, de1, de2, act, mask1, mask2, partial, counter, loss_out);
     else
         hipLaunchKernelGGL(pair_loss_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, e1, e2, y, y_dtype, B,
-                           (int)D, kind, (double)margin, scale, de1, de2, partial);
-    hipLaunchKernelGGL(pair_loss_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks, scale, loss_out);
+                           (int)D, kind, (double)margin, scale, de1, de2, act, mask1, mask2, partial, counter, loss_out);
     ABN_CHECK_LAUNCH("pair_loss");
     return ABN_OK;
+}
+
+int abn_pair_loss(const float* e1, const float* e2, const void* y, int y_dtype, int64_t B, int64_t D, int kind,
+                  float margin, int avg, float* loss_out, float* de1, float* de2, void* ws, void* stream)
+{
+    return pair_loss_impl(e1, e2, y, y_dtype, B, D, kind, margin, avg, loss_out, de1, de2, ABN_ACT_NONE, nullptr, nullptr, ws,
+                          stream);
+}
+
+int abn_pair_loss_dz(const float* e1, const float* e2, const void* y, int y_dtype, int64_t B, int64_t D, int kind,
+                     float margin, int avg, int act, const float* mask1, const float* mask2, float* loss_out, float* dz1,
+                     float* dz2, void* ws, void* stream)
+{
+    ABN_REQUIRE(dz1 && dz2, "pair_loss_dz: null gradient buffers");
+    return pair_loss_impl(e1, e2, y, y_dtype, B, D, kind, margin, avg, loss_out, dz1, dz2, act, mask1, mask2, ws, stream);
 }
 
 }  // extern "C"

@@ -673,13 +673,17 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     const float* xin = x2 ? ws + L.x : x1;
     const int nl = t->n_layers;
     int cur = 0;
+    const float* dz_in = nullptr;                // the output layer's dz when the caller supplied it
 
     // dz of the output layer from d_out
     {
         const int N = (int)t->dims[nl];
         const float* a = ws + L.a[nl - 1];
         float* dz = scratch + B.dz[cur];
-        if (!t->batch_norm) {
+        if (t->d_out_is_dz) {
+            ABN_REQUIRE(!t->batch_norm, "tower_backward: d_out_is_dz cannot be combined with batch_norm");
+            dz_in = d_out;                       // abn_pair_loss_dz already applied act' and the dropout mask
+        } else if (!t->batch_norm) {
             hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, a, d_out,
                                t->drop_mask[nl - 1], dz, rows * N, t->last_act);
         } else {
@@ -700,7 +704,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     float* slabs = scratch + B.slabs;
     for (int l = nl - 1; l >= 0; --l) {
         const int Kin = (int)t->dims[l], Nout = (int)t->dims[l + 1];
-        const float* dz = scratch + B.dz[cur];
+        const float* dz = (l == nl - 1 && dz_in) ? dz_in : scratch + B.dz[cur];
         const float* a_in = (l == 0) ? xin : ws + L.a[l - 1];
         // wgrad: dW[Nout, Kin] (+ db via the ones column) = dz^T a_in, split over rows
         GemmP pw = {};

@@ -32,8 +32,27 @@ def unit_grad(device):
     return t
 
 
-def _pair_loss_raw(e1, e2, y, kind, margin, avg, need_grad):
-    """abn_pair_loss: (0-dim loss, [2, B, D] gradient of the loss w.r.t. (e1, e2) or None)."""
+_WS = {}          # (device index, stream) -> zero-initialised scratch (partial sums + ticket counter)
+
+
+def _scratch(nbytes, device):
+    """abn_pair_loss's scratch: its ticket counter has to be zero before the first call and is
+    left zero by every call, so one buffer per (device, stream) is zeroed once and reused."""
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture: a buffer of the graph's own pool, zeroed by a captured memset
+        return torch.zeros(max(int(nbytes), 4096), dtype=torch.uint8, device=device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS[key] = torch.zeros(max(int(nbytes), 4096), dtype=torch.uint8, device=device)
+    return ws
+
+
+def _pair_loss_raw(e1, e2, y, kind, margin, avg, need_grad, act=None, masks=None):
+    """abn_pair_loss: (0-dim loss, [2, B, D] gradient of the loss w.r.t. (e1, e2) or None).
+    With `act` (the activation that produced e1 / e2) the gradient is taken w.r.t. the
+    pre-activations instead (abn_pair_loss_dz; `masks` = the output layer's dropout
+    multipliers for the two towers, or None)."""
     lib = _lib.load()
     _lib.require_device(e1, e2, y)
     if e1.dtype != torch.float32 or e2.dtype != torch.float32:
@@ -46,7 +65,15 @@ def _pair_loss_raw(e1, e2, y, kind, margin, avg, need_grad):
     e1, e2, y = e1.contiguous(), e2.contiguous(), y.contiguous()
     loss = torch.empty((), dtype=torch.float32, device=e1.device)
     de = torch.empty(2, B, D, dtype=torch.float32, device=e1.device) if need_grad else None
-    ws = torch.empty(lib.abn_pair_loss_ws_bytes(B), dtype=torch.uint8, device=e1.device)
+    ws = _scratch(lib.abn_pair_loss_ws_bytes(B), e1.device)
+    if act is not None:
+        m1, m2 = masks if masks is not None else (None, None)
+        _lib.check(lib.abn_pair_loss_dz(
+            _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(y), _lib.Y_DTYPE[y.dtype], B, D,
+            _lib.LOSS[kind], float(margin), int(bool(avg)), _lib.ACT[act], _lib.ptr(m1), _lib.ptr(m2),
+            _lib.ptr(loss), _lib.ptr(de[0]), _lib.ptr(de[1]), _lib.ptr(ws), _lib.stream()),
+            'abn_pair_loss_dz')
+        return loss, de
     _lib.check(lib.abn_pair_loss(
         _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(y), _lib.Y_DTYPE[y.dtype], B, D,
         _lib.LOSS[kind], float(margin), int(bool(avg)), _lib.ptr(loss),
@@ -112,6 +139,13 @@ class coscos2(LossBuilder):
         assert input1.size() == input2.size(), 'Input not the same size'
         return _pair_loss_raw(input1, input2, y, 'coscos2', 0.0, self.avg, True)
 
+    def value_and_dz(self, input1, input2, y, act, masks=None):
+        """(loss, [2, B, D] gradient w.r.t. the PRE-activations of the layer that produced the
+        inputs through `act`): the loss gradient and the output layer's activation derivative
+        in one launch."""
+        assert input1.size() == input2.size(), 'Input not the same size'
+        return _pair_loss_raw(input1, input2, y, 'coscos2', 0.0, self.avg, True, act=act, masks=masks)
+
 
 class cosmargin(LossBuilder):
     """cosmargin Loss function (abnet3/loss.py:70-105); margin in [0, 1]."""
@@ -129,6 +163,10 @@ class cosmargin(LossBuilder):
     def value_and_grad(self, input1, input2, y):
         assert input1.size() == input2.size(), 'Input not the same size'
         return _pair_loss_raw(input1, input2, y, 'cosmargin', self.margin, self.avg, True)
+
+    def value_and_dz(self, input1, input2, y, act, masks=None):
+        assert input1.size() == input2.size(), 'Input not the same size'
+        return _pair_loss_raw(input1, input2, y, 'cosmargin', self.margin, self.avg, True, act=act, masks=masks)
 
 
 class weighted_loss_multi(LossBuilder):

@@ -145,13 +145,14 @@ class _Segment(object):
         self._desc_cache = (key, d, grad_slots)
         return d
 
-    def descriptor(self, with_grads, grad_buf=None, masks=None):
+    def descriptor(self, with_grads, grad_buf=None, masks=None, d_out_is_dz=False):
         """abn_tower_desc for one call.  grad_buf: the flat gradient buffer of this
         backward pass (gradients land at the parameters' offsets in it)."""
         tmpl = self._template()
         if not with_grads and masks is None:
             return tmpl                        # read-only for the library
         d = _lib.TowerDesc.from_buffer_copy(tmpl)
+        d.d_out_is_dz = int(d_out_is_dz)
         if masks is not None:
             for l, m in enumerate(masks):
                 d.drop_mask[l] = m.data_ptr()
@@ -239,7 +240,7 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2):
     return out, sv
 
 
-def _segment_backward(seg, sv, d_out, grad_pass, need_dx):
+def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False):
     """Raw backward of one segment: abn_tower_backward into the pass's flat gradient
     buffer.  Returns (per-parameter gradient views, dx or None)."""
     lib = _lib.load()
@@ -252,7 +253,7 @@ def _segment_backward(seg, sv, d_out, grad_pass, need_dx):
     _lib.require_device(d_out)
     rows = d_out.shape[0]
     grad_buf, grads = grad_pass.views(seg)
-    desc = seg.descriptor(with_grads=True, grad_buf=grad_buf, masks=sv.masks)
+    desc = seg.descriptor(with_grads=True, grad_buf=grad_buf, masks=sv.masks, d_out_is_dz=d_out_is_dz)
     scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
     scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32, device=d_out.device)
     dx = torch.empty(rows, seg.input_dim, dtype=torch.float32,
@@ -632,12 +633,26 @@ class SiameseNetwork(_HipNetwork):
         out, sv = _segment_forward(seg, masks, 2, x1, x2)
         return out, (seg, sv, _GradPass(self))
 
-    def direct_backward(self, state, d_out):
+    def direct_dz_info(self, state):
+        """What the pair loss needs to hand back d loss / d z of the output layer itself
+        (abn_pair_loss_dz): (activation name, (mask tower 1, mask tower 2) | None), or None when
+        the tower's backward must start from d loss / d e (BatchNorm in front of the activation)."""
+        seg, sv, _ = state
+        if seg.batch_norm:
+            return None
+        masks = None
+        if sv.masks is not None:
+            m = sv.masks[-1]
+            half = m.shape[0] // 2
+            masks = (m[:half], m[half:])
+        return seg.last_act, masks
+
+    def direct_backward(self, state, d_out, d_out_is_dz=False):
         """Backward of direct_forward: gradients of every parameter land in a fresh
         flat buffer and are installed as p.grad (views), exactly what autograd's
         backward leaves behind."""
         seg, sv, grad_pass = state
-        grads, _ = _segment_backward(seg, sv, d_out, grad_pass, False)
+        grads, _ = _segment_backward(seg, sv, d_out, grad_pass, False, d_out_is_dz)
         for p, g in zip(seg.params, grads):
             p.grad = g
 

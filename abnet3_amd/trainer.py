@@ -311,9 +311,14 @@ class TrainerSiamese(TrainerBuilder):
             y_batch = y_batch.cuda(non_blocking=True)
             emb, state = self.network.direct_forward(X_batch1, X_batch2)
             n = X_batch1.shape[0]
-            loss_value, de = self.loss.value_and_grad(emb[:n], emb[n:], y_batch)
+            info = self.network.direct_dz_info(state)
             self.optimizer.zero_grad()
-            self.network.direct_backward(state, de.view(2 * n, -1))
+            if info is not None:      # loss gradient and the output layer's act' (+ dropout) in ONE launch
+                loss_value, dz = self.loss.value_and_dz(emb[:n], emb[n:], y_batch, info[0], info[1])
+                self.network.direct_backward(state, dz.view(2 * n, -1), d_out_is_dz=True)
+            else:
+                loss_value, de = self.loss.value_and_grad(emb[:n], emb[n:], y_batch)
+                self.network.direct_backward(state, de.view(2 * n, -1))
             if self.world_size > 1:
                 self.optimizer.grad_scale = parallel.all_reduce_gradients(
                     self.network.flat_grad(), self._loss_is_mean())

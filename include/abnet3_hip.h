@@ -88,9 +88,15 @@ typedef struct abn_tower_desc {
     const float* drop_mask[ABN_MAX_LAYERS];
     /* 0 = fp32 on the exact-fp32 MFMA (the parity path, default); 1 = throughput mode:
      * matrix operands rounded to bf16 at fragment time, fp32 accumulation, everything
-     * else (storage, BatchNorm, loss, optimizer) still fp32.  NOT within the 1e-5 bar. */
+     * else (storage, BatchNorm, loss, optimizer) still fp32.  NOT within the 1e-5 bar.
+     * 2 = bf16 x 3: every operand split into three bf16 terms, six bf16 MFMAs per product
+     * block: fp32-grade results (as close to a float64 evaluation as mode 0 is) that are not
+     * bit-identical to mode 0. */
     int32_t precision;
-    int32_t reserved_;
+    /* backward only: d_out already IS d loss / d z of the output layer (abn_pair_loss_dz), so
+     * the activation derivative / dropout step in front of the last layer's GEMMs is skipped.
+     * Not with batch_norm (its backward needs d loss / d a). */
+    int32_t d_out_is_dz;
 } abn_tower_desc;
 
 /* Workspace of one forward call (saved activations for backward), in floats,
@@ -149,12 +155,24 @@ int abn_linear_backward(const float* dz, const float* W, const float* a_in, int6
  * abnet3/loss.py:46-67 and :85-105 (nn.CosineSimilarity(dim=1, eps=1e-6)).
  * loss_out: device scalar (fp32).  de1/de2: [B, D] gradients of the (already
  * /B-scaled when avg) loss; both may be NULL for a forward-only call.
- * ws: abn_pair_loss_ws_bytes(B) bytes of device scratch. */
+ * ws: abn_pair_loss_ws_bytes(B) bytes of device scratch whose FIRST 8 bytes (a ticket
+ * counter) must be zero before the first call on this buffer; every call leaves them zero
+ * (ONE launch: the workgroup that finishes last sums the per-workgroup partial losses in a
+ * fixed order).  Calls sharing a ws buffer must be ordered on one stream. */
 int64_t abn_pair_loss_ws_bytes(int64_t B);
 int abn_pair_loss(const float* e1, const float* e2, const void* y, int y_dtype,
                   int64_t B, int64_t D, int kind, float margin, int avg,
                   float* loss_out, float* de1, float* de2, void* ws,
                   void* stream);
+/* The same with the output layer's activation derivative (and dropout multipliers, mask1 /
+ * mask2 [B, D] or NULL) folded in: e1 / e2 are the tower's outputs act(z), and dz1 / dz2
+ * receive d loss / d z = d loss / d e * act'(e) [* mask] -- the first step of
+ * loss.backward() (abnet3/trainer.py:239) through a tower without BatchNorm.  Hand
+ * [dz1; dz2] to abn_tower_backward with abn_tower_desc.d_out_is_dz = 1. */
+int abn_pair_loss_dz(const float* e1, const float* e2, const void* y, int y_dtype,
+                     int64_t B, int64_t D, int kind, float margin, int avg, int act,
+                     const float* mask1, const float* mask2, float* loss_out,
+                     float* dz1, float* dz2, void* ws, void* stream);
 
 /* torch.optim.{SGD(momentum),Adadelta,Adam,Adagrad,RMSprop}.step over one flat
  * fp32 parameter buffer (abnet3/trainer.py:68-87, :240).  state1/state2: flat

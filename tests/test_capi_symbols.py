@@ -64,7 +64,7 @@ def test_host_side_sizing_and_argument_errors(lib):
     assert b'divisible' in lib.abn_last_error()
     d.n_layers = 99
     assert lib.abn_tower_ws_floats(ctypes.byref(d), rows, 2) == -1
-    assert lib.abn_pair_loss_ws_bytes(4096) == 512 * 8
+    assert lib.abn_pair_loss_ws_bytes(4096) == 512 * 8 + 8      # per-workgroup partial sums + the ticket counter
     assert lib.abn_linear_wgrad_scratch_floats(8192, 500, 500) == 16 * 250560
     # argument validation happens before any launch
     assert lib.abn_pair_loss(None, None, None, 2, 4, 4, 0, 0.5, 1, None, None, None, None, None) == -1
