@@ -274,6 +274,162 @@ __device__ __forceinline__ f32x4 frag_read(const float* __restrict__ lds, int ro
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// PREC 3 = bf16 x 3 with the split done ONCE per tile, when the tile is committed to LDS (PREC 2
+// splits at fragment time: every wave re-splits what it reads, and the kernel turns VALU-bound).
+// An operand tile [BMN rows][32 k] lives in LDS as THREE bf16 planes (hi, mid, lo) of 64-byte
+// rows; 16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3): a lane's MFMA operand (8
+// consecutive k of one row) is one ds_read_b128, conflict-free for the 16-lane groups, whichever
+// way the tile was filled.  k-major operands (dgrad's W, both wgrad operands) are transposed on
+// the way in: a thread owns 4 consecutive k of 4 consecutive rows (4 float4 loads), splits the
+// 16 values and writes, per row and plane, the 4 k as 8 bytes.
+// ---------------------------------------------------------------------------------------------
+template <int BMN> struct Tile3 {
+    static constexpr int plane_bytes = BMN * 64;
+    static constexpr int bytes = 3 * plane_bytes;
+    static constexpr int units = BMN * BK / 4;
+    static constexpr int per_thread = units / 256;
+};
+__device__ __forceinline__ int t3_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// four fp32 -> 4 x (hi, mid, lo) bf16, each quadruple packed into 8 bytes
+__device__ __forceinline__ void split4(const float v0, const float v1, const float v2, const float v3, uint2& hi, uint2& mid,
+                                       uint2& lo)
+{
+    const float v[4] = {v0, v1, v2, v3};
+    uint16_t h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 bh = (__bf16)v[i];
+        const float r1 = v[i] - (float)bh;
+        const __bf16 bm = (__bf16)r1;
+        const float r2 = r1 - (float)bm;
+        const __bf16 bl = (__bf16)r2;
+        h[i] = __builtin_bit_cast(uint16_t, bh); m[i] = __builtin_bit_cast(uint16_t, bm); l[i] = __builtin_bit_cast(uint16_t, bl);
+    }
+    hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    mid = make_uint2((uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16));
+    lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+
+// unit -> (row, k) of a thread's i-th float4.  K-contiguous: the fp32 path's map.  k-major: a
+// thread's units are 4 (BMN = 128) or 2 (BMN = 64) CONSECUTIVE k of the same 4 rows.
+template <int BMN, bool KCONTIG>
+__device__ __forceinline__ void unit3(int t, int i, int& row, int& k)
+{
+    if constexpr (KCONTIG) { const int u = t + 256 * i; row = u >> 3; k = 4 * (u & 7); }
+    else {
+        constexpr int PT = Tile3<BMN>::per_thread, MG = BMN / 4;        // row groups of 4
+        row = 4 * (t % MG);
+        k = PT * (t / MG) + i;
+    }
+}
+
+template <int BMN, bool KCONTIG>
+__device__ __forceinline__ void tile3_offsets(uint32_t* voff, int64_t ld)
+{
+    constexpr int PT = Tile3<BMN>::per_thread;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        int row, k;
+        unit3<BMN, KCONTIG>((int)threadIdx.x, i, row, k);
+        voff[i] = KCONTIG ? (uint32_t)(row * (uint32_t)ld + k) : (uint32_t)(k * (uint32_t)ld + row);
+    }
+}
+
+// edge tiles: clamped loads (always valid addresses), validity applied at commit
+template <int BMN, bool KCONTIG>
+__device__ __forceinline__ void tile3_issue(f32x4* r, const float* __restrict__ X, int64_t ld, int MN, int mn0, int k0, int k_end)
+{
+    constexpr int PT = Tile3<BMN>::per_thread;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        int row, k;
+        unit3<BMN, KCONTIG>((int)threadIdx.x, i, row, k);
+        const int m = mn0 + row, kk = k0 + k;
+        const bool ok = m < MN && kk < k_end;          // 16-byte units are entirely inside or outside (VEC)
+        const int64_t off = KCONTIG ? ((int64_t)m * ld + kk) : ((int64_t)kk * ld + m);
+        r[i] = *reinterpret_cast<const f32x4*>(X + (ok ? off : 0));
+    }
+}
+
+template <int BMN, bool KCONTIG, bool INTERIOR>
+__device__ __forceinline__ void tile3_commit(const f32x4* r, char* __restrict__ lds, int MN, int mn0, int k0, int k_end, int ones_col)
+{
+    constexpr int PT = Tile3<BMN>::per_thread, PB = Tile3<BMN>::plane_bytes;
+    const int t = threadIdx.x;
+    if constexpr (KCONTIG) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            int row, k;
+            unit3<BMN, true>(t, i, row, k);
+            f32x4 v = r[i];
+            if constexpr (!INTERIOR) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (mn0 + row < MN && k0 + k + e < k_end) ? v[e] : 0.0f;
+            }
+            uint2 hi, mid, lo;
+            split4(v[0], v[1], v[2], v[3], hi, mid, lo);
+            char* dst = lds + t3_off(row, k >> 3) + (k & 4) * 2;
+            *reinterpret_cast<uint2*>(dst) = hi;
+            *reinterpret_cast<uint2*>(dst + PB) = mid;
+            *reinterpret_cast<uint2*>(dst + 2 * PB) = lo;
+        }
+    } else {
+        int row, k;
+        unit3<BMN, false>(t, 0, row, k);            // k of unit 0; units 1 .. PT-1 follow at k + 1 ...
+        f32x4 v[PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            v[i] = r[i];
+            if constexpr (!INTERIOR) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int me = mn0 + row + e, ke = k0 + k + i;
+                    float x = (me < MN && ke < k_end) ? v[i][e] : 0.0f;
+                    if (me == ones_col && ke < k_end) x = 1.0f;       // wgrad's bias column (ones_col = -1: never)
+                    v[i][e] = x;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {               // row (row + e): PT consecutive k
+            if constexpr (PT == 4) {
+                uint2 hi, mid, lo;
+                split4(v[0][e], v[1][e], v[2][e], v[3][e], hi, mid, lo);
+                char* dst = lds + t3_off(row + e, k >> 3) + (k & 4) * 2;
+                *reinterpret_cast<uint2*>(dst) = hi;
+                *reinterpret_cast<uint2*>(dst + PB) = mid;
+                *reinterpret_cast<uint2*>(dst + 2 * PB) = lo;
+            } else {
+                static_assert(PT == 2 || PT == 4, "tile3: 64- or 128-row tiles");
+                uint2 hi, mid, lo;
+                split4(v[0][e], v[1][e], 0.0f, 0.0f, hi, mid, lo);
+                char* dst = lds + t3_off(row + e, k >> 3) + (k & 7) * 2;
+                *reinterpret_cast<uint32_t*>(dst) = hi.x;
+                *reinterpret_cast<uint32_t*>(dst + PB) = mid.x;
+                *reinterpret_cast<uint32_t*>(dst + 2 * PB) = lo.x;
+            }
+        }
+    }
+}
+
+// MFMA operand of row block `row0` for the 16-deep slab `sl` of the tile: lane (r, h) takes k = 16 sl + 8 h .. + 7
+__device__ __forceinline__ bf16x8 frag3(const char* __restrict__ plane, int row0, int sl, int lane)
+{
+    const int r = row0 + (lane & 31);
+    return *reinterpret_cast<const bf16x8*>(plane + t3_off(r, 2 * sl + (lane >> 5)));
+}
+
+template <int BM, int BN>
+constexpr size_t gemm_lds_bytes3()
+{
+    constexpr size_t tiles = 2 * (size_t)(Tile3<BM>::bytes + Tile3<BN>::bytes);
+    constexpr size_t stage = sizeof(float) * BM * (BN + 4);
+    return tiles > stage ? tiles : stage;
+}
+
 // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (and its L2), so
 // hand XCD x the contiguous tile range [x*n/8, (x+1)*n/8) when n % 8 == 0.
 __device__ __forceinline__ int xcd_tile_index(int b, int n)
@@ -360,6 +516,80 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int block_id)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    if constexpr (BF16 == 3) {
+        // ---- bf16 x 3, split at commit time (see Tile3) ----
+        static_assert(VEC, "the plane image is filled from 16-byte units");
+        char* const cs = reinterpret_cast<char*>(smem);
+        constexpr int SA = Tile3<BM>::bytes, SB = Tile3<BN>::bytes, STG = SA + SB;
+        constexpr int PA = Tile3<BM>::per_thread, PBt = Tile3<BN>::per_thread;
+        f32x4 ra[PA], rb[PBt];
+        const int ones = (EPI == EPI_WGRAD) ? p.ones_col : -1;
+        const int nB = (ones >= 0) ? ones : p.N;
+        const bool a_in = m0 + BM <= p.M, b_in = n0 + BN <= nB;
+        uint32_t voa[PA], vob[PBt];
+        tile3_offsets<BM, A_KC>(voa, p.lda);
+        tile3_offsets<BN, B_KC>(vob, p.ldb);
+        const float* const a_org = p.A + (A_KC ? (int64_t)m0 * p.lda : (int64_t)m0);
+        const float* const b_org = p.B + (B_KC ? (int64_t)n0 * p.ldb : (int64_t)n0);
+        auto issue = [&](int k0) {
+            const bool k_in = k0 + BK <= ke;
+            if (a_in && k_in) {
+                const float* an = a_org + (A_KC ? (int64_t)k0 : (int64_t)k0 * p.lda);
+#pragma unroll
+                for (int i = 0; i < PA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(an + voa[i]);
+            } else tile3_issue<BM, A_KC>(ra, p.A, p.lda, p.M, m0, k0, ke);
+            if (b_in && k_in) {
+                const float* bn = b_org + (B_KC ? (int64_t)k0 : (int64_t)k0 * p.ldb);
+#pragma unroll
+                for (int i = 0; i < PBt; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bn + vob[i]);
+            } else tile3_issue<BN, B_KC>(rb, p.B, p.ldb, nB, n0, k0, ke);
+        };
+        auto commit = [&](int k0, char* st) {
+            const bool k_in = k0 + BK <= ke;
+            if (a_in && k_in) tile3_commit<BM, A_KC, true>(ra, st, p.M, m0, k0, ke, -1);
+            else tile3_commit<BM, A_KC, false>(ra, st, p.M, m0, k0, ke, -1);
+            if (b_in && k_in) tile3_commit<BN, B_KC, true>(rb, st + SA, nB, n0, k0, ke, ones);
+            else tile3_commit<BN, B_KC, false>(rb, st + SA, nB, n0, k0, ke, ones);
+        };
+        if (nkt > 0) {
+            issue(kb);
+            commit(kb, cs);
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nkt;
+            const int knext = kb + (kt + 1) * BK;
+            const char* as = cs + cur * STG;
+            const char* bs = as + SA;
+            if (more) issue(knext);                     // the loads fly behind this tile's MFMAs
+#pragma unroll
+            for (int sl = 0; sl < BK / 16; ++sl) {
+                bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fa[i][pl] = frag3(as + pl * Tile3<BM>::plane_bytes, wm0 + 32 * i, sl, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fb[j][pl] = frag3(bs + pl * Tile3<BN>::plane_bytes, wn0 + 32 * j, sl, lane);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {       // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (more) commit(knext, cs + (cur ^ 1) * STG);
+            __syncthreads();
+        }
+    } else {
     f32x4 ra[TA::per_thread], rb[TB::per_thread];
     const int ones = (EPI == EPI_WGRAD) ? p.ones_col : -1;
     // the ones column is synthesised, never read: B really has `ones` columns
@@ -503,6 +733,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int block_id)
         ABN_STAMP();
     }
 
+    }
     // Epilogue.  The accumulators go through LDS (free after the k loop) so that
     // every global access of the epilogue -- C, the bias, the dgrad's saved
     // activations -- is a full-row 16-byte access: storing straight from the

@@ -146,9 +146,12 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
         // write-through store, then the ticket: the workgroup that draws the last ticket sums
         // all partials in a FIXED order (deterministic, unlike an atomic sum) -- the second
         // launch this used to take
+        // (a write-through store that is drained before the ticket is drawn, read back with
+        // loads that bypass the L1: no release / acquire fence, which would write back and
+        // invalidate whole caches once per workgroup -- measured 23 us instead of 9 for this kernel)
         __hip_atomic_store(&partial[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = ticket == gridDim.x - 1;
     }
     __syncthreads();

@@ -32,7 +32,7 @@ template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool VEC, int BF16>
 static void launch_one(const GemmP& p, int splits, hipStream_t st)
 {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    constexpr size_t lds = gemm_lds_bytes<BM, BN, A_KC, B_KC>();
+    constexpr size_t lds = BF16 == 3 ? gemm_lds_bytes3<BM, BN>() : gemm_lds_bytes<BM, BN, A_KC, B_KC>();
     auto k = gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, VEC, BF16>;
     static bool attr_set[16] = {};     // > 64 KiB of dynamic LDS needs the opt-in, once per device
     int dev = 0;
@@ -59,7 +59,9 @@ static void launch_cfg(const GemmP& p, int splits, hipStream_t st)
         return;
     }
     if (p.bf16 == 2) {                    // bf16 x 3 (abn_tower_desc.precision = 2): fp32-grade products on the bf16 matrix cores
-        if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true, 2>(p, splits, st);
+        static const bool planes = !(getenv("ABN_BF16X3_PLANES") && atoi(getenv("ABN_BF16X3_PLANES")) == 0);   // A/B switch
+        if (p.a_vec && p.b_vec && planes) launch_one<BM, BN, A_KC, B_KC, EPI, true, 3>(p, splits, st);   // split once per tile (LDS planes)
+        else if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true, 2>(p, splits, st);
         else launch_one<BM, BN, A_KC, B_KC, EPI, false, 2>(p, splits, st);
         return;
     }
@@ -121,12 +123,19 @@ static int launch_gemm(GemmP p, int splits, hipStream_t st)
     return ABN_OK;
 }
 
+static bool bf16x3_planes()
+{
+    static const bool on = !(getenv("ABN_BF16X3_PLANES") && atoi(getenv("ABN_BF16X3_PLANES")) == 0);
+    return on;
+}
+
 // wgrad + dgrad of one backward layer in ONE grid (gemm_bwd_pair_kernel) when both take
 // their usual vectorised instantiations; otherwise two launches.
 template <int WM, int WN, int BF16>
 static void launch_pair_one(const GemmP& pw, int n0, const GemmP& pd, int n1, hipStream_t st)
 {
-    constexpr size_t lw = gemm_lds_bytes<WM, WN, false, false>(), ld = gemm_lds_bytes<128, 64, true, false>();
+    constexpr size_t lw = BF16 == 3 ? gemm_lds_bytes3<WM, WN>() : gemm_lds_bytes<WM, WN, false, false>();
+    constexpr size_t ld = BF16 == 3 ? gemm_lds_bytes3<128, 64>() : gemm_lds_bytes<128, 64, true, false>();
     constexpr size_t lds = lw > ld ? lw : ld;
     auto k = gemm_bwd_pair_kernel<WM, WN, BF16>;
     static bool attr_set[16] = {};
@@ -156,10 +165,12 @@ static int launch_bwd_pair(GemmP pw, int splits, GemmP pd, hipStream_t st)
         if (n0 % 8 == 0) {
             if (tw == 1) {
                 if (pw.bf16 == 1) launch_pair_one<128, 64, 1>(pw, n0, pd, n1, st);
+                else if (pw.bf16 == 2 && bf16x3_planes()) launch_pair_one<128, 64, 3>(pw, n0, pd, n1, st);
                 else if (pw.bf16 == 2) launch_pair_one<128, 64, 2>(pw, n0, pd, n1, st);
                 else launch_pair_one<128, 64, 0>(pw, n0, pd, n1, st);
             } else {
                 if (pw.bf16 == 1) launch_pair_one<64, 64, 1>(pw, n0, pd, n1, st);
+                else if (pw.bf16 == 2 && bf16x3_planes()) launch_pair_one<64, 64, 3>(pw, n0, pd, n1, st);
                 else if (pw.bf16 == 2) launch_pair_one<64, 64, 2>(pw, n0, pd, n1, st);
                 else launch_pair_one<64, 64, 0>(pw, n0, pd, n1, st);
             }

@@ -638,7 +638,7 @@ class SiameseNetwork(_HipNetwork):
         (abn_pair_loss_dz): (activation name, (mask tower 1, mask tower 2) | None), or None when
         the tower's backward must start from d loss / d e (BatchNorm in front of the activation)."""
         seg, sv, _ = state
-        if seg.batch_norm:
+        if seg.batch_norm or os.environ.get('ABN_LOSS_DZ') == '0':      # (the variable: A/B measurements)
             return None
         masks = None
         if sv.masks is not None:

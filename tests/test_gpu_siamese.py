@@ -428,6 +428,47 @@ def test_bf16_throughput_mode_tracks_fp32(fixture, bn):
     assert curves[1][-1] <= curves[1][0]           # (a sigmoid tower at its initialisation barely moves)
 
 
+@pytest.mark.parametrize('planes', ['1', '0'])
+@pytest.mark.parametrize('fixture,bn,B', [('train_c2_bn0.npz', False, 4096), ('train_mid_bn1.npz', True, 96),
+                                          ('train_c2_bn1.npz', True, 1000)])
+def test_bf16x3_precision_is_fp32_grade(fixture, bn, B, planes, monkeypatch):
+    """precision='bf16x3': every tower GEMM sums six bf16 products per operand pair (operands
+    split into hi + mid + lo bf16 terms; ABN_BF16X3_PLANES picks where the split happens).
+    Embeddings, loss and every parameter gradient must agree with the exact-fp32 MFMA path
+    to a few 1e-6 -- the level at which fp32 itself sits from a float64 evaluation."""
+    import copy
+    import abnet3_amd.loss as L
+    from abnet3_amd.trainer import TrainerSiamese
+    monkeypatch.setenv('ABN_BF16X3_PLANES', planes)
+    g = load_golden(fixture)
+    net32, kw = cuda_net(g, seed=2 if 'c2' in fixture else None, prefix=None if 'c2' in fixture else 'p.')
+    net3 = copy.deepcopy(net32)
+    net3.precision = 'bf16x3'
+    rng = np.random.default_rng(3)
+    x1 = dev(rng.standard_normal((B, kw['input_dim'])).astype(np.float32))
+    x2 = dev(rng.standard_normal((B, kw['input_dim'])).astype(np.float32))
+    y = dev(rng.choice([1, -1], B))
+    out = []
+    for net in (net32, net3):
+        net.output_path = '/tmp/abn_x3'
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='sgd', lr=0.0,
+                            dataloader=None, log_dir='/tmp/abn_runs')
+        net.eval()
+        with torch.no_grad():
+            e = net.forward_once(x1).cpu().numpy()
+        net.train()
+        loss = float(tr.train_step((x1, x2, y), True))
+        out.append((e, loss, {k: p.grad.cpu().numpy().copy() for k, p in net.named_parameters()}))
+    assert rel_err(out[1][0], out[0][0]) < 3e-6
+    assert abs(out[1][1] - out[0][1]) <= 3e-6 * abs(out[0][1])
+    gmax = max(np.abs(v).max() for v in out[0][2].values())
+    from conftest import is_pre_bn_bias
+    for k, v in out[1][2].items():
+        if is_pre_bn_bias(k, bn):          # mathematically zero: rounding noise on both sides
+            continue
+        assert rel_err(v, out[0][2][k], floor=1e-2 * gmax) < 2e-5, (k, rel_err(v, out[0][2][k], floor=1e-2 * gmax))
+
+
 class _ListLoader(object):
     """Minimal dataloader contract the trainer consumes (dataloader.py:263-312)."""
 
