@@ -58,7 +58,7 @@ struct GemmP {
     int ones_col;           // WGRAD: column of B that is identically 1, or -1
     int a_vec, b_vec;       // 16-byte global loads allowed for A / B
     int c_vec;              // 16-byte epilogue accesses allowed (C, bias, aux)
-    int bf16;               // throughput mode: operands rounded to bf16 at fragment time (fp32 accumulate)
+    int bf16;               // 0 fp32 MFMA, 1 bf16 operands, 2 bf16 x 3 (split per fragment or, vectorised tiles, per LDS commit)
 #ifdef ABN_STAMPS
     unsigned long long* stamps;   // diagnostic build only: [block][128] s_memtime stamps
 #endif
@@ -278,39 +278,46 @@ __device__ __forceinline__ f32x4 frag_read(const float* __restrict__ lds, int ro
 // ---------------------------------------------------------------------------------------------
 // PREC 3 = bf16 x 3 with the split done ONCE per tile, when the tile is committed to LDS (PREC 2
 // splits at fragment time: every wave re-splits what it reads, and the kernel turns VALU-bound).
-// An operand tile [BMN rows][32 k] lives in LDS as THREE bf16 planes (hi, mid, lo) of 64-byte
-// rows; 16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3): a lane's MFMA operand (8
-// consecutive k of one row) is one ds_read_b128, conflict-free for the 16-lane groups, whichever
-// way the tile was filled.  k-major operands (dgrad's W, both wgrad operands) are transposed on
-// the way in: a thread owns 4 consecutive k of 4 consecutive rows (4 float4 loads), splits the
-// 16 values and writes, per row and plane, the 4 k as 8 bytes.
+// An operand tile [BMN rows][32 k] lives in LDS as rows of 208 bytes: the row's 32 k as bf16 three
+// times over -- [hi 64 B | mid 64 B | lo 64 B] -- and 16 bytes of padding.  A lane's MFMA operand
+// (8 consecutive k of one row and plane) is one ds_read_b128; 16 consecutive rows start at 16
+// distinct multiples of 16 bytes modulo 256 (208 r mod 256), so the reads are conflict-free, and
+// rows 4 apart alternate between the two halves of the 128-byte window the writes see (the first
+// image -- three separate planes of 64-byte rows -- spent half its LDS cycles in bank conflicts:
+// SQ_LDS_BANK_CONFLICT 9.6 M of SQ_LDS_IDX_ACTIVE 19.4 M per launch).
+// k-major operands (dgrad's W, both wgrad operands) are transposed on the way in: a thread owns
+// 4 (or 2) consecutive k of 4 consecutive rows, splits the values and writes, per row and plane,
+// its k as 8 (4) bytes; eight lanes with consecutive k-groups fill one row's 64 bytes.
 // ---------------------------------------------------------------------------------------------
+constexpr int T3_ROW = 208;              // bytes per row of the image: 3 x 64 + 16
 template <int BMN> struct Tile3 {
-    static constexpr int plane_bytes = BMN * 64;
-    static constexpr int bytes = 3 * plane_bytes;
+    static constexpr int plane_bytes = 64;              // hi -> mid -> lo inside a row
+    static constexpr int bytes = BMN * T3_ROW;
     static constexpr int units = BMN * BK / 4;
     static constexpr int per_thread = units / 256;
 };
-__device__ __forceinline__ int t3_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+__device__ __forceinline__ int t3_off(int row, int chunk) { return row * T3_ROW + (chunk << 4); }
+
+// two fp32 -> (hi, mid, lo) bf16 pairs, each pair in one dword: v_cvt_pk_bf16_f32 converts both at
+// once, a bf16 widens back to fp32 by a shift / a mask, and both differences are exact
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo)
+{
+    const f32x2 v = {a, b};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 r1 = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    mid = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+    const f32x2 r2 = {r1.x - __uint_as_float(mid << 16), r1.y - __uint_as_float(mid & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
+}
 
 // four fp32 -> 4 x (hi, mid, lo) bf16, each quadruple packed into 8 bytes
 __device__ __forceinline__ void split4(const float v0, const float v1, const float v2, const float v3, uint2& hi, uint2& mid,
                                        uint2& lo)
 {
-    const float v[4] = {v0, v1, v2, v3};
-    uint16_t h[4], m[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const __bf16 bh = (__bf16)v[i];
-        const float r1 = v[i] - (float)bh;
-        const __bf16 bm = (__bf16)r1;
-        const float r2 = r1 - (float)bm;
-        const __bf16 bl = (__bf16)r2;
-        h[i] = __builtin_bit_cast(uint16_t, bh); m[i] = __builtin_bit_cast(uint16_t, bm); l[i] = __builtin_bit_cast(uint16_t, bl);
-    }
-    hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-    mid = make_uint2((uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16));
-    lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+    split2(v0, v1, hi.x, mid.x, lo.x);
+    split2(v2, v3, hi.y, mid.y, lo.y);
 }
 
 // unit -> (row, k) of a thread's i-th float4.  K-contiguous: the fp32 path's map.  k-major: a
@@ -320,9 +327,9 @@ __device__ __forceinline__ void unit3(int t, int i, int& row, int& k)
 {
     if constexpr (KCONTIG) { const int u = t + 256 * i; row = u >> 3; k = 4 * (u & 7); }
     else {
-        constexpr int PT = Tile3<BMN>::per_thread, MG = BMN / 4;        // row groups of 4
-        row = 4 * (t % MG);
-        k = PT * (t / MG) + i;
+        constexpr int PT = Tile3<BMN>::per_thread, KG = BK / PT;        // k-groups of PT along the tile's 32 k
+        row = 4 * (t / KG);                                             // consecutive lanes: consecutive k-groups of
+        k = PT * (t % KG) + i;                                          // the same 4 rows (one row's bytes side by side)
     }
 }
 
@@ -522,7 +529,10 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int block_id)
         char* const cs = reinterpret_cast<char*>(smem);
         constexpr int SA = Tile3<BM>::bytes, SB = Tile3<BN>::bytes, STG = SA + SB;
         constexpr int PA = Tile3<BM>::per_thread, PBt = Tile3<BN>::per_thread;
-        f32x4 ra[PA], rb[PBt];
+        // TWO register stages: with six 32-cycle MFMAs per block and slab a tile's matrix work
+        // (~770 cycles) is shorter than a global load's latency, so the loads run two tiles
+        // ahead of the MFMAs (one tile in LDS, the next in registers, the one after in flight).
+        f32x4 ra[2][PA], rb[2][PBt];
         const int ones = (EPI == EPI_WGRAD) ? p.ones_col : -1;
         const int nB = (ones >= 0) ? ones : p.N;
         const bool a_in = m0 + BM <= p.M, b_in = n0 + BN <= nB;
@@ -531,38 +541,27 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int block_id)
         tile3_offsets<BN, B_KC>(vob, p.ldb);
         const float* const a_org = p.A + (A_KC ? (int64_t)m0 * p.lda : (int64_t)m0);
         const float* const b_org = p.B + (B_KC ? (int64_t)n0 * p.ldb : (int64_t)n0);
-        auto issue = [&](int k0) {
+        auto issue = [&](int k0, f32x4* qa, f32x4* qb) {
             const bool k_in = k0 + BK <= ke;
             if (a_in && k_in) {
                 const float* an = a_org + (A_KC ? (int64_t)k0 : (int64_t)k0 * p.lda);
 #pragma unroll
-                for (int i = 0; i < PA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(an + voa[i]);
-            } else tile3_issue<BM, A_KC>(ra, p.A, p.lda, p.M, m0, k0, ke);
+                for (int i = 0; i < PA; ++i) qa[i] = *reinterpret_cast<const f32x4*>(an + voa[i]);
+            } else tile3_issue<BM, A_KC>(qa, p.A, p.lda, p.M, m0, k0, ke);
             if (b_in && k_in) {
                 const float* bn = b_org + (B_KC ? (int64_t)k0 : (int64_t)k0 * p.ldb);
 #pragma unroll
-                for (int i = 0; i < PBt; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bn + vob[i]);
-            } else tile3_issue<BN, B_KC>(rb, p.B, p.ldb, nB, n0, k0, ke);
+                for (int i = 0; i < PBt; ++i) qb[i] = *reinterpret_cast<const f32x4*>(bn + vob[i]);
+            } else tile3_issue<BN, B_KC>(qb, p.B, p.ldb, nB, n0, k0, ke);
         };
-        auto commit = [&](int k0, char* st) {
+        auto commit = [&](int k0, char* st, const f32x4* qa, const f32x4* qb) {
             const bool k_in = k0 + BK <= ke;
-            if (a_in && k_in) tile3_commit<BM, A_KC, true>(ra, st, p.M, m0, k0, ke, -1);
-            else tile3_commit<BM, A_KC, false>(ra, st, p.M, m0, k0, ke, -1);
-            if (b_in && k_in) tile3_commit<BN, B_KC, true>(rb, st + SA, nB, n0, k0, ke, ones);
-            else tile3_commit<BN, B_KC, false>(rb, st + SA, nB, n0, k0, ke, ones);
+            if (a_in && k_in) tile3_commit<BM, A_KC, true>(qa, st, p.M, m0, k0, ke, -1);
+            else tile3_commit<BM, A_KC, false>(qa, st, p.M, m0, k0, ke, -1);
+            if (b_in && k_in) tile3_commit<BN, B_KC, true>(qb, st + SA, nB, n0, k0, ke, ones);
+            else tile3_commit<BN, B_KC, false>(qb, st + SA, nB, n0, k0, ke, ones);
         };
-        if (nkt > 0) {
-            issue(kb);
-            commit(kb, cs);
-        }
-        __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int cur = kt & 1;
-            const bool more = kt + 1 < nkt;
-            const int knext = kb + (kt + 1) * BK;
-            const char* as = cs + cur * STG;
-            const char* bs = as + SA;
-            if (more) issue(knext);                     // the loads fly behind this tile's MFMAs
+        auto compute = [&](const char* as, const char* bs) {
 #pragma unroll
             for (int sl = 0; sl < BK / 16; ++sl) {
                 bf16x8 fa[TM][3], fb[TN][3];
@@ -586,8 +585,33 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int block_id)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
                     }
             }
-            if (more) commit(knext, cs + (cur ^ 1) * STG);
-            __syncthreads();
+        };
+        if (nkt > 0) {
+            issue(kb, ra[0], rb[0]);
+            if (nkt > 1) issue(kb + BK, ra[1], rb[1]);
+            commit(kb, cs, ra[0], rb[0]);
+        }
+        __syncthreads();
+        // iteration kt: tile kt in LDS stage kt & 1, tile kt+1 in register set (kt+1) & 1; the loads of
+        // tile kt+2 go into register set kt & 1 (free since its tile was committed).  Unrolled by two
+        // so that the register sets are addressed statically.
+        for (int kt = 0; kt < nkt; kt += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = kt + h;
+                if (k >= nkt) break;
+                const char* as = cs + h * STG;
+#ifndef ABN_EXP_NOLOAD
+                if (k + 2 < nkt) issue(kb + (k + 2) * BK, ra[h], rb[h]);
+#endif
+#ifndef ABN_EXP_NOMFMA
+                compute(as, as + SA);
+#endif
+#ifndef ABN_EXP_NOCOMMIT
+                if (k + 1 < nkt) commit(kb + (k + 1) * BK, cs + (h ^ 1) * STG, ra[h ^ 1], rb[h ^ 1]);
+#endif
+                __syncthreads();
+            }
         }
     } else {
     f32x4 ra[TA::per_thread], rb[TB::per_thread];

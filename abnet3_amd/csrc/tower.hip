@@ -896,6 +896,10 @@ int abn_linear_backward(const float* dz, const float* W, const float* a_in, int6
     pd.aux = act_prev == ABN_ACT_NONE ? nullptr : a_in; pd.ldaux = in_dim; pd.act = act_prev; pd.ones_col = -1;
     pd.a_vec = aligned16(dz) && (out_dim % 4 == 0);
     pd.b_vec = aligned16(W) && (in_dim % 4 == 0);
+    // the single-layer entry points compute in exact fp32 unless ABN_LINEAR_PREC says otherwise
+    // (1 = bf16, 2 = bf16 x 3: kernel measurements of the other arithmetic modes)
+    static const int prec = getenv("ABN_LINEAR_PREC") ? atoi(getenv("ABN_LINEAR_PREC")) : 0;
+    pw.bf16 = pd.bf16 = (prec >= 0 && prec <= 2) ? prec : 0;
     int rc = launch_bwd_pair(pw, splits, pd, st);
     if (rc != ABN_OK) return rc;
     ReduceTable rt = {};

@@ -11,6 +11,14 @@ import torch
 from conftest import load_golden, rel_err, check_grads, check_params
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=['bf16x3', 'fp32'])
+def tower_precision(request, monkeypatch):
+    """Every test of this file runs on both parity-grade arithmetics of the tower GEMMs: the
+    default bf16 x 3 split products and the exact-fp32 MFMA (SiameseNetwork.precision)."""
+    monkeypatch.setenv('ABNET3_PRECISION', request.param)
+    return request.param
 TOL = 1e-5
 GTOL = {'sig': 1e-4, 'relu_bn': 2e-5, 'tanh0': 2e-5}    # see tests/test_oracle_multitask.py
 RUNS = [('sgd', 0.3, 0.001), ('adadelta', 0.5, 0.1), ('adam', 1.0, 0.001)]

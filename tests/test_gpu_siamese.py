@@ -11,6 +11,14 @@ from conftest import (load_golden, rel_err, check_grads, check_params,
                       check_loss_grads)
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=['bf16x3', 'fp32'])
+def tower_precision(request, monkeypatch):
+    """Every test of this file runs on both parity-grade arithmetics of the tower GEMMs: the
+    default bf16 x 3 split products and the exact-fp32 MFMA (SiameseNetwork.precision)."""
+    monkeypatch.setenv('ABNET3_PRECISION', request.param)
+    return request.param
 TOL = 1e-5       # BASELINE.json: 1e-5 relative fp32 on embeddings and losses
 
 
@@ -398,7 +406,7 @@ def test_bf16_throughput_mode_tracks_fp32(fixture, bn):
     net32, kw = cuda_net(g, seed=2 if 'c2' in fixture else None, prefix=None if 'c2' in fixture else 'p.')
     net16 = copy.deepcopy(net32)
     net16.precision = 'bf16'
-    assert net32.precision == 'fp32'
+    net32.precision = 'fp32'
     rng = np.random.default_rng(1)
     B = 256
     x1 = dev(rng.standard_normal((B, kw['input_dim'])).astype(np.float32))
@@ -444,6 +452,7 @@ def test_bf16x3_precision_is_fp32_grade(fixture, bn, B, planes, monkeypatch):
     net32, kw = cuda_net(g, seed=2 if 'c2' in fixture else None, prefix=None if 'c2' in fixture else 'p.')
     net3 = copy.deepcopy(net32)
     net3.precision = 'bf16x3'
+    net32.precision = 'fp32'
     rng = np.random.default_rng(3)
     x1 = dev(rng.standard_normal((B, kw['input_dim'])).astype(np.float32))
     x2 = dev(rng.standard_normal((B, kw['input_dim'])).astype(np.float32))
