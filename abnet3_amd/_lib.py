@@ -39,6 +39,7 @@ SYMBOLS = {
     'abn_linear_wgrad_scratch_floats': (_i64, [_i64, _i64, _i64]),
     'abn_linear_wgrad': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     'abn_linear_backward': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'abn_linear_backward_prec': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp]),
     'abn_softmax_rows': (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     'abn_softmax_rows_backward': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     'abn_pair_loss_ws_bytes': (_i64, [_i64]),

@@ -869,6 +869,14 @@ int abn_linear_backward(const float* dz, const float* W, const float* a_in, int6
                         int64_t out_dim, int act_prev, float* dW, float* db, float* dx, float* scratch,
                         int64_t scratch_floats, void* stream)
 {
+    return abn_linear_backward_prec(dz, W, a_in, rows, in_dim, out_dim, act_prev, 0, dW, db, dx, scratch, scratch_floats, stream);
+}
+
+int abn_linear_backward_prec(const float* dz, const float* W, const float* a_in, int64_t rows, int64_t in_dim,
+                             int64_t out_dim, int act_prev, int precision, float* dW, float* db, float* dx,
+                             float* scratch, int64_t scratch_floats, void* stream)
+{
+    ABN_REQUIRE(precision >= 0 && precision <= 2, "linear_backward: precision=%d (0 = fp32, 1 = bf16, 2 = bf16 x 3)", precision);
     ABN_REQUIRE(dz && W && a_in && dW && db && dx && scratch, "linear_backward: null pointer");
     ABN_REQUIRE(rows >= 1 && rows < (1LL << 30) && in_dim >= 1 && out_dim >= 1 && in_dim < (1 << 24) && out_dim < (1 << 24),
                 "linear_backward: bad shape");
@@ -896,10 +904,7 @@ int abn_linear_backward(const float* dz, const float* W, const float* a_in, int6
     pd.aux = act_prev == ABN_ACT_NONE ? nullptr : a_in; pd.ldaux = in_dim; pd.act = act_prev; pd.ones_col = -1;
     pd.a_vec = aligned16(dz) && (out_dim % 4 == 0);
     pd.b_vec = aligned16(W) && (in_dim % 4 == 0);
-    // the single-layer entry points compute in exact fp32 unless ABN_LINEAR_PREC says otherwise
-    // (1 = bf16, 2 = bf16 x 3: kernel measurements of the other arithmetic modes)
-    static const int prec = getenv("ABN_LINEAR_PREC") ? atoi(getenv("ABN_LINEAR_PREC")) : 0;
-    pw.bf16 = pd.bf16 = (prec >= 0 && prec <= 2) ? prec : 0;
+    pw.bf16 = pd.bf16 = precision;
     int rc = launch_bwd_pair(pw, splits, pd, st);
     if (rc != ABN_OK) return rc;
     ReduceTable rt = {};

@@ -10,7 +10,7 @@ W = torch.randn(n, k, device='cuda') * 0.05
 dW, db, dx = torch.empty(n, k, device='cuda'), torch.empty(n, device='cuda'), torch.empty(rows, k, device='cuda')
 sc_n = lib.abn_linear_wgrad_scratch_floats(rows, k, n); sc = torch.empty(sc_n, device='cuda')
 def run():
-    _lib.check(lib.abn_linear_backward(_lib.ptr(dz), _lib.ptr(W), _lib.ptr(a), rows, k, n, 1, _lib.ptr(dW), _lib.ptr(db), _lib.ptr(dx), _lib.ptr(sc), sc_n, _lib.stream()), 'bwd')
+    _lib.check(lib.abn_linear_backward_prec(_lib.ptr(dz), _lib.ptr(W), _lib.ptr(a), rows, k, n, 1, int(os.environ.get('ABN_LINEAR_PREC', '0')), _lib.ptr(dW), _lib.ptr(db), _lib.ptr(dx), _lib.ptr(sc), sc_n, _lib.stream()), 'bwd')
 for _ in range(20): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
