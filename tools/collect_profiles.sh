@@ -1,0 +1,28 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, collected on the GPU box as MI355X_MICROARCH.md prescribes:
+#   1. rocprofv3 --kernel-trace --stats of the default bench.py command (kernel durations)
+#   2. FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (kernel-trace only) -> HBM bytes per launch
+#   3. SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / SQ_WAVE_CYCLES / SQ_INSTS_VALU ... pass (matrix-core and VALU use)
+#   tools/collect_profiles.sh r02      (results under gpurun_out/prof_r02*, summaries copied by the caller)
+set -e
+tag=${1:-r02}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+args="--steps 100 --warmup 20 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py $args > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/traffic/fetch -- python3 $root/bench.py $args > $out/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/traffic/write -- python3 $root/bench.py $args > $out/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $out/sq -- python3 $root/bench.py $args > $out/sq.log 2>&1
+# filterbank leg (bench runs it only with the CPU baselines): its own passes
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/traffic_fb/fetch -- python3 $root/tools/fbank_time.py 3000 > $out/fb_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/traffic_fb/write -- python3 $root/tools/fbank_time.py 3000 > $out/fb_write.log 2>&1
+cd $root
+python3 tools/prof_summary.py $out/stats 20 > $out/kernel_stats.txt
+cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
+python3 tools/traffic_summary.py $out/traffic > $out/traffic.txt
+python3 tools/traffic_summary.py $out/traffic_fb > $out/traffic_fb.txt
+python3 tools/pmc_summary.py $out/sq abn:: > $out/sq_counters.txt
+grep -h "^{\"metric\"" $out/stats.log | tail -1 > $out/bench_line_under_rocprof.json
+echo collected $out
