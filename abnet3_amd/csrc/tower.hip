@@ -877,7 +877,7 @@ int abn_linear_backward_prec(const float* dz, const float* W, const float* a_in,
                              float* scratch, int64_t scratch_floats, void* stream)
 {
     ABN_REQUIRE(precision >= 0 && precision <= 2, "linear_backward: precision=%d (0 = fp32, 1 = bf16, 2 = bf16 x 3)", precision);
-    ABN_REQUIRE(dz && W && a_in && dW && db && dx && scratch, "linear_backward: null pointer");
+    ABN_REQUIRE(dz && W && a_in && dx && scratch && ((dW == nullptr) == (db == nullptr)), "linear_backward: null pointer");
     ABN_REQUIRE(rows >= 1 && rows < (1LL << 30) && in_dim >= 1 && out_dim >= 1 && in_dim < (1 << 24) && out_dim < (1 << 24),
                 "linear_backward: bad shape");
     ABN_REQUIRE(act_prev >= ABN_ACT_NONE && act_prev <= ABN_ACT_TANH, "linear_backward: unsupported activation %d", act_prev);
@@ -907,6 +907,7 @@ int abn_linear_backward_prec(const float* dz, const float* W, const float* a_in,
     pw.bf16 = pd.bf16 = precision;
     int rc = launch_bwd_pair(pw, splits, pd, st);
     if (rc != ABN_OK) return rc;
+    if (!dW) return ABN_OK;                      // slabs left unreduced in scratch: the pair grid alone (kernel timing)
     ReduceTable rt = {};
     rt.n_layers = 1; rt.splits[0] = splits; rt.slab_stride = stride;
     rt.off[0] = 0; rt.nW[0] = out_dim * in_dim; rt.nb[0] = out_dim; rt.dW[0] = dW; rt.db[0] = db;

@@ -114,10 +114,10 @@ def _traffic(kernel):
 def tower_roofline(torch, net, reps=20):
     """The dominant kernel of the step by time: gemm_bwd_pair_kernel<128, 64, .> -- the wgrad and
     the dgrad of a 500x500 layer over the 2 x 4096 tower rows in ONE grid, two launches per step.
-    Timed live in the network's arithmetic through abn_linear_backward_prec (the single-layer
-    entry that issues exactly what the tower backward issues: that grid, then the layer's slab
-    reduction), `reps` calls captured into one hipGraph and bracketed by HIP events on the launch
-    stream.  Algorithmic FLOPs per launch: 2 GEMMs x 2 * 8192 * 500 * 500 (+ the bias column).
+    Timed live in the network's arithmetic through abn_linear_backward_prec with dW = NULL (the
+    single-layer entry that issues exactly the grid the tower backward issues, without the
+    layer's slab reduction), `reps` launches captured into one hipGraph and bracketed by HIP
+    events on the launch stream.  Algorithmic FLOPs per launch: 2 GEMMs x 2 * 8192 * 500 * 500 (+ the bias column).
     Roof: the matrix cores in the arithmetic the kernel uses -- fp32 MFMA 157.3 TFLOP/s for
     'fp32'; for 'bf16x3' the dense bf16 MFMA peak divided by the six bf16 products each
     algorithmic product costs (2500 / 6 = 416.7 TFLOP/s algorithmic).  The whole-forward kernel
@@ -136,9 +136,17 @@ def tower_roofline(torch, net, reps=20):
 
     def pair():
         _lib.check(lib.abn_linear_backward_prec(_lib.ptr(dz), _lib.ptr(W), _lib.ptr(a), rows, k, n, _lib.ACT['sigmoid'],
-                                                PREC_CODE[prec], _lib.ptr(dW), _lib.ptr(db), _lib.ptr(dx), _lib.ptr(sc),
+                                                PREC_CODE[prec], None, None, _lib.ptr(dx), _lib.ptr(sc),
                                                 sc_n, _lib.stream()), 'abn_linear_backward_prec')
     t_pair = _time_launches(torch, pair, reps)
+    # what a back-to-back launch costs on top of the kernel itself in this harness: the same
+    # measurement with a kernel that does (almost) nothing
+    tiny_idx = torch.zeros(1, dtype=torch.int64, device='cuda')
+    tiny_out = torch.empty(1, k, device='cuda')
+
+    def tiny():
+        _lib.check(lib.abn_gather_rows(_lib.ptr(a), _lib.ptr(tiny_idx), 1, k, _lib.ptr(tiny_out), _lib.stream()), 'gather')
+    t_gap = _time_launches(torch, tiny, reps)
     flop = 2.0 * rows * k * n + 2.0 * rows * (k + 1) * n
     achieved = flop / t_pair / 1e12
     out = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1),
@@ -149,9 +157,10 @@ def tower_roofline(torch, net, reps=20):
                          'bf16x3': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per algorithmic product',
                          'bf16': 'dense bf16 MFMA'}[prec],
            'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-           'kernel': pair_name + '  (wgrad + dgrad of a 500x500 layer in one grid; avg_launch_us also '
-                     'holds the layer\'s ~10 us slab reduction and the dispatch gaps, so the fraction is a lower bound)',
-           'avg_launch_us': round(t_pair * 1e6, 2), 'flop_per_launch': flop}
+           'kernel': pair_name + '  (wgrad + dgrad of a 500x500 layer in one grid: that grid alone, launched '
+                     'back to back from one hipGraph; avg_launch_us includes the ~2 us dispatch gap between launches)',
+           'avg_launch_us': round(t_pair * 1e6, 2), 'flop_per_launch': flop,
+           'empty_launch_us_same_harness': round(t_gap * 1e6, 2)}
 
     # the whole forward of both towers, one launch (the largest single launch of the step)
     x12 = torch.randn(rows, 40, device='cuda')

@@ -151,7 +151,9 @@ int abn_linear_backward(const float* dz, const float* W, const float* a_in, int6
                         float* db, float* dx, float* scratch, int64_t scratch_floats,
                         void* stream);
 /* ... in the arithmetic abn_tower_desc.precision names (0 exact fp32 = abn_linear_backward,
- * 1 bf16 operands, 2 bf16 x 3): the grid abn_tower_backward issues for that network. */
+ * 1 bf16 operands, 2 bf16 x 3): the grid abn_tower_backward issues for that network.  dW and db
+ * both NULL: only that grid runs and the split-K slabs stay unreduced in scratch (bench.py times
+ * the grid alone this way). */
 int abn_linear_backward_prec(const float* dz, const float* W, const float* a_in, int64_t rows,
                              int64_t in_dim, int64_t out_dim, int act_prev, int precision,
                              float* dW, float* db, float* dx, float* scratch,

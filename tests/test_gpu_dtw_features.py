@@ -165,6 +165,31 @@ def test_dtw_ties_and_long_tokens():
         assert (got[p][0] == ref[0]).all() and (got[p][1] == ref[1]).all(), p
 
 
+def test_dtw_tokens_longer_than_1024_frames():
+    """The reference aligns tokens of any length (abnet3/utils.py:147-153).  Round 1 refused a
+    whole batch when one token exceeded 1024 frames; the banded kernel has no limit: 1500 x 1100
+    and 40 x 2300 next to ordinary pairs, both frame widths' kernels, bit-exact vs the oracle."""
+    from abnet3_amd.utils import dtw_align_batch
+    from oracle import dtw_oracle as O
+    for D in (40, 24):
+        rng = np.random.default_rng(1500 + D)
+        n1 = np.array([1500, 40, 70, 1025, 33], dtype=np.int32)
+        n2 = np.array([1100, 2300, 65, 31, 1024], dtype=np.int32)
+        f1 = rng.standard_normal((int(n1.sum()), D)).astype(np.float32)
+        f2 = rng.standard_normal((int(n2.sum()), D)).astype(np.float32)
+        o1 = np.concatenate(([0], np.cumsum(n1)[:-1]))
+        o2 = np.concatenate(([0], np.cumsum(n2)[:-1]))
+        src = np.rint(np.linspace(0, n1[0] - 1, n2[0])).astype(int)        # pair 0: a warped noisy copy
+        f2[:n2[0]] = f1[src] + 0.1 * f2[:n2[0]]
+        res = dtw_align_batch(torch.from_numpy(f1).cuda(), o1, n1, torch.from_numpy(f2).cuda(), o2, n2)
+        got, cost = res.to_lists(), res.total_cost.cpu().numpy()
+        for p in range(len(n1)):
+            d = O.cosine_distance(f1[o1[p]:o1[p] + n1[p]], f2[o2[p]:o2[p] + n2[p]])
+            q1, q2 = O.dtw_path(d)
+            assert got[p] is not None and np.array_equal(got[p][0], q1) and np.array_equal(got[p][1], q2), (D, p)
+            assert cost[p] == O.dtw_cost(d), (D, p)
+
+
 def test_dtw_dropped_pair_and_empty_token():
     from abnet3_amd.utils import dtw_align_batch
     g = load_golden('cosdist.npz')
