@@ -1,54 +1,19 @@
 // ops.hip -- the small HBM-bound kernels around the tower: fused optimizer
 // step over the flat parameter buffer, row gathers, frame stacking.
+#include <math.h>
+
 #include "common.h"
+#include "opt_rule.h"
 
 namespace abn {
 
-// torch.optim single-tensor update rules (abnet3/trainer.py:68-87 picks the
-// class, torch supplies the defaults); one flat buffer, one launch.
-__global__ void optimizer_kernel(int kind, float* __restrict__ p, const float* __restrict__ g,
-                                 float* __restrict__ s1, float* __restrict__ s2, int64_t n, float lr,
-                                 float hp0, float hp1, float eps, int first, float bc1, float bc2_sqrt,
-                                 float gscale)
+// one flat buffer, one launch (the update rules: opt_rule.h)
+__global__ void optimizer_kernel(OptP o, float* __restrict__ p, const float* __restrict__ g,
+                                 float* __restrict__ s1, float* __restrict__ s2, int64_t n)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        float pi = p[i];
-        switch (kind) {
-            case ABN_OPT_SGD: {          // buf = g (first step) | mu*buf + g ; p -= lr*buf
-                const float buf = first ? gi : hp0 * s1[i] + gi;
-                s1[i] = buf;
-                pi -= lr * buf;
-            } break;
-            case ABN_OPT_ADADELTA: {     // rho = hp0
-                const float sq = hp0 * s1[i] + (1.0f - hp0) * gi * gi;
-                const float delta = sqrtf(s2[i] + eps) / sqrtf(sq + eps) * gi;
-                s1[i] = sq;
-                s2[i] = hp0 * s2[i] + (1.0f - hp0) * delta * delta;
-                pi -= lr * delta;
-            } break;
-            case ABN_OPT_ADAM: {         // beta1 = hp0, beta2 = hp1
-                const float m = s1[i] + (gi - s1[i]) * (1.0f - hp0);      // lerp_
-                const float v = hp1 * s2[i] + (1.0f - hp1) * gi * gi;
-                s1[i] = m;
-                s2[i] = v;
-                const float denom = sqrtf(v) / bc2_sqrt + eps;
-                pi -= (lr / bc1) * (m / denom);
-            } break;
-            case ABN_OPT_ADAGRAD: {
-                const float s = s1[i] + gi * gi;
-                s1[i] = s;
-                pi -= lr * (gi / (sqrtf(s) + eps));
-            } break;
-            default: {                   // RMSprop, alpha = hp0
-                const float sq = hp0 * s1[i] + (1.0f - hp0) * gi * gi;
-                s1[i] = sq;
-                pi -= lr * (gi / (sqrtf(sq) + eps));
-            } break;
-        }
-        p[i] = pi;
-    }
+         i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = opt_update(o, p[i], g[i], s1, s2, i);
 }
 
 // out[i][:] = table[idx[i]][:]  (dataloader.py:204-205 feat[path, :])
@@ -169,13 +134,8 @@ int abn_optimizer_step(int kind, float* params, const float* grads, float* state
     ABN_REQUIRE(state2 || (kind != ABN_OPT_ADADELTA && kind != ABN_OPT_ADAM), "optimizer_step: state2 required");
     ABN_REQUIRE(n >= 0 && step >= 1, "optimizer_step: bad n/step");
     if (n == 0) return ABN_OK;
-    float bc1 = 1.0f, bc2s = 1.0f;
-    if (kind == ABN_OPT_ADAM) {
-        bc1 = (float)(1.0 - pow((double)hp0, (double)step));
-        bc2s = (float)sqrt(1.0 - pow((double)hp1, (double)step));
-    }
-    hipLaunchKernelGGL(optimizer_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, kind, params, grads,
-                       state1, state2, n, lr, hp0, hp1, eps, step == 1 ? 1 : 0, bc1, bc2s, grad_scale);
+    hipLaunchKernelGGL(optimizer_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                       make_optp(kind, lr, hp0, hp1, eps, step, grad_scale), params, grads, state1, state2, n);
     ABN_CHECK_LAUNCH("optimizer_step");
     return ABN_OK;
 }

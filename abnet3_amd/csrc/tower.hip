@@ -10,9 +10,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <math.h>
+
 #include "common.h"
 #include "gemm_f32.h"
+#include "opt_rule.h"
 #include "tower_fused.h"
+#include "tower_planes.h"
 
 namespace abn {
 
@@ -239,6 +243,46 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, ReduceTable 
     }
 }
 
+// The same reduction with the optimizer step applied to each element as soon as its gradient is
+// known (single process, no gradient exchange in between): one launch instead of two, the
+// gradient is written once (p.grad stays valid) and never read back.  Parameters, gradients and
+// optimizer state share ONE flat layout: element j of layer l's dW lives at float offset
+// (t.dW[l] - grads) + j of all four buffers.
+__global__ void slab_reduce_step_kernel(const float* __restrict__ slabs, ReduceTable t, OptP o, float* __restrict__ params,
+                                        float* __restrict__ grads, float* __restrict__ s1, float* __restrict__ s2)
+{
+    const int64_t n4 = (t.total + 3) / 4;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4;
+         q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = 4 * q;
+        int l = 0;
+        while (l + 1 < t.n_layers && i >= t.off[l + 1]) ++l;
+        const int S = t.splits[l];
+        f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, p2 = p0, p3 = p0;
+        const float* src = slabs + i;
+        int k = 0;
+        for (; k + 3 < S; k += 4) {
+            p0 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 0) * t.slab_stride);
+            p1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 1) * t.slab_stride);
+            p2 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 2) * t.slab_stride);
+            p3 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 3) * t.slab_stride);
+        }
+        for (; k < S; ++k) p0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * t.slab_stride);
+        const f32x4 s = (p0 + p1) + (p2 + p3);
+        const int64_t baseW = t.dW[l] - grads, baseb = t.db[l] - grads;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t j = i + e - t.off[l];
+            int64_t idx;
+            if (j < t.nW[l]) idx = baseW + j;
+            else if (j - t.nW[l] < t.nb[l]) idx = baseb + (j - t.nW[l]);
+            else continue;
+            grads[idx] = s[e];
+            params[idx] = opt_update(o, params[idx], s[e], s1, s2, idx);
+        }
+    }
+}
+
 constexpr float BN_EPS = 1e-5f;
 constexpr float BN_MOMENTUM = 0.1f;
 
@@ -407,8 +451,18 @@ struct Layout {
     int64_t xhat[ABN_MAX_LAYERS];        // BN only (z is produced here, then normalised in place)
     int64_t mean[ABN_MAX_LAYERS], invstd[ABN_MAX_LAYERS], var[ABN_MAX_LAYERS];
     int64_t bn_part;                     // BN only: stage-1 partial sums (doubles), shared by the layers
+    int64_t wp[ABN_MAX_LAYERS];          // precision 1 / 2 without BN: the weights as MFMA operand fragments (tower_planes.h)
     int64_t total;
 };
+
+static inline int planes_of(int precision) { return precision == 2 ? 3 : 1; }
+static bool planes_shape_ok(const abn_tower_desc* t)
+{
+    if (t->batch_norm || t->precision < 1) return false;
+    for (int l = 0; l <= t->n_layers; ++l)
+        if (t->dims[l] < 4 || t->dims[l] > PL_MAXW || t->dims[l] % 4 != 0) return false;
+    return true;
+}
 
 static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
 {
@@ -434,6 +488,10 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
         for (int l = 1; l <= t->n_layers; ++l) maxw = t->dims[l] > maxw ? t->dims[l] : maxw;
         L.bn_part = take(2 * n_calls * bn_chunks(rows / n_calls) * 2 * maxw);      // doubles = 2 floats each
     }
+    for (int l = 0; l < t->n_layers; ++l) L.wp[l] = -1;
+    if (planes_shape_ok(t))
+        for (int l = 0; l < t->n_layers; ++l)
+            L.wp[l] = take(pl_image_bytes(t->dims[l + 1], t->dims[l], planes_of(t->precision)) / 4);
     L.total = o;
     return L;
 }
@@ -513,6 +571,24 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
 
 static inline int grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
 
+static ReduceTable make_reduce_table(const abn_tower_desc* t, const BwdLayout& B)
+{
+    ReduceTable rt = {};
+    const int nl = t->n_layers;
+    rt.n_layers = nl;
+    rt.slab_stride = B.slab_stride;
+    for (int l = 0; l < nl; ++l) {
+        rt.splits[l] = B.splits[l];
+        rt.off[l] = B.off[l];
+        rt.nW[l] = t->dims[l + 1] * t->dims[l];
+        rt.nb[l] = t->dims[l + 1];
+        rt.dW[l] = t->dW[l];
+        rt.db[l] = t->db[l];
+    }
+    rt.total = B.off[nl - 1] + rt.nW[nl - 1] + rt.nb[nl - 1];
+    return rt;
+}
+
 }  // namespace abn
 
 using namespace abn;
@@ -570,6 +646,56 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         fusable = t->dims[l] >= 4 && t->dims[l] <= FUSED_MAXW && t->dims[l] % 4 == 0;
     for (int l = 0; l < t->n_layers && fusable; ++l)
         fusable = aligned16(t->W[l]) && (!t->drop_mask[l] || !train || aligned16(t->drop_mask[l]));
+    const bool planes_enabled = !(getenv("ABN_PLANES") && atoi(getenv("ABN_PLANES")) == 0);
+    if (fusable && planes_enabled && planes_shape_ok(t)) {
+        const int np = planes_of(t->precision);
+        PackTable pk = {};
+        PlanesFwdP f = {};
+        f.n_layers = t->n_layers;
+        f.rows = (int)rows;
+        f.rows_call = (int)rpc;
+        f.x1 = x1; f.x2 = x2;
+        f.x_copy = x2 ? ws + L.x : nullptr;
+        pk.base = reinterpret_cast<char*>(ws);
+        for (int l = 0; l <= t->n_layers; ++l) f.dims[l] = (int)t->dims[l];
+        for (int l = 0; l < t->n_layers; ++l) {
+            f.act[l] = (l == t->n_layers - 1) ? t->last_act : t->act;
+            f.b[l] = t->b[l];
+            f.mask[l] = train ? t->drop_mask[l] : nullptr;
+            f.out[l] = ws + L.a[l];
+            f.wp[l] = reinterpret_cast<const char*>(ws + L.wp[l]);
+            PackJob& J = pk.job[pk.n_jobs++];
+            J.W = t->W[l]; J.N = (int)t->dims[l + 1]; J.K = (int)t->dims[l]; J.transposed = 0;
+            J.nblk = pl_blocks(J.N); J.nsteps = pl_steps(J.K);
+            J.tile0 = pk.n_tiles; J.dst = L.wp[l] * 4;
+            pk.n_tiles += J.nblk * J.nsteps;
+        }
+#ifdef ABN_STAMPS
+        f.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
+#endif
+        static bool pl_attr_set[16] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev = (dev >= 0 && dev < 16) ? dev : 0;
+        if (!pl_attr_set[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_planes_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(1));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_planes_kernel<3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(3));
+            pl_attr_set[dev] = true;
+        }
+        const dim3 pgrid((unsigned)((pk.n_tiles + 3) / 4));
+        const dim3 fgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
+        if (np == 3) {
+            hipLaunchKernelGGL(pack_planes_kernel<3>, pgrid, dim3(256), 0, st, pk);
+            hipLaunchKernelGGL(tower_fwd_planes_kernel<3>, fgrid, dim3(PL_NT), pl_lds_bytes(3), st, f);
+        } else {
+            hipLaunchKernelGGL(pack_planes_kernel<1>, pgrid, dim3(256), 0, st, pk);
+            hipLaunchKernelGGL(tower_fwd_planes_kernel<1>, fgrid, dim3(PL_NT), pl_lds_bytes(1), st, f);
+        }
+        ABN_CHECK_LAUNCH("tower_fwd_planes");
+        return ABN_OK;
+    }
     if (fusable) {
         FusedFwdP f = {};
         f.n_layers = t->n_layers;
@@ -769,20 +895,39 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             cur ^= 1;
         }
     }
-    ReduceTable rt = {};
-    rt.n_layers = nl;
-    rt.slab_stride = B.slab_stride;
-    for (int l = 0; l < nl; ++l) {
-        rt.splits[l] = B.splits[l];
-        rt.off[l] = B.off[l];
-        rt.nW[l] = t->dims[l + 1] * t->dims[l];
-        rt.nb[l] = t->dims[l + 1];
-        rt.dW[l] = t->dW[l];
-        rt.db[l] = t->db[l];
+    if (t->defer_reduce) {
+        ABN_REQUIRE(!t->batch_norm, "tower_backward: defer_reduce cannot be combined with batch_norm");
+        return ABN_OK;                           // abn_tower_reduce_step finishes the job
     }
-    rt.total = B.off[nl - 1] + rt.nW[nl - 1] + rt.nb[nl - 1];
+    const ReduceTable rt = make_reduce_table(t, B);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, slabs, rt);
     ABN_CHECK_LAUNCH("slab_reduce");
+    return ABN_OK;
+}
+
+int abn_tower_reduce_step(const abn_tower_desc* t, int64_t rows, const float* scratch, int64_t scratch_floats, int kind,
+                          float* params, float* grads, float* state1, float* state2, int64_t n, float lr, float hp0,
+                          float hp1, float eps, int64_t step, float grad_scale, void* stream)
+{
+    int rc = check_desc(t, rows, 1);
+    if (rc != ABN_OK) return rc;
+    ABN_REQUIRE(!t->batch_norm, "tower_reduce_step: not with batch_norm (its gradients do not come in slabs)");
+    ABN_REQUIRE(kind >= ABN_OPT_SGD && kind <= ABN_OPT_RMSPROP, "tower_reduce_step: unknown optimizer %d", kind);
+    ABN_REQUIRE(scratch && params && grads && state1, "tower_reduce_step: null pointer");
+    ABN_REQUIRE(state2 || (kind != ABN_OPT_ADADELTA && kind != ABN_OPT_ADAM), "tower_reduce_step: state2 required");
+    ABN_REQUIRE(step >= 1 && n >= 1, "tower_reduce_step: bad n/step");
+    const BwdLayout B = make_bwd_layout(t, rows);
+    if (scratch_floats < B.total) { set_error("tower_reduce_step: scratch too small"); return ABN_E_WORKSPACE; }
+    const ReduceTable rt = make_reduce_table(t, B);
+    for (int l = 0; l < t->n_layers; ++l) {      // every gradient tensor must lie inside the flat buffers
+        ABN_REQUIRE(t->dW[l] && t->db[l] && t->dW[l] >= grads && t->dW[l] + rt.nW[l] <= grads + n && t->db[l] >= grads &&
+                        t->db[l] + rt.nb[l] <= grads + n,
+                    "tower_reduce_step: layer %d's gradients are not inside the flat buffer", l);
+    }
+    hipLaunchKernelGGL(slab_reduce_step_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       scratch + B.slabs, rt, make_optp(kind, lr, hp0, hp1, eps, step, grad_scale), params, grads, state1,
+                       state2);
+    ABN_CHECK_LAUNCH("tower_reduce_step");
     return ABN_OK;
 }
 

@@ -117,6 +117,9 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
     }
     const int kc_lane = 4 * ((lane & 3) ^ ((lane >> 3) & 3));      // (n >> 1) & 3 == (lane >> 3) & 3
     auto dma = [&](int kt, int stage) {
+#ifdef FEXP_NODMA
+        return;
+#endif
         float* dst = Wst + stage * FUSED_WTILE;
         int gk = (kt_first + kt) * FUSED_BK + kc_lane;
         gk = gk <= K - 4 ? gk : K - 4;
@@ -173,8 +176,17 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
         // with one wave per SIMD nothing but the wave itself hides LDS latency:
         // the second k-group's fragments are read before the first group's MFMAs
         f32x4 fa0, fa1, fb0[BPW], fb1[BPW];
+#ifdef FEXP_NOFRAG
+        fa0 = fa1 = f32x4{(float)kt, 1.f, 2.f, 3.f};
+        for (int j = 0; j < BPW; ++j) fb0[j] = fb1[j] = f32x4{(float)lane, 1.f, (float)kt, 3.f};
+#else
         load_frags(fa0, fb0, ws, k0, 0);
         load_frags(fa1, fb1, ws, k0, 1);
+#endif
+#ifdef FEXP_NOMFMA
+        for (int j = 0; j < BPW; ++j) acc[j][kt & 15] += fa0[0] * fb0[j][1] + fa1[2] * fb1[j][3];
+        continue;
+#endif
         if constexpr (BF16 == 2) {                // bf16 x 3 (gemm_f32.h): six bf16 MFMAs per column block and tile
             const bf16x8x3 pa = split_bf16x3(fa0, fa1);
 #pragma unroll
@@ -254,6 +266,9 @@ __device__ __forceinline__ void fused_layer(const FusedFwdP& p, int l, float* __
     // X -> HBM (saved activation for the backward / the embedding), full rows,
     // 16 bytes per lane; asynchronous: nobody waits for these stores
     float* __restrict__ out = p.out[l];
+#ifdef FEXP_NOOUT
+    if (p.rows > 0) return;
+#endif
     const int n4 = N / 4;
     for (int i = threadIdx.x; i < FUSED_ROWS * n4; i += FUSED_NT) {
         const int r = i / n4, c = 4 * (i % n4);

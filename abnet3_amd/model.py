@@ -145,7 +145,7 @@ class _Segment(object):
         self._desc_cache = (key, d, grad_slots)
         return d
 
-    def descriptor(self, with_grads, grad_buf=None, masks=None, d_out_is_dz=False):
+    def descriptor(self, with_grads, grad_buf=None, masks=None, d_out_is_dz=False, defer_reduce=False):
         """abn_tower_desc for one call.  grad_buf: the flat gradient buffer of this
         backward pass (gradients land at the parameters' offsets in it)."""
         tmpl = self._template()
@@ -153,6 +153,7 @@ class _Segment(object):
             return tmpl                        # read-only for the library
         d = _lib.TowerDesc.from_buffer_copy(tmpl)
         d.d_out_is_dz = int(d_out_is_dz)
+        d.defer_reduce = int(defer_reduce)
         if masks is not None:
             for l, m in enumerate(masks):
                 d.drop_mask[l] = m.data_ptr()
@@ -240,9 +241,11 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2):
     return out, sv
 
 
-def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False):
+def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False, defer_reduce=False):
     """Raw backward of one segment: abn_tower_backward into the pass's flat gradient
-    buffer.  Returns (per-parameter gradient views, dx or None)."""
+    buffer.  Returns (per-parameter gradient views, dx or None).  With defer_reduce the
+    weight gradients stay unreduced in the scratch and the third return value is what
+    abn_tower_reduce_step needs to finish: (descriptor, rows, scratch, scratch floats, buffer)."""
     lib = _lib.load()
     if seg.batch_norm and not sv.train:
         raise NotImplementedError(
@@ -253,7 +256,8 @@ def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False):
     _lib.require_device(d_out)
     rows = d_out.shape[0]
     grad_buf, grads = grad_pass.views(seg)
-    desc = seg.descriptor(with_grads=True, grad_buf=grad_buf, masks=sv.masks, d_out_is_dz=d_out_is_dz)
+    desc = seg.descriptor(with_grads=True, grad_buf=grad_buf, masks=sv.masks, d_out_is_dz=d_out_is_dz,
+                          defer_reduce=defer_reduce)
     scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
     scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32, device=d_out.device)
     dx = torch.empty(rows, seg.input_dim, dtype=torch.float32,
@@ -262,6 +266,8 @@ def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False):
         _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(d_out), rows,
         sv.n_calls, _lib.ptr(sv.ws), _lib.ptr(scratch), scratch_floats,
         _lib.ptr(dx), _lib.stream()), 'abn_tower_backward')
+    if defer_reduce:
+        return grads, dx, (desc, rows, scratch, scratch_floats, grad_buf)
     return grads, dx
 
 
@@ -653,14 +659,33 @@ class SiameseNetwork(_HipNetwork):
             masks = (m[:half], m[half:])
         return seg.last_act, masks
 
-    def direct_backward(self, state, d_out, d_out_is_dz=False):
+    def can_defer_reduce(self, state):
+        """True when direct_backward may leave the split-K reduction to the optimizer's
+        launch (abn_tower_reduce_step): no BatchNorm, and one segment owns every live parameter."""
+        seg = state[0]
+        return (not seg.batch_norm and os.environ.get('ABN_FUSED_STEP') != '0'      # (the variable: A/B runs)
+                and len(seg.params) == len(self.live_parameters()))
+
+    def direct_backward(self, state, d_out, d_out_is_dz=False, defer_reduce=False):
         """Backward of direct_forward: gradients of every parameter land in a fresh
         flat buffer and are installed as p.grad (views), exactly what autograd's
-        backward leaves behind."""
+        backward leaves behind.  With defer_reduce the p.grad views are installed but
+        hold nothing yet: FlatOptimizer.step() must follow, it sums the split-K slabs,
+        fills the gradients and updates the parameters in one launch."""
         seg, sv, grad_pass = state
-        grads, _ = _segment_backward(seg, sv, d_out, grad_pass, False, d_out_is_dz)
+        self._pending_reduce = None
+        if defer_reduce:
+            grads, _, self._pending_reduce = _segment_backward(seg, sv, d_out, grad_pass, False, d_out_is_dz, True)
+        else:
+            grads, _ = _segment_backward(seg, sv, d_out, grad_pass, False, d_out_is_dz)
         for p, g in zip(seg.params, grads):
             p.grad = g
+
+    def take_pending_reduce(self):
+        """The unfinished reduction a direct_backward(defer_reduce=True) left (or None); clears it."""
+        pending = getattr(self, '_pending_reduce', None)
+        self._pending_reduce = None
+        return pending
 
     # -- reference surface ---------------------------------------------------
     def forward_once(self, x):

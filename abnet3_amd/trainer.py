@@ -86,12 +86,24 @@ class FlatOptimizer(object):
     def step(self):
         lib = _lib.load()
         flat = self._state()
+        take = getattr(self.network, 'take_pending_reduce', None)
+        pending = take() if take is not None else None
         grad = self.network.flat_grad()
         _lib.require_device(flat, grad)
         self.step_count += 1
         hp0, hp1, eps = self.HP[self.kind]
         if self.kind == 'sgd':
             hp0 = self.momentum
+        if pending is not None:
+            # the backward left its split-K slabs unreduced: reduction + update in one launch
+            desc, rows, scratch, scratch_floats, grad_buf = pending
+            if grad_buf.data_ptr() != grad.data_ptr():
+                raise RuntimeError('abnet3_amd: gradients were replaced between a deferred backward and step()')
+            _lib.check(lib.abn_tower_reduce_step(
+                _lib.C.byref(desc), rows, _lib.ptr(scratch), scratch_floats, _lib.OPT[self.kind], _lib.ptr(flat),
+                _lib.ptr(grad), _lib.ptr(self._s1), _lib.ptr(self._s2), flat.numel(), self.lr, hp0, hp1, eps,
+                self.step_count, float(self.grad_scale), _lib.stream()), 'abn_tower_reduce_step')
+            return
         _lib.check(lib.abn_optimizer_step(
             _lib.OPT[self.kind], _lib.ptr(flat), _lib.ptr(grad), _lib.ptr(self._s1),
             _lib.ptr(self._s2), flat.numel(), self.lr, hp0, hp1, eps, self.step_count,
@@ -313,12 +325,15 @@ class TrainerSiamese(TrainerBuilder):
             n = X_batch1.shape[0]
             info = self.network.direct_dz_info(state)
             self.optimizer.zero_grad()
+            # single process: nothing happens between backward and step, so the split-K
+            # reduction of the weight gradients rides in the optimizer's launch
+            defer = self.world_size == 1 and self.network.can_defer_reduce(state)
             if info is not None:      # loss gradient and the output layer's act' (+ dropout) in ONE launch
                 loss_value, dz = self.loss.value_and_dz(emb[:n], emb[n:], y_batch, info[0], info[1])
-                self.network.direct_backward(state, dz.view(2 * n, -1), d_out_is_dz=True)
+                self.network.direct_backward(state, dz.view(2 * n, -1), d_out_is_dz=True, defer_reduce=defer)
             else:
                 loss_value, de = self.loss.value_and_grad(emb[:n], emb[n:], y_batch)
-                self.network.direct_backward(state, de.view(2 * n, -1))
+                self.network.direct_backward(state, de.view(2 * n, -1), defer_reduce=defer)
             if self.world_size > 1:
                 self.optimizer.grad_scale = parallel.all_reduce_gradients(
                     self.network.flat_grad(), self._loss_is_mean())

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 7
+#define ABN_ABI_VERSION 8
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -97,6 +97,11 @@ typedef struct abn_tower_desc {
      * the activation derivative / dropout step in front of the last layer's GEMMs is skipped.
      * Not with batch_norm (its backward needs d loss / d a). */
     int32_t d_out_is_dz;
+    /* backward only: leave the weight gradients as unreduced split-K slabs in `scratch`; the
+     * caller finishes with abn_tower_reduce_step (reduction + optimizer step in one launch).
+     * Not with batch_norm. */
+    int32_t defer_reduce;
+    int32_t reserved_;
 } abn_tower_desc;
 
 /* Workspace of one forward call (saved activations for backward), in floats,
@@ -126,6 +131,18 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
                        const float* d_out, int64_t rows, int64_t n_calls,
                        const float* ws, float* scratch, int64_t scratch_floats,
                        float* dx, void* stream);
+
+/* Finishes an abn_tower_backward that ran with defer_reduce = 1 (same descriptor, rows and
+ * scratch): sums the split-K slabs in their fixed order, writes the gradients to dW / db AND
+ * applies abn_optimizer_step's update to the same elements -- one launch for what is otherwise
+ * the slab reduction followed by the optimizer step (abnet3/trainer.py:239-240 back to back, no
+ * gradient exchange in between: single process).  params / grads / state1 / state2 are the flat
+ * buffers (n floats each) that hold every tensor of the descriptor at the same offsets: element j
+ * of layer l's weight lives at (dW[l] - grads) + j in all four. */
+int abn_tower_reduce_step(const abn_tower_desc* t, int64_t rows, const float* scratch,
+                          int64_t scratch_floats, int kind, float* params, float* grads,
+                          float* state1, float* state2, int64_t n, float lr, float hp0,
+                          float hp1, float eps, int64_t step, float grad_scale, void* stream);
 
 /* One nn.Linear at a time with the same kernels (what abn_tower_* chains):
  *   forward  y = act(x W^T + b)                       (addmm + activation)

@@ -225,3 +225,32 @@ def test_strided_inputs_are_accepted():
         a = net.forward_once(sl)
         b = net.forward_once(sl.contiguous())
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('oname', ['sgd', 'adadelta', 'adam', 'adagrad', 'RMSprop'])
+def test_fused_reduce_and_step_equals_the_two_launches_bit_for_bit(oname, monkeypatch):
+    """abn_tower_reduce_step (split-K reduction + optimizer update in one launch, what
+    train_step uses in a single process without BatchNorm) against slab_reduce followed by
+    abn_optimizer_step: same summation order, same update arithmetic -> identical bits in
+    the gradients, the parameters and the optimizer state after three steps."""
+    g = load_golden('train_c1_bn0.npz')
+    batch = (dev(g['x1']), dev(g['x2']), dev(g['y']))
+    runs = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('ABN_FUSED_STEP', fused)
+        net, _ = cuda_net(g)
+        tr = trainer(net, 'coscos2', 0, oname)
+        net.train()
+        for s in range(3):
+            tr.train_step(batch, True)
+            pending = getattr(net, '_pending_reduce', None)
+            assert pending is None                       # step() consumed it
+        assert net.grads_in_flat_buffer()
+        runs.append(([p.grad.clone() for p in net.parameters()], [p.detach().clone() for p in net.parameters()],
+                     tr.optimizer._s1.clone(), tr.optimizer._s2.clone(), net._offsets, net))
+    (ga, pa, s1a, s2a, offs, net), (gb, pb, s1b, s2b, _, _) = runs
+    for a, b in zip(ga + pa, gb + pb):
+        assert torch.equal(a, b)
+    for p, off in zip(net.live_parameters(), offs):      # state of the real elements (padding is never touched fused)
+        n = p.numel()
+        assert torch.equal(s1a[off:off + n], s1b[off:off + n]) and torch.equal(s2a[off:off + n], s2b[off:off + n])
