@@ -451,7 +451,9 @@ struct Layout {
     int64_t xhat[ABN_MAX_LAYERS];        // BN only (z is produced here, then normalised in place)
     int64_t mean[ABN_MAX_LAYERS], invstd[ABN_MAX_LAYERS], var[ABN_MAX_LAYERS];
     int64_t bn_part;                     // BN only: stage-1 partial sums (doubles), shared by the layers
-    int64_t wp[ABN_MAX_LAYERS];          // precision 1 / 2 without BN: the weights as MFMA operand fragments (tower_planes.h)
+    // precision 1 / 2 without BN (tower_planes.h): the weights and their transposes as MFMA operand
+    // fragments, and the weight-gradient operands [x | 1], [a_l | 1] as transposed planes
+    int64_t wp[ABN_MAX_LAYERS], wpt[ABN_MAX_LAYERS], tp[ABN_MAX_LAYERS];
     int64_t total;
 };
 
@@ -488,12 +490,33 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
         for (int l = 1; l <= t->n_layers; ++l) maxw = t->dims[l] > maxw ? t->dims[l] : maxw;
         L.bn_part = take(2 * n_calls * bn_chunks(rows / n_calls) * 2 * maxw);      // doubles = 2 floats each
     }
-    for (int l = 0; l < t->n_layers; ++l) L.wp[l] = -1;
-    if (planes_shape_ok(t))
-        for (int l = 0; l < t->n_layers; ++l)
-            L.wp[l] = take(pl_image_bytes(t->dims[l + 1], t->dims[l], planes_of(t->precision)) / 4);
+    for (int l = 0; l < t->n_layers; ++l) L.wp[l] = L.wpt[l] = L.tp[l] = -1;
+    if (planes_shape_ok(t)) {
+        const int np = planes_of(t->precision);
+        for (int l = 0; l < t->n_layers; ++l) {
+            L.wp[l] = take(pl_image_bytes(t->dims[l + 1], t->dims[l], np) / 4);
+            if (l > 0) L.wpt[l] = take(pl_image_bytes(t->dims[l], t->dims[l + 1], np) / 4);
+            L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, rows, np) / 4);
+        }
+    }
     L.total = o;
     return L;
+}
+
+// The planes kernels (tower_planes.h) take a call when ...  Forward and backward must agree: both ask here.
+// (the switches are read per call: tests flip them inside one process)
+static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws)
+{
+    if (getenv("ABN_PLANES") && atoi(getenv("ABN_PLANES")) == 0) return false;
+    if (getenv("ABN_FUSED") && atoi(getenv("ABN_FUSED")) == 0) return false;
+    // a workgroup walks its 32 rows through every layer whatever the batch: it only pays once there
+    // are workgroups for most CUs; below that the per-layer GEMMs (tiles over rows AND columns) win
+    const int64_t min_rows = getenv("ABN_FUSED_MIN_ROWS") ? atoll(getenv("ABN_FUSED_MIN_ROWS")) : 6144;
+    if (rows < min_rows || !planes_shape_ok(t)) return false;
+    if (!aligned16(x1) || (x2 && !aligned16(x2)) || !aligned16(ws)) return false;
+    for (int l = 0; l < t->n_layers; ++l)
+        if (!aligned16(t->W[l]) || !aligned16(t->b[l]) || (t->drop_mask[l] && !aligned16(t->drop_mask[l]))) return false;
+    return true;
 }
 
 static int check_desc(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
@@ -540,6 +563,7 @@ struct BwdLayout {
     int64_t slab_stride;
     int64_t off[ABN_MAX_LAYERS];
     int splits[ABN_MAX_LAYERS];
+    int64_t dzp[ABN_MAX_LAYERS];     // tower_planes.h: transposed planes of dZ_l
     int64_t total;
 };
 
@@ -565,6 +589,8 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
         smax = B.splits[l] > smax ? B.splits[l] : smax;
     }
     B.slabs = take(B.slab_stride * smax);
+    for (int l = 0; l < t->n_layers; ++l)
+        B.dzp[l] = planes_shape_ok(t) ? take(pl_timage_bytes(t->dims[l + 1], rows, planes_of(t->precision)) / 4) : -1;
     B.total = o;
     return B;
 }
@@ -610,6 +636,17 @@ int64_t abn_tower_out_offset(const abn_tower_desc* t, int64_t rows, int64_t n_ca
     return make_layout(t, rows, n_calls).a[t->n_layers - 1];
 }
 
+// Diagnostics / tests only (not in the header): float offset of one of the operand-fragment images
+// -- which = 0 packed W_l, 1 packed W_l^T, 2 transposed planes [input of layer l | 1] (all in the
+// forward workspace), 3 transposed planes of dZ_l (in the backward scratch) -- or -1.
+int64_t abn_debug_planes_offset(const abn_tower_desc* t, int64_t rows, int64_t n_calls, int which, int l)
+{
+    if (check_desc(t, rows, n_calls) != ABN_OK || l < 0 || l >= t->n_layers) return -1;
+    if (which == 3) return make_bwd_layout(t, rows).dzp[l];
+    const Layout L = make_layout(t, rows, n_calls);
+    return which == 0 ? L.wp[l] : which == 1 ? L.wpt[l] : which == 2 ? L.tp[l] : -1;
+}
+
 int64_t abn_tower_bwd_scratch_floats(const abn_tower_desc* t, int64_t rows)
 {
     if (check_desc(t, rows, 1) != ABN_OK) return -1;
@@ -646,8 +683,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         fusable = t->dims[l] >= 4 && t->dims[l] <= FUSED_MAXW && t->dims[l] % 4 == 0;
     for (int l = 0; l < t->n_layers && fusable; ++l)
         fusable = aligned16(t->W[l]) && (!t->drop_mask[l] || !train || aligned16(t->drop_mask[l]));
-    const bool planes_enabled = !(getenv("ABN_PLANES") && atoi(getenv("ABN_PLANES")) == 0);
-    if (fusable && planes_enabled && planes_shape_ok(t)) {
+    if (planes_path(t, rows, x1, x2, ws)) {
         const int np = planes_of(t->precision);
         PackTable pk = {};
         PlanesFwdP f = {};
@@ -669,7 +705,16 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
             J.nblk = pl_blocks(J.N); J.nsteps = pl_steps(J.K);
             J.tile0 = pk.n_tiles; J.dst = L.wp[l] * 4;
             pk.n_tiles += J.nblk * J.nsteps;
+            if (l > 0) {                         // W_l^T for the backward's data-gradient chain
+                PackJob& T = pk.job[pk.n_jobs++];
+                T.W = t->W[l]; T.N = J.N; T.K = J.K; T.transposed = 1;
+                T.nblk = pl_blocks(T.K); T.nsteps = pl_steps(T.N);
+                T.tile0 = pk.n_tiles; T.dst = L.wpt[l] * 4;
+                pk.n_tiles += T.nblk * T.nsteps;
+            }
+            f.tp[l] = reinterpret_cast<char*>(ws + L.tp[l]);
         }
+        f.tp_steps = pl_row_steps(rows);
 #ifdef ABN_STAMPS
         f.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
 #endif
@@ -809,6 +854,81 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     const int64_t rpc = rows / n_calls;
     const float* xin = x2 ? ws + L.x : x1;
     const int nl = t->n_layers;
+
+    // The forward that filled `ws` went through the planes kernels (same predicate): its workspace
+    // holds W^T and the weight-gradient operands as operand fragments.  Two launches: the data
+    // gradient chain (one workgroup per 32 rows, all layers), then every layer's weight gradient.
+    if (!dx && planes_path(t, rows, x1, x2, ws)) {
+        const int np = planes_of(t->precision);
+        PlanesBwdP b = {};
+        b.n_layers = nl;
+        b.rows = (int)rows;
+        b.d_out = d_out;
+        b.d_out_is_dz = t->d_out_is_dz;
+        b.tp_steps = pl_row_steps(rows);
+        ABN_REQUIRE(aligned16(d_out) && aligned16(scratch), "tower_backward: d_out / scratch must be 16-byte aligned");
+        for (int l = 0; l <= nl; ++l) b.dims[l] = (int)t->dims[l];
+        for (int l = 0; l < nl; ++l) {
+            b.act[l] = (l == nl - 1) ? t->last_act : t->act;
+            b.a[l] = ws + L.a[l];
+            b.mask[l] = t->drop_mask[l];
+            b.wpt[l] = l > 0 ? reinterpret_cast<const char*>(ws + L.wpt[l]) : nullptr;
+            b.dzp[l] = reinterpret_cast<char*>(scratch + B.dzp[l]);
+        }
+        WgradP w = {};
+        w.slabs = scratch + B.slabs;
+        w.slab_stride = B.slab_stride;
+        w.tp_steps = b.tp_steps;
+        // launch order: most row steps per workgroup first
+        int order[ABN_MAX_LAYERS];
+        for (int l = 0; l < nl; ++l) order[l] = l;
+        for (int i = 1; i < nl; ++i)
+            for (int j = i; j > 0 && B.splits[order[j]] < B.splits[order[j - 1]]; --j) { int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
+        int n_wg = 0;
+        for (int i = 0; i < nl; ++i) {
+            const int l = order[i];
+            WgradLayer& W = w.L[w.n_layers++];
+            W.dzp = b.dzp[l];
+            W.ap = reinterpret_cast<const char*>(ws + L.tp[l]);
+            W.N = (int)t->dims[l + 1]; W.K = (int)t->dims[l];
+            W.nblk = pl_blocks(W.N); W.kblk = pl_blocks(W.K + 1);
+            W.tiles_n = (W.nblk + 3) / 4; W.tiles_k = (W.kblk + 3) / 4;
+            W.splits = B.splits[l];
+            W.first_wg = n_wg;
+            W.slab_off = B.off[l];
+            n_wg += W.tiles_n * W.tiles_k * W.splits;
+        }
+        static bool bw_attr_set[16] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev = (dev >= 0 && dev < 16) ? dev : 0;
+        if (!bw_attr_set[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_dgrad_planes_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(1));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_dgrad_planes_kernel<3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(3));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<1>());
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<3>());
+            bw_attr_set[dev] = true;
+        }
+        const dim3 cgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
+        if (np == 3) {
+            hipLaunchKernelGGL(tower_dgrad_planes_kernel<3>, cgrid, dim3(PL_NT), pl_lds_bytes(3), st, b);
+            hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
+        } else {
+            hipLaunchKernelGGL(tower_dgrad_planes_kernel<1>, cgrid, dim3(PL_NT), pl_lds_bytes(1), st, b);
+            hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
+        }
+        ABN_CHECK_LAUNCH("tower_backward (planes)");
+        if (t->defer_reduce) return ABN_OK;      // abn_tower_reduce_step finishes the job
+        const ReduceTable rt = make_reduce_table(t, B);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, scratch + B.slabs, rt);
+        ABN_CHECK_LAUNCH("slab_reduce");
+        return ABN_OK;
+    }
+
     int cur = 0;
     const float* dz_in = nullptr;                // the output layer's dz when the caller supplied it
 

@@ -1,28 +1,34 @@
-// tower_planes.h -- the tower forward on bf16 MFMA operands that are split ONCE (bf16 x 3, or plain
-// bf16), no BatchNorm, widths <= 512.  Replaces tower_fused.h's kernel for precision 1 and 2.
+// tower_planes.h -- the tower forward AND backward on bf16 MFMA operands that are split ONCE
+// (bf16 x 3, or plain bf16), no BatchNorm, widths <= 512.  Precision 1 and 2 only.
 //
-// What the stamps and the knock-out builds said about that kernel: its floor is
-// the per-wave weight stream (LDS-DMA of 64-byte row pieces, 1.6 us latency under load: 80 us with
+// What the stamps and the knock-out builds said about tower_fused.h / gemm_f32.h:
+// the forward's floor was the per-wave weight stream (LDS-DMA of 64-byte row pieces: 80 us with
 // every MFMA and fragment read removed), and in the bf16 x 3 arithmetic every wave re-split the same
-// fp32 fragments on the VALU (activations 8 times per workgroup, weights once per workgroup = 256
-// times per step).  Here nothing on the k-loop touches the VALU:
+// fp32 fragments on the VALU (activations 8 times per workgroup, weights 256 times per step).
+// Here nothing on a k-loop touches the VALU:
 //
-//   * pack_planes_kernel turns each weight matrix into MFMA operand fragments once per call:
-//       image[block of 32 output features][step of 16 k][plane hi|mid|lo][lane][8 bf16]
-//     -- 1 KB per (block, step, plane), consecutive steps contiguous: a wave streams its block's
-//     weights with one 16-byte global load per lane, plane and step, STRAIGHT INTO REGISTERS
-//     (full cache lines, no LDS round trip, the ring of PL_DEPTH steps lives in VGPRs);
-//   * the products are transposed, Y^T = W X^T: the weights are the MFMA's A operand, the 32 rows of
-//     the workgroup its B operand.  The accumulator then has the batch row on the lane and 16
-//     output features in its registers -- which IS the B-operand layout of the next layer (guide:
-//     "an accumulator tile as the next MFMA's operand", k order 16s + 8(j>>2) + 4h + (j&3) inside
-//     a step; the packed weights carry the same permutation).  The epilogue splits each value once
-//     and writes whole fragments, 16 bytes per lane and plane, into the LDS image
-//       img[step][plane][lane][8 bf16]
-//     that all eight waves read back lane-linearly (conflict free) as their B operand.
-//
-// Per step and 32-feature block a wave issues 3 global loads, (shared by its blocks) 3 LDS reads
-// and 6 MFMAs -- no conversion, no address arithmetic beyond an add.
+//   * pack_planes_kernel turns each weight matrix (and its transpose, for the backward) into MFMA
+//     operand fragments once per step:
+//       image[block of 32 operand rows][step of 16 along the sum][plane hi|mid|lo][lane][8 bf16]
+//     1 KB per (block, step, plane), consecutive steps contiguous: a wave streams its block's
+//     weights with one 16-byte load per lane, plane and step STRAIGHT INTO REGISTERS (whole cache
+//     lines, no LDS round trip; the ring of PL_DEPTH steps lives in VGPRs);
+//   * the chain products are transposed, Y^T = W X^T and dZ_in^T = W^T dZ_out^T: the weights are the
+//     MFMA's A operand, the 32 batch rows of the workgroup its B operand.  The accumulator then has
+//     the batch row on the lane and 16 features in its registers -- which IS the B-operand layout
+//     of the next product of the chain (guide: "an accumulator tile as the next MFMA's operand",
+//     k order 16s + 8(j>>2) + 4h + (j&3) inside a step; the packed weights carry the same
+//     permutation).  The epilogue splits each value once and writes whole fragments, 16 bytes per
+//     lane and plane, into the LDS image  img[step][plane][lane][8 bf16]  that all eight waves read
+//     back lane-linearly (conflict free);
+//   * the weight gradient dW = dZ^T A sums over the batch rows, the lane index of both chains'
+//     accumulators.  Each chain epilogue therefore also hands its tile to the MFMA once more, as
+//     the A operand against a (permuted) identity: the result is the tile transposed -- feature on
+//     the lane, batch rows in the registers, exact, because every plane is a bf16 value times 1 --
+//     and goes to HBM as ready-made operand fragments
+//       planes[block of 32 features][step of 16 batch rows][plane][lane][8 bf16].
+//     wgrad_planes_kernel streams both operands in that form (LDS-DMA, lane-linear) and does nothing
+//     but MFMAs.  A column of ones appended to the activation image yields the bias gradient.
 #pragma once
 #include <type_traits>
 
@@ -45,12 +51,92 @@ constexpr int PL_DEPTH = 4;                       // weight steps in flight per 
 constexpr int PL_PART_BYTES = 4 * 16 * 64 * 4;    // K-split hand-over: 4 waves x one accumulator block
 
 __host__ __device__ inline int pl_steps(int64_t contraction) { return ((int)((contraction + 15) / 16) + PL_DEPTH - 1) / PL_DEPTH * PL_DEPTH; }
-static inline int pl_blocks(int64_t features) { return (int)((features + 31) / 32); }
+__host__ __device__ inline int pl_blocks(int64_t features) { return (int)((features + 31) / 32); }
 static inline int64_t pl_image_bytes(int64_t features, int64_t contraction, int np)
 {
     return (int64_t)pl_blocks(features) * pl_steps(contraction) * np * 1024;
 }
+// batch-row steps of the transposed (weight-gradient) images: two per 32-row workgroup
+static inline int64_t pl_row_steps(int64_t rows) { return (rows + PL_ROWS - 1) / PL_ROWS * 2; }
+static inline int64_t pl_timage_bytes(int64_t features, int64_t rows, int np) { return (int64_t)pl_blocks(features) * pl_row_steps(rows) * np * 1024; }
 static inline size_t pl_lds_bytes(int np) { return (size_t)PL_MAXSTEPS * np * 1024 + PL_PART_BYTES; }
+
+#ifdef ABN_STAMPS
+#define PSTAMPF(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 128 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PSTAMPF(slot) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// fragments
+// ---------------------------------------------------------------------------------------------
+template <int NP> struct Frag { bf16x8 p[NP]; };
+
+template <int NP>
+__device__ __forceinline__ Frag<NP> make_frag(const f32x4& v0, const f32x4& v1)
+{
+    Frag<NP> f;
+    if constexpr (NP == 3) {
+        const bf16x8x3 s = split_bf16x3(v0, v1);
+        f.p[0] = s.hi; f.p[1] = s.mid; f.p[2] = s.lo;
+    } else {
+        f.p[0] = pack_bf16(v0, v1);
+    }
+    return f;
+}
+
+template <int NP>
+__device__ __forceinline__ void store_frag(char* dst, const Frag<NP>& f)
+{
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<bf16x8*>(dst + pl * 1024) = f.p[pl];
+}
+
+template <int NP>
+__device__ __forceinline__ void write_frag(char* dst, const f32x4& v0, const f32x4& v1)
+{
+    store_frag<NP>(dst, make_frag<NP>(v0, v1));
+}
+
+// B operand of the transposing product: element j of lane (c, h) in step s is 1 where the (permuted)
+// k index 16 s + 8 (j >> 2) + 4 h + (j & 3) equals the column c
+__device__ __forceinline__ void make_identity(bf16x8 idf[2], int lane)
+{
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) idf[s][j] = (__bf16)((16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) == c ? 1.0f : 0.0f);
+}
+
+// One 32-feature block of one workgroup (32 batch rows), held as the two k-steps' fragments f[0], f[1]
+// (lane = batch row), written transposed: dst -> planes[block][this workgroup's first row step], + lane * 16.
+// ones_c >= 0: that column of the block is the appended column of ones (rows below rows_left only).
+template <int NP>
+__device__ __forceinline__ void emit_planes(char* dst, const Frag<NP> f[2], const bf16x8 idf[2], int lane, int ones_c, int rows_left)
+{
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+        f32x16 t;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = 0.0f;
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0].p[pl], idf[0], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1].p[pl], idf[1], t, 0, 0, 0);
+        // t[q] of lane (c, h) = feature c of batch row (q & 3) + 8 (q >> 2) + 4 h
+        if (c == ones_c) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t[q] = (pl == 0 && (q & 3) + 8 * (q >> 2) + 4 * h < rows_left) ? 1.0f : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)t[8 * s + j];
+            *reinterpret_cast<bf16x8*>(dst + (s * NP + pl) * 1024) = o;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // weights -> operand fragments
@@ -71,19 +157,6 @@ struct PackTable {
 };
 
 template <int NP>
-__device__ __forceinline__ void write_frag(char* dst, const f32x4& v0, const f32x4& v1)
-{
-    if constexpr (NP == 3) {
-        const bf16x8x3 s = split_bf16x3(v0, v1);
-        *reinterpret_cast<bf16x8*>(dst) = s.hi;
-        *reinterpret_cast<bf16x8*>(dst + 1024) = s.mid;
-        *reinterpret_cast<bf16x8*>(dst + 2048) = s.lo;
-    } else {
-        *reinterpret_cast<bf16x8*>(dst) = pack_bf16(v0, v1);
-    }
-}
-
-template <int NP>
 __global__ __launch_bounds__(256) void pack_planes_kernel(PackTable t)
 {
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -99,14 +172,125 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(PackTable t)
     const int len_c = J.transposed ? J.N : J.K;      // length of the sum
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
     if (a < rows_a) {
+        const int c0 = 16 * s + 4 * h, c1 = c0 + 8;
+        if (!J.transposed) {                         // K % 4 == 0: four k in or out together
+            if (c0 < len_c) v0 = *reinterpret_cast<const f32x4*>(J.W + (int64_t)a * J.K + c0);
+            if (c1 < len_c) v1 = *reinterpret_cast<const f32x4*>(J.W + (int64_t)a * J.K + c1);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c0 = 16 * s + 4 * h + e, c1 = c0 + 8;
-            if (c0 < len_c) v0[e] = J.transposed ? J.W[(int64_t)c0 * J.K + a] : J.W[(int64_t)a * J.K + c0];
-            if (c1 < len_c) v1[e] = J.transposed ? J.W[(int64_t)c1 * J.K + a] : J.W[(int64_t)a * J.K + c1];
+            for (int e = 0; e < 4; ++e) {
+                if (c0 + e < len_c) v0[e] = J.W[(int64_t)(c0 + e) * J.K + a];
+                if (c1 + e < len_c) v1[e] = J.W[(int64_t)(c1 + e) * J.K + a];
+            }
         }
     }
     write_frag<NP>(t.base + J.dst + ((int64_t)local * NP) * 1024 + lane * 16, v0, v1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the chains' k-loop
+// ---------------------------------------------------------------------------------------------
+// acc[j] += image block (blk0 + j) x img, over steps s_first .. s_first + my_steps (a multiple of PL_DEPTH)
+template <int NP, int BPW>
+__device__ __forceinline__ void planes_kloop(f32x16* acc, const char* __restrict__ image, int nblk, int nsteps,
+                                             const char* __restrict__ img, int blk0, int s_first, int my_steps, int lane)
+{
+    // The weight ring is filled with raw buffer loads: the compiler counts their vmcnt itself, and --
+    // unlike plain loads, which InstCombine sinks through the loop's phi right in front of their
+    // MFMAs -- they stay where the pipeline puts them, PL_DEPTH steps ahead.
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(image), 0, nblk * nsteps * (NP * 1024), 0x00020000);
+    int wv[BPW];
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+        const int blk = blk0 + j < nblk ? blk0 + j : nblk - 1;        // an odd block count leaves the last wave half idle
+        wv[j] = (blk * nsteps + s_first) * (NP * 1024) + lane * 16;
+    }
+    const char* ab = img + (int64_t)s_first * (NP * 1024) + lane * 16;
+    v4i wq[PL_DEPTH][BPW][NP];
+#pragma unroll
+    for (int i = 0; i < PL_DEPTH; ++i)
+#pragma unroll
+        for (int j = 0; j < BPW; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                // (fenced one by one: the in-order vmcnt the compiler derives for the loop is the worst of
+                // the loop's own order and this one)
+                wq[i][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, wv[j], (i * NP + pl) * 1024, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    // activation fragments: read one step ahead, into alternating register sets
+    bf16x8 af[2][NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(ab + pl * 1024);
+    for (int s0 = 0; s0 < my_steps; s0 += PL_DEPTH) {
+#pragma unroll
+        for (int i = 0; i < PL_DEPTH; ++i) {
+            const int s = s0 + i;
+            // (the three regions are fenced: left alone, the machine scheduler issues a refill before
+            // the slot's last MFMA -- a second register set and copies that wait for the loads at the
+            // loop's end -- or gathers all refills there)
+            const int s1 = s + 1 < my_steps ? s + 1 : s;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) af[(i + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(ab + (s1 * NP + pl) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8* a = af[i & 1];
+            if constexpr (NP == 3) {
+                // smallest terms first (gemm_f32.h); the blocks alternate so that consecutive MFMAs are independent
+                constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, AP[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int j = 0; j < BPW; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[i][j][WP[t]]), a[AP[t]], acc[j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < BPW; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[i][j][0]), a[0], acc[j], 0, 0, 0);
+            }
+            // (pure MFMA nodes float across a sched_barrier at instruction selection: the empty asm
+            // ties the accumulators, and with them every MFMA of the step, in front of the refills)
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) asm volatile("" : "+v"(acc[j]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // refill the slot for step s + PL_DEPTH (clamped: the last PL_DEPTH loads are repeats nobody reads)
+            const int sn = s + PL_DEPTH < my_steps ? s + PL_DEPTH : my_steps - 1;
+#pragma unroll
+            for (int j = 0; j < BPW; ++j)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) wq[i][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, wv[j], (sn * NP + pl) * 1024, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// which blocks and steps a wave sums in a layer with `nblk` output blocks (KS = 2, at most 4 blocks:
+// waves 4..7 sum the second half of the steps for the blocks of waves 0..3 and hand their
+// accumulators over through LDS)
+template <int BPW, int KS>
+struct WaveShare {
+    int khalf, blk0, s_first, my_steps;
+    bool active;
+    __device__ __forceinline__ WaveShare(int wave, int nblk, int nsteps)
+    {
+        khalf = KS == 2 ? wave >> 2 : 0;
+        blk0 = KS == 2 ? (wave & 3) : wave * BPW;
+        s_first = KS == 2 ? khalf * (nsteps / 2) : 0;
+        my_steps = KS == 2 ? nsteps / 2 : nsteps;          // a multiple of PL_DEPTH (KS = 2 only if nsteps % (2 PL_DEPTH) == 0)
+        active = blk0 < nblk;
+    }
+};
+
+// f(std::integral_constant<int, act>) for the runtime act: the activation's switch stays out of the
+// unrolled loops (inside them it was most of the kernel's code, run once, from a cold instruction cache)
+template <class F>
+__device__ __forceinline__ void with_act(int act, F&& f)
+{
+    switch (act) {
+        case ACT_SIGMOID: f(std::integral_constant<int, ACT_SIGMOID>{}); break;
+        case ACT_RELU: f(std::integral_constant<int, ACT_RELU>{}); break;
+        case ACT_TANH: f(std::integral_constant<int, ACT_TANH>{}); break;
+        default: f(std::integral_constant<int, ACT_NONE>{}); break;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -125,37 +309,27 @@ struct PlanesFwdP {
     const float* b[ABN_MAX_LAYERS];
     const float* mask[ABN_MAX_LAYERS];
     float* out[ABN_MAX_LAYERS];    // [rows, dims[l+1]] post-activation outputs
+    // training only (null otherwise): the weight-gradient operands, transposed planes with a column of
+    // ones appended: tp[0] the inputs (dims[0] + 1 features), tp[l + 1] the outputs of layer l < n_layers - 1
+    char* tp[ABN_MAX_LAYERS];
+    int64_t tp_steps;              // row steps of those images (pl_row_steps(rows))
 #ifdef ABN_STAMPS
     unsigned long long* stamps;
 #endif
 };
 
-#ifdef ABN_STAMPS
-#define PSTAMPF(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 128 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define WSTAMP(k) do { if (p.stamps && lane == 0) p.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 12 + 4 * l + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define PSTAMPF(slot) do {} while (0)
-#define WSTAMP(k) do {} while (0)
-#endif
-
 // One layer for one workgroup.  img holds the input fragments of all pl_steps(K) steps (zero in
 // the padding); on return it holds this layer's output the same way, for pl_steps(N) steps.
-// KS = 2 (at most 4 blocks): waves 4..7 sum the second half of the steps for the blocks of
-// waves 0..3 and hand their accumulators over through LDS.
 template <int NP, int BPW, int KS>
 __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* __restrict__ img,
-                                             float* __restrict__ part, int wave, int lane, int row0)
+                                             float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0)
 {
     const int K = p.dims[l], N = p.dims[l + 1];
     const int nsteps = pl_steps(K), nblk = (N + 31) / 32;
     const int r = lane & 31, h = lane >> 5;
-    const int khalf = KS == 2 ? wave >> 2 : 0;
-    const int blk0 = KS == 2 ? (wave & 3) : wave * BPW;
-    const int s_first = KS == 2 ? khalf * (nsteps / 2) : 0;
-    const int my_steps = KS == 2 ? nsteps / 2 : nsteps;          // a multiple of PL_DEPTH (host: KS = 2 only if nsteps % 8 == 0)
-    const bool active = blk0 < nblk;
+    const WaveShare<BPW, KS> ws(wave, nblk, nsteps);
+    const int blk0 = ws.blk0;
     PSTAMPF(2 + 5 * l);
-    WSTAMP(0);
 
     f32x16 acc[BPW];
 #pragma unroll
@@ -163,6 +337,9 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
 
+    // All loads of the epilogue are issued as one batch from clamped addresses (a load under a
+    // per-group `if` waits for its own round trip: eight of them in a row were 8.5 k cycles per layer),
+    // the bias before the k-loop, the dropout mask after it.
     f32x4 bv[BPW][4];
     {
         const float* __restrict__ bias = p.b[l];
@@ -171,114 +348,20 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = 32 * (blk0 + j) + 4 * h + 8 * g;
-                bv[j][g] = bias && active ? *reinterpret_cast<const f32x4*>(bias + (n < N ? n : N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bv[j][g] = bias && ws.active ? *reinterpret_cast<const f32x4*>(bias + (n < N ? n : N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
     }
-    if (active) {
-        // The weight ring is filled with raw buffer loads: the compiler counts their vmcnt itself, and --
-        // unlike plain loads, which InstCombine sinks through the loop's phi right in front of their
-        // MFMAs -- they stay where the pipeline puts them, PL_DEPTH steps ahead.
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(p.wp[l]), 0, nblk * nsteps * (NP * 1024), 0x00020000);
-        int wv[BPW];
-#pragma unroll
-        for (int j = 0; j < BPW; ++j) {
-            const int blk = blk0 + j < nblk ? blk0 + j : nblk - 1;        // an odd block count leaves the last wave half idle
-            wv[j] = (blk * nsteps + s_first) * (NP * 1024) + lane * 16;
-        }
-        const char* ab = img + (int64_t)s_first * (NP * 1024) + lane * 16;
-        v4i wq[PL_DEPTH][BPW][NP];
-#pragma unroll
-        for (int i = 0; i < PL_DEPTH; ++i)
-#pragma unroll
-            for (int j = 0; j < BPW; ++j)
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-                {   // (fenced one by one: the in-order vmcnt the compiler derives for the loop is the worst of
-                    // the loop's own order and this one)
-                    wq[i][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, wv[j], (i * NP + pl) * 1024, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-        // activation fragments: read one step ahead, into alternating register sets
-        bf16x8 af[2][NP];
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(ab + pl * 1024);
-        for (int s0 = 0; s0 < my_steps; s0 += PL_DEPTH) {
-            if (s0 == PL_DEPTH) WSTAMP(1);
-#pragma unroll
-            for (int i = 0; i < PL_DEPTH; ++i) {
-                const int s = s0 + i;
-                // (the three regions are fenced: left alone, the machine scheduler issues a refill before
-                // the slot's last MFMA -- a second register set and copies that wait for the loads at the
-                // loop's end -- or gathers all refills there)
-                const int s1 = s + 1 < my_steps ? s + 1 : s;
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-#ifndef PEXP_NOA
-                    af[(i + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(ab + (s1 * NP + pl) * 1024);
-#else
-                    af[(i + 1) & 1][pl][0] = (__bf16)(float)s1;
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8* a = af[i & 1];
-#ifdef PEXP_NOMFMA
-#pragma unroll
-                for (int j = 0; j < BPW; ++j)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) acc[j][pl] += (float)wq[i][j][pl][0] + (float)a[pl][1];
-#else
-                if constexpr (NP == 3) {
-                    // smallest terms first (gemm_f32.h); the blocks alternate so that consecutive MFMAs are independent
-                    constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, AP[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                    for (int t = 0; t < 6; ++t)
-#pragma unroll
-                        for (int j = 0; j < BPW; ++j)
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[i][j][WP[t]]), a[AP[t]], acc[j], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < BPW; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[i][j][0]), a[0], acc[j], 0, 0, 0);
-                }
-#endif
-                // (pure MFMA nodes float across a sched_barrier at instruction selection: the empty asm
-                // ties the accumulators, and with them every MFMA of the step, in front of the refills)
-#pragma unroll
-                for (int j = 0; j < BPW; ++j) asm volatile("" : "+v"(acc[j]) :: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                // refill the slot for step s + PL_DEPTH (clamped: the last PL_DEPTH loads are repeats nobody reads)
-                const int sn = s + PL_DEPTH < my_steps ? s + PL_DEPTH : my_steps - 1;
-#pragma unroll
-                for (int j = 0; j < BPW; ++j)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl)
-#if defined(PEXP_SAMEW)
-                        wq[i][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, ((sn & 3) * NP + pl) * 1024, 0);
-#elif !defined(PEXP_NOW)
-                        wq[i][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, wv[j], (sn * NP + pl) * 1024, 0);
-#else
-                        wq[i][j][pl][0] += sn;
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
+    if (ws.active) planes_kloop<NP, BPW>(acc, p.wp[l], nblk, nsteps, img, blk0, ws.s_first, ws.my_steps, lane);
     PSTAMPF(3 + 5 * l);
-    WSTAMP(2);
+
     // epilogue.  Register q of block j is output feature 32 (blk0 + j) + (q & 3) + 8 (q >> 2) + 4 h of
     // batch row r: registers 4g .. 4g+3 are four consecutive features (one 16-byte piece of the
     // row-major output), registers 8t .. 8t+7 the lane's operand of step 2 blk + t of the next layer.
-    // All loads of the epilogue are issued as one batch from clamped addresses (a load under a
-    // per-group `if` waits for its own round trip: eight of them in a row were 8.5 k cycles per layer),
-    // the bias before the k-loop, the dropout mask here; the activation is a template argument
-    // (its runtime switch inside the unrolled loops was most of the kernel's code, run once, from a
-    // cold instruction cache).
     const float* __restrict__ mask = p.mask[l];
     const int gr = row0 + r;
     const bool row_ok = gr < p.rows;
     f32x4 mv[BPW][4];
-    if (mask && active && khalf == 0) {
+    if (mask && ws.active && ws.khalf == 0) {
         const float* mrow = mask + (int64_t)(row_ok ? gr : p.rows - 1) * N;
 #pragma unroll
         for (int j = 0; j < BPW; ++j)
@@ -288,65 +371,64 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
                 mv[j][g] = *reinterpret_cast<const f32x4*>(mrow + (n < N ? n : N - 4));
             }
     }
-    auto finish_as = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-        for (int j = 0; j < BPW; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const bool live = 32 * (blk0 + j) + 4 * h + 8 * g < N;      // N % 4 == 0: four features in or out together
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[j][4 * g + e] + bv[j][g][e];
-                    if (mask) v *= mv[j][g][e];
-                    acc[j][4 * g + e] = live ? act_apply(v, ACT) : 0.0f;
-                }
-            }
-    };
     auto finish = [&]() {
-        switch (p.act[l]) {
-            case ACT_SIGMOID: finish_as(std::integral_constant<int, ACT_SIGMOID>{}); break;
-            case ACT_RELU: finish_as(std::integral_constant<int, ACT_RELU>{}); break;
-            case ACT_TANH: finish_as(std::integral_constant<int, ACT_TANH>{}); break;
-            default: finish_as(std::integral_constant<int, ACT_NONE>{}); break;
-        }
+        with_act(p.act[l], [&](auto tag) {
+            constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+            for (int j = 0; j < BPW; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bool live = 32 * (blk0 + j) + 4 * h + 8 * g < N;      // N % 4 == 0: four features in or out together
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[j][4 * g + e] + bv[j][g][e];
+                        if (mask) v *= mv[j][g][e];
+                        acc[j][4 * g + e] = live ? act_apply(v, ACT) : 0.0f;
+                    }
+                }
+        });
     };
     if (KS == 1) {
-        if (active) finish();
-    } else if (active && khalf == 1) {
+        if (ws.active) finish();
+    } else if (ws.active && ws.khalf == 1) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) part[((wave & 3) * 16 + q) * 64 + lane] = acc[0][q];
     }
     PSTAMPF(4 + 5 * l);
-    WSTAMP(3);
     __syncthreads();                               // every wave is done reading img
     PSTAMPF(5 + 5 * l);
-    if (KS == 2 && active && khalf == 0) {
+    if (KS == 2 && ws.active && ws.khalf == 0) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[0][q] += part[(wave * 16 + q) * 64 + lane];
         finish();
     }
     float* __restrict__ out = p.out[l];
-    if (active && khalf == 0) {
+    char* const tp = l + 1 < p.n_layers ? p.tp[l + 1] : nullptr;
+    if (ws.active && ws.khalf == 0) {
 #pragma unroll
         for (int j = 0; j < BPW; ++j) {
             const int blk = blk0 + j;
             if (blk < nblk) {
+                Frag<NP> f[2];
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2) {
                     const f32x4 v0 = {acc[j][8 * t2], acc[j][8 * t2 + 1], acc[j][8 * t2 + 2], acc[j][8 * t2 + 3]};
                     const f32x4 v1 = {acc[j][8 * t2 + 4], acc[j][8 * t2 + 5], acc[j][8 * t2 + 6], acc[j][8 * t2 + 7]};
-                    write_frag<NP>(img + (int64_t)(2 * blk + t2) * (NP * 1024) + lane * 16, v0, v1);
+                    f[t2] = make_frag<NP>(v0, v1);
+                    store_frag<NP>(img + (int64_t)(2 * blk + t2) * (NP * 1024) + lane * 16, f[t2]);
                     const int n = 32 * blk + 16 * t2 + 4 * h;
-#ifndef PEXP_NOOUT
                     if (row_ok && n < N) *reinterpret_cast<f32x4*>(out + (int64_t)gr * N + n) = v0;
                     if (row_ok && n + 8 < N) *reinterpret_cast<f32x4*>(out + (int64_t)gr * N + n + 8) = v1;
-#else
-                    if (row_ok && n < -N) *reinterpret_cast<f32x4*>(out + (int64_t)gr * N + n) = v0 + v1;
-#endif
                 }
+                if (tp)
+                    emit_planes<NP>(tp + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, f, idf, lane,
+                                    blk == N / 32 ? N % 32 : -1, p.rows - row0);
             }
         }
+    }
+    if (tp && N % 32 == 0 && wave == PL_WAVES - 1) {       // the column of ones opens a block of its own
+        Frag<NP> z[2] = {};
+        emit_planes<NP>(tp + ((int64_t)nblk * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, z, idf, lane, 0, p.rows - row0);
     }
     PSTAMPF(6 + 5 * l);
     // steps of the next layer's padding that no block of this layer covers
@@ -371,38 +453,342 @@ __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
     const int r = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * PL_ROWS;
     const int D0 = p.dims[0];
+    bf16x8 idf[2];
+    make_identity(idf, lane);
     PSTAMPF(0);
 
     // input rows -> operand fragments (+ the concatenated copy for the backward): lane (r, h) of
-    // step s holds x[row r][16 s + 4 h + 0..3] and x[row r][16 s + 8 + 4 h + 0..3]
-    const int steps0 = pl_steps(D0);
-    for (int s = wave; s < steps0; s += PL_WAVES) {
-        const int gr = row0 + r;
-        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-        if (gr < p.rows) {
-            const float* src = (p.x2 && gr >= p.rows_call) ? p.x2 + (int64_t)(gr - p.rows_call) * D0 : p.x1 + (int64_t)gr * D0;
+    // step s holds x[row r][16 s + 4 h + 0..3] and x[row r][16 s + 8 + 4 h + 0..3]; a wave takes
+    // whole 32-feature blocks (two steps), which it also writes transposed for the weight gradient
+    const int steps0 = pl_steps(D0), blocks0 = steps0 / 2;     // PL_DEPTH is even
+    const int gr = row0 + r;
+    const float* src = nullptr;
+    if (gr < p.rows) src = (p.x2 && gr >= p.rows_call) ? p.x2 + (int64_t)(gr - p.rows_call) * D0 : p.x1 + (int64_t)gr * D0;
+    for (int kb = wave; kb < blocks0; kb += PL_WAVES) {
+        Frag<NP> f[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int s = 2 * kb + t2;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
             const int c0 = 16 * s + 4 * h, c1 = c0 + 8;
-            if (c0 < D0) {
+            if (src && c0 < D0) {
                 v0 = *reinterpret_cast<const f32x4*>(src + c0);
                 if (p.x_copy) *reinterpret_cast<f32x4*>(p.x_copy + (int64_t)gr * D0 + c0) = v0;
             }
-            if (c1 < D0) {
+            if (src && c1 < D0) {
                 v1 = *reinterpret_cast<const f32x4*>(src + c1);
                 if (p.x_copy) *reinterpret_cast<f32x4*>(p.x_copy + (int64_t)gr * D0 + c1) = v1;
             }
+            f[t2] = make_frag<NP>(v0, v1);
+            store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
         }
-        write_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, v0, v1);
+        if (p.tp[0] && kb < pl_blocks(D0 + 1))
+            emit_planes<NP>(p.tp[0] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, f, idf, lane,
+                            kb == D0 / 32 ? D0 % 32 : -1, p.rows - row0);
+    }
+    if (p.tp[0] && pl_blocks(D0 + 1) > blocks0 && wave == PL_WAVES - 1) {     // D0 % 32 == 0 and no padding block to hold the ones
+        Frag<NP> z[2] = {};
+        emit_planes<NP>(p.tp[0] + ((int64_t)(D0 / 32) * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, z, idf, lane, 0, p.rows - row0);
     }
     PSTAMPF(1);
     __syncthreads();
 
     for (int l = 0; l < p.n_layers; ++l) {
         const int nblk = (p.dims[l + 1] + 31) / 32;
-        if (nblk > PL_WAVES) planes_layer<NP, 2, 1>(p, l, img, part, wave, lane, row0);
-        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1>(p, l, img, part, wave, lane, row0);
-        else planes_layer<NP, 1, 2>(p, l, img, part, wave, lane, row0);
+        if (nblk > PL_WAVES) planes_layer<NP, 2, 1>(p, l, img, part, idf, wave, lane, row0);
+        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1>(p, l, img, part, idf, wave, lane, row0);
+        else planes_layer<NP, 1, 2>(p, l, img, part, idf, wave, lane, row0);
     }
     PSTAMPF(2 + 5 * p.n_layers);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, data gradient chain: dZ_{l-1} = (dZ_l W_l) act'(A_{l-1}) mask_{l-1}, for l = n_layers-1 .. 1
+// ---------------------------------------------------------------------------------------------
+struct PlanesBwdP {
+    int n_layers;
+    int rows;
+    int dims[ABN_MAX_LAYERS + 1];
+    int act[ABN_MAX_LAYERS];
+    const float* d_out;            // [rows, dims[n_layers]]: d loss / d output, or d loss / d (pre-activation) of the last layer
+    int d_out_is_dz;
+    const float* a[ABN_MAX_LAYERS];       // [rows, dims[l+1]] post-activation outputs (forward's out[l])
+    const float* mask[ABN_MAX_LAYERS];
+    const char* wpt[ABN_MAX_LAYERS];      // packed W_l^T images, l >= 1
+    char* dzp[ABN_MAX_LAYERS];            // out: transposed planes of dZ_l (dims[l+1] features)
+    int64_t tp_steps;
+};
+
+// dZ_{l-1} from dZ_l (in img, pl_steps(dims[l+1]) steps): output features = the dims[l] inputs of layer l
+template <int NP, int BPW, int KS>
+__device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, char* __restrict__ img,
+                                                   float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0)
+{
+    const int N = p.dims[l + 1], K = p.dims[l];        // sum over N, K output features
+    const int nsteps = pl_steps(N), nblk = (K + 31) / 32;
+    const int r = lane & 31, h = lane >> 5;
+    const WaveShare<BPW, KS> ws(wave, nblk, nsteps);
+    const int blk0 = ws.blk0;
+
+    f32x16 acc[BPW];
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+    if (ws.active) planes_kloop<NP, BPW>(acc, p.wpt[l], nblk, nsteps, img, blk0, ws.s_first, ws.my_steps, lane);
+
+    const float* __restrict__ mask = p.mask[l - 1];
+    const int gr = row0 + r;
+    const bool row_ok = gr < p.rows;
+    const int grc = row_ok ? gr : p.rows - 1;
+    f32x4 av[BPW][4], mv[BPW][4];
+    if (ws.active && ws.khalf == 0) {
+        const float* arow = p.a[l - 1] + (int64_t)grc * K;
+#pragma unroll
+        for (int j = 0; j < BPW; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int k = 32 * (blk0 + j) + 4 * h + 8 * g;
+                av[j][g] = *reinterpret_cast<const f32x4*>(arow + (k < K ? k : K - 4));
+                if (mask) mv[j][g] = *reinterpret_cast<const f32x4*>(mask + (int64_t)grc * K + (k < K ? k : K - 4));
+            }
+    }
+    auto finish = [&]() {
+        with_act(p.act[l - 1], [&](auto tag) {
+            constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+            for (int j = 0; j < BPW; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bool live = 32 * (blk0 + j) + 4 * h + 8 * g < K;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[j][4 * g + e] * act_grad(av[j][g][e], ACT);
+                        if (mask) v *= mv[j][g][e];
+                        acc[j][4 * g + e] = live ? v : 0.0f;
+                    }
+                }
+        });
+    };
+    if (KS == 1) {
+        if (ws.active) finish();
+    } else if (ws.active && ws.khalf == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part[((wave & 3) * 16 + q) * 64 + lane] = acc[0][q];
+    }
+    __syncthreads();                               // every wave is done reading img
+    if (KS == 2 && ws.active && ws.khalf == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[0][q] += part[(wave * 16 + q) * 64 + lane];
+        finish();
+    }
+    if (ws.active && ws.khalf == 0) {
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int blk = blk0 + j;
+            if (blk < nblk) {
+                Frag<NP> f[2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const f32x4 v0 = {acc[j][8 * t2], acc[j][8 * t2 + 1], acc[j][8 * t2 + 2], acc[j][8 * t2 + 3]};
+                    const f32x4 v1 = {acc[j][8 * t2 + 4], acc[j][8 * t2 + 5], acc[j][8 * t2 + 6], acc[j][8 * t2 + 7]};
+                    f[t2] = make_frag<NP>(v0, v1);
+                    store_frag<NP>(img + (int64_t)(2 * blk + t2) * (NP * 1024) + lane * 16, f[t2]);
+                }
+                emit_planes<NP>(p.dzp[l - 1] + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, f, idf, lane, -1, 0);
+            }
+        }
+    }
+    if (l - 1 >= 1) {
+        const int next_steps = pl_steps(K);
+        const bf16x8 z = {};
+        for (int s = 2 * nblk + wave; s < next_steps; s += PL_WAVES)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<bf16x8*>(img + ((int64_t)s * NP + pl) * 1024 + lane * 16) = z;
+    }
+    __syncthreads();
+}
+
+template <int NP>
+__global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
+{
+    extern __shared__ __attribute__((aligned(16))) char pl_smem[];
+    char* const img = pl_smem;
+    float* const part = reinterpret_cast<float*>(pl_smem + PL_MAXSTEPS * NP * 1024);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * PL_ROWS;
+    const int top = p.n_layers - 1;
+    const int NT = p.dims[top + 1];
+    bf16x8 idf[2];
+    make_identity(idf, lane);
+
+    // dZ of the last layer -> operand fragments and transposed planes
+    const int steps_t = pl_steps(NT), blocks_t = steps_t / 2;
+    const int gr = row0 + r;
+    const bool row_ok = gr < p.rows;
+    const float* __restrict__ mask = p.mask[top];
+    for (int kb = wave; kb < blocks_t; kb += PL_WAVES) {
+        Frag<NP> f[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int s = 2 * kb + t2;
+            f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = 16 * s + 4 * h + 8 * u;
+                if (row_ok && c < NT) {
+                    v[u] = *reinterpret_cast<const f32x4*>(p.d_out + (int64_t)gr * NT + c);
+                    if (!p.d_out_is_dz) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(p.a[top] + (int64_t)gr * NT + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[u][e] *= act_grad(a[e], p.act[top]);
+                        if (mask) {
+                            const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (int64_t)gr * NT + c);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[u][e] *= m[e];
+                        }
+                    }
+                }
+            }
+            f[t2] = make_frag<NP>(v[0], v[1]);
+            store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
+        }
+        if (kb < pl_blocks(NT))
+            emit_planes<NP>(p.dzp[top] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, f, idf, lane, -1, 0);
+    }
+    __syncthreads();
+
+    for (int l = top; l >= 1; --l) {
+        const int nblk = (p.dims[l] + 31) / 32;
+        if (nblk > PL_WAVES) planes_dgrad_layer<NP, 2, 1>(p, l, img, part, idf, wave, lane, row0);
+        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l + 1]) % (2 * PL_DEPTH) != 0) planes_dgrad_layer<NP, 1, 1>(p, l, img, part, idf, wave, lane, row0);
+        else planes_dgrad_layer<NP, 1, 2>(p, l, img, part, idf, wave, lane, row0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, weight gradients: dW_l = dZ_l^T [A_{l-1} | 1], split over the batch rows into slabs
+// ---------------------------------------------------------------------------------------------
+// One workgroup: a 128 x 128 tile (4 x 4 blocks) of one layer's [N][K + 1] gradient over a range of
+// row steps.  Wave (wn, wk) = (wave >> 2, wave & 3) owns the blocks (2 wn, wk) and (2 wn + 1, wk).
+// Both operands arrive by LDS-DMA, 1 KB per wave instruction, lane-linear, in chunks of two row
+// steps, three chunks in flight.
+constexpr int WG_CHUNK_STEPS = 2;
+constexpr int WG_STAGES = 3;
+struct WgradLayer {
+    const char* dzp;       // transposed planes of dZ_l        [nblk][steps]
+    const char* ap;        // transposed planes of [A_{l-1} | 1] [kblk][steps]
+    int N, K;              // gradient is [N][K] (+ bias column K)
+    int nblk, kblk;
+    int tiles_n, tiles_k;  // 128 x 128 tiles
+    int splits;            // slabs this layer's sum over the rows is cut into
+    int first_wg;          // workgroups [first_wg, first_wg + tiles_n * tiles_k * splits) belong to this layer
+    int64_t slab_off;      // float offset of this layer's packed (dW | db) region inside a slab
+};
+struct WgradP {
+    int n_layers;          // in launch order (largest first)
+    WgradLayer L[ABN_MAX_LAYERS];
+    float* slabs;
+    int64_t slab_stride;   // floats
+    int64_t tp_steps;
+};
+
+template <int NP>
+constexpr size_t wgrad_lds_bytes() { return (size_t)WG_STAGES * WG_CHUNK_STEPS * 8 * NP * 1024; }
+
+template <int NP>
+__global__ __launch_bounds__(PL_NT) void wgrad_planes_kernel(WgradP p)
+{
+    extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int li = 0;
+    while (li + 1 < p.n_layers && (int)blockIdx.x >= p.L[li + 1].first_wg) ++li;
+    const WgradLayer& L = p.L[li];
+    struct { int nb0, kb0, s_begin, s_end, split; } it;
+    {
+        int local = blockIdx.x - L.first_wg;
+        it.kb0 = 4 * (local % L.tiles_k); local /= L.tiles_k;
+        it.nb0 = 4 * (local % L.tiles_n); local /= L.tiles_n;
+        it.split = local;
+        const int64_t chunks = p.tp_steps / WG_CHUNK_STEPS;
+        it.s_begin = (int)(chunks * it.split / L.splits) * WG_CHUNK_STEPS;
+        it.s_end = (int)(chunks * (it.split + 1) / L.splits) * WG_CHUNK_STEPS;
+    }
+    const int wn = wave >> 2, wk = wave & 3;
+    constexpr int FR = NP * 1024;                        // bytes of one (block, step) fragment set
+    constexpr int STAGE = WG_CHUNK_STEPS * 8 * FR;       // [step][operand block 0..7][plane][1 KB]
+    // DMA share of a wave: operand block `wave` (0..3: dZ blocks nb0 + wave, 4..7: A blocks kb0 + wave - 4)
+    const int ob = wave < 4 ? it.nb0 + wave : it.kb0 + (wave - 4);
+    const int ob_max = wave < 4 ? L.nblk : L.kblk;
+    const char* const src = (wave < 4 ? L.dzp : L.ap) + (int64_t)(ob < ob_max ? ob : ob_max - 1) * p.tp_steps * FR + lane * 16;
+    auto dma = [&](int chunk_step, int stage) {
+#pragma unroll
+        for (int t = 0; t < WG_CHUNK_STEPS; ++t)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + ((int64_t)(chunk_step + t) * NP + pl) * 1024),
+                    (__attribute__((address_space(3))) void*)(wg_smem + stage * STAGE + (t * 8 + wave) * FR + pl * 1024), 16, 0, 0);
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+
+    const int n_chunks = (it.s_end - it.s_begin) / WG_CHUNK_STEPS;
+    // chunks c + 1 and c + 2 are in flight while chunk c is summed; every wave issues the same number
+    // of DMAs per chunk (clamped repeats past the end), so "my chunk c has landed" is vmcnt(one chunk)
+    auto chunk_at = [&](int c) { return it.s_begin + (c < n_chunks ? c : n_chunks - 1) * WG_CHUNK_STEPS; };
+    if (n_chunks > 0) {
+        dma(chunk_at(0), 0);
+        dma(chunk_at(1), 1);
+    }
+    for (int c = 0; c < n_chunks; ++c) {
+        if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __syncthreads();            // chunk c is in LDS for everybody; everybody is done with chunk c - 1
+        dma(chunk_at(c + 2), (c + 2) % WG_STAGES);
+        const char* st = wg_smem + (c % WG_STAGES) * STAGE + lane * 16;
+#pragma unroll
+        for (int t = 0; t < WG_CHUNK_STEPS; ++t) {
+            bf16x8 fa[2][NP], fb[NP];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                fa[0][pl] = *reinterpret_cast<const bf16x8*>(st + (t * 8 + 2 * wn) * FR + pl * 1024);
+                fa[1][pl] = *reinterpret_cast<const bf16x8*>(st + (t * 8 + 2 * wn + 1) * FR + pl * 1024);
+                fb[pl] = *reinterpret_cast<const bf16x8*>(st + (t * 8 + 4 + wk) * FR + pl * 1024);
+            }
+            if constexpr (NP == 3) {
+                constexpr int AP[6] = {2, 0, 1, 1, 0, 0}, BP[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j][AP[u]], fb[BP[u]], acc[j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j][0], fb[0], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped repeats still target this workgroup's LDS
+
+    // acc[j][q] of lane (c, h): row n = 32 (nb0 + 2 wn + j) + (q & 3) + 8 (q >> 2) + 4 h, column k = 32 (kb0 + wk) + c
+    float* const slab = p.slabs + (int64_t)it.split * p.slab_stride + L.slab_off;
+    const int k = 32 * (it.kb0 + wk) + (lane & 31), h = lane >> 5;
+    if (k <= L.K) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int n = 32 * (it.nb0 + 2 * wn + j) + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (n < L.N) slab[k < L.K ? (int64_t)n * L.K + k : (int64_t)L.N * L.K + n] = acc[j][q];
+            }
+    }
 }
 
 }  // namespace abn
