@@ -210,6 +210,31 @@ struct ReduceTable {
     int64_t total;
 };
 
+// sum_s slab[s][0..3] in a FIXED order: four interleaved partial sums (s mod 4), combined as
+// (p0 + p1) + (p2 + p3).  Sixteen slabs are loaded before any of them is added: the sum of 16-32
+// slabs is then 1-2 memory round trips instead of 4-8 (the launch was latency, not bytes).
+__device__ __forceinline__ f32x4 sum_slabs(const float* __restrict__ src, int S, int64_t stride)
+{
+    f32x4 p[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int k = 0;
+    for (; k + 15 < S; k += 16) {
+        f32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) p[u & 3] += v[u];
+    }
+    for (; k + 3 < S; k += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] += v[u];
+    }
+    for (; k < S; ++k) p[0] += *reinterpret_cast<const f32x4*>(src + (int64_t)k * stride);
+    return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
 // grad[i] = sum_s slab[s][i] in a FIXED order (deterministic, unlike atomics):
 // four interleaved partial sums (s mod 4) so that four loads are in flight,
 // combined as (p0 + p1) + (p2 + p3).  Layer boundaries are 64-float aligned, so
@@ -223,17 +248,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, ReduceTable 
         int l = 0;
         while (l + 1 < t.n_layers && i >= t.off[l + 1]) ++l;
         const int S = t.splits[l];
-        f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, p2 = p0, p3 = p0;
-        const float* src = slabs + i;
-        int k = 0;
-        for (; k + 3 < S; k += 4) {
-            p0 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 0) * t.slab_stride);
-            p1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 1) * t.slab_stride);
-            p2 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 2) * t.slab_stride);
-            p3 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 3) * t.slab_stride);
-        }
-        for (; k < S; ++k) p0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * t.slab_stride);
-        const f32x4 s = (p0 + p1) + (p2 + p3);
+        const f32x4 s = sum_slabs(slabs + i, S, t.slab_stride);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int64_t j = i + e - t.off[l];
@@ -258,21 +273,34 @@ __global__ void slab_reduce_step_kernel(const float* __restrict__ slabs, ReduceT
         int l = 0;
         while (l + 1 < t.n_layers && i >= t.off[l + 1]) ++l;
         const int S = t.splits[l];
-        f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, p2 = p0, p3 = p0;
-        const float* src = slabs + i;
-        int k = 0;
-        for (; k + 3 < S; k += 4) {
-            p0 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 0) * t.slab_stride);
-            p1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 1) * t.slab_stride);
-            p2 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 2) * t.slab_stride);
-            p3 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 3) * t.slab_stride);
-        }
-        for (; k < S; ++k) p0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * t.slab_stride);
-        const f32x4 s = (p0 + p1) + (p2 + p3);
         const int64_t baseW = t.dW[l] - grads, baseb = t.db[l] - grads;
+        const int64_t j0 = i - t.off[l];
+        // the four elements inside one tensor, 16-byte aligned in the flat buffers (the usual case):
+        // parameters and state come as float4, requested BEFORE the slabs are summed
+        const bool inW = j0 + 3 < t.nW[l], inb = j0 >= t.nW[l] && (j0 - t.nW[l]) + 3 < t.nb[l];
+        const int64_t idx0 = inW ? baseW + j0 : baseb + (j0 - t.nW[l]);
+        if ((inW || inb) && (idx0 & 3) == 0) {
+            f32x4 pv = *reinterpret_cast<const f32x4*>(params + idx0);
+            f32x4 av = *reinterpret_cast<const f32x4*>(s1 + idx0);
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (opt_uses_s2(o)) bv = *reinterpret_cast<const f32x4*>(s2 + idx0);
+            const f32x4 s = sum_slabs(slabs + i, S, t.slab_stride);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a1 = av[e], a2 = bv[e];
+                pv[e] = opt_update_reg(o, pv[e], s[e], a1, a2);
+                av[e] = a1; bv[e] = a2;
+            }
+            *reinterpret_cast<f32x4*>(grads + idx0) = s;
+            *reinterpret_cast<f32x4*>(params + idx0) = pv;
+            *reinterpret_cast<f32x4*>(s1 + idx0) = av;
+            if (opt_uses_s2(o)) *reinterpret_cast<f32x4*>(s2 + idx0) = bv;
+            continue;
+        }
+        const f32x4 s = sum_slabs(slabs + i, S, t.slab_stride);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int64_t j = i + e - t.off[l];
+            const int64_t j = j0 + e;
             int64_t idx;
             if (j < t.nW[l]) idx = baseW + j;
             else if (j - t.nW[l] < t.nb[l]) idx = baseb + (j - t.nW[l]);
@@ -555,6 +583,21 @@ static int split_count(int64_t rows, int64_t out_dim, int64_t in_dim)
     return (int)(s < 1 ? 1 : s);
 }
 
+// The same for a tower the planes kernels can take (tower_planes.h, whichever path runs in the end):
+// their weight-gradient tiles are up to 256 x 256, so a layer needs more slices to spread over the CUs.
+static int planes_split_count(int64_t rows, int64_t out_dim, int64_t in_dim)
+{
+    int shape, bn, bk;
+    const int nblk = pl_blocks(out_dim), kblk = pl_blocks(in_dim + 1);
+    wgrad_shape(nblk, kblk, &shape, &bn, &bk);
+    const int64_t tiles = (int64_t)((nblk + bn - 1) / bn) * ((kblk + bk - 1) / bk);
+    int64_t s = (128 + tiles - 1) / tiles;               // ~128 workgroups per layer
+    const int64_t by_rows = rows / 128 < 1 ? 1 : rows / 128;
+    if (s > by_rows) s = by_rows;
+    if (s > MAX_SPLITS) s = MAX_SPLITS;
+    return (int)(s < 1 ? 1 : s);
+}
+
 struct BwdLayout {
     int64_t dz[2];
     int64_t bn_s1, bn_s2;
@@ -585,7 +628,7 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
     B.slab_stride = align_up(packed, 64);
     int smax = 1;
     for (int l = 0; l < t->n_layers; ++l) {
-        B.splits[l] = split_count(rows, t->dims[l + 1], t->dims[l]);
+        B.splits[l] = planes_shape_ok(t) ? planes_split_count(rows, t->dims[l + 1], t->dims[l]) : split_count(rows, t->dims[l + 1], t->dims[l]);
         smax = B.splits[l] > smax ? B.splits[l] : smax;
     }
     B.slabs = take(B.slab_stride * smax);
@@ -892,7 +935,9 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             W.ap = reinterpret_cast<const char*>(ws + L.tp[l]);
             W.N = (int)t->dims[l + 1]; W.K = (int)t->dims[l];
             W.nblk = pl_blocks(W.N); W.kblk = pl_blocks(W.K + 1);
-            W.tiles_n = (W.nblk + 3) / 4; W.tiles_k = (W.kblk + 3) / 4;
+            int bn, bk;
+            wgrad_shape(W.nblk, W.kblk, &W.shape, &bn, &bk);
+            W.tiles_n = (W.nblk + bn - 1) / bn; W.tiles_k = (W.kblk + bk - 1) / bk;
             W.splits = B.splits[l];
             W.first_wg = n_wg;
             W.slab_off = B.off[l];

@@ -671,32 +671,193 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
 // ---------------------------------------------------------------------------------------------
 // backward, weight gradients: dW_l = dZ_l^T [A_{l-1} | 1], split over the batch rows into slabs
 // ---------------------------------------------------------------------------------------------
-// One workgroup: a 128 x 128 tile (4 x 4 blocks) of one layer's [N][K + 1] gradient over a range of
-// row steps.  Wave (wn, wk) = (wave >> 2, wave & 3) owns the blocks (2 wn, wk) and (2 wn + 1, wk).
-// Both operands arrive by LDS-DMA, 1 KB per wave instruction, lane-linear, in chunks of two row
-// steps, three chunks in flight.
-constexpr int WG_CHUNK_STEPS = 2;
-constexpr int WG_STAGES = 3;
+// One workgroup: a tile of one layer's [N][K + 1] gradient over a range of row steps.  Its eight
+// waves form a WN x WK grid, each wave owning TN x TK blocks of 32 x 32.  Both operands arrive by
+// LDS-DMA, 1 KB per wave instruction, lane-linear, one row step per stage, three stages in flight.
+// The launch is bound by the operand stream (every dZ block is read once per tile column, every
+// activation block once per tile row, from the Infinity Cache at ~6 TB/s), so the tiles are as
+// large as LDS allows:
+//   shape 0  TN 4 TK 1 WN 2 WK 4   256 x 128   the general case
+//   shape 1  TN 1 TK 2 WN 8 WK 1   256 x  64   at most two column blocks (the first layer: K + 1 = 41)
+//   shape 2  TN 4 TK 1 WN 1 WK 8   128 x 256   at most four row blocks (the output layer: N = 100)
+// (256 x 256 tiles halve the operand stream again but need twice the slabs to fill the chip: the slab
+// writes and their reduction then cost what the operands saved -- measured, 77 + 23 us against 81 + 16.)
+constexpr int WG_STAGES = 4;
+constexpr int WG_MAX_BLOCKS = 12;                 // operand blocks of one row step (shape 0: 8 + 4)
 struct WgradLayer {
     const char* dzp;       // transposed planes of dZ_l        [nblk][steps]
     const char* ap;        // transposed planes of [A_{l-1} | 1] [kblk][steps]
     int N, K;              // gradient is [N][K] (+ bias column K)
     int nblk, kblk;
-    int tiles_n, tiles_k;  // 128 x 128 tiles
+    int shape;
+    int tiles_n, tiles_k;
     int splits;            // slabs this layer's sum over the rows is cut into
     int first_wg;          // workgroups [first_wg, first_wg + tiles_n * tiles_k * splits) belong to this layer
     int64_t slab_off;      // float offset of this layer's packed (dW | db) region inside a slab
 };
 struct WgradP {
-    int n_layers;          // in launch order (largest first)
+    int n_layers;          // in launch order
     WgradLayer L[ABN_MAX_LAYERS];
     float* slabs;
     int64_t slab_stride;   // floats
     int64_t tp_steps;
 };
+static inline void wgrad_shape(int nblk, int kblk, int* shape, int* bn, int* bk)
+{
+    if (kblk <= 2) { *shape = 1; *bn = 8; *bk = 2; }
+    else if (nblk <= 4) { *shape = 2; *bn = 4; *bk = 8; }
+    else { *shape = 0; *bn = 8; *bk = 4; }
+}
 
 template <int NP>
-constexpr size_t wgrad_lds_bytes() { return (size_t)WG_STAGES * WG_CHUNK_STEPS * 8 * NP * 1024; }
+constexpr size_t wgrad_lds_bytes() { return (size_t)WG_STAGES * WG_MAX_BLOCKS * NP * 1024; }
+
+template <int NP, int TN, int TK, int WN, int WK>
+__device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L, char* __restrict__ smem, int nb0, int kb0,
+                                           int s_begin, int s_end, int split, int wave, int lane)
+{
+    static_assert(WN * WK == PL_WAVES, "eight waves");
+    constexpr int BN = WN * TN, BK_ = WK * TK, NB = BN + BK_;     // operand blocks per row step: dZ blocks first
+    constexpr int PER_WAVE = (NB + PL_WAVES - 1) / PL_WAVES;
+    constexpr int FR = NP * 1024;
+    constexpr int STAGE = NB * FR;
+    static_assert(NB <= WG_MAX_BLOCKS, "LDS stage");
+    const int wn = wave % WN, wk = wave / WN;
+    // this wave's share of the DMA: operand blocks wave, wave + 8, ... below NB (n_mine of them: the wait
+    // for "my part of step c" counts this wave's own instructions)
+    const char* src[PER_WAVE];
+    int dst[PER_WAVE];
+    int n_mine = 0;
+#pragma unroll
+    for (int u = 0; u < PER_WAVE; ++u) {
+        const int b = wave + PL_WAVES * u;
+        const bool is_dz = b < BN;
+        const int ob = is_dz ? nb0 + b : kb0 + (b - BN);
+        const int ob_max = is_dz ? L.nblk : L.kblk;
+        src[u] = (is_dz ? L.dzp : L.ap) + (int64_t)(ob < ob_max ? ob : ob_max - 1) * p.tp_steps * FR + lane * 16;
+        dst[u] = b * FR;
+        if (b < NB) n_mine = u + 1;
+    }
+    auto dma = [&](int step, int stage) {
+#ifdef WEXP_NODMA
+        return;
+#endif
+#pragma unroll
+        for (int u = 0; u < PER_WAVE; ++u)
+            if (u < n_mine) {
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(src[u] + ((int64_t)step * NP + pl) * 1024),
+                        (__attribute__((address_space(3))) void*)(smem + stage * STAGE + dst[u] + pl * 1024), 16, 0, 0);
+            }
+    };
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+
+    // blocks past the matrix are padding: a wave whose blocks all are skips the MFMAs (not the DMAs or barriers)
+    const bool live = nb0 + wn * TN < L.nblk && kb0 + wk * TK < L.kblk;
+    const int n_steps = s_end - s_begin;
+    // Steps c + 2 and c + 3 are in flight while step c is summed and step c + 1's fragments are read
+    // into the second register set (every wave sits behind the same barrier: without that read-ahead
+    // they all wait for LDS together, then all issue MFMAs together).  A wave issues the same DMAs
+    // for every step (clamped repeats past the end), so "my part of step c + 1 has landed" is
+    // vmcnt(one step's worth of my DMAs).
+    auto step_at = [&](int c) { return s_begin + (c < n_steps ? c : n_steps - 1); };
+    auto wait_one_step_left = [&]() {
+        static_assert(PER_WAVE == 2, "vmcnt literals: n_mine * NP");
+        if (n_mine == 2) {
+            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else if (n_mine == 1) {
+            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        }
+    };
+    struct Frags { bf16x8 a[TN][NP], b[TK][NP]; };
+    auto read_frags = [&](Frags& f, int c) {
+        const char* st = smem + (c % WG_STAGES) * STAGE + lane * 16;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) f.a[i][pl] = *reinterpret_cast<const bf16x8*>(st + (wn * TN + i) * FR + pl * 1024);
+#pragma unroll
+            for (int j = 0; j < TK; ++j) f.b[j][pl] = *reinterpret_cast<const bf16x8*>(st + (BN + wk * TK + j) * FR + pl * 1024);
+        }
+    };
+    auto mfmas = [&](const Frags& f) {
+        if constexpr (NP == 3) {
+            constexpr int AP[6] = {2, 0, 1, 1, 0, 0}, BP[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TK; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][AP[u]], f.b[j][BP[u]], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][0], acc[i][j], 0, 0, 0);
+        }
+    };
+    Frags fr[2];
+    if (n_steps > 0) {
+        dma(step_at(0), 0);
+        dma(step_at(1), 1);
+        dma(step_at(2), 2);
+        // step 0: two steps' worth may stay in flight
+        if (n_mine == 2) {
+            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else if (n_mine == 1) {
+            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        __syncthreads();
+        if (live) read_frags(fr[0], 0);
+    }
+    // one step: cur holds step c's fragments; nxt receives step c + 1's
+    auto one_step = [&](int c, const Frags& cur, Frags& nxt) {
+        wait_one_step_left();       // my part of step c + 1 is in LDS
+        __syncthreads();            // ... and everybody's; everybody has read step c (its stage is not reused before the next barrier)
+        dma(step_at(c + 3), (c + 3) % WG_STAGES);      // into the stage of step c - 1
+        if (live) {
+            if (c + 1 < n_steps) read_frags(nxt, c + 1);
+            mfmas(cur);
+        }
+    };
+    static_assert(WG_STAGES == 4, "stage arithmetic above");
+    for (int c = 0; c < n_steps; c += 2) {
+        one_step(c, fr[0], fr[1]);
+        if (c + 1 < n_steps) one_step(c + 1, fr[1], fr[0]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped repeats still target this workgroup's LDS
+
+    // acc[i][j][q] of lane (c, h): row n = 32 (nb0 + wn TN + i) + (q & 3) + 8 (q >> 2) + 4 h, column k = 32 (kb0 + wk TK + j) + c
+    float* const slab = p.slabs + (int64_t)split * p.slab_stride + L.slab_off;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+        const int k = 32 * (kb0 + wk * TK + j) + (lane & 31);
+        if (k <= L.K) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int n = 32 * (nb0 + wn * TN + i) + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (n < L.N) slab[k < L.K ? (int64_t)n * L.K + k : (int64_t)L.N * L.K + n] = acc[i][j][q];
+                }
+        }
+    }
+}
 
 template <int NP>
 __global__ __launch_bounds__(PL_NT) void wgrad_planes_kernel(WgradP p)
@@ -707,88 +868,14 @@ __global__ __launch_bounds__(PL_NT) void wgrad_planes_kernel(WgradP p)
     int li = 0;
     while (li + 1 < p.n_layers && (int)blockIdx.x >= p.L[li + 1].first_wg) ++li;
     const WgradLayer& L = p.L[li];
-    struct { int nb0, kb0, s_begin, s_end, split; } it;
-    {
-        int local = blockIdx.x - L.first_wg;
-        it.kb0 = 4 * (local % L.tiles_k); local /= L.tiles_k;
-        it.nb0 = 4 * (local % L.tiles_n); local /= L.tiles_n;
-        it.split = local;
-        const int64_t chunks = p.tp_steps / WG_CHUNK_STEPS;
-        it.s_begin = (int)(chunks * it.split / L.splits) * WG_CHUNK_STEPS;
-        it.s_end = (int)(chunks * (it.split + 1) / L.splits) * WG_CHUNK_STEPS;
-    }
-    const int wn = wave >> 2, wk = wave & 3;
-    constexpr int FR = NP * 1024;                        // bytes of one (block, step) fragment set
-    constexpr int STAGE = WG_CHUNK_STEPS * 8 * FR;       // [step][operand block 0..7][plane][1 KB]
-    // DMA share of a wave: operand block `wave` (0..3: dZ blocks nb0 + wave, 4..7: A blocks kb0 + wave - 4)
-    const int ob = wave < 4 ? it.nb0 + wave : it.kb0 + (wave - 4);
-    const int ob_max = wave < 4 ? L.nblk : L.kblk;
-    const char* const src = (wave < 4 ? L.dzp : L.ap) + (int64_t)(ob < ob_max ? ob : ob_max - 1) * p.tp_steps * FR + lane * 16;
-    auto dma = [&](int chunk_step, int stage) {
-#pragma unroll
-        for (int t = 0; t < WG_CHUNK_STEPS; ++t)
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + ((int64_t)(chunk_step + t) * NP + pl) * 1024),
-                    (__attribute__((address_space(3))) void*)(wg_smem + stage * STAGE + (t * 8 + wave) * FR + pl * 1024), 16, 0, 0);
-    };
-    f32x16 acc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
-
-    const int n_chunks = (it.s_end - it.s_begin) / WG_CHUNK_STEPS;
-    // chunks c + 1 and c + 2 are in flight while chunk c is summed; every wave issues the same number
-    // of DMAs per chunk (clamped repeats past the end), so "my chunk c has landed" is vmcnt(one chunk)
-    auto chunk_at = [&](int c) { return it.s_begin + (c < n_chunks ? c : n_chunks - 1) * WG_CHUNK_STEPS; };
-    if (n_chunks > 0) {
-        dma(chunk_at(0), 0);
-        dma(chunk_at(1), 1);
-    }
-    for (int c = 0; c < n_chunks; ++c) {
-        if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __syncthreads();            // chunk c is in LDS for everybody; everybody is done with chunk c - 1
-        dma(chunk_at(c + 2), (c + 2) % WG_STAGES);
-        const char* st = wg_smem + (c % WG_STAGES) * STAGE + lane * 16;
-#pragma unroll
-        for (int t = 0; t < WG_CHUNK_STEPS; ++t) {
-            bf16x8 fa[2][NP], fb[NP];
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                fa[0][pl] = *reinterpret_cast<const bf16x8*>(st + (t * 8 + 2 * wn) * FR + pl * 1024);
-                fa[1][pl] = *reinterpret_cast<const bf16x8*>(st + (t * 8 + 2 * wn + 1) * FR + pl * 1024);
-                fb[pl] = *reinterpret_cast<const bf16x8*>(st + (t * 8 + 4 + wk) * FR + pl * 1024);
-            }
-            if constexpr (NP == 3) {
-                constexpr int AP[6] = {2, 0, 1, 1, 0, 0}, BP[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int u = 0; u < 6; ++u)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j][AP[u]], fb[BP[u]], acc[j], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j][0], fb[0], acc[j], 0, 0, 0);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped repeats still target this workgroup's LDS
-
-    // acc[j][q] of lane (c, h): row n = 32 (nb0 + 2 wn + j) + (q & 3) + 8 (q >> 2) + 4 h, column k = 32 (kb0 + wk) + c
-    float* const slab = p.slabs + (int64_t)it.split * p.slab_stride + L.slab_off;
-    const int k = 32 * (it.kb0 + wk) + (lane & 31), h = lane >> 5;
-    if (k <= L.K) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int n = 32 * (it.nb0 + 2 * wn + j) + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (n < L.N) slab[k < L.K ? (int64_t)n * L.K + k : (int64_t)L.N * L.K + n] = acc[j][q];
-            }
-    }
+    int local = blockIdx.x - L.first_wg;
+    const int tk = local % L.tiles_k; local /= L.tiles_k;
+    const int tn = local % L.tiles_n; local /= L.tiles_n;
+    const int split = local;
+    const int s_begin = (int)(p.tp_steps * split / L.splits), s_end = (int)(p.tp_steps * (split + 1) / L.splits);
+    if (L.shape == 0) wgrad_tile<NP, 4, 1, 2, 4>(p, L, wg_smem, 8 * tn, 4 * tk, s_begin, s_end, split, wave, lane);
+    else if (L.shape == 1) wgrad_tile<NP, 1, 2, 8, 1>(p, L, wg_smem, 8 * tn, 2 * tk, s_begin, s_end, split, wave, lane);
+    else wgrad_tile<NP, 4, 1, 1, 8>(p, L, wg_smem, 4 * tn, 8 * tk, s_begin, s_end, split, wave, lane);
 }
 
 }  // namespace abn
