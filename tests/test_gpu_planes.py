@@ -1,0 +1,187 @@
+"""The operand-plane kernels of csrc/tower_planes.h (precision bf16x3 / bf16, no BatchNorm, widths <= 512 and
+multiples of 4): the library takes them from 6144 rows up by itself; here ABN_FUSED_MIN_ROWS = 0 forces them on
+small towers whose shapes walk every branch -- one and two column blocks per wave, the K-split of narrow layers,
+widths that are multiples of 32 (the column of ones then opens a block of its own), 512-wide layers, ragged row
+counts, dropout, every activation -- against the numpy oracle, plus a decode of the operand images themselves.
+Needs an MI355X: run with -m gpu."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, check_grads
+from planes_decode import decode
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def planes_forced(monkeypatch):
+    monkeypatch.setenv('ABN_FUSED_MIN_ROWS', '0')
+    monkeypatch.setenv('ABN_PLANES', '1')
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def build(kw, seed, precision):
+    from abnet3_amd.model import SiameseNetwork
+    from oracle import siamese_np as O
+    torch.manual_seed(seed)
+    net = SiameseNetwork(**kw).cuda()
+    net.precision = precision
+    spec = O.TowerSpec(kw['input_dim'], kw['num_hidden_layers'], kw['hidden_dim'], kw['output_dim'],
+                       kw['activation_layer'], False, kw.get('last_non_linearity', 'default'))
+    p = {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}
+    return net, spec, p
+
+
+SHAPES = [  # (input, hidden layers, hidden, output, B)
+    (40, 2, 500, 100, 48),      # C2's widths: two blocks per wave, K-split output layer
+    (32, 1, 64, 32, 33),        # every width a multiple of 32: the ones column gets its own block; ragged rows
+    (64, 1, 512, 128, 16),      # the widest layer the LDS image holds; K-split with 32 steps
+    (4, 0, 8, 4, 5),            # the smallest tower the kernels accept
+    (128, 3, 288, 36, 70),      # 9 blocks (odd count on two-block waves), 36-wide output
+    (20, 14, 32, 12, 40),       # 16 Linear layers
+]
+
+
+@pytest.mark.parametrize('precision,tol,gtol', [('bf16x3', 1e-5, 1e-4), ('bf16', 3e-2, None)])
+@pytest.mark.parametrize('act', ['sigmoid', 'tanh', 'relu'])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_forward_loss_and_gradients_against_the_oracle(shape, act, precision, tol, gtol):
+    import abnet3_amd.loss as L
+    from oracle import siamese_np as O
+    d_in, nh, hid, d_out, B = shape
+    if nh > 8 and (act == 'sigmoid' or precision == 'bf16'):
+        pytest.skip('sixteen sigmoid layers at initialisation map every input to the same embedding (gradients are '
+                    'rounding noise on both sides); sixteen bf16 layers are outside any tolerance worth writing')
+    kw = dict(input_dim=d_in, num_hidden_layers=nh, hidden_dim=hid, output_dim=d_out, activation_layer=act,
+              p_dropout=0.0, batch_norm=False)
+    if act == 'relu':
+        kw['last_non_linearity'] = None
+    net, spec, p = build(kw, seed=B, precision=precision)
+    rng = np.random.default_rng(B)
+    x1 = rng.standard_normal((B, d_in)).astype(np.float32)
+    x2 = rng.standard_normal((B, d_in)).astype(np.float32)
+    y = rng.choice([1, -1], B)
+    net.train()
+    e1, e2 = net(dev(x1), dev(x2))
+    lv = L.coscos2(avg=False)(e1, e2, dev(y))
+    lv.backward()
+    o1, c1 = O.tower_forward(p, x1, spec, True)
+    o2, c2 = O.tower_forward(p, x2, spec, True)
+    ol, d1, d2, _ = O.pair_loss(o1, o2, y, 'coscos2', 0.5, False)
+    og = {}
+    O.tower_backward(p, c1, d1, spec, og)
+    O.tower_backward(p, c2, d2, spec, og)
+    assert rel_err(e1.detach().cpu().numpy(), o1) < tol
+    assert rel_err(e2.detach().cpu().numpy(), o2) < tol
+    assert abs(float(lv.detach()) - ol) <= 10 * tol * abs(ol) + 1e-6
+    grads = {k: q.grad.cpu().numpy() for k, q in net.named_parameters()}
+    if precision == 'bf16x3':
+        check_grads(grads, og, spec.param_keys(), False, tol=gtol)
+    else:
+        # 8-bit operands under a loss whose gradient is a difference of near-equal vectors: the
+        # direction and size of every gradient tensor, not its entries
+        # (the output layer's: further down a sigmoid tower at its initialisation the true gradient shrinks
+        # below what 8-bit operands resolve; the bf16 x 3 cases pin the arithmetic, these the data paths)
+        for k in spec.param_keys()[-2:]:
+            a, b = grads[k].ravel().astype(np.float64), og[k].ravel().astype(np.float64)
+            assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.9, k
+            assert abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < 0.3, k
+    # the direct path (fused loss gradient + d_out_is_dz, deferred reduction) yields the same gradients
+    from abnet3_amd.trainer import TrainerSiamese
+    tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='sgd', lr=0.0, dataloader=None,
+                        log_dir='/tmp/abn_runs')
+    tr.train_step((dev(x1), dev(x2), dev(y)), True)
+    for k, q in net.named_parameters():
+        assert rel_err(q.grad.cpu().numpy(), grads[k], floor=1e-30) < (1e-6 if precision == 'bf16x3' else 1e-5), k
+
+
+def test_dropout_masks_scale_both_chains():
+    """train mode with p_dropout: the masks multiply the pre-activations in the forward epilogue and the data
+    gradient in the backward chain (abnet3/model.py:137,148,157 Dropout between Linear and the activation)."""
+    import abnet3_amd.loss as L
+    from oracle import siamese_np as O
+    kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=100, output_dim=36, activation_layer='sigmoid',
+              p_dropout=0.3, batch_norm=False)
+    net, spec, p = build(kw, seed=9, precision='bf16x3')
+    B = 50
+    rng = np.random.default_rng(9)
+    x1 = rng.standard_normal((B, 40)).astype(np.float32)
+    x2 = rng.standard_normal((B, 40)).astype(np.float32)
+    y = rng.choice([1, -1], B)
+    widths = [100, 100, 100, 36]
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    masks = [(torch.rand(2 * B, w, device='cuda', generator=gen) > 0.3).float() / 0.7 for w in widths]
+    net._mask_override = masks
+    net.train()
+    e1, e2 = net(dev(x1), dev(x2))
+    lv = L.cosmargin(avg=True)(e1, e2, dev(y))
+    lv.backward()
+    net._mask_override = None
+    m = [t.cpu().numpy() for t in masks]
+    o1, c1 = O.tower_forward(p, x1, spec, True, masks=[t[:B] for t in m])
+    o2, c2 = O.tower_forward(p, x2, spec, True, masks=[t[B:] for t in m])
+    ol, d1, d2, _ = O.pair_loss(o1, o2, y, 'cosmargin', 0.5, True)
+    og = {}
+    O.tower_backward(p, c1, d1, spec, og)
+    O.tower_backward(p, c2, d2, spec, og)
+    assert rel_err(e1.detach().cpu().numpy(), o1) < 1e-5 and rel_err(e2.detach().cpu().numpy(), o2) < 1e-5
+    check_grads({k: q.grad.cpu().numpy() for k, q in net.named_parameters()}, og, spec.param_keys(), False, tol=1e-4)
+
+
+@pytest.mark.parametrize('precision,NP', [('bf16x3', 3), ('bf16', 1)])
+def test_operand_images_decode_to_their_tensors(precision, NP):
+    """The packed weights (both orientations), the transposed planes of every layer input with their column of
+    ones, and the transposed planes of every dZ, read back from the forward workspace / backward scratch."""
+    from abnet3_amd import _lib, model as M
+    kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=96, output_dim=32, activation_layer='sigmoid',
+              p_dropout=0.0, batch_norm=False)
+    net, spec, p = build(kw, seed=4, precision=precision)
+    lib = _lib.load()
+    fn = lib.abn_debug_planes_offset
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    B = 37
+    R = 2 * B
+    dims = [40, 96, 96, 32]
+    rng = np.random.default_rng(4)
+    x1, x2 = dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32))
+    net.train()
+    out, (seg, sv, gp) = net.direct_forward(x1, x2)
+    dz_top = dev((rng.standard_normal((R, 32)) * 1e-3).astype(np.float32))
+    _, _, pending = M._segment_backward(seg, sv, dz_top, gp, False, True, True)
+    torch.cuda.synchronize()
+    desc = pending[0]
+    ws16 = sv.ws.view(torch.int16).cpu().numpy().view(np.uint16)
+    sc16 = pending[2].view(torch.int16).cpu().numpy().view(np.uint16)
+    Ws = [q.detach().double().cpu().numpy() for k, q in net.named_parameters() if k.endswith('weight')]
+    bs = [q.detach().double().cpu().numpy() for k, q in net.named_parameters() if k.endswith('bias')]
+    acts = [torch.cat([x1, x2]).double().cpu().numpy()]
+    for l in range(3):
+        acts.append(1 / (1 + np.exp(-(acts[-1] @ Ws[l].T + bs[l]))))
+    dz = [None, None, dz_top.double().cpu().numpy()]
+    for l in (2, 1):
+        dz[l - 1] = (dz[l] @ Ws[l]) * acts[l] * (1 - acts[l])
+    eps = 2.0 ** -22 if NP == 3 else 2.0 ** -8           # three bf16 terms carry 24 bits, one carries 8
+    steps = lambda c: ((c + 15) // 16 + 3) // 4 * 4
+    row_steps = (R + 31) // 32 * 2
+    for l in range(3):
+        d = decode(ws16[2 * fn(ctypes.byref(desc), R, 2, 0, l):], (dims[l + 1] + 31) // 32, steps(dims[l]), NP)
+        assert np.abs(d[:dims[l + 1], :dims[l]] - Ws[l]).max() <= eps * np.abs(Ws[l]).max()
+        assert np.abs(d[dims[l + 1]:]).max(initial=0) == 0 and np.abs(d[:, dims[l]:]).max(initial=0) == 0
+        if l > 0:
+            d = decode(ws16[2 * fn(ctypes.byref(desc), R, 2, 1, l):], (dims[l] + 31) // 32, steps(dims[l + 1]), NP)
+            assert np.abs(d[:dims[l], :dims[l + 1]] - Ws[l].T).max() <= eps * np.abs(Ws[l]).max()
+        d = decode(ws16[2 * fn(ctypes.byref(desc), R, 2, 2, l):], (dims[l] + 1 + 31) // 32, row_steps, NP)
+        assert np.abs(d[:dims[l], :R] - acts[l].T).max() <= max(eps, 3e-7) * np.abs(acts[l]).max()
+        assert np.array_equal(d[dims[l], :R], np.ones(R)) and np.abs(d[dims[l], R:]).max(initial=0) == 0
+        assert np.abs(d[dims[l] + 1:]).max(initial=0) == 0
+        d = decode(sc16[2 * fn(ctypes.byref(desc), R, 2, 3, l):], (dims[l + 1] + 31) // 32, row_steps, NP)
+        tol = 3e-6 if NP == 3 else 3e-2
+        assert np.abs(d[:dims[l + 1], :R] - dz[l].T).max() <= tol * np.abs(dz[l]).max(), l
+        assert np.abs(d[:, R:]).max(initial=0) == 0          # rows past the batch contribute nothing

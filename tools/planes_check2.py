@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 from abnet3_amd import _lib, model as M
 from abnet3_amd.model import SiameseNetwork
-from tools.planes_decode import decode
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); from planes_decode import decode
 rows = int(os.environ.get('ROWS', 64))
 os.environ.setdefault('ABN_FUSED_MIN_ROWS', '0')
 cfg = dict(bench.C2)

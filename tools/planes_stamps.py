@@ -28,10 +28,3 @@ d = np.diff(s, axis=1)
 for i in range(n - 1):
     print('%-24s median %8.0f   max %8.0f' % (names[i], np.median(d[:, i]), d[:, i].max()))
 print('wg start spread: median %.0f max %.0f; wg total median %.0f; last end %.0f' % (np.median(s[:, 0]), s[:, 0].max(), np.median(s[:, n - 1] - s[:, 0]), s[:, n - 1].max()))
-w = buf.cpu().numpy().reshape(1024, 128)[:256, 32:32 + 96].astype(np.float64).reshape(256, 8, 3, 4)  # (first three layers)
-base = buf.cpu().numpy().reshape(1024, 128)[:256, 0].astype(np.float64)
-print('per wave (median over workgroups), ticks since the workgroup started:  layer start | after 4 steps | k-loop end | finish end')
-for l in range(3):
-    for wv in range(8):
-        v = np.median(w[:, wv, l, :] - base[:, None], axis=0)
-        print('L%d wave %d  %8.0f %8.0f %8.0f %8.0f   (k-loop %6.0f, first round %6.0f)' % (l, wv, v[0], v[1], v[2], v[3], v[2] - v[0], v[1] - v[0]))
