@@ -523,7 +523,7 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
         const int np = planes_of(t->precision);
         for (int l = 0; l < t->n_layers; ++l) {
             L.wp[l] = take(pl_image_bytes(t->dims[l + 1], t->dims[l], np) / 4);
-            if (l > 0) L.wpt[l] = take(pl_image_bytes(t->dims[l], t->dims[l + 1], np) / 4);
+            L.wpt[l] = take(pl_image_bytes(t->dims[l], t->dims[l + 1], np) / 4);
             L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, rows, np) / 4);
         }
     }
@@ -734,21 +734,21 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         f.rows = (int)rows;
         f.rows_call = (int)rpc;
         f.x1 = x1; f.x2 = x2;
-        f.x_copy = x2 ? ws + L.x : nullptr;
+        f.x_copy = nullptr;                      // the planes backward reads the transposed images only
         pk.base = reinterpret_cast<char*>(ws);
         for (int l = 0; l <= t->n_layers; ++l) f.dims[l] = (int)t->dims[l];
         for (int l = 0; l < t->n_layers; ++l) {
             f.act[l] = (l == t->n_layers - 1) ? t->last_act : t->act;
             f.b[l] = t->b[l];
             f.mask[l] = train ? t->drop_mask[l] : nullptr;
-            f.out[l] = ws + L.a[l];
+            f.out[l] = l == t->n_layers - 1 ? ws + L.a[l] : nullptr;     // hidden activations live in tp[l + 1] only
             f.wp[l] = reinterpret_cast<const char*>(ws + L.wp[l]);
             PackJob& J = pk.job[pk.n_jobs++];
             J.W = t->W[l]; J.N = (int)t->dims[l + 1]; J.K = (int)t->dims[l]; J.transposed = 0;
             J.nblk = pl_blocks(J.N); J.nsteps = pl_steps(J.K);
             J.tile0 = pk.n_tiles; J.dst = L.wp[l] * 4;
             pk.n_tiles += J.nblk * J.nsteps;
-            if (l > 0) {                         // W_l^T for the backward's data-gradient chain
+            {                                    // W_l^T for the backward's data-gradient chain (l = 0: d loss / d input)
                 PackJob& T = pk.job[pk.n_jobs++];
                 T.W = t->W[l]; T.N = J.N; T.K = J.K; T.transposed = 1;
                 T.nblk = pl_blocks(T.K); T.nsteps = pl_steps(T.N);
@@ -901,7 +901,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     // The forward that filled `ws` went through the planes kernels (same predicate): its workspace
     // holds W^T and the weight-gradient operands as operand fragments.  Two launches: the data
     // gradient chain (one workgroup per 32 rows, all layers), then every layer's weight gradient.
-    if (!dx && planes_path(t, rows, x1, x2, ws)) {
+    if (planes_path(t, rows, x1, x2, ws)) {
         const int np = planes_of(t->precision);
         PlanesBwdP b = {};
         b.n_layers = nl;
@@ -909,13 +909,16 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
         b.d_out = d_out;
         b.d_out_is_dz = t->d_out_is_dz;
         b.tp_steps = pl_row_steps(rows);
-        ABN_REQUIRE(aligned16(d_out) && aligned16(scratch), "tower_backward: d_out / scratch must be 16-byte aligned");
+        ABN_REQUIRE(aligned16(d_out) && aligned16(scratch) && (!dx || aligned16(dx)),
+                    "tower_backward: d_out / scratch / dx must be 16-byte aligned");
+        b.a_top = ws + L.a[nl - 1];
+        b.dx = dx;
         for (int l = 0; l <= nl; ++l) b.dims[l] = (int)t->dims[l];
         for (int l = 0; l < nl; ++l) {
             b.act[l] = (l == nl - 1) ? t->last_act : t->act;
-            b.a[l] = ws + L.a[l];
+            b.tp[l] = reinterpret_cast<const char*>(ws + L.tp[l]);
             b.mask[l] = t->drop_mask[l];
-            b.wpt[l] = l > 0 ? reinterpret_cast<const char*>(ws + L.wpt[l]) : nullptr;
+            b.wpt[l] = reinterpret_cast<const char*>(ws + L.wpt[l]);
             b.dzp[l] = reinterpret_cast<char*>(scratch + B.dzp[l]);
         }
         WgradP w = {};

@@ -25,10 +25,14 @@
 //     accumulators.  Each chain epilogue therefore also hands its tile to the MFMA once more, as
 //     the A operand against a (permuted) identity: the result is the tile transposed -- feature on
 //     the lane, batch rows in the registers, exact, because every plane is a bf16 value times 1 --
-//     and goes to HBM as ready-made operand fragments
-//       planes[block of 32 features][step of 16 batch rows][plane][lane][8 bf16].
-//     wgrad_planes_kernel streams both operands in that form (LDS-DMA, lane-linear) and does nothing
-//     but MFMAs.  A column of ones appended to the activation image yields the bias gradient.
+//     and goes to HBM in operand-fragment order
+//       timage[block of 32 features][step of 16 batch rows][lane][8 values],
+//     the three planes added up again (exactly) to one fp32 value per element for bf16 x 3 (4 bytes
+//     instead of 6: these images are the step's largest HBM streams -- they are also the ONLY copy
+//     of the hidden activations: the data-gradient chain gathers act'(a) from them), one bf16 for
+//     the bf16 mode.  wgrad_planes_kernel streams both operands in that form (LDS-DMA, lane-linear),
+//     splits the fp32 fragments after the LDS read and otherwise only issues MFMAs.  A column of
+//     ones appended to the activation image yields the bias gradient.
 #pragma once
 #include <type_traits>
 
@@ -58,7 +62,9 @@ static inline int64_t pl_image_bytes(int64_t features, int64_t contraction, int 
 }
 // batch-row steps of the transposed (weight-gradient) images: two per 32-row workgroup
 static inline int64_t pl_row_steps(int64_t rows) { return (rows + PL_ROWS - 1) / PL_ROWS * 2; }
-static inline int64_t pl_timage_bytes(int64_t features, int64_t rows, int np) { return (int64_t)pl_blocks(features) * pl_row_steps(rows) * np * 1024; }
+// bytes of one (block, row step) tile of a transposed image: 64 lanes x 8 fp32 (bf16 x 3) or 8 bf16 (bf16)
+template <int NP> constexpr int tile_bytes() { return NP == 3 ? 2048 : 1024; }
+static inline int64_t pl_timage_bytes(int64_t features, int64_t rows, int np) { return (int64_t)pl_blocks(features) * pl_row_steps(rows) * (np == 3 ? 2048 : 1024); }
 static inline size_t pl_lds_bytes(int np) { return (size_t)PL_MAXSTEPS * np * 1024 + PL_PART_BYTES; }
 
 #ifdef ABN_STAMPS
@@ -110,33 +116,61 @@ __device__ __forceinline__ void make_identity(bf16x8 idf[2], int lane)
 }
 
 // One 32-feature block of one workgroup (32 batch rows), held as the two k-steps' fragments f[0], f[1]
-// (lane = batch row), written transposed: dst -> planes[block][this workgroup's first row step], + lane * 16.
+// (lane = batch row), written transposed: dst -> timage[block][this workgroup's first row step].
 // ones_c >= 0: that column of the block is the appended column of ones (rows below rows_left only).
 template <int NP>
 __device__ __forceinline__ void emit_planes(char* dst, const Frag<NP> f[2], const bf16x8 idf[2], int lane, int ones_c, int rows_left)
 {
     const int c = lane & 31, h = lane >> 5;
+    f32x16 t;                  // t[q] of lane (c, h) = feature c of batch row (q & 3) + 8 (q >> 2) + 4 h
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
-        f32x16 t;
+        f32x16 u;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t[q] = 0.0f;
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0].p[pl], idf[0], t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1].p[pl], idf[1], t, 0, 0, 0);
-        // t[q] of lane (c, h) = feature c of batch row (q & 3) + 8 (q >> 2) + 4 h
-        if (c == ones_c) {
+        for (int q = 0; q < 16; ++q) u[q] = 0.0f;
+        u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0].p[pl], idf[0], u, 0, 0, 0);
+        u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1].p[pl], idf[1], u, 0, 0, 0);
+        if (pl == 0) t = u;
+        else t += u;           // hi + mid, then + lo: exact, the three terms do not overlap
+    }
+    if (c == ones_c) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) t[q] = (pl == 0 && (q & 3) + 8 * (q >> 2) + 4 * h < rows_left) ? 1.0f : 0.0f;
-        }
+        for (int q = 0; q < 16; ++q) t[q] = (q & 3) + 8 * (q >> 2) + 4 * h < rows_left ? 1.0f : 0.0f;
+    }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < 2; ++s) {
+        if constexpr (NP == 3) {       // tile = [elements 0..3 | 4..7][lane][4 floats]: two lane-linear 1 KB halves
+            char* o = dst + s * 2048 + lane * 16;
+            *reinterpret_cast<f32x4*>(o) = f32x4{t[8 * s], t[8 * s + 1], t[8 * s + 2], t[8 * s + 3]};
+            *reinterpret_cast<f32x4*>(o + 1024) = f32x4{t[8 * s + 4], t[8 * s + 5], t[8 * s + 6], t[8 * s + 7]};
+        } else {
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (__bf16)t[8 * s + j];
-            *reinterpret_cast<bf16x8*>(dst + (s * NP + pl) * 1024) = o;
+            *reinterpret_cast<bf16x8*>(dst + s * 1024 + lane * 16) = o;
         }
     }
 }
+
+// The reverse gather for one lane of a chain accumulator (batch row r of the workgroup, registers =
+// features (q & 3) + 8 (q >> 2) + 4 h of a block): byte offset of its row inside a (block, 2 row steps)
+// tile pair, to which feature c adds c * (8 elements).
+template <int NP>
+__device__ __forceinline__ int tgather_row_offset(int r)
+{
+    // r = 16 s' + 8 (j >> 2) + 4 h' + (j & 3)
+    const int sp = r >> 4, jh = (r >> 3) & 1, jl = r & 3, hp = (r >> 2) & 1;
+    if constexpr (NP == 3) return sp * 2048 + jh * 1024 + hp * 32 * 16 + jl * 4;      // + c * 16
+    else return sp * 1024 + hp * 32 * 16 + (4 * jh + jl) * 2;                         // + c * 16
+}
+template <int NP>
+__device__ __forceinline__ float tgather(const char* tile_pair, int row_off, int c)
+{
+    if constexpr (NP == 3) return *reinterpret_cast<const float*>(tile_pair + row_off + c * 16);
+    else return (float)*reinterpret_cast<const __bf16*>(tile_pair + row_off + c * 16);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // ---------------------------------------------------------------------------------------------
 // weights -> operand fragments
@@ -308,9 +342,10 @@ struct PlanesFwdP {
     const char* wp[ABN_MAX_LAYERS];   // packed forward image of layer l
     const float* b[ABN_MAX_LAYERS];
     const float* mask[ABN_MAX_LAYERS];
-    float* out[ABN_MAX_LAYERS];    // [rows, dims[l+1]] post-activation outputs
-    // training only (null otherwise): the weight-gradient operands, transposed planes with a column of
-    // ones appended: tp[0] the inputs (dims[0] + 1 features), tp[l + 1] the outputs of layer l < n_layers - 1
+    float* out[ABN_MAX_LAYERS];    // [rows, dims[l+1]] post-activation outputs, row-major: the last layer's (the others' may be null)
+    // the layer inputs as transposed images with a column of ones appended (what the backward reads, and
+    // the only copy of the hidden activations): tp[0] the inputs (dims[0] + 1 features), tp[l + 1] the
+    // outputs of layer l < n_layers - 1
     char* tp[ABN_MAX_LAYERS];
     int64_t tp_steps;              // row steps of those images (pl_row_steps(rows))
 #ifdef ABN_STAMPS
@@ -417,18 +452,18 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
                     f[t2] = make_frag<NP>(v0, v1);
                     store_frag<NP>(img + (int64_t)(2 * blk + t2) * (NP * 1024) + lane * 16, f[t2]);
                     const int n = 32 * blk + 16 * t2 + 4 * h;
-                    if (row_ok && n < N) *reinterpret_cast<f32x4*>(out + (int64_t)gr * N + n) = v0;
-                    if (row_ok && n + 8 < N) *reinterpret_cast<f32x4*>(out + (int64_t)gr * N + n + 8) = v1;
+                    if (out && row_ok && n < N) *reinterpret_cast<f32x4*>(out + (int64_t)gr * N + n) = v0;
+                    if (out && row_ok && n + 8 < N) *reinterpret_cast<f32x4*>(out + (int64_t)gr * N + n + 8) = v1;
                 }
                 if (tp)
-                    emit_planes<NP>(tp + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, f, idf, lane,
+                    emit_planes<NP>(tp + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
                                     blk == N / 32 ? N % 32 : -1, p.rows - row0);
             }
         }
     }
     if (tp && N % 32 == 0 && wave == PL_WAVES - 1) {       // the column of ones opens a block of its own
         Frag<NP> z[2] = {};
-        emit_planes<NP>(tp + ((int64_t)nblk * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, z, idf, lane, 0, p.rows - row0);
+        emit_planes<NP>(tp + ((int64_t)nblk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, p.rows - row0);
     }
     PSTAMPF(6 + 5 * l);
     // steps of the next layer's padding that no block of this layer covers
@@ -483,12 +518,12 @@ __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
             store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
         }
         if (p.tp[0] && kb < pl_blocks(D0 + 1))
-            emit_planes<NP>(p.tp[0] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, f, idf, lane,
+            emit_planes<NP>(p.tp[0] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
                             kb == D0 / 32 ? D0 % 32 : -1, p.rows - row0);
     }
     if (p.tp[0] && pl_blocks(D0 + 1) > blocks0 && wave == PL_WAVES - 1) {     // D0 % 32 == 0 and no padding block to hold the ones
         Frag<NP> z[2] = {};
-        emit_planes<NP>(p.tp[0] + ((int64_t)(D0 / 32) * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, z, idf, lane, 0, p.rows - row0);
+        emit_planes<NP>(p.tp[0] + ((int64_t)(D0 / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, p.rows - row0);
     }
     PSTAMPF(1);
     __syncthreads();
@@ -512,7 +547,9 @@ struct PlanesBwdP {
     int act[ABN_MAX_LAYERS];
     const float* d_out;            // [rows, dims[n_layers]]: d loss / d output, or d loss / d (pre-activation) of the last layer
     int d_out_is_dz;
-    const float* a[ABN_MAX_LAYERS];       // [rows, dims[l+1]] post-activation outputs (forward's out[l])
+    const float* a_top;                   // [rows, dims[n_layers]] the last layer's output, row-major (needed unless d_out_is_dz)
+    const char* tp[ABN_MAX_LAYERS];       // forward's transposed images: tp[l + 1] holds the outputs of layer l
+    float* dx;                            // optional [rows, dims[0]]: gradient w.r.t. the inputs (needs wpt[0])
     const float* mask[ABN_MAX_LAYERS];
     const char* wpt[ABN_MAX_LAYERS];      // packed W_l^T images, l >= 1
     char* dzp[ABN_MAX_LAYERS];            // out: transposed planes of dZ_l (dims[l+1] features)
@@ -537,23 +574,30 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
         for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
     if (ws.active) planes_kloop<NP, BPW>(acc, p.wpt[l], nblk, nsteps, img, blk0, ws.s_first, ws.my_steps, lane);
 
-    const float* __restrict__ mask = p.mask[l - 1];
+    const float* __restrict__ mask = l >= 1 ? p.mask[l - 1] : nullptr;
     const int gr = row0 + r;
     const bool row_ok = gr < p.rows;
     const int grc = row_ok ? gr : p.rows - 1;
+    // act'(a) comes from the forward's transposed image of this layer's input (lane = batch row here,
+    // feature on the lane there: a gather of 4- or 2-byte elements, 8 rows of one feature per 32 bytes)
     f32x4 av[BPW][4], mv[BPW][4];
-    if (ws.active && ws.khalf == 0) {
-        const float* arow = p.a[l - 1] + (int64_t)grc * K;
+    if (ws.active && ws.khalf == 0 && l >= 1) {
+        const int row_off = tgather_row_offset<NP>(r);
 #pragma unroll
-        for (int j = 0; j < BPW; ++j)
+        for (int j = 0; j < BPW; ++j) {
+            const int blk = blk0 + j < nblk ? blk0 + j : nblk - 1;
+            const char* tile = p.tp[l] + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>();
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[j][g][e] = tgather<NP>(tile, row_off, 8 * g + 4 * h + e);
                 const int k = 32 * (blk0 + j) + 4 * h + 8 * g;
-                av[j][g] = *reinterpret_cast<const f32x4*>(arow + (k < K ? k : K - 4));
                 if (mask) mv[j][g] = *reinterpret_cast<const f32x4*>(mask + (int64_t)grc * K + (k < K ? k : K - 4));
             }
+        }
     }
     auto finish = [&]() {
+        if (l == 0) return;                          // d loss / d input: the plain product
         with_act(p.act[l - 1], [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
 #pragma unroll
@@ -592,14 +636,20 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
                 for (int t2 = 0; t2 < 2; ++t2) {
                     const f32x4 v0 = {acc[j][8 * t2], acc[j][8 * t2 + 1], acc[j][8 * t2 + 2], acc[j][8 * t2 + 3]};
                     const f32x4 v1 = {acc[j][8 * t2 + 4], acc[j][8 * t2 + 5], acc[j][8 * t2 + 6], acc[j][8 * t2 + 7]};
-                    f[t2] = make_frag<NP>(v0, v1);
-                    store_frag<NP>(img + (int64_t)(2 * blk + t2) * (NP * 1024) + lane * 16, f[t2]);
+                    if (l == 0) {
+                        const int k = 32 * blk + 16 * t2 + 4 * h;
+                        if (row_ok && k < K) *reinterpret_cast<f32x4*>(p.dx + (int64_t)gr * K + k) = v0;
+                        if (row_ok && k + 8 < K) *reinterpret_cast<f32x4*>(p.dx + (int64_t)gr * K + k + 8) = v1;
+                    } else {
+                        f[t2] = make_frag<NP>(v0, v1);
+                        store_frag<NP>(img + (int64_t)(2 * blk + t2) * (NP * 1024) + lane * 16, f[t2]);
+                    }
                 }
-                emit_planes<NP>(p.dzp[l - 1] + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, f, idf, lane, -1, 0);
+                if (l >= 1) emit_planes<NP>(p.dzp[l - 1] + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane, -1, 0);
             }
         }
     }
-    if (l - 1 >= 1) {
+    if (l - 1 >= 1 || (l == 1 && p.dx)) {
         const int next_steps = pl_steps(K);
         const bf16x8 z = {};
         for (int s = 2 * nblk + wave; s < next_steps; s += PL_WAVES)
@@ -641,7 +691,7 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
                 if (row_ok && c < NT) {
                     v[u] = *reinterpret_cast<const f32x4*>(p.d_out + (int64_t)gr * NT + c);
                     if (!p.d_out_is_dz) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(p.a[top] + (int64_t)gr * NT + c);
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(p.a_top + (int64_t)gr * NT + c);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[u][e] *= act_grad(a[e], p.act[top]);
                         if (mask) {
@@ -656,11 +706,11 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
             store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
         }
         if (kb < pl_blocks(NT))
-            emit_planes<NP>(p.dzp[top] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * (NP * 1024) + lane * 16, f, idf, lane, -1, 0);
+            emit_planes<NP>(p.dzp[top] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane, -1, 0);
     }
     __syncthreads();
 
-    for (int l = top; l >= 1; --l) {
+    for (int l = top; l >= (p.dx ? 0 : 1); --l) {
         const int nblk = (p.dims[l] + 31) / 32;
         if (nblk > PL_WAVES) planes_dgrad_layer<NP, 2, 1>(p, l, img, part, idf, wave, lane, row0);
         else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l + 1]) % (2 * PL_DEPTH) != 0) planes_dgrad_layer<NP, 1, 1>(p, l, img, part, idf, wave, lane, row0);
@@ -682,7 +732,11 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
 //   shape 2  TN 4 TK 1 WN 1 WK 8   128 x 256   at most four row blocks (the output layer: N = 100)
 // (256 x 256 tiles halve the operand stream again but need twice the slabs to fill the chip: the slab
 // writes and their reduction then cost what the operands saved -- measured, 77 + 23 us against 81 + 16.)
-constexpr int WG_STAGES = 4;
+// LDS-DMA ring: row steps in flight + the one being consumed (HBM latency under this load: 3-4 us).
+// bf16 x 3 streams fp32 tiles (2 KB) and keeps ONE more buffer for the step's operands split into
+// planes (3 KB per block) -- each tile is split once, by the wave that fetched it, not by the
+// four / two waves that multiply it (that was 116 us, VALU-bound, against 78 for 6-byte planes).
+template <int NP> constexpr int wg_stages() { return NP == 3 ? 5 : 6; }
 constexpr int WG_MAX_BLOCKS = 12;                 // operand blocks of one row step (shape 0: 8 + 4)
 struct WgradLayer {
     const char* dzp;       // transposed planes of dZ_l        [nblk][steps]
@@ -710,7 +764,7 @@ static inline void wgrad_shape(int nblk, int kblk, int* shape, int* bn, int* bk)
 }
 
 template <int NP>
-constexpr size_t wgrad_lds_bytes() { return (size_t)WG_STAGES * WG_MAX_BLOCKS * NP * 1024; }
+constexpr size_t wgrad_lds_bytes() { return (size_t)wg_stages<NP>() * WG_MAX_BLOCKS * tile_bytes<NP>() + (NP == 3 ? WG_MAX_BLOCKS * 3 * 1024 : 0); }
 
 template <int NP, int TN, int TK, int WN, int WK>
 __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L, char* __restrict__ smem, int nb0, int kb0,
@@ -719,9 +773,12 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
     static_assert(WN * WK == PL_WAVES, "eight waves");
     constexpr int BN = WN * TN, BK_ = WK * TK, NB = BN + BK_;     // operand blocks per row step: dZ blocks first
     constexpr int PER_WAVE = (NB + PL_WAVES - 1) / PL_WAVES;
-    constexpr int FR = NP * 1024;
+    constexpr int FR = tile_bytes<NP>();                 // one (block, row step) tile, in HBM and in LDS
+    constexpr int DI = FR / 1024;                        // DMA instructions per tile (1 KB each)
     constexpr int STAGE = NB * FR;
+    constexpr int WG_STAGES = wg_stages<NP>();
     static_assert(NB <= WG_MAX_BLOCKS, "LDS stage");
+    char* const planes = smem + WG_STAGES * WG_MAX_BLOCKS * FR;      // bf16 x 3 only: [block][plane][1 KB] of the step being summed
     const int wn = wave % WN, wk = wave / WN;
     // this wave's share of the DMA: operand blocks wave, wave + 8, ... below NB (n_mine of them: the wait
     // for "my part of step c" counts this wave's own instructions)
@@ -746,10 +803,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         for (int u = 0; u < PER_WAVE; ++u)
             if (u < n_mine) {
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
+                for (int d = 0; d < DI; ++d)
                     __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(src[u] + ((int64_t)step * NP + pl) * 1024),
-                        (__attribute__((address_space(3))) void*)(smem + stage * STAGE + dst[u] + pl * 1024), 16, 0, 0);
+                        (const __attribute__((address_space(1))) void*)(src[u] + (int64_t)step * FR + d * 1024),
+                        (__attribute__((address_space(3))) void*)(smem + stage * STAGE + dst[u] + d * 1024), 16, 0, 0);
             }
     };
     f32x16 acc[TN][TK];
@@ -763,32 +820,46 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
     // blocks past the matrix are padding: a wave whose blocks all are skips the MFMAs (not the DMAs or barriers)
     const bool live = nb0 + wn * TN < L.nblk && kb0 + wk * TK < L.kblk;
     const int n_steps = s_end - s_begin;
-    // Steps c + 2 and c + 3 are in flight while step c is summed and step c + 1's fragments are read
-    // into the second register set (every wave sits behind the same barrier: without that read-ahead
-    // they all wait for LDS together, then all issue MFMAs together).  A wave issues the same DMAs
-    // for every step (clamped repeats past the end), so "my part of step c + 1 has landed" is
-    // vmcnt(one step's worth of my DMAs).
+    // Steps c + 2 .. c + WG_STAGES - 1 are in flight while step c is summed and step c + 1's fragments are
+    // read into the second register set (every wave sits behind the same barrier: without that
+    // read-ahead they all wait for LDS together, then all issue MFMAs together).  A wave issues the
+    // same DMAs for every step (clamped repeats past the end), so "my part of step c + 1 has landed"
+    // is vmcnt((WG_STAGES - 3) steps' worth of my DMAs).
     auto step_at = [&](int c) { return s_begin + (c < n_steps ? c : n_steps - 1); };
-    auto wait_one_step_left = [&]() {
-        static_assert(PER_WAVE == 2, "vmcnt literals: n_mine * NP");
-        if (n_mine == 2) {
-            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else if (n_mine == 1) {
-            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        }
+    static_assert(PER_WAVE == 2, "n_mine is 1 or 2 below");
+    auto wait_steps_left = [&](auto steps_tag) {
+        constexpr int S = decltype(steps_tag)::value;
+        if (n_mine == 2) wait_vmcnt<S * 2 * DI>();
+        else if (n_mine == 1) wait_vmcnt<S * DI>();
     };
     struct Frags { bf16x8 a[TN][NP], b[TK][NP]; };
     auto read_frags = [&](Frags& f, int c) {
-        const char* st = smem + (c % WG_STAGES) * STAGE + lane * 16;
+        if constexpr (NP == 3) {       // from the planes buffer (filled by convert() for this step)
+            const char* st = planes + lane * 16;
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
+            for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-            for (int i = 0; i < TN; ++i) f.a[i][pl] = *reinterpret_cast<const bf16x8*>(st + (wn * TN + i) * FR + pl * 1024);
+                for (int i = 0; i < TN; ++i) f.a[i][pl] = *reinterpret_cast<const bf16x8*>(st + (wn * TN + i) * 3072 + pl * 1024);
 #pragma unroll
-            for (int j = 0; j < TK; ++j) f.b[j][pl] = *reinterpret_cast<const bf16x8*>(st + (BN + wk * TK + j) * FR + pl * 1024);
+                for (int j = 0; j < TK; ++j) f.b[j][pl] = *reinterpret_cast<const bf16x8*>(st + (BN + wk * TK + j) * 3072 + pl * 1024);
+            }
+        } else {
+            const char* st = smem + (c % WG_STAGES) * STAGE + lane * 16;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) f.a[i][0] = *reinterpret_cast<const bf16x8*>(st + (wn * TN + i) * FR);
+#pragma unroll
+            for (int j = 0; j < TK; ++j) f.b[j][0] = *reinterpret_cast<const bf16x8*>(st + (BN + wk * TK + j) * FR);
         }
+    };
+    // bf16 x 3: this wave's tiles of step c, fp32 in the ring -> three planes in the planes buffer
+    auto convert = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < PER_WAVE; ++u)
+            if (u < n_mine) {
+                const char* t = smem + (c % WG_STAGES) * STAGE + dst[u] + lane * 16;
+                store_frag<3>(planes + (dst[u] / FR) * 3072 + lane * 16,
+                              make_frag<3>(*reinterpret_cast<const f32x4*>(t), *reinterpret_cast<const f32x4*>(t + 1024)));
+            }
     };
     auto mfmas = [&](const Frags& f) {
         if constexpr (NP == 3) {
@@ -809,35 +880,53 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         }
     };
     Frags fr[2];
-    if (n_steps > 0) {
-        dma(step_at(0), 0);
-        dma(step_at(1), 1);
-        dma(step_at(2), 2);
-        // step 0: two steps' worth may stay in flight
-        if (n_mine == 2) {
-            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else if (n_mine == 1) {
-            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (NP == 3) {
+        // ring of WG_STAGES fp32 stages, all but one in flight; per step two barriers around the planes buffer:
+        //   X: everybody has read step c's fragments out of it   -> convert my tiles of step c + 1 into it, issue step c's MFMAs
+        //   Y: everybody's tiles of step c + 1 are in it         -> read them (second register set)
+        if (n_steps > 0) {
+#pragma unroll
+            for (int c = 0; c < WG_STAGES - 1; ++c) dma(step_at(c), c);
+            wait_steps_left(std::integral_constant<int, WG_STAGES - 2>{});      // my tiles of step 0 are in
+            convert(0);
+            __syncthreads();
+            if (live) read_frags(fr[0], 0);
         }
-        __syncthreads();
-        if (live) read_frags(fr[0], 0);
-    }
-    // one step: cur holds step c's fragments; nxt receives step c + 1's
-    auto one_step = [&](int c, const Frags& cur, Frags& nxt) {
-        wait_one_step_left();       // my part of step c + 1 is in LDS
-        __syncthreads();            // ... and everybody's; everybody has read step c (its stage is not reused before the next barrier)
-        dma(step_at(c + 3), (c + 3) % WG_STAGES);      // into the stage of step c - 1
-        if (live) {
-            if (c + 1 < n_steps) read_frags(nxt, c + 1);
-            mfmas(cur);
+        auto one_step = [&](int c, const Frags& cur, Frags& nxt) {
+            wait_steps_left(std::integral_constant<int, WG_STAGES - 3>{});      // my tiles of step c + 1 are in the ring
+            __syncthreads();                                                        // X
+            if (c + 1 < n_steps) convert(c + 1);
+            dma(step_at(c + WG_STAGES - 1), (c + WG_STAGES - 1) % WG_STAGES);       // into the stage of step c - 1 (converted long ago)
+            if (live) mfmas(cur);                                                   // (issued before Y: the matrix cores run through the wait)
+            __syncthreads();                                                        // Y
+            if (live && c + 1 < n_steps) read_frags(nxt, c + 1);
+        };
+        for (int c = 0; c < n_steps; c += 2) {
+            one_step(c, fr[0], fr[1]);
+            if (c + 1 < n_steps) one_step(c + 1, fr[1], fr[0]);
         }
-    };
-    static_assert(WG_STAGES == 4, "stage arithmetic above");
-    for (int c = 0; c < n_steps; c += 2) {
-        one_step(c, fr[0], fr[1]);
-        if (c + 1 < n_steps) one_step(c + 1, fr[1], fr[0]);
+    } else {
+        if (n_steps > 0) {
+#pragma unroll
+            for (int c = 0; c < WG_STAGES - 1; ++c) dma(step_at(c), c);
+            wait_steps_left(std::integral_constant<int, WG_STAGES - 2>{});      // step 0 is in
+            __syncthreads();
+            if (live) read_frags(fr[0], 0);
+        }
+        // one step: cur holds step c's fragments; nxt receives step c + 1's
+        auto one_step = [&](int c, const Frags& cur, Frags& nxt) {
+            wait_steps_left(std::integral_constant<int, WG_STAGES - 3>{});      // my part of step c + 1 is in LDS
+            __syncthreads();            // ... and everybody's; everybody has read step c (its stage is not reused before the next barrier)
+            dma(step_at(c + WG_STAGES - 1), (c + WG_STAGES - 1) % WG_STAGES);   // into the stage of step c - 1
+            if (live) {
+                if (c + 1 < n_steps) read_frags(nxt, c + 1);
+                mfmas(cur);
+            }
+        };
+        for (int c = 0; c < n_steps; c += 2) {
+            one_step(c, fr[0], fr[1]);
+            if (c + 1 < n_steps) one_step(c + 1, fr[1], fr[0]);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped repeats still target this workgroup's LDS
 

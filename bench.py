@@ -61,10 +61,13 @@ def make_pool(seed, device):
 
 
 def kernel_names(prec):
-    code = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[prec]
-    pair = 3 if prec == 'bf16x3' else code          # vectorised tiles split once per LDS commit (template value 3)
-    return ('void abn::tower_fwd_fused_kernel<%d>(abn::FusedFwdP)' % code,
-            'void abn::gemm_bwd_pair_kernel<128, 64, %d>(abn::GemmP, int, abn::GemmP)' % pair)
+    """(forward kernel, dominant backward kernel) of the step in `prec`."""
+    if prec == 'fp32':
+        return ('void abn::tower_fwd_fused_kernel<0>(abn::FusedFwdP)',
+                'void abn::gemm_bwd_pair_kernel<128, 64, 0>(abn::GemmP, int, abn::GemmP)')
+    planes = 3 if prec == 'bf16x3' else 1
+    return ('void abn::tower_fwd_planes_kernel<%d>(abn::PlanesFwdP)' % planes,
+            'void abn::wgrad_planes_kernel<%d>(abn::WgradP)' % planes)
 
 
 def _time_launches(torch, fn, reps):
@@ -111,8 +114,58 @@ def _traffic(kernel):
     return None
 
 
+def planes_roofline(torch, net, reps=20):
+    """precision bf16x3 / bf16 (csrc/tower_planes.h): the step is three launches of similar length -- the
+    forward chain, the data-gradient chain, the weight gradients -- plus the fused reduction + optimizer.
+    The DOMINANT one by time is tower_fwd_planes_kernel (the whole forward of both towers: 2 x 4096
+    rows through 40-500-500-500-100).  It is timed live as abn_tower_forward issues it, i.e. together
+    with pack_planes_kernel (~5 us: the weights as operand fragments, once per step), `reps` launch
+    pairs captured into one hipGraph and bracketed by HIP events on the launch stream.  Algorithmic
+    FLOPs per launch: 2 * 8192 * (40*500 + 2*500*500 + 500*100).  Roof: the dense bf16 MFMA peak
+    divided by the bf16 products each algorithmic product costs (six for bf16x3: 2500 / 6 = 416.7
+    TFLOP/s algorithmic; one for bf16).  Both peaks assume the 2.4 GHz boost clock; under this
+    workload the chip holds ~1.6-1.8 GHz (s_memtime against wall clock, tools/probes/mfma_peak.hip)."""
+    prec = net.precision
+    peak = {'bf16x3': X3_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS}[prec]
+    fwd_name, wgrad_name = kernel_names(prec)
+    rows = 2 * BATCH
+    x12 = torch.randn(rows, 40, device='cuda')
+    net.train()
+
+    def fwd():
+        with torch.no_grad():
+            net.forward_pair_rows(x12)
+    t = _time_launches(torch, fwd, reps)
+    fl = 2.0 * rows * (40 * 500 + 2 * 500 * 500 + 500 * 100)
+    achieved = fl / t / 1e12
+    out = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+           'frac': round(achieved / peak, 4), 'traffic': _traffic('tower_fwd_planes_kernel'), 'arithmetic': prec,
+           'peak_note': {'bf16x3': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per algorithmic product',
+                         'bf16': 'dense bf16 MFMA'}[prec],
+           'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+           'kernel': fwd_name + '  (the whole forward of both towers; timed with the pack_planes_kernel launch that '
+                     'precedes it in abn_tower_forward, launched back to back from one hipGraph)',
+           'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl}
+    # the backward of the same step: the data-gradient chain and the weight gradients (slabs left
+    # unreduced: the reduction rides in the optimizer's launch), timed as one sequence
+    emb, state = net.direct_forward(x12[:BATCH].contiguous(), x12[BATCH:].contiguous())
+    d_out = torch.randn_like(emb) * 1e-3
+
+    def bwd():
+        net.direct_backward(state, d_out, d_out_is_dz=True, defer_reduce=True)
+    t = _time_launches(torch, bwd, reps)
+    net.take_pending_reduce()
+    fl = 2.0 * rows * (2 * (40 * 500 + 2 * 500 * 500 + 500 * 100) - 40 * 500)      # wgrad everywhere, no dgrad into the input
+    out['backward'] = {'kernels': 'tower_dgrad_planes_kernel + ' + wgrad_name,
+                       'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / peak, 4),
+                       'avg_sequence_us': round(t * 1e6, 2), 'flop_per_sequence': fl,
+                       'traffic': {'dgrad': _traffic('tower_dgrad_planes_kernel'), 'wgrad': _traffic('wgrad_planes_kernel')}}
+    return out
+
+
 def tower_roofline(torch, net, reps=20):
-    """The dominant kernel of the step by time: gemm_bwd_pair_kernel<128, 64, .> -- the wgrad and
+    """(precision fp32; planes_roofline covers bf16x3 / bf16.)
+    The dominant kernel of the step by time: gemm_bwd_pair_kernel<128, 64, .> -- the wgrad and
     the dgrad of a 500x500 layer over the 2 x 4096 tower rows in ONE grid, two launches per step.
     Timed live in the network's arithmetic through abn_linear_backward_prec with dW = NULL (the
     single-layer entry that issues exactly the grid the tower backward issues, without the
@@ -299,10 +352,11 @@ def mode_bench(torch, trainer, net, pool, args, world, prec, note):
     default = net.precision
     net.eval()
     with torch.no_grad():
+        x12 = torch.cat([x1, x2])                   # both towers' rows: the launch shape of the timed step
         net.precision = 'fp32'
-        ref = net.forward_once(x1)
+        ref = torch.cat(net.forward_pair_rows(x12))
         net.precision = prec
-        got = net.forward_once(x1)
+        got = torch.cat(net.forward_pair_rows(x12))
     err = float((got - ref).abs().max() / ref.abs().max())
     net.train()
     step = make_stepper(trainer, pool, args.graph)
@@ -503,12 +557,13 @@ def main():
     if rank == 0:
         with torch.no_grad():
             net.eval()
-            x1 = pool[0][0]
+            x1, x2 = pool[0][0], pool[0][1]
             keep = net.precision
+            x12 = torch.cat([x1, x2])               # both towers' rows: the launch shape of the timed step
             net.precision = 'fp32'
-            ref = net.forward_once(x1)
+            ref = torch.cat(net.forward_pair_rows(x12))
             net.precision = keep
-            err_default = float((net.forward_once(x1) - ref).abs().max() / ref.abs().max())
+            err_default = float((torch.cat(net.forward_pair_rows(x12)) - ref).abs().max() / ref.abs().max())
             net.train()
     f32x = mode_bench(torch, trainer, net, pool, args, world, 'fp32',
                       'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): one sequential fp32 fma chain per output, round 1\'s headline arithmetic')
@@ -538,7 +593,7 @@ def main():
             'tflops_whole_step': round(value * FLOP_PER_PAIR / 1e12, 2),
             'last_loss': last_loss,
         }
-        out['roofline'] = tower_roofline(torch, net)
+        out['roofline'] = tower_roofline(torch, net) if net.precision == 'fp32' else planes_roofline(torch, net)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(torch)
             out['cpu_baseline'] = cb

@@ -24,3 +24,19 @@ def decode(buf_u16, nblk, nsteps, np_):
             # img[blk, s, h, r, j] -> row 32 blk + r, column 16 s + P[h][j]
             out[:, P[h][j]::16] = img[:, :, h, :, j].transpose(0, 2, 1).reshape(nblk * 32, nsteps)
     return out
+
+
+def decode_t(buf_u16, nblk, nsteps, np_):
+    """Transposed image (tower_planes.h emit_planes) -> float64 matrix [32 nblk features][16 nsteps batch rows].
+    np_ = 1: [nblk][nsteps][64 lanes][8 bf16], the layout decode() reads with one plane.
+    np_ = 3: [nblk][nsteps][elements 0..3 | 4..7][64 lanes][4 fp32]."""
+    if np_ == 1:
+        return decode(buf_u16, nblk, nsteps, 1)
+    f = buf_u16[:nblk * nsteps * 1024].view(np.float32).reshape(nblk, nsteps, 2, 2, 32, 4).astype(np.float64)
+    out = np.zeros((nblk * 32, nsteps * 16))
+    P = perm16()
+    for h in range(2):
+        for j in range(8):
+            # f[blk, s, j >> 2, h, c, j & 3] -> row 32 blk + c, column 16 s + P[h][j]
+            out[:, P[h][j]::16] = f[:, :, j >> 2, h, :, j & 3].transpose(0, 2, 1).reshape(nblk * 32, nsteps)
+    return out

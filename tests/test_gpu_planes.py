@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from conftest import rel_err, check_grads
-from planes_decode import decode
+from planes_decode import decode, decode_t
 
 pytestmark = pytest.mark.gpu
 
@@ -101,6 +101,31 @@ def test_forward_loss_and_gradients_against_the_oracle(shape, act, precision, to
         assert rel_err(q.grad.cpu().numpy(), grads[k], floor=1e-30) < (1e-6 if precision == 'bf16x3' else 1e-5), k
 
 
+def test_input_gradient_through_the_chain():
+    """x.requires_grad: the data-gradient chain runs one product further (dX = dZ_0 W_0)."""
+    import abnet3_amd.loss as L
+    from oracle import siamese_np as O
+    kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=72, output_dim=36, activation_layer='tanh',
+              p_dropout=0.0, batch_norm=False)
+    net, spec, p = build(kw, seed=6, precision='bf16x3')
+    B = 45
+    rng = np.random.default_rng(6)
+    x1n, x2n = rng.standard_normal((B, 40)).astype(np.float32), rng.standard_normal((B, 40)).astype(np.float32)
+    y = rng.choice([1, -1], B)
+    x1, x2 = dev(x1n).requires_grad_(True), dev(x2n).requires_grad_(True)
+    net.train()
+    e1, e2 = net(x1, x2)
+    L.coscos2(avg=False)(e1, e2, dev(y)).backward()
+    o1, c1 = O.tower_forward(p, x1n, spec, True)
+    o2, c2 = O.tower_forward(p, x2n, spec, True)
+    _, d1, d2, _ = O.pair_loss(o1, o2, y, 'coscos2', 0.5, False)
+    og = {}
+    _, dx1 = O.tower_backward(p, c1, d1, spec, og, return_dx=True)
+    _, dx2 = O.tower_backward(p, c2, d2, spec, og, return_dx=True)
+    assert rel_err(x1.grad.cpu().numpy(), dx1) < 1e-5 and rel_err(x2.grad.cpu().numpy(), dx2) < 1e-5
+    check_grads({k: q.grad.cpu().numpy() for k, q in net.named_parameters()}, og, spec.param_keys(), False, tol=1e-4)
+
+
 def test_dropout_masks_scale_both_chains():
     """train mode with p_dropout: the masks multiply the pre-activations in the forward epilogue and the data
     gradient in the backward chain (abnet3/model.py:137,148,157 Dropout between Linear and the activation)."""
@@ -174,14 +199,13 @@ def test_operand_images_decode_to_their_tensors(precision, NP):
         d = decode(ws16[2 * fn(ctypes.byref(desc), R, 2, 0, l):], (dims[l + 1] + 31) // 32, steps(dims[l]), NP)
         assert np.abs(d[:dims[l + 1], :dims[l]] - Ws[l]).max() <= eps * np.abs(Ws[l]).max()
         assert np.abs(d[dims[l + 1]:]).max(initial=0) == 0 and np.abs(d[:, dims[l]:]).max(initial=0) == 0
-        if l > 0:
-            d = decode(ws16[2 * fn(ctypes.byref(desc), R, 2, 1, l):], (dims[l] + 31) // 32, steps(dims[l + 1]), NP)
-            assert np.abs(d[:dims[l], :dims[l + 1]] - Ws[l].T).max() <= eps * np.abs(Ws[l]).max()
-        d = decode(ws16[2 * fn(ctypes.byref(desc), R, 2, 2, l):], (dims[l] + 1 + 31) // 32, row_steps, NP)
+        d = decode(ws16[2 * fn(ctypes.byref(desc), R, 2, 1, l):], (dims[l] + 31) // 32, steps(dims[l + 1]), NP)
+        assert np.abs(d[:dims[l], :dims[l + 1]] - Ws[l].T).max() <= eps * np.abs(Ws[l]).max()
+        d = decode_t(ws16[2 * fn(ctypes.byref(desc), R, 2, 2, l):], (dims[l] + 1 + 31) // 32, row_steps, NP)
         assert np.abs(d[:dims[l], :R] - acts[l].T).max() <= max(eps, 3e-7) * np.abs(acts[l]).max()
         assert np.array_equal(d[dims[l], :R], np.ones(R)) and np.abs(d[dims[l], R:]).max(initial=0) == 0
         assert np.abs(d[dims[l] + 1:]).max(initial=0) == 0
-        d = decode(sc16[2 * fn(ctypes.byref(desc), R, 2, 3, l):], (dims[l + 1] + 31) // 32, row_steps, NP)
+        d = decode_t(sc16[2 * fn(ctypes.byref(desc), R, 2, 3, l):], (dims[l + 1] + 31) // 32, row_steps, NP)
         tol = 3e-6 if NP == 3 else 3e-2
         assert np.abs(d[:dims[l + 1], :R] - dz[l].T).max() <= tol * np.abs(dz[l]).max(), l
         assert np.abs(d[:, R:]).max(initial=0) == 0          # rows past the batch contribute nothing
