@@ -727,16 +727,17 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
 // The launch is bound by the operand stream (every dZ block is read once per tile column, every
 // activation block once per tile row, from the Infinity Cache at ~6 TB/s), so the tiles are as
 // large as LDS allows:
-//   shape 0  TN 4 TK 1 WN 2 WK 4   256 x 128   the general case
+//   shape 0  TN 2 TK 2 WN 4 WK 2   256 x 128   the general case
 //   shape 1  TN 1 TK 2 WN 8 WK 1   256 x  64   at most two column blocks (the first layer: K + 1 = 41)
-//   shape 2  TN 4 TK 1 WN 1 WK 8   128 x 256   at most four row blocks (the output layer: N = 100)
+//   shape 2  TN 2 TK 2 WN 2 WK 4   128 x 256   at most four row blocks (the output layer: N = 100)
 // (256 x 256 tiles halve the operand stream again but need twice the slabs to fill the chip: the slab
 // writes and their reduction then cost what the operands saved -- measured, 77 + 23 us against 81 + 16.)
-// LDS-DMA ring: row steps in flight + the one being consumed (HBM latency under this load: 3-4 us).
-// bf16 x 3 streams fp32 tiles (2 KB) and keeps ONE more buffer for the step's operands split into
-// planes (3 KB per block) -- each tile is split once, by the wave that fetched it, not by the
-// four / two waves that multiply it (that was 116 us, VALU-bound, against 78 for 6-byte planes).
-template <int NP> constexpr int wg_stages() { return NP == 3 ? 5 : 6; }
+// bf16: LDS-DMA ring of 1 KB tiles, row steps in flight + the one being consumed (HBM latency under this
+// load: 3-4 us).  bf16 x 3: the fp32 tiles (2 KB) are fetched into REGISTERS four row steps ahead, split
+// once by the wave that fetched them -- not by the four / two waves that multiply them: that was 116 us,
+// VALU-bound -- and written as three planes (3 KB per block) into a ring of four LDS stages.
+template <int NP> constexpr int wg_stages() { return NP == 3 ? 4 : 6; }
+constexpr int WG_REG_DEPTH = 4;
 constexpr int WG_MAX_BLOCKS = 12;                 // operand blocks of one row step (shape 0: 8 + 4)
 struct WgradLayer {
     const char* dzp;       // transposed planes of dZ_l        [nblk][steps]
@@ -764,7 +765,7 @@ static inline void wgrad_shape(int nblk, int kblk, int* shape, int* bn, int* bk)
 }
 
 template <int NP>
-constexpr size_t wgrad_lds_bytes() { return (size_t)wg_stages<NP>() * WG_MAX_BLOCKS * tile_bytes<NP>() + (NP == 3 ? WG_MAX_BLOCKS * 3 * 1024 : 0); }
+constexpr size_t wgrad_lds_bytes() { return (size_t)wg_stages<NP>() * WG_MAX_BLOCKS * (NP == 3 ? 3072 : 1024); }
 
 template <int NP, int TN, int TK, int WN, int WK>
 __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L, char* __restrict__ smem, int nb0, int kb0,
@@ -778,7 +779,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
     constexpr int STAGE = NB * FR;
     constexpr int WG_STAGES = wg_stages<NP>();
     static_assert(NB <= WG_MAX_BLOCKS, "LDS stage");
-    char* const planes = smem + WG_STAGES * WG_MAX_BLOCKS * FR;      // bf16 x 3 only: [block][plane][1 KB] of the step being summed
+    constexpr int PSTAGE = NB * 3072;                    // bf16 x 3: one LDS stage = [block][plane][1 KB]
     const int wn = wave % WN, wk = wave / WN;
     // this wave's share of the DMA: operand blocks wave, wave + 8, ... below NB (n_mine of them: the wait
     // for "my part of step c" counts this wave's own instructions)
@@ -834,8 +835,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
     };
     struct Frags { bf16x8 a[TN][NP], b[TK][NP]; };
     auto read_frags = [&](Frags& f, int c) {
-        if constexpr (NP == 3) {       // from the planes buffer (filled by convert() for this step)
-            const char* st = planes + lane * 16;
+        if constexpr (NP == 3) {
+            const char* st = smem + (c % WG_STAGES) * PSTAGE + lane * 16;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
@@ -850,16 +851,6 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
 #pragma unroll
             for (int j = 0; j < TK; ++j) f.b[j][0] = *reinterpret_cast<const bf16x8*>(st + (BN + wk * TK + j) * FR);
         }
-    };
-    // bf16 x 3: this wave's tiles of step c, fp32 in the ring -> three planes in the planes buffer
-    auto convert = [&](int c) {
-#pragma unroll
-        for (int u = 0; u < PER_WAVE; ++u)
-            if (u < n_mine) {
-                const char* t = smem + (c % WG_STAGES) * STAGE + dst[u] + lane * 16;
-                store_frag<3>(planes + (dst[u] / FR) * 3072 + lane * 16,
-                              make_frag<3>(*reinterpret_cast<const f32x4*>(t), *reinterpret_cast<const f32x4*>(t + 1024)));
-            }
     };
     auto mfmas = [&](const Frags& f) {
         if constexpr (NP == 3) {
@@ -881,29 +872,62 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
     };
     Frags fr[2];
     if constexpr (NP == 3) {
-        // ring of WG_STAGES fp32 stages, all but one in flight; per step two barriers around the planes buffer:
-        //   X: everybody has read step c's fragments out of it   -> convert my tiles of step c + 1 into it, issue step c's MFMAs
-        //   Y: everybody's tiles of step c + 1 are in it         -> read them (second register set)
+        // Register ring: slot k % 4 holds this wave's fp32 tiles of step k, fetched four steps before they
+        // are split (raw buffer loads: the compiler counts their vmcnt and leaves them where they stand).
+        // Iteration c, behind ONE barrier: split step c + 2 into LDS stage (c + 2) % 4 and refill its slot
+        // with step c + 6; read step c + 1's fragments (second register set); step c's MFMAs.  The loop
+        // runs to a multiple of four steps, branch free: steps past the end are written as zeros.
+        static_assert(WG_REG_DEPTH == 4 && WG_STAGES == 4, "slot / stage arithmetic below");
+        __amdgpu_buffer_rsrc_t rs[PER_WAVE];
+#pragma unroll
+        for (int u = 0; u < PER_WAVE; ++u)
+            rs[u] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src[u] - lane * 16), 0, (int)(p.tp_steps * FR), 0x00020000);
+        v4i rq[WG_REG_DEPTH][PER_WAVE][2];
+        const int n4 = (n_steps + 3) / 4 * 4;
+        auto load = [&](int slot, int k) {
+            const int off = step_at(k) * FR;
+#pragma unroll
+            for (int u = 0; u < PER_WAVE; ++u)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    rq[slot][u][d] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], lane * 16, off + d * 1024, 0);
+                }
+        };
+        auto convert = [&](int slot, int k) {
+            const bool real = k < n_steps;
+#pragma unroll
+            for (int u = 0; u < PER_WAVE; ++u)
+                if (u < n_mine) {
+                    f32x4 v0 = __builtin_bit_cast(f32x4, rq[slot][u][0]), v1 = __builtin_bit_cast(f32x4, rq[slot][u][1]);
+                    if (!real) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+                    store_frag<3>(smem + (k % WG_STAGES) * PSTAGE + (dst[u] / FR) * 3072 + lane * 16, make_frag<3>(v0, v1));
+                }
+        };
         if (n_steps > 0) {
 #pragma unroll
-            for (int c = 0; c < WG_STAGES - 1; ++c) dma(step_at(c), c);
-            wait_steps_left(std::integral_constant<int, WG_STAGES - 2>{});      // my tiles of step 0 are in
-            convert(0);
+            for (int k = 0; k < WG_REG_DEPTH; ++k) load(k, k);
+            convert(0, 0); load(0, 4);
+            convert(1, 1); load(1, 5);
             __syncthreads();
             if (live) read_frags(fr[0], 0);
         }
-        auto one_step = [&](int c, const Frags& cur, Frags& nxt) {
-            wait_steps_left(std::integral_constant<int, WG_STAGES - 3>{});      // my tiles of step c + 1 are in the ring
-            __syncthreads();                                                        // X
-            if (c + 1 < n_steps) convert(c + 1);
-            dma(step_at(c + WG_STAGES - 1), (c + WG_STAGES - 1) % WG_STAGES);       // into the stage of step c - 1 (converted long ago)
-            if (live) mfmas(cur);                                                   // (issued before Y: the matrix cores run through the wait)
-            __syncthreads();                                                        // Y
-            if (live && c + 1 < n_steps) read_frags(nxt, c + 1);
-        };
-        for (int c = 0; c < n_steps; c += 2) {
-            one_step(c, fr[0], fr[1]);
-            if (c + 1 < n_steps) one_step(c + 1, fr[1], fr[0]);
+        for (int c0 = 0; c0 < n4; c0 += 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + i;
+                __syncthreads();        // step c + 1's planes are in LDS for everybody; nobody still reads stage (c + 2) % 4
+                if (live) read_frags(fr[(i + 1) & 1], c + 1);
+                convert((i + 2) & 3, c + 2);
+                if (live) mfmas(fr[i & 1]);
+                // the split is ~70 VALU instructions: left in one piece in front of (or behind) the MFMAs it idles
+                // the matrix cores of a SIMD whose two waves sit behind the same barrier; woven in, two MFMAs at a time
+#pragma unroll
+                for (int g = 0; g < TN * TK * 3; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                }
+                load((i + 2) & 3, c + 6);
+            }
         }
     } else {
         if (n_steps > 0) {
@@ -962,9 +986,9 @@ __global__ __launch_bounds__(PL_NT) void wgrad_planes_kernel(WgradP p)
     const int tn = local % L.tiles_n; local /= L.tiles_n;
     const int split = local;
     const int s_begin = (int)(p.tp_steps * split / L.splits), s_end = (int)(p.tp_steps * (split + 1) / L.splits);
-    if (L.shape == 0) wgrad_tile<NP, 4, 1, 2, 4>(p, L, wg_smem, 8 * tn, 4 * tk, s_begin, s_end, split, wave, lane);
+    if (L.shape == 0) wgrad_tile<NP, 2, 2, 4, 2>(p, L, wg_smem, 8 * tn, 4 * tk, s_begin, s_end, split, wave, lane);
     else if (L.shape == 1) wgrad_tile<NP, 1, 2, 8, 1>(p, L, wg_smem, 8 * tn, 2 * tk, s_begin, s_end, split, wave, lane);
-    else wgrad_tile<NP, 4, 1, 1, 8>(p, L, wg_smem, 4 * tn, 8 * tk, s_begin, s_end, split, wave, lane);
+    else wgrad_tile<NP, 2, 2, 2, 4>(p, L, wg_smem, 4 * tn, 8 * tk, s_begin, s_end, split, wave, lane);
 }
 
 }  // namespace abn
