@@ -531,15 +531,17 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
     return L;
 }
 
-// The planes kernels (tower_planes.h) take a call when ...  Forward and backward must agree: both ask here.
+// Whether the planes kernels (tower_planes.h) take a call.  Forward and backward must agree (the forward then
+// leaves the hidden activations in the transposed images only): both ask here.
 // (the switches are read per call: tests flip them inside one process)
 static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws)
 {
     if (getenv("ABN_PLANES") && atoi(getenv("ABN_PLANES")) == 0) return false;
     if (getenv("ABN_FUSED") && atoi(getenv("ABN_FUSED")) == 0) return false;
-    // a workgroup walks its 32 rows through every layer whatever the batch: it only pays once there
-    // are workgroups for most CUs; below that the per-layer GEMMs (tiles over rows AND columns) win
-    const int64_t min_rows = getenv("ABN_FUSED_MIN_ROWS") ? atoll(getenv("ABN_FUSED_MIN_ROWS")) : 6144;
+    // a workgroup walks its 32 rows through every layer in ~50 us whatever the batch; from a few workgroups
+    // up that beats the per-layer GEMMs (tools/rows_sweep.py, tools/fwd_rows_sweep.py: C2 train step 0.148 vs
+    // 0.180 ms at 512 rows, 0.234 vs 0.331 at 8192; forward alone 62 vs 94 us at 5000 rows)
+    const int64_t min_rows = getenv("ABN_FUSED_MIN_ROWS") ? atoll(getenv("ABN_FUSED_MIN_ROWS")) : 256;
     if (rows < min_rows || !planes_shape_ok(t)) return false;
     if (!aligned16(x1) || (x2 && !aligned16(x2)) || !aligned16(ws)) return false;
     for (int l = 0; l < t->n_layers; ++l)
