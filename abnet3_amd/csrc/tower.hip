@@ -964,12 +964,16 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             bw_attr_set[dev] = true;
         }
         const dim3 cgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
+        // (measurement only, bench.py: ABN_PLANES_BWD_ONLY=dgrad|wgrad issues one of the two launches, the other's
+        // output being in place from an earlier complete call)
+        const char* only = getenv("ABN_PLANES_BWD_ONLY");
+        const bool do_dgrad = !only || !strcmp(only, "dgrad"), do_wgrad = !only || !strcmp(only, "wgrad");
         if (np == 3) {
-            hipLaunchKernelGGL(tower_dgrad_planes_kernel<3>, cgrid, dim3(PL_NT), pl_lds_bytes(3), st, b);
-            hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
+            if (do_dgrad) hipLaunchKernelGGL(tower_dgrad_planes_kernel<3>, cgrid, dim3(PL_NT), pl_lds_bytes(3), st, b);
+            if (do_wgrad) hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
         } else {
-            hipLaunchKernelGGL(tower_dgrad_planes_kernel<1>, cgrid, dim3(PL_NT), pl_lds_bytes(1), st, b);
-            hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
+            if (do_dgrad) hipLaunchKernelGGL(tower_dgrad_planes_kernel<1>, cgrid, dim3(PL_NT), pl_lds_bytes(1), st, b);
+            if (do_wgrad) hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
         }
         ABN_CHECK_LAUNCH("tower_backward (planes)");
         if (t->defer_reduce) return ABN_OK;      // abn_tower_reduce_step finishes the job

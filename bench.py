@@ -117,49 +117,73 @@ def _traffic(kernel):
 def planes_roofline(torch, net, reps=20):
     """precision bf16x3 / bf16 (csrc/tower_planes.h): the step is three launches of similar length -- the
     forward chain, the data-gradient chain, the weight gradients -- plus the fused reduction + optimizer.
-    The DOMINANT one by time is tower_fwd_planes_kernel (the whole forward of both towers: 2 x 4096
-    rows through 40-500-500-500-100).  It is timed live as abn_tower_forward issues it, i.e. together
-    with pack_planes_kernel (~5 us: the weights as operand fragments, once per step), `reps` launch
-    pairs captured into one hipGraph and bracketed by HIP events on the launch stream.  Algorithmic
-    FLOPs per launch: 2 * 8192 * (40*500 + 2*500*500 + 500*100).  Roof: the dense bf16 MFMA peak
-    divided by the bf16 products each algorithmic product costs (six for bf16x3: 2500 / 6 = 416.7
-    TFLOP/s algorithmic; one for bf16).  Both peaks assume the 2.4 GHz boost clock; under this
-    workload the chip holds ~1.6-1.8 GHz (s_memtime against wall clock, tools/probes/mfma_peak.hip)."""
+    The DOMINANT one by time is wgrad_planes_kernel: every layer's dW = dZ^T [A | 1] over the 2 x 4096
+    rows, split over the rows into slabs, one launch.  Each of the three is timed live, alone, `reps`
+    launches captured into one hipGraph and bracketed by HIP events on the launch stream (the two
+    backward kernels through abn_tower_backward with ABN_PLANES_BWD_ONLY, a measurement switch that
+    issues one of its two launches; the forward together with the ~5 us pack_planes_kernel that
+    precedes it).  Algorithmic FLOPs of the weight gradients: 2 * 8192 * sum_l N_l (K_l + 1).
+    Roof: the dense bf16 MFMA peak divided by the bf16 products each algorithmic product costs (six
+    for bf16x3: 2500 / 6 = 416.7 TFLOP/s algorithmic; one for bf16).  Both peaks assume the 2.4 GHz
+    boost clock; under this workload the chip holds ~1.6-1.8 GHz (s_memtime against wall clock,
+    tools/probes/mfma_peak.hip), and the kernel's other bound is its operand stream:
+    `hbm` gives the measured TCC traffic per launch over the launch time against ~6 TB/s attainable."""
     prec = net.precision
     peak = {'bf16x3': X3_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS}[prec]
     fwd_name, wgrad_name = kernel_names(prec)
+    dims = [40, 500, 500, 500, 100]
     rows = 2 * BATCH
     x12 = torch.randn(rows, 40, device='cuda')
     net.train()
-
-    def fwd():
-        with torch.no_grad():
-            net.forward_pair_rows(x12)
-    t = _time_launches(torch, fwd, reps)
-    fl = 2.0 * rows * (40 * 500 + 2 * 500 * 500 + 500 * 100)
-    achieved = fl / t / 1e12
-    out = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-           'frac': round(achieved / peak, 4), 'traffic': _traffic('tower_fwd_planes_kernel'), 'arithmetic': prec,
-           'peak_note': {'bf16x3': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per algorithmic product',
-                         'bf16': 'dense bf16 MFMA'}[prec],
-           'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-           'kernel': fwd_name + '  (the whole forward of both towers; timed with the pack_planes_kernel launch that '
-                     'precedes it in abn_tower_forward, launched back to back from one hipGraph)',
-           'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl}
-    # the backward of the same step: the data-gradient chain and the weight gradients (slabs left
-    # unreduced: the reduction rides in the optimizer's launch), timed as one sequence
     emb, state = net.direct_forward(x12[:BATCH].contiguous(), x12[BATCH:].contiguous())
     d_out = torch.randn_like(emb) * 1e-3
 
     def bwd():
         net.direct_backward(state, d_out, d_out_is_dz=True, defer_reduce=True)
-    t = _time_launches(torch, bwd, reps)
+    bwd()                                           # a complete backward: both kernels' outputs are in place
+    times = {}
+    for which in ('wgrad', 'dgrad', None):
+        if which:
+            os.environ['ABN_PLANES_BWD_ONLY'] = which
+        else:
+            os.environ.pop('ABN_PLANES_BWD_ONLY', None)
+        times[which or 'both'] = _time_launches(torch, bwd, reps)
     net.take_pending_reduce()
-    fl = 2.0 * rows * (2 * (40 * 500 + 2 * 500 * 500 + 500 * 100) - 40 * 500)      # wgrad everywhere, no dgrad into the input
-    out['backward'] = {'kernels': 'tower_dgrad_planes_kernel + ' + wgrad_name,
-                       'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / peak, 4),
-                       'avg_sequence_us': round(t * 1e6, 2), 'flop_per_sequence': fl,
-                       'traffic': {'dgrad': _traffic('tower_dgrad_planes_kernel'), 'wgrad': _traffic('wgrad_planes_kernel')}}
+    fl_w = 2.0 * rows * sum(dims[l + 1] * (dims[l] + 1) for l in range(4))
+    fl_d = 2.0 * rows * sum(dims[l + 1] * dims[l] for l in range(1, 4))
+    t = times['wgrad']
+    achieved = fl_w / t / 1e12
+    traffic = _traffic('wgrad_planes_kernel')
+    out = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+           'frac': round(achieved / peak, 4), 'traffic': traffic, 'arithmetic': prec,
+           'peak_note': {'bf16x3': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per algorithmic product',
+                         'bf16': 'dense bf16 MFMA'}[prec],
+           'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+           'kernel': wgrad_name + '  (all four layers\' weight and bias gradients, one launch, alone, back to back '
+                     'from one hipGraph)',
+           'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl_w}
+    if traffic:
+        gbs = traffic / t / 1e9
+        out['hbm'] = {'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
+                      'note': 'measured TCC traffic per launch (profiles/r02_pmc_traffic.json) / launch time: the '
+                              'kernel streams both operands of every layer from HBM / Infinity Cache'}
+    t = times['dgrad']
+    out['dgrad_chain'] = {'kernel': 'tower_dgrad_planes_kernel (dZ through the three upper layers, one launch)',
+                          'achieved': round(fl_d / t / 1e12, 2), 'frac': round(fl_d / t / 1e12 / peak, 4),
+                          'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl_d,
+                          'traffic': _traffic('tower_dgrad_planes_kernel')}
+    out['backward_sequence_us'] = round(times['both'] * 1e6, 2)
+
+    def fwd():
+        with torch.no_grad():
+            net.forward_pair_rows(x12)
+    t = _time_launches(torch, fwd, reps)
+    fl = 2.0 * rows * sum(dims[l + 1] * dims[l] for l in range(4))
+    out['forward'] = {'kernel': fwd_name + '  (the whole forward of both towers; timed with the pack_planes_kernel '
+                                'launch that precedes it in abn_tower_forward)',
+                      'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / peak, 4),
+                      'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl,
+                      'traffic': _traffic('tower_fwd_planes_kernel')}
     return out
 
 
