@@ -104,11 +104,13 @@ typedef struct abn_tower_desc {
     int32_t reserved_;
 } abn_tower_desc;
 
-/* Workspace of one forward call (saved activations for backward), in floats,
- * and the offset inside it of the [rows, dims[n_layers]] output embedding. */
+/* Workspace of one forward call (what the backward needs: the saved activations, for the
+ * default arithmetic also the weights as MFMA operand fragments; its layout is the library's
+ * own and depends on the descriptor), in floats, and the offset inside it of the
+ * [rows, dims[n_layers]] output embedding -- the only public position in it. */
 int64_t abn_tower_ws_floats(const abn_tower_desc* t, int64_t rows, int64_t n_calls);
 int64_t abn_tower_out_offset(const abn_tower_desc* t, int64_t rows, int64_t n_calls);
-/* Scratch of one backward call (split-K slabs + dZ ping-pong), in floats. */
+/* Scratch of one backward call (split-K slabs + the dZ of every layer), in floats. */
 int64_t abn_tower_bwd_scratch_floats(const abn_tower_desc* t, int64_t rows);
 
 /* SiameseNetwork.forward_once / forward, abnet3/model.py:179-196.
@@ -126,7 +128,8 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
 /* Autograd of the above (what loss.backward() runs, abnet3/trainer.py:239).
  * d_out: [rows, dims[n_layers]] gradient w.r.t. the output embeddings.
  * Writes dW/db (+dbn_w/dbn_b) summed over all rows (both towers), and dx
- * ([rows, dims[0]], may be NULL: the reference never needs it). */
+ * ([rows, dims[0]], may be NULL: the reference never needs it).  t, x1, x2, rows, n_calls and
+ * ws must be the forward call's (ws unchanged since). */
 int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2,
                        const float* d_out, int64_t rows, int64_t n_calls,
                        const float* ws, float* scratch, int64_t scratch_floats,
