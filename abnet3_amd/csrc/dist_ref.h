@@ -183,6 +183,99 @@ __device__ __forceinline__ float angular_distance_ref(float dot, float nx, float
     return v;
 }
 
+// ---------------------------------------------------------------------------------------
+// The same cell function on TWO cells at a time (the plain path only).  The distance epilogue is
+// ~95 VALU instructions per cell and the DTW kernel is bound by them; ~70 of those are fp32
+// multiplies / adds / fmas, which gfx950 issues two per lane as v_pk_mul_f32 / v_pk_add_f32 /
+// v_pk_fma_f32 -- element by element the same IEEE operations in the same order, so every
+// result is bit-identical to the scalar functions above (tests/test_gpu_dtw_features.py compare
+// both against the reference's own output).
+// ---------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ u32x2 bits2(f32x2 v) { return __builtin_bit_cast(u32x2, v); }
+__device__ __forceinline__ f32x2 float2_of(u32x2 v) { return __builtin_bit_cast(f32x2, v); }
+
+__device__ __forceinline__ f32x2 div_normal2(f32x2 a, f32x2 b)
+{
+    f32x2 y = f32x2{__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+    const f32x2 e = fma2(-b, y, splat2(1.0f));
+    y = fma2(e, y, y);
+    f32x2 q = a * y;
+    f32x2 r = fma2(-b, q, a);
+    q = fma2(r, y, q);
+    r = fma2(-b, q, a);
+    return fma2(r, y, q);
+}
+
+__device__ __forceinline__ f32x2 sqrt_normal2(f32x2 x)
+{
+    const f32x2 s = f32x2{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+    const f32x2 sdn = float2_of(bits2(s) - 1u), sup = float2_of(bits2(s) + 1u);
+    const f32x2 rdn = fma2(-sdn, s, x), rup = fma2(-sup, s, x);
+    f32x2 t = (splat2(0.0f) >= rdn) ? sdn : s;
+    t = (splat2(0.0f) < rup) ? sup : t;
+    return t;
+}
+
+__device__ __forceinline__ f32x2 div_pi2(f32x2 a)
+{
+    const f32x2 pi_f = splat2(bits_f32(0x40490fdbu)), inv_pi = splat2(bits_f32(0x3ea2f983u));
+    const f32x2 q = a * inv_pi;
+    const f32x2 r = fma2(-q, pi_f, a);
+    return fma2(r, inv_pi, q);
+}
+
+__device__ __forceinline__ f32x2 acosf_ref2(f32x2 x)
+{
+    const f32x2 one = splat2(1.0f);
+    const f32x2 pi = splat2(bits_f32(0x40490fdau)), pio2_hi = splat2(bits_f32(0x3fc90fdau)), pio2_lo = splat2(bits_f32(0x33a22168u));
+    const f32x2 pS0 = splat2(bits_f32(0x3e2aaaabu)), pS1 = splat2(-bits_f32(0x3ea6b090u)), pS2 = splat2(bits_f32(0x3e4e0aa8u)),
+                pS3 = splat2(-bits_f32(0x3d241146u)), pS4 = splat2(bits_f32(0x3a4f7f04u)), pS5 = splat2(bits_f32(0x3811ef08u));
+    const f32x2 qS1 = splat2(-bits_f32(0x4019d139u)), qS2 = splat2(bits_f32(0x4001572du)), qS3 = splat2(-bits_f32(0x3f303361u)),
+                qS4 = splat2(bits_f32(0x3d9dc62eu));
+    const u32x2 hx = bits2(x), ix = hx & 0x7fffffffu;
+    const f32x2 ax = float2_of(ix);
+    const i32x2 small = ix < 0x3f000000u;
+    const f32x2 z = small ? x * x : (one - ax) * splat2(0.5f);
+    const f32x2 p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const f32x2 q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const f32x2 r = div_normal2(p, q);
+    f32x2 res = pio2_hi - (x - (pio2_lo - x * r));
+    if (__any(!(small.x && small.y))) {
+        const f32x2 s = sqrt_normal2(z);
+        const f32x2 wn = r * s - pio2_lo;
+        const f32x2 neg = pi - splat2(2.0f) * (s + wn);
+        f32x2 big = neg;
+        const i32x2 posb = (~small) & (__builtin_bit_cast(i32x2, hx) >= 0);
+        if (__any(posb.x || posb.y)) {
+            const f32x2 df = float2_of(bits2(s) & 0xfffff000u);
+            const f32x2 c = div_normal2(z - df * df, s + df);
+            const f32x2 wp = r * s + c;
+            big = posb ? splat2(2.0f) * (df + wp) : neg;
+        }
+        res = small ? res : big;
+    }
+    const i32x2 tiny = ix <= 0x32800000u, ge1 = ix >= 0x3f800000u;
+    if (__any(tiny.x || tiny.y || ge1.x || ge1.y)) {
+        res = tiny ? pio2_hi + pio2_lo : res;
+        const f32x2 at1 = (__builtin_bit_cast(i32x2, hx) > 0) ? splat2(0.0f) : pi + splat2(2.0f) * pio2_lo;
+        res = (ix == 0x3f800000u) ? at1 : res;
+        res = (ix > 0x3f800000u) ? splat2(__builtin_nanf("")) : res;
+    }
+    return res;
+}
+
+// two cells of one row of x (norm nx) against two rows of y: the PLAIN path of angular_distance_ref
+__device__ __forceinline__ f32x2 angular_distance_plain2(f32x2 dot, float nx, f32x2 ny)
+{
+    return div_pi2(acosf_ref2(div_normal2(dot, splat2(nx) * ny)));
+}
+
 // is the norm inside the range angular_distance_ref<true> is valid for?
 __device__ __forceinline__ bool norm_is_plain(float v) { return v >= 9.094947e-13f && v <= 1.0995116e12f; }
 

@@ -515,11 +515,21 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         __builtin_amdgcn_sched_barrier(0);
                         const float4 ny4 = *reinterpret_cast<const float4*>(&ny_s[q][8 * g + 4 * half]);
                         const float nyv[4] = {ny4.x, ny4.y, ny4.z, ny4.w};
+                        if constexpr (decltype(pl)::value) {          // two cells per instruction (dist_ref.h)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float dv = angular_distance_ref<decltype(pl)::value>(acc[4 * g + e], nxl, nyv[e]);
-                            ob |= __float_as_uint(dv);          // padded rows / columns repeat real ones: no masking needed
-                            dreg[q][4 * g + e] = dv;
+                            for (int e = 0; e < 4; e += 2) {
+                                const f32x2 dv = angular_distance_plain2(f32x2{acc[4 * g + e], acc[4 * g + e + 1]}, nxl, f32x2{nyv[e], nyv[e + 1]});
+                                ob |= __float_as_uint(dv.x) | __float_as_uint(dv.y);      // padded rows / columns repeat real ones: no masking needed
+                                dreg[q][4 * g + e] = dv.x;
+                                dreg[q][4 * g + e + 1] = dv.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float dv = angular_distance_ref<false>(acc[4 * g + e], nxl, nyv[e]);
+                                ob |= __float_as_uint(dv);
+                                dreg[q][4 * g + e] = dv;
+                            }
                         }
                     }
                 };

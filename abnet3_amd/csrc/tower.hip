@@ -660,6 +660,110 @@ static ReduceTable make_reduce_table(const abn_tower_desc* t, const BwdLayout& B
     return rt;
 }
 
+// The pair loss riding in the chain kernel's first phase (abn_tower_backward_loss)
+struct LossArgs {
+    const void* y;
+    int y_dtype, kind, avg;
+    float margin;
+    float* loss_out;
+    void* ws;              // 8 bytes of ticket counter (zero before the first call, left zero) + one double per workgroup
+};
+
+static int planes_backward(const abn_tower_desc* t, const float* d_out, const LossArgs* loss, int64_t rows, const Layout& L,
+                           const BwdLayout& B, const float* ws, float* scratch, float* dx, hipStream_t st)
+{
+    const int nl = t->n_layers;
+    const int np = planes_of(t->precision);
+    PlanesBwdP b = {};
+    b.n_layers = nl;
+    b.rows = (int)rows;
+    b.d_out = d_out;
+    b.d_out_is_dz = t->d_out_is_dz;
+    b.tp_steps = pl_row_steps(rows);
+    ABN_REQUIRE((loss || aligned16(d_out)) && aligned16(scratch) && (!dx || aligned16(dx)),
+                "tower_backward: d_out / scratch / dx must be 16-byte aligned");
+    b.loss_kind = -1;
+    b.B = (int)rows;                             // (no tower boundary inside the rows unless the loss rides along)
+    if (loss) {
+        b.loss_kind = loss->kind;
+        b.y = loss->y; b.y_dtype = loss->y_dtype;
+        b.B = (int)(rows / 2);
+        b.margin = (double)loss->margin;
+        b.scale = loss->avg ? 1.0 / (double)(rows / 2) : 1.0;
+        b.loss_counter = reinterpret_cast<unsigned*>(loss->ws);
+        b.loss_partial = reinterpret_cast<double*>(reinterpret_cast<char*>(loss->ws) + 8);
+        b.loss_out = loss->loss_out;
+    }
+    b.a_top = ws + L.a[nl - 1];
+    b.dx = dx;
+    for (int l = 0; l <= nl; ++l) b.dims[l] = (int)t->dims[l];
+    for (int l = 0; l < nl; ++l) {
+        b.act[l] = (l == nl - 1) ? t->last_act : t->act;
+        b.tp[l] = reinterpret_cast<const char*>(ws + L.tp[l]);
+        b.mask[l] = t->drop_mask[l];
+        b.wpt[l] = reinterpret_cast<const char*>(ws + L.wpt[l]);
+        b.dzp[l] = reinterpret_cast<char*>(scratch + B.dzp[l]);
+    }
+    WgradP w = {};
+    w.slabs = scratch + B.slabs;
+    w.slab_stride = B.slab_stride;
+    w.tp_steps = b.tp_steps;
+    // launch order: most row steps per workgroup first
+    int order[ABN_MAX_LAYERS];
+    for (int l = 0; l < nl; ++l) order[l] = l;
+    for (int i = 1; i < nl; ++i)
+        for (int j = i; j > 0 && B.splits[order[j]] < B.splits[order[j - 1]]; --j) { int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
+    int n_wg = 0;
+    for (int i = 0; i < nl; ++i) {
+        const int l = order[i];
+        WgradLayer& W = w.L[w.n_layers++];
+        W.dzp = b.dzp[l];
+        W.ap = reinterpret_cast<const char*>(ws + L.tp[l]);
+        W.N = (int)t->dims[l + 1]; W.K = (int)t->dims[l];
+        W.nblk = pl_blocks(W.N); W.kblk = pl_blocks(W.K + 1);
+        int bn, bk;
+        wgrad_shape(W.nblk, W.kblk, &W.shape, &bn, &bk);
+        W.tiles_n = (W.nblk + bn - 1) / bn; W.tiles_k = (W.kblk + bk - 1) / bk;
+        W.splits = B.splits[l];
+        W.first_wg = n_wg;
+        W.slab_off = B.off[l];
+        n_wg += W.tiles_n * W.tiles_k * W.splits;
+    }
+    static bool bw_attr_set[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = (dev >= 0 && dev < 16) ? dev : 0;
+    if (!bw_attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_dgrad_planes_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(1));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_dgrad_planes_kernel<3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(3));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<1>());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<3>());
+        bw_attr_set[dev] = true;
+    }
+    const dim3 cgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
+    // (measurement only, bench.py: ABN_PLANES_BWD_ONLY=dgrad|wgrad issues one of the two launches, the other's
+    // output being in place from an earlier complete call)
+    const char* only = getenv("ABN_PLANES_BWD_ONLY");
+    const bool do_dgrad = !only || !strcmp(only, "dgrad"), do_wgrad = !only || !strcmp(only, "wgrad");
+    if (np == 3) {
+        if (do_dgrad) hipLaunchKernelGGL(tower_dgrad_planes_kernel<3>, cgrid, dim3(PL_NT), pl_lds_bytes(3), st, b);
+        if (do_wgrad) hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
+    } else {
+        if (do_dgrad) hipLaunchKernelGGL(tower_dgrad_planes_kernel<1>, cgrid, dim3(PL_NT), pl_lds_bytes(1), st, b);
+        if (do_wgrad) hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
+    }
+    ABN_CHECK_LAUNCH("tower_backward (planes)");
+    if (t->defer_reduce) return ABN_OK;      // abn_tower_reduce_step finishes the job
+    const ReduceTable rt = make_reduce_table(t, B);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, scratch + B.slabs, rt);
+    ABN_CHECK_LAUNCH("slab_reduce");
+    return ABN_OK;
+}
+
 }  // namespace abn
 
 using namespace abn;
@@ -903,85 +1007,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     // The forward that filled `ws` went through the planes kernels (same predicate): its workspace
     // holds W^T and the weight-gradient operands as operand fragments.  Two launches: the data
     // gradient chain (one workgroup per 32 rows, all layers), then every layer's weight gradient.
-    if (planes_path(t, rows, x1, x2, ws)) {
-        const int np = planes_of(t->precision);
-        PlanesBwdP b = {};
-        b.n_layers = nl;
-        b.rows = (int)rows;
-        b.d_out = d_out;
-        b.d_out_is_dz = t->d_out_is_dz;
-        b.tp_steps = pl_row_steps(rows);
-        ABN_REQUIRE(aligned16(d_out) && aligned16(scratch) && (!dx || aligned16(dx)),
-                    "tower_backward: d_out / scratch / dx must be 16-byte aligned");
-        b.a_top = ws + L.a[nl - 1];
-        b.dx = dx;
-        for (int l = 0; l <= nl; ++l) b.dims[l] = (int)t->dims[l];
-        for (int l = 0; l < nl; ++l) {
-            b.act[l] = (l == nl - 1) ? t->last_act : t->act;
-            b.tp[l] = reinterpret_cast<const char*>(ws + L.tp[l]);
-            b.mask[l] = t->drop_mask[l];
-            b.wpt[l] = reinterpret_cast<const char*>(ws + L.wpt[l]);
-            b.dzp[l] = reinterpret_cast<char*>(scratch + B.dzp[l]);
-        }
-        WgradP w = {};
-        w.slabs = scratch + B.slabs;
-        w.slab_stride = B.slab_stride;
-        w.tp_steps = b.tp_steps;
-        // launch order: most row steps per workgroup first
-        int order[ABN_MAX_LAYERS];
-        for (int l = 0; l < nl; ++l) order[l] = l;
-        for (int i = 1; i < nl; ++i)
-            for (int j = i; j > 0 && B.splits[order[j]] < B.splits[order[j - 1]]; --j) { int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
-        int n_wg = 0;
-        for (int i = 0; i < nl; ++i) {
-            const int l = order[i];
-            WgradLayer& W = w.L[w.n_layers++];
-            W.dzp = b.dzp[l];
-            W.ap = reinterpret_cast<const char*>(ws + L.tp[l]);
-            W.N = (int)t->dims[l + 1]; W.K = (int)t->dims[l];
-            W.nblk = pl_blocks(W.N); W.kblk = pl_blocks(W.K + 1);
-            int bn, bk;
-            wgrad_shape(W.nblk, W.kblk, &W.shape, &bn, &bk);
-            W.tiles_n = (W.nblk + bn - 1) / bn; W.tiles_k = (W.kblk + bk - 1) / bk;
-            W.splits = B.splits[l];
-            W.first_wg = n_wg;
-            W.slab_off = B.off[l];
-            n_wg += W.tiles_n * W.tiles_k * W.splits;
-        }
-        static bool bw_attr_set[16] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        dev = (dev >= 0 && dev < 16) ? dev : 0;
-        if (!bw_attr_set[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_dgrad_planes_kernel<1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(1));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_dgrad_planes_kernel<3>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(3));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<1>());
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<3>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<3>());
-            bw_attr_set[dev] = true;
-        }
-        const dim3 cgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
-        // (measurement only, bench.py: ABN_PLANES_BWD_ONLY=dgrad|wgrad issues one of the two launches, the other's
-        // output being in place from an earlier complete call)
-        const char* only = getenv("ABN_PLANES_BWD_ONLY");
-        const bool do_dgrad = !only || !strcmp(only, "dgrad"), do_wgrad = !only || !strcmp(only, "wgrad");
-        if (np == 3) {
-            if (do_dgrad) hipLaunchKernelGGL(tower_dgrad_planes_kernel<3>, cgrid, dim3(PL_NT), pl_lds_bytes(3), st, b);
-            if (do_wgrad) hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
-        } else {
-            if (do_dgrad) hipLaunchKernelGGL(tower_dgrad_planes_kernel<1>, cgrid, dim3(PL_NT), pl_lds_bytes(1), st, b);
-            if (do_wgrad) hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
-        }
-        ABN_CHECK_LAUNCH("tower_backward (planes)");
-        if (t->defer_reduce) return ABN_OK;      // abn_tower_reduce_step finishes the job
-        const ReduceTable rt = make_reduce_table(t, B);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, scratch + B.slabs, rt);
-        ABN_CHECK_LAUNCH("slab_reduce");
-        return ABN_OK;
-    }
+    if (planes_path(t, rows, x1, x2, ws)) return planes_backward(t, d_out, nullptr, rows, L, B, ws, scratch, dx, st);
 
     int cur = 0;
     const float* dz_in = nullptr;                // the output layer's dz when the caller supplied it
@@ -1077,6 +1103,31 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, slabs, rt);
     ABN_CHECK_LAUNCH("slab_reduce");
     return ABN_OK;
+}
+
+int64_t abn_tower_backward_loss_ws_bytes(int64_t rows) { return 8 + ((rows + PL_ROWS - 1) / PL_ROWS) * (int64_t)sizeof(double); }
+
+int abn_tower_backward_loss(const abn_tower_desc* t, const float* x1, const float* x2, const void* y, int y_dtype,
+                            int loss_kind, float margin, int avg, int64_t rows, const float* ws, float* scratch,
+                            int64_t scratch_floats, float* loss_out, void* loss_ws, void* stream)
+{
+    int rc = check_desc(t, rows, 2);
+    if (rc != ABN_OK) return rc;
+    ABN_REQUIRE(x1 && y && ws && scratch && loss_out && loss_ws, "tower_backward_loss: null pointer");
+    ABN_REQUIRE(loss_kind == ABN_LOSS_COSCOS2 || loss_kind == ABN_LOSS_COSMARGIN, "tower_backward_loss: unknown loss kind %d", loss_kind);
+    ABN_REQUIRE(y_dtype >= ABN_Y_I8 && y_dtype <= ABN_Y_F64, "tower_backward_loss: unknown label dtype %d", y_dtype);
+    ABN_REQUIRE(loss_kind != ABN_LOSS_COSMARGIN || (margin >= 0.0f && margin <= 1.0f), "tower_backward_loss: margin outside [0,1]");
+    for (int l = 0; l < t->n_layers; ++l) ABN_REQUIRE(t->dW[l] && t->db[l], "tower_backward_loss: layer %d has null gradient buffers", l);
+    if (rows == 0 || !planes_path(t, rows, x1, x2, ws)) {
+        set_error("tower_backward_loss: only for towers the operand-plane kernels take (bf16x3 / bf16, no BatchNorm, "
+                  "widths <= 512 and multiples of 4, enough rows): use abn_pair_loss_dz + abn_tower_backward");
+        return ABN_E_UNSUPPORTED;
+    }
+    const Layout L = make_layout(t, rows, 2);
+    const BwdLayout B = make_bwd_layout(t, rows);
+    if (scratch_floats < B.total) { set_error("tower_backward_loss: scratch too small"); return ABN_E_WORKSPACE; }
+    LossArgs la = {y, y_dtype, loss_kind, avg, margin, loss_out, loss_ws};
+    return planes_backward(t, nullptr, &la, rows, L, B, ws, scratch, nullptr, (hipStream_t)stream);
 }
 
 int abn_tower_reduce_step(const abn_tower_desc* t, int64_t rows, const float* scratch, int64_t scratch_floats, int kind,

@@ -554,6 +554,17 @@ struct PlanesBwdP {
     const char* wpt[ABN_MAX_LAYERS];      // packed W_l^T images, l >= 1
     char* dzp[ABN_MAX_LAYERS];            // out: transposed planes of dZ_l (dims[l+1] features)
     int64_t tp_steps;
+    // The pair loss inside the chain (abn_tower_backward_loss; loss_kind < 0: d_out is given): rows are
+    // [tower 1: pairs 0 .. B-1 | tower 2: pairs 0 .. B-1], the embeddings are a_top, and the first phase
+    // computes what abn_pair_loss_dz would have written to d_out -- same arithmetic (loss.hip), fp64 per row.
+    int loss_kind;
+    int y_dtype;
+    const void* y;
+    int B;
+    double margin, scale;
+    double* loss_partial;                 // one per workgroup
+    unsigned* loss_counter;               // ticket (zero before, zero after)
+    float* loss_out;
 };
 
 // dZ_{l-1} from dZ_l (in img, pl_steps(dims[l+1]) steps): output features = the dims[l] inputs of layer l
@@ -674,11 +685,101 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
     bf16x8 idf[2];
     make_identity(idf, lane);
 
+    // the pair loss, when it rides along: per-row coefficients of d loss / d e = partner * inv - self * kself
+    double* const coef = reinterpret_cast<double*>(part);          // [32][2]  (the K-split buffer is idle here)
+    double* const term_s = coef + 64;                              // [32]
+    int* const is_last_s = reinterpret_cast<int*>(term_s + 32);
+    const bool with_loss = p.loss_kind >= 0;
+    if (with_loss) {
+        const int B = p.B;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int lr = 4 * wave + 2 * it + (lane >> 5), l = lane & 31;
+            const int g = row0 + lr;
+            double inv = 0.0, kself = 0.0, term = 0.0;
+            const bool ok = g < p.rows;
+            const int tower = ok && g >= B ? 1 : 0, pi_ = ok ? g - tower * B : 0;
+            const float* a = p.a_top + (int64_t)pi_ * NT;           // e1[pair], e2[pair]: the order loss.hip sums in
+            const float* b = p.a_top + (int64_t)(B + pi_) * NT;
+            double dot = 0.0, s11 = 0.0, s22 = 0.0;
+            for (int c = l; c < NT / 4; c += 32) {
+                const float4 u = reinterpret_cast<const float4*>(a)[c];
+                const float4 v = reinterpret_cast<const float4*>(b)[c];
+                dot += (double)u.x * v.x + (double)u.y * v.y + (double)u.z * v.z + (double)u.w * v.w;
+                s11 += (double)u.x * u.x + (double)u.y * u.y + (double)u.z * u.z + (double)u.w * u.w;
+                s22 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+            }
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) {
+                dot += __shfl_xor(dot, o, 64);
+                s11 += __shfl_xor(s11, o, 64);
+                s22 += __shfl_xor(s22, o, 64);
+            }
+            if (ok) {
+                constexpr double EPS = 1e-6;
+                const double n1 = sqrt(s11), n2 = sqrt(s22);
+                const double c1 = n1 > EPS ? n1 : EPS, c2 = n2 > EPS ? n2 : EPS;
+                const double cs = dot / (c1 * c2);
+                double v = 0.0;
+                switch (p.y_dtype) {
+                    case ABN_Y_I8: v = ((const int8_t*)p.y)[pi_]; break;
+                    case ABN_Y_I32: v = ((const int32_t*)p.y)[pi_]; break;
+                    case ABN_Y_I64: v = (double)((const int64_t*)p.y)[pi_]; break;
+                    case ABN_Y_F32: v = ((const float*)p.y)[pi_]; break;
+                    default: v = ((const double*)p.y)[pi_]; break;
+                }
+                const int code = v == 1.0 ? 1 : (v == -1.0 ? -1 : 0);
+                double dcos;
+                if (p.loss_kind == ABN_LOSS_COSCOS2) {
+                    if (code == 1) { term = (1.0 - cs) * 0.5; dcos = -0.5; }
+                    else if (code == -1) { term = cs * cs; dcos = 2.0 * cs; }
+                    else { term = cs; dcos = 1.0; }
+                } else {
+                    if (code == 1) { term = 1.0 - cs; dcos = -1.0; }
+                    else if (code == -1) { const double hh = cs - p.margin; term = hh > 0.0 ? hh : 0.0; dcos = hh >= 0.0 ? 1.0 : 0.0; }
+                    else { term = cs; dcos = 1.0; }
+                }
+                dcos *= p.scale;
+                inv = dcos / (c1 * c2);
+                const double k1 = n1 > 0.0 ? dcos * cs / (c1 * n1) : 0.0;
+                const double k2 = n2 > 0.0 ? dcos * cs / (c2 * n2) : 0.0;
+                kself = tower ? k2 : k1;
+                if (tower) term = 0.0;                               // a pair's term counts once
+            }
+            if (l == 0) { coef[2 * lr] = inv; coef[2 * lr + 1] = kself; term_s[lr] = term; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double sum = 0.0;
+            for (int i = 0; i < 32; ++i) sum += term_s[i];
+            // (write-through store drained before the ticket, partials read back past the L1: loss.hip)
+            __hip_atomic_store(&p.loss_partial[blockIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned ticket = __hip_atomic_fetch_add(p.loss_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *is_last_s = ticket == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (*is_last_s && wave == 0) {                            // the last workgroup to arrive: fixed-order sum of all partials
+            double sum = 0.0;
+            for (int i = lane; i < (int)gridDim.x; i += 64) sum += __hip_atomic_load(&p.loss_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            if (lane == 0) {
+                *p.loss_out = (float)(sum * (p.scale));
+                __hip_atomic_store(p.loss_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+
     // dZ of the last layer -> operand fragments and transposed planes
     const int steps_t = pl_steps(NT), blocks_t = steps_t / 2;
     const int gr = row0 + r;
     const bool row_ok = gr < p.rows;
     const float* __restrict__ mask = p.mask[top];
+    const int my_tower = gr >= p.B ? 1 : 0;
+    const float* const self_row = p.a_top + (int64_t)(row_ok ? gr : 0) * NT;
+    const float* const partner_row = p.a_top + (int64_t)(row_ok && with_loss ? (my_tower ? gr - p.B : gr + p.B) : 0) * NT;
+    const double my_inv = with_loss ? coef[2 * r] : 0.0, my_k = with_loss ? coef[2 * r + 1] : 0.0;
     for (int kb = wave; kb < blocks_t; kb += PL_WAVES) {
         Frag<NP> f[2];
 #pragma unroll
@@ -689,15 +790,31 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
             for (int u = 0; u < 2; ++u) {
                 const int c = 16 * s + 4 * h + 8 * u;
                 if (row_ok && c < NT) {
-                    v[u] = *reinterpret_cast<const f32x4*>(p.d_out + (int64_t)gr * NT + c);
-                    if (!p.d_out_is_dz) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(p.a_top + (int64_t)gr * NT + c);
+                    if (with_loss) {
+                        const f32x4 es = *reinterpret_cast<const f32x4*>(self_row + c);
+                        const f32x4 ep = *reinterpret_cast<const f32x4*>(partner_row + c);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[u][e] *= act_grad(a[e], p.act[top]);
+                        for (int e = 0; e < 4; ++e) {
+                            float o = (float)(ep[e] * my_inv - es[e] * my_k);
+                            if (p.act[top] != ACT_NONE) o *= act_grad(es[e], p.act[top]);
+                            v[u][e] = o;
+                        }
                         if (mask) {
                             const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (int64_t)gr * NT + c);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[u][e] *= m[e];
+                        }
+                    } else {
+                        v[u] = *reinterpret_cast<const f32x4*>(p.d_out + (int64_t)gr * NT + c);
+                        if (!p.d_out_is_dz) {
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(p.a_top + (int64_t)gr * NT + c);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[u][e] *= act_grad(a[e], p.act[top]);
+                            if (mask) {
+                                const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (int64_t)gr * NT + c);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[u][e] *= m[e];
+                            }
                         }
                     }
                 }

@@ -681,6 +681,45 @@ class SiameseNetwork(_HipNetwork):
         for p, g in zip(seg.params, grads):
             p.grad = g
 
+    def direct_backward_loss(self, state, y, loss_kind, margin, avg, defer_reduce=False):
+        """loss(emb1, emb2, y) and its backward in the backward's own launches (abn_tower_backward_loss:
+        the data-gradient chain computes the pair loss and d loss / d z of the output layer in its first
+        phase).  Returns the 0-dim loss, or None when the library does not take this tower that way
+        (BatchNorm, exact-fp32 arithmetic, odd widths): the caller then uses value_and_dz + direct_backward."""
+        seg, sv, grad_pass = state
+        rows = sv.rows
+        if (seg.batch_norm or sv.n_calls != 2 or os.environ.get('ABN_LOSS_IN_BACKWARD') == '0'      # (the variable: A/B runs)
+                or self._fused_loss_refused == (rows, self.precision)):
+            return None
+        from .loss import _scratch
+        lib = _lib.load()
+        y = y.contiguous()
+        _lib.require_device(y)
+        if y.dtype not in _lib.Y_DTYPE or y.numel() * 2 != rows:
+            return None
+        grad_buf, grads = grad_pass.views(seg)
+        desc = seg.descriptor(with_grads=True, grad_buf=grad_buf, masks=sv.masks, d_out_is_dz=True, defer_reduce=defer_reduce)
+        scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
+        scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32, device=y.device)
+        loss = torch.empty((), dtype=torch.float32, device=y.device)
+        lws = _scratch(lib.abn_tower_backward_loss_ws_bytes(rows), y.device)
+        rc = lib.abn_tower_backward_loss(
+            _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(y), _lib.Y_DTYPE[y.dtype], _lib.LOSS[loss_kind],
+            float(margin), int(bool(avg)), rows, _lib.ptr(sv.ws), _lib.ptr(scratch), scratch_floats, _lib.ptr(loss),
+            _lib.ptr(lws), _lib.stream())
+        if rc == _lib.E_UNSUPPORTED:
+            self._fused_loss_refused = (rows, self.precision)
+            grad_pass.buf = None                 # nothing was written: the separate calls start this pass afresh
+            grad_pass.used.discard(id(seg))
+            return None
+        _lib.check(rc, 'abn_tower_backward_loss')
+        self._pending_reduce = (desc, rows, scratch, scratch_floats, grad_buf) if defer_reduce else None
+        for p, g in zip(seg.params, grads):
+            p.grad = g
+        return loss
+
+    _fused_loss_refused = None
+
     def take_pending_reduce(self):
         """The unfinished reduction a direct_backward(defer_reduce=True) left (or None); clears it."""
         pending = getattr(self, '_pending_reduce', None)

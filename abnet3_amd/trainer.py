@@ -328,7 +328,13 @@ class TrainerSiamese(TrainerBuilder):
             # single process: nothing happens between backward and step, so the split-K
             # reduction of the weight gradients rides in the optimizer's launch
             defer = self.world_size == 1 and self.network.can_defer_reduce(state)
-            if info is not None:      # loss gradient and the output layer's act' (+ dropout) in ONE launch
+            loss_value = None
+            if info is not None:      # the pair loss inside the backward's first launch, where the library offers it
+                loss_value = self.network.direct_backward_loss(
+                    state, y_batch, type(self.loss).__name__, getattr(self.loss, 'margin', 0.0), self.loss.avg, defer_reduce=defer)
+            if loss_value is not None:
+                pass
+            elif info is not None:    # loss gradient and the output layer's act' (+ dropout) in ONE launch
                 loss_value, dz = self.loss.value_and_dz(emb[:n], emb[n:], y_batch, info[0], info[1])
                 self.network.direct_backward(state, dz.view(2 * n, -1), d_out_is_dz=True, defer_reduce=defer)
             else:

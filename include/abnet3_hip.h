@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 8
+#define ABN_ABI_VERSION 9
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -134,6 +134,20 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
                        const float* d_out, int64_t rows, int64_t n_calls,
                        const float* ws, float* scratch, int64_t scratch_floats,
                        float* dx, void* stream);
+
+/* abn_pair_loss_dz + abn_tower_backward in the backward's own launches (abnet3/trainer.py:238-239:
+ * loss = self.loss(emb1, emb2, y); loss.backward()): rows = 2 B tower rows, [tower 1: pairs 0..B-1 |
+ * tower 2: pairs 0..B-1], whose embeddings the forward left in ws; the first phase of the data
+ * gradient chain computes the loss and d loss / d z of the output layer (same arithmetic, fp64 per
+ * pair) instead of reading d_out.  Only for towers the operand-plane kernels take (default
+ * arithmetic, no BatchNorm, widths <= 512 and multiples of 4): ABN_E_UNSUPPORTED otherwise, and the
+ * caller uses the two separate calls.  loss_ws: abn_tower_backward_loss_ws_bytes(rows) bytes whose
+ * first 8 (a ticket counter) are zero before the first call and are left zero. */
+int64_t abn_tower_backward_loss_ws_bytes(int64_t rows);
+int abn_tower_backward_loss(const abn_tower_desc* t, const float* x1, const float* x2, const void* y,
+                            int y_dtype, int loss_kind, float margin, int avg, int64_t rows,
+                            const float* ws, float* scratch, int64_t scratch_floats,
+                            float* loss_out, void* loss_ws, void* stream);
 
 /* Finishes an abn_tower_backward that ran with defer_reduce = 1 (same descriptor, rows and
  * scratch): sums the split-K slabs in their fixed order, writes the gradients to dW / db AND

@@ -209,3 +209,45 @@ def test_operand_images_decode_to_their_tensors(precision, NP):
         tol = 3e-6 if NP == 3 else 3e-2
         assert np.abs(d[:dims[l + 1], :R] - dz[l].T).max() <= tol * np.abs(dz[l]).max(), l
         assert np.abs(d[:, R:]).max(initial=0) == 0          # rows past the batch contribute nothing
+
+
+@pytest.mark.parametrize('lname,avg', [('coscos2', False), ('coscos2', True), ('cosmargin', True), ('cosmargin', False)])
+@pytest.mark.parametrize('B,ydtype,act,p_drop', [(4096, torch.int64, 'sigmoid', 0.0), (33, torch.float32, 'tanh', 0.0),
+                                               (70, torch.int8, 'sigmoid', 0.25), (48, torch.float64, 'relu', 0.0)])
+def test_pair_loss_inside_the_backward_equals_the_two_calls(lname, avg, B, ydtype, act, p_drop, monkeypatch):
+    """abn_tower_backward_loss (TrainerSiamese.train_step's path): the data-gradient chain computes the pair loss
+    and d loss / d z in its first phase.  Against abn_pair_loss_dz + abn_tower_backward on the same forward: loss
+    and every gradient agree to rounding (the per-pair arithmetic is the same, fp64)."""
+    import abnet3_amd.loss as L
+    kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=500 if B > 1000 else 72, output_dim=100 if B > 1000 else 36,
+              activation_layer=act, p_dropout=p_drop, batch_norm=False)
+    if act == 'relu':
+        kw['last_non_linearity'] = None
+    net, spec, p = build(kw, seed=B, precision='bf16x3')
+    loss = getattr(L, lname)(avg=avg) if lname == 'coscos2' else L.cosmargin(avg=avg, margin=0.3)
+    rng = np.random.default_rng(B)
+    x1, x2 = dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32))
+    y = dev(rng.choice([1, -1, 0] if B == 48 else [1, -1], B)).to(ydtype)
+    net.train()
+    if p_drop:
+        gen = torch.Generator(device='cuda').manual_seed(1)
+        widths = [kw['hidden_dim']] * 3 + [kw['output_dim']]
+        net._mask_override = [(torch.rand(2 * B, w, device='cuda', generator=gen) > p_drop).float() / (1 - p_drop) for w in widths]
+    res = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('ABN_LOSS_IN_BACKWARD', fused)
+        for q in net.parameters():
+            q.grad = None
+        emb, state = net.direct_forward(x1, x2)
+        info = net.direct_dz_info(state)
+        lv = net.direct_backward_loss(state, y, lname, 0.3, avg) if fused == '1' else None
+        assert (lv is not None) == (fused == '1')
+        if lv is None:
+            lv, dz = loss.value_and_dz(emb[:B], emb[B:], y, info[0], info[1])
+            net.direct_backward(state, dz.view(2 * B, -1), d_out_is_dz=True)
+        res.append((float(lv), [q.grad.clone() for q in net.parameters()]))
+    net._mask_override = None
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0]) + 1e-12
+    gmax = max(float(g.abs().max()) for g in res[1][1])
+    for (k, _), a, b in zip(net.named_parameters(), res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-2 * gmax), k
