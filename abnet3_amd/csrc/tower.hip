@@ -481,7 +481,7 @@ struct Layout {
     int64_t bn_part;                     // BN only: stage-1 partial sums (doubles), shared by the layers
     // precision 1 / 2 without BN (tower_planes.h): the weights and their transposes as MFMA operand
     // fragments, and the weight-gradient operands [x | 1], [a_l | 1] as transposed planes
-    int64_t wp[ABN_MAX_LAYERS], wpt[ABN_MAX_LAYERS], tp[ABN_MAX_LAYERS];
+    int64_t wpack, tp[ABN_MAX_LAYERS];   // wpack: the PackLayout image (unless the caller keeps a persistent one)
     int64_t total;
 };
 
@@ -492,6 +492,23 @@ static bool planes_shape_ok(const abn_tower_desc* t)
     for (int l = 0; l <= t->n_layers; ++l)
         if (t->dims[l] < 4 || t->dims[l] > PL_MAXW || t->dims[l] % 4 != 0) return false;
     return true;
+}
+
+// The weights as operand fragments: W_l and W_l^T for every layer, in a caller-owned persistent buffer
+// (abn_tower_desc.wpack) or inside the forward's workspace.  Byte offsets from the image's base.
+struct PackLayout { int64_t wp[ABN_MAX_LAYERS], wpt[ABN_MAX_LAYERS], bytes; };
+static PackLayout make_pack_layout(const abn_tower_desc* t)
+{
+    PackLayout P = {};
+    if (!planes_shape_ok(t)) return P;
+    const int np = planes_of(t->precision);
+    int64_t o = 0;
+    for (int l = 0; l < t->n_layers; ++l) {
+        P.wp[l] = o; o += pl_image_bytes(t->dims[l + 1], t->dims[l], np);
+        P.wpt[l] = o; o += pl_image_bytes(t->dims[l], t->dims[l + 1], np);
+    }
+    P.bytes = o;
+    return P;
 }
 
 static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
@@ -518,14 +535,12 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
         for (int l = 1; l <= t->n_layers; ++l) maxw = t->dims[l] > maxw ? t->dims[l] : maxw;
         L.bn_part = take(2 * n_calls * bn_chunks(rows / n_calls) * 2 * maxw);      // doubles = 2 floats each
     }
-    for (int l = 0; l < t->n_layers; ++l) L.wp[l] = L.wpt[l] = L.tp[l] = -1;
+    for (int l = 0; l < t->n_layers; ++l) L.tp[l] = -1;
+    L.wpack = -1;
     if (planes_shape_ok(t)) {
         const int np = planes_of(t->precision);
-        for (int l = 0; l < t->n_layers; ++l) {
-            L.wp[l] = take(pl_image_bytes(t->dims[l + 1], t->dims[l], np) / 4);
-            L.wpt[l] = take(pl_image_bytes(t->dims[l], t->dims[l + 1], np) / 4);
-            L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, rows, np) / 4);
-        }
+        L.wpack = take(make_pack_layout(t).bytes / 4);
+        for (int l = 0; l < t->n_layers; ++l) L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, rows, np) / 4);
     }
     L.total = o;
     return L;
@@ -696,12 +711,14 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
     }
     b.a_top = ws + L.a[nl - 1];
     b.dx = dx;
+    const PackLayout PL = make_pack_layout(t);
+    const char* const image = t->wpack ? reinterpret_cast<const char*>(t->wpack) : reinterpret_cast<const char*>(ws + L.wpack);
     for (int l = 0; l <= nl; ++l) b.dims[l] = (int)t->dims[l];
     for (int l = 0; l < nl; ++l) {
         b.act[l] = (l == nl - 1) ? t->last_act : t->act;
         b.tp[l] = reinterpret_cast<const char*>(ws + L.tp[l]);
         b.mask[l] = t->drop_mask[l];
-        b.wpt[l] = reinterpret_cast<const char*>(ws + L.wpt[l]);
+        b.wpt[l] = image + PL.wpt[l];
         b.dzp[l] = reinterpret_cast<char*>(scratch + B.dzp[l]);
     }
     WgradP w = {};
@@ -793,7 +810,23 @@ int64_t abn_debug_planes_offset(const abn_tower_desc* t, int64_t rows, int64_t n
     if (check_desc(t, rows, n_calls) != ABN_OK || l < 0 || l >= t->n_layers) return -1;
     if (which == 3) return make_bwd_layout(t, rows).dzp[l];
     const Layout L = make_layout(t, rows, n_calls);
-    return which == 0 ? L.wp[l] : which == 1 ? L.wpt[l] : which == 2 ? L.tp[l] : -1;
+    if (which == 2) return L.tp[l];
+    if (which != 0 && which != 1) return -1;
+    const PackLayout P = make_pack_layout(t);
+    // relative to abn_tower_desc.wpack when the caller keeps one, else to the workspace
+    return (t->wpack ? 0 : L.wpack) + (which == 0 ? P.wp[l] : P.wpt[l]) / 4;
+}
+
+int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws)
+{
+    if (check_desc(t, rows, 1) != ABN_OK) return -1;
+    return planes_path(t, rows, x1, x2, ws) ? 1 : 0;
+}
+
+int64_t abn_tower_wpack_floats(const abn_tower_desc* t)
+{
+    if (check_desc(t, 0, 1) != ABN_OK) return -1;
+    return make_pack_layout(t).bytes / 4;
 }
 
 int64_t abn_tower_bwd_scratch_floats(const abn_tower_desc* t, int64_t rows)
@@ -841,24 +874,28 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         f.rows_call = (int)rpc;
         f.x1 = x1; f.x2 = x2;
         f.x_copy = nullptr;                      // the planes backward reads the transposed images only
-        pk.base = reinterpret_cast<char*>(ws);
+        const PackLayout PL = make_pack_layout(t);
+        char* const image = t->wpack ? reinterpret_cast<char*>(t->wpack) : reinterpret_cast<char*>(ws + L.wpack);
+        const bool repack = !(t->wpack && t->wpack_valid);
+        ABN_REQUIRE(aligned16(image), "tower_forward: wpack must be 16-byte aligned");
+        pk.base = image;
         for (int l = 0; l <= t->n_layers; ++l) f.dims[l] = (int)t->dims[l];
         for (int l = 0; l < t->n_layers; ++l) {
             f.act[l] = (l == t->n_layers - 1) ? t->last_act : t->act;
             f.b[l] = t->b[l];
             f.mask[l] = train ? t->drop_mask[l] : nullptr;
             f.out[l] = l == t->n_layers - 1 ? ws + L.a[l] : nullptr;     // hidden activations live in tp[l + 1] only
-            f.wp[l] = reinterpret_cast<const char*>(ws + L.wp[l]);
+            f.wp[l] = image + PL.wp[l];
             PackJob& J = pk.job[pk.n_jobs++];
             J.W = t->W[l]; J.N = (int)t->dims[l + 1]; J.K = (int)t->dims[l]; J.transposed = 0;
             J.nblk = pl_blocks(J.N); J.nsteps = pl_steps(J.K);
-            J.tile0 = pk.n_tiles; J.dst = L.wp[l] * 4;
+            J.tile0 = pk.n_tiles; J.dst = PL.wp[l];
             pk.n_tiles += J.nblk * J.nsteps;
             {                                    // W_l^T for the backward's data-gradient chain (l = 0: d loss / d input)
                 PackJob& T = pk.job[pk.n_jobs++];
                 T.W = t->W[l]; T.N = J.N; T.K = J.K; T.transposed = 1;
                 T.nblk = pl_blocks(T.K); T.nsteps = pl_steps(T.N);
-                T.tile0 = pk.n_tiles; T.dst = L.wpt[l] * 4;
+                T.tile0 = pk.n_tiles; T.dst = PL.wpt[l];
                 pk.n_tiles += T.nblk * T.nsteps;
             }
             f.tp[l] = reinterpret_cast<char*>(ws + L.tp[l]);
@@ -881,10 +918,10 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         const dim3 pgrid((unsigned)((pk.n_tiles + 3) / 4));
         const dim3 fgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
         if (np == 3) {
-            hipLaunchKernelGGL(pack_planes_kernel<3>, pgrid, dim3(256), 0, st, pk);
+            if (repack) hipLaunchKernelGGL(pack_planes_kernel<3>, pgrid, dim3(256), 0, st, pk);
             hipLaunchKernelGGL(tower_fwd_planes_kernel<3>, fgrid, dim3(PL_NT), pl_lds_bytes(3), st, f);
         } else {
-            hipLaunchKernelGGL(pack_planes_kernel<1>, pgrid, dim3(256), 0, st, pk);
+            if (repack) hipLaunchKernelGGL(pack_planes_kernel<1>, pgrid, dim3(256), 0, st, pk);
             hipLaunchKernelGGL(tower_fwd_planes_kernel<1>, fgrid, dim3(PL_NT), pl_lds_bytes(1), st, f);
         }
         ABN_CHECK_LAUNCH("tower_fwd_planes");

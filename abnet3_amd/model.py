@@ -142,16 +142,46 @@ class _Segment(object):
                 d.bn_rv[l] = bn.running_var.data_ptr()
                 grad_slots += [('dbn_w', l, offs[gi]), ('dbn_b', l, offs[gi + 1])]
                 gi += 2
+        # a persistent image of the weights as operand fragments (abn_tower_desc.wpack): the forward skips its
+        # pack launch while the image is known to match the parameters (_weights_key)
+        self._wpack, self._wpack_key = None, None
+        if net._flat.is_cuda and os.environ.get('ABN_WPACK') != '0':      # (the variable: A/B runs)
+            n = _lib.load().abn_tower_wpack_floats(_lib.C.byref(d))
+            if n > 0:
+                self._wpack = torch.zeros(n, dtype=torch.float32, device=net._flat.device)
+                d.wpack = self._wpack.data_ptr()
         self._desc_cache = (key, d, grad_slots)
         return d
+
+    def _weights_key(self):
+        net = self.net
+        return (net._flat.data_ptr(), net._generation, net.precision, tuple(p._version for p in self.params))
+
+    def wpack_state(self):
+        """(valid flag for the next call's descriptor, key of the weights as they stand)"""
+        if getattr(self, '_wpack', None) is None:
+            return 0, None
+        if torch.cuda.is_current_stream_capturing():     # a captured call is replayed with other weights: always rebuild
+            self._wpack_key = None
+            return 0, None
+        key = self._weights_key()
+        return int(self._wpack_key == key), key
+
+    def wpack_matches(self, key):
+        """the image was (re)built from, or kept in step with, the weights `key` describes"""
+        if getattr(self, '_wpack', None) is not None:
+            self._wpack_key = key
 
     def descriptor(self, with_grads, grad_buf=None, masks=None, d_out_is_dz=False, defer_reduce=False):
         """abn_tower_desc for one call.  grad_buf: the flat gradient buffer of this
         backward pass (gradients land at the parameters' offsets in it)."""
         tmpl = self._template()
+        valid, self._key_at_descriptor = self.wpack_state()
         if not with_grads and masks is None:
+            tmpl.wpack_valid = valid
             return tmpl                        # read-only for the library
         d = _lib.TowerDesc.from_buffer_copy(tmpl)
+        d.wpack_valid = valid
         d.d_out_is_dz = int(d_out_is_dz)
         d.defer_reduce = int(defer_reduce)
         if masks is not None:
@@ -232,6 +262,10 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2):
     _lib.check(lib.abn_tower_forward(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2),
                                      rows, n_calls, int(train), _lib.ptr(ws),
                                      _lib.stream()), 'abn_tower_forward')
+    if desc.wpack and not desc.wpack_valid and seg._key_at_descriptor is not None:
+        # the operand-plane kernels rebuilt the persistent weight image (the per-layer path never touches it)
+        if lib.abn_tower_uses_planes(_lib.C.byref(desc), rows, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(ws)) == 1:
+            seg.wpack_matches(seg._key_at_descriptor)
     if train and seg.batch_norm:        # one launch for all the counters
         torch._foreach_add_([bn.num_batches_tracked for bn in seg.bn_modules()], n_calls)
     off = lib.abn_tower_out_offset(_lib.C.byref(desc), rows, n_calls)
@@ -267,7 +301,7 @@ def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False, def
         sv.n_calls, _lib.ptr(sv.ws), _lib.ptr(scratch), scratch_floats,
         _lib.ptr(dx), _lib.stream()), 'abn_tower_backward')
     if defer_reduce:
-        return grads, dx, (desc, rows, scratch, scratch_floats, grad_buf)
+        return grads, dx, (desc, rows, scratch, scratch_floats, grad_buf, seg)
     return grads, dx
 
 
@@ -713,12 +747,18 @@ class SiameseNetwork(_HipNetwork):
             grad_pass.used.discard(id(seg))
             return None
         _lib.check(rc, 'abn_tower_backward_loss')
-        self._pending_reduce = (desc, rows, scratch, scratch_floats, grad_buf) if defer_reduce else None
+        self._pending_reduce = (desc, rows, scratch, scratch_floats, grad_buf, seg) if defer_reduce else None
         for p, g in zip(seg.params, grads):
             p.grad = g
         return loss
 
     _fused_loss_refused = None
+
+    def weights_changed_behind_torch(self):
+        """Called by whoever rewrites the parameters without torch noticing (abn_optimizer_step, a replayed
+        hipGraph): the persistent weight images are stale."""
+        for seg in self._segment_list():
+            seg._wpack_key = None
 
     def take_pending_reduce(self):
         """The unfinished reduction a direct_backward(defer_reduce=True) left (or None); clears it."""

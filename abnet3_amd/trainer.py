@@ -96,14 +96,17 @@ class FlatOptimizer(object):
             hp0 = self.momentum
         if pending is not None:
             # the backward left its split-K slabs unreduced: reduction + update in one launch
-            desc, rows, scratch, scratch_floats, grad_buf = pending
+            desc, rows, scratch, scratch_floats, grad_buf, seg = pending
             if grad_buf.data_ptr() != grad.data_ptr():
                 raise RuntimeError('abnet3_amd: gradients were replaced between a deferred backward and step()')
             _lib.check(lib.abn_tower_reduce_step(
                 _lib.C.byref(desc), rows, _lib.ptr(scratch), scratch_floats, _lib.OPT[self.kind], _lib.ptr(flat),
                 _lib.ptr(grad), _lib.ptr(self._s1), _lib.ptr(self._s2), flat.numel(), self.lr, hp0, hp1, eps,
                 self.step_count, float(self.grad_scale), _lib.stream()), 'abn_tower_reduce_step')
+            self.network.weights_changed_behind_torch()
             return
+        if hasattr(self.network, 'weights_changed_behind_torch'):
+            self.network.weights_changed_behind_torch()
         _lib.check(lib.abn_optimizer_step(
             _lib.OPT[self.kind], _lib.ptr(flat), _lib.ptr(grad), _lib.ptr(self._s1),
             _lib.ptr(self._s2), flat.numel(), self.lr, hp0, hp1, eps, self.step_count,
@@ -419,6 +422,8 @@ class TrainerSiamese(TrainerBuilder):
                 for dst, src in zip(static, batch):
                     dst.copy_(src, non_blocking=True)
             graph.replay()
+            if hasattr(net, 'weights_changed_behind_torch'):
+                net.weights_changed_behind_torch()
             for p, g in zip(live, captured_grads):
                 p.grad = g
             if captured_flat is not None:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 9
+#define ABN_ABI_VERSION 10
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -101,7 +101,17 @@ typedef struct abn_tower_desc {
      * caller finishes with abn_tower_reduce_step (reduction + optimizer step in one launch).
      * Not with batch_norm. */
     int32_t defer_reduce;
-    int32_t reserved_;
+    /* Optional persistent image of the weights as MFMA operand fragments (default arithmetic):
+     * wpack = abn_tower_wpack_floats() floats owned by the caller, zero before the first use, or
+     * NULL (the forward then builds the image inside its workspace every call).  wpack_valid != 0:
+     * the caller vouches that the image matches W as it stands -- it does after a forward that
+     * was given the buffer with wpack_valid = 0 (which rebuilds it: ~6 us) until anything writes
+     * to W (abn_optimizer_step and abn_tower_reduce_step included).  What it buys: repeated
+     * forwards with unchanged weights (embedding extraction) skip the rebuild.  (Keeping the image
+     * in step inside abn_tower_reduce_step was measured: the transposed half is 2-byte scattered
+     * stores, +10 us on that launch against the 6 us saved.) */
+    int32_t wpack_valid;
+    void* wpack;
 } abn_tower_desc;
 
 /* Workspace of one forward call (what the backward needs: the saved activations, for the
@@ -112,6 +122,14 @@ int64_t abn_tower_ws_floats(const abn_tower_desc* t, int64_t rows, int64_t n_cal
 int64_t abn_tower_out_offset(const abn_tower_desc* t, int64_t rows, int64_t n_calls);
 /* Scratch of one backward call (split-K slabs + the dZ of every layer), in floats. */
 int64_t abn_tower_bwd_scratch_floats(const abn_tower_desc* t, int64_t rows);
+/* Size of the optional abn_tower_desc.wpack buffer, in floats (0: this tower has no such image). */
+int64_t abn_tower_wpack_floats(const abn_tower_desc* t);
+/* 1 when abn_tower_forward / backward with these arguments run on the operand-plane kernels (the
+ * ones that read, and with wpack_valid = 0 rebuild, wpack), 0 when on the per-layer GEMMs, < 0 on
+ * a bad descriptor.  Depends on the descriptor, the row count, pointer alignment and the
+ * library's environment switches. */
+int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2,
+                          const float* ws);
 
 /* SiameseNetwork.forward_once / forward, abnet3/model.py:179-196.
  * `rows` input rows in total, made of `n_calls` forward_once calls of

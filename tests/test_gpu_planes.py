@@ -183,6 +183,7 @@ def test_operand_images_decode_to_their_tensors(precision, NP):
     torch.cuda.synchronize()
     desc = pending[0]
     ws16 = sv.ws.view(torch.int16).cpu().numpy().view(np.uint16)
+    w16 = seg._wpack.view(torch.int16).cpu().numpy().view(np.uint16) if desc.wpack else ws16      # the weight images' home
     sc16 = pending[2].view(torch.int16).cpu().numpy().view(np.uint16)
     Ws = [q.detach().double().cpu().numpy() for k, q in net.named_parameters() if k.endswith('weight')]
     bs = [q.detach().double().cpu().numpy() for k, q in net.named_parameters() if k.endswith('bias')]
@@ -196,10 +197,10 @@ def test_operand_images_decode_to_their_tensors(precision, NP):
     steps = lambda c: ((c + 15) // 16 + 3) // 4 * 4
     row_steps = (R + 31) // 32 * 2
     for l in range(3):
-        d = decode(ws16[2 * fn(ctypes.byref(desc), R, 2, 0, l):], (dims[l + 1] + 31) // 32, steps(dims[l]), NP)
+        d = decode(w16[2 * fn(ctypes.byref(desc), R, 2, 0, l):], (dims[l + 1] + 31) // 32, steps(dims[l]), NP)
         assert np.abs(d[:dims[l + 1], :dims[l]] - Ws[l]).max() <= eps * np.abs(Ws[l]).max()
         assert np.abs(d[dims[l + 1]:]).max(initial=0) == 0 and np.abs(d[:, dims[l]:]).max(initial=0) == 0
-        d = decode(ws16[2 * fn(ctypes.byref(desc), R, 2, 1, l):], (dims[l] + 31) // 32, steps(dims[l + 1]), NP)
+        d = decode(w16[2 * fn(ctypes.byref(desc), R, 2, 1, l):], (dims[l] + 31) // 32, steps(dims[l + 1]), NP)
         assert np.abs(d[:dims[l], :dims[l + 1]] - Ws[l].T).max() <= eps * np.abs(Ws[l]).max()
         d = decode_t(ws16[2 * fn(ctypes.byref(desc), R, 2, 2, l):], (dims[l] + 1 + 31) // 32, row_steps, NP)
         assert np.abs(d[:dims[l], :R] - acts[l].T).max() <= max(eps, 3e-7) * np.abs(acts[l]).max()
@@ -251,3 +252,61 @@ def test_pair_loss_inside_the_backward_equals_the_two_calls(lname, avg, B, ydtyp
     gmax = max(float(g.abs().max()) for g in res[1][1])
     for (k, _), a, b in zip(net.named_parameters(), res[0][1], res[1][1]):
         assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-2 * gmax), k
+
+
+@pytest.mark.parametrize('oname', ['adadelta', 'sgd'])
+def test_persistent_weight_image_follows_every_kind_of_update(oname, monkeypatch):
+    """abn_tower_desc.wpack: the forward skips its pack launch while the image is known to match the
+    parameters (repeated forwards with unchanged weights).  Optimizer launches, torch-side writes and
+    state_dict loads must make the next forward rebuild it.  Every variant against the same run without the image."""
+    import abnet3_amd.loss as L
+    from abnet3_amd.trainer import TrainerSiamese
+    kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=96, output_dim=32, activation_layer='sigmoid',
+              p_dropout=0.0, batch_norm=False)
+    rng = np.random.default_rng(2)
+    B = 64
+    batches = [(dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32)),
+                dev(rng.choice([1, -1], B))) for _ in range(3)]
+    outs = []
+    for wpack in ('1', '0'):
+        monkeypatch.setenv('ABN_WPACK', wpack)
+        net, _, _ = build(kw, seed=1, precision='bf16x3')
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type=oname, lr=0.05, dataloader=None,
+                            log_dir='/tmp/abn_runs')
+        net.train()
+        seg = net._segment_list()[0]
+        losses = []
+        for s in range(2):
+            losses.append(float(tr.train_step(batches[s], True)))            # fused step: the image is stale afterwards
+        assert (getattr(seg, '_wpack', None) is not None) == (wpack == '1')
+        if wpack == '1':
+            assert seg._wpack_key is None
+            net.eval()
+            with torch.no_grad():
+                a = net.forward_once(batches[0][0])
+                assert seg._wpack_key == seg._weights_key()                    # rebuilt; the next forward will not pack
+                b = net.forward_once(batches[0][0])
+            assert torch.equal(a, b)
+            net.train()
+        with torch.no_grad():
+            net.input_emb[0].weight.mul_(1.5)                                  # a torch-side write
+        losses.append(float(tr.train_step(batches[2], True)))
+        tr.optimizer.zero_grad()
+        e1, e2 = net(batches[0][0], batches[0][1])                             # autograd path + plain optimizer launch
+        lv = L.coscos2(avg=False)(e1, e2, batches[0][2])
+        lv.backward()
+        tr.optimizer.step()
+        if wpack == '1':
+            assert seg._wpack_key is None
+        losses.append(float(lv.detach()))
+        losses.append(float(tr.train_step(batches[1], True)))
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        net.load_state_dict({k: v * 0.5 for k, v in sd.items()})
+        net.eval()
+        with torch.no_grad():
+            emb = net.forward_once(batches[2][0]).cpu().numpy()
+        outs.append((losses, emb, {k: v.detach().cpu().numpy() for k, v in net.named_parameters()}))
+    assert np.allclose(outs[0][0], outs[1][0], rtol=1e-6), (outs[0][0], outs[1][0])
+    assert rel_err(outs[0][1], outs[1][1]) < 1e-6
+    for k in outs[0][2]:
+        assert rel_err(outs[0][2][k], outs[1][2][k]) < 1e-6, k
