@@ -540,7 +540,8 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
     if (planes_shape_ok(t)) {
         const int np = planes_of(t->precision);
         L.wpack = take(make_pack_layout(t).bytes / 4);
-        for (int l = 0; l < t->n_layers; ++l) L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, rows, np) / 4);
+        if (!t->forward_only)                    // (last in the workspace: an inference call simply asks for less)
+            for (int l = 0; l < t->n_layers; ++l) L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, rows, np) / 4);
     }
     L.total = o;
     return L;
@@ -898,7 +899,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 T.tile0 = pk.n_tiles; T.dst = PL.wpt[l];
                 pk.n_tiles += T.nblk * T.nsteps;
             }
-            f.tp[l] = reinterpret_cast<char*>(ws + L.tp[l]);
+            f.tp[l] = t->forward_only ? nullptr : reinterpret_cast<char*>(ws + L.tp[l]);     // (inference: nothing kept for a backward)
         }
         f.tp_steps = pl_row_steps(rows);
 #ifdef ABN_STAMPS

@@ -172,16 +172,18 @@ class _Segment(object):
         if getattr(self, '_wpack', None) is not None:
             self._wpack_key = key
 
-    def descriptor(self, with_grads, grad_buf=None, masks=None, d_out_is_dz=False, defer_reduce=False):
+    def descriptor(self, with_grads, grad_buf=None, masks=None, d_out_is_dz=False, defer_reduce=False, forward_only=False):
         """abn_tower_desc for one call.  grad_buf: the flat gradient buffer of this
         backward pass (gradients land at the parameters' offsets in it)."""
         tmpl = self._template()
         valid, self._key_at_descriptor = self.wpack_state()
         if not with_grads and masks is None:
             tmpl.wpack_valid = valid
+            tmpl.forward_only = int(forward_only)
             return tmpl                        # read-only for the library
         d = _lib.TowerDesc.from_buffer_copy(tmpl)
         d.wpack_valid = valid
+        d.forward_only = int(forward_only)
         d.d_out_is_dz = int(d_out_is_dz)
         d.defer_reduce = int(defer_reduce)
         if masks is not None:
@@ -232,7 +234,7 @@ class _Saved(object):
     __slots__ = ('x1', 'x2', 'ws', 'masks', 'n_calls', 'train', 'rows')
 
 
-def _segment_forward(seg, all_masks, n_calls, x1, x2):
+def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
     """Raw forward of one segment (no autograd): the launch sequence of
     abn_tower_forward.  Returns ([rows, out] embeddings as a view of the workspace,
     _Saved)."""
@@ -254,7 +256,7 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2):
     train = bool(net.training)
     rows = x1.shape[0] * (2 if x2 is not None else 1)
     masks = seg.masks_of(all_masks) if train else None
-    desc = seg.descriptor(with_grads=False, masks=masks)
+    desc = seg.descriptor(with_grads=False, masks=masks, forward_only=forward_only)
     ws_floats = lib.abn_tower_ws_floats(_lib.C.byref(desc), rows, n_calls)
     if ws_floats < 0:
         _lib.check(-1, 'abn_tower_ws_floats')
@@ -315,7 +317,8 @@ class _TowerFunction(torch.autograd.Function):
         for p_ in params:
             if not p_.is_cuda:
                 _lib.require_device(p_)
-        out, sv = _segment_forward(seg, all_masks, n_calls, x1, x2)
+        # nothing requires a gradient (torch.no_grad(), frozen parameters): inference, the library keeps nothing for a backward
+        out, sv = _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=not any(ctx.needs_input_grad))
         ctx.seg, ctx.grad_pass, ctx.sv = seg, grad_pass, sv
         ctx.have_x2 = x2 is not None
         ctx.split = split

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 10
+#define ABN_ABI_VERSION 11
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -111,6 +111,11 @@ typedef struct abn_tower_desc {
      * in step inside abn_tower_reduce_step was measured: the transposed half is 2-byte scattered
      * stores, +10 us on that launch against the 6 us saved.) */
     int32_t wpack_valid;
+    /* forward only: no backward will follow this forward (inference): it may skip whatever it
+     * would store for one (the default arithmetic writes more than half of its bytes for the
+     * backward).  A backward after such a forward reads garbage. */
+    int32_t forward_only;
+    int32_t reserved_;
     void* wpack;
 } abn_tower_desc;
 
