@@ -970,6 +970,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         }
     };
     auto mfmas = [&](const Frags& f) {
+#ifdef WEXP_NOMFMA
+        for (int i = 0; i < TN; ++i) for (int j = 0; j < TK; ++j) acc[i][j][0] += (float)f.a[i][0][0] * (float)f.b[j][0][1];
+        return;
+#endif
         if constexpr (NP == 3) {
             constexpr int AP[6] = {2, 0, 1, 1, 0, 0}, BP[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -989,36 +993,65 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
     };
     Frags fr[2];
     if constexpr (NP == 3) {
-        // Register ring: slot k % 4 holds this wave's fp32 tiles of step k, fetched four steps before they
-        // are split (raw buffer loads: the compiler counts their vmcnt and leaves them where they stand).
+        // Register ring: slot k % 4 holds this wave's share of step k's fp32 tiles, fetched four steps before
+        // it is split (raw buffer loads: the compiler counts their vmcnt and leaves them where they stand).
+        // The share is the same for every wave -- one whole tile (operand block `wave`) and one 1 KB half of
+        // a tile of the blocks 8 .. NB-1 -- so that the step's body is ONE branch-free scheduling region:
+        // only there can the ~70 VALU instructions of the split be woven between the MFMAs
+        // (sched_group_barrier); in a block of their own, in front of the MFMAs, they idle the matrix cores
+        // of a SIMD whose two waves sit behind the same barrier (measured: +16 us).
         // Iteration c, behind ONE barrier: split step c + 2 into LDS stage (c + 2) % 4 and refill its slot
         // with step c + 6; read step c + 1's fragments (second register set); step c's MFMAs.  The loop
-        // runs to a multiple of four steps, branch free: steps past the end are written as zeros.
+        // runs to a multiple of four steps: steps past the end are written as zeros.
         static_assert(WG_REG_DEPTH == 4 && WG_STAGES == 4, "slot / stage arithmetic below");
-        __amdgpu_buffer_rsrc_t rs[PER_WAVE];
-#pragma unroll
-        for (int u = 0; u < PER_WAVE; ++u)
-            rs[u] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src[u] - lane * 16), 0, (int)(p.tp_steps * FR), 0x00020000);
-        v4i rq[WG_REG_DEPTH][PER_WAVE][2];
+        static_assert(NB > PL_WAVES && NB <= 12, "one whole tile per wave plus halves of the rest");
+        constexpr int NHALF = 2 * (NB - PL_WAVES);                 // 1 KB halves of the tiles 8 .. NB-1 (8: one each; 4: shared, written twice)
+        const int hb = PL_WAVES + ((wave % NHALF) >> 1), hh = wave & 1;          // this wave's half: tile hb, elements 4 hh .. 4 hh + 3
+        auto image_of = [&](int b) -> const char* {
+            const bool is_dz = b < BN;
+            const int ob = is_dz ? nb0 + b : kb0 + (b - BN);
+            const int ob_max = is_dz ? L.nblk : L.kblk;
+            return (is_dz ? L.dzp : L.ap) + (int64_t)(ob < ob_max ? ob : ob_max - 1) * p.tp_steps * FR;
+        };
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(image_of(wave)), 0, (int)(p.tp_steps * FR), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(image_of(hb)), 0, (int)(p.tp_steps * FR), 0x00020000);
+        v4i rq[WG_REG_DEPTH][3];
         const int n4 = (n_steps + 3) / 4 * 4;
         auto load = [&](int slot, int k) {
             const int off = step_at(k) * FR;
-#pragma unroll
-            for (int u = 0; u < PER_WAVE; ++u)
-#pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    rq[slot][u][d] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], lane * 16, off + d * 1024, 0);
-                }
+#ifdef WEXP_NOLOAD
+            rq[slot][0] = rq[slot][1] = rq[slot][2] = v4i{k, slot, 1, 2};
+#else
+            rq[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs0, lane * 16, off, 0);
+            rq[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs0, lane * 16, off + 1024, 0);
+            rq[slot][2] = __builtin_amdgcn_raw_buffer_load_b128(rs1, lane * 16, off + hh * 1024, 0);
+#endif
         };
         auto convert = [&](int slot, int k) {
+#ifdef WEXP_NOCONVERT
+            if (k >= 0) return;
+#endif
             const bool real = k < n_steps;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v0 = real ? __builtin_bit_cast(f32x4, rq[slot][0]) : z4;
+            const f32x4 v1 = real ? __builtin_bit_cast(f32x4, rq[slot][1]) : z4;
+            const f32x4 v2 = real ? __builtin_bit_cast(f32x4, rq[slot][2]) : z4;
+            char* const st = smem + (k % WG_STAGES) * PSTAGE + lane * 16;
+            store_frag<3>(st + wave * 3072, make_frag<3>(v0, v1));
+            // the half tile: four values -> 8 bytes per plane
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 ph, pm, pl;
 #pragma unroll
-            for (int u = 0; u < PER_WAVE; ++u)
-                if (u < n_mine) {
-                    f32x4 v0 = __builtin_bit_cast(f32x4, rq[slot][u][0]), v1 = __builtin_bit_cast(f32x4, rq[slot][u][1]);
-                    if (!real) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
-                    store_frag<3>(smem + (k % WG_STAGES) * PSTAGE + (dst[u] / FR) * 3072 + lane * 16, make_frag<3>(v0, v1));
-                }
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 hq = (__bf16)v2[e];
+                const float r1 = v2[e] - (float)hq;
+                const __bf16 mq = (__bf16)r1;
+                ph[e] = hq; pm[e] = mq; pl[e] = (__bf16)(r1 - (float)mq);
+            }
+            char* const sh = st + hb * 3072 + hh * 8;
+            *reinterpret_cast<bf16x4*>(sh) = ph;
+            *reinterpret_cast<bf16x4*>(sh + 1024) = pm;
+            *reinterpret_cast<bf16x4*>(sh + 2048) = pl;
         };
         if (n_steps > 0) {
 #pragma unroll
@@ -1026,22 +1059,20 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
             convert(0, 0); load(0, 4);
             convert(1, 1); load(1, 5);
             __syncthreads();
-            if (live) read_frags(fr[0], 0);
+            read_frags(fr[0], 0);
         }
         for (int c0 = 0; c0 < n4; c0 += 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = c0 + i;
                 __syncthreads();        // step c + 1's planes are in LDS for everybody; nobody still reads stage (c + 2) % 4
-                if (live) read_frags(fr[(i + 1) & 1], c + 1);
+                read_frags(fr[(i + 1) & 1], c + 1);
                 convert((i + 2) & 3, c + 2);
-                if (live) mfmas(fr[i & 1]);
-                // the split is ~70 VALU instructions: left in one piece in front of (or behind) the MFMAs it idles
-                // the matrix cores of a SIMD whose two waves sit behind the same barrier; woven in, two MFMAs at a time
+                mfmas(fr[i & 1]);       // (a wave whose blocks are all padding multiplies clamped copies: nothing of it is stored)
 #pragma unroll
-                for (int g = 0; g < TN * TK * 3; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                for (int g = 0; g < TN * TK * 6; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 }
                 load((i + 2) & 3, c + 6);
             }
