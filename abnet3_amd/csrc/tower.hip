@@ -609,10 +609,14 @@ static int planes_split_count(int64_t rows, int64_t out_dim, int64_t in_dim)
     const int nblk = pl_blocks(out_dim), kblk = pl_blocks(in_dim + 1);
     wgrad_shape(nblk, kblk, &shape, &bn, &bk);
     const int64_t tiles = (int64_t)((nblk + bn - 1) / bn) * ((kblk + bk - 1) / bk);
-    int64_t s = (128 + tiles - 1) / tiles;               // ~128 workgroups per layer
+    // ~128 workgroups per layer.  The light shapes (first / output layer: half-empty tiles, small slabs) may be cut
+    // twice as fine: at C2 every CU then gets one heavy workgroup (32 row steps) and one light one (8) -- with
+    // 16-step light ones half the CUs idled through the launch's tail
+    int64_t s = (128 + tiles - 1) / tiles;
     const int64_t by_rows = rows / 128 < 1 ? 1 : rows / 128;
+    const int64_t cap = shape == 0 ? MAX_SPLITS : 2 * MAX_SPLITS;
     if (s > by_rows) s = by_rows;
-    if (s > MAX_SPLITS) s = MAX_SPLITS;
+    if (s > cap) s = cap;
     return (int)(s < 1 ? 1 : s);
 }
 
