@@ -558,7 +558,7 @@ static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, 
     // up that beats the per-layer GEMMs (tools/rows_sweep.py, tools/fwd_rows_sweep.py: C2 train step 0.148 vs
     // 0.180 ms at 512 rows, 0.234 vs 0.331 at 8192; forward alone 62 vs 94 us at 5000 rows)
     const int64_t min_rows = getenv("ABN_FUSED_MIN_ROWS") ? atoll(getenv("ABN_FUSED_MIN_ROWS")) : 256;
-    if (rows < min_rows || !planes_shape_ok(t)) return false;
+    if (rows < min_rows || rows > (1LL << 20) || !planes_shape_ok(t)) return false;      // (32-bit byte offsets inside one image)
     if (!aligned16(x1) || (x2 && !aligned16(x2)) || !aligned16(ws)) return false;
     for (int l = 0; l < t->n_layers; ++l)
         if (!aligned16(t->W[l]) || !aligned16(t->b[l]) || (t->drop_mask[l] && !aligned16(t->drop_mask[l]))) return false;
