@@ -716,6 +716,8 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
     }
     b.a_top = ws + L.a[nl - 1];
     b.dx = dx;
+    b.drop_seed = reinterpret_cast<const unsigned long long*>(t->drop_seed);
+    b.drop_p = t->drop_p;
     const PackLayout PL = make_pack_layout(t);
     const char* const image = t->wpack ? reinterpret_cast<const char*>(t->wpack) : reinterpret_cast<const char*>(ws + L.wpack);
     for (int l = 0; l <= nl; ++l) b.dims[l] = (int)t->dims[l];
@@ -870,6 +872,10 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         fusable = t->dims[l] >= 4 && t->dims[l] <= FUSED_MAXW && t->dims[l] % 4 == 0;
     for (int l = 0; l < t->n_layers && fusable; ++l)
         fusable = aligned16(t->W[l]) && (!t->drop_mask[l] || !train || aligned16(t->drop_mask[l]));
+    if (t->drop_seed && train && !planes_path(t, rows, x1, x2, ws)) {
+        for (int l = 0; l < t->n_layers; ++l)
+            if (!t->drop_mask[l]) { set_error("tower_forward: in-kernel dropout (drop_seed) needs the operand-plane kernels: pass drop_mask tensors"); return ABN_E_UNSUPPORTED; }
+    }
     if (planes_path(t, rows, x1, x2, ws)) {
         const int np = planes_of(t->precision);
         PackTable pk = {};
@@ -906,6 +912,8 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
             f.tp[l] = t->forward_only ? nullptr : reinterpret_cast<char*>(ws + L.tp[l]);     // (inference: nothing kept for a backward)
         }
         f.tp_steps = pl_row_steps(rows);
+        f.drop_seed = train ? reinterpret_cast<const unsigned long long*>(t->drop_seed) : nullptr;
+        f.drop_p = t->drop_p;
 #ifdef ABN_STAMPS
         f.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
 #endif

@@ -65,7 +65,8 @@ static inline int64_t pl_row_steps(int64_t rows) { return (rows + PL_ROWS - 1) /
 // bytes of one (block, row step) tile of a transposed image: 64 lanes x 8 fp32 (bf16 x 3) or 8 bf16 (bf16)
 template <int NP> constexpr int tile_bytes() { return NP == 3 ? 2048 : 1024; }
 static inline int64_t pl_timage_bytes(int64_t features, int64_t rows, int np) { return (int64_t)pl_blocks(features) * pl_row_steps(rows) * (np == 3 ? 2048 : 1024); }
-static inline size_t pl_lds_bytes(int np) { return (size_t)PL_MAXSTEPS * np * 1024 + PL_PART_BYTES; }
+constexpr int PL_BIAS_BYTES = PL_WAVES * 64 * 4;   // a wave's 64 bias values, parked in LDS across its k-loop
+static inline size_t pl_lds_bytes(int np) { return (size_t)PL_MAXSTEPS * np * 1024 + PL_PART_BYTES + PL_BIAS_BYTES; }
 
 #ifdef ABN_STAMPS
 #define PSTAMPF(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 128 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -328,6 +329,48 @@ __device__ __forceinline__ void with_act(int act, F&& f)
 }
 
 // ---------------------------------------------------------------------------------------------
+// dropout drawn in the kernels: multiplier of (layer, batch row, feature) = a hash of them and of the
+// call's seed -- 0 with probability p (16 bits), else 1 / (1 - p).  The forward epilogue and the
+// backward's act' step evaluate the same function: no mask tensor is drawn, stored or read (with the
+// reference's default p = 0.1 those were 40 us of a 220 us step: 13 M bernoulli draws, 52 MB
+// written, scaled, read twice).
+// ---------------------------------------------------------------------------------------------
+struct DropGen {
+    uint32_t key, thr;
+    float scale;
+    bool on;
+};
+__device__ __forceinline__ uint32_t hash32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ DropGen make_drop(const unsigned long long* seedp, float p, int layer)
+{
+    DropGen g = {0u, 0u, 1.0f, false};
+    if (!seedp) return g;
+    const unsigned long long seed = *seedp;
+    g.key = hash32((uint32_t)seed ^ (0x9e3779b9u * (uint32_t)(layer + 1))) ^ (uint32_t)(seed >> 32);
+    const float t = p * 65536.0f + 0.5f;
+    g.thr = t >= 65536.0f ? 65536u : (uint32_t)t;
+    g.scale = p < 1.0f ? 1.0f / (1.0f - p) : 0.0f;
+    g.on = true;
+    return g;
+}
+// the four multipliers of features n .. n + 3 (n % 4 == 0, n < 512) of batch row gr (< 2^20)
+__device__ __forceinline__ f32x4 drop4(const DropGen& g, int gr, int n)
+{
+    const uint32_t c = ((uint32_t)gr * 128u + (uint32_t)(n >> 2)) * 2u;
+    const uint32_t h0 = hash32(c ^ g.key), h1 = hash32((c + 1u) ^ g.key);
+    f32x4 m;
+    m[0] = (h0 & 0xffffu) >= g.thr ? g.scale : 0.0f;
+    m[1] = (h0 >> 16) >= g.thr ? g.scale : 0.0f;
+    m[2] = (h1 & 0xffffu) >= g.thr ? g.scale : 0.0f;
+    m[3] = (h1 >> 16) >= g.thr ? g.scale : 0.0f;
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
 struct PlanesFwdP {
@@ -348,6 +391,8 @@ struct PlanesFwdP {
     // outputs of layer l < n_layers - 1
     char* tp[ABN_MAX_LAYERS];
     int64_t tp_steps;              // row steps of those images (pl_row_steps(rows))
+    const unsigned long long* drop_seed;   // in-kernel dropout for the layers without a mask tensor (null: off)
+    float drop_p;
 #ifdef ABN_STAMPS
     unsigned long long* stamps;
 #endif
@@ -373,18 +418,15 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
         for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
 
     // All loads of the epilogue are issued as one batch from clamped addresses (a load under a
-    // per-group `if` waits for its own round trip: eight of them in a row were 8.5 k cycles per layer),
-    // the bias before the k-loop, the dropout mask after it.
-    f32x4 bv[BPW][4];
+    // per-group `if` waits for its own round trip: eight of them in a row were 8.5 k cycles per layer).
+    // The bias: ONE value per lane (feature 32 blk0 + lane of the wave's up to 64), requested before the
+    // k-loop, parked in a per-wave LDS slot after it and read back as the 16-byte pieces the
+    // accumulator layout wants (32 registers held across the k-loop spilled the bf16 x 3 kernel).
+    float bias_lane = 0.0f;
     {
         const float* __restrict__ bias = p.b[l];
-#pragma unroll
-        for (int j = 0; j < BPW; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = 32 * (blk0 + j) + 4 * h + 8 * g;
-                bv[j][g] = bias && ws.active ? *reinterpret_cast<const f32x4*>(bias + (n < N ? n : N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        const int n = 32 * blk0 + lane;
+        if (bias && ws.active && lane < 32 * BPW) bias_lane = bias[n < N ? n : N - 1];
     }
     if (ws.active) planes_kloop<NP, BPW>(acc, p.wp[l], nblk, nsteps, img, blk0, ws.s_first, ws.my_steps, lane);
     PSTAMPF(3 + 5 * l);
@@ -393,8 +435,14 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     // batch row r: registers 4g .. 4g+3 are four consecutive features (one 16-byte piece of the
     // row-major output), registers 8t .. 8t+7 the lane's operand of step 2 blk + t of the next layer.
     const float* __restrict__ mask = p.mask[l];
+    const DropGen drop = make_drop(mask ? nullptr : p.drop_seed, p.drop_p, l);
+    const bool masked = mask || drop.on;
     const int gr = row0 + r;
     const bool row_ok = gr < p.rows;
+    float* const bias_s = part + PL_PART_BYTES / 4 + wave * 64;
+    bias_s[lane] = bias_lane;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");        // (this wave's own LDS accesses complete in order)
+    __builtin_amdgcn_wave_barrier();
     f32x4 mv[BPW][4];
     if (mask && ws.active && ws.khalf == 0) {
         const float* mrow = mask + (int64_t)(row_ok ? gr : p.rows - 1) * N;
@@ -414,10 +462,14 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const bool live = 32 * (blk0 + j) + 4 * h + 8 * g < N;      // N % 4 == 0: four features in or out together
+                    f32x4 m4 = {1.f, 1.f, 1.f, 1.f};
+                    if (mask) m4 = mv[j][g];
+                    else if (drop.on) m4 = drop4(drop, gr, 32 * (blk0 + j) + 4 * h + 8 * g);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + 32 * j + 4 * h + 8 * g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc[j][4 * g + e] + bv[j][g][e];
-                        if (mask) v *= mv[j][g][e];
+                        float v = acc[j][4 * g + e] + b4[e];
+                        if (masked) v *= m4[e];
                         acc[j][4 * g + e] = live ? act_apply(v, ACT) : 0.0f;
                     }
                 }
@@ -554,6 +606,8 @@ struct PlanesBwdP {
     const char* wpt[ABN_MAX_LAYERS];      // packed W_l^T images, l >= 1
     char* dzp[ABN_MAX_LAYERS];            // out: transposed planes of dZ_l (dims[l+1] features)
     int64_t tp_steps;
+    const unsigned long long* drop_seed;  // the forward's in-kernel dropout, regenerated here (null: off)
+    float drop_p;
     // The pair loss inside the chain (abn_tower_backward_loss; loss_kind < 0: d_out is given): rows are
     // [tower 1: pairs 0 .. B-1 | tower 2: pairs 0 .. B-1], the embeddings are a_top, and the first phase
     // computes what abn_pair_loss_dz would have written to d_out -- same arithmetic (loss.hip), fp64 per row.
@@ -586,6 +640,8 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
     if (ws.active) planes_kloop<NP, BPW>(acc, p.wpt[l], nblk, nsteps, img, blk0, ws.s_first, ws.my_steps, lane);
 
     const float* __restrict__ mask = l >= 1 ? p.mask[l - 1] : nullptr;
+    const DropGen drop = make_drop(l >= 1 && !mask ? p.drop_seed : nullptr, p.drop_p, l - 1);
+    const bool masked = mask || drop.on;
     const int gr = row0 + r;
     const bool row_ok = gr < p.rows;
     const int grc = row_ok ? gr : p.rows - 1;
@@ -604,6 +660,7 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
                 for (int e = 0; e < 4; ++e) av[j][g][e] = tgather<NP>(tile, row_off, 8 * g + 4 * h + e);
                 const int k = 32 * (blk0 + j) + 4 * h + 8 * g;
                 if (mask) mv[j][g] = *reinterpret_cast<const f32x4*>(mask + (int64_t)grc * K + (k < K ? k : K - 4));
+                else if (drop.on) mv[j][g] = drop4(drop, gr, k);
             }
         }
     }
@@ -619,7 +676,7 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[j][4 * g + e] * act_grad(av[j][g][e], ACT);
-                        if (mask) v *= mv[j][g][e];
+                        if (masked) v *= mv[j][g][e];
                         acc[j][4 * g + e] = live ? v : 0.0f;
                     }
                 }
@@ -776,6 +833,7 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
     const int gr = row0 + r;
     const bool row_ok = gr < p.rows;
     const float* __restrict__ mask = p.mask[top];
+    const DropGen drop_top = make_drop(mask ? nullptr : p.drop_seed, p.drop_p, top);
     const int my_tower = gr >= p.B ? 1 : 0;
     const float* const self_row = p.a_top + (int64_t)(row_ok ? gr : 0) * NT;
     const float* const partner_row = p.a_top + (int64_t)(row_ok && with_loss ? (my_tower ? gr - p.B : gr + p.B) : 0) * NT;
@@ -799,8 +857,8 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
                             if (p.act[top] != ACT_NONE) o *= act_grad(es[e], p.act[top]);
                             v[u][e] = o;
                         }
-                        if (mask) {
-                            const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (int64_t)gr * NT + c);
+                        if (mask || drop_top.on) {
+                            const f32x4 m = mask ? *reinterpret_cast<const f32x4*>(mask + (int64_t)gr * NT + c) : drop4(drop_top, gr, c);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[u][e] *= m[e];
                         }
@@ -810,8 +868,8 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
                             const f32x4 a = *reinterpret_cast<const f32x4*>(p.a_top + (int64_t)gr * NT + c);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[u][e] *= act_grad(a[e], p.act[top]);
-                            if (mask) {
-                                const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (int64_t)gr * NT + c);
+                            if (mask || drop_top.on) {
+                                const f32x4 m = mask ? *reinterpret_cast<const f32x4*>(mask + (int64_t)gr * NT + c) : drop4(drop_top, gr, c);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[u][e] *= m[e];
                             }

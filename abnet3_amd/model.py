@@ -101,6 +101,8 @@ class _Segment(object):
         return net._offsets[first:first + len(self.params)]
 
     def masks_of(self, all_masks):
+        if isinstance(all_masks, _DropoutInKernel):
+            return all_masks
         if all_masks is None:
             return None
         return all_masks[self.first_block:self.first_block + len(self.blocks)]
@@ -186,7 +188,10 @@ class _Segment(object):
         d.forward_only = int(forward_only)
         d.d_out_is_dz = int(d_out_is_dz)
         d.defer_reduce = int(defer_reduce)
-        if masks is not None:
+        if isinstance(masks, _DropSeed):
+            d.drop_seed = masks.seed.data_ptr()
+            d.drop_p = masks.p
+        elif masks is not None:
             for l, m in enumerate(masks):
                 d.drop_mask[l] = m.data_ptr()
         if with_grads:
@@ -229,6 +234,25 @@ class _GradPass(object):
         return buf, [buf.as_strided(shape, stride, off) for shape, stride, off in specs[1]]
 
 
+class _DropoutInKernel(object):
+    """What _draw_dropout_masks hands down when no mask tensors were asked for: nn.Dropout(p) to be drawn
+    inside the kernels (abn_tower_desc.drop_seed) wherever the library can, as tensors elsewhere."""
+    __slots__ = ('p', 'net')
+
+    def __init__(self, p, net):
+        self.p, self.net = p, net
+
+
+class _DropSeed(object):
+    """The in-kernel dropout of ONE forward of one segment: a device uint64 drawn by torch's generator (so that
+    a captured step redraws it at every replay) and p.  The backward gets the same object."""
+    __slots__ = ('seed', 'p')
+
+    def __init__(self, p, device):
+        self.seed = torch.empty(1, dtype=torch.int64, device=device).random_()
+        self.p = float(p)
+
+
 class _Saved(object):
     """What a segment's forward leaves for its backward."""
     __slots__ = ('x1', 'x2', 'ws', 'masks', 'n_calls', 'train', 'rows')
@@ -256,6 +280,13 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
     train = bool(net.training)
     rows = x1.shape[0] * (2 if x2 is not None else 1)
     masks = seg.masks_of(all_masks) if train else None
+    if isinstance(masks, _DropoutInKernel):
+        # drawn inside the kernels where they are the operand-plane ones, as tensors for the per-layer path
+        probe = seg.descriptor(with_grads=False)
+        if lib.abn_tower_uses_planes(_lib.C.byref(probe), rows, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(x1)) == 1:
+            masks = _DropSeed(masks.p, x1.device)
+        else:
+            masks = seg.masks_of(masks.net._draw_mask_tensors(rows, x1.device))
     desc = seg.descriptor(with_grads=False, masks=masks, forward_only=forward_only)
     ws_floats = lib.abn_tower_ws_floats(_lib.C.byref(desc), rows, n_calls)
     if ws_floats < 0:
@@ -535,6 +566,12 @@ class _HipNetwork(NetworkBuilder):
         p = float(self.p_dropout)
         if p <= 0.0:
             return None
+        if os.environ.get('ABN_DROPOUT_IN_KERNEL') != '0':      # (the variable: A/B runs)
+            return _DropoutInKernel(p, self)
+        return self._draw_mask_tensors(rows, device)
+
+    def _draw_mask_tensors(self, rows, device):
+        p = float(self.p_dropout)
         # all layers' masks in ONE buffer: two launches per forward (bernoulli, scale)
         # instead of three per layer; every mask starts 256-byte aligned
         widths = [lin.out_features for lin, _ in self._blocks()]
@@ -690,6 +727,8 @@ class SiameseNetwork(_HipNetwork):
         if seg.batch_norm or os.environ.get('ABN_LOSS_DZ') == '0':      # (the variable: A/B measurements)
             return None
         masks = None
+        if isinstance(sv.masks, _DropSeed):
+            return None                          # the output layer's mask exists inside the tower kernels only
         if sv.masks is not None:
             m = sv.masks[-1]
             half = m.shape[0] // 2

@@ -331,10 +331,9 @@ class TrainerSiamese(TrainerBuilder):
             # single process: nothing happens between backward and step, so the split-K
             # reduction of the weight gradients rides in the optimizer's launch
             defer = self.world_size == 1 and self.network.can_defer_reduce(state)
-            loss_value = None
-            if info is not None:      # the pair loss inside the backward's first launch, where the library offers it
-                loss_value = self.network.direct_backward_loss(
-                    state, y_batch, type(self.loss).__name__, getattr(self.loss, 'margin', 0.0), self.loss.avg, defer_reduce=defer)
+            # the pair loss inside the backward's first launch, where the library offers it
+            loss_value = self.network.direct_backward_loss(
+                state, y_batch, type(self.loss).__name__, getattr(self.loss, 'margin', 0.0), self.loss.avg, defer_reduce=defer)
             if loss_value is not None:
                 pass
             elif info is not None:    # loss gradient and the output layer's act' (+ dropout) in ONE launch

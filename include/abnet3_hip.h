@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 11
+#define ABN_ABI_VERSION 12
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -117,6 +117,16 @@ typedef struct abn_tower_desc {
     int32_t forward_only;
     int32_t reserved_;
     void* wpack;
+    /* Dropout drawn inside the kernels instead of read from drop_mask (default arithmetic only;
+     * where drop_mask[l] is given it wins): drop_seed = device pointer to one uint64 the caller
+     * draws per forward (NULL: off), drop_p = nn.Dropout's p.  The multiplier of element
+     * (layer, row, feature) is a hash of (seed, layer, row, feature): 0 with probability p
+     * (to 2^-16), else 1 / (1 - p) -- the backward, given the same descriptor fields, regenerates
+     * it.  A forward / backward that cannot run on the operand-plane kernels
+     * (abn_tower_uses_planes) returns ABN_E_UNSUPPORTED when only a seed is given. */
+    const void* drop_seed;
+    float drop_p;
+    int32_t reserved2_;
 } abn_tower_desc;
 
 /* Workspace of one forward call (what the backward needs: the saved activations, for the

@@ -310,3 +310,70 @@ def test_persistent_weight_image_follows_every_kind_of_update(oname, monkeypatch
     assert rel_err(outs[0][1], outs[1][1]) < 1e-6
     for k in outs[0][2]:
         assert rel_err(outs[0][2][k], outs[1][2][k]) < 1e-6, k
+
+
+@pytest.mark.parametrize('precision,NP', [('bf16x3', 3)])
+def test_dropout_drawn_inside_the_kernels(precision, NP, monkeypatch):
+    """p_dropout > 0 without mask tensors (abn_tower_desc.drop_seed): the multipliers are a hash of (seed, layer,
+    row, feature) evaluated in the forward epilogue and again in the backward.  Recovered from the activations
+    (tanh(z m) = 0 exactly where m = 0), they must (i) be Bernoulli(1 - p) / (1 - p), (ii) reproduce the embeddings
+    through the oracle, (iii) be the ones the backward used: its gradients equal the oracle's with those masks,
+    (iv) differ from one forward to the next."""
+    import abnet3_amd.loss as L
+    from abnet3_amd import _lib
+    from oracle import siamese_np as O
+    pdrop = 0.3
+    kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=96, output_dim=36, activation_layer='tanh',
+              p_dropout=pdrop, batch_norm=False)
+    net, spec, p = build(kw, seed=12, precision=precision)
+    lib = _lib.load()
+    fn = lib.abn_debug_planes_offset
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    B = 200
+    R = 2 * B
+    dims = [40, 96, 96, 96, 36]
+    rng = np.random.default_rng(12)
+    x1n, x2n = rng.standard_normal((B, 40)).astype(np.float32), rng.standard_normal((B, 40)).astype(np.float32)
+    y = rng.choice([1, -1], B)
+    net.train()
+    seen = []
+    for rep in range(2):
+        for q in net.parameters():
+            q.grad = None
+        emb, state = net.direct_forward(dev(x1n), dev(x2n))
+        seg, sv, gp = state
+        assert type(sv.masks).__name__ == '_DropSeed'
+        lv = net.direct_backward_loss(state, dev(y), 'coscos2', 0.0, False)
+        assert lv is not None
+        torch.cuda.synchronize()
+        desc = seg.descriptor(False)
+        ws16 = sv.ws.view(torch.int16).cpu().numpy().view(np.uint16)
+        row_steps = (R + 31) // 32 * 2
+        masks = []
+        for l in range(3):          # hidden activations live in the transposed image of the next layer's input
+            d = decode_t(ws16[2 * fn(ctypes.byref(desc), R, 2, 2, l + 1):], (dims[l + 1] + 1 + 31) // 32, row_steps, NP)
+            masks.append((d[:dims[l + 1], :R].T != 0).astype(np.float32) / (1 - pdrop))
+        e = emb.cpu().numpy()
+        masks.append((e != 0).astype(np.float32) / (1 - pdrop))
+        for m in masks:
+            frac = float((m == 0).mean())
+            assert abs(frac - pdrop) < 4 * np.sqrt(pdrop * (1 - pdrop) / m.size) + 1e-3, frac
+        seen.append(masks)
+        o1, c1 = O.tower_forward(p, x1n, spec, True, masks=[m[:B] for m in masks])
+        o2, c2 = O.tower_forward(p, x2n, spec, True, masks=[m[B:] for m in masks])
+        assert rel_err(e[:B], o1) < 1e-5 and rel_err(e[B:], o2) < 1e-5
+        ol, d1, d2, _ = O.pair_loss(o1, o2, y, 'coscos2', 0.5, False)
+        assert abs(float(lv) - ol) <= 1e-5 * abs(ol) + 1e-6
+        og = {}
+        O.tower_backward(p, c1, d1, spec, og)
+        O.tower_backward(p, c2, d2, spec, og)
+        check_grads({k: q.grad.cpu().numpy() for k, q in net.named_parameters()}, og, spec.param_keys(), False, tol=1e-4)
+    assert any((a != b).any() for a, b in zip(*seen))
+    # the autograd path and the per-layer GEMM path (mask tensors) still train
+    e1, e2 = net(dev(x1n), dev(x2n))
+    L.coscos2(avg=False)(e1, e2, dev(y)).backward()
+    monkeypatch.setenv('ABN_PLANES', '0')
+    e1, e2 = net(dev(x1n), dev(x2n))
+    L.coscos2(avg=False)(e1, e2, dev(y)).backward()
+    assert all(torch.isfinite(q.grad).all() for q in net.parameters())

@@ -323,7 +323,7 @@ def test_dropout_masks_forward_backward_vs_oracle(bn, forward_path):
     assert rel_err(ev.cpu().numpy(), oe) < TOL
     # the generator: zeros with probability p, survivors scaled by 1/(1-p)
     net._mask_override = None
-    drawn = net._draw_dropout_masks(4096, torch.device('cuda'))
+    drawn = net._draw_mask_tensors(4096, torch.device('cuda'))          # (the tensor form: per-layer path)
     for m in drawn:
         frac = float((m == 0).float().mean())
         assert abs(frac - 0.25) < 0.01
