@@ -1,5 +1,5 @@
 """Decodes the operand-fragment images of tower_planes.h from a forward workspace / backward scratch and compares
-them with the tensors they were made from (diagnostic; used by tests/test_gpu_planes.py and tools/planes_check2.py)."""
+them with the tensors they were made from (used by tests/test_gpu_planes.py)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,5 @@
 """Phase cycles of the producer / consumer DTW kernel (library built with -DABN_DTW_STAMPS:
-tools/dtw_variants.sh "-DABN_DTW_STAMPS"; run with ABNET3_HIP_LIB=tools/variants/lib_ABN_DTW_STAMPS.so)."""
+tools/variants.sh dtw "-DABN_DTW_STAMPS"; run with ABNET3_HIP_LIB=tools/variants/lib_ABN_DTW_STAMPS.so)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
