@@ -1,5 +1,5 @@
 // sustained v_mfma_f32_32x32x16_bf16 rate with every SIMD busy (what clock the chip holds under MFMA load)
-//   hipcc -O3 --offload-arch=gfx950 -o mfma_peak mfma_peak.hip && ./mfma_peak
+//   hipcc -O3 --offload-arch=gfx950 -o tools/probes/mfma_peak tools/probes/mfma_peak.hip && tools/probes/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
