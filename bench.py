@@ -334,15 +334,17 @@ def make_stepper(trainer, pool, use_graph):
 
 def variants_bench(torch, pool, args, rank, world):
     """SURVEY.md 8d also lists the C2 step with BatchNorm on, and with the trainer's
-    class-default optimizer SGD(0.001, 0.9): same workload, shorter runs, reported
-    beside the headline (canonical: no BatchNorm, Adadelta(0.1))."""
+    class-default optimizer SGD(0.001, 0.9); the third variant is the model's class-default
+    p_dropout = 0.1: same workload, shorter runs, reported beside the headline (canonical:
+    no BatchNorm, no dropout, Adadelta(0.1))."""
     from abnet3_amd.model import SiameseNetwork
     from abnet3_amd.loss import coscos2
     from abnet3_amd.trainer import TrainerSiamese
     out = {}
-    for name, bn, opt, lr in (('batch_norm_adadelta', True, 'adadelta', 0.1), ('no_bn_sgd', False, 'sgd', 0.001)):
+    for name, bn, opt, lr, pdrop in (('batch_norm_adadelta', True, 'adadelta', 0.1, 0.0), ('no_bn_sgd', False, 'sgd', 0.001, 0.0),
+                                     ('dropout_0.1_adadelta', False, 'adadelta', 0.1, 0.1)):      # (0.1: the reference's default p_dropout)
         torch.manual_seed(0)
-        net = SiameseNetwork(output_path='/tmp/abnet3_bench_v%d' % rank, **dict(C2, batch_norm=bn))
+        net = SiameseNetwork(output_path='/tmp/abnet3_bench_v%d' % rank, **dict(C2, batch_norm=bn, p_dropout=pdrop))
         tr = TrainerSiamese(network=net, loss=coscos2(avg=False), optimizer_type=opt, lr=lr,
                             dataloader=None, log_dir='/tmp/abnet3_bench_runs')
         net.train()
