@@ -377,3 +377,31 @@ def test_dropout_drawn_inside_the_kernels(precision, NP, monkeypatch):
     e1, e2 = net(dev(x1n), dev(x2n))
     L.coscos2(avg=False)(e1, e2, dev(y)).backward()
     assert all(torch.isfinite(q.grad).all() for q in net.parameters())
+
+
+def test_two_seeded_runs_are_bit_identical():
+    """A race detector (tools/soak.py in small): the same seeded C2-shaped training run twice -- dropout drawn in
+    the kernels, fused loss, deferred slab sum -- must produce bit-identical losses and parameters (every reduction
+    in these kernels has a fixed order; nothing accumulates through atomics)."""
+    import abnet3_amd.loss as L
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.trainer import TrainerSiamese
+    kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=500, output_dim=100, activation_layer='sigmoid',
+              p_dropout=0.1, batch_norm=False)
+    rng = np.random.default_rng(5)
+    B = 1024
+    pool = [(dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32)),
+             dev(rng.choice([1, -1], B))) for _ in range(3)]
+    outs = []
+    for run in range(2):
+        torch.manual_seed(0)
+        torch.cuda.manual_seed(0)
+        net = SiameseNetwork(output_path='/tmp/abn_det', **kw)
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1, dataloader=None,
+                            log_dir='/tmp/abn_runs')
+        net.train()
+        losses = torch.stack([tr.train_step(pool[i % 3], True) for i in range(60)])
+        assert torch.isfinite(losses).all()
+        outs.append((losses, [q.detach().clone() for q in net.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
