@@ -486,13 +486,16 @@ struct Layout {
 };
 
 static inline int planes_of(int precision) { return precision == 2 ? 3 : 1; }
-static bool planes_shape_ok(const abn_tower_desc* t)
+// the operand-plane kernels (tower_planes.h) take this tower's arithmetic and widths; with BatchNorm only
+// its inference forward (running statistics: a per-feature affine map in the epilogue)
+static bool planes_dims_ok(const abn_tower_desc* t)
 {
-    if (t->batch_norm || t->precision < 1) return false;
+    if (t->precision < 1) return false;
     for (int l = 0; l <= t->n_layers; ++l)
         if (t->dims[l] < 4 || t->dims[l] > PL_MAXW || t->dims[l] % 4 != 0) return false;
     return true;
 }
+static bool planes_shape_ok(const abn_tower_desc* t) { return !t->batch_norm && planes_dims_ok(t); }
 
 // The weights as operand fragments: W_l and W_l^T for every layer, in a caller-owned persistent buffer
 // (abn_tower_desc.wpack) or inside the forward's workspace.  Byte offsets from the image's base.
@@ -500,7 +503,7 @@ struct PackLayout { int64_t wp[ABN_MAX_LAYERS], wpt[ABN_MAX_LAYERS], bytes; };
 static PackLayout make_pack_layout(const abn_tower_desc* t)
 {
     PackLayout P = {};
-    if (!planes_shape_ok(t)) return P;
+    if (!planes_dims_ok(t)) return P;
     const int np = planes_of(t->precision);
     int64_t o = 0;
     for (int l = 0; l < t->n_layers; ++l) {
@@ -537,10 +540,10 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
     }
     for (int l = 0; l < t->n_layers; ++l) L.tp[l] = -1;
     L.wpack = -1;
-    if (planes_shape_ok(t)) {
+    if (planes_dims_ok(t)) {
         const int np = planes_of(t->precision);
         L.wpack = take(make_pack_layout(t).bytes / 4);
-        if (!t->forward_only)                    // (last in the workspace: an inference call simply asks for less)
+        if (!t->forward_only && !t->batch_norm)                    // (last in the workspace: an inference call simply asks for less)
             for (int l = 0; l < t->n_layers; ++l) L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, rows, np) / 4);
     }
     L.total = o;
@@ -550,7 +553,9 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
 // Whether the planes kernels (tower_planes.h) take a call.  Forward and backward must agree (the forward then
 // leaves the hidden activations in the transposed images only): both ask here.
 // (the switches are read per call: tests flip them inside one process)
-static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws)
+enum { PLANES_TRAIN = 0, PLANES_EVAL_FORWARD = 1 };      // a forward in train mode or any backward | a forward with train == 0
+static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws,
+                        int mode = PLANES_TRAIN)
 {
     if (getenv("ABN_PLANES") && atoi(getenv("ABN_PLANES")) == 0) return false;
     if (getenv("ABN_FUSED") && atoi(getenv("ABN_FUSED")) == 0) return false;
@@ -558,7 +563,9 @@ static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, 
     // up that beats the per-layer GEMMs (tools/rows_sweep.py, tools/fwd_rows_sweep.py: C2 train step 0.148 vs
     // 0.180 ms at 512 rows, 0.234 vs 0.331 at 8192; forward alone 62 vs 94 us at 5000 rows)
     const int64_t min_rows = getenv("ABN_FUSED_MIN_ROWS") ? atoll(getenv("ABN_FUSED_MIN_ROWS")) : 256;
-    if (rows < min_rows || rows > (1LL << 20) || !planes_shape_ok(t)) return false;      // (32-bit byte offsets inside one image)
+    if (rows < min_rows || rows > (1LL << 20)) return false;                                // (32-bit byte offsets inside one image)
+    // BatchNorm: only the inference forward (running statistics), and only when no backward will follow
+    if (!(mode == PLANES_EVAL_FORWARD && t->forward_only ? planes_dims_ok(t) : planes_shape_ok(t))) return false;
     if (!aligned16(x1) || (x2 && !aligned16(x2)) || !aligned16(ws)) return false;
     for (int l = 0; l < t->n_layers; ++l)
         if (!aligned16(t->W[l]) || !aligned16(t->b[l]) || (t->drop_mask[l] && !aligned16(t->drop_mask[l]))) return false;
@@ -824,10 +831,16 @@ int64_t abn_debug_planes_offset(const abn_tower_desc* t, int64_t rows, int64_t n
     return (t->wpack ? 0 : L.wpack) + (which == 0 ? P.wp[l] : P.wpt[l]) / 4;
 }
 
-int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws)
+// Diagnostics / tests only (not in the header): which kernels the calling thread's last abn_tower_forward
+// launched -- 0 per-layer, 1 the fp32 fused tower, 2 / 3 / 4 the operand-plane tower: for a backward,
+// inference, inference with BatchNorm.
+static thread_local int last_forward_path = -1;
+int abn_debug_last_forward_path(void) { return last_forward_path; }
+
+int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws, int train)
 {
     if (check_desc(t, rows, 1) != ABN_OK) return -1;
-    return planes_path(t, rows, x1, x2, ws) ? 1 : 0;
+    return planes_path(t, rows, x1, x2, ws, train ? PLANES_TRAIN : PLANES_EVAL_FORWARD) ? 1 : 0;
 }
 
 int64_t abn_tower_wpack_floats(const abn_tower_desc* t)
@@ -872,11 +885,12 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         fusable = t->dims[l] >= 4 && t->dims[l] <= FUSED_MAXW && t->dims[l] % 4 == 0;
     for (int l = 0; l < t->n_layers && fusable; ++l)
         fusable = aligned16(t->W[l]) && (!t->drop_mask[l] || !train || aligned16(t->drop_mask[l]));
-    if (t->drop_seed && train && !planes_path(t, rows, x1, x2, ws)) {
+    const int pmode = train ? PLANES_TRAIN : PLANES_EVAL_FORWARD;
+    if (t->drop_seed && train && !planes_path(t, rows, x1, x2, ws, pmode)) {
         for (int l = 0; l < t->n_layers; ++l)
             if (!t->drop_mask[l]) { set_error("tower_forward: in-kernel dropout (drop_seed) needs the operand-plane kernels: pass drop_mask tensors"); return ABN_E_UNSUPPORTED; }
     }
-    if (planes_path(t, rows, x1, x2, ws)) {
+    if (planes_path(t, rows, x1, x2, ws, pmode)) {
         const int np = planes_of(t->precision);
         PackTable pk = {};
         PlanesFwdP f = {};
@@ -909,11 +923,13 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 T.tile0 = pk.n_tiles; T.dst = PL.wpt[l];
                 pk.n_tiles += T.nblk * T.nsteps;
             }
-            f.tp[l] = t->forward_only ? nullptr : reinterpret_cast<char*>(ws + L.tp[l]);     // (inference: nothing kept for a backward)
+            f.tp[l] = (t->forward_only || t->batch_norm) ? nullptr : reinterpret_cast<char*>(ws + L.tp[l]);     // (inference: nothing kept for a backward)
+            if (t->batch_norm) { f.bn_rm[l] = t->bn_rm[l]; f.bn_rv[l] = t->bn_rv[l]; f.bn_w[l] = t->bn_w[l]; f.bn_b[l] = t->bn_b[l]; }
         }
         f.tp_steps = pl_row_steps(rows);
         f.drop_seed = train ? reinterpret_cast<const unsigned long long*>(t->drop_seed) : nullptr;
         f.drop_p = t->drop_p;
+        f.bn_eps = BN_EPS;
 #ifdef ABN_STAMPS
         f.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
 #endif
@@ -921,22 +937,31 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         int dev = 0;
         (void)hipGetDevice(&dev);
         dev = (dev >= 0 && dev < 16) ? dev : 0;
+        // inference (no mask, no seed, nothing kept for a backward) has its own, lighter instantiations
+        const bool infer = t->batch_norm || (t->forward_only && !f.drop_seed && !train);
+        const int mode = t->batch_norm ? PL_INFER_BN : infer ? PL_INFER : PL_TRAIN;
+        const size_t lds = t->batch_norm ? pl_lds_bytes_bn(np) : pl_lds_bytes(np);
+        const void* kernels[2][3] = {
+            {reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_TRAIN>), reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_INFER>),
+             reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_INFER_BN>)},
+            {reinterpret_cast<const void*>(tower_fwd_planes_kernel<3, PL_TRAIN>), reinterpret_cast<const void*>(tower_fwd_planes_kernel<3, PL_INFER>),
+             reinterpret_cast<const void*>(tower_fwd_planes_kernel<3, PL_INFER_BN>)}};
         if (!pl_attr_set[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_planes_kernel<1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(1));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_planes_kernel<3>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(3));
+            for (int a = 0; a < 2; ++a)
+                for (int m = 0; m < 3; ++m)
+                    (void)hipFuncSetAttribute(kernels[a][m], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)(m == PL_INFER_BN ? pl_lds_bytes_bn(a ? 3 : 1) : pl_lds_bytes(a ? 3 : 1)));
             pl_attr_set[dev] = true;
         }
         const dim3 pgrid((unsigned)((pk.n_tiles + 3) / 4));
         const dim3 fgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
-        if (np == 3) {
-            if (repack) hipLaunchKernelGGL(pack_planes_kernel<3>, pgrid, dim3(256), 0, st, pk);
-            hipLaunchKernelGGL(tower_fwd_planes_kernel<3>, fgrid, dim3(PL_NT), pl_lds_bytes(3), st, f);
-        } else {
-            if (repack) hipLaunchKernelGGL(pack_planes_kernel<1>, pgrid, dim3(256), 0, st, pk);
-            hipLaunchKernelGGL(tower_fwd_planes_kernel<1>, fgrid, dim3(PL_NT), pl_lds_bytes(1), st, f);
+        if (repack) {
+            if (np == 3) hipLaunchKernelGGL(pack_planes_kernel<3>, pgrid, dim3(256), 0, st, pk);
+            else hipLaunchKernelGGL(pack_planes_kernel<1>, pgrid, dim3(256), 0, st, pk);
         }
+        void* kargs[] = {&f};
+        (void)hipLaunchKernel(kernels[np == 3][mode], fgrid, dim3(PL_NT), kargs, lds, st);
+        last_forward_path = 2 + mode;
         ABN_CHECK_LAUNCH("tower_fwd_planes");
         return ABN_OK;
     }
@@ -976,6 +1001,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         else if (f.bf16 == 2) hipLaunchKernelGGL(tower_fwd_fused_kernel<2>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
         else hipLaunchKernelGGL(tower_fwd_fused_kernel<0>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
         ABN_CHECK_LAUNCH("tower_fwd_fused");
+        last_forward_path = 1;
         return ABN_OK;
     }
 
@@ -1028,6 +1054,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         }
         in = a;
     }
+    last_forward_path = 0;
     return ABN_OK;
 }
 

@@ -67,6 +67,8 @@ template <int NP> constexpr int tile_bytes() { return NP == 3 ? 2048 : 1024; }
 static inline int64_t pl_timage_bytes(int64_t features, int64_t rows, int np) { return (int64_t)pl_blocks(features) * pl_row_steps(rows) * (np == 3 ? 2048 : 1024); }
 constexpr int PL_BIAS_BYTES = PL_WAVES * 64 * 4;   // a wave's 64 bias values, parked in LDS across its k-loop
 static inline size_t pl_lds_bytes(int np) { return (size_t)PL_MAXSTEPS * np * 1024 + PL_PART_BYTES + PL_BIAS_BYTES; }
+// the inference forward of a BatchNorm tower parks four more per-feature vectors beside the bias
+static inline size_t pl_lds_bytes_bn(int np) { return pl_lds_bytes(np) + 4 * PL_BIAS_BYTES; }
 
 #ifdef ABN_STAMPS
 #define PSTAMPF(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 128 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -393,6 +395,13 @@ struct PlanesFwdP {
     int64_t tp_steps;              // row steps of those images (pl_row_steps(rows))
     const unsigned long long* drop_seed;   // in-kernel dropout for the layers without a mask tensor (null: off)
     float drop_p;
+    // BatchNorm with running statistics (the BN instantiation only: inference), after the bias and before the
+    // activation, the arithmetic of bn_apply_kernel's eval branch (tower.hip): ((z - rm) / sqrt(rv + eps)) gamma + beta
+    const float* bn_rm[ABN_MAX_LAYERS];
+    const float* bn_rv[ABN_MAX_LAYERS];
+    const float* bn_w[ABN_MAX_LAYERS];
+    const float* bn_b[ABN_MAX_LAYERS];
+    float bn_eps;
 #ifdef ABN_STAMPS
     unsigned long long* stamps;
 #endif
@@ -400,10 +409,14 @@ struct PlanesFwdP {
 
 // One layer for one workgroup.  img holds the input fragments of all pl_steps(K) steps (zero in
 // the padding); on return it holds this layer's output the same way, for pl_steps(N) steps.
-template <int NP, int BPW, int KS>
+// MODE: what the forward is for.  The inference instantiations compile the dropout and the transposed
+// images out (their loop-invariant address and mask registers are what fills the register file).
+enum { PL_TRAIN = 0, PL_INFER = 1, PL_INFER_BN = 2 };
+template <int NP, int BPW, int KS, int MODE = PL_TRAIN>
 __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* __restrict__ img,
                                              float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0)
 {
+    constexpr bool BN = MODE == PL_INFER_BN, INFER = MODE != PL_TRAIN;
     const int K = p.dims[l], N = p.dims[l + 1];
     const int nsteps = pl_steps(K), nblk = (N + 31) / 32;
     const int r = lane & 31, h = lane >> 5;
@@ -422,11 +435,15 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     // The bias: ONE value per lane (feature 32 blk0 + lane of the wave's up to 64), requested before the
     // k-loop, parked in a per-wave LDS slot after it and read back as the 16-byte pieces the
     // accumulator layout wants (32 registers held across the k-loop spilled the bf16 x 3 kernel).
-    float bias_lane = 0.0f;
+    float bias_lane = 0.0f, bn_lane[4] = {0.0f, 1.0f, 1.0f, 0.0f};      // running mean, running variance, gamma, beta
     {
         const float* __restrict__ bias = p.b[l];
         const int n = 32 * blk0 + lane;
         if (bias && ws.active && lane < 32 * BPW) bias_lane = bias[n < N ? n : N - 1];
+        if (BN && ws.active && lane < 32 * BPW) {
+            const int nc = n < N ? n : N - 1;
+            bn_lane[0] = p.bn_rm[l][nc]; bn_lane[1] = p.bn_rv[l][nc]; bn_lane[2] = p.bn_w[l][nc]; bn_lane[3] = p.bn_b[l][nc];
+        }
     }
     if (ws.active) planes_kloop<NP, BPW>(acc, p.wp[l], nblk, nsteps, img, blk0, ws.s_first, ws.my_steps, lane);
     PSTAMPF(3 + 5 * l);
@@ -434,13 +451,19 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     // epilogue.  Register q of block j is output feature 32 (blk0 + j) + (q & 3) + 8 (q >> 2) + 4 h of
     // batch row r: registers 4g .. 4g+3 are four consecutive features (one 16-byte piece of the
     // row-major output), registers 8t .. 8t+7 the lane's operand of step 2 blk + t of the next layer.
-    const float* __restrict__ mask = p.mask[l];
-    const DropGen drop = make_drop(mask ? nullptr : p.drop_seed, p.drop_p, l);
+    const float* __restrict__ mask = INFER ? nullptr : p.mask[l];
+    const DropGen drop = make_drop(INFER || mask ? nullptr : p.drop_seed, p.drop_p, l);
     const bool masked = mask || drop.on;
     const int gr = row0 + r;
     const bool row_ok = gr < p.rows;
     float* const bias_s = part + PL_PART_BYTES / 4 + wave * 64;
     bias_s[lane] = bias_lane;
+    if (BN) {
+        bias_s[PL_BIAS_BYTES / 4 + lane] = bn_lane[0];
+        bias_s[2 * (PL_BIAS_BYTES / 4) + lane] = 1.0f / sqrtf(bn_lane[1] + p.bn_eps);
+        bias_s[3 * (PL_BIAS_BYTES / 4) + lane] = bn_lane[2];
+        bias_s[4 * (PL_BIAS_BYTES / 4) + lane] = bn_lane[3];
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");        // (this wave's own LDS accesses complete in order)
     __builtin_amdgcn_wave_barrier();
     f32x4 mv[BPW][4];
@@ -465,13 +488,27 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
                     f32x4 m4 = {1.f, 1.f, 1.f, 1.f};
                     if (mask) m4 = mv[j][g];
                     else if (drop.on) m4 = drop4(drop, gr, 32 * (blk0 + j) + 4 * h + 8 * g);
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + 32 * j + 4 * h + 8 * g);
+                    int so = 32 * j + 4 * h + 8 * g;
+                    // (the BN vectors of all eight groups, hoisted above the activation switch as common code,
+                    // are 160 registers: an opaque offset keeps each group's reads where they are used)
+                    if (BN) asm volatile("" : "+v"(so));
+                    const float* const slot = bias_s + so;
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(slot);
+                    f32x4 mu4 = {}, is4 = {}, ga4 = {}, be4 = {};
+                    if (BN) {
+                        mu4 = *reinterpret_cast<const f32x4*>(slot + PL_BIAS_BYTES / 4);
+                        is4 = *reinterpret_cast<const f32x4*>(slot + 2 * (PL_BIAS_BYTES / 4));
+                        ga4 = *reinterpret_cast<const f32x4*>(slot + 3 * (PL_BIAS_BYTES / 4));
+                        be4 = *reinterpret_cast<const f32x4*>(slot + 4 * (PL_BIAS_BYTES / 4));
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[j][4 * g + e] + b4[e];
+                        if (BN) v = ((v - mu4[e]) * is4[e]) * ga4[e] + be4[e];
                         if (masked) v *= m4[e];
                         acc[j][4 * g + e] = live ? act_apply(v, ACT) : 0.0f;
                     }
+                    if (BN) __builtin_amdgcn_sched_barrier(0);
                 }
         });
     };
@@ -490,7 +527,7 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
         finish();
     }
     float* __restrict__ out = p.out[l];
-    char* const tp = l + 1 < p.n_layers ? p.tp[l + 1] : nullptr;
+    char* const tp = !INFER && l + 1 < p.n_layers ? p.tp[l + 1] : nullptr;
     if (ws.active && ws.khalf == 0) {
 #pragma unroll
         for (int j = 0; j < BPW; ++j) {
@@ -529,9 +566,10 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     __syncthreads();
 }
 
-template <int NP>
+template <int NP, int MODE = PL_TRAIN>
 __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
 {
+    constexpr bool INFER = MODE != PL_TRAIN;
     extern __shared__ __attribute__((aligned(16))) char pl_smem[];
     char* const img = pl_smem;
     float* const part = reinterpret_cast<float*>(pl_smem + PL_MAXSTEPS * NP * 1024);
@@ -569,11 +607,11 @@ __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
             f[t2] = make_frag<NP>(v0, v1);
             store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
         }
-        if (p.tp[0] && kb < pl_blocks(D0 + 1))
+        if (!INFER && p.tp[0] && kb < pl_blocks(D0 + 1))
             emit_planes<NP>(p.tp[0] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
                             kb == D0 / 32 ? D0 % 32 : -1, p.rows - row0);
     }
-    if (p.tp[0] && pl_blocks(D0 + 1) > blocks0 && wave == PL_WAVES - 1) {     // D0 % 32 == 0 and no padding block to hold the ones
+    if (!INFER && p.tp[0] && pl_blocks(D0 + 1) > blocks0 && wave == PL_WAVES - 1) {     // D0 % 32 == 0 and no padding block to hold the ones
         Frag<NP> z[2] = {};
         emit_planes<NP>(p.tp[0] + ((int64_t)(D0 / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, p.rows - row0);
     }
@@ -582,9 +620,9 @@ __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
 
     for (int l = 0; l < p.n_layers; ++l) {
         const int nblk = (p.dims[l + 1] + 31) / 32;
-        if (nblk > PL_WAVES) planes_layer<NP, 2, 1>(p, l, img, part, idf, wave, lane, row0);
-        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1>(p, l, img, part, idf, wave, lane, row0);
-        else planes_layer<NP, 1, 2>(p, l, img, part, idf, wave, lane, row0);
+        if (nblk > PL_WAVES) planes_layer<NP, 2, 1, MODE>(p, l, img, part, idf, wave, lane, row0);
+        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, MODE>(p, l, img, part, idf, wave, lane, row0);
+        else planes_layer<NP, 1, 2, MODE>(p, l, img, part, idf, wave, lane, row0);
     }
     PSTAMPF(2 + 5 * p.n_layers);
 }

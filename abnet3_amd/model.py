@@ -283,7 +283,7 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
     if isinstance(masks, _DropoutInKernel):
         # drawn inside the kernels where they are the operand-plane ones, as tensors for the per-layer path
         probe = seg.descriptor(with_grads=False)
-        if lib.abn_tower_uses_planes(_lib.C.byref(probe), rows, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(x1)) == 1:
+        if lib.abn_tower_uses_planes(_lib.C.byref(probe), rows, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(x1), 1) == 1:
             masks = _DropSeed(masks.p, x1.device)
         else:
             masks = seg.masks_of(masks.net._draw_mask_tensors(rows, x1.device))
@@ -297,7 +297,7 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
                                      _lib.stream()), 'abn_tower_forward')
     if desc.wpack and not desc.wpack_valid and seg._key_at_descriptor is not None:
         # the operand-plane kernels rebuilt the persistent weight image (the per-layer path never touches it)
-        if lib.abn_tower_uses_planes(_lib.C.byref(desc), rows, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(ws)) == 1:
+        if lib.abn_tower_uses_planes(_lib.C.byref(desc), rows, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(ws), int(train)) == 1:
             seg.wpack_matches(seg._key_at_descriptor)
     if train and seg.batch_norm:        # one launch for all the counters
         torch._foreach_add_([bn.num_batches_tracked for bn in seg.bn_modules()], n_calls)
@@ -342,14 +342,17 @@ class _TowerFunction(torch.autograd.Function):
     """One launch sequence for n_calls forward_once calls of one segment."""
 
     @staticmethod
-    def forward(ctx, seg, grad_pass, all_masks, n_calls, split, x1, x2, *params):
+    def forward(ctx, seg, grad_pass, all_masks, n_calls, split, infer, x1, x2, *params):
         # parameters are views of the flat buffer (dense by construction); only the
         # device is checked here
         for p_ in params:
             if not p_.is_cuda:
                 _lib.require_device(p_)
-        # nothing requires a gradient (torch.no_grad(), frozen parameters): inference, the library keeps nothing for a backward
-        out, sv = _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=not any(ctx.needs_input_grad))
+        # nothing requires a gradient (torch.no_grad() -- needs_input_grad does not see it, and grad mode is
+        # always off in here: the caller passes it -- or frozen parameters): inference, the library keeps
+        # nothing for a backward
+        out, sv = _segment_forward(seg, all_masks, n_calls, x1, x2,
+                                   forward_only=infer or not any(ctx.needs_input_grad))
         ctx.seg, ctx.grad_pass, ctx.sv = seg, grad_pass, sv
         ctx.have_x2 = x2 is not None
         ctx.split = split
@@ -378,7 +381,7 @@ class _TowerFunction(torch.autograd.Function):
                 d_out = torch.cat([d1, d2])
         else:
             d_out = d_outs[0]
-        need_dx = ctx.needs_input_grad[5] or (ctx.have_x2 and ctx.needs_input_grad[6])
+        need_dx = ctx.needs_input_grad[6] or (ctx.have_x2 and ctx.needs_input_grad[7])
         grads, dx = _segment_backward(seg, ctx.sv, d_out, ctx.grad_pass, need_dx)
         dx1 = dx2 = None
         if need_dx:
@@ -387,7 +390,7 @@ class _TowerFunction(torch.autograd.Function):
                 dx1, dx2 = dx[:rows // 2], dx[rows // 2:]
             else:
                 dx1 = dx
-        return (None, None, None, None, None, dx1, dx2) + tuple(grads)
+        return (None, None, None, None, None, None, dx1, dx2) + tuple(grads)
 
 
 class _SoftmaxRows(torch.autograd.Function):
@@ -595,7 +598,8 @@ class _HipNetwork(NetworkBuilder):
                                  % (seg.input_dim, tuple(x1.shape)))
             empty = x1.new_zeros((0, seg.output_dim))
             return (empty, empty.clone()) if split else empty
-        return _TowerFunction.apply(seg, grad_pass, masks, n_calls, split, x1, x2, *seg.params)
+        return _TowerFunction.apply(seg, grad_pass, masks, n_calls, split, not torch.is_grad_enabled(), x1, x2,
+                                    *seg.params)
 
     # HIP plumbing kept in __dict__ next to the reference's attributes: device
     # buffers, ctypes descriptors and caches -- not part of the description of the

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 12
+#define ABN_ABI_VERSION 13
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -139,12 +139,14 @@ int64_t abn_tower_out_offset(const abn_tower_desc* t, int64_t rows, int64_t n_ca
 int64_t abn_tower_bwd_scratch_floats(const abn_tower_desc* t, int64_t rows);
 /* Size of the optional abn_tower_desc.wpack buffer, in floats (0: this tower has no such image). */
 int64_t abn_tower_wpack_floats(const abn_tower_desc* t);
-/* 1 when abn_tower_forward / backward with these arguments run on the operand-plane kernels (the
- * ones that read, and with wpack_valid = 0 rebuild, wpack), 0 when on the per-layer GEMMs, < 0 on
- * a bad descriptor.  Depends on the descriptor, the row count, pointer alignment and the
- * library's environment switches. */
+/* 1 when abn_tower_forward(train) / the backward after it with these arguments run on the
+ * operand-plane kernels (the ones that read, and with wpack_valid = 0 rebuild, wpack), 0 when on
+ * the per-layer GEMMs, < 0 on a bad descriptor.  Depends on the descriptor, the row count, pointer
+ * alignment and the library's environment switches.  train = 0 asks about the inference forward:
+ * a batch_norm tower takes the operand-plane kernel there (forward_only descriptors: running
+ * statistics folded into the epilogue), and only there. */
 int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2,
-                          const float* ws);
+                          const float* ws, int train);
 
 /* SiameseNetwork.forward_once / forward, abnet3/model.py:179-196.
  * `rows` input rows in total, made of `n_calls` forward_once calls of

@@ -405,3 +405,87 @@ def test_two_seeded_runs_are_bit_identical():
         outs.append((losses, [q.detach().clone() for q in net.parameters()]))
     assert torch.equal(outs[0][0], outs[1][0])
     assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+
+
+@pytest.mark.parametrize('precision,tol', [('bf16x3', 1e-5), ('bf16', 3e-2)])
+@pytest.mark.parametrize('act', ['sigmoid', 'tanh', 'relu'])
+@pytest.mark.parametrize('shape', SHAPES[:5])
+def test_batch_norm_inference_forward_against_the_oracle(shape, act, precision, tol, monkeypatch):
+    """Embedding extraction from a BatchNorm tower (eval mode, no gradient wanted): the running statistics
+    are a per-feature affine map in the epilogue of the same single launch.  Against the numpy oracle and
+    against the per-layer kernels; a backward through it stays refused; train mode stays on the per-layer path."""
+    from oracle import siamese_np as O
+    from abnet3_amd import _lib
+    d_in, nh, hid, d_out, B = shape
+    kw = dict(input_dim=d_in, num_hidden_layers=nh, hidden_dim=hid, output_dim=d_out, activation_layer=act,
+              p_dropout=0.1, batch_norm=True)
+    net, _, _ = build(kw, seed=B + 1, precision=precision)
+    spec = O.TowerSpec(d_in, nh, hid, d_out, act, True)
+    rng = np.random.default_rng(B)
+    with torch.no_grad():           # statistics and affine parameters away from their initial 0 / 1
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                n = m.num_features
+                m.running_mean.copy_(dev(rng.standard_normal(n).astype(np.float32) * 0.3))
+                m.running_var.copy_(dev(rng.uniform(0.2, 3.0, n).astype(np.float32)))
+                m.weight.copy_(dev(rng.uniform(0.5, 1.5, n).astype(np.float32)))
+                m.bias.copy_(dev(rng.standard_normal(n).astype(np.float32) * 0.2))
+    p = {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}
+    x = rng.standard_normal((B, d_in)).astype(np.float32)
+    net.eval()
+    seg = net._segment_list()[0]
+    lib = _lib.load()
+    xd = dev(x)
+    probe = seg.descriptor(with_grads=False, forward_only=True)
+    assert lib.abn_tower_uses_planes(ctypes.byref(probe), B, _lib.ptr(xd), None, _lib.ptr(xd), 0) == 1
+    assert lib.abn_tower_uses_planes(ctypes.byref(probe), B, _lib.ptr(xd), None, _lib.ptr(xd), 1) == 0
+    probe = seg.descriptor(with_grads=False, forward_only=False)
+    assert lib.abn_tower_uses_planes(ctypes.byref(probe), B, _lib.ptr(xd), None, _lib.ptr(xd), 0) == 0
+    with torch.no_grad():
+        e = net.forward_once(xd).cpu().numpy()
+        assert lib.abn_debug_last_forward_path() == 4
+        e1, e2 = net(xd, dev(x[::-1].copy()))
+        assert lib.abn_debug_last_forward_path() == 4
+    monkeypatch.setenv('ABN_PLANES', '0')
+    with torch.no_grad():
+        ref = net.forward_once(xd).cpu().numpy()
+        assert lib.abn_debug_last_forward_path() == 0
+    monkeypatch.setenv('ABN_PLANES', '1')
+    o, _ = O.tower_forward(p, x, spec, False)
+    # (8-bit operands: the normalisation multiplies a layer's rounding error by up to gamma / sqrt(running_var))
+    tol = tol if precision == 'bf16x3' else 3 * tol
+    assert rel_err(e, o) < tol
+    assert rel_err(e, ref) < tol
+    assert rel_err(e1.cpu().numpy(), o) < tol and rel_err(e2.cpu().numpy(), o[::-1]) < tol
+    # the running statistics are inputs here: untouched
+    for k, v in net.state_dict().items():
+        assert np.array_equal(v.cpu().numpy(), p[k]), k
+    # with a gradient wanted the eval forward stays on the per-layer kernels (whose backward refuses, as before)
+    xg = xd.clone().requires_grad_(True)
+    eg = net.forward_once(xg)
+    assert lib.abn_debug_last_forward_path() == 0
+    assert rel_err(eg.detach().cpu().numpy(), ref) == 0.0
+    with pytest.raises(NotImplementedError):
+        eg.sum().backward()
+
+
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_inference_instantiation_equals_the_training_forward(shape, precision):
+    """torch.no_grad() forwards run the instantiation without dropout and transposed images: same arithmetic,
+    the same bits as the forward a backward will follow."""
+    d_in, nh, hid, d_out, B = shape
+    kw = dict(input_dim=d_in, num_hidden_layers=nh, hidden_dim=hid, output_dim=d_out, activation_layer='tanh',
+              p_dropout=0.0, batch_norm=False)
+    net, _, _ = build(kw, seed=B, precision=precision)
+    x = dev(np.random.default_rng(B).standard_normal((B, d_in)).astype(np.float32))
+    from abnet3_amd import _lib
+    lib = _lib.load()
+    for mode in (net.train, net.eval):
+        mode()
+        a = net.forward_once(x).detach()
+        assert lib.abn_debug_last_forward_path() == 2
+        with torch.no_grad():
+            b = net.forward_once(x)
+        assert lib.abn_debug_last_forward_path() == (2 if net.training else 3)
+        assert torch.equal(a, b)
