@@ -760,6 +760,13 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
         W.slab_off = B.off[l];
         n_wg += W.tiles_n * W.tiles_k * W.splits;
     }
+    // (ABN_WGRAD_XCD=0: workgroups in launch order, A/B measurements)
+    w.xcd_groups = !(getenv("ABN_WGRAD_XCD") && atoi(getenv("ABN_WGRAD_XCD")) == 0);
+    if (w.xcd_groups) {
+        int most = 0;
+        for (int x = 0; x < 8; ++x) most = wgrad_slots(w, x) > most ? wgrad_slots(w, x) : most;
+        n_wg = 8 * most;
+    }
     static bool bw_attr_set[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);

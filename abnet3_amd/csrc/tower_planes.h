@@ -969,7 +969,28 @@ struct WgradP {
     float* slabs;
     int64_t slab_stride;   // floats
     int64_t tp_steps;
+    int xcd_groups;        // workgroup -> (layer, slab, tile) through wgrad_place (0: in launch order, first_wg)
 };
+
+// Placement.  The tiles_n * tiles_k tiles of one (layer, slab) -- a group -- read the same row steps of the
+// same two operand images; workgroups b and b + 8 are observed to share an XCD (round-robin dispatch: speed
+// only, nothing depends on it), so a group's tiles sit at blockIdx.x = x + 8 (slot ...) of one x and the
+// XCD's L2 serves the re-reads.  Groups are dealt round-robin over the eight x in launch order (every XCD
+// gets the same mix of heavy and light groups, heavy first).  Grid = 8 x wgrad_slots(p, x) maximised over x.
+__host__ __device__ inline int wgrad_group_count(int g0, int splits, int x, int* first)
+{
+    *first = g0 + ((x - g0) & 7);                  // the layer's first group with index = x (mod 8)
+    return *first < g0 + splits ? (g0 + splits - 1 - *first) / 8 + 1 : 0;
+}
+static inline int wgrad_slots(const WgradP& p, int x)
+{
+    int slots = 0, g0 = 0, first;
+    for (int i = 0; i < p.n_layers; ++i) {
+        slots += wgrad_group_count(g0, p.L[i].splits, x, &first) * p.L[i].tiles_n * p.L[i].tiles_k;
+        g0 += p.L[i].splits;
+    }
+    return slots;
+}
 static inline void wgrad_shape(int nblk, int kblk, int* shape, int* bn, int* bk)
 {
     if (kblk <= 2) { *shape = 1; *bn = 8; *bk = 2; }
@@ -1222,13 +1243,33 @@ __global__ __launch_bounds__(PL_NT) void wgrad_planes_kernel(WgradP p)
     extern __shared__ __attribute__((aligned(16))) char wg_smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int li = 0;
-    while (li + 1 < p.n_layers && (int)blockIdx.x >= p.L[li + 1].first_wg) ++li;
+    int li = 0, tk, tn, split;
+    if (p.xcd_groups) {
+        const int x = blockIdx.x & 7;
+        int slot = blockIdx.x >> 3, g0 = 0;
+        for (;; ++li) {
+            if (li == p.n_layers) return;          // this x has fewer slots than the grid's eighth
+            int first;
+            const int G = p.L[li].tiles_n * p.L[li].tiles_k;
+            const int cnt = wgrad_group_count(g0, p.L[li].splits, x, &first);
+            if (slot < cnt * G) {
+                split = first - g0 + 8 * (slot / G);
+                slot %= G;
+                tk = slot % p.L[li].tiles_k;
+                tn = slot / p.L[li].tiles_k;
+                break;
+            }
+            slot -= cnt * G;
+            g0 += p.L[li].splits;
+        }
+    } else {
+        while (li + 1 < p.n_layers && (int)blockIdx.x >= p.L[li + 1].first_wg) ++li;
+        int local = blockIdx.x - p.L[li].first_wg;
+        tk = local % p.L[li].tiles_k; local /= p.L[li].tiles_k;
+        tn = local % p.L[li].tiles_n; local /= p.L[li].tiles_n;
+        split = local;
+    }
     const WgradLayer& L = p.L[li];
-    int local = blockIdx.x - L.first_wg;
-    const int tk = local % L.tiles_k; local /= L.tiles_k;
-    const int tn = local % L.tiles_n; local /= L.tiles_n;
-    const int split = local;
     const int s_begin = (int)(p.tp_steps * split / L.splits), s_end = (int)(p.tp_steps * (split + 1) / L.splits);
     if (L.shape == 0) wgrad_tile<NP, 2, 2, 4, 2>(p, L, wg_smem, 8 * tn, 4 * tk, s_begin, s_end, split, wave, lane);
     else if (L.shape == 1) wgrad_tile<NP, 1, 2, 8, 1>(p, L, wg_smem, 8 * tn, 2 * tk, s_begin, s_end, split, wave, lane);
