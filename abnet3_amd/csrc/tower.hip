@@ -398,6 +398,59 @@ __global__ void bn_stats_finish_kernel(const double* __restrict__ part, int nchu
     rv[c] = v_run;
 }
 
+// The same, from the per-workgroup statistics bn_fwd_layer_kernel leaves (tower_planes.h): 32 rows each,
+// sums shifted by the workgroup's first row c -- sum z = sd + 32 c, sum z^2 = sq + 2 c sd + 32 c^2 in float64.
+// A block = 64 columns x 8 groups of workgroups: every group adds its share in order, thread group 0 the
+// eight group sums in order (one thread per column walking 128 workgroups alone took 18 us).
+constexpr int BN_WG_GROUPS = 8;
+__global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
+    const float* __restrict__ part, int wgs_per_call, int64_t rows_per_call, int C, int n_calls, float* __restrict__ mean,
+    float* __restrict__ invstd, float* __restrict__ var_out, float* __restrict__ rm, float* __restrict__ rv)
+{
+    __shared__ double sa[BN_WG_GROUPS][64], sb[BN_WG_GROUPS][64];
+    const int tx = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const bool ok = c < C;
+    float m_run = 0.0f, v_run = 0.0f;
+    if (ok && kg == 0) { m_run = rm[c]; v_run = rv[c]; }
+    const float unb = rows_per_call > 1 ? (float)((double)rows_per_call / (double)(rows_per_call - 1)) : 1.0f;
+    const int per = (wgs_per_call + BN_WG_GROUPS - 1) / BN_WG_GROUPS;
+    for (int g = 0; g < n_calls; ++g) {
+        double a = 0.0, b = 0.0;
+        const int k0 = kg * per, k1 = min(k0 + per, wgs_per_call);
+        if (ok) {
+#pragma unroll 4
+            for (int k = k0; k < k1; ++k) {           // fixed order; the loads are independent
+                const float* src = part + (int64_t)(g * wgs_per_call + k) * (3 * PL_MAXW);
+                const double sd = src[c], sq = src[PL_MAXW + c], cc = src[2 * PL_MAXW + c];
+                a += sd + 32.0 * cc;
+                b += sq + 2.0 * cc * sd + 32.0 * cc * cc;
+            }
+        }
+        __syncthreads();                              // (the previous call's sums have been read)
+        sa[kg][tx] = a;
+        sb[kg][tx] = b;
+        __syncthreads();
+        if (ok && kg == 0) {
+            for (int k = 1; k < BN_WG_GROUPS; ++k) { a += sa[k][tx]; b += sb[k][tx]; }
+            const double n = (double)rows_per_call;
+            const double m = a / n;
+            double var = b / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const int64_t idx = (int64_t)g * C + c;
+            mean[idx] = (float)m;
+            var_out[idx] = (float)var;
+            invstd[idx] = 1.0f / sqrtf((float)var + BN_EPS);
+            m_run = (1.0f - BN_MOMENTUM) * m_run + BN_MOMENTUM * (float)m;
+            v_run = (1.0f - BN_MOMENTUM) * v_run + BN_MOMENTUM * ((float)var * unb);
+        }
+    }
+    if (ok && kg == 0) {
+        rm[c] = m_run;
+        rv[c] = v_run;
+    }
+}
+
 // backward: s1 = sum dy, s2 = sum dy * xhat per (call, column)
 __global__ void bn_bwd_finish_kernel(const double* __restrict__ part, int nchunks, int C, int n_calls,
                                      float* __restrict__ s1o, float* __restrict__ s2o)
@@ -482,6 +535,7 @@ struct Layout {
     // precision 1 / 2 without BN (tower_planes.h): the weights and their transposes as MFMA operand
     // fragments, and the weight-gradient operands [x | 1], [a_l | 1] as transposed planes
     int64_t wpack, tp[ABN_MAX_LAYERS];   // wpack: the PackLayout image (unless the caller keeps a persistent one)
+    int64_t bn_wg;                       // per-workgroup column statistics of bn_fwd_layer_kernel ([rows / 32][3][PL_MAXW])
     int64_t total;
 };
 
@@ -540,6 +594,8 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
     }
     for (int l = 0; l < t->n_layers; ++l) L.tp[l] = -1;
     L.wpack = -1;
+    L.bn_wg = -1;
+    if (planes_dims_ok(t) && t->batch_norm && !t->forward_only) L.bn_wg = take((rows / PL_ROWS + 1) * 3 * PL_MAXW);
     if (planes_dims_ok(t)) {
         const int np = planes_of(t->precision);
         L.wpack = take(make_pack_layout(t).bytes / 4);
@@ -570,6 +626,20 @@ static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, 
     for (int l = 0; l < t->n_layers; ++l)
         if (!aligned16(t->W[l]) || !aligned16(t->b[l]) || (t->drop_mask[l] && !aligned16(t->drop_mask[l]))) return false;
     return true;
+}
+
+// The training forward of a BatchNorm tower, one operand-plane launch per layer (bn_fwd_layer_kernel): same
+// conditions, whole workgroups per forward_once call, mask tensors for the dropout (the backward is the
+// per-layer one).  ABN_BN_PLANES=0: the per-layer kernels (A/B measurements).
+static bool bn_train_planes_path(const abn_tower_desc* t, int64_t rows, int64_t n_calls, const float* x1, const float* x2,
+                                 const float* ws)
+{
+    if (!t->batch_norm || t->forward_only) return false;
+    if (getenv("ABN_BN_PLANES") && atoi(getenv("ABN_BN_PLANES")) == 0) return false;
+    if ((rows / n_calls) % PL_ROWS != 0) return false;
+    abn_tower_desc u = *t;
+    u.batch_norm = 0;
+    return planes_path(&u, rows, x1, x2, ws);
 }
 
 static int check_desc(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
@@ -897,7 +967,8 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         for (int l = 0; l < t->n_layers; ++l)
             if (!t->drop_mask[l]) { set_error("tower_forward: in-kernel dropout (drop_seed) needs the operand-plane kernels: pass drop_mask tensors"); return ABN_E_UNSUPPORTED; }
     }
-    if (planes_path(t, rows, x1, x2, ws, pmode)) {
+    const bool bn_train = train && bn_train_planes_path(t, rows, n_calls, x1, x2, ws);
+    if (bn_train || planes_path(t, rows, x1, x2, ws, pmode)) {
         const int np = planes_of(t->precision);
         PackTable pk = {};
         PlanesFwdP f = {};
@@ -944,6 +1015,48 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         int dev = 0;
         (void)hipGetDevice(&dev);
         dev = (dev >= 0 && dev < 16) ? dev : 0;
+        const dim3 pgrid((unsigned)((pk.n_tiles + 3) / 4));
+        const dim3 fgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
+        if (repack) {
+            if (np == 3) hipLaunchKernelGGL(pack_planes_kernel<3>, pgrid, dim3(256), 0, st, pk);
+            else hipLaunchKernelGGL(pack_planes_kernel<1>, pgrid, dim3(256), 0, st, pk);
+        }
+        if (bn_train) {
+            static bool bn_attr_set[16] = {};
+            if (!bn_attr_set[dev]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_fwd_layer_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(1));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_fwd_layer_kernel<3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(3));
+                bn_attr_set[dev] = true;
+            }
+            f.x_copy = x2 ? ws + L.x : nullptr;                // the per-layer backward reads the concatenated input
+            f.bn_part = ws + L.bn_wg;
+            const int nl = t->n_layers;
+            for (int l = 0; l < nl; ++l) {
+                PlanesFwdP fl = f;
+                for (int i = 0; i < nl; ++i) { fl.tp[i] = nullptr; fl.out[i] = nullptr; }
+                fl.act[l] = ACT_NONE;                          // z_l leaves the launch as it is; act[l - 1] is applied on the way in
+                fl.out[l] = ws + L.xhat[l];                    // (z lands where xhat will live)
+                BnTrainP q = {};
+                q.l = l;
+                if (l > 0) { q.mean = ws + L.mean[l - 1]; q.invstd = ws + L.invstd[l - 1]; q.z_prev = ws + L.xhat[l - 1]; q.a_prev = ws + L.a[l - 1]; }
+                if (np == 3) hipLaunchKernelGGL(bn_fwd_layer_kernel<3>, fgrid, dim3(PL_NT), pl_lds_bytes(3), st, fl, q);
+                else hipLaunchKernelGGL(bn_fwd_layer_kernel<1>, fgrid, dim3(PL_NT), pl_lds_bytes(1), st, fl, q);
+                const int N = (int)t->dims[l + 1];
+                hipLaunchKernelGGL(bn_stats_finish_wg_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, ws + L.bn_wg,
+                                   (int)(rpc / PL_ROWS), rpc, N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l],
+                                   t->bn_rm[l], t->bn_rv[l]);
+            }
+            const int N = (int)t->dims[nl];
+            float* z = ws + L.xhat[nl - 1];
+            hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, z, rows, rpc, N, ws + L.mean[nl - 1],
+                               ws + L.invstd[nl - 1], t->bn_rm[nl - 1], t->bn_rv[nl - 1], 1, t->bn_w[nl - 1], t->bn_b[nl - 1],
+                               t->last_act, z, ws + L.a[nl - 1]);
+            ABN_CHECK_LAUNCH("tower_forward (BatchNorm, planes)");
+            last_forward_path = 5;
+            return ABN_OK;
+        }
         // inference (no mask, no seed, nothing kept for a backward) has its own, lighter instantiations
         const bool infer = t->batch_norm || (t->forward_only && !f.drop_seed && !train);
         const int mode = t->batch_norm ? PL_INFER_BN : infer ? PL_INFER : PL_TRAIN;
@@ -959,12 +1072,6 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                     (void)hipFuncSetAttribute(kernels[a][m], hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)(m == PL_INFER_BN ? pl_lds_bytes_bn(a ? 3 : 1) : pl_lds_bytes(a ? 3 : 1)));
             pl_attr_set[dev] = true;
-        }
-        const dim3 pgrid((unsigned)((pk.n_tiles + 3) / 4));
-        const dim3 fgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
-        if (repack) {
-            if (np == 3) hipLaunchKernelGGL(pack_planes_kernel<3>, pgrid, dim3(256), 0, st, pk);
-            else hipLaunchKernelGGL(pack_planes_kernel<1>, pgrid, dim3(256), 0, st, pk);
         }
         void* kargs[] = {&f};
         (void)hipLaunchKernel(kernels[np == 3][mode], fgrid, dim3(PL_NT), kargs, lds, st);

@@ -402,6 +402,9 @@ struct PlanesFwdP {
     const float* bn_w[ABN_MAX_LAYERS];
     const float* bn_b[ABN_MAX_LAYERS];
     float bn_eps;
+    // BatchNorm in training (bn_fwd_layer_kernel: one launch per layer, out[l] = the pre-normalisation z):
+    // per-workgroup column statistics of z, [workgroup][3][PL_MAXW] floats -- sum (z - c), sum (z - c)^2, c
+    float* bn_part;
 #ifdef ABN_STAMPS
     unsigned long long* stamps;
 #endif
@@ -411,12 +414,28 @@ struct PlanesFwdP {
 // the padding); on return it holds this layer's output the same way, for pl_steps(N) steps.
 // MODE: what the forward is for.  The inference instantiations compile the dropout and the transposed
 // images out (their loop-invariant address and mask registers are what fills the register file).
-enum { PL_TRAIN = 0, PL_INFER = 1, PL_INFER_BN = 2 };
+// PL_BN_TRAIN: one layer of a BatchNorm tower in training (the kernel ends after it: the batch statistics
+// span every workgroup's rows): the host asks for no activation and no transposed image; nothing is left in
+// img; the column statistics of the workgroup's 32 rows go to bn_part.
+enum { PL_TRAIN = 0, PL_INFER = 1, PL_INFER_BN = 2, PL_BN_TRAIN = 3 };
+
+// sum over the 32 lanes of a half wave, valid in its lanes 16..31 (DPP: two quad permutes, two row rotations,
+// row_bcast15 into the odd rows)
+__device__ __forceinline__ float half_wave_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));    // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));    // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));    // row_bcast15 -> rows 1, 3
+    return v;
+}
+
 template <int NP, int BPW, int KS, int MODE = PL_TRAIN>
 __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* __restrict__ img,
                                              float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0)
 {
-    constexpr bool BN = MODE == PL_INFER_BN, INFER = MODE != PL_TRAIN;
+    constexpr bool BN = MODE == PL_INFER_BN, INFER = MODE == PL_INFER || MODE == PL_INFER_BN, BNT = MODE == PL_BN_TRAIN;
     const int K = p.dims[l], N = p.dims[l + 1];
     const int nsteps = pl_steps(K), nblk = (N + 31) / 32;
     const int r = lane & 31, h = lane >> 5;
@@ -527,7 +546,38 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
         finish();
     }
     float* __restrict__ out = p.out[l];
-    char* const tp = !INFER && l + 1 < p.n_layers ? p.tp[l + 1] : nullptr;
+    char* const tp = !INFER && !BNT && l + 1 < p.n_layers ? p.tp[l + 1] : nullptr;
+    if (BNT && ws.active && ws.khalf == 0) {
+        // Column statistics of this workgroup's 32 rows (all of one forward_once call), shifted by the first
+        // row's value so that the float32 sums are of the variance's size, not the mean's: the finishing
+        // kernel (tower.hip) rebuilds sum z and sum z^2 in float64 and adds the workgroups in a fixed order.
+        float* const pw = p.bn_part + (int64_t)blockIdx.x * (3 * PL_MAXW);
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            if (blk0 + j >= nblk) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 sd, sq, cc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float zv = acc[j][4 * g + e];
+                    const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zv), 0));
+                    const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zv), 32));
+                    const float c = h ? c1 : c0;
+                    const float d = zv - c;
+                    sd[e] = half_wave_sum(d);
+                    sq[e] = half_wave_sum(d * d);
+                    cc[e] = c;
+                }
+                if (r == 16) {
+                    const int n = 32 * (blk0 + j) + 8 * g + 4 * h;
+                    *reinterpret_cast<f32x4*>(pw + n) = sd;
+                    *reinterpret_cast<f32x4*>(pw + PL_MAXW + n) = sq;
+                    *reinterpret_cast<f32x4*>(pw + 2 * PL_MAXW + n) = cc;
+                }
+            }
+        }
+    }
     if (ws.active && ws.khalf == 0) {
 #pragma unroll
         for (int j = 0; j < BPW; ++j) {
@@ -538,8 +588,10 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
                 for (int t2 = 0; t2 < 2; ++t2) {
                     const f32x4 v0 = {acc[j][8 * t2], acc[j][8 * t2 + 1], acc[j][8 * t2 + 2], acc[j][8 * t2 + 3]};
                     const f32x4 v1 = {acc[j][8 * t2 + 4], acc[j][8 * t2 + 5], acc[j][8 * t2 + 6], acc[j][8 * t2 + 7]};
-                    f[t2] = make_frag<NP>(v0, v1);
-                    store_frag<NP>(img + (int64_t)(2 * blk + t2) * (NP * 1024) + lane * 16, f[t2]);
+                    if (!BNT) {
+                        f[t2] = make_frag<NP>(v0, v1);
+                        store_frag<NP>(img + (int64_t)(2 * blk + t2) * (NP * 1024) + lane * 16, f[t2]);
+                    }
                     const int n = 32 * blk + 16 * t2 + 4 * h;
                     if (out && row_ok && n < N) *reinterpret_cast<f32x4*>(out + (int64_t)gr * N + n) = v0;
                     if (out && row_ok && n + 8 < N) *reinterpret_cast<f32x4*>(out + (int64_t)gr * N + n + 8) = v1;
@@ -556,7 +608,7 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     }
     PSTAMPF(6 + 5 * l);
     // steps of the next layer's padding that no block of this layer covers
-    if (l + 1 < p.n_layers) {
+    if (!BNT && l + 1 < p.n_layers) {
         const int next_steps = pl_steps(N);
         const bf16x8 z = {};
         for (int s = 2 * nblk + wave; s < next_steps; s += PL_WAVES)
@@ -566,22 +618,14 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     __syncthreads();
 }
 
-template <int NP, int MODE = PL_TRAIN>
-__global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
+// The input rows of a workgroup -> operand fragments in img (+ the concatenated copy, + the transposed image
+// for the weight gradient).
+template <int NP, bool INFER>
+__device__ __forceinline__ void planes_input_stage(const PlanesFwdP& p, char* __restrict__ img, const bf16x8* idf, int wave,
+                                                   int lane, int row0)
 {
-    constexpr bool INFER = MODE != PL_TRAIN;
-    extern __shared__ __attribute__((aligned(16))) char pl_smem[];
-    char* const img = pl_smem;
-    float* const part = reinterpret_cast<float*>(pl_smem + PL_MAXSTEPS * NP * 1024);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * PL_ROWS;
     const int D0 = p.dims[0];
-    bf16x8 idf[2];
-    make_identity(idf, lane);
-    PSTAMPF(0);
-
     // input rows -> operand fragments (+ the concatenated copy for the backward): lane (r, h) of
     // step s holds x[row r][16 s + 4 h + 0..3] and x[row r][16 s + 8 + 4 h + 0..3]; a wave takes
     // whole 32-feature blocks (two steps), which it also writes transposed for the weight gradient
@@ -615,6 +659,23 @@ __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
         Frag<NP> z[2] = {};
         emit_planes<NP>(p.tp[0] + ((int64_t)(D0 / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, p.rows - row0);
     }
+}
+
+template <int NP, int MODE = PL_TRAIN>
+__global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
+{
+    constexpr bool INFER = MODE != PL_TRAIN;
+    extern __shared__ __attribute__((aligned(16))) char pl_smem[];
+    char* const img = pl_smem;
+    float* const part = reinterpret_cast<float*>(pl_smem + PL_MAXSTEPS * NP * 1024);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = blockIdx.x * PL_ROWS;
+    bf16x8 idf[2];
+    make_identity(idf, lane);
+    PSTAMPF(0);
+
+    planes_input_stage<NP, INFER>(p, img, idf, wave, lane, row0);
     PSTAMPF(1);
     __syncthreads();
 
@@ -625,6 +686,90 @@ __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
         else planes_layer<NP, 1, 2, MODE>(p, l, img, part, idf, wave, lane, row0);
     }
     PSTAMPF(2 + 5 * p.n_layers);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward of a BatchNorm tower in training: one launch per layer.  The statistics of layer l - 1 span
+// all rows of a forward_once call, so layer l starts in a new launch: its workgroups normalise their 32
+// rows of z_{l-1} on the way into the operand image (and leave xhat and the activation for the backward),
+// run the layer's product exactly as the single-launch forward does, and leave z_l + its per-workgroup
+// column statistics (planes_layer, PL_BN_TRAIN).  Rows per call must be a multiple of 32.
+// ---------------------------------------------------------------------------------------------
+struct BnTrainP {
+    int l;
+    const float* mean;      // [n_calls][dims[l]] of layer l - 1 (l >= 1)
+    const float* invstd;
+    float* z_prev;          // [rows][dims[l]]: z_{l-1} in, xhat_{l-1} out (in place)
+    float* a_prev;          // [rows][dims[l]]: act(gamma xhat + beta) out, row-major
+};
+
+template <int NP>
+__global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTrainP q)
+{
+    extern __shared__ __attribute__((aligned(16))) char pl_smem[];
+    char* const img = pl_smem;
+    float* const part = reinterpret_cast<float*>(pl_smem + PL_MAXSTEPS * NP * 1024);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * PL_ROWS;
+    const int l = q.l;
+    bf16x8 idf[2];
+    make_identity(idf, lane);
+
+    if (l == 0) {
+        planes_input_stage<NP, true>(p, img, idf, wave, lane, row0);
+    } else {
+        // the four per-feature vectors of this workgroup's call, parked in the (idle) K-split buffer
+        const int K = p.dims[l];
+        const int call = row0 / p.rows_call;
+        float* const mean_s = part, * const is_s = part + PL_MAXW, * const ga_s = part + 2 * PL_MAXW, * const be_s = part + 3 * PL_MAXW;
+        for (int c = threadIdx.x; c < K; c += PL_NT) {
+            mean_s[c] = q.mean[(int64_t)call * K + c];
+            is_s[c] = q.invstd[(int64_t)call * K + c];
+            ga_s[c] = p.bn_w[l - 1][c];
+            be_s[c] = p.bn_b[l - 1][c];
+        }
+        __syncthreads();
+        const int steps = pl_steps(K), blocks = steps / 2;
+        const int gr = row0 + r;                       // (whole workgroups only: rows_call % 32 == 0)
+        float* const zrow = q.z_prev + (int64_t)gr * K;
+        float* const arow = q.a_prev + (int64_t)gr * K;
+        with_act(p.act[l - 1], [&](auto tag) {
+            constexpr int ACT = decltype(tag)::value;
+            for (int kb = wave; kb < blocks; kb += PL_WAVES) {
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int s = 2 * kb + t2;
+                    f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int c = 16 * s + 4 * h + 8 * u;
+                        if (c < K) {
+                            const f32x4 z4 = *reinterpret_cast<const f32x4*>(zrow + c);
+                            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean_s + c), is = *reinterpret_cast<const f32x4*>(is_s + c);
+                            const f32x4 ga = *reinterpret_cast<const f32x4*>(ga_s + c), be = *reinterpret_cast<const f32x4*>(be_s + c);
+                            f32x4 xh;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                xh[e] = (z4[e] - mu[e]) * is[e];
+                                v[u][e] = act_apply(xh[e] * ga[e] + be[e], ACT);
+                            }
+                            *reinterpret_cast<f32x4*>(zrow + c) = xh;
+                            *reinterpret_cast<f32x4*>(arow + c) = v[u];
+                        }
+                    }
+                    store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, make_frag<NP>(v[0], v[1]));
+                }
+            }
+        });
+    }
+    __syncthreads();
+
+    const int nblk = (p.dims[l + 1] + 31) / 32;
+    if (nblk > PL_WAVES) planes_layer<NP, 2, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0);
+    else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0);
+    else planes_layer<NP, 1, 2, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -489,3 +489,69 @@ def test_inference_instantiation_equals_the_training_forward(shape, precision):
             b = net.forward_once(x)
         assert lib.abn_debug_last_forward_path() == (2 if net.training else 3)
         assert torch.equal(a, b)
+
+
+BN_SHAPES = [  # (input, hidden layers, hidden, output, B): B a multiple of 32 (whole workgroups per forward_once call)
+    (40, 2, 500, 100, 64),
+    (32, 1, 64, 32, 32),
+    (64, 1, 512, 128, 32),
+    (128, 3, 288, 36, 96),
+    (4, 0, 8, 4, 32),
+]
+
+
+@pytest.mark.parametrize('p_drop', [0.0, 0.25])
+@pytest.mark.parametrize('act', ['sigmoid', 'tanh', 'relu'])
+@pytest.mark.parametrize('shape', BN_SHAPES)
+def test_batch_norm_training_step_against_the_oracle(shape, act, p_drop):
+    """Linear -> Dropout -> BatchNorm -> activation in training: one operand-plane launch per layer, the
+    batch statistics from per-workgroup column sums.  Embeddings, loss, running statistics and every
+    gradient against the numpy oracle, with shared dropout masks."""
+    import abnet3_amd.loss as L
+    from abnet3_amd import _lib
+    from oracle import siamese_np as O
+    d_in, nh, hid, d_out, B = shape
+    kw = dict(input_dim=d_in, num_hidden_layers=nh, hidden_dim=hid, output_dim=d_out, activation_layer=act,
+              p_dropout=p_drop, batch_norm=True)
+    net, _, _ = build(kw, seed=B + 3, precision='bf16x3')
+    spec = O.TowerSpec(d_in, nh, hid, d_out, act, True)
+    rng = np.random.default_rng(B + nh)
+    with torch.no_grad():           # affine parameters away from 1 / 0, a bias that shifts the column means
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                n = m.num_features
+                m.weight.copy_(dev(rng.uniform(0.5, 1.5, n).astype(np.float32)))
+                m.bias.copy_(dev(rng.standard_normal(n).astype(np.float32) * 0.2))
+            if isinstance(m, torch.nn.Linear):
+                m.bias.copy_(dev(rng.standard_normal(m.out_features).astype(np.float32) * 3.0))
+    p = {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}
+    x1 = rng.standard_normal((B, d_in)).astype(np.float32)
+    x2 = (rng.standard_normal((B, d_in)) * 2.0 + 1.0).astype(np.float32)
+    y = rng.choice([1, -1], B)
+    widths = [hid] * (nh + 1) + [d_out]
+    masks = None
+    if p_drop:
+        masks = [((rng.random((2 * B, w)) >= p_drop) / (1 - p_drop)).astype(np.float32) for w in widths]
+        net._mask_override = [dev(m) for m in masks]
+    net.train()
+    e1, e2 = net(dev(x1), dev(x2))
+    assert _lib.load().abn_debug_last_forward_path() == 5
+    lv = L.coscos2(avg=False)(e1, e2, dev(y))
+    lv.backward()
+    o1, c1 = O.tower_forward(p, x1, spec, True, masks=[m[:B] for m in masks] if masks else None)
+    o2, c2 = O.tower_forward(p, x2, spec, True, masks=[m[B:] for m in masks] if masks else None)
+    ol, d1, d2, _ = O.pair_loss(o1, o2, y, 'coscos2', 0.5, False)
+    og = {}
+    O.tower_backward(p, c1, d1, spec, og)
+    O.tower_backward(p, c2, d2, spec, og)
+    assert rel_err(e1.detach().cpu().numpy(), o1) < 2e-5
+    assert rel_err(e2.detach().cpu().numpy(), o2) < 2e-5
+    assert abs(float(lv.detach()) - ol) <= 1e-4 * abs(ol) + 1e-6
+    sd = net.state_dict()
+    for k in p:                     # the oracle updated its running statistics in place, once per call
+        if 'running' in k:
+            assert rel_err(sd[k].cpu().numpy(), p[k]) < 1e-5, k
+        if 'num_batches' in k:
+            assert int(sd[k]) == int(p[k]) == 2, k
+    grads = {k: q.grad.cpu().numpy() for k, q in net.named_parameters()}
+    check_grads(grads, og, spec.param_keys(), not p_drop, tol=2e-4)
