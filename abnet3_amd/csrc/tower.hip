@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <math.h>
+#include <atomic>
 
 #include "common.h"
 #include "gemm_f32.h"
@@ -523,6 +524,70 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ a, const float* da
     }
 }
 
+// bn_planes_backward's small kernels.  The output layer's sums of dy and dy * xhat per workgroup of 32 rows
+// (further down bn_bwd_layer_kernel leaves them itself): one thread per column, [workgroup][2][PL_MAXW].
+__global__ __launch_bounds__(128) void bn_bwd_sums_wg_kernel(const float* __restrict__ da, const float* __restrict__ xhat,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int act, int C, float* __restrict__ part)
+{
+    const int64_t r0 = (int64_t)blockIdx.x * PL_ROWS;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float ga = gamma[c], be = beta[c];
+        float u = 0.0f, v = 0.0f;
+        for (int r = 0; r < PL_ROWS; ++r) {
+            const int64_t i = (r0 + r) * C + c;
+            const float xh = xhat[i];
+            const float dy = da[i] * act_grad(act_apply(xh * ga + be, act), act);
+            u += dy;
+            v += dy * xh;
+        }
+        part[(int64_t)blockIdx.x * (2 * PL_MAXW) + c] = u;
+        part[(int64_t)blockIdx.x * (2 * PL_MAXW) + PL_MAXW + c] = v;
+    }
+}
+
+// s1 = sum dy, s2 = sum dy * xhat per (call, column) from the workgroups' sums, added in a fixed order in
+// float64 (64 columns x 8 groups of workgroups per block, as bn_stats_finish_wg_kernel); d gamma, d beta
+__global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_bwd_finish_wg_kernel(const float* __restrict__ part, int wgs_per_call,
+                                                                             int C, int n_calls, float* __restrict__ s1o,
+                                                                             float* __restrict__ s2o, float* __restrict__ dgamma,
+                                                                             float* __restrict__ dbeta)
+{
+    __shared__ double sa[BN_WG_GROUPS][64], sb[BN_WG_GROUPS][64];
+    const int tx = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const bool ok = c < C;
+    const int per = (wgs_per_call + BN_WG_GROUPS - 1) / BN_WG_GROUPS;
+    float sg = 0.0f, sbeta = 0.0f;
+    for (int g = 0; g < n_calls; ++g) {
+        double a = 0.0, b = 0.0;
+        const int k0 = kg * per, k1 = min(k0 + per, wgs_per_call);
+        if (ok) {
+#pragma unroll 4
+            for (int k = k0; k < k1; ++k) {
+                const float* src = part + (int64_t)(g * wgs_per_call + k) * (2 * PL_MAXW);
+                a += (double)src[c];
+                b += (double)src[PL_MAXW + c];
+            }
+        }
+        __syncthreads();
+        sa[kg][tx] = a;
+        sb[kg][tx] = b;
+        __syncthreads();
+        if (ok && kg == 0) {
+            for (int k = 1; k < BN_WG_GROUPS; ++k) { a += sa[k][tx]; b += sb[k][tx]; }
+            s1o[(int64_t)g * C + c] = (float)a;
+            s2o[(int64_t)g * C + c] = (float)b;
+            sg += (float)b;
+            sbeta += (float)a;
+        }
+    }
+    if (ok && kg == 0) {
+        dgamma[c] = sg;
+        dbeta[c] = sbeta;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // workspace layout
 // ---------------------------------------------------------------------------
@@ -599,7 +664,7 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
     if (planes_dims_ok(t)) {
         const int np = planes_of(t->precision);
         L.wpack = take(make_pack_layout(t).bytes / 4);
-        if (!t->forward_only && !t->batch_norm)                    // (last in the workspace: an inference call simply asks for less)
+        if (!t->forward_only)                                      // (last in the workspace: an inference call simply asks for less)
             for (int l = 0; l < t->n_layers; ++l) L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, rows, np) / 4);
     }
     L.total = o;
@@ -628,9 +693,10 @@ static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, 
     return true;
 }
 
-// The training forward of a BatchNorm tower, one operand-plane launch per layer (bn_fwd_layer_kernel): same
-// conditions, whole workgroups per forward_once call, mask tensors for the dropout (the backward is the
-// per-layer one).  ABN_BN_PLANES=0: the per-layer kernels (A/B measurements).
+// The training forward and the backward of a BatchNorm tower, one operand-plane launch per layer
+// (bn_fwd_layer_kernel, bn_bwd_layer_kernel): same conditions, whole workgroups per forward_once call, mask
+// tensors for the dropout.  Forward and backward must agree: both ask here.
+// ABN_BN_PLANES=0: the per-layer kernels (A/B measurements).
 static bool bn_train_planes_path(const abn_tower_desc* t, int64_t rows, int64_t n_calls, const float* x1, const float* x2,
                                  const float* ws)
 {
@@ -705,7 +771,9 @@ struct BwdLayout {
     int64_t slab_stride;
     int64_t off[ABN_MAX_LAYERS];
     int splits[ABN_MAX_LAYERS];
+    int psplits[ABN_MAX_LAYERS];     // BatchNorm: the slabs of the operand-plane weight-gradient launch (bn_planes_backward)
     int64_t dzp[ABN_MAX_LAYERS];     // tower_planes.h: transposed planes of dZ_l
+    int64_t bn_wg;                   // bn_bwd_layer_kernel's per-workgroup sums ([rows / 32][2][PL_MAXW])
     int64_t total;
 };
 
@@ -728,11 +796,14 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
     int smax = 1;
     for (int l = 0; l < t->n_layers; ++l) {
         B.splits[l] = planes_shape_ok(t) ? planes_split_count(rows, t->dims[l + 1], t->dims[l]) : split_count(rows, t->dims[l + 1], t->dims[l]);
+        B.psplits[l] = planes_dims_ok(t) ? planes_split_count(rows, t->dims[l + 1], t->dims[l]) : B.splits[l];
         smax = B.splits[l] > smax ? B.splits[l] : smax;
+        smax = B.psplits[l] > smax ? B.psplits[l] : smax;
     }
     B.slabs = take(B.slab_stride * smax);
     for (int l = 0; l < t->n_layers; ++l)
-        B.dzp[l] = planes_shape_ok(t) ? take(pl_timage_bytes(t->dims[l + 1], rows, planes_of(t->precision)) / 4) : -1;
+        B.dzp[l] = planes_dims_ok(t) ? take(pl_timage_bytes(t->dims[l + 1], rows, planes_of(t->precision)) / 4) : -1;
+    B.bn_wg = planes_dims_ok(t) && t->batch_norm ? take((rows / PL_ROWS + 1) * 2 * PL_MAXW) : -1;
     B.total = o;
     return B;
 }
@@ -765,6 +836,121 @@ struct LossArgs {
     float* loss_out;
     void* ws;              // 8 bytes of ticket counter (zero before the first call, left zero) + one double per workgroup
 };
+
+// Every layer's weight-gradient tiles for one wgrad_planes_kernel launch: operands = the transposed images
+// the forward (ws + L.tp[l]) and the data-gradient launches (scratch + B.dzp[l]) left.
+static WgradP make_wgrad(const abn_tower_desc* t, int64_t rows, const Layout& L, const BwdLayout& B, const float* ws,
+                         float* scratch, int* n_wg_out)
+{
+    const int nl = t->n_layers;
+    WgradP w = {};
+    w.slabs = scratch + B.slabs;
+    w.slab_stride = B.slab_stride;
+    w.tp_steps = pl_row_steps(rows);
+    // launch order: most row steps per workgroup first
+    int order[ABN_MAX_LAYERS];
+    for (int l = 0; l < nl; ++l) order[l] = l;
+    for (int i = 1; i < nl; ++i)
+        for (int j = i; j > 0 && B.splits[order[j]] < B.splits[order[j - 1]]; --j) { int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
+    int n_wg = 0;
+    for (int i = 0; i < nl; ++i) {
+        const int l = order[i];
+        WgradLayer& W = w.L[w.n_layers++];
+        W.dzp = reinterpret_cast<const char*>(scratch + B.dzp[l]);
+        W.ap = reinterpret_cast<const char*>(ws + L.tp[l]);
+        W.N = (int)t->dims[l + 1]; W.K = (int)t->dims[l];
+        W.nblk = pl_blocks(W.N); W.kblk = pl_blocks(W.K + 1);
+        int bn, bk;
+        wgrad_shape(W.nblk, W.kblk, &W.shape, &bn, &bk);
+        W.tiles_n = (W.nblk + bn - 1) / bn; W.tiles_k = (W.kblk + bk - 1) / bk;
+        W.splits = B.splits[l];
+        W.first_wg = n_wg;
+        W.slab_off = B.off[l];
+        n_wg += W.tiles_n * W.tiles_k * W.splits;
+    }
+    // (ABN_WGRAD_XCD=0: workgroups in launch order, A/B measurements)
+    w.xcd_groups = !(getenv("ABN_WGRAD_XCD") && atoi(getenv("ABN_WGRAD_XCD")) == 0);
+    if (w.xcd_groups) {
+        int most = 0;
+        for (int x = 0; x < 8; ++x) most = wgrad_slots(w, x) > most ? wgrad_slots(w, x) : most;
+        n_wg = 8 * most;
+    }
+    *n_wg_out = n_wg;
+    return w;
+}
+
+// Backward of a BatchNorm tower whose forward went through bn_fwd_layer_kernel (same predicate): per layer,
+// top down, [bn_bwd_layer_kernel, bn_bwd_finish_wg_kernel]; then every layer's weight gradient in one launch
+// and the slab reduction.
+static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64_t rows, int64_t n_calls, const Layout& L,
+                              const BwdLayout& B0, const float* ws, float* scratch, float* dx, hipStream_t st)
+{
+    const int nl = t->n_layers;
+    const int np = planes_of(t->precision);
+    const int64_t rpc = rows / n_calls;
+    ABN_REQUIRE(aligned16(d_out) && aligned16(scratch) && (!dx || aligned16(dx)), "tower_backward: d_out / scratch / dx must be 16-byte aligned");
+    ABN_REQUIRE(!t->d_out_is_dz && !t->defer_reduce, "tower_backward: d_out_is_dz / defer_reduce cannot be combined with batch_norm");
+    BwdLayout B = B0;
+    for (int l = 0; l < nl; ++l) B.splits[l] = B0.psplits[l];
+    const PackLayout PL = make_pack_layout(t);
+    const char* const image = t->wpack ? reinterpret_cast<const char*>(t->wpack) : reinterpret_cast<const char*>(ws + L.wpack);
+    static bool attr_set[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = (dev >= 0 && dev < 16) ? dev : 0;
+    if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_layer_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(1));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_layer_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(3));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<1>());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<3>());
+        attr_set[dev] = true;
+    }
+    const dim3 cgrid((unsigned)(rows / PL_ROWS));
+    float* const part = scratch + B.bn_wg;
+    float* const s1 = scratch + B.bn_s1, * const s2 = scratch + B.bn_s2;
+    const int wgs_per_call = (int)(rpc / PL_ROWS);
+    {
+        const int N = (int)t->dims[nl];
+        hipLaunchKernelGGL(bn_bwd_sums_wg_kernel, cgrid, dim3(128), 0, st, d_out, ws + L.xhat[nl - 1], t->bn_w[nl - 1], t->bn_b[nl - 1],
+                           t->last_act, N, part);
+        hipLaunchKernelGGL(bn_bwd_finish_wg_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, part, wgs_per_call, N,
+                           (int)n_calls, s1, s2, t->dbn_w[nl - 1], t->dbn_b[nl - 1]);
+    }
+    int cur = 0;
+    for (int l = nl - 1; l >= 0; --l) {
+        BnBwdP q = {};
+        q.l = l; q.rows = (int)rows; q.rows_call = (int)rpc;
+        q.N = (int)t->dims[l + 1]; q.K = (int)t->dims[l];
+        q.act_l = (l == nl - 1) ? t->last_act : t->act;
+        q.act_prev = t->act;
+        q.da = (l == nl - 1) ? d_out : scratch + B.dz[cur];
+        q.xhat = ws + L.xhat[l];
+        q.invstd = ws + L.invstd[l];
+        q.gamma = t->bn_w[l]; q.beta = t->bn_b[l];
+        q.s1 = s1; q.s2 = s2;
+        q.mask = t->drop_mask[l];
+        q.dzp = reinterpret_cast<char*>(scratch + B.dzp[l]);
+        q.tp_steps = pl_row_steps(rows);
+        q.wpt = (l >= 1 || dx) ? image + PL.wpt[l] : nullptr;
+        q.da_prev = l >= 1 ? scratch + B.dz[cur ^ 1] : dx;
+        if (l >= 1) { q.xhat_prev = ws + L.xhat[l - 1]; q.gamma_prev = t->bn_w[l - 1]; q.beta_prev = t->bn_b[l - 1]; q.part_out = part; }
+        if (np == 3) hipLaunchKernelGGL(bn_bwd_layer_kernel<3>, cgrid, dim3(PL_NT), pl_lds_bytes(3), st, q);
+        else hipLaunchKernelGGL(bn_bwd_layer_kernel<1>, cgrid, dim3(PL_NT), pl_lds_bytes(1), st, q);
+        if (l >= 1) {
+            hipLaunchKernelGGL(bn_bwd_finish_wg_kernel, dim3((unsigned)((q.K + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, part, wgs_per_call,
+                               q.K, (int)n_calls, s1, s2, t->dbn_w[l - 1], t->dbn_b[l - 1]);
+            cur ^= 1;
+        }
+    }
+    int n_wg = 0;
+    const WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
+    if (np == 3) hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
+    else hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
+    const ReduceTable rt = make_reduce_table(t, B);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, scratch + B.slabs, rt);
+    ABN_CHECK_LAUNCH("tower_backward (BatchNorm, planes)");
+    return ABN_OK;
+}
 
 static int planes_backward(const abn_tower_desc* t, const float* d_out, const LossArgs* loss, int64_t rows, const Layout& L,
                            const BwdLayout& B, const float* ws, float* scratch, float* dx, hipStream_t st)
@@ -805,38 +991,8 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
         b.wpt[l] = image + PL.wpt[l];
         b.dzp[l] = reinterpret_cast<char*>(scratch + B.dzp[l]);
     }
-    WgradP w = {};
-    w.slabs = scratch + B.slabs;
-    w.slab_stride = B.slab_stride;
-    w.tp_steps = b.tp_steps;
-    // launch order: most row steps per workgroup first
-    int order[ABN_MAX_LAYERS];
-    for (int l = 0; l < nl; ++l) order[l] = l;
-    for (int i = 1; i < nl; ++i)
-        for (int j = i; j > 0 && B.splits[order[j]] < B.splits[order[j - 1]]; --j) { int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
     int n_wg = 0;
-    for (int i = 0; i < nl; ++i) {
-        const int l = order[i];
-        WgradLayer& W = w.L[w.n_layers++];
-        W.dzp = b.dzp[l];
-        W.ap = reinterpret_cast<const char*>(ws + L.tp[l]);
-        W.N = (int)t->dims[l + 1]; W.K = (int)t->dims[l];
-        W.nblk = pl_blocks(W.N); W.kblk = pl_blocks(W.K + 1);
-        int bn, bk;
-        wgrad_shape(W.nblk, W.kblk, &W.shape, &bn, &bk);
-        W.tiles_n = (W.nblk + bn - 1) / bn; W.tiles_k = (W.kblk + bk - 1) / bk;
-        W.splits = B.splits[l];
-        W.first_wg = n_wg;
-        W.slab_off = B.off[l];
-        n_wg += W.tiles_n * W.tiles_k * W.splits;
-    }
-    // (ABN_WGRAD_XCD=0: workgroups in launch order, A/B measurements)
-    w.xcd_groups = !(getenv("ABN_WGRAD_XCD") && atoi(getenv("ABN_WGRAD_XCD")) == 0);
-    if (w.xcd_groups) {
-        int most = 0;
-        for (int x = 0; x < 8; ++x) most = wgrad_slots(w, x) > most ? wgrad_slots(w, x) : most;
-        n_wg = 8 * most;
-    }
+    const WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
     static bool bw_attr_set[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -908,11 +1064,15 @@ int64_t abn_debug_planes_offset(const abn_tower_desc* t, int64_t rows, int64_t n
     return (t->wpack ? 0 : L.wpack) + (which == 0 ? P.wp[l] : P.wpt[l]) / 4;
 }
 
-// Diagnostics / tests only (not in the header): which kernels the calling thread's last abn_tower_forward
-// launched -- 0 per-layer, 1 the fp32 fused tower, 2 / 3 / 4 the operand-plane tower: for a backward,
+// Diagnostics / tests only (not in the header): which kernels the last abn_tower_forward
+// launched (process-wide: autograd runs backwards on its own thread) -- 0 per-layer, 1 the fp32 fused tower, 2 / 3 / 4 the operand-plane tower: for a backward,
 // inference, inference with BatchNorm.
-static thread_local int last_forward_path = -1;
+static std::atomic<int> last_forward_path{-1};
 int abn_debug_last_forward_path(void) { return last_forward_path; }
+// ... and its last abn_tower_backward: 0 per-layer, 2 the operand-plane chain + weight-gradient launches, 5 BatchNorm's
+// one launch per layer
+static std::atomic<int> last_backward_path{-1};
+int abn_debug_last_backward_path(void) { return last_backward_path; }
 
 int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws, int train)
 {
@@ -1030,17 +1190,17 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(3));
                 bn_attr_set[dev] = true;
             }
-            f.x_copy = x2 ? ws + L.x : nullptr;                // the per-layer backward reads the concatenated input
             f.bn_part = ws + L.bn_wg;
             const int nl = t->n_layers;
             for (int l = 0; l < nl; ++l) {
                 PlanesFwdP fl = f;
                 for (int i = 0; i < nl; ++i) { fl.tp[i] = nullptr; fl.out[i] = nullptr; }
+                fl.tp[l] = reinterpret_cast<char*>(ws + L.tp[l]);        // [a_{l-1} | 1] transposed: the weight gradient's operand
                 fl.act[l] = ACT_NONE;                          // z_l leaves the launch as it is; act[l - 1] is applied on the way in
                 fl.out[l] = ws + L.xhat[l];                    // (z lands where xhat will live)
                 BnTrainP q = {};
                 q.l = l;
-                if (l > 0) { q.mean = ws + L.mean[l - 1]; q.invstd = ws + L.invstd[l - 1]; q.z_prev = ws + L.xhat[l - 1]; q.a_prev = ws + L.a[l - 1]; }
+                if (l > 0) { q.mean = ws + L.mean[l - 1]; q.invstd = ws + L.invstd[l - 1]; q.z_prev = ws + L.xhat[l - 1]; q.a_prev = nullptr; }
                 if (np == 3) hipLaunchKernelGGL(bn_fwd_layer_kernel<3>, fgrid, dim3(PL_NT), pl_lds_bytes(3), st, fl, q);
                 else hipLaunchKernelGGL(bn_fwd_layer_kernel<1>, fgrid, dim3(PL_NT), pl_lds_bytes(1), st, fl, q);
                 const int N = (int)t->dims[l + 1];
@@ -1198,7 +1358,9 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     // The forward that filled `ws` went through the planes kernels (same predicate): its workspace
     // holds W^T and the weight-gradient operands as operand fragments.  Two launches: the data
     // gradient chain (one workgroup per 32 rows, all layers), then every layer's weight gradient.
-    if (planes_path(t, rows, x1, x2, ws)) return planes_backward(t, d_out, nullptr, rows, L, B, ws, scratch, dx, st);
+    if (planes_path(t, rows, x1, x2, ws)) { last_backward_path = 2; return planes_backward(t, d_out, nullptr, rows, L, B, ws, scratch, dx, st); }
+    if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) { last_backward_path = 5; return bn_planes_backward(t, d_out, rows, n_calls, L, B, ws, scratch, dx, st); }
+    last_backward_path = 0;
 
     int cur = 0;
     const float* dz_in = nullptr;                // the output layer's dz when the caller supplied it

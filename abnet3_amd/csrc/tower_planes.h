@@ -700,7 +700,8 @@ struct BnTrainP {
     const float* mean;      // [n_calls][dims[l]] of layer l - 1 (l >= 1)
     const float* invstd;
     float* z_prev;          // [rows][dims[l]]: z_{l-1} in, xhat_{l-1} out (in place)
-    float* a_prev;          // [rows][dims[l]]: act(gamma xhat + beta) out, row-major
+    float* a_prev;          // [rows][dims[l]]: act(gamma xhat + beta) out, row-major (null: not wanted)
+    // (p.tp[l]: the same activations as the transposed image [a_{l-1} | 1] the weight gradient reads)
 };
 
 template <int NP>
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
     make_identity(idf, lane);
 
     if (l == 0) {
-        planes_input_stage<NP, true>(p, img, idf, wave, lane, row0);
+        planes_input_stage<NP, false>(p, img, idf, wave, lane, row0);
     } else {
         // the four per-feature vectors of this workgroup's call, parked in the (idle) K-split buffer
         const int K = p.dims[l];
@@ -734,10 +735,12 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
         const int steps = pl_steps(K), blocks = steps / 2;
         const int gr = row0 + r;                       // (whole workgroups only: rows_call % 32 == 0)
         float* const zrow = q.z_prev + (int64_t)gr * K;
-        float* const arow = q.a_prev + (int64_t)gr * K;
+        float* const arow = q.a_prev ? q.a_prev + (int64_t)gr * K : nullptr;
+        char* const tp = p.tp[l];
         with_act(p.act[l - 1], [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
             for (int kb = wave; kb < blocks; kb += PL_WAVES) {
+                Frag<NP> f[2];
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2) {
                     const int s = 2 * kb + t2;
@@ -756,13 +759,21 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
                                 v[u][e] = act_apply(xh[e] * ga[e] + be[e], ACT);
                             }
                             *reinterpret_cast<f32x4*>(zrow + c) = xh;
-                            *reinterpret_cast<f32x4*>(arow + c) = v[u];
+                            if (arow) *reinterpret_cast<f32x4*>(arow + c) = v[u];
                         }
                     }
-                    store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, make_frag<NP>(v[0], v[1]));
+                    f[t2] = make_frag<NP>(v[0], v[1]);
+                    store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
                 }
+                if (tp && kb < pl_blocks(K + 1))
+                    emit_planes<NP>(tp + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
+                                    kb == K / 32 ? K % 32 : -1, p.rows - row0);
             }
         });
+        if (tp && pl_blocks(K + 1) > blocks && wave == PL_WAVES - 1) {      // K % 32 == 0 and no padding block to hold the ones
+            Frag<NP> z[2] = {};
+            emit_planes<NP>(tp + ((int64_t)(K / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, p.rows - row0);
+        }
     }
     __syncthreads();
 
@@ -1074,6 +1085,170 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
         else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l + 1]) % (2 * PL_DEPTH) != 0) planes_dgrad_layer<NP, 1, 1>(p, l, img, part, idf, wave, lane, row0);
         else planes_dgrad_layer<NP, 1, 2>(p, l, img, part, idf, wave, lane, row0);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of a BatchNorm tower: one launch per layer, top down.  The launch of layer l turns d loss / d a_l
+// into dz_l on the way into the operand image -- dy = da act'(a), dz = gamma invstd / n (n dy - s1 - xhat s2)
+// mask, with s1 = sum dy and s2 = sum dy xhat over the rows of the forward_once call (they span every
+// workgroup's rows: hence the launch boundary) -- leaves dz_l as the transposed image the weight-gradient
+// launch reads, multiplies by W_l, stores d loss / d a_{l-1} and the per-workgroup sums of dy_{l-1} and
+// dy_{l-1} xhat_{l-1}; a small kernel (tower.hip) adds them in a fixed order before the next launch.
+// ---------------------------------------------------------------------------------------------
+struct BnBwdP {
+    int l, rows, rows_call;
+    int N, K;                      // dims[l + 1], dims[l]
+    int act_l, act_prev;           // activations behind BatchNorm l and l - 1
+    const float* da;               // [rows][N] d loss / d a_l
+    const float* xhat;             // [rows][N]
+    const float* invstd;           // [n_calls][N]
+    const float* gamma;            // [N]
+    const float* beta;
+    const float* s1;               // [n_calls][N]
+    const float* s2;
+    const float* mask;             // layer l's dropout mask [rows][N] (null: none)
+    char* dzp;                     // out: transposed planes of dz_l
+    int64_t tp_steps;
+    const char* wpt;               // packed W_l^T (null: no product -- layer 0 without an input gradient)
+    float* da_prev;                // out [rows][K]: d loss / d a_{l-1}, or d loss / d input for l == 0
+    const float* xhat_prev;        // [rows][K]  (l >= 1)
+    const float* gamma_prev;       // [K]
+    const float* beta_prev;
+    float* part_out;               // out [workgroup][2][PL_MAXW]: sums over its 32 rows of dy_{l-1}, dy_{l-1} xhat_{l-1}
+};
+
+template <int NP, int BPW, int KS>
+__device__ __forceinline__ void bn_dgrad_product(const BnBwdP& q, char* __restrict__ img, float* __restrict__ part, int wave,
+                                                 int lane, int row0)
+{
+    const int N = q.N, K = q.K;                       // sum over N, K output features
+    const int nsteps = pl_steps(N), nblk = (K + 31) / 32;
+    const int r = lane & 31, h = lane >> 5;
+    const WaveShare<BPW, KS> ws(wave, nblk, nsteps);
+    const int blk0 = ws.blk0;
+    f32x16 acc[BPW];
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) acc[j][x] = 0.0f;
+    if (ws.active) planes_kloop<NP, BPW>(acc, q.wpt, nblk, nsteps, img, blk0, ws.s_first, ws.my_steps, lane);
+    if (KS == 2 && ws.active && ws.khalf == 1) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) part[((wave & 3) * 16 + x) * 64 + lane] = acc[0][x];
+    }
+    if (KS == 2) __syncthreads();
+    if (!(ws.active && ws.khalf == 0)) return;
+    if (KS == 2) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) acc[0][x] += part[(wave * 16 + x) * 64 + lane];
+    }
+    const int gr = row0 + r;                          // (whole workgroups only)
+    float* const orow = q.da_prev + (int64_t)gr * K;
+    float* const pw = q.l >= 1 ? q.part_out + (int64_t)blockIdx.x * (2 * PL_MAXW) : nullptr;
+    with_act(q.act_prev, [&](auto tag) {
+        constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+        for (int j = 0; j < BPW; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * (blk0 + j) + 8 * g + 4 * h;
+                const bool live = n < K;              // K % 4 == 0: four features in or out together
+                const f32x4 d4 = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                if (live) *reinterpret_cast<f32x4*>(orow + n) = d4;
+                if (q.l >= 1) {
+                    const int nc = live ? n : K - 4;
+                    const f32x4 xh = *reinterpret_cast<const f32x4*>(q.xhat_prev + (int64_t)gr * K + nc);
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(q.gamma_prev + nc), be = *reinterpret_cast<const f32x4*>(q.beta_prev + nc);
+                    f32x4 sd, sq;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = act_apply(xh[e] * ga[e] + be[e], ACT);
+                        const float dy = live ? d4[e] * act_grad(a, ACT) : 0.0f;
+                        sd[e] = half_wave_sum(dy);
+                        sq[e] = half_wave_sum(dy * xh[e]);
+                    }
+                    if (r == 16 && live) {
+                        *reinterpret_cast<f32x4*>(pw + n) = sd;
+                        *reinterpret_cast<f32x4*>(pw + PL_MAXW + n) = sq;
+                    }
+                }
+            }
+    });
+}
+
+template <int NP>
+__global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
+{
+    extern __shared__ __attribute__((aligned(16))) char pl_smem[];
+    char* const img = pl_smem;
+    float* const part = reinterpret_cast<float*>(pl_smem + PL_MAXSTEPS * NP * 1024);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * PL_ROWS;
+    const int N = q.N;
+    bf16x8 idf[2];
+    make_identity(idf, lane);
+
+    // the per-feature vectors of this workgroup's call, parked in the (still idle) K-split buffer
+    const int call = row0 / q.rows_call;
+    const float nf = (float)q.rows_call;
+    float* const k_s = part, * const ga_s = part + PL_MAXW, * const be_s = part + 2 * PL_MAXW, * const s1_s = part + 3 * PL_MAXW,
+               * const s2_s = part + 4 * PL_MAXW;
+    for (int c = threadIdx.x; c < N; c += PL_NT) {
+        const float ga = q.gamma[c];
+        k_s[c] = ga * q.invstd[(int64_t)call * N + c] / nf;
+        ga_s[c] = ga;
+        be_s[c] = q.beta[c];
+        s1_s[c] = q.s1[(int64_t)call * N + c];
+        s2_s[c] = q.s2[(int64_t)call * N + c];
+    }
+    __syncthreads();
+    const int steps = pl_steps(N), blocks = steps / 2;
+    const int gr = row0 + r;
+    const float* const drow = q.da + (int64_t)gr * N;
+    const float* const xrow = q.xhat + (int64_t)gr * N;
+    const float* const mrow = q.mask ? q.mask + (int64_t)gr * N : nullptr;
+    with_act(q.act_l, [&](auto tag) {
+        constexpr int ACT = decltype(tag)::value;
+        for (int kb = wave; kb < blocks; kb += PL_WAVES) {
+            Frag<NP> f[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int s = 2 * kb + t2;
+                f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = 16 * s + 4 * h + 8 * u;
+                    if (c < N) {
+                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + c), xh = *reinterpret_cast<const f32x4*>(xrow + c);
+                        const f32x4 k4 = *reinterpret_cast<const f32x4*>(k_s + c), ga = *reinterpret_cast<const f32x4*>(ga_s + c);
+                        const f32x4 be = *reinterpret_cast<const f32x4*>(be_s + c);
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(s1_s + c), a2 = *reinterpret_cast<const f32x4*>(s2_s + c);
+                        f32x4 m4 = {1.f, 1.f, 1.f, 1.f};
+                        if (mrow) m4 = *reinterpret_cast<const f32x4*>(mrow + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = act_apply(xh[e] * ga[e] + be[e], ACT);
+                            const float dy = d4[e] * act_grad(a, ACT);
+                            v[u][e] = k4[e] * (nf * dy - a1[e] - xh[e] * a2[e]) * m4[e];
+                        }
+                    }
+                }
+                f[t2] = make_frag<NP>(v[0], v[1]);
+                store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
+            }
+            if (kb < pl_blocks(N))
+                emit_planes<NP>(q.dzp + ((int64_t)kb * q.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane, -1, 0);
+        }
+    });
+    __syncthreads();
+    if (!q.wpt) return;
+
+    const int nblk = (q.K + 31) / 32;
+    if (nblk > PL_WAVES) bn_dgrad_product<NP, 2, 1>(q, img, part, wave, lane, row0);
+    else if (nblk > PL_WAVES / 2 || pl_steps(N) % (2 * PL_DEPTH) != 0) bn_dgrad_product<NP, 1, 1>(q, img, part, wave, lane, row0);
+    else bn_dgrad_product<NP, 1, 2>(q, img, part, wave, lane, row0);
 }
 
 // ---------------------------------------------------------------------------------------------

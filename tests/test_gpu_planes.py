@@ -538,6 +538,7 @@ def test_batch_norm_training_step_against_the_oracle(shape, act, p_drop):
     assert _lib.load().abn_debug_last_forward_path() == 5
     lv = L.coscos2(avg=False)(e1, e2, dev(y))
     lv.backward()
+    assert _lib.load().abn_debug_last_backward_path() == 5
     o1, c1 = O.tower_forward(p, x1, spec, True, masks=[m[:B] for m in masks] if masks else None)
     o2, c2 = O.tower_forward(p, x2, spec, True, masks=[m[B:] for m in masks] if masks else None)
     ol, d1, d2, _ = O.pair_loss(o1, o2, y, 'coscos2', 0.5, False)
@@ -555,3 +556,38 @@ def test_batch_norm_training_step_against_the_oracle(shape, act, p_drop):
             assert int(sd[k]) == int(p[k]) == 2, k
     grads = {k: q.grad.cpu().numpy() for k, q in net.named_parameters()}
     check_grads(grads, og, spec.param_keys(), not p_drop, tol=2e-4)
+
+
+def test_batch_norm_input_gradient_and_fallbacks(monkeypatch):
+    """d loss / d input through the BatchNorm launches (layer 0's product with W_0), against the per-layer kernels;
+    a forward_once call whose rows are not whole workgroups stays on the per-layer kernels."""
+    from abnet3_amd import _lib
+    kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=96, output_dim=32, activation_layer='tanh', p_dropout=0.0,
+              batch_norm=True)
+    rng = np.random.default_rng(4)
+    x1 = rng.standard_normal((64, 40)).astype(np.float32)
+    x2 = rng.standard_normal((64, 40)).astype(np.float32)
+    w = dev(rng.standard_normal((64, 32)).astype(np.float32))
+    res = []
+    for planes in ('1', '0'):
+        monkeypatch.setenv('ABN_BN_PLANES', planes)
+        net, _, _ = build(kw, seed=9, precision='bf16x3')
+        net.train()
+        a, b = dev(x1).requires_grad_(True), dev(x2).requires_grad_(True)
+        e1, e2 = net(a, b)
+        ((e1 * w).sum() + (e2 * e2 * w).sum()).backward()
+        assert _lib.load().abn_debug_last_backward_path() == (5 if planes == '1' else 0)
+        res.append([a.grad.cpu().numpy(), b.grad.cpu().numpy()] + [q.grad.cpu().numpy() for q in net.parameters()])
+    gmax = max(np.abs(v).max() for v in res[1])
+    for u, v in zip(*res):
+        if np.abs(v).max() < 1e-5 * gmax:           # the Linear biases in front of a BatchNorm: zero but for rounding
+            assert np.abs(u).max() < 1e-5 * gmax
+        else:
+            assert rel_err(u, v, floor=1e-3 * np.abs(v).max()) < 1e-4
+    monkeypatch.setenv('ABN_BN_PLANES', '1')
+    net, _, _ = build(kw, seed=9, precision='bf16x3')
+    net.train()
+    e = net.forward_once(dev(x1[:48]))
+    assert _lib.load().abn_debug_last_forward_path() == 0
+    e.sum().backward()
+    assert _lib.load().abn_debug_last_backward_path() == 0
