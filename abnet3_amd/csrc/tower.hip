@@ -401,9 +401,9 @@ __global__ void bn_stats_finish_kernel(const double* __restrict__ part, int nchu
 
 // The same, from the per-workgroup statistics bn_fwd_layer_kernel leaves (tower_planes.h): 32 rows each,
 // sums shifted by the workgroup's first row c -- sum z = sd + 32 c, sum z^2 = sq + 2 c sd + 32 c^2 in float64.
-// A block = 64 columns x 8 groups of workgroups: every group adds its share in order, thread group 0 the
-// eight group sums in order (one thread per column walking 128 workgroups alone took 18 us).
-constexpr int BN_WG_GROUPS = 8;
+// A block = 64 columns x 16 groups of workgroups: every group adds its share in order, thread group 0 the
+// sixteen group sums in order (one thread per column walking 128 workgroups alone took 18 us).
+constexpr int BN_WG_GROUPS = 16;
 __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
     const float* __restrict__ part, int wgs_per_call, int64_t rows_per_call, int C, int n_calls, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ var_out, float* __restrict__ rm, float* __restrict__ rv)
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
         double a = 0.0, b = 0.0;
         const int k0 = kg * per, k1 = min(k0 + per, wgs_per_call);
         if (ok) {
-#pragma unroll 4
+#pragma unroll 8
             for (int k = k0; k < k1; ++k) {           // fixed order; the loads are independent
                 const float* src = part + (int64_t)(g * wgs_per_call + k) * (3 * PL_MAXW);
                 const double sd = src[c], sq = src[PL_MAXW + c], cc = src[2 * PL_MAXW + c];
@@ -526,28 +526,41 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ a, const float* da
 
 // bn_planes_backward's small kernels.  The output layer's sums of dy and dy * xhat per workgroup of 32 rows
 // (further down bn_bwd_layer_kernel leaves them itself): one thread per column, [workgroup][2][PL_MAXW].
-__global__ __launch_bounds__(128) void bn_bwd_sums_wg_kernel(const float* __restrict__ da, const float* __restrict__ xhat,
+__global__ __launch_bounds__(512) void bn_bwd_sums_wg_kernel(const float* __restrict__ da, const float* __restrict__ xhat,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              int act, int C, float* __restrict__ part)
 {
-    const int64_t r0 = (int64_t)blockIdx.x * PL_ROWS;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float ga = gamma[c], be = beta[c];
+    __shared__ float su[8][64], sv[8][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;         // 64 columns x 8 groups of 4 rows
+    const int64_t r0 = (int64_t)blockIdx.x * PL_ROWS + 4 * ty;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + tx;
         float u = 0.0f, v = 0.0f;
-        for (int r = 0; r < PL_ROWS; ++r) {
-            const int64_t i = (r0 + r) * C + c;
-            const float xh = xhat[i];
-            const float dy = da[i] * act_grad(act_apply(xh * ga + be, act), act);
-            u += dy;
-            v += dy * xh;
+        if (c < C) {
+            const float ga = gamma[c], be = beta[c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = (r0 + r) * C + c;
+                const float xh = xhat[i];
+                const float dy = da[i] * act_grad(act_apply(xh * ga + be, act), act);
+                u += dy;
+                v += dy * xh;
+            }
         }
-        part[(int64_t)blockIdx.x * (2 * PL_MAXW) + c] = u;
-        part[(int64_t)blockIdx.x * (2 * PL_MAXW) + PL_MAXW + c] = v;
+        __syncthreads();
+        su[ty][tx] = u;
+        sv[ty][tx] = v;
+        __syncthreads();
+        if (ty == 0 && c < C) {
+            for (int k = 1; k < 8; ++k) { u += su[k][tx]; v += sv[k][tx]; }
+            part[(int64_t)blockIdx.x * (2 * PL_MAXW) + c] = u;
+            part[(int64_t)blockIdx.x * (2 * PL_MAXW) + PL_MAXW + c] = v;
+        }
     }
 }
 
 // s1 = sum dy, s2 = sum dy * xhat per (call, column) from the workgroups' sums, added in a fixed order in
-// float64 (64 columns x 8 groups of workgroups per block, as bn_stats_finish_wg_kernel); d gamma, d beta
+// float64 (64 columns x 16 groups of workgroups per block, as bn_stats_finish_wg_kernel); d gamma, d beta
 __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_bwd_finish_wg_kernel(const float* __restrict__ part, int wgs_per_call,
                                                                              int C, int n_calls, float* __restrict__ s1o,
                                                                              float* __restrict__ s2o, float* __restrict__ dgamma,
@@ -563,7 +576,7 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_bwd_finish_wg_kernel(con
         double a = 0.0, b = 0.0;
         const int k0 = kg * per, k1 = min(k0 + per, wgs_per_call);
         if (ok) {
-#pragma unroll 4
+#pragma unroll 8
             for (int k = k0; k < k1; ++k) {
                 const float* src = part + (int64_t)(g * wgs_per_call + k) * (2 * PL_MAXW);
                 a += (double)src[c];
@@ -911,7 +924,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     const int wgs_per_call = (int)(rpc / PL_ROWS);
     {
         const int N = (int)t->dims[nl];
-        hipLaunchKernelGGL(bn_bwd_sums_wg_kernel, cgrid, dim3(128), 0, st, d_out, ws + L.xhat[nl - 1], t->bn_w[nl - 1], t->bn_b[nl - 1],
+        hipLaunchKernelGGL(bn_bwd_sums_wg_kernel, cgrid, dim3(512), 0, st, d_out, ws + L.xhat[nl - 1], t->bn_w[nl - 1], t->bn_b[nl - 1],
                            t->last_act, N, part);
         hipLaunchKernelGGL(bn_bwd_finish_wg_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, part, wgs_per_call, N,
                            (int)n_calls, s1, s2, t->dbn_w[nl - 1], t->dbn_b[nl - 1]);

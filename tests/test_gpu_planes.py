@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err, check_grads
+from conftest import rel_err, check_grads, is_pre_bn_bias
 from planes_decode import decode, decode_t
 
 pytestmark = pytest.mark.gpu
@@ -591,3 +591,38 @@ def test_batch_norm_input_gradient_and_fallbacks(monkeypatch):
     assert _lib.load().abn_debug_last_forward_path() == 0
     e.sum().backward()
     assert _lib.load().abn_debug_last_backward_path() == 0
+
+
+def test_batch_norm_training_in_the_bf16_arithmetic(monkeypatch):
+    """The single-plane instantiations of the BatchNorm launches: against the per-layer kernels in the same
+    arithmetic (8-bit operands on both sides, different summation orders)."""
+    import abnet3_amd.loss as L
+    from abnet3_amd import _lib
+    kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=500, output_dim=100, activation_layer='sigmoid', p_dropout=0.0,
+              batch_norm=True)
+    rng = np.random.default_rng(11)
+    B = 128
+    x1, x2 = dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32))
+    y = dev(rng.choice([1, -1], B))
+    res = []
+    for planes in ('1', '0'):
+        monkeypatch.setenv('ABN_BN_PLANES', planes)
+        net, _, _ = build(kw, seed=2, precision='bf16')
+        net.train()
+        e1, e2 = net(x1, x2)
+        assert _lib.load().abn_debug_last_forward_path() == (5 if planes == '1' else 0)
+        lv = L.coscos2(avg=False)(e1, e2, y)
+        lv.backward()
+        res.append((e1.detach().cpu().numpy(), float(lv.detach()), {k: q.grad.cpu().numpy() for k, q in net.named_parameters()},
+                    {k: v.cpu().numpy() for k, v in net.state_dict().items() if 'running' in k}))
+    assert rel_err(res[0][0], res[1][0]) < 3e-2
+    assert abs(res[0][1] - res[1][1]) < 3e-2 * abs(res[1][1])
+    for k, v in res[1][3].items():
+        assert rel_err(res[0][3][k], v) < 1e-2, k
+    gmax = max(np.abs(v).max() for v in res[1][2].values())
+    for k, v in res[1][2].items():
+        if np.abs(v).max() < 1e-4 * gmax or is_pre_bn_bias(k, True):      # (zero but for rounding)
+            continue
+        a, b = res[0][2][k].ravel().astype(np.float64), v.ravel().astype(np.float64)
+        assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.98, k
+        assert abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < 0.1, k
