@@ -526,22 +526,24 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ a, const float* da
 
 // bn_planes_backward's small kernels.  The output layer's sums of dy and dy * xhat per workgroup of 32 rows
 // (further down bn_bwd_layer_kernel leaves them itself): one thread per column, [workgroup][2][PL_MAXW].
-__global__ __launch_bounds__(512) void bn_bwd_sums_wg_kernel(const float* __restrict__ da, const float* __restrict__ xhat,
+__global__ __launch_bounds__(512) void bn_bwd_sums_wg_kernel(const float* __restrict__ da, const float* __restrict__ z,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             int act, int C, float* __restrict__ part)
+                                                             int act, int C, int64_t rows_per_call, float* __restrict__ part)
 {
     __shared__ float su[8][64], sv[8][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;         // 64 columns x 8 groups of 4 rows
     const int64_t r0 = (int64_t)blockIdx.x * PL_ROWS + 4 * ty;
+    const int64_t g = ((int64_t)blockIdx.x * PL_ROWS) / rows_per_call;
     for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = c0 + tx;
         float u = 0.0f, v = 0.0f;
         if (c < C) {
-            const float ga = gamma[c], be = beta[c];
+            const float ga = gamma[c], be = beta[c], mu = mean[g * C + c], is = invstd[g * C + c];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t i = (r0 + r) * C + c;
-                const float xh = xhat[i];
+                const float xh = (z[i] - mu) * is;
                 const float dy = da[i] * act_grad(act_apply(xh * ga + be, act), act);
                 u += dy;
                 v += dy * xh;
@@ -924,8 +926,8 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     const int wgs_per_call = (int)(rpc / PL_ROWS);
     {
         const int N = (int)t->dims[nl];
-        hipLaunchKernelGGL(bn_bwd_sums_wg_kernel, cgrid, dim3(512), 0, st, d_out, ws + L.xhat[nl - 1], t->bn_w[nl - 1], t->bn_b[nl - 1],
-                           t->last_act, N, part);
+        hipLaunchKernelGGL(bn_bwd_sums_wg_kernel, cgrid, dim3(512), 0, st, d_out, ws + L.xhat[nl - 1], ws + L.mean[nl - 1],
+                           ws + L.invstd[nl - 1], t->bn_w[nl - 1], t->bn_b[nl - 1], t->last_act, N, rpc, part);
         hipLaunchKernelGGL(bn_bwd_finish_wg_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, part, wgs_per_call, N,
                            (int)n_calls, s1, s2, t->dbn_w[nl - 1], t->dbn_b[nl - 1]);
     }
@@ -937,7 +939,8 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
         q.act_l = (l == nl - 1) ? t->last_act : t->act;
         q.act_prev = t->act;
         q.da = (l == nl - 1) ? d_out : scratch + B.dz[cur];
-        q.xhat = ws + L.xhat[l];
+        q.z = ws + L.xhat[l];                         // (the forward left z there, un-normalised)
+        q.mean = ws + L.mean[l];
         q.invstd = ws + L.invstd[l];
         q.gamma = t->bn_w[l]; q.beta = t->bn_b[l];
         q.s1 = s1; q.s2 = s2;
@@ -946,7 +949,8 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
         q.tp_steps = pl_row_steps(rows);
         q.wpt = (l >= 1 || dx) ? image + PL.wpt[l] : nullptr;
         q.da_prev = l >= 1 ? scratch + B.dz[cur ^ 1] : dx;
-        if (l >= 1) { q.xhat_prev = ws + L.xhat[l - 1]; q.gamma_prev = t->bn_w[l - 1]; q.beta_prev = t->bn_b[l - 1]; q.part_out = part; }
+        if (l >= 1) { q.z_prev = ws + L.xhat[l - 1]; q.mean_prev = ws + L.mean[l - 1]; q.invstd_prev = ws + L.invstd[l - 1];
+                      q.gamma_prev = t->bn_w[l - 1]; q.beta_prev = t->bn_b[l - 1]; q.part_out = part; }
         if (np == 3) hipLaunchKernelGGL(bn_bwd_layer_kernel<3>, cgrid, dim3(PL_NT), pl_lds_bytes(3), st, q);
         else hipLaunchKernelGGL(bn_bwd_layer_kernel<1>, cgrid, dim3(PL_NT), pl_lds_bytes(1), st, q);
         if (l >= 1) {
@@ -1222,10 +1226,10 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                                    t->bn_rm[l], t->bn_rv[l]);
             }
             const int N = (int)t->dims[nl];
-            float* z = ws + L.xhat[nl - 1];
+            const float* z = ws + L.xhat[nl - 1];      // (stays un-normalised, like every layer's: the backward normalises again)
             hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, z, rows, rpc, N, ws + L.mean[nl - 1],
                                ws + L.invstd[nl - 1], t->bn_rm[nl - 1], t->bn_rv[nl - 1], 1, t->bn_w[nl - 1], t->bn_b[nl - 1],
-                               t->last_act, z, ws + L.a[nl - 1]);
+                               t->last_act, static_cast<float*>(nullptr), ws + L.a[nl - 1]);
             ABN_CHECK_LAUNCH("tower_forward (BatchNorm, planes)");
             last_forward_path = 5;
             return ABN_OK;

@@ -699,7 +699,7 @@ struct BnTrainP {
     int l;
     const float* mean;      // [n_calls][dims[l]] of layer l - 1 (l >= 1)
     const float* invstd;
-    float* z_prev;          // [rows][dims[l]]: z_{l-1} in, xhat_{l-1} out (in place)
+    const float* z_prev;    // [rows][dims[l]]: z_{l-1} (it stays: the backward normalises it again)
     float* a_prev;          // [rows][dims[l]]: act(gamma xhat + beta) out, row-major (null: not wanted)
     // (p.tp[l]: the same activations as the transposed image [a_{l-1} | 1] the weight gradient reads)
 };
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
         __syncthreads();
         const int steps = pl_steps(K), blocks = steps / 2;
         const int gr = row0 + r;                       // (whole workgroups only: rows_call % 32 == 0)
-        float* const zrow = q.z_prev + (int64_t)gr * K;
+        const float* const zrow = q.z_prev + (int64_t)gr * K;
         float* const arow = q.a_prev ? q.a_prev + (int64_t)gr * K : nullptr;
         char* const tp = p.tp[l];
         with_act(p.act[l - 1], [&](auto tag) {
@@ -752,13 +752,8 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
                             const f32x4 z4 = *reinterpret_cast<const f32x4*>(zrow + c);
                             const f32x4 mu = *reinterpret_cast<const f32x4*>(mean_s + c), is = *reinterpret_cast<const f32x4*>(is_s + c);
                             const f32x4 ga = *reinterpret_cast<const f32x4*>(ga_s + c), be = *reinterpret_cast<const f32x4*>(be_s + c);
-                            f32x4 xh;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                xh[e] = (z4[e] - mu[e]) * is[e];
-                                v[u][e] = act_apply(xh[e] * ga[e] + be[e], ACT);
-                            }
-                            *reinterpret_cast<f32x4*>(zrow + c) = xh;
+                            for (int e = 0; e < 4; ++e) v[u][e] = act_apply(((z4[e] - mu[e]) * is[e]) * ga[e] + be[e], ACT);
                             if (arow) *reinterpret_cast<f32x4*>(arow + c) = v[u];
                         }
                     }
@@ -1100,7 +1095,8 @@ struct BnBwdP {
     int N, K;                      // dims[l + 1], dims[l]
     int act_l, act_prev;           // activations behind BatchNorm l and l - 1
     const float* da;               // [rows][N] d loss / d a_l
-    const float* xhat;             // [rows][N]
+    const float* z;                // [rows][N] the forward's pre-normalisation values: xhat = (z - mean) invstd, as there
+    const float* mean;             // [n_calls][N]
     const float* invstd;           // [n_calls][N]
     const float* gamma;            // [N]
     const float* beta;
@@ -1111,7 +1107,9 @@ struct BnBwdP {
     int64_t tp_steps;
     const char* wpt;               // packed W_l^T (null: no product -- layer 0 without an input gradient)
     float* da_prev;                // out [rows][K]: d loss / d a_{l-1}, or d loss / d input for l == 0
-    const float* xhat_prev;        // [rows][K]  (l >= 1)
+    const float* z_prev;           // [rows][K]  (l >= 1)
+    const float* mean_prev;        // [n_calls][K]
+    const float* invstd_prev;
     const float* gamma_prev;       // [K]
     const float* beta_prev;
     float* part_out;               // out [workgroup][2][PL_MAXW]: sums over its 32 rows of dy_{l-1}, dy_{l-1} xhat_{l-1}
@@ -1143,6 +1141,7 @@ __device__ __forceinline__ void bn_dgrad_product(const BnBwdP& q, char* __restri
         for (int x = 0; x < 16; ++x) acc[0][x] += part[(wave * 16 + x) * 64 + lane];
     }
     const int gr = row0 + r;                          // (whole workgroups only)
+    const int call = row0 / q.rows_call;
     float* const orow = q.da_prev + (int64_t)gr * K;
     float* const pw = q.l >= 1 ? q.part_out + (int64_t)blockIdx.x * (2 * PL_MAXW) : nullptr;
     with_act(q.act_prev, [&](auto tag) {
@@ -1157,7 +1156,12 @@ __device__ __forceinline__ void bn_dgrad_product(const BnBwdP& q, char* __restri
                 if (live) *reinterpret_cast<f32x4*>(orow + n) = d4;
                 if (q.l >= 1) {
                     const int nc = live ? n : K - 4;
-                    const f32x4 xh = *reinterpret_cast<const f32x4*>(q.xhat_prev + (int64_t)gr * K + nc);
+                    const f32x4 z4 = *reinterpret_cast<const f32x4*>(q.z_prev + (int64_t)gr * K + nc);
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(q.mean_prev + (int64_t)call * K + nc);
+                    const f32x4 is = *reinterpret_cast<const f32x4*>(q.invstd_prev + (int64_t)call * K + nc);
+                    f32x4 xh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xh[e] = (z4[e] - mu[e]) * is[e];
                     const f32x4 ga = *reinterpret_cast<const f32x4*>(q.gamma_prev + nc), be = *reinterpret_cast<const f32x4*>(q.beta_prev + nc);
                     f32x4 sd, sq;
 #pragma unroll
@@ -1194,10 +1198,12 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
     const int call = row0 / q.rows_call;
     const float nf = (float)q.rows_call;
     float* const k_s = part, * const ga_s = part + PL_MAXW, * const be_s = part + 2 * PL_MAXW, * const s1_s = part + 3 * PL_MAXW,
-               * const s2_s = part + 4 * PL_MAXW;
+               * const s2_s = part + 4 * PL_MAXW, * const mu_s = part + 5 * PL_MAXW, * const is_s = part + 6 * PL_MAXW;
     for (int c = threadIdx.x; c < N; c += PL_NT) {
         const float ga = q.gamma[c];
         k_s[c] = ga * q.invstd[(int64_t)call * N + c] / nf;
+        mu_s[c] = q.mean[(int64_t)call * N + c];
+        is_s[c] = q.invstd[(int64_t)call * N + c];
         ga_s[c] = ga;
         be_s[c] = q.beta[c];
         s1_s[c] = q.s1[(int64_t)call * N + c];
@@ -1207,7 +1213,7 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
     const int steps = pl_steps(N), blocks = steps / 2;
     const int gr = row0 + r;
     const float* const drow = q.da + (int64_t)gr * N;
-    const float* const xrow = q.xhat + (int64_t)gr * N;
+    const float* const zrow = q.z + (int64_t)gr * N;
     const float* const mrow = q.mask ? q.mask + (int64_t)gr * N : nullptr;
     with_act(q.act_l, [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
@@ -1221,7 +1227,11 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
                 for (int u = 0; u < 2; ++u) {
                     const int c = 16 * s + 4 * h + 8 * u;
                     if (c < N) {
-                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + c), xh = *reinterpret_cast<const f32x4*>(xrow + c);
+                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + c), z4 = *reinterpret_cast<const f32x4*>(zrow + c);
+                        const f32x4 mu = *reinterpret_cast<const f32x4*>(mu_s + c), is = *reinterpret_cast<const f32x4*>(is_s + c);
+                        f32x4 xh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xh[e] = (z4[e] - mu[e]) * is[e];
                         const f32x4 k4 = *reinterpret_cast<const f32x4*>(k_s + c), ga = *reinterpret_cast<const f32x4*>(ga_s + c);
                         const f32x4 be = *reinterpret_cast<const f32x4*>(be_s + c);
                         const f32x4 a1 = *reinterpret_cast<const f32x4*>(s1_s + c), a2 = *reinterpret_cast<const f32x4*>(s2_s + c);

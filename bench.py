@@ -66,7 +66,7 @@ def kernel_names(prec):
         return ('void abn::tower_fwd_fused_kernel<0>(abn::FusedFwdP)',
                 'void abn::gemm_bwd_pair_kernel<128, 64, 0>(abn::GemmP, int, abn::GemmP)')
     planes = 3 if prec == 'bf16x3' else 1
-    return ('void abn::tower_fwd_planes_kernel<%d>(abn::PlanesFwdP)' % planes,
+    return ('void abn::tower_fwd_planes_kernel<%d, 0>(abn::PlanesFwdP)' % planes,
             'void abn::wgrad_planes_kernel<%d>(abn::WgradP)' % planes)
 
 
@@ -117,17 +117,19 @@ def _traffic(kernel):
 def planes_roofline(torch, net, reps=20):
     """precision bf16x3 / bf16 (csrc/tower_planes.h): the step is three launches of similar length -- the
     forward chain, the data-gradient chain, the weight gradients -- plus the fused reduction + optimizer.
-    The DOMINANT one by time is wgrad_planes_kernel: every layer's dW = dZ^T [A | 1] over the 2 x 4096
-    rows, split over the rows into slabs, one launch.  Each of the three is timed live, alone, `reps`
+    They are within a few microseconds of each other; the one that took longest in THIS run is the line's
+    top level (`dominant` names it), the other two follow under their names.  wgrad_planes_kernel: every
+    layer's dW = dZ^T [A | 1] over the 2 x 4096 rows, split over the rows into slabs, one launch (its tiles
+    placed so that an XCD's L2 serves the re-reads).  Each of the three is timed live, alone, `reps`
     launches captured into one hipGraph and bracketed by HIP events on the launch stream (the two
     backward kernels through abn_tower_backward with ABN_PLANES_BWD_ONLY, a measurement switch that
-    issues one of its two launches; the forward together with the ~5 us pack_planes_kernel that
-    precedes it).  Algorithmic FLOPs of the weight gradients: 2 * 8192 * sum_l N_l (K_l + 1).
+    issues one of its two launches; the forward with its packed weight image still valid, i.e. without
+    the ~5 us pack_planes_kernel a step's forward starts with).  Algorithmic FLOPs: weight gradients 2 * 8192 * sum_l N_l (K_l + 1), the chains
+    2 * 8192 * sum_l N_l K_l (the data-gradient chain without the first layer).
     Roof: the dense bf16 MFMA peak divided by the bf16 products each algorithmic product costs (six
     for bf16x3: 2500 / 6 = 416.7 TFLOP/s algorithmic; one for bf16).  Both peaks assume the 2.4 GHz
     boost clock; under this workload the chip holds ~1.6-1.8 GHz (s_memtime against wall clock,
-    tools/probes/mfma_peak.hip), and the kernel's other bound is its operand stream:
-    `hbm` gives the measured TCC traffic per launch over the launch time against ~6 TB/s attainable."""
+    tools/probes/mfma_peak.hip).  `hbm` gives the dominant launch's measured TCC traffic over its time."""
     prec = net.precision
     peak = {'bf16x3': X3_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS}[prec]
     fwd_name, wgrad_name = kernel_names(prec)
@@ -151,39 +153,45 @@ def planes_roofline(torch, net, reps=20):
     net.take_pending_reduce()
     fl_w = 2.0 * rows * sum(dims[l + 1] * (dims[l] + 1) for l in range(4))
     fl_d = 2.0 * rows * sum(dims[l + 1] * dims[l] for l in range(1, 4))
-    t = times['wgrad']
-    achieved = fl_w / t / 1e12
-    traffic = _traffic('wgrad_planes_kernel')
-    out = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-           'frac': round(achieved / peak, 4), 'traffic': traffic, 'arithmetic': prec,
+    fl_f = 2.0 * rows * sum(dims[l + 1] * dims[l] for l in range(4))
+
+    def fwd():                                      # the training forward (the inference one stores nothing for a backward)
+        net.direct_forward(x12[:BATCH], x12[BATCH:])
+    times['forward'] = _time_launches(torch, fwd, reps)
+    planes = 3 if prec == 'bf16x3' else 1
+    launches = {
+        'weight_gradients': (wgrad_name, 'wgrad_planes_kernel<%d>' % planes, times['wgrad'], fl_w,
+                             "all four layers' weight and bias gradients, one launch"),
+        'dgrad_chain': ('void abn::tower_dgrad_planes_kernel<%d>(abn::PlanesBwdP)' % planes,
+                        'tower_dgrad_planes_kernel<%d>' % planes, times['dgrad'], fl_d, 'dZ through the three upper layers, one launch'),
+        'forward': (fwd_name, 'tower_fwd_planes_kernel<%d, 0>' % planes, times['forward'], fl_f,
+                    'the whole training forward of both towers; the persistent weight image is valid across these '
+                    'launches, so no pack_planes_kernel runs in between'),
+    }
+    entries = {}
+    for key, (name, short, t, fl, what) in launches.items():
+        entries[key] = {'kernel': '%s  (%s; alone, back to back from one hipGraph)' % (name, what),
+                        'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / peak, 4),
+                        'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl, 'traffic': _traffic(short)}
+    # the three launches are within a few us of each other: the line's top level is whichever took longest here
+    dominant = max(entries, key=lambda k: entries[k]['avg_launch_us'])
+    e = entries[dominant]
+    out = {'bound': 'mfma', 'achieved': e['achieved'], 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': e['frac'],
+           'traffic': e['traffic'], 'arithmetic': prec,
            'peak_note': {'bf16x3': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per algorithmic product',
                          'bf16': 'dense bf16 MFMA'}[prec],
-           'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-           'kernel': wgrad_name + '  (all four layers\' weight and bias gradients, one launch, alone, back to back '
-                     'from one hipGraph)',
-           'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl_w}
-    if traffic:
-        gbs = traffic / t / 1e9
+           'frac_of_fp32_mfma_peak': round(e['achieved'] / FP32_MFMA_PEAK_TFLOPS, 4),
+           'dominant': dominant, 'kernel': e['kernel'], 'avg_launch_us': e['avg_launch_us'],
+           'flop_per_launch': e['flop_per_launch']}
+    if e['traffic']:
+        gbs = e['traffic'] / (e['avg_launch_us'] * 1e-6) / 1e9
         out['hbm'] = {'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
-                      'note': 'measured TCC traffic per launch (profiles/r02_pmc_traffic.json) / launch time: the '
-                              'kernel streams both operands of every layer from HBM / Infinity Cache'}
-    t = times['dgrad']
-    out['dgrad_chain'] = {'kernel': 'tower_dgrad_planes_kernel (dZ through the three upper layers, one launch)',
-                          'achieved': round(fl_d / t / 1e12, 2), 'frac': round(fl_d / t / 1e12 / peak, 4),
-                          'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl_d,
-                          'traffic': _traffic('tower_dgrad_planes_kernel')}
+                      'note': 'measured TCC traffic per launch (profiles/r02_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, '
+                              'Infinity-Cache hits included) / launch time'}
+    for key, v in entries.items():
+        if key != dominant:
+            out[key] = v
     out['backward_sequence_us'] = round(times['both'] * 1e6, 2)
-
-    def fwd():
-        with torch.no_grad():
-            net.forward_pair_rows(x12)
-    t = _time_launches(torch, fwd, reps)
-    fl = 2.0 * rows * sum(dims[l + 1] * dims[l] for l in range(4))
-    out['forward'] = {'kernel': fwd_name + '  (the whole forward of both towers; timed with the pack_planes_kernel '
-                                'launch that precedes it in abn_tower_forward)',
-                      'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / peak, 4),
-                      'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl,
-                      'traffic': _traffic('tower_fwd_planes_kernel')}
     return out
 
 
