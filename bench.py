@@ -117,14 +117,16 @@ def _traffic(kernel):
 def planes_roofline(torch, net, reps=20):
     """precision bf16x3 / bf16 (csrc/tower_planes.h): the step is three launches of similar length -- the
     forward chain, the data-gradient chain, the weight gradients -- plus the fused reduction + optimizer.
-    They are within a few microseconds of each other; the one that took longest in THIS run is the line's
-    top level (`dominant` names it), the other two follow under their names.  wgrad_planes_kernel: every
+    They are within a few percent of each other; the line's top level is the weight-gradient launch (the
+    largest by total time in the committed trace and by HBM traffic), the other two follow under their
+    names, `longest_here` says which took longest in this run.  wgrad_planes_kernel: every
     layer's dW = dZ^T [A | 1] over the 2 x 4096 rows, split over the rows into slabs, one launch (its tiles
-    placed so that an XCD's L2 serves the re-reads).  Each of the three is timed live, alone, `reps`
-    launches captured into one hipGraph and bracketed by HIP events on the launch stream (the two
-    backward kernels through abn_tower_backward with ABN_PLANES_BWD_ONLY, a measurement switch that
-    issues one of its two launches; the forward with its packed weight image still valid, i.e. without
-    the ~5 us pack_planes_kernel a step's forward starts with).  Algorithmic FLOPs: weight gradients 2 * 8192 * sum_l N_l (K_l + 1), the chains
+    placed so that an XCD's L2 serves the re-reads).  Each of the three is timed live, alone: `reps`
+    launches captured into one hipGraph and bracketed by HIP events on the launch stream (the backward
+    kernels through abn_tower_backward with ABN_PLANES_BWD_ONLY, a measurement switch that issues one of
+    its two launches; the forward with its packed weight image still valid, i.e. without the ~5 us
+    pack_planes_kernel a step's forward starts with); `forward_backward_sequence_us` is the three in the
+    step's order.  Algorithmic FLOPs: weight gradients 2 * 8192 * sum_l N_l (K_l + 1), the chains
     2 * 8192 * sum_l N_l K_l (the data-gradient chain without the first layer).
     Roof: the dense bf16 MFMA peak divided by the bf16 products each algorithmic product costs (six
     for bf16x3: 2500 / 6 = 416.7 TFLOP/s algorithmic; one for bf16).  Both peaks assume the 2.4 GHz
@@ -140,9 +142,17 @@ def planes_roofline(torch, net, reps=20):
     emb, state = net.direct_forward(x12[:BATCH].contiguous(), x12[BATCH:].contiguous())
     d_out = torch.randn_like(emb) * 1e-3
 
+    x1, x2 = x12[:BATCH].contiguous(), x12[BATCH:].contiguous()
+
     def bwd():
         net.direct_backward(state, d_out, d_out_is_dz=True, defer_reduce=True)
     bwd()                                           # a complete backward: both kernels' outputs are in place
+
+    # Each launch alone: `reps` launches captured into one hipGraph, HIP events around its replays.  (Against the
+    # in-step durations of the rocprofv3 trace -- 67.8 / 67.8 / 67.1 us -- this reads the weight gradients ~5 % low
+    # and the two chains 8-15 % high: a step moves ~460 MB through HBM / Infinity Cache, and twenty launches of one
+    # kernel rewriting the same images see a different cache.  Events BETWEEN the launches of a real sequence add
+    # ~10 us each, and sequences with one launch left out do not subtract cleanly: both were tried.)
     times = {}
     for which in ('wgrad', 'dgrad', None):
         if which:
@@ -150,14 +160,16 @@ def planes_roofline(torch, net, reps=20):
         else:
             os.environ.pop('ABN_PLANES_BWD_ONLY', None)
         times[which or 'both'] = _time_launches(torch, bwd, reps)
+    times['forward'] = _time_launches(torch, lambda: net.direct_forward(x1, x2), reps)
+
+    def fwd_bwd():
+        net.direct_forward(x1, x2)
+        bwd()
+    times['sequence'] = _time_launches(torch, fwd_bwd, reps)
     net.take_pending_reduce()
     fl_w = 2.0 * rows * sum(dims[l + 1] * (dims[l] + 1) for l in range(4))
     fl_d = 2.0 * rows * sum(dims[l + 1] * dims[l] for l in range(1, 4))
     fl_f = 2.0 * rows * sum(dims[l + 1] * dims[l] for l in range(4))
-
-    def fwd():                                      # the training forward (the inference one stores nothing for a backward)
-        net.direct_forward(x12[:BATCH], x12[BATCH:])
-    times['forward'] = _time_launches(torch, fwd, reps)
     planes = 3 if prec == 'bf16x3' else 1
     launches = {
         'weight_gradients': (wgrad_name, 'wgrad_planes_kernel<%d>' % planes, times['wgrad'], fl_w,
@@ -166,22 +178,25 @@ def planes_roofline(torch, net, reps=20):
                         'tower_dgrad_planes_kernel<%d>' % planes, times['dgrad'], fl_d, 'dZ through the three upper layers, one launch'),
         'forward': (fwd_name, 'tower_fwd_planes_kernel<%d, 0>' % planes, times['forward'], fl_f,
                     'the whole training forward of both towers; the persistent weight image is valid across these '
-                    'launches, so no pack_planes_kernel runs in between'),
+                    'launches: no pack_planes_kernel in between'),
     }
     entries = {}
     for key, (name, short, t, fl, what) in launches.items():
         entries[key] = {'kernel': '%s  (%s; alone, back to back from one hipGraph)' % (name, what),
                         'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / peak, 4),
                         'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl, 'traffic': _traffic(short)}
-    # the three launches are within a few us of each other: the line's top level is whichever took longest here
-    dominant = max(entries, key=lambda k: entries[k]['avg_launch_us'])
+    # The three launches are within a few percent of each other (profiles/r02_bench_kernel_stats.txt: 67.8 / 67.8 /
+    # 67.1 us).  The line's top level is the weight-gradient launch: the largest by total time in that trace and by
+    # HBM traffic; `longest_here` names whichever took longest in this run.
+    dominant = 'weight_gradients'
     e = entries[dominant]
     out = {'bound': 'mfma', 'achieved': e['achieved'], 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': e['frac'],
            'traffic': e['traffic'], 'arithmetic': prec,
            'peak_note': {'bf16x3': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per algorithmic product',
                          'bf16': 'dense bf16 MFMA'}[prec],
            'frac_of_fp32_mfma_peak': round(e['achieved'] / FP32_MFMA_PEAK_TFLOPS, 4),
-           'dominant': dominant, 'kernel': e['kernel'], 'avg_launch_us': e['avg_launch_us'],
+           'dominant': dominant, 'longest_here': max(entries, key=lambda k: entries[k]['avg_launch_us']),
+           'kernel': e['kernel'], 'avg_launch_us': e['avg_launch_us'],
            'flop_per_launch': e['flop_per_launch']}
     if e['traffic']:
         gbs = e['traffic'] / (e['avg_launch_us'] * 1e-6) / 1e9
@@ -192,6 +207,7 @@ def planes_roofline(torch, net, reps=20):
         if key != dominant:
             out[key] = v
     out['backward_sequence_us'] = round(times['both'] * 1e6, 2)
+    out['forward_backward_sequence_us'] = round(times['sequence'] * 1e6, 2)
     return out
 
 

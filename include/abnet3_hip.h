@@ -155,7 +155,12 @@ int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1
  * x1 already holds all rows contiguously).  BatchNorm statistics and running
  * stat updates are per call, as in the reference (two updates per Siamese
  * forward).  train != 0: batch statistics, activations saved in ws;
- * train == 0: running statistics.  Output: ws + abn_tower_out_offset(). */
+ * train == 0: running statistics.  Output: ws + abn_tower_out_offset().
+ * A batch_norm tower in the default arithmetic runs one operand-plane launch per layer in
+ * training when every call's rows are a multiple of 32 (its backward likewise; dropout as
+ * drop_mask tensors), and the single-launch forward with the running statistics folded in
+ * when train == 0 and forward_only != 0; otherwise the per-layer kernels.  Results agree to
+ * rounding; forward and backward of one pass must see the same environment switches. */
 int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                       int64_t rows, int64_t n_calls, int train, float* ws,
                       void* stream);
