@@ -709,8 +709,8 @@ static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, 
 }
 
 // The training forward and the backward of a BatchNorm tower, one operand-plane launch per layer
-// (bn_fwd_layer_kernel, bn_bwd_layer_kernel): same conditions, whole workgroups per forward_once call, mask
-// tensors for the dropout.  Forward and backward must agree: both ask here.
+// (bn_fwd_layer_kernel, bn_bwd_layer_kernel): same conditions, whole workgroups per forward_once call.
+// Forward and backward must agree: both ask here.
 // ABN_BN_PLANES=0: the per-layer kernels (A/B measurements).
 static bool bn_train_planes_path(const abn_tower_desc* t, int64_t rows, int64_t n_calls, const float* x1, const float* x2,
                                  const float* ws)
@@ -945,6 +945,8 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
         q.gamma = t->bn_w[l]; q.beta = t->bn_b[l];
         q.s1 = s1; q.s2 = s2;
         q.mask = t->drop_mask[l];
+        q.drop_seed = reinterpret_cast<const unsigned long long*>(t->drop_seed);
+        q.drop_p = t->drop_p;
         q.dzp = reinterpret_cast<char*>(scratch + B.dzp[l]);
         q.tp_steps = pl_row_steps(rows);
         q.wpt = (l >= 1 || dx) ? image + PL.wpt[l] : nullptr;
@@ -1068,13 +1070,14 @@ int64_t abn_tower_out_offset(const abn_tower_desc* t, int64_t rows, int64_t n_ca
 
 // Diagnostics / tests only (not in the header): float offset of one of the operand-fragment images
 // -- which = 0 packed W_l, 1 packed W_l^T, 2 transposed planes [input of layer l | 1] (all in the
-// forward workspace), 3 transposed planes of dZ_l (in the backward scratch) -- or -1.
+// forward workspace), 3 transposed planes of dZ_l (in the backward scratch), 4 a BatchNorm layer's z_l -- or -1.
 int64_t abn_debug_planes_offset(const abn_tower_desc* t, int64_t rows, int64_t n_calls, int which, int l)
 {
     if (check_desc(t, rows, n_calls) != ABN_OK || l < 0 || l >= t->n_layers) return -1;
     if (which == 3) return make_bwd_layout(t, rows).dzp[l];
     const Layout L = make_layout(t, rows, n_calls);
     if (which == 2) return L.tp[l];
+    if (which == 4) return L.xhat[l];            // BatchNorm: z_l (bn_fwd_layer_kernel) / xhat_l (per-layer kernels)
     if (which != 0 && which != 1) return -1;
     const PackLayout P = make_pack_layout(t);
     // relative to abn_tower_desc.wpack when the caller keeps one, else to the workspace
@@ -1094,6 +1097,12 @@ int abn_debug_last_backward_path(void) { return last_backward_path; }
 int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws, int train)
 {
     if (check_desc(t, rows, 1) != ABN_OK) return -1;
+    // (BatchNorm in training: the call count is not known here -- yes when every possible one gives whole workgroups)
+    if (train && t->batch_norm) {
+        for (int64_t n = 1; n <= 8; ++n)
+            if (rows % n == 0 && !bn_train_planes_path(t, rows, n, x1, x2, ws)) return 0;
+        return 1;
+    }
     return planes_path(t, rows, x1, x2, ws, train ? PLANES_TRAIN : PLANES_EVAL_FORWARD) ? 1 : 0;
 }
 
@@ -1140,11 +1149,11 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
     for (int l = 0; l < t->n_layers && fusable; ++l)
         fusable = aligned16(t->W[l]) && (!t->drop_mask[l] || !train || aligned16(t->drop_mask[l]));
     const int pmode = train ? PLANES_TRAIN : PLANES_EVAL_FORWARD;
-    if (t->drop_seed && train && !planes_path(t, rows, x1, x2, ws, pmode)) {
+    const bool bn_train = train && bn_train_planes_path(t, rows, n_calls, x1, x2, ws);
+    if (t->drop_seed && train && !bn_train && !planes_path(t, rows, x1, x2, ws, pmode)) {
         for (int l = 0; l < t->n_layers; ++l)
             if (!t->drop_mask[l]) { set_error("tower_forward: in-kernel dropout (drop_seed) needs the operand-plane kernels: pass drop_mask tensors"); return ABN_E_UNSUPPORTED; }
     }
-    const bool bn_train = train && bn_train_planes_path(t, rows, n_calls, x1, x2, ws);
     if (bn_train || planes_path(t, rows, x1, x2, ws, pmode)) {
         const int np = planes_of(t->precision);
         PackTable pk = {};

@@ -1102,7 +1102,9 @@ struct BnBwdP {
     const float* beta;
     const float* s1;               // [n_calls][N]
     const float* s2;
-    const float* mask;             // layer l's dropout mask [rows][N] (null: none)
+    const float* mask;             // layer l's dropout mask [rows][N] (null: none, or the seed's)
+    const unsigned long long* drop_seed;   // the forward's in-kernel dropout, regenerated here (null: off; mask wins)
+    float drop_p;
     char* dzp;                     // out: transposed planes of dz_l
     int64_t tp_steps;
     const char* wpt;               // packed W_l^T (null: no product -- layer 0 without an input gradient)
@@ -1215,6 +1217,7 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
     const float* const drow = q.da + (int64_t)gr * N;
     const float* const zrow = q.z + (int64_t)gr * N;
     const float* const mrow = q.mask ? q.mask + (int64_t)gr * N : nullptr;
+    const DropGen drop = make_drop(q.mask ? nullptr : q.drop_seed, q.drop_p, q.l);
     with_act(q.act_l, [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
         for (int kb = wave; kb < blocks; kb += PL_WAVES) {
@@ -1237,6 +1240,7 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
                         const f32x4 a1 = *reinterpret_cast<const f32x4*>(s1_s + c), a2 = *reinterpret_cast<const f32x4*>(s2_s + c);
                         f32x4 m4 = {1.f, 1.f, 1.f, 1.f};
                         if (mrow) m4 = *reinterpret_cast<const f32x4*>(mrow + c);
+                        else if (drop.on) m4 = drop4(drop, gr, c);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float a = act_apply(xh[e] * ga[e] + be[e], ACT);

@@ -626,3 +626,54 @@ def test_batch_norm_training_in_the_bf16_arithmetic(monkeypatch):
         a, b = res[0][2][k].ravel().astype(np.float64), v.ravel().astype(np.float64)
         assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.98, k
         assert abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < 0.1, k
+
+
+def test_batch_norm_with_dropout_drawn_inside_the_kernels():
+    """p_dropout > 0 on a BatchNorm tower: the per-layer launches hash the same per-forward seed as the
+    single-launch chains (forward epilogue, regenerated by the backward).  The masks are recovered from the
+    pre-normalisation values the forward leaves (a dropped entry is an exact zero) and fed back as tensors:
+    same embeddings, same gradients."""
+    from abnet3_amd import _lib
+    p_drop = 0.25
+    kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=96, output_dim=32, activation_layer='tanh', p_dropout=p_drop,
+              batch_norm=True)
+    net, _, _ = build(kw, seed=3, precision='bf16x3')
+    net.train()
+    rng = np.random.default_rng(8)
+    B = 128                                                     # 256 rows: whole workgroups for every call count
+    x1, x2 = dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32))
+    d_out = dev(rng.standard_normal((2 * B, 32)).astype(np.float32))
+    seg = net._segment_list()[0]
+    lib = _lib.load()
+    probe = seg.descriptor(with_grads=False)
+    assert lib.abn_tower_uses_planes(ctypes.byref(probe), 2 * B, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(x1), 1) == 1
+    emb, state = net.direct_forward(x1, x2)
+    assert lib.abn_debug_last_forward_path() == 5
+    sv = state[1]
+    assert type(sv.masks).__name__ == '_DropSeed'
+    net.direct_backward(state, d_out)
+    assert lib.abn_debug_last_backward_path() == 5
+    emb = emb.clone()
+    grads = {k: q.grad.clone() for k, q in net.named_parameters()}
+    fn = lib.abn_debug_planes_offset
+    fn.restype = ctypes.c_int64
+    desc = seg.descriptor(with_grads=False, masks=sv.masks)
+    masks = []
+    for l, w in enumerate((96, 96, 32)):
+        off = fn(ctypes.byref(desc), ctypes.c_int64(2 * B), ctypes.c_int64(2), 4, l)
+        assert off >= 0
+        z = sv.ws[off:off + 2 * B * w].view(2 * B, w)
+        m = (z != 0).float() / (1 - p_drop)
+        frac = float((z == 0).float().mean())
+        assert abs(frac - p_drop) < 0.03, (l, frac)
+        masks.append(m)
+    emb_b, state_b = net.direct_forward(x1, x2)
+    assert not torch.equal(emb, emb_b)                          # another forward, another seed
+    net._mask_override = masks
+    for q in net.parameters():
+        q.grad = None
+    emb_t, state_t = net.direct_forward(x1, x2)
+    net.direct_backward(state_t, d_out)
+    assert rel_err(emb_t.cpu().numpy(), emb.cpu().numpy()) < 1e-6
+    for k, q in net.named_parameters():
+        assert rel_err(q.grad.cpu().numpy(), grads[k].cpu().numpy(), floor=1e-6 * float(grads[k].abs().max()) + 1e-30) < 1e-5, k
