@@ -1,8 +1,10 @@
-"""The operand-plane kernels of csrc/tower_planes.h (precision bf16x3 / bf16, no BatchNorm, widths <= 512 and
-multiples of 4): the library takes them from 256 rows up by itself; here ABN_FUSED_MIN_ROWS = 0 forces them on
-small towers whose shapes walk every branch -- one and two column blocks per wave, the K-split of narrow layers,
-widths that are multiples of 32 (the column of ones then opens a block of its own), 512-wide layers, ragged row
-counts, dropout, every activation -- against the numpy oracle, plus a decode of the operand images themselves.
+"""The operand-plane kernels of csrc/tower_planes.h (precision bf16x3 / bf16, widths <= 512 and multiples of
+4): the library takes them from 256 rows up by itself; here ABN_FUSED_MIN_ROWS = 0 forces them on small towers
+whose shapes walk every branch -- one and two column blocks per wave, the K-split of narrow layers, widths that
+are multiples of 32 (the column of ones then opens a block of its own), 512-wide layers, ragged row counts,
+dropout, every activation -- against the numpy oracle, plus a decode of the operand images themselves.
+BatchNorm towers: the inference forward (running statistics in the epilogue), the one-launch-per-layer training
+forward and backward (batch statistics from per-workgroup sums), their dropout, bf16 and fallback cases.
 Needs an MI355X: run with -m gpu."""
 import ctypes
 
