@@ -400,7 +400,8 @@ __global__ void bn_stats_finish_kernel(const double* __restrict__ part, int nchu
 }
 
 // The same, from the per-workgroup statistics bn_fwd_layer_kernel leaves (tower_planes.h): 32 rows each,
-// sums shifted by the workgroup's first row c -- sum z = sd + 32 c, sum z^2 = sq + 2 c sd + 32 c^2 in float64.
+// sums shifted by the workgroup's first row c -- sum z = sd + n c, sum z^2 = sq + 2 c sd + n c^2 in float64
+// (n = the workgroup's rows: 32, fewer in the last one of a call).
 // A block = 64 columns x 16 groups of workgroups: every group adds its share in order, thread group 0 the
 // sixteen group sums in order (one thread per column walking 128 workgroups alone took 18 us).
 constexpr int BN_WG_GROUPS = 16;
@@ -424,8 +425,10 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
             for (int k = k0; k < k1; ++k) {           // fixed order; the loads are independent
                 const float* src = part + (int64_t)(g * wgs_per_call + k) * (3 * PL_MAXW);
                 const double sd = src[c], sq = src[PL_MAXW + c], cc = src[2 * PL_MAXW + c];
-                a += sd + 32.0 * cc;
-                b += sq + 2.0 * cc * sd + 32.0 * cc * cc;
+                const int64_t left = rows_per_call - (int64_t)k * PL_ROWS;
+                const double nk = left < PL_ROWS ? (double)left : (double)PL_ROWS;      // rows of workgroup k
+                a += sd + nk * cc;
+                b += sq + 2.0 * cc * sd + nk * cc * cc;
             }
         }
         __syncthreads();                              // (the previous call's sums have been read)
@@ -533,8 +536,9 @@ __global__ __launch_bounds__(512) void bn_bwd_sums_wg_kernel(const float* __rest
 {
     __shared__ float su[8][64], sv[8][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;         // 64 columns x 8 groups of 4 rows
-    const int64_t r0 = (int64_t)blockIdx.x * PL_ROWS + 4 * ty;
-    const int64_t g = ((int64_t)blockIdx.x * PL_ROWS) / rows_per_call;
+    const int64_t wpc = (rows_per_call + PL_ROWS - 1) / PL_ROWS;    // (bn_fwd_layer_kernel's workgroup -> rows map)
+    const int64_t g = blockIdx.x / wpc;
+    const int64_t r0 = g * rows_per_call + (blockIdx.x - g * wpc) * PL_ROWS + 4 * ty, r_end = (g + 1) * rows_per_call;
     for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = c0 + tx;
         float u = 0.0f, v = 0.0f;
@@ -542,6 +546,7 @@ __global__ __launch_bounds__(512) void bn_bwd_sums_wg_kernel(const float* __rest
             const float ga = gamma[c], be = beta[c], mu = mean[g * C + c], is = invstd[g * C + c];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (r0 + r >= r_end) break;
                 const int64_t i = (r0 + r) * C + c;
                 const float xh = (z[i] - mu) * is;
                 const float dy = da[i] * act_grad(act_apply(xh * ga + be, act), act);
@@ -620,6 +625,10 @@ struct Layout {
 };
 
 static inline int planes_of(int precision) { return precision == 2 ? 3 : 1; }
+// BatchNorm launches: workgroups of 32 rows never straddle two forward_once calls, so the row axis of the
+// transposed images is padded per call
+static inline int64_t bn_wgs_per_call(int64_t rows, int64_t n_calls) { return (rows / n_calls + PL_ROWS - 1) / PL_ROWS; }
+static inline int64_t bn_vrows(int64_t rows, int64_t n_calls) { return n_calls * bn_wgs_per_call(rows, n_calls) * PL_ROWS; }
 // the operand-plane kernels (tower_planes.h) take this tower's arithmetic and widths; with BatchNorm only
 // its inference forward (running statistics: a per-feature affine map in the epilogue)
 static bool planes_dims_ok(const abn_tower_desc* t)
@@ -675,12 +684,12 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
     for (int l = 0; l < t->n_layers; ++l) L.tp[l] = -1;
     L.wpack = -1;
     L.bn_wg = -1;
-    if (planes_dims_ok(t) && t->batch_norm && !t->forward_only) L.bn_wg = take((rows / PL_ROWS + 1) * 3 * PL_MAXW);
+    if (planes_dims_ok(t) && t->batch_norm && !t->forward_only) L.bn_wg = take((n_calls * bn_wgs_per_call(rows, n_calls) + 1) * 3 * PL_MAXW);
     if (planes_dims_ok(t)) {
         const int np = planes_of(t->precision);
         L.wpack = take(make_pack_layout(t).bytes / 4);
         if (!t->forward_only)                                      // (last in the workspace: an inference call simply asks for less)
-            for (int l = 0; l < t->n_layers; ++l) L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, rows, np) / 4);
+            for (int l = 0; l < t->n_layers; ++l) L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, t->batch_norm ? bn_vrows(rows, n_calls) : rows, np) / 4);
     }
     L.total = o;
     return L;
@@ -709,15 +718,14 @@ static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, 
 }
 
 // The training forward and the backward of a BatchNorm tower, one operand-plane launch per layer
-// (bn_fwd_layer_kernel, bn_bwd_layer_kernel): same conditions, whole workgroups per forward_once call.
-// Forward and backward must agree: both ask here.
+// (bn_fwd_layer_kernel, bn_bwd_layer_kernel): same conditions.  Forward and backward must agree: both ask here.
 // ABN_BN_PLANES=0: the per-layer kernels (A/B measurements).
 static bool bn_train_planes_path(const abn_tower_desc* t, int64_t rows, int64_t n_calls, const float* x1, const float* x2,
                                  const float* ws)
 {
     if (!t->batch_norm || t->forward_only) return false;
     if (getenv("ABN_BN_PLANES") && atoi(getenv("ABN_BN_PLANES")) == 0) return false;
-    if ((rows / n_calls) % PL_ROWS != 0) return false;
+    (void)n_calls;                                  // (any split of the rows into calls: workgroups are cut per call)
     abn_tower_desc u = *t;
     u.batch_norm = 0;
     return planes_path(&u, rows, x1, x2, ws);
@@ -817,8 +825,8 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
     }
     B.slabs = take(B.slab_stride * smax);
     for (int l = 0; l < t->n_layers; ++l)
-        B.dzp[l] = planes_dims_ok(t) ? take(pl_timage_bytes(t->dims[l + 1], rows, planes_of(t->precision)) / 4) : -1;
-    B.bn_wg = planes_dims_ok(t) && t->batch_norm ? take((rows / PL_ROWS + 1) * 2 * PL_MAXW) : -1;
+        B.dzp[l] = planes_dims_ok(t) ? take(pl_timage_bytes(t->dims[l + 1], t->batch_norm ? rows + 8 * PL_ROWS : rows, planes_of(t->precision)) / 4) : -1;
+    B.bn_wg = planes_dims_ok(t) && t->batch_norm ? take((rows / PL_ROWS + 9) * 2 * PL_MAXW) : -1;     // (up to 8 calls, each padded)
     B.total = o;
     return B;
 }
@@ -920,10 +928,11 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<3>());
         attr_set[dev] = true;
     }
-    const dim3 cgrid((unsigned)(rows / PL_ROWS));
+    const int wgs_per_call = (int)bn_wgs_per_call(rows, n_calls);
+    const dim3 cgrid((unsigned)(n_calls * wgs_per_call));
+    const int64_t tp_steps = 2 * n_calls * wgs_per_call;      // (the images' row axis is padded per call)
     float* const part = scratch + B.bn_wg;
     float* const s1 = scratch + B.bn_s1, * const s2 = scratch + B.bn_s2;
-    const int wgs_per_call = (int)(rpc / PL_ROWS);
     {
         const int N = (int)t->dims[nl];
         hipLaunchKernelGGL(bn_bwd_sums_wg_kernel, cgrid, dim3(512), 0, st, d_out, ws + L.xhat[nl - 1], ws + L.mean[nl - 1],
@@ -948,7 +957,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
         q.drop_seed = reinterpret_cast<const unsigned long long*>(t->drop_seed);
         q.drop_p = t->drop_p;
         q.dzp = reinterpret_cast<char*>(scratch + B.dzp[l]);
-        q.tp_steps = pl_row_steps(rows);
+        q.tp_steps = tp_steps;
         q.wpt = (l >= 1 || dx) ? image + PL.wpt[l] : nullptr;
         q.da_prev = l >= 1 ? scratch + B.dz[cur ^ 1] : dx;
         if (l >= 1) { q.z_prev = ws + L.xhat[l - 1]; q.mean_prev = ws + L.mean[l - 1]; q.invstd_prev = ws + L.invstd[l - 1];
@@ -962,7 +971,8 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
         }
     }
     int n_wg = 0;
-    const WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
+    WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
+    w.tp_steps = tp_steps;
     if (np == 3) hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
     else hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
     const ReduceTable rt = make_reduce_table(t, B);
@@ -1097,12 +1107,7 @@ int abn_debug_last_backward_path(void) { return last_backward_path; }
 int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws, int train)
 {
     if (check_desc(t, rows, 1) != ABN_OK) return -1;
-    // (BatchNorm in training: the call count is not known here -- yes when every possible one gives whole workgroups)
-    if (train && t->batch_norm) {
-        for (int64_t n = 1; n <= 8; ++n)
-            if (rows % n == 0 && !bn_train_planes_path(t, rows, n, x1, x2, ws)) return 0;
-        return 1;
-    }
+    if (train && t->batch_norm) return bn_train_planes_path(t, rows, 1, x1, x2, ws) ? 1 : 0;
     return planes_path(t, rows, x1, x2, ws, train ? PLANES_TRAIN : PLANES_EVAL_FORWARD) ? 1 : 0;
 }
 
@@ -1218,6 +1223,9 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
             }
             f.bn_part = ws + L.bn_wg;
             const int nl = t->n_layers;
+            const int64_t wpc = bn_wgs_per_call(rows, n_calls);
+            const dim3 bgrid((unsigned)(n_calls * wpc));
+            f.tp_steps = 2 * n_calls * wpc;                    // (the images' row axis is padded per call)
             for (int l = 0; l < nl; ++l) {
                 PlanesFwdP fl = f;
                 for (int i = 0; i < nl; ++i) { fl.tp[i] = nullptr; fl.out[i] = nullptr; }
@@ -1227,11 +1235,11 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 BnTrainP q = {};
                 q.l = l;
                 if (l > 0) { q.mean = ws + L.mean[l - 1]; q.invstd = ws + L.invstd[l - 1]; q.z_prev = ws + L.xhat[l - 1]; q.a_prev = nullptr; }
-                if (np == 3) hipLaunchKernelGGL(bn_fwd_layer_kernel<3>, fgrid, dim3(PL_NT), pl_lds_bytes(3), st, fl, q);
-                else hipLaunchKernelGGL(bn_fwd_layer_kernel<1>, fgrid, dim3(PL_NT), pl_lds_bytes(1), st, fl, q);
+                if (np == 3) hipLaunchKernelGGL(bn_fwd_layer_kernel<3>, bgrid, dim3(PL_NT), pl_lds_bytes(3), st, fl, q);
+                else hipLaunchKernelGGL(bn_fwd_layer_kernel<1>, bgrid, dim3(PL_NT), pl_lds_bytes(1), st, fl, q);
                 const int N = (int)t->dims[l + 1];
                 hipLaunchKernelGGL(bn_stats_finish_wg_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, ws + L.bn_wg,
-                                   (int)(rpc / PL_ROWS), rpc, N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l],
+                                   (int)wpc, rpc, N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l],
                                    t->bn_rm[l], t->bn_rv[l]);
             }
             const int N = (int)t->dims[nl];

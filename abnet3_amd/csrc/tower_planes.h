@@ -433,9 +433,11 @@ __device__ __forceinline__ float half_wave_sum(float v)
 
 template <int NP, int BPW, int KS, int MODE = PL_TRAIN>
 __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* __restrict__ img,
-                                             float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0)
+                                             float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0,
+                                             int row_end = -1)
 {
     constexpr bool BN = MODE == PL_INFER_BN, INFER = MODE == PL_INFER || MODE == PL_INFER_BN, BNT = MODE == PL_BN_TRAIN;
+    const int rows_lim = row_end >= 0 ? row_end : p.rows;      // (BatchNorm training: the end of the workgroup's forward_once call)
     const int K = p.dims[l], N = p.dims[l + 1];
     const int nsteps = pl_steps(K), nblk = (N + 31) / 32;
     const int r = lane & 31, h = lane >> 5;
@@ -474,7 +476,7 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     const DropGen drop = make_drop(INFER || mask ? nullptr : p.drop_seed, p.drop_p, l);
     const bool masked = mask || drop.on;
     const int gr = row0 + r;
-    const bool row_ok = gr < p.rows;
+    const bool row_ok = gr < rows_lim;
     float* const bias_s = part + PL_PART_BYTES / 4 + wave * 64;
     bias_s[lane] = bias_lane;
     if (BN) {
@@ -487,7 +489,7 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     __builtin_amdgcn_wave_barrier();
     f32x4 mv[BPW][4];
     if (mask && ws.active && ws.khalf == 0) {
-        const float* mrow = mask + (int64_t)(row_ok ? gr : p.rows - 1) * N;
+        const float* mrow = mask + (int64_t)(row_ok ? gr : rows_lim - 1) * N;
 #pragma unroll
         for (int j = 0; j < BPW; ++j)
 #pragma unroll
@@ -548,7 +550,7 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     float* __restrict__ out = p.out[l];
     char* const tp = !INFER && !BNT && l + 1 < p.n_layers ? p.tp[l + 1] : nullptr;
     if (BNT && ws.active && ws.khalf == 0) {
-        // Column statistics of this workgroup's 32 rows (all of one forward_once call), shifted by the first
+        // Column statistics of this workgroup's (up to) 32 rows (all of one forward_once call), shifted by the first
         // row's value so that the float32 sums are of the variance's size, not the mean's: the finishing
         // kernel (tower.hip) rebuilds sum z and sum z^2 in float64 and adds the workgroups in a fixed order.
         float* const pw = p.bn_part + (int64_t)blockIdx.x * (3 * PL_MAXW);
@@ -564,7 +566,7 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
                     const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zv), 0));
                     const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zv), 32));
                     const float c = h ? c1 : c0;
-                    const float d = zv - c;
+                    const float d = row_ok ? zv - c : 0.0f;           // (a last workgroup of a call may hold fewer rows)
                     sd[e] = half_wave_sum(d);
                     sq[e] = half_wave_sum(d * d);
                     cc[e] = c;
@@ -598,13 +600,13 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
                 }
                 if (tp)
                     emit_planes<NP>(tp + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
-                                    blk == N / 32 ? N % 32 : -1, p.rows - row0);
+                                    blk == N / 32 ? N % 32 : -1, rows_lim - row0);
             }
         }
     }
     if (tp && N % 32 == 0 && wave == PL_WAVES - 1) {       // the column of ones opens a block of its own
         Frag<NP> z[2] = {};
-        emit_planes<NP>(tp + ((int64_t)nblk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, p.rows - row0);
+        emit_planes<NP>(tp + ((int64_t)nblk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, rows_lim - row0);
     }
     PSTAMPF(6 + 5 * l);
     // steps of the next layer's padding that no block of this layer covers
@@ -622,8 +624,9 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
 // for the weight gradient).
 template <int NP, bool INFER>
 __device__ __forceinline__ void planes_input_stage(const PlanesFwdP& p, char* __restrict__ img, const bf16x8* idf, int wave,
-                                                   int lane, int row0)
+                                                   int lane, int row0, int row_end = -1)
 {
+    const int rows_lim = row_end >= 0 ? row_end : p.rows;
     const int r = lane & 31, h = lane >> 5;
     const int D0 = p.dims[0];
     // input rows -> operand fragments (+ the concatenated copy for the backward): lane (r, h) of
@@ -632,7 +635,7 @@ __device__ __forceinline__ void planes_input_stage(const PlanesFwdP& p, char* __
     const int steps0 = pl_steps(D0), blocks0 = steps0 / 2;     // PL_DEPTH is even
     const int gr = row0 + r;
     const float* src = nullptr;
-    if (gr < p.rows) src = (p.x2 && gr >= p.rows_call) ? p.x2 + (int64_t)(gr - p.rows_call) * D0 : p.x1 + (int64_t)gr * D0;
+    if (gr < rows_lim) src = (p.x2 && gr >= p.rows_call) ? p.x2 + (int64_t)(gr - p.rows_call) * D0 : p.x1 + (int64_t)gr * D0;
     for (int kb = wave; kb < blocks0; kb += PL_WAVES) {
         Frag<NP> f[2];
 #pragma unroll
@@ -653,11 +656,11 @@ __device__ __forceinline__ void planes_input_stage(const PlanesFwdP& p, char* __
         }
         if (!INFER && p.tp[0] && kb < pl_blocks(D0 + 1))
             emit_planes<NP>(p.tp[0] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
-                            kb == D0 / 32 ? D0 % 32 : -1, p.rows - row0);
+                            kb == D0 / 32 ? D0 % 32 : -1, rows_lim - row0);
     }
     if (!INFER && p.tp[0] && pl_blocks(D0 + 1) > blocks0 && wave == PL_WAVES - 1) {     // D0 % 32 == 0 and no padding block to hold the ones
         Frag<NP> z[2] = {};
-        emit_planes<NP>(p.tp[0] + ((int64_t)(D0 / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, p.rows - row0);
+        emit_planes<NP>(p.tp[0] + ((int64_t)(D0 / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, rows_lim - row0);
     }
 }
 
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
 // all rows of a forward_once call, so layer l starts in a new launch: its workgroups normalise their 32
 // rows of z_{l-1} on the way into the operand image (and leave xhat and the activation for the backward),
 // run the layer's product exactly as the single-launch forward does, and leave z_l + its per-workgroup
-// column statistics (planes_layer, PL_BN_TRAIN).  Rows per call must be a multiple of 32.
+// column statistics (planes_layer, PL_BN_TRAIN).
 // ---------------------------------------------------------------------------------------------
 struct BnTrainP {
     int l;
@@ -713,17 +716,21 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * PL_ROWS;
+    // workgroups never straddle two forward_once calls: ceil(rows_call / 32) per call, the last one of a call
+    // possibly short (its missing rows are zero rows of the transposed images, whose row axis is padded per call)
+    const int wpc = (p.rows_call + PL_ROWS - 1) / PL_ROWS;
+    const int call = blockIdx.x / wpc;
+    const int row0 = call * p.rows_call + (blockIdx.x - call * wpc) * PL_ROWS;
+    const int row_end = (call + 1) * p.rows_call;
     const int l = q.l;
     bf16x8 idf[2];
     make_identity(idf, lane);
 
     if (l == 0) {
-        planes_input_stage<NP, false>(p, img, idf, wave, lane, row0);
+        planes_input_stage<NP, false>(p, img, idf, wave, lane, row0, row_end);
     } else {
         // the four per-feature vectors of this workgroup's call, parked in the (idle) K-split buffer
         const int K = p.dims[l];
-        const int call = row0 / p.rows_call;
         float* const mean_s = part, * const is_s = part + PL_MAXW, * const ga_s = part + 2 * PL_MAXW, * const be_s = part + 3 * PL_MAXW;
         for (int c = threadIdx.x; c < K; c += PL_NT) {
             mean_s[c] = q.mean[(int64_t)call * K + c];
@@ -733,8 +740,9 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
         }
         __syncthreads();
         const int steps = pl_steps(K), blocks = steps / 2;
-        const int gr = row0 + r;                       // (whole workgroups only: rows_call % 32 == 0)
-        const float* const zrow = q.z_prev + (int64_t)gr * K;
+        const int gr = row0 + r;
+        const bool row_ok = gr < row_end;
+        const float* const zrow = q.z_prev + (int64_t)(row_ok ? gr : row0) * K;
         float* const arow = q.a_prev ? q.a_prev + (int64_t)gr * K : nullptr;
         char* const tp = p.tp[l];
         with_act(p.act[l - 1], [&](auto tag) {
@@ -748,7 +756,7 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int c = 16 * s + 4 * h + 8 * u;
-                        if (c < K) {
+                        if (c < K && row_ok) {
                             const f32x4 z4 = *reinterpret_cast<const f32x4*>(zrow + c);
                             const f32x4 mu = *reinterpret_cast<const f32x4*>(mean_s + c), is = *reinterpret_cast<const f32x4*>(is_s + c);
                             const f32x4 ga = *reinterpret_cast<const f32x4*>(ga_s + c), be = *reinterpret_cast<const f32x4*>(be_s + c);
@@ -762,20 +770,20 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
                 }
                 if (tp && kb < pl_blocks(K + 1))
                     emit_planes<NP>(tp + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
-                                    kb == K / 32 ? K % 32 : -1, p.rows - row0);
+                                    kb == K / 32 ? K % 32 : -1, row_end - row0);
             }
         });
         if (tp && pl_blocks(K + 1) > blocks && wave == PL_WAVES - 1) {      // K % 32 == 0 and no padding block to hold the ones
             Frag<NP> z[2] = {};
-            emit_planes<NP>(tp + ((int64_t)(K / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, p.rows - row0);
+            emit_planes<NP>(tp + ((int64_t)(K / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, row_end - row0);
         }
     }
     __syncthreads();
 
     const int nblk = (p.dims[l + 1] + 31) / 32;
-    if (nblk > PL_WAVES) planes_layer<NP, 2, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0);
-    else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0);
-    else planes_layer<NP, 1, 2, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0);
+    if (nblk > PL_WAVES) planes_layer<NP, 2, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, row_end);
+    else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, row_end);
+    else planes_layer<NP, 1, 2, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, row_end);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1119,7 +1127,7 @@ struct BnBwdP {
 
 template <int NP, int BPW, int KS>
 __device__ __forceinline__ void bn_dgrad_product(const BnBwdP& q, char* __restrict__ img, float* __restrict__ part, int wave,
-                                                 int lane, int row0)
+                                                 int lane, int row0, int row_end, int call)
 {
     const int N = q.N, K = q.K;                       // sum over N, K output features
     const int nsteps = pl_steps(N), nblk = (K + 31) / 32;
@@ -1142,9 +1150,10 @@ __device__ __forceinline__ void bn_dgrad_product(const BnBwdP& q, char* __restri
 #pragma unroll
         for (int x = 0; x < 16; ++x) acc[0][x] += part[(wave * 16 + x) * 64 + lane];
     }
-    const int gr = row0 + r;                          // (whole workgroups only)
-    const int call = row0 / q.rows_call;
-    float* const orow = q.da_prev + (int64_t)gr * K;
+    const int gr = row0 + r;
+    const bool row_ok = gr < row_end;
+    const int grc = row_ok ? gr : row0;
+    float* const orow = q.da_prev + (int64_t)grc * K;
     float* const pw = q.l >= 1 ? q.part_out + (int64_t)blockIdx.x * (2 * PL_MAXW) : nullptr;
     with_act(q.act_prev, [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
@@ -1155,10 +1164,10 @@ __device__ __forceinline__ void bn_dgrad_product(const BnBwdP& q, char* __restri
                 const int n = 32 * (blk0 + j) + 8 * g + 4 * h;
                 const bool live = n < K;              // K % 4 == 0: four features in or out together
                 const f32x4 d4 = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-                if (live) *reinterpret_cast<f32x4*>(orow + n) = d4;
+                if (live && row_ok) *reinterpret_cast<f32x4*>(orow + n) = d4;
                 if (q.l >= 1) {
                     const int nc = live ? n : K - 4;
-                    const f32x4 z4 = *reinterpret_cast<const f32x4*>(q.z_prev + (int64_t)gr * K + nc);
+                    const f32x4 z4 = *reinterpret_cast<const f32x4*>(q.z_prev + (int64_t)grc * K + nc);
                     const f32x4 mu = *reinterpret_cast<const f32x4*>(q.mean_prev + (int64_t)call * K + nc);
                     const f32x4 is = *reinterpret_cast<const f32x4*>(q.invstd_prev + (int64_t)call * K + nc);
                     f32x4 xh;
@@ -1169,7 +1178,7 @@ __device__ __forceinline__ void bn_dgrad_product(const BnBwdP& q, char* __restri
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float a = act_apply(xh[e] * ga[e] + be[e], ACT);
-                        const float dy = live ? d4[e] * act_grad(a, ACT) : 0.0f;
+                        const float dy = live && row_ok ? d4[e] * act_grad(a, ACT) : 0.0f;
                         sd[e] = half_wave_sum(dy);
                         sq[e] = half_wave_sum(dy * xh[e]);
                     }
@@ -1191,13 +1200,15 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * PL_ROWS;
+    const int wpc = (q.rows_call + PL_ROWS - 1) / PL_ROWS;        // (the forward's workgroup -> rows map)
+    const int call = blockIdx.x / wpc;
+    const int row0 = call * q.rows_call + (blockIdx.x - call * wpc) * PL_ROWS;
+    const int row_end = (call + 1) * q.rows_call;
     const int N = q.N;
     bf16x8 idf[2];
     make_identity(idf, lane);
 
     // the per-feature vectors of this workgroup's call, parked in the (still idle) K-split buffer
-    const int call = row0 / q.rows_call;
     const float nf = (float)q.rows_call;
     float* const k_s = part, * const ga_s = part + PL_MAXW, * const be_s = part + 2 * PL_MAXW, * const s1_s = part + 3 * PL_MAXW,
                * const s2_s = part + 4 * PL_MAXW, * const mu_s = part + 5 * PL_MAXW, * const is_s = part + 6 * PL_MAXW;
@@ -1214,9 +1225,11 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
     __syncthreads();
     const int steps = pl_steps(N), blocks = steps / 2;
     const int gr = row0 + r;
-    const float* const drow = q.da + (int64_t)gr * N;
-    const float* const zrow = q.z + (int64_t)gr * N;
-    const float* const mrow = q.mask ? q.mask + (int64_t)gr * N : nullptr;
+    const bool row_ok = gr < row_end;                 // rows past the call's end: dz = 0 (zero rows of the image)
+    const int grc = row_ok ? gr : row0;
+    const float* const drow = q.da + (int64_t)grc * N;
+    const float* const zrow = q.z + (int64_t)grc * N;
+    const float* const mrow = q.mask ? q.mask + (int64_t)grc * N : nullptr;
     const DropGen drop = make_drop(q.mask ? nullptr : q.drop_seed, q.drop_p, q.l);
     with_act(q.act_l, [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
@@ -1229,7 +1242,7 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int c = 16 * s + 4 * h + 8 * u;
-                    if (c < N) {
+                    if (c < N && row_ok) {
                         const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + c), z4 = *reinterpret_cast<const f32x4*>(zrow + c);
                         const f32x4 mu = *reinterpret_cast<const f32x4*>(mu_s + c), is = *reinterpret_cast<const f32x4*>(is_s + c);
                         f32x4 xh;
@@ -1260,9 +1273,9 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
     if (!q.wpt) return;
 
     const int nblk = (q.K + 31) / 32;
-    if (nblk > PL_WAVES) bn_dgrad_product<NP, 2, 1>(q, img, part, wave, lane, row0);
-    else if (nblk > PL_WAVES / 2 || pl_steps(N) % (2 * PL_DEPTH) != 0) bn_dgrad_product<NP, 1, 1>(q, img, part, wave, lane, row0);
-    else bn_dgrad_product<NP, 1, 2>(q, img, part, wave, lane, row0);
+    if (nblk > PL_WAVES) bn_dgrad_product<NP, 2, 1>(q, img, part, wave, lane, row0, row_end, call);
+    else if (nblk > PL_WAVES / 2 || pl_steps(N) % (2 * PL_DEPTH) != 0) bn_dgrad_product<NP, 1, 1>(q, img, part, wave, lane, row0, row_end, call);
+    else bn_dgrad_product<NP, 1, 2>(q, img, part, wave, lane, row0, row_end, call);
 }
 
 // ---------------------------------------------------------------------------------------------

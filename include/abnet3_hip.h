@@ -142,8 +142,7 @@ int64_t abn_tower_wpack_floats(const abn_tower_desc* t);
 /* 1 when abn_tower_forward(train) / the backward after it with these arguments run on the
  * operand-plane kernels (the ones that read, and with wpack_valid = 0 rebuild, wpack), 0 when on
  * the per-layer GEMMs, < 0 on a bad descriptor.  Depends on the descriptor, the row count, pointer
- * alignment and the library's environment switches.  For a batch_norm tower in training the
- * answer covers every call count (1..8) that divides rows.  train = 0 asks about the inference forward:
+ * alignment and the library's environment switches.  train = 0 asks about the inference forward:
  * a batch_norm tower takes the operand-plane kernel there (forward_only descriptors: running
  * statistics folded into the epilogue), and only there. */
 int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2,
@@ -158,8 +157,7 @@ int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1
  * forward).  train != 0: batch statistics, activations saved in ws;
  * train == 0: running statistics.  Output: ws + abn_tower_out_offset().
  * A batch_norm tower in the default arithmetic runs one operand-plane launch per layer in
- * training when every call's rows are a multiple of 32 (its backward likewise), and the
- * single-launch forward with the running statistics folded in
+ * training (its backward likewise), and the single-launch forward with the running statistics folded in
  * when train == 0 and forward_only != 0; otherwise the per-layer kernels.  Results agree to
  * rounding; forward and backward of one pass must see the same environment switches. */
 int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,

@@ -493,12 +493,13 @@ def test_inference_instantiation_equals_the_training_forward(shape, precision):
         assert torch.equal(a, b)
 
 
-BN_SHAPES = [  # (input, hidden layers, hidden, output, B): B a multiple of 32 (whole workgroups per forward_once call)
+BN_SHAPES = [  # (input, hidden layers, hidden, output, B): whole and ragged workgroups per forward_once call
     (40, 2, 500, 100, 64),
-    (32, 1, 64, 32, 32),
+    (32, 1, 64, 32, 33),
     (64, 1, 512, 128, 32),
-    (128, 3, 288, 36, 96),
-    (4, 0, 8, 4, 32),
+    (128, 3, 288, 36, 70),
+    (4, 0, 8, 4, 5),
+    (40, 1, 96, 48, 250),
 ]
 
 
@@ -561,15 +562,15 @@ def test_batch_norm_training_step_against_the_oracle(shape, act, p_drop):
 
 
 def test_batch_norm_input_gradient_and_fallbacks(monkeypatch):
-    """d loss / d input through the BatchNorm launches (layer 0's product with W_0), against the per-layer kernels;
-    a forward_once call whose rows are not whole workgroups stays on the per-layer kernels."""
+    """d loss / d input through the BatchNorm launches (layer 0's product with W_0), against the per-layer kernels,
+    with ragged calls (50 rows each: a whole and a short workgroup per call); a single ragged forward_once call."""
     from abnet3_amd import _lib
     kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=96, output_dim=32, activation_layer='tanh', p_dropout=0.0,
               batch_norm=True)
     rng = np.random.default_rng(4)
-    x1 = rng.standard_normal((64, 40)).astype(np.float32)
-    x2 = rng.standard_normal((64, 40)).astype(np.float32)
-    w = dev(rng.standard_normal((64, 32)).astype(np.float32))
+    x1 = rng.standard_normal((50, 40)).astype(np.float32)
+    x2 = rng.standard_normal((50, 40)).astype(np.float32)
+    w = dev(rng.standard_normal((50, 32)).astype(np.float32))
     res = []
     for planes in ('1', '0'):
         monkeypatch.setenv('ABN_BN_PLANES', planes)
@@ -586,13 +587,22 @@ def test_batch_norm_input_gradient_and_fallbacks(monkeypatch):
             assert np.abs(u).max() < 1e-5 * gmax
         else:
             assert rel_err(u, v, floor=1e-3 * np.abs(v).max()) < 1e-4
-    monkeypatch.setenv('ABN_BN_PLANES', '1')
-    net, _, _ = build(kw, seed=9, precision='bf16x3')
-    net.train()
-    e = net.forward_once(dev(x1[:48]))
-    assert _lib.load().abn_debug_last_forward_path() == 0
-    e.sum().backward()
-    assert _lib.load().abn_debug_last_backward_path() == 0
+    outs = []
+    for planes in ('1', '0'):
+        monkeypatch.setenv('ABN_BN_PLANES', planes)
+        net, _, _ = build(kw, seed=9, precision='bf16x3')
+        net.train()
+        e = net.forward_once(dev(x1[:37]))
+        assert _lib.load().abn_debug_last_forward_path() == (5 if planes == '1' else 0)
+        (e * e).sum().backward()
+        assert _lib.load().abn_debug_last_backward_path() == (5 if planes == '1' else 0)
+        outs.append([e.detach().cpu().numpy()] + [q.grad.cpu().numpy() for q in net.parameters()]
+                    + [v.cpu().numpy() for k, v in net.state_dict().items() if 'running' in k])
+    gmax = max(np.abs(v).max() for v in outs[1][1:])
+    for u, v in zip(*outs):
+        if np.abs(v).max() < 1e-5 * gmax:
+            continue
+        assert rel_err(u, v, floor=1e-3 * np.abs(v).max()) < 1e-4
 
 
 def test_batch_norm_training_in_the_bf16_arithmetic(monkeypatch):
