@@ -1,5 +1,8 @@
 // tower_planes.h -- the tower forward AND backward on bf16 MFMA operands that are split ONCE
-// (bf16 x 3, or plain bf16), no BatchNorm, widths <= 512.  Precision 1 and 2 only.
+// (bf16 x 3, or plain bf16), widths <= 512.  Precision 1 and 2 only.  Without BatchNorm: one launch for the
+// forward, one for the data-gradient chain, one for every layer's weight gradient.  With BatchNorm: inference
+// in the same single launch (running statistics in the epilogue); training one launch per layer each way
+// (bn_fwd_layer_kernel, bn_bwd_layer_kernel), the same weight-gradient launch.
 //
 // What the stamps and the knock-out builds said about tower_fused.h / gemm_f32.h:
 // the forward's floor was the per-wave weight stream (LDS-DMA of 64-byte row pieces: 80 us with
@@ -30,9 +33,10 @@
 //     the three planes added up again (exactly) to one fp32 value per element for bf16 x 3 (4 bytes
 //     instead of 6: these images are the step's largest HBM streams -- they are also the ONLY copy
 //     of the hidden activations: the data-gradient chain gathers act'(a) from them), one bf16 for
-//     the bf16 mode.  wgrad_planes_kernel streams both operands in that form (LDS-DMA, lane-linear),
-//     splits the fp32 fragments after the LDS read and otherwise only issues MFMAs.  A column of
-//     ones appended to the activation image yields the bias gradient.
+//     the bf16 mode.  wgrad_planes_kernel streams both operands in that form (bf16: LDS-DMA,
+//     lane-linear; bf16 x 3: fetched into registers, split once by the fetching wave, planes into an LDS
+//     ring) and otherwise only issues MFMAs.  A column of ones appended to the activation image yields
+//     the bias gradient.  A slab's tiles are placed on one XCD (wgrad_group_count): its L2 serves the re-reads.
 #pragma once
 #include <type_traits>
 
