@@ -149,7 +149,7 @@ def planes_roofline(torch, net, reps=20):
     bwd()                                           # a complete backward: both kernels' outputs are in place
 
     # Each launch alone: `reps` launches captured into one hipGraph, HIP events around its replays.  (Against the
-    # in-step durations of the rocprofv3 trace -- 67.8 / 67.8 / 67.1 us -- this reads the weight gradients ~5 % low
+    # in-step durations of the rocprofv3 trace -- 68.4 / 69.4 / 70.0 us -- this reads the weight gradients ~5 % low
     # and the two chains 8-15 % high: a step moves ~460 MB through HBM / Infinity Cache, and twenty launches of one
     # kernel rewriting the same images see a different cache.  Events BETWEEN the launches of a real sequence add
     # ~10 us each, and sequences with one launch left out do not subtract cleanly: both were tried.)
@@ -185,8 +185,8 @@ def planes_roofline(torch, net, reps=20):
         entries[key] = {'kernel': '%s  (%s; alone, back to back from one hipGraph)' % (name, what),
                         'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / peak, 4),
                         'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl, 'traffic': _traffic(short)}
-    # The three launches are within a few percent of each other (profiles/r02_bench_kernel_stats.txt: 67.8 / 67.8 /
-    # 67.1 us).  The line's top level is the weight-gradient launch: the largest by total time in that trace and by
+    # The three launches are within a few percent of each other (profiles/r02_bench_kernel_stats.txt: 68.4 / 69.4 /
+    # 70.0 us).  The line's top level is the weight-gradient launch: the largest by total time in that trace and by
     # HBM traffic; `longest_here` names whichever took longest in this run.
     dominant = 'weight_gradients'
     e = entries[dominant]
