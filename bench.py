@@ -117,8 +117,8 @@ def _traffic(kernel):
 def planes_roofline(torch, net, reps=20):
     """precision bf16x3 / bf16 (csrc/tower_planes.h): the step is three launches of similar length -- the
     forward chain, the data-gradient chain, the weight gradients -- plus the fused reduction + optimizer.
-    They are within a few percent of each other; the line's top level is the weight-gradient launch (the
-    largest by total time in the committed trace and by HBM traffic), the other two follow under their
+    They are within a few percent of each other; the line's top level is the weight-gradient launch (level
+    with the data-gradient chain by total time in the committed trace, the largest by HBM traffic), the other two follow under their
     names, `longest_here` says which took longest in this run.  wgrad_planes_kernel: every
     layer's dW = dZ^T [A | 1] over the 2 x 4096 rows, split over the rows into slabs, one launch (its tiles
     placed so that an XCD's L2 serves the re-reads).  Each of the three is timed live, alone: `reps`
@@ -186,8 +186,9 @@ def planes_roofline(torch, net, reps=20):
                         'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / peak, 4),
                         'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl, 'traffic': _traffic(short)}
     # The three launches are within a few percent of each other (profiles/r02_bench_kernel_stats.txt: 68.4 / 69.4 /
-    # 70.0 us).  The line's top level is the weight-gradient launch: the largest by total time in that trace and by
-    # HBM traffic; `longest_here` names whichever took longest in this run.
+    # 70.0 us, 27.6 / 27.6 / 26.6 % of the trace).  The line's top level is the weight-gradient launch: level with
+    # the data-gradient chain by total time in that trace, the largest by HBM traffic; `longest_here` names
+    # whichever took longest in this run.
     dominant = 'weight_gradients'
     e = entries[dominant]
     out = {'bound': 'mfma', 'achieved': e['achieved'], 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': e['frac'],
