@@ -1,5 +1,5 @@
 """Race detector: the same seeded C2 training run twice (dropout drawn in the kernels, eval forwards interleaved);
-every parameter must come out bit-identical, every loss finite."""
+every parameter must come out bit-identical, every loss finite.  BATCH_NORM=1: the BatchNorm launches."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -11,7 +11,7 @@ outs = []
 for run in range(2):
     torch.manual_seed(0)
     torch.cuda.manual_seed(0)
-    net = SiameseNetwork(output_path='/tmp/abn_soak', **dict(bench.C2, p_dropout=0.1))
+    net = SiameseNetwork(output_path='/tmp/abn_soak', **dict(bench.C2, p_dropout=0.1, batch_norm=bool(int(os.environ.get('BATCH_NORM', '0')))))
     if os.environ.get('ABN_PRECISION'): net.precision = os.environ['ABN_PRECISION']
     tr = TrainerSiamese(network=net, loss=coscos2(avg=False), optimizer_type='adadelta', lr=0.1, dataloader=None, log_dir='/tmp/abn_runs')
     pool = bench.make_pool(seed=0, device=torch.device('cuda'))
