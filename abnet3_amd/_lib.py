@@ -108,11 +108,19 @@ def load():
                                   '(stale build?)' % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
+    lib.abn_debug_reload_switches.restype = None
+    lib.abn_debug_reload_switches.argtypes = []
     if lib.abn_abi_version() != ABI_VERSION:
         raise HipLibraryError('abnet3_amd: ABI version mismatch (library %d, '
                               'binding %d)' % (lib.abn_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+def reload_switches():
+    """The library reads its A/B switches (ABN_PLANES, ABN_FUSED_MIN_ROWS, ...) from the environment once,
+    when it is loaded; tests and A/B tools that change one inside a process call this afterwards."""
+    load().abn_debug_reload_switches()
 
 
 E_UNSUPPORTED = -4

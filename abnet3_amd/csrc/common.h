@@ -28,6 +28,23 @@ void set_error(const char* fmt, ...);
         }                                                                    \
     } while (0)
 
+// The library's A/B switches (kernel choice only, never results beyond fp32 summation order), read from
+// the environment ONCE, at the first call that asks.  abn_debug_reload_switches() (not in the header:
+// tests and A/B tools that flip a switch inside one process) reads them again.
+struct Switches {
+    bool planes;              // ABN_PLANES=0: never the operand-plane kernels
+    bool fused;               // ABN_FUSED=0: per-layer kernels only
+    int64_t fused_min_rows;   // ABN_FUSED_MIN_ROWS: -1 = each path's own default
+    bool bn_planes;           // ABN_BN_PLANES=0: BatchNorm training on the per-layer kernels
+    bool wgrad_xcd;           // ABN_WGRAD_XCD=0: weight-gradient workgroups in launch order
+    bool bf16x3_planes;       // ABN_BF16X3_PLANES=0: (GEMM kernels) split per fragment instead of per tile
+    bool bwd_pair;            // ABN_BWD_PAIR=0: wgrad and dgrad of a layer as two grids
+    int gemm_tile;            // ABN_GEMM_TILE=0..3: force a tile shape
+    bool dtw_f40, dtw_pc;     // ABN_DTW_F40=0 / ABN_DTW_PC=0: the general DTW kernels
+};
+const Switches& switches();
+void reload_switches();
+
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -961,8 +961,8 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
         int64_t nwg = (nq + 1) / 2;
         if (nwg > w.nwg) nwg = w.nwg;
         const bool vec = D % 4 == 0 && aligned16(feats1) && aligned16(feats2);
-        static const bool pipelined = !(getenv("ABN_DTW_F40") && atoi(getenv("ABN_DTW_F40")) == 0);     // A/B switch of the 40-d specialisation
-        static const bool pc = !(getenv("ABN_DTW_PC") && atoi(getenv("ABN_DTW_PC")) == 0);                // A/B switch: producer / consumer form
+        const bool pipelined = switches().dtw_f40;     // A/B switch of the 40-d specialisation
+        const bool pc = switches().dtw_pc;              // A/B switch: producer / consumer form
         if (vec && D == KCH && pc) hipLaunchKernelGGL(dtw_pc_kernel, dim3((unsigned)nwg), dim3(128), 0, st, P);
         else if (vec && D == KCH && pipelined) hipLaunchKernelGGL((dtw_fused_kernel<true, true>), dim3((unsigned)nwg), dim3(64), 0, st, P);
         else if (vec) hipLaunchKernelGGL((dtw_fused_kernel<true, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);

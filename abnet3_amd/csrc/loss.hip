@@ -150,7 +150,11 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
         // loads that bypass the L1: no release / acquire fence, which would write back and
         // invalidate whole caches once per workgroup -- measured 23 us instead of 9 for this kernel)
         __hip_atomic_store(&partial[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (compiler: keep the partial's store in front of the drain and the ticket behind it -- a signal fence costs no
+        // instruction; hardware: the store is write-through and s_waitcnt waits for its acknowledgement)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_s_waitcnt(0);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = ticket == gridDim.x - 1;
     }

@@ -30,6 +30,27 @@ void set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+// The A/B switches: one read of the environment (common.h).
+static Switches read_switches()
+{
+    auto off = [](const char* name) { const char* v = getenv(name); return v && atoi(v) == 0; };
+    Switches s;
+    s.planes = !off("ABN_PLANES");
+    s.fused = !off("ABN_FUSED");
+    s.fused_min_rows = getenv("ABN_FUSED_MIN_ROWS") ? atoll(getenv("ABN_FUSED_MIN_ROWS")) : -1;
+    s.bn_planes = !off("ABN_BN_PLANES");
+    s.wgrad_xcd = !off("ABN_WGRAD_XCD");
+    s.bf16x3_planes = !off("ABN_BF16X3_PLANES");
+    s.bwd_pair = !off("ABN_BWD_PAIR");
+    s.gemm_tile = getenv("ABN_GEMM_TILE") ? atoi(getenv("ABN_GEMM_TILE")) : -1;
+    s.dtw_f40 = !off("ABN_DTW_F40");
+    s.dtw_pc = !off("ABN_DTW_PC");
+    return s;
+}
+static Switches g_switches = read_switches();       // (at library load: no call ever reads the environment)
+const Switches& switches() { return g_switches; }
+void reload_switches() { g_switches = read_switches(); }
+
 // ---------------------------------------------------------------------------
 // GEMM dispatch
 // ---------------------------------------------------------------------------
@@ -64,7 +85,7 @@ static void launch_cfg(const GemmP& p, int splits, hipStream_t st)
         return;
     }
     if (p.bf16 == 2) {                    // bf16 x 3 (abn_tower_desc.precision = 2): fp32-grade products on the bf16 matrix cores
-        static const bool planes = !(getenv("ABN_BF16X3_PLANES") && atoi(getenv("ABN_BF16X3_PLANES")) == 0);   // A/B switch
+        const bool planes = switches().bf16x3_planes;   // A/B switch
         if (p.a_vec && p.b_vec && planes) launch_one<BM, BN, A_KC, B_KC, EPI, true, 3>(p, splits, st);   // split once per tile (LDS planes)
         else if (p.a_vec && p.b_vec) launch_one<BM, BN, A_KC, B_KC, EPI, true, 2>(p, splits, st);
         else launch_one<BM, BN, A_KC, B_KC, EPI, false, 2>(p, splits, st);
@@ -104,7 +125,7 @@ static int prepare_gemm(GemmP& p, int splits)
 #ifdef ABN_STAMPS
     p.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
 #endif
-    static const int force = getenv("ABN_GEMM_TILE") ? atoi(getenv("ABN_GEMM_TILE")) : -1;
+    const int force = switches().gemm_tile;
     if (force >= 0 && force <= 3) return force;
     const int64_t pad_a = (int64_t)((p.M + 127) / 128 * 128) * ((p.N + 63) / 64 * 64);
     const int64_t pad_b = (int64_t)((p.M + 63) / 64 * 64) * ((p.N + 127) / 128 * 128);
@@ -130,8 +151,7 @@ static int launch_gemm(GemmP p, int splits, hipStream_t st)
 
 static bool bf16x3_planes()
 {
-    static const bool on = !(getenv("ABN_BF16X3_PLANES") && atoi(getenv("ABN_BF16X3_PLANES")) == 0);
-    return on;
+    return switches().bf16x3_planes;
 }
 
 // wgrad + dgrad of one backward layer in ONE grid (gemm_bwd_pair_kernel) when both take
@@ -156,7 +176,7 @@ static void launch_pair_one(const GemmP& pw, int n0, const GemmP& pd, int n1, hi
 
 static int launch_bwd_pair(GemmP pw, int splits, GemmP pd, hipStream_t st)
 {
-    static const bool enabled = !(getenv("ABN_BWD_PAIR") && atoi(getenv("ABN_BWD_PAIR")) == 0);
+    const bool enabled = switches().bwd_pair;
     const int tw = prepare_gemm<false, false, EPI_WGRAD>(pw, splits);
     const int td = prepare_gemm<true, false, EPI_DGRAD>(pd, 1);
     if (tw < -1) return tw + 100;
@@ -697,17 +717,15 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
 
 // Whether the planes kernels (tower_planes.h) take a call.  Forward and backward must agree (the forward then
 // leaves the hidden activations in the transposed images only): both ask here.
-// (the switches are read per call: tests flip them inside one process)
 enum { PLANES_TRAIN = 0, PLANES_EVAL_FORWARD = 1 };      // a forward in train mode or any backward | a forward with train == 0
 static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws,
                         int mode = PLANES_TRAIN)
 {
-    if (getenv("ABN_PLANES") && atoi(getenv("ABN_PLANES")) == 0) return false;
-    if (getenv("ABN_FUSED") && atoi(getenv("ABN_FUSED")) == 0) return false;
+    if (!switches().planes || !switches().fused) return false;
     // a workgroup walks its 32 rows through every layer in ~50 us whatever the batch; from a few workgroups
     // up that beats the per-layer GEMMs (tools/rows_sweep.py, tools/fwd_rows_sweep.py: C2 train step 0.148 vs
     // 0.180 ms at 512 rows, 0.234 vs 0.331 at 8192; forward alone 62 vs 94 us at 5000 rows)
-    const int64_t min_rows = getenv("ABN_FUSED_MIN_ROWS") ? atoll(getenv("ABN_FUSED_MIN_ROWS")) : 256;
+    const int64_t min_rows = switches().fused_min_rows >= 0 ? switches().fused_min_rows : 256;
     if (rows < min_rows || rows > (1LL << 20)) return false;                                // (32-bit byte offsets inside one image)
     // BatchNorm: only the inference forward (running statistics), and only when no backward will follow
     if (!(mode == PLANES_EVAL_FORWARD && t->forward_only ? planes_dims_ok(t) : planes_shape_ok(t))) return false;
@@ -724,7 +742,7 @@ static bool bn_train_planes_path(const abn_tower_desc* t, int64_t rows, int64_t 
                                  const float* ws)
 {
     if (!t->batch_norm || t->forward_only) return false;
-    if (getenv("ABN_BN_PLANES") && atoi(getenv("ABN_BN_PLANES")) == 0) return false;
+    if (!switches().bn_planes) return false;
     (void)n_calls;                                  // (any split of the rows into calls: workgroups are cut per call)
     abn_tower_desc u = *t;
     u.batch_norm = 0;
@@ -892,7 +910,7 @@ static WgradP make_wgrad(const abn_tower_desc* t, int64_t rows, const Layout& L,
         n_wg += W.tiles_n * W.tiles_k * W.splits;
     }
     // (ABN_WGRAD_XCD=0: workgroups in launch order, A/B measurements)
-    w.xcd_groups = !(getenv("ABN_WGRAD_XCD") && atoi(getenv("ABN_WGRAD_XCD")) == 0);
+    w.xcd_groups = switches().wgrad_xcd;
     if (w.xcd_groups) {
         int most = 0;
         for (int x = 0; x < 8; ++x) most = wgrad_slots(w, x) > most ? wgrad_slots(w, x) : most;
@@ -981,8 +999,11 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     return ABN_OK;
 }
 
+// part: PLANES_BWD_ALL for the product entries; the measurement entry abn_debug_tower_backward_part
+// issues one of the two launches (the other's output being in place from an earlier complete call).
+enum { PLANES_BWD_ALL = 0, PLANES_BWD_DGRAD = 1, PLANES_BWD_WGRAD = 2 };
 static int planes_backward(const abn_tower_desc* t, const float* d_out, const LossArgs* loss, int64_t rows, const Layout& L,
-                           const BwdLayout& B, const float* ws, float* scratch, float* dx, hipStream_t st)
+                           const BwdLayout& B, const float* ws, float* scratch, float* dx, hipStream_t st, int part = PLANES_BWD_ALL)
 {
     const int nl = t->n_layers;
     const int np = planes_of(t->precision);
@@ -1038,10 +1059,7 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
         bw_attr_set[dev] = true;
     }
     const dim3 cgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
-    // (measurement only, bench.py: ABN_PLANES_BWD_ONLY=dgrad|wgrad issues one of the two launches, the other's
-    // output being in place from an earlier complete call)
-    const char* only = getenv("ABN_PLANES_BWD_ONLY");
-    const bool do_dgrad = !only || !strcmp(only, "dgrad"), do_wgrad = !only || !strcmp(only, "wgrad");
+    const bool do_dgrad = part != PLANES_BWD_WGRAD, do_wgrad = part != PLANES_BWD_DGRAD;
     if (np == 3) {
         if (do_dgrad) hipLaunchKernelGGL(tower_dgrad_planes_kernel<3>, cgrid, dim3(PL_NT), pl_lds_bytes(3), st, b);
         if (do_wgrad) hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
@@ -1140,13 +1158,12 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
     // (tower_fused.h): no BatchNorm (its statistics span all rows), widths <= 512
     // and multiples of 4, 16-byte aligned tensors.  ABN_FUSED=0 forces the
     // per-layer path (A/B measurements).
-    // (both switches are read per call: tests flip them inside one process)
-    const bool fused_enabled = !(getenv("ABN_FUSED") && atoi(getenv("ABN_FUSED")) == 0);
+    const bool fused_enabled = switches().fused;
     // A fused workgroup walks its 32 rows through every layer in ~110 us whatever the
     // batch: it only pays once there are workgroups for most CUs.  Below that the
     // per-layer GEMMs (tiles over rows AND columns) are faster (measured: 4096 rows 91 vs
     // 116 us, 1024 rows 64 vs 107 us; 8192 rows 145 vs 131 us).
-    const int64_t fused_min_rows = getenv("ABN_FUSED_MIN_ROWS") ? atoll(getenv("ABN_FUSED_MIN_ROWS")) : 6144;
+    const int64_t fused_min_rows = switches().fused_min_rows >= 0 ? switches().fused_min_rows : 6144;
     bool fusable = fused_enabled && rows >= fused_min_rows && !t->batch_norm && aligned16(x1) && (!x2 || aligned16(x2)) &&
                    aligned16(ws);
     for (int l = 0; l <= t->n_layers && fusable; ++l)
@@ -1491,6 +1508,27 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     ABN_CHECK_LAUNCH("slab_reduce");
     return ABN_OK;
 }
+
+// Measurement only (not in the header; bench.py's per-launch timings): ONE of the two launches of the operand-plane
+// backward -- part 1 the data-gradient chain, 2 the weight gradients -- after a complete backward with the same
+// arguments has left the other launch's output in place.  Never reduces the slabs.
+int abn_debug_tower_backward_part(const abn_tower_desc* t, const float* x1, const float* x2, const float* d_out,
+                                  int64_t rows, int64_t n_calls, const float* ws, float* scratch,
+                                  int64_t scratch_floats, int part, void* stream)
+{
+    int rc = check_desc(t, rows, n_calls);
+    if (rc != ABN_OK) return rc;
+    ABN_REQUIRE(x1 && d_out && ws && scratch && (part == PLANES_BWD_DGRAD || part == PLANES_BWD_WGRAD), "tower_backward_part: bad argument");
+    if (rows == 0 || !planes_path(t, rows, x1, x2, ws)) { set_error("tower_backward_part: operand-plane towers only"); return ABN_E_UNSUPPORTED; }
+    const Layout L = make_layout(t, rows, n_calls);
+    const BwdLayout B = make_bwd_layout(t, rows);
+    if (scratch_floats < B.total) { set_error("tower_backward_part: scratch too small"); return ABN_E_WORKSPACE; }
+    abn_tower_desc u = *t;
+    u.defer_reduce = 1;
+    return planes_backward(&u, d_out, nullptr, rows, L, B, ws, scratch, nullptr, (hipStream_t)stream, part);
+}
+
+void abn_debug_reload_switches(void) { abn::reload_switches(); }
 
 int64_t abn_tower_backward_loss_ws_bytes(int64_t rows) { return 8 + ((rows + PL_ROWS - 1) / PL_ROWS) * (int64_t)sizeof(double); }
 

@@ -1012,7 +1012,11 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
             for (int i = 0; i < 32; ++i) sum += term_s[i];
             // (write-through store drained before the ticket, partials read back past the L1: loss.hip)
             __hip_atomic_store(&p.loss_partial[blockIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (compiler: keep the partial's store in front of the drain and the ticket behind it -- a signal fence costs no
+            // instruction; hardware: the store is write-through and s_waitcnt waits for its acknowledgement)
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
             __builtin_amdgcn_s_waitcnt(0);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
             const unsigned ticket = __hip_atomic_fetch_add(p.loss_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *is_last_s = ticket == gridDim.x - 1;
         }

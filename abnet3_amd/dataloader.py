@@ -159,9 +159,12 @@ class OriginalDataLoader(DataLoader):
     def _token(self, f, s, e, frames):
         return self.features.token_frames(f, s, e) if frames else self.features.token(f, s, e)
 
-    # cells (sum of n1*n2) one batched DTW call may cover: bounds the call's workspace
-    # and its [pairs, stride] path arrays whatever the size of the dataset
+    # cells (sum of n1*n2) one batched DTW call may cover: bounds the call's workspace whatever the
+    # size of the dataset; its [pairs, stride] path arrays (2 x int32) and what _align_chunk makes of
+    # them (int64 copies, a mask) are bounded separately: ALIGN_PATH_BYTES per entry, ALIGN_PATH_BUDGET in all
     ALIGN_CELL_BUDGET = 1 << 30
+    ALIGN_PATH_BYTES = 28
+    ALIGN_PATH_BUDGET = 4 << 30
 
     shards_itself = True          # see parallel.py: the trainer must not shard again
 
@@ -188,35 +191,50 @@ class OriginalDataLoader(DataLoader):
         exchange=True under torch.distributed: the pairs are split over the ranks
         (pair k goes to rank k % R), each rank aligns its share and the index lists
         are all-gathered, so that every rank ends up with every alignment."""
-        todo, queued = [], set()
+        rank, ws = parallel.world()
+        exchange = exchange and ws > 1
+        keys, queued = [], set()
         for p in same_pairs:
             key = tuple(p) + (frames,)
-            if key in self._align or key in queued:
+            if key in queued:
                 continue
             f1, s1, e1, f2, s2, e2 = p
             if (s1 > e1) or (s2 > e2):
                 continue
-            todo.append(key)
+            keys.append(key)
             queued.add(key)
-        if not todo:             # (the same list on every rank: nobody waits in a collective)
+        if exchange:
+            # The ranks' caches differ (an epoch of sharded batches fills them with rank-specific entries),
+            # the pair list does not: agree on the work first -- a key is skipped only when EVERY rank holds
+            # it -- so that all ranks cut the same list and nobody leaves before the collectives.
+            have = np.array([k in self._align for k in keys], dtype=np.int64)
+            have = parallel.all_reduce_min(have)
+            todo = [k for k, h in zip(keys, have) if not h]
+        else:
+            todo = [k for k in keys if k not in self._align]
+        if not todo:             # (with exchange: the same list on every rank, see above)
             return
-        rank, ws = parallel.world()
-        exchange = exchange and ws > 1
         mine = todo[rank::ws] if exchange else todo
         lens_all, g1_all, g2_all = [], [], []
-        chunk, cells = [], 0
+        chunk, cells, stride = [], 0, 0
         for key in mine + [None]:
             if key is not None:
                 f1, s1, e1, f2, s2, e2, fr = key
-                c = self._token(f1, s1, e1, fr)[1] * self._token(f2, s2, e2, fr)[1]
-                if not chunk or cells + c <= self.ALIGN_CELL_BUDGET:
+                a, b = self._token(f1, s1, e1, fr)[1], self._token(f2, s2, e2, fr)[1]
+                c = a * b
+                st = max(stride, a + b - 1)
+                # the [pairs, stride] path arrays (and the gather's temporaries) grow with pairs x the LONGEST
+                # path of the chunk, not with the cells: one long token among many short pairs must not blow them up
+                if not chunk or (cells + c <= self.ALIGN_CELL_BUDGET and
+                                 (len(chunk) + 1) * st * self.ALIGN_PATH_BYTES <= self.ALIGN_PATH_BUDGET):
                     chunk.append(key)
                     cells += c
+                    stride = st
                     continue
             if chunk:
                 lens, g1, g2 = self._align_chunk(chunk)
                 lens_all.append(lens); g1_all.append(g1); g2_all.append(g2)
-            chunk, cells = ([key], c) if key is not None else ([], 0)
+            chunk, cells, stride = ([key], c, a + b - 1) if key is not None else ([], 0, 0)
         dev = self.features.table.device
         empty = torch.zeros(0, dtype=torch.int64, device=dev)
         lens = np.concatenate(lens_all) if lens_all else np.zeros(0, dtype=np.int32)

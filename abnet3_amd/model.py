@@ -157,7 +157,10 @@ class _Segment(object):
 
     def _weights_key(self):
         net = self.net
-        return (net._flat.data_ptr(), net._generation, net.precision, tuple(p._version for p in self.params))
+        # (writes through p.data / the flat buffer do not bump p._version: the flat buffer's own counter and
+        # the network's `_weights_epoch`, bumped by whoever writes behind torch, cover them)
+        return (net._flat.data_ptr(), net._generation, net.precision, net._flat._version,
+                getattr(net, '_weights_epoch', 0), tuple(p._version for p in self.params))
 
     def wpack_state(self):
         """(valid flag for the next call's descriptor, key of the weights as they stand)"""
@@ -281,8 +284,10 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
     rows = x1.shape[0] * (2 if x2 is not None else 1)
     masks = seg.masks_of(all_masks) if train else None
     if isinstance(masks, _DropoutInKernel):
-        # drawn inside the kernels where they are the operand-plane ones, as tensors for the per-layer path
-        probe = seg.descriptor(with_grads=False)
+        # drawn inside the kernels where they are the operand-plane ones, as tensors for the per-layer path.
+        # The probe carries the call's own forward_only: a BatchNorm tower in train mode under torch.no_grad()
+        # (TrainerBuilder.train's first pass, abnet3/trainer.py:137) runs on the per-layer kernels
+        probe = seg.descriptor(with_grads=False, forward_only=forward_only)
         if lib.abn_tower_uses_planes(_lib.C.byref(probe), rows, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(x1), 1) == 1:
             masks = _DropSeed(masks.p, x1.device)
         else:
@@ -589,6 +594,16 @@ class _HipNetwork(NetworkBuilder):
             flat.zero_()
         return [flat[off:off + rows * w].view(rows, w) for off, w in zip(offs, widths)]
 
+    def weights_changed_behind_torch(self):
+        """Called by whoever rewrites the parameters without torch noticing (abn_optimizer_step, a replayed
+        hipGraph, a broadcast into the flat buffer, writes through p.data): the persistent weight images
+        are stale."""
+        self._weights_epoch = getattr(self, '_weights_epoch', 0) + 1
+        for seg in (getattr(self, '_segs', None) or ()):
+            seg._wpack_key = None
+
+    _weights_rewritten = weights_changed_behind_torch
+
     def _run(self, seg, grad_pass, masks, x1, x2, n_calls, split):
         if x1.shape[0] == 0:
             # nn.Linear on zero rows gives zero rows (and nothing to launch)
@@ -605,7 +620,7 @@ class _HipNetwork(NetworkBuilder):
     # buffers, ctypes descriptors and caches -- not part of the description of the
     # network and not picklable
     _HIP_STATE = ('_flat', '_last_grad_flat', '_offsets', '_segs', '_mask_override',
-                  '_generation', '_live_cache')
+                  '_generation', '_live_cache', '_weights_epoch', '_pending_reduce', '_fused_loss_refused')
 
     def whoami(self):
         """Output description for the neural network and all parameters
@@ -689,6 +704,7 @@ class SiameseNetwork(_HipNetwork):
             init_func(layer.weight.data,
                       gain=nn.init.calculate_gain(self.activation_layer))
             layer.bias.data.fill_(0.0)
+            self._weights_rewritten()
 
     # -- HIP plumbing ------------------------------------------------------
     def _segments(self):
@@ -800,12 +816,6 @@ class SiameseNetwork(_HipNetwork):
 
     _fused_loss_refused = None
 
-    def weights_changed_behind_torch(self):
-        """Called by whoever rewrites the parameters without torch noticing (abn_optimizer_step, a replayed
-        hipGraph): the persistent weight images are stale."""
-        for seg in self._segment_list():
-            seg._wpack_key = None
-
     def take_pending_reduce(self):
         """The unfinished reduction a direct_backward(defer_reduce=True) left (or None); clears it."""
         pending = getattr(self, '_pending_reduce', None)
@@ -915,6 +925,7 @@ class SiameseMultitaskNetwork(_HipNetwork):
             init_func(layer.weight.data,
                       gain=nn.init.calculate_gain(self.activation_layer))
             layer.bias.data.fill_(0.0)
+            self._weights_rewritten()
 
     def _segments(self):
         act, bn = self.activation_layer, self.batch_norm

@@ -127,6 +127,17 @@ def broadcast_array(arr, src=0):
     return t.cpu().numpy()
 
 
+def all_reduce_min(arr):
+    """int64 numpy array, same length on every rank -> elementwise minimum over the ranks."""
+    _, ws = world()
+    arr = np.ascontiguousarray(arr, dtype=np.int64)
+    if ws == 1 or arr.size == 0:
+        return arr
+    t = torch.from_numpy(arr.copy()).to(_comm_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return t.cpu().numpy()
+
+
 def all_gather_varlen(t):
     """1-d tensors of rank-dependent length -> list of every rank's tensor (on t's
     device), in rank order."""

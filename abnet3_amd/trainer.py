@@ -164,6 +164,8 @@ class TrainerBuilder:
                                            self.momentum)
         if self.world_size > 1:
             parallel.broadcast_parameters(self.network.flat_parameters())
+            if hasattr(self.network, 'weights_changed_behind_torch'):
+                self.network.weights_changed_behind_torch()      # (a rank that already ran a forward holds a stale image)
             # one RNG state on all ranks to start from; what an epoch visits is
             # broadcast from rank 0 anyway (parallel.py, the loaders' batch_iterator)
             parallel.seed_all(self.seed)

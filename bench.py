@@ -117,14 +117,13 @@ def _traffic(kernel):
 def planes_roofline(torch, net, reps=20):
     """precision bf16x3 / bf16 (csrc/tower_planes.h): the step is three launches of similar length -- the
     forward chain, the data-gradient chain, the weight gradients -- plus the fused reduction + optimizer.
-    They are within a few percent of each other; the line's top level is the weight-gradient launch (level
-    with the data-gradient chain by total time in the committed trace, the largest by HBM traffic), the other two follow under their
-    names, `longest_here` says which took longest in this run.  wgrad_planes_kernel: every
+    The line's top level is whichever of the three took LONGEST in this run, the other two follow under their
+    names; `whole_step` (added by main) is the timed loop's own figure against the same roof.  wgrad_planes_kernel: every
     layer's dW = dZ^T [A | 1] over the 2 x 4096 rows, split over the rows into slabs, one launch (its tiles
     placed so that an XCD's L2 serves the re-reads).  Each of the three is timed live, alone: `reps`
     launches captured into one hipGraph and bracketed by HIP events on the launch stream (the backward
-    kernels through abn_tower_backward with ABN_PLANES_BWD_ONLY, a measurement switch that issues one of
-    its two launches; the forward with its packed weight image still valid, i.e. without the ~5 us
+    kernels through abn_debug_tower_backward_part, a measurement entry outside the header that issues one of
+    the backward's two launches; the forward with its packed weight image still valid, i.e. without the ~5 us
     pack_planes_kernel a step's forward starts with); `forward_backward_sequence_us` is the three in the
     step's order.  Algorithmic FLOPs: weight gradients 2 * 8192 * sum_l N_l (K_l + 1), the chains
     2 * 8192 * sum_l N_l K_l (the data-gradient chain without the first layer).
@@ -154,12 +153,24 @@ def planes_roofline(torch, net, reps=20):
     # kernel rewriting the same images see a different cache.  Events BETWEEN the launches of a real sequence add
     # ~10 us each, and sequences with one launch left out do not subtract cleanly: both were tried.)
     times = {}
-    for which in ('wgrad', 'dgrad', None):
-        if which:
-            os.environ['ABN_PLANES_BWD_ONLY'] = which
-        else:
-            os.environ.pop('ABN_PLANES_BWD_ONLY', None)
-        times[which or 'both'] = _time_launches(torch, bwd, reps)
+    from abnet3_amd import _lib
+    lib = _lib.load()
+    part_fn = lib.abn_debug_tower_backward_part       # measurement entry (not in the header): one of the two launches
+    part_fn.restype = _lib.C.c_int
+    seg, sv, gp = state
+    gbuf, _ = gp.views(seg)
+    desc = seg.descriptor(with_grads=True, grad_buf=gbuf, masks=sv.masks, d_out_is_dz=True, defer_reduce=True)
+    sc_n = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
+    pending = net._pending_reduce                     # (desc, rows, scratch, ...) of the complete backward above
+    scratch = pending[2]
+
+    def part(which):
+        _lib.check(part_fn(_lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(d_out), _lib.C.c_int64(rows),
+                           _lib.C.c_int64(2), _lib.ptr(sv.ws), _lib.ptr(scratch), _lib.C.c_int64(sc_n), which, _lib.stream()),
+                   'abn_debug_tower_backward_part')
+    times['dgrad'] = _time_launches(torch, lambda: part(1), reps)
+    times['wgrad'] = _time_launches(torch, lambda: part(2), reps)
+    times['both'] = _time_launches(torch, bwd, reps)
     times['forward'] = _time_launches(torch, lambda: net.direct_forward(x1, x2), reps)
 
     def fwd_bwd():
@@ -185,18 +196,17 @@ def planes_roofline(torch, net, reps=20):
         entries[key] = {'kernel': '%s  (%s; alone, back to back from one hipGraph)' % (name, what),
                         'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / peak, 4),
                         'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl, 'traffic': _traffic(short)}
-    # The three launches are within a few percent of each other (profiles/r02_bench_kernel_stats.txt: 68.4 / 69.4 /
-    # 70.0 us, 27.6 / 27.6 / 26.6 % of the trace).  The line's top level is the weight-gradient launch: level with
-    # the data-gradient chain by total time in that trace, the largest by HBM traffic; `longest_here` names
-    # whichever took longest in this run.
-    dominant = 'weight_gradients'
+    # The line's top level is whichever of the three launches took LONGEST in this run (alone, back to back: against
+    # the in-step durations of the committed rocprofv3 trace this reads the chains 8-15 % high and the weight
+    # gradients ~5 % low, so the top-level fraction is the conservative one); the other two follow under their names.
+    dominant = max(entries, key=lambda k: entries[k]['avg_launch_us'])
     e = entries[dominant]
     out = {'bound': 'mfma', 'achieved': e['achieved'], 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': e['frac'],
            'traffic': e['traffic'], 'arithmetic': prec,
            'peak_note': {'bf16x3': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per algorithmic product',
                          'bf16': 'dense bf16 MFMA'}[prec],
            'frac_of_fp32_mfma_peak': round(e['achieved'] / FP32_MFMA_PEAK_TFLOPS, 4),
-           'dominant': dominant, 'longest_here': max(entries, key=lambda k: entries[k]['avg_launch_us']),
+           'dominant': dominant,
            'kernel': e['kernel'], 'avg_launch_us': e['avg_launch_us'],
            'flop_per_launch': e['flop_per_launch']}
     if e['traffic']:
@@ -544,6 +554,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--repeats', type=int, default=9, help='timed regions of --steps steps each; the median is reported')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtw-pairs', type=int, default=10000,
                     help='token pairs per GPU for the DTW leg (0 = skip)')
@@ -587,21 +598,28 @@ def main():
         torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # EXACTLY --steps steps between barrier + synchronize on both sides, MAX over ranks -- repeated --repeats
+    # times back to back; the line's value is the MEDIAN repeat (a 20-step region is a 4 ms sample: one
+    # repeat alone reads +-5 % from run to run), min / max beside it
+    elapsed_all = []
+    for rep in range(max(1, args.repeats)):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss = step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        elapsed_all.append(el)
+    elapsed = sorted(elapsed_all)[len(elapsed_all) // 2]
     last_loss = float(loss)
 
     err_default = None
@@ -630,6 +648,8 @@ def main():
             'value': round(value, 1), 'unit': 'frame-pairs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'repeats': len(elapsed_all),
+            'ms_per_step_min_max': [round(min(elapsed_all) / args.steps * 1e3, 4), round(max(elapsed_all) / args.steps * 1e3, 4)],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16x3' if net.precision == 'bf16x3' else {'fp32': 'f32', 'bf16': 'bf16'}[net.precision],
             'data': 'synthetic',
@@ -645,6 +665,11 @@ def main():
             'last_loss': last_loss,
         }
         out['roofline'] = tower_roofline(torch, net) if net.precision == 'fp32' else planes_roofline(torch, net)
+        # the whole step against the same roof, from the timed loop above (pack, both chains, weight gradients,
+        # reduction + optimizer, every gap): the number the per-launch fractions have to be read beside
+        out['roofline']['whole_step'] = {'achieved': round(value * FLOP_PER_PAIR / world / 1e12, 2), 'unit': 'TFLOP/s',
+                                         'frac': round(value * FLOP_PER_PAIR / world / 1e12 / out['roofline']['peak'], 4),
+                                         'ms_per_step': round(elapsed / args.steps * 1e3, 4)}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(torch)
             out['cpu_baseline'] = cb

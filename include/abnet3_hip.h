@@ -14,9 +14,11 @@
  *    says "host".  The caller owns all buffers; the library never allocates device
  *    memory, frees or synchronises (graph-capturable).  Process state it keeps: a
  *    thread-local error string, per-kernel "attribute already set" flags (dynamic LDS
- *    opt-in, set once per device), and the A/B switches it reads from the environment
- *    (ABN_FUSED, ABN_FUSED_MIN_ROWS, ABN_GEMM_TILE, ABN_BWD_PAIR, ABN_DTW_F40: kernel
- *    choice only, never results beyond fp32 summation order).  No streams, no events.
+ *    opt-in, set once per device), and the A/B switches it reads from the environment ONCE,
+ *    when the library is loaded (ABN_PLANES, ABN_FUSED, ABN_FUSED_MIN_ROWS, ABN_BN_PLANES,
+ *    ABN_WGRAD_XCD, ABN_BF16X3_PLANES, ABN_GEMM_TILE, ABN_BWD_PAIR, ABN_DTW_F40, ABN_DTW_PC:
+ *    kernel choice only, never results beyond fp32 summation order; no call reads the
+ *    environment, and none of them makes a call do less than its contract).  No streams, no events.
  *  - Row-major contiguous fp32 tensors; sizes are int64_t; `stream` is a
  *    hipStream_t passed as void* (NULL = the null stream).
  *  - Return value: 0 = ok, negative = error (ABN_E_*); abn_last_error() gives
@@ -37,8 +39,8 @@ extern "C" {
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
        ABN_E_UNSUPPORTED = -4 };
 
-/* activation_functions table, abnet3/model.py:19-23 (softmax is not offered on
- * the accelerated path: ABN_E_UNSUPPORTED) */
+/* activation_functions table, abnet3/model.py:19-23.  'softmax' (last_non_linearity only,
+ * model.py:161-166) is not an epilogue: the tower ends with ABN_ACT_NONE and abn_softmax_rows follows. */
 enum { ABN_ACT_NONE = 0, ABN_ACT_SIGMOID = 1, ABN_ACT_RELU = 2, ABN_ACT_TANH = 3 };
 
 /* abnet3/loss.py:37 (coscos2), :70 (cosmargin) */
@@ -53,8 +55,8 @@ enum { ABN_Y_I8 = 0, ABN_Y_I32 = 1, ABN_Y_I64 = 2, ABN_Y_F32 = 3, ABN_Y_F64 = 4 
 enum { ABN_OPT_SGD = 0, ABN_OPT_ADADELTA = 1, ABN_OPT_ADAM = 2,
        ABN_OPT_ADAGRAD = 3, ABN_OPT_RMSPROP = 4 };
 
-/* compute type of the tower GEMMs: exact fp32 MFMA (parity mode) */
-enum { ABN_COMPUTE_F32 = 0 };
+/* abn_tower_desc.precision: arithmetic of the tower GEMMs (see the field's comment) */
+enum { ABN_PREC_F32 = 0, ABN_PREC_BF16 = 1, ABN_PREC_BF16X3 = 2 };
 
 int abn_abi_version(void);
 const char* abn_last_error(void);          /* host string, thread-local */

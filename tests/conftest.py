@@ -54,6 +54,33 @@ def pytest_unconfigure(config):
             p.kill()
 
 
+@pytest.fixture(autouse=True)
+def _library_switches(monkeypatch):
+    """libabnet3_hip.so reads its A/B switches (ABN_PLANES, ABN_FUSED_MIN_ROWS, ...) from the environment once;
+    a test that sets one through monkeypatch gets the library to read them again, and every test starts from
+    the environment as it stands (the previous test's changes are undone by then)."""
+    lib_path = os.path.join(ROOT, 'abnet3_amd', 'lib', 'libabnet3_hip.so')
+
+    def reload():
+        if os.path.exists(lib_path):
+            from abnet3_amd import _lib
+            _lib.reload_switches()
+    reload()
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_and_reload(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        if name.startswith('ABN_'):
+            reload()
+
+    def delenv_and_reload(name, *a, **k):
+        delenv(name, *a, **k)
+        if name.startswith('ABN_'):
+            reload()
+    monkeypatch.setenv, monkeypatch.delenv = setenv_and_reload, delenv_and_reload
+    yield
+
+
 @pytest.fixture(params=['per_layer', 'fused'])
 def forward_path(request, monkeypatch):
     """Runs a test once on the per-layer GEMM forward and once on the fused

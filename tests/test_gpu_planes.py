@@ -689,3 +689,63 @@ def test_batch_norm_with_dropout_drawn_inside_the_kernels():
     assert rel_err(emb_t.cpu().numpy(), emb.cpu().numpy()) < 1e-6
     for k, q in net.named_parameters():
         assert rel_err(q.grad.cpu().numpy(), grads[k].cpu().numpy(), floor=1e-6 * float(grads[k].abs().max()) + 1e-30) < 1e-5, k
+
+
+def test_batch_norm_dropout_train_mode_without_gradients(tmp_path):
+    """The reference's standard configuration (batch_norm=True, p_dropout=0.1): TrainerBuilder.train() starts with
+    optimize_model(do_training=False) -- net.train() under torch.no_grad() (abnet3/trainer.py:137,226-235).  A
+    forward that keeps nothing for a backward cannot use the BatchNorm training launches, so the dropout probe
+    must ask with the call's own forward_only: the step falls back to mask tensors on the per-layer kernels
+    instead of failing with 'in-kernel dropout needs the operand-plane kernels'."""
+    from abnet3_amd import _lib
+    from abnet3_amd.loss import coscos2
+    from abnet3_amd.trainer import TrainerSiamese
+    kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=96, output_dim=32, activation_layer='sigmoid', p_dropout=0.1,
+              batch_norm=True, output_path=str(tmp_path / 'net'))
+    net, _, _ = build(kw, seed=5, precision='bf16x3')
+    rng = np.random.default_rng(2)
+    B = 160                                                    # 320 rows: the planes kernels take it by themselves
+    batch = (dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32)),
+             dev(rng.choice([1.0, -1.0], B)))
+
+    class Loader(object):
+        def batch_iterator(self, train_mode=True):
+            for _ in range(3):
+                yield batch
+
+        def whoami(self):
+            return {'class_name': 'Loader'}
+    tr = TrainerSiamese(network=net, loss=coscos2(avg=False), optimizer_type='adadelta', lr=0.1, num_epochs=2, patience=5,
+                        dataloader=Loader(), log_dir=str(tmp_path / 'runs'))
+    net.train()
+    lib = _lib.load()
+    v = tr.train_step(batch, False)                            # train mode, no gradients
+    assert lib.abn_debug_last_forward_path() == 0 and np.isfinite(float(v))
+    v = tr.train_step(batch, True)                             # the same tower in a real step: the BatchNorm launches
+    assert lib.abn_debug_last_forward_path() == 5 and np.isfinite(float(v))
+    tr.train()                                                 # the reference's whole loop, first pass included
+    assert len(tr.train_losses) == 3 and all(np.isfinite(tr.train_losses))
+
+
+def test_persistent_weight_image_sees_writes_behind_torch():
+    """Writes that do not bump the parameters' version counters -- init_weight_method's .data writes, a copy into
+    the flat buffer (what parallel.broadcast_parameters does) -- still invalidate the persistent weight image."""
+    kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=64, output_dim=32, activation_layer='tanh', p_dropout=0.0)
+    net, _, _ = build(kw, seed=11, precision='bf16x3')
+    net.eval()
+    x = dev(np.random.default_rng(0).standard_normal((64, 40)).astype(np.float32))
+    with torch.no_grad():
+        a = net.forward_once(x).clone()
+        assert torch.equal(net.forward_once(x), a)             # image reused
+        torch.manual_seed(99)
+        net.apply(net.init_weight_method)                      # layer.weight.data / bias.data writes
+        b = net.forward_once(x).clone()
+        assert not torch.equal(a, b)
+        fresh, _, _ = build(kw, seed=11, precision='bf16x3')
+        fresh.eval()
+        fresh.load_state_dict(net.state_dict())
+        assert torch.equal(fresh.forward_once(x), b)
+        net.flat_parameters().copy_(net.flat_parameters() * 0.5)   # behind every parameter's back
+        c = net.forward_once(x).clone()
+        fresh.load_state_dict(net.state_dict())
+        assert torch.equal(fresh.forward_once(x), c) and not torch.equal(b, c)
