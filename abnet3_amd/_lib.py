@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ABNET3_HIP_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get('ABNET3_HIP_LIB') or os.path.join(HERE, 'lib', 'libabnet3_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_LAYERS = 16
 
 ACT = {'none': 0, None: 0, 'sigmoid': 1, 'relu': 2, 'tanh': 3}
@@ -37,7 +37,7 @@ SYMBOLS = {
     'abn_tower_wpack_floats': (_i64, [_vp]),
     'abn_tower_uses_planes': (C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int]),
     'abn_tower_backward_loss_ws_bytes': (_i64, [_i64]),
-    'abn_tower_backward_loss': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, C.c_int, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    'abn_tower_backward_loss': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, C.c_int, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     'abn_tower_reduce_step': (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32,
                                          _f32, _i64, _f32, _vp]),
     'abn_linear_forward': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _vp, _vp]),
@@ -64,12 +64,16 @@ SYMBOLS = {
     'abn_cosine_distance_f64': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     'abn_arccos_f32': (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
     'abn_gather_rows': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    'abn_gather_pairs': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     'abn_stack_frames': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    'abn_stack_frames_batched': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     'abn_mvn_ws_bytes': (_i64, [_i64, _i64]),
     'abn_mvn_stats': (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp]),
     'abn_mvn_apply': (C.c_int, [_vp, _i64, _i64, _vp, _vp, C.c_int, _f32, _vp, _vp]),
     'abn_fbank': (C.c_int, [_vp, C.c_int, _i64, _i32, C.c_double, _i32, _i32,
                              _f32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'abn_fbank_batched': (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _i32, C.c_double, _i32, _i32,
+                                     _f32, _vp, _vp, _vp, _i64, _vp, _vp]),
     'abn_deltas': (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
 }
 

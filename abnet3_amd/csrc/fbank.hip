@@ -6,7 +6,11 @@
 // The arithmetic of the third-party `spectral` package is not in the
 // reference; the definition implemented here is oracle/features_np.py (parity
 // unpinned, see its header): per frame pre-emphasis -> Hamming window ->
-// |rfft(nfft)|^2 -> triangular mel bank -> log(max(., 1e-5)).
+// |rfft(nfft)|^2 -> triangular mel bank -> log(max(., 1e-5)).  Framing follows the
+// Sphinx-III mfcc.py lineage of that package, quirks included: the pre-emphasis history of a
+// frame's first sample is the LAST sample of the previous frame (0 for frame 0), and a frame
+// cut short by the end of the signal is filled by repeating its samples cyclically
+// (np.resize), see FrameSrc.
 //
 // One workgroup per frame: the frame is loaded straight into bit-reversed
 // order in LDS, a radix-2 FFT runs in place (8 KB for nfft=1024), and the mel
@@ -23,30 +27,74 @@ constexpr float FB_FLOOR = 1e-5f;
 
 __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
 
+// Where a frame's samples come from (oracle/features_np.py, `frame_samples`): frame `fr` of an
+// utterance of `len` samples starts at round(fr * fshift) and holds wlen samples; with fewer than
+// wlen left it repeats what is there cyclically (np.resize; an empty frame is zeros).  The
+// pre-emphasis history of element 0 is element wlen - 1 of the PREVIOUS frame (0 for frame 0).
+struct FrameSrc {
+    const void* base;          // the utterance's first sample
+    int is_i16;
+    int64_t start;             // first sample of the frame
+    int avail;                 // samples between start and the end of the utterance, capped at wlen
+    int wlen;
+    __device__ __forceinline__ float raw(int64_t i) const
+    {
+        return is_i16 ? (float)((const int16_t*)base)[i] : ((const float*)base)[i];
+    }
+    // element i of the frame, 0 <= i < wlen
+    __device__ __forceinline__ float at(int i) const
+    {
+        if (avail >= wlen) return raw(start + i);
+        if (avail <= 0) return 0.0f;
+        return raw(start + i % avail);
+    }
+};
+__device__ __forceinline__ FrameSrc frame_src(const void* base, int is_i16, int64_t len, int64_t fr, double fshift, int wlen)
+{
+    FrameSrc f;
+    f.base = base; f.is_i16 = is_i16; f.wlen = wlen;
+    f.start = (int64_t)rint((double)fr * fshift);
+    const int64_t left = len - f.start;
+    f.avail = left >= wlen ? wlen : (left > 0 ? (int)left : 0);
+    return f;
+}
+// utterance of global frame `frame` in a batch (utt_foff: cumulative frame counts, [n_utts + 1])
+__device__ __forceinline__ int find_utt(const int64_t* __restrict__ utt_foff, int n_utts, int64_t frame)
+{
+    int lo = 0, hi = n_utts - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (utt_foff[mid] <= frame) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void fbank_kernel(const void* __restrict__ samples, int is_i16, int64_t nsamples,
                                                     int wlen, double fshift, int nfft, int log2n, int nfilt,
                                                     float alpha, const float* __restrict__ window,
-                                                    const float* __restrict__ melbank, float* __restrict__ out)
+                                                    const float* __restrict__ melbank, float* __restrict__ out,
+                                                    const int64_t* __restrict__ utt_soff, const int64_t* __restrict__ utt_foff,
+                                                    int n_utts)
 {
     __shared__ float re[FB_MAX_NFFT], im[FB_MAX_NFFT];
     __shared__ float twr[FB_MAX_NFFT / 2], twi[FB_MAX_NFFT / 2];
     __shared__ float part[256];
     const int tid = threadIdx.x;
     const int64_t frame = blockIdx.x;
-    const int64_t start = (int64_t)rint((double)frame * fshift);
-    auto sample_at = [&](int64_t i) -> float {
-        if (i < 0 || i >= nsamples) return 0.0f;
-        return is_i16 ? (float)((const int16_t*)samples)[i] : ((const float*)samples)[i];
-    };
+    int64_t fr = frame, len = nsamples;
+    const char* base = (const char*)samples;
+    if (n_utts > 0) {
+        const int u = find_utt(utt_foff, n_utts, frame);
+        fr = frame - utt_foff[u];
+        len = utt_soff[u + 1] - utt_soff[u];
+        base += utt_soff[u] * (is_i16 ? 2 : 4);
+    }
+    const FrameSrc cur = frame_src(base, is_i16, len, fr, fshift, wlen);
+    const FrameSrc prv = frame_src(base, is_i16, len, fr > 0 ? fr - 1 : 0, fshift, wlen);
+    const float prior = fr > 0 ? prv.at(wlen - 1) : 0.0f;
     for (int n = tid; n < nfft; n += 256) {
         float v = 0.0f;
-        if (n < wlen) {
-            const int64_t i = start + n;
-            // pre-emphasis runs over the zero-padded frame: its history is the
-            // previous SIGNAL sample (0 before the first one), so the first
-            // padded sample still sees -alpha * last (oracle/features_np.py)
-            v = (sample_at(i) - alpha * sample_at(i - 1)) * window[n];
-        }
+        if (n < wlen) v = (cur.at(n) - alpha * (n > 0 ? cur.at(n - 1) : prior)) * window[n];
         const unsigned r = bitrev((unsigned)n, log2n);
         re[r] = v;
         im[r] = 0.0f;
@@ -139,7 +187,8 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
                                                                   float alpha, const float* __restrict__ window,
                                                                   const float* __restrict__ melbank,
                                                                   const int32_t* __restrict__ band, int64_t nframes,
-                                                                  float* __restrict__ out)
+                                                                  float* __restrict__ out, const int64_t* __restrict__ utt_soff,
+                                                                  const int64_t* __restrict__ utt_foff, int n_utts)
 {
     __shared__ cf zbuf[FB_WAVES][512];
     __shared__ float pw[FB_WAVES][516];
@@ -189,28 +238,47 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
     }
     const int nwaves = gridDim.x * FB_WAVES;
     for (int64_t frame = (int64_t)blockIdx.x * FB_WAVES + wave; frame < nframes; frame += nwaves) {
-        const int64_t start = (int64_t)rint((double)frame * fshift);
+        int64_t fr = frame, len = nsamples;
+        const char* base = (const char*)samples;
+        if (n_utts > 0) {                                          // (wave-uniform: one frame per wavefront)
+            const int u = find_utt(utt_foff, n_utts, frame);
+            fr = frame - utt_foff[u];
+            len = utt_soff[u + 1] - utt_soff[u];
+            base += utt_soff[u] * (is_i16 ? 2 : 4);
+        }
+        const FrameSrc cur = frame_src(base, is_i16, len, fr, fshift, wlen);
         cf v[8];
-        // pre-emphasis over the zero-padded frame: y[n] = x[n] - alpha x[n-1] (x = 0 outside the signal)
+        // pre-emphasis y[n] = x[n] - alpha x[n-1] inside the frame; element 0's history is the previous frame's
+        // last element (FrameSrc).  Whole frames -- all but an utterance's last two -- read their samples directly.
+        if (cur.avail >= wlen) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int n0 = 2 * (j + 64 * r);
-            float a = 0.0f, b = 0.0f, c = 0.0f;                  // x[n0 - 1], x[n0], x[n0 + 1]
-            if (n0 < wlen) {                                      // wave-uniform for whole r beyond the window? no: per lane
-                const int64_t i = start + n0;
-                if (is_i16) {
-                    const int16_t* sp = (const int16_t*)samples;
-                    a = (i - 1 >= 0 && i - 1 < nsamples) ? (float)sp[i - 1] : 0.0f;
-                    b = (i >= 0 && i < nsamples) ? (float)sp[i] : 0.0f;
-                    c = (i + 1 < nsamples) ? (float)sp[i + 1] : 0.0f;
-                } else {
-                    const float* sp = (const float*)samples;
-                    a = (i - 1 >= 0 && i - 1 < nsamples) ? sp[i - 1] : 0.0f;
-                    b = (i >= 0 && i < nsamples) ? sp[i] : 0.0f;
-                    c = (i + 1 < nsamples) ? sp[i + 1] : 0.0f;
+            for (int r = 0; r < 8; ++r) {
+                const int n0 = 2 * (j + 64 * r);
+                float a = 0.0f, b = 0.0f, c = 0.0f;                  // x[n0 - 1], x[n0], x[n0 + 1]
+                if (n0 < wlen) {
+                    const int64_t i = cur.start + n0;
+                    // n0 == 0: the previous frame (whole too: it starts earlier) ends at sample prev_start + wlen - 1
+                    const int64_t ia = n0 > 0 ? i - 1 : (fr > 0 ? (int64_t)rint((double)(fr - 1) * fshift) + wlen - 1 : -1);
+                    a = ia >= 0 ? cur.raw(ia) : 0.0f;
+                    b = cur.raw(i);
+                    c = n0 + 1 < wlen ? cur.raw(i + 1) : 0.0f;
                 }
+                v[r] = {(b - alpha * a) * w0[r], (c - alpha * b) * w1[r]};
             }
-            v[r] = {(b - alpha * a) * w0[r], (c - alpha * b) * w1[r]};
+        } else {
+            const FrameSrc prv = frame_src(base, is_i16, len, fr > 0 ? fr - 1 : 0, fshift, wlen);
+            const float prior = fr > 0 ? prv.at(wlen - 1) : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int n0 = 2 * (j + 64 * r);
+                float a = 0.0f, b = 0.0f, c = 0.0f;
+                if (n0 < wlen) {
+                    a = n0 > 0 ? cur.at(n0 - 1) : prior;
+                    b = cur.at(n0);
+                    c = n0 + 1 < wlen ? cur.at(n0 + 1) : 0.0f;
+                }
+                v[r] = {(b - alpha * a) * w0[r], (c - alpha * b) * w1[r]};
+            }
         }
         // pass 0 (sub-transform size 1): no twiddles; outputs to 8 j + r
         dft8(v);
@@ -312,9 +380,10 @@ __global__ void deltas_kernel(const float* __restrict__ x, int64_t T, int D, flo
 
 using namespace abn;
 
-extern "C" int abn_fbank(const void* samples, int sample_is_i16, int64_t nsamples, int32_t wlen, double fshift,
-                         int32_t nfft, int32_t nfilt, float alpha, const float* window, const float* melbank,
-                         const int32_t* band, int64_t nframes, float* out, void* stream)
+static int fbank_launch(const void* samples, int sample_is_i16, int64_t nsamples, const int64_t* utt_soff,
+                        const int64_t* utt_foff, int64_t n_utts, int32_t wlen, double fshift, int32_t nfft, int32_t nfilt,
+                        float alpha, const float* window, const float* melbank, const int32_t* band, int64_t nframes,
+                        float* out, void* stream)
 {
     ABN_REQUIRE(nframes >= 0 && nsamples >= 0, "fbank: negative sizes");
     if (nframes == 0) return ABN_OK;
@@ -323,22 +392,42 @@ extern "C" int abn_fbank(const void* samples, int sample_is_i16, int64_t nsample
     ABN_REQUIRE(wlen >= 1 && wlen <= nfft, "fbank: wlen=%d must be in [1, nfft]", wlen);
     ABN_REQUIRE(nfilt >= 1 && nfilt <= FB_MAX_FILT, "fbank: nfilt=%d out of range", nfilt);
     ABN_REQUIRE(fshift > 0.0, "fbank: frame shift must be positive");
+    ABN_REQUIRE(n_utts >= 0 && n_utts < (1LL << 30) && nframes < (1LL << 31), "fbank: too many utterances / frames");
     hipStream_t st = (hipStream_t)stream;
     if (nfft == 1024 && nfilt <= 64 && band) {
         // persistent: enough wavefronts to fill the chip, each walks frames wave, wave + W, ...
         int64_t wgs = (nframes + FB_WAVES - 1) / FB_WAVES;
         if (wgs > 256 * 6) wgs = 256 * 6;
         hipLaunchKernelGGL(fbank1024_kernel, dim3((unsigned)wgs), dim3(64 * FB_WAVES), 0, st, samples, sample_is_i16, nsamples,
-                           (int)wlen, fshift, (int)nfilt, alpha, window, melbank, band, nframes, out);
+                           (int)wlen, fshift, (int)nfilt, alpha, window, melbank, band, nframes, out, utt_soff, utt_foff, (int)n_utts);
         ABN_CHECK_LAUNCH("fbank1024");
         return ABN_OK;
     }
     int log2n = 0;
     while ((1 << log2n) < nfft) ++log2n;
     hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)nframes), dim3(256), 0, st, samples, sample_is_i16,
-                       nsamples, (int)wlen, fshift, (int)nfft, log2n, (int)nfilt, alpha, window, melbank, out);
+                       nsamples, (int)wlen, fshift, (int)nfft, log2n, (int)nfilt, alpha, window, melbank, out, utt_soff, utt_foff,
+                       (int)n_utts);
     ABN_CHECK_LAUNCH("fbank");
     return ABN_OK;
+}
+
+extern "C" int abn_fbank(const void* samples, int sample_is_i16, int64_t nsamples, int32_t wlen, double fshift,
+                         int32_t nfft, int32_t nfilt, float alpha, const float* window, const float* melbank,
+                         const int32_t* band, int64_t nframes, float* out, void* stream)
+{
+    return fbank_launch(samples, sample_is_i16, nsamples, nullptr, nullptr, 0, wlen, fshift, nfft, nfilt, alpha, window, melbank,
+                        band, nframes, out, stream);
+}
+
+extern "C" int abn_fbank_batched(const void* samples, int sample_is_i16, const int64_t* utt_sample_off,
+                                 const int64_t* utt_frame_off, int64_t n_utts, int32_t wlen, double fshift, int32_t nfft,
+                                 int32_t nfilt, float alpha, const float* window, const float* melbank, const int32_t* band,
+                                 int64_t nframes, float* out, void* stream)
+{
+    ABN_REQUIRE(n_utts >= 1 && utt_sample_off && utt_frame_off, "fbank_batched: utterance tables missing");
+    return fbank_launch(samples, sample_is_i16, 0, utt_sample_off, utt_frame_off, n_utts, wlen, fshift, nfft, nfilt, alpha, window,
+                        melbank, band, nframes, out, stream);
 }
 
 extern "C" int abn_deltas(const float* feats, int64_t T, int64_t D, float* out, void* stream)

@@ -45,6 +45,60 @@ __global__ void stack_frames_kernel(const float* __restrict__ in, int64_t T, int
     }
 }
 
+// The same for a batch of utterances laid end to end (utt_foff: cumulative frame counts, [n_utts + 1]):
+// the window never crosses an utterance boundary.
+__global__ void stack_frames_batched_kernel(const float* __restrict__ in, const int64_t* __restrict__ utt_foff, int n_utts,
+                                            int64_t T, int D, int nframes, float* __restrict__ out)
+{
+    const int W = D * nframes, h = nframes / 2;
+    const int64_t total = T * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / W;
+        const int j = (int)(i - t * W);
+        const int k = j / D, c = j - k * D;
+        int lo = 0, hi = n_utts - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (utt_foff[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        const int64_t src = t + k - h;
+        out[i] = (src >= utt_foff[lo] && src < utt_foff[lo + 1]) ? in[src * D + c] : 0.0f;
+    }
+}
+
+// One training batch of frame pairs straight into the layout a (captured) train step reads:
+//   x12[r]         = table[idx1[first + r]]   r < n          (tower 1)
+//   x12[n_pad + r] = table[idx2[first + r]]   r < n          (tower 2)
+// rows n .. n_pad - 1 of both halves zero; labels copied (padding 0); *n_valid = n.
+// One 16-byte piece per thread (D % 4 == 0) or one element.
+template <bool VEC>
+__global__ void gather_pairs_kernel(const float* __restrict__ table, int D, const int64_t* __restrict__ idx1,
+                                    const int64_t* __restrict__ idx2, int64_t first, int n, int n_pad,
+                                    const char* __restrict__ labels, int label_bytes, float* __restrict__ x12,
+                                    char* __restrict__ y_out, int32_t* __restrict__ n_valid)
+{
+    const int per_row = VEC ? D / 4 : D;
+    const int64_t total = (int64_t)2 * n_pad * per_row;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / per_row);
+        const int c = (int)(i - (int64_t)row * per_row);
+        const int tower = row >= n_pad, r = row - tower * n_pad;
+        if (VEC) {
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < n) v = reinterpret_cast<const float4*>(table + (tower ? idx2 : idx1)[first + r] * D)[c];
+            reinterpret_cast<float4*>(x12 + (int64_t)row * D)[c] = v;
+        } else {
+            x12[(int64_t)row * D + c] = r < n ? table[(tower ? idx2 : idx1)[first + r] * D + c] : 0.0f;
+        }
+    }
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (labels && y_out)
+        for (int64_t i = tid; i < (int64_t)n_pad * label_bytes; i += (int64_t)gridDim.x * blockDim.x)
+            y_out[i] = i < (int64_t)n * label_bytes ? labels[first * label_bytes + i] : 0;
+    if (n_valid && tid == 0) *n_valid = n;
+}
+
 // Mean / variance normalisation, abnet3/features.py:205-244 and :263-297:
 //   mean = np.mean(features, axis), std = np.std(features, axis)   (axis 0 = per
 //   channel, None = whole spectrum), out = (x - mean) / (std + eps).
@@ -148,6 +202,37 @@ int abn_gather_rows(const float* table, const int64_t* idx, int64_t n, int64_t D
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * D)), dim3(256), 0, (hipStream_t)stream, table, idx, n,
                        (int)D, out);
     ABN_CHECK_LAUNCH("gather_rows");
+    return ABN_OK;
+}
+
+int abn_stack_frames_batched(const float* feats, const int64_t* utt_frame_off, int64_t n_utts, int64_t T, int64_t D,
+                             int32_t nframes, float* out, void* stream)
+{
+    ABN_REQUIRE(nframes >= 1 && nframes % 2 == 1, "stack_frames: number of stacked frames must be odd");
+    ABN_REQUIRE(T >= 0 && D >= 1 && D < (1 << 20) && n_utts >= 1 && n_utts < (1LL << 30), "stack_frames_batched: bad shape");
+    if (T == 0) return ABN_OK;
+    ABN_REQUIRE(feats && out && utt_frame_off, "stack_frames_batched: null pointer");
+    hipLaunchKernelGGL(stack_frames_batched_kernel, dim3(grid_for(T * D * nframes)), dim3(256), 0, (hipStream_t)stream, feats,
+                       utt_frame_off, (int)n_utts, T, (int)D, (int)nframes, out);
+    ABN_CHECK_LAUNCH("stack_frames_batched");
+    return ABN_OK;
+}
+
+int abn_gather_pairs(const float* table, int64_t D, const int64_t* idx1, const int64_t* idx2, int64_t first, int64_t n,
+                     int64_t n_pad, const void* labels, int32_t label_bytes, float* x12, void* y_out, int32_t* n_valid,
+                     void* stream)
+{
+    ABN_REQUIRE(D >= 1 && D < (1 << 20) && first >= 0 && n >= 0 && n_pad >= n && n_pad < (1 << 24), "gather_pairs: bad shape");
+    ABN_REQUIRE((labels == nullptr) == (y_out == nullptr) && (!labels || (label_bytes >= 1 && label_bytes <= 8)), "gather_pairs: labels / y_out / label_bytes");
+    if (n_pad == 0) return ABN_OK;
+    ABN_REQUIRE(table && idx1 && idx2 && x12, "gather_pairs: null pointer");
+    const bool vec = D % 4 == 0 && aligned16(table) && aligned16(x12);
+    const int64_t work = 2 * n_pad * (vec ? D / 4 : D);
+    if (vec) hipLaunchKernelGGL(gather_pairs_kernel<true>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, table, (int)D, idx1, idx2,
+                                first, (int)n, (int)n_pad, (const char*)labels, (int)label_bytes, x12, (char*)y_out, n_valid);
+    else hipLaunchKernelGGL(gather_pairs_kernel<false>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, table, (int)D, idx1, idx2,
+                            first, (int)n, (int)n_pad, (const char*)labels, (int)label_bytes, x12, (char*)y_out, n_valid);
+    ABN_CHECK_LAUNCH("gather_pairs");
     return ABN_OK;
 }
 

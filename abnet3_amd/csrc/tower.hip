@@ -876,6 +876,8 @@ struct LossArgs {
     float margin;
     float* loss_out;
     void* ws;              // 8 bytes of ticket counter (zero before the first call, left zero) + one double per workgroup
+    const int32_t* n_valid;
+    double* loss_accum;
 };
 
 // Every layer's weight-gradient tiles for one wgrad_planes_kernel launch: operands = the transposed images
@@ -1026,6 +1028,8 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
         b.loss_counter = reinterpret_cast<unsigned*>(loss->ws);
         b.loss_partial = reinterpret_cast<double*>(reinterpret_cast<char*>(loss->ws) + 8);
         b.loss_out = loss->loss_out;
+        b.n_valid = loss->n_valid;
+        b.loss_accum = loss->loss_accum;
     }
     b.a_top = ws + L.a[nl - 1];
     b.dx = dx;
@@ -1534,7 +1538,8 @@ int64_t abn_tower_backward_loss_ws_bytes(int64_t rows) { return 8 + ((rows + PL_
 
 int abn_tower_backward_loss(const abn_tower_desc* t, const float* x1, const float* x2, const void* y, int y_dtype,
                             int loss_kind, float margin, int avg, int64_t rows, const float* ws, float* scratch,
-                            int64_t scratch_floats, float* loss_out, void* loss_ws, void* stream)
+                            int64_t scratch_floats, float* loss_out, void* loss_ws, const int32_t* n_valid, double* loss_accum,
+                            void* stream)
 {
     int rc = check_desc(t, rows, 2);
     if (rc != ABN_OK) return rc;
@@ -1551,7 +1556,7 @@ int abn_tower_backward_loss(const abn_tower_desc* t, const float* x1, const floa
     const Layout L = make_layout(t, rows, 2);
     const BwdLayout B = make_bwd_layout(t, rows);
     if (scratch_floats < B.total) { set_error("tower_backward_loss: scratch too small"); return ABN_E_WORKSPACE; }
-    LossArgs la = {y, y_dtype, loss_kind, avg, margin, loss_out, loss_ws};
+    LossArgs la = {y, y_dtype, loss_kind, avg, margin, loss_out, loss_ws, n_valid, loss_accum};
     return planes_backward(t, nullptr, &la, rows, L, B, ws, scratch, nullptr, (hipStream_t)stream);
 }
 

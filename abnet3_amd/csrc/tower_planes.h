@@ -820,6 +820,11 @@ struct PlanesBwdP {
     double* loss_partial;                 // one per workgroup
     unsigned* loss_counter;               // ticket (zero before, zero after)
     float* loss_out;
+    // padded batches (a captured step serving a bucket of batch sizes): only the first *n_valid pairs are real,
+    // the others contribute no loss term and get dz = 0 (so nothing of them reaches a gradient); avg divides
+    // by *n_valid.  null: all B pairs.
+    const int* n_valid;
+    double* loss_accum;                   // optional: the call's loss is also added here (an epoch's running sum)
 };
 
 // dZ_{l-1} from dZ_l (in img, pl_steps(dims[l+1]) steps): output features = the dims[l] inputs of layer l
@@ -950,13 +955,15 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
     const bool with_loss = p.loss_kind >= 0;
     if (with_loss) {
         const int B = p.B;
+        const int Bv = p.n_valid ? *p.n_valid : B;
+        const double lscale = p.n_valid && p.scale != 1.0 ? 1.0 / (double)(Bv > 0 ? Bv : 1) : p.scale;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int lr = 4 * wave + 2 * it + (lane >> 5), l = lane & 31;
             const int g = row0 + lr;
             double inv = 0.0, kself = 0.0, term = 0.0;
-            const bool ok = g < p.rows;
-            const int tower = ok && g >= B ? 1 : 0, pi_ = ok ? g - tower * B : 0;
+            const int tower = g < p.rows && g >= B ? 1 : 0, pi_ = g < p.rows ? g - tower * B : 0;
+            const bool ok = g < p.rows && pi_ < Bv;
             const float* a = p.a_top + (int64_t)pi_ * NT;           // e1[pair], e2[pair]: the order loss.hip sums in
             const float* b = p.a_top + (int64_t)(B + pi_) * NT;
             double dot = 0.0, s11 = 0.0, s22 = 0.0;
@@ -997,7 +1004,7 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
                     else if (code == -1) { const double hh = cs - p.margin; term = hh > 0.0 ? hh : 0.0; dcos = hh >= 0.0 ? 1.0 : 0.0; }
                     else { term = cs; dcos = 1.0; }
                 }
-                dcos *= p.scale;
+                dcos *= lscale;
                 inv = dcos / (c1 * c2);
                 const double k1 = n1 > 0.0 ? dcos * cs / (c1 * n1) : 0.0;
                 const double k2 = n2 > 0.0 ? dcos * cs / (c2 * n2) : 0.0;
@@ -1027,7 +1034,9 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
             if (lane == 0) {
-                *p.loss_out = (float)(sum * (p.scale));
+                const float lv = (float)(sum * lscale);
+                *p.loss_out = lv;
+                if (p.loss_accum) *p.loss_accum += (double)lv;        // (one thread of one workgroup per call, calls in stream order)
                 __hip_atomic_store(p.loss_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }

@@ -66,6 +66,32 @@ class DeviceCorpus(object):
         self.dim = chunks[0].shape[1]
         self.table = torch.from_numpy(np.concatenate(chunks, axis=0)).cuda()
         self.total = o
+        self._init_lookup()
+
+    @classmethod
+    def from_table(cls, table, names, lengths, times):
+        """The same corpus from features that are already in HBM (FeaturesGenerator.features_from_waves):
+        `table` [sum(lengths), D] float32 on the device, utterance k = its rows
+        [sum(lengths[:k]), sum(lengths[:k + 1])); times {name: [T] frame times}."""
+        _lib.require_device(table)
+        self = cls.__new__(cls)
+        self.names = list(names)
+        self.offset, self.length, self.times = {}, {}, {}
+        o = 0
+        for k, n in zip(self.names, lengths):
+            self.offset[k], self.length[k] = o, int(n)
+            self.times[k] = np.asarray(times[k])
+            o += int(n)
+        assert o == table.shape[0], 'lengths do not add up to the table'
+        self.dim = table.shape[1]
+        self.table = table
+        self.total = o
+        self._init_lookup()
+        return self
+
+    def _init_lookup(self):
+        self._tokens = {}                    # (name, on, off) -> (first global row, frames)
+        self._sorted = {}                    # name -> are its frame times non-decreasing (then: binary search)
 
     def _name(self, f):
         b = f.encode('UTF-8') if isinstance(f, str) else f
@@ -73,18 +99,66 @@ class DeviceCorpus(object):
 
     def token(self, f, on, off):
         """(first global row, number of frames) of the token (f, on, off)."""
+        key = (f, on, off)
+        hit = self._tokens.get(key)
+        if hit is not None:
+            return hit
         k = self._name(f)
         t = self.times[k]
-        ind = Features_Accessor.get_indices_between(t, on, off)
-        if len(ind) == 0:
-            return self.offset[k], 0
-        assert ind[-1] - ind[0] + 1 == len(ind), 'frame times must be sorted'
-        return self.offset[k] + int(ind[0]), len(ind)
+        srt = self._sorted.get(k)
+        if srt is None:
+            srt = self._sorted[k] = bool(len(t) < 2 or np.all(t[1:] >= t[:-1]))
+        if srt:
+            # np.where((t >= on) & (t <= off)) of sorted times is one run of frames: two binary searches
+            lo, hi = int(np.searchsorted(t, on, 'left')), int(np.searchsorted(t, off, 'right'))
+            out = (self.offset[k] + lo, hi - lo) if hi > lo else (self.offset[k], 0)
+        else:
+            ind = Features_Accessor.get_indices_between(t, on, off)
+            if len(ind) == 0:
+                out = (self.offset[k], 0)
+            else:
+                assert ind[-1] - ind[0] + 1 == len(ind), 'frame times must be sorted'
+                out = (self.offset[k] + int(ind[0]), len(ind))
+        self._tokens[key] = out
+        return out
 
     def token_frames(self, f, frame_on, frame_off):
         k = self._name(f)
         lo, hi, _ = slice(frame_on, frame_off).indices(self.length[k])
         return self.offset[k] + lo, max(0, hi - lo)
+
+
+class BatchPlan(object):
+    """Every batch of a dataset as index lists in HBM: batch b is the frame pairs
+    [offsets[b], offsets[b + 1]) of (idx1, idx2, labels) -- global rows of `table` and the pair labels,
+    already in the order the reference's iterator would yield them (vstack order, then the seed-0
+    permutation, abnet3/dataloader.py:248-255) -- and `order` is the batch ids one pass visits (this
+    rank's share).  A trainer that understands plans (TrainerSiamese) gathers batch b with ONE launch
+    (abn_gather_pairs) into the buffers of a captured step; materialise(b) gives the tensors the plain
+    iterator yields."""
+
+    def __init__(self, table, idx1, idx2, labels, offsets, order):
+        self.table, self.idx1, self.idx2, self.labels = table, idx1, idx2, labels
+        self.offsets = np.asarray(offsets, dtype=np.int64)
+        self.order = [int(b) for b in order]
+
+    def __len__(self):
+        return len(self.order)
+
+    def span(self, b):
+        """(first frame pair, number of frame pairs) of batch b"""
+        return int(self.offsets[b]), int(self.offsets[b + 1] - self.offsets[b])
+
+    def materialise(self, b):
+        first, n = self.span(b)
+        if n == 0:
+            raise ValueError('need at least one array to concatenate')
+        sl = slice(first, first + n)
+        return (gather_rows(self.table, self.idx1[sl]), gather_rows(self.table, self.idx2[sl]), self.labels[sl])
+
+    def __iter__(self):
+        for b in self.order:
+            yield self.materialise(b)
 
 
 class OriginalDataLoader(DataLoader):
@@ -377,6 +451,126 @@ class OriginalDataLoader(DataLoader):
                 batch = self.add_tcl_to_batch(batch)
             yield batch
 
+    # -- the same batches as index lists in HBM (BatchPlan) -------------------------------
+    _PERMS = {}          # n -> np.random.seed(0); np.random.permutation(n)  (dataloader.py:248-249)
+
+    @classmethod
+    def _seed0_permutation(cls, n):
+        p = cls._PERMS.get(n)
+        if p is None:
+            # RandomState(0) is the generator np.random.seed(0) re-creates: the same permutation, and the
+            # global stream is left alone until the pass is over (plan(): see there)
+            p = cls._PERMS[n] = np.random.RandomState(0).permutation(n)
+        return p
+
+    def _plan_store(self, mode):
+        """(idx1, idx2, labels, offsets) of EVERY batch of self.pairs[mode] -- batch b = pairs
+        [b * batch_size, (b + 1) * batch_size) -- built once per pairs list: the content of a batch never
+        changes between epochs (alignments are cached, the permutation is seeded with 0 every time), only
+        which batches an epoch visits and in which order does."""
+        pairs = self.pairs[mode]
+        cached = getattr(self, '_plans', {}).get(mode)
+        if cached is not None and cached[0] is pairs and cached[1] == len(pairs):
+            return cached[2]
+        self.align_pairs([p[:6] for p in pairs if p[6] == 'same'], exchange=True)
+        dev = self.features.table.device
+        bs = self.batch_size
+        nb = (len(pairs) + bs - 1) // bs
+        d1, d2 = [], []
+        # frames_from_pairs_device's loop, for all batches at once: same pairs first, then diff pairs
+        per_batch = [[] for _ in range(nb)]  # [(+1 | -1, the aligned index lists | position in d1 / d2, rows, labels)]
+        for b in range(nb):
+            chunk = pairs[b * bs:(b + 1) * bs]
+            same = [p for p in chunk if p[6] == 'same']
+            diff = [p for p in chunk if p[6] == 'diff']
+            assert len(same) + len(diff) == len(chunk), 'Unsupported pair type'
+            for f1, s1, e1, f2, s2, e2, _ in same:
+                if (s1 > e1) or (s2 > e2):
+                    continue
+                al = self._align.get((f1, s1, e1, f2, s2, e2, False))
+                if al is None:
+                    continue
+                per_batch[b].append((1, al, len(al[0]), len(al[0])))
+            for f1, s1, e1, f2, s2, e2, _ in diff:
+                if (s1 > e1) or (s2 > e2):
+                    continue
+                (a0, n1), (b0, n2) = self._token(f1, s1, e1, False), self._token(f2, s2, e2, False)
+                if self.align_different_words:
+                    if n2 < n1:
+                        mn0, mnl, mx0, mxl = b0, n2, a0, n1
+                    else:
+                        mn0, mnl = a0, n1
+                        mx0, mxl = (b0, n2) if n2 > n1 else (a0, n1)
+                    mapping = np.rint(np.linspace(0, mnl - 1, num=mxl)).astype(int)
+                    w1, w2 = mx0 + np.arange(mxl), mn0 + mapping
+                else:
+                    m = min(n1, n2)
+                    w1, w2 = a0 + np.arange(m), b0 + np.arange(m)
+                # (the labels count min(n1, n2) frames, dataloader.py:231, whatever the number of rows is)
+                per_batch[b].append((-1, len(d1), len(w1), min(n1, n2)))
+                d1.append(w1.astype(np.int64)); d2.append(w2.astype(np.int64))
+        if d1:
+            lens_d = np.array([len(w) for w in d1], dtype=np.int64)
+            offs_d = np.concatenate(([0], np.cumsum(lens_d)))
+            both = torch.from_numpy(np.concatenate(d1 + d2)).to(dev)
+            dd1, dd2 = both[:both.numel() // 2], both[both.numel() // 2:]
+        parts1, parts2, labels, perm, offsets, row0 = [], [], [], [], [0], 0
+        for b in range(nb):
+            n, rows = 0, 0
+            for kind, payload, ln, nlab in per_batch[b]:
+                if kind == 1:
+                    parts1.append(payload[0]); parts2.append(payload[1])
+                else:
+                    parts1.append(dd1[offs_d[payload]:offs_d[payload] + ln]); parts2.append(dd2[offs_d[payload]:offs_d[payload] + ln])
+                labels.append(np.full(nlab, float(kind)))
+                n += nlab
+                rows += ln
+            # the reference permutes len(y) = n indices and applies them to the rows AND the labels
+            # (dataloader.py:247-255): with align_different_words a batch can hold more rows than labels,
+            # and the permutation then draws from its first n rows
+            perm.append((row0 + self._seed0_permutation(n), offsets[-1] + self._seed0_permutation(n)))
+            offsets.append(offsets[-1] + n)
+            row0 += rows
+        empty = torch.zeros(0, dtype=torch.int64, device=dev)
+        if parts1:
+            perm_rows = np.concatenate([p[0] for p in perm])
+            perm_lab = np.concatenate([p[1] for p in perm])
+            perm_d = torch.from_numpy(perm_rows).to(dev)
+            i1, i2 = torch.cat(parts1)[perm_d], torch.cat(parts2)[perm_d]
+            y = torch.from_numpy(np.concatenate(labels)[perm_lab]).to(dev)
+        else:
+            i1, i2, y = empty, empty, torch.zeros(0, dtype=torch.float64, device=dev)
+        # (statistics_training counts a pair every time an epoch visits it: plan() adds these per visited batch)
+        counts = np.array([[sum(1 for e in pb if e[0] == 1), sum(1 for e in pb if e[0] == -1)] for pb in per_batch], dtype=np.int64).reshape(nb, 2)
+        store = (i1, i2, y, np.asarray(offsets, dtype=np.int64), counts)
+        if not hasattr(self, '_plans'):
+            self._plans = {}
+        self._plans[mode] = (pairs, len(pairs), store)
+        return store
+
+    def plan(self, train_mode=True):
+        """batch_iterator(train_mode) as a BatchPlan (same batches, same order, same draws from the global
+        RNGs), or None where only the iterator applies (temporal-coherence pairs are drawn per batch)."""
+        if self.tcl > 0:
+            return None
+        self.load_data()
+        mode = 'train' if train_mode else 'dev'
+        pairs = self.pairs[mode]
+        if self.shuffle_between_epochs:
+            self._shuffle_pairs(pairs)
+            getattr(self, '_plans', {}).pop(mode, None)      # the batches' composition changed
+        i1, i2, y, offsets, counts = self._plan_store(mode)
+        selected = self._select_batches(len(offsets) - 1, train_mode)
+        order = [int(b) for b in selected]
+        if order:
+            self.statistics_training['SameType'] += int(counts[order, 0].sum())
+            self.statistics_training['DiffType'] += int(counts[order, 1].sum())
+            # the iterator would leave numpy's global generator where its last batch put it
+            # (np.random.seed(0); np.random.permutation(n), dataloader.py:248-249): so does the plan
+            np.random.seed(0)
+            np.random.permutation(int(offsets[order[-1] + 1] - offsets[order[-1]]))
+        return BatchPlan(self.features.table, i1, i2, y, offsets, order)
+
     @staticmethod
     def _shuffle_pairs(pairs):
         """random.shuffle(pairs) (dataloader.py:276-277); under torch.distributed the
@@ -504,8 +698,8 @@ class FramesDataLoader(OriginalDataLoader):
         return (gather_rows(self.features.table, i1[sl]),
                 gather_rows(self.features.table, i2[sl]), y[sl])
 
-    def batch_iterator(self, train_mode=True):
-        """(dataloader.py:686-739)"""
+    def _batch_ids(self, train_mode):
+        """The shuffles and the batch ids of one pass (dataloader.py:686-739), this rank's share."""
         self.load_data()
         mode = 'train' if train_mode else 'dev'
         num_pairs = len(self.frame_pairs[mode][2])
@@ -528,9 +722,25 @@ class FramesDataLoader(OriginalDataLoader):
         rank, ws = parallel.world()
         if ws > 1:       # rank r gathers batches r, r+R, ... of the epoch's (shared) order
             batch_ids = parallel.shard_ids(list(batch_ids), rank, ws, equal=train_mode)
-        for i in batch_ids:
+        return list(batch_ids)
+
+    def batch_iterator(self, train_mode=True):
+        """(dataloader.py:686-739)"""
+        mode = 'train' if train_mode else 'dev'
+        for i in self._batch_ids(train_mode):
             yield self.load_batch(slice(i * self.batch_size,
                                         i * self.batch_size + self.batch_size), mode)
+
+    def plan(self, train_mode=True):
+        """batch_iterator(train_mode) as a BatchPlan: the same shuffles, batch b = frame pairs
+        [b * batch_size, (b + 1) * batch_size) of the (re)shuffled dataset."""
+        ids = self._batch_ids(train_mode)
+        mode = 'train' if train_mode else 'dev'
+        i1, i2, y = self.frame_pairs[mode]
+        num_pairs = len(y)
+        num_batches = max(1, num_pairs // self.batch_size)
+        offsets = np.minimum(np.arange(num_batches + 1, dtype=np.int64) * self.batch_size, num_pairs)
+        return BatchPlan(self.features.table, i1, i2, y, offsets, ids)
 
 
 class MultiTaskDataLoader(OriginalDataLoader):
@@ -544,6 +754,9 @@ class MultiTaskDataLoader(OriginalDataLoader):
         assert speaker_match in ('identity', 'equal')
         self.fid2spk_file = fid2spk_file
         self.speaker_match = speaker_match
+
+    def plan(self, train_mode=True):
+        return None                    # (four tensors per batch: the iterator)
 
     def batch_iterator(self, train_mode=True):
         self.load_data()

@@ -70,6 +70,18 @@ class EmbedderSiamese(EmbedderBuilder):
             o += n
         return out
 
+    def embed_table(self, table):
+        """embed_features for features that already sit in HBM as one [frames, D] table (utterances laid end to
+        end: rows are independent in eval mode): [frames, output_dim] on the device, ROWS_PER_LAUNCH frames per
+        launch."""
+        self.network.eval()
+        self.network.cuda()
+        out = torch.empty(table.shape[0], self.network.output_dim, dtype=torch.float32, device=table.device)
+        with torch.no_grad():
+            for r0 in range(0, table.shape[0], self.ROWS_PER_LAUNCH):
+                out[r0:r0 + self.ROWS_PER_LAUNCH] = self.network.forward_once(table[r0:r0 + self.ROWS_PER_LAUNCH])
+        return out
+
     def embed(self):
         """Embed method to embed features based on a saved network."""
         if self.network_path is not None:

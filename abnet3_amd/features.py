@@ -135,6 +135,94 @@ class FeaturesGenerator:
             out = torch.cat(cols, dim=1)
         return out
 
+    # -- a whole corpus at once, device resident (features.py:160-203, :345-404 without the files) -------
+    def fbank_batch(self, waves, srate, alpha=0.97, frate=100, wlen=0.025, nfft=1024):
+        """do_fbank for a list of utterances in ONE launch (abn_fbank_batched): `waves` = int16 (or float)
+        numpy arrays, or one device tensor per utterance, or (device tensor of all samples, sample counts).  Returns (table [sum T_u, n_filters * (1 + deltas +
+        deltasdeltas)] float32 on the device, frame counts [T_u]); utterance u is framed on its own, exactly as
+        fbank_from_samples(waves[u]) frames it."""
+        lib = _lib.load()
+        if isinstance(waves, tuple):             # (all samples end to end on the device, sample counts)
+            s, lens = waves[0], np.asarray(waves[1], dtype=np.int64)
+            assert int(lens.sum()) == s.numel()
+        else:
+            lens = np.array([len(w) for w in waves], dtype=np.int64)
+        if isinstance(waves, tuple):
+            pass
+        elif isinstance(waves[0], torch.Tensor):
+            s = torch.cat([w.reshape(-1) for w in waves]).cuda()
+        else:
+            dt = np.int16 if all(w.dtype == np.int16 for w in waves) else np.float32
+            s = torch.from_numpy(np.concatenate([np.asarray(w, dtype=dt).reshape(-1) for w in waves])).cuda()
+        if s.dtype not in (torch.int16, torch.float32):
+            s = s.float()
+        s = s.contiguous()
+        wl = int(wlen * srate)
+        fshift = float(srate) / frate
+        nfr = (lens / fshift + 1).astype(np.int64)           # int(len / fshift + 1) per utterance
+        soff = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+        foff = np.concatenate(([0], np.cumsum(nfr))).astype(np.int64)
+        total = int(foff[-1])
+        tables = torch.from_numpy(np.concatenate((soff, foff))).cuda()
+        win, bank, band = self._table(srate, wl, nfft, s.device)
+        out = torch.empty(total, self.n_filters, dtype=torch.float32, device=s.device)
+        _lib.check(lib.abn_fbank_batched(_lib.ptr(s), int(s.dtype == torch.int16), _lib.ptr(tables[:len(soff)]),
+                                         _lib.ptr(tables[len(soff):]), len(lens), wl, fshift, nfft, self.n_filters, alpha,
+                                         _lib.ptr(win), _lib.ptr(bank), _lib.ptr(band), total, _lib.ptr(out), _lib.stream()),
+                   'abn_fbank_batched')
+        if self.deltas or self.deltasdeltas:               # slopes never cross an utterance boundary: per utterance
+            cols = [out]
+            d1 = torch.cat([self.deltas_of(out[foff[u]:foff[u + 1]]) for u in range(len(lens))])
+            if self.deltas:
+                cols.append(d1)
+            if self.deltasdeltas:
+                cols.append(torch.cat([self.deltas_of(d1[foff[u]:foff[u + 1]]) for u in range(len(lens))]))
+            out = torch.cat(cols, dim=1)
+        return out, nfr
+
+    def normalize_table(self, table, lengths):
+        """mean_variance_normalisation / mean_var_norm_per_file (features.py:205-297) on a device table of
+        utterances laid end to end (no VAD here: normalize_features takes one).  Returns (table, stats)."""
+        if self.norm_per_file:
+            out, stats, o = torch.empty_like(table), [], 0
+            for n in lengths:
+                n = int(n)
+                mean, std = self._stats(table[o:o + n])
+                out[o:o + n] = self._apply(table[o:o + n], mean, std)
+                stats.append((mean, std))
+                o += n
+            return out, stats
+        mean, std = self._stats(table)
+        return self._apply(table, mean, std), (mean, std)
+
+    def stack_table(self, table, lengths, nframes=None):
+        """stack_fbanks of every utterance of a device table in one launch (abn_stack_frames_batched)."""
+        nframes = self.nframes if nframes is None else nframes
+        assert nframes % 2 == 1, 'number of stacked frames must be odd'
+        lib = _lib.load()
+        foff = torch.from_numpy(np.concatenate(([0], np.cumsum(np.asarray(lengths, dtype=np.int64))))).cuda()
+        T, D = table.shape
+        out = torch.empty(T, D * nframes, dtype=torch.float32, device=table.device)
+        _lib.check(lib.abn_stack_frames_batched(_lib.ptr(table.contiguous()), _lib.ptr(foff), len(lengths), T, D, nframes,
+                                                _lib.ptr(out), _lib.stream()), 'abn_stack_frames_batched')
+        return out
+
+    def features_from_waves(self, waves, srate, names=None):
+        """generate() (features.py:365-404) for in-memory audio, everything staying in HBM: filterbanks ->
+        [normalisation] -> [stacking], one launch per stage for the whole corpus.  Returns
+        (table [frames, dim], names, frame counts, {name: frame times}) -- DeviceCorpus.from_table's arguments;
+        times as h5features_compute writes them (features.py:195)."""
+        if isinstance(waves, dict):
+            names, waves = list(waves.keys()), list(waves.values())
+        names = list(names) if names is not None else ['utt%06d' % i for i in range(len(waves))]
+        table, nfr = self.fbank_batch(waves, srate)
+        if self.normalization:
+            table, _ = self.normalize_table(table, nfr)
+        if self.stack:
+            table = self.stack_table(table, nfr)
+        times = {k: np.arange(int(n), dtype=float) * 0.01 + 0.0025 for k, n in zip(names, nfr)}
+        return table, names, nfr, times
+
     def do_fbank(self, fname):
         """Compute standard filterbanks from a wav file (features.py:99-114)."""
         from scipy.io import wavfile

@@ -777,11 +777,13 @@ class SiameseNetwork(_HipNetwork):
         for p, g in zip(seg.params, grads):
             p.grad = g
 
-    def direct_backward_loss(self, state, y, loss_kind, margin, avg, defer_reduce=False):
+    def direct_backward_loss(self, state, y, loss_kind, margin, avg, defer_reduce=False, n_valid=None, loss_accum=None):
         """loss(emb1, emb2, y) and its backward in the backward's own launches (abn_tower_backward_loss:
         the data-gradient chain computes the pair loss and d loss / d z of the output layer in its first
         phase).  Returns the 0-dim loss, or None when the library does not take this tower that way
-        (BatchNorm, exact-fp32 arithmetic, odd widths): the caller then uses value_and_dz + direct_backward."""
+        (BatchNorm, exact-fp32 arithmetic, odd widths): the caller then uses value_and_dz + direct_backward.
+        n_valid (device int32 tensor): a padded batch, only the first n_valid pairs are real; loss_accum (device
+        float64 tensor): the loss is also added to it (include/abnet3_hip.h)."""
         seg, sv, grad_pass = state
         rows = sv.rows
         if (seg.batch_norm or sv.n_calls != 2 or os.environ.get('ABN_LOSS_IN_BACKWARD') == '0'      # (the variable: A/B runs)
@@ -802,7 +804,7 @@ class SiameseNetwork(_HipNetwork):
         rc = lib.abn_tower_backward_loss(
             _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(y), _lib.Y_DTYPE[y.dtype], _lib.LOSS[loss_kind],
             float(margin), int(bool(avg)), rows, _lib.ptr(sv.ws), _lib.ptr(scratch), scratch_floats, _lib.ptr(loss),
-            _lib.ptr(lws), _lib.stream())
+            _lib.ptr(lws), _lib.ptr(n_valid), _lib.ptr(loss_accum), _lib.stream())
         if rc == _lib.E_UNSUPPORTED:
             self._fused_loss_refused = (rows, self.precision)
             grad_pass.buf = None                 # nothing was written: the separate calls start this pass afresh

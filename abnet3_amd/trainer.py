@@ -471,6 +471,142 @@ class TrainerSiamese(TrainerBuilder):
         self._graphs[key] = step
         return step.warmup_loss
 
+    # -- planned passes: loaders that hand out a BatchPlan (dataloader.py) ----------------------------------
+    # The reference's canonical loader yields a different number of frame pairs every step (8 word pairs =
+    # a few hundred 280-d rows, abnet3/dataloader.py:248-255): the step is tens of microseconds of GPU work
+    # behind ~150 us of per-batch host work.  With a plan, a step is ONE gather launch (abn_gather_pairs,
+    # straight into the static buffers of a captured step, zero rows up to the bucket's size and the number
+    # of real pairs in a device word) and ONE graph replay; a bucket = the batch sizes that round up to the
+    # same multiple of BUCKET pairs.  Padded rows contribute no loss and no gradient (abn_tower_backward_loss,
+    # n_valid).  planned_passes = False switches back to the plain iterator.
+    BUCKET = 32              # pairs: a tower call is padded to whole 32-row workgroups anyway
+    MIN_BUCKET = 128         # the operand-plane kernels start at 256 rows (both towers)
+    MAX_BUCKET_GRAPHS = 96
+
+    def _planned(self, train_mode):
+        """The loader's plan of one pass, or None when this trainer / network / loader takes the iterator."""
+        dl = self.dataloader
+        if not getattr(self, 'planned_passes', True) or not hasattr(dl, 'plan'):
+            return None
+        if not self._direct_ok() or getattr(self.network, 'batch_norm', False):
+            return None                      # (BatchNorm: padded rows would enter the batch statistics)
+        if getattr(self, '_plan_refused', False):
+            return None
+        return dl.plan(train_mode)
+
+    def _bucket(self, n):
+        return max(self.MIN_BUCKET, (n + self.BUCKET - 1) // self.BUCKET * self.BUCKET)
+
+    def _bucket_state(self, npad, plan):
+        st = getattr(self, '_buckets', None)
+        if st is None:
+            st = self._buckets = {}
+            self._bucket_pool = torch.cuda.graph_pool_handle()
+            self._loss_acc = torch.zeros((), dtype=torch.float64, device=plan.table.device)
+        key = (npad, plan.table.shape[1], plan.labels.dtype)
+        b = st.get(key)
+        if b is None:
+            dev, D = plan.table.device, plan.table.shape[1]
+            b = st[key] = dict(x12=torch.zeros(2 * npad, D, dtype=torch.float32, device=dev),
+                               y=torch.zeros(npad, dtype=plan.labels.dtype, device=dev),
+                               nv=torch.zeros(1, dtype=torch.int32, device=dev), graph=None, npad=npad)
+        return b
+
+    def _bucket_body(self, b):
+        """The five statements of the reference's loop (abnet3/trainer.py:236-240) on a bucket's static buffers."""
+        net, opt, npad = self.network, self.optimizer, b['npad']
+        x12 = b['x12']
+        emb, state = net.direct_forward(x12[:npad], x12[npad:])
+        opt.zero_grad()
+        defer = self.world_size == 1 and net.can_defer_reduce(state)
+        loss_value = net.direct_backward_loss(state, b['y'], type(self.loss).__name__, getattr(self.loss, 'margin', 0.0),
+                                              self.loss.avg, defer_reduce=defer, n_valid=b['nv'], loss_accum=self._loss_acc)
+        return loss_value
+
+    def _bucket_finish(self):
+        opt = self.optimizer
+        if self.world_size > 1:
+            opt.grad_scale = parallel.all_reduce_gradients(self.network.flat_grad(), self._loss_is_mean())
+        opt.step()
+
+    def _planned_step(self, plan, bid):
+        """One training step on batch `bid` of the plan; returns False when the library refuses the padded
+        form for this network (the caller falls back to the iterator for good)."""
+        lib = _lib.load()
+        first, n = plan.span(bid)
+        if n == 0:
+            raise ValueError('need at least one array to concatenate')      # (the reference's np.vstack([]))
+        b = self._bucket_state(self._bucket(n), plan)
+        _lib.check(lib.abn_gather_pairs(_lib.ptr(plan.table), plan.table.shape[1], _lib.ptr(plan.idx1), _lib.ptr(plan.idx2),
+                                        first, n, b['npad'], _lib.ptr(plan.labels), plan.labels.element_size(),
+                                        _lib.ptr(b['x12']), _lib.ptr(b['y']), _lib.ptr(b['nv']), _lib.stream()),
+                   'abn_gather_pairs')
+        opt = self.optimizer
+        in_graph_opt = self.world_size == 1 and opt.kind != 'adam'      # (Adam's bias correction is host arithmetic per step)
+        if b['graph'] is not None:
+            g, grads, flat, pending = b['graph']
+            g.replay()
+            net = self.network
+            net.weights_changed_behind_torch()
+            for p_, g_ in zip(net.live_parameters(), grads):
+                p_.grad = g_
+            net._last_grad_flat = flat
+            if in_graph_opt:
+                opt.step_count += 1
+            else:
+                net._pending_reduce = pending
+                self._bucket_finish()
+            return True
+        # first batch of this bucket: the step itself runs eagerly (and warms everything up), then the same
+        # launch sequence is captured for the batches to come (capturing executes nothing)
+        if self._bucket_body(b) is None:
+            return False
+        self._bucket_finish()
+        if len([1 for v in self._buckets.values() if v['graph'] is not None]) >= self.MAX_BUCKET_GRAPHS:
+            return True
+        steps_before = opt.step_count
+        acc_keep = self._loss_acc.clone()
+        graph = torch.cuda.CUDAGraph()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()                          # (see make_graphed_step)
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, pool=self._bucket_pool):
+                self._bucket_body(b)
+                pending = getattr(self.network, '_pending_reduce', None)
+                if in_graph_opt:
+                    opt.step()
+        finally:
+            if gc_was_enabled:
+                gc.enable()
+        opt.step_count = steps_before
+        self._loss_acc.copy_(acc_keep)
+        net = self.network
+        b['graph'] = (graph, [p_.grad for p_ in net.live_parameters()], getattr(net, '_last_grad_flat', None), pending)
+        return True
+
+    def _run_planned(self, plan, do_training, loss_sum):
+        """The training pass over a plan; adds the batches' losses to `loss_sum` (device float64) and returns
+        the number of batches, or None when the padded form is refused (nothing has been stepped then)."""
+        if not do_training:
+            n = 0
+            for minibatch in plan:
+                loss_sum.add_(self.train_step(minibatch, False))
+                n += 1
+            return n
+        if not plan.order:
+            return 0
+        self._bucket_state(self._bucket(plan.span(plan.order[0])[1]), plan)      # (creates the accumulator)
+        self._loss_acc.zero_()
+        for k, bid in enumerate(plan.order):
+            if not self._planned_step(plan, bid):
+                if k == 0:
+                    self._plan_refused = True
+                    return None
+                raise RuntimeError('abnet3_amd: the padded step was refused in the middle of a pass')
+        loss_sum.add_(self._loss_acc)
+        return len(plan.order)
+
     @staticmethod
     def _packed_layout(B, D, y):
         nx = 2 * B * D * 4
@@ -526,21 +662,38 @@ class TrainerSiamese(TrainerBuilder):
         dev_loss = torch.zeros((), dtype=torch.float64, device=dev_)
         num_batches_train = 0
         num_batches_dev = 0
+        timed = getattr(self, 'time_passes', False)      # (measurement: one more synchronisation per pass)
+        if timed:
+            torch.cuda.synchronize()
+            t_pass = time.perf_counter()
         self.network.train()
-        for minibatch in self._batches(True):
-            # fp64 accumulator += fp32 loss in ONE launch (add_ promotes the operand)
-            if do_training:
-                train_loss.add_(self.train_step_auto(minibatch))
-            else:
-                train_loss.add_(self.train_step(minibatch, False))
-            num_batches_train += 1
+        plan = self._planned(True)
+        done = self._run_planned(plan, do_training, train_loss) if plan is not None else None
+        if done is not None:
+            num_batches_train = done
+        else:
+            it = iter(plan) if plan is not None else self._batches(True)     # (a refused plan: the same batches, as tensors)
+            for minibatch in it:
+                # fp64 accumulator += fp32 loss in ONE launch (add_ promotes the operand)
+                if do_training:
+                    train_loss.add_(self.train_step_auto(minibatch))
+                else:
+                    train_loss.add_(self.train_step(minibatch, False))
+                num_batches_train += 1
 
+        if timed:
+            torch.cuda.synchronize()
+            t_mid = time.perf_counter()
         self.network.eval()
         with torch.no_grad():
-            for minibatch in self._batches(False):
+            plan = self._planned(False)
+            for minibatch in (plan if plan is not None else self._batches(False)):
                 num_batches_dev += 1
                 dev_loss.add_(self.give_batch_to_network(minibatch))
 
+        if timed:
+            torch.cuda.synchronize()
+            self.pass_seconds = getattr(self, 'pass_seconds', []) + [(t_mid - t_pass, time.perf_counter() - t_mid)]
         sums = torch.stack([train_loss, dev_loss])
         counts = torch.tensor([num_batches_train, num_batches_dev], dtype=torch.float64,
                               device=dev_)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 13
+#define ABN_ABI_VERSION 14
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -183,12 +183,20 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
  * pair) instead of reading d_out.  Only for towers the operand-plane kernels take (default
  * arithmetic, no BatchNorm, widths <= 512 and multiples of 4): ABN_E_UNSUPPORTED otherwise, and the
  * caller uses the two separate calls.  loss_ws: abn_tower_backward_loss_ws_bytes(rows) bytes whose
- * first 8 (a ticket counter) are zero before the first call and are left zero. */
+ * first 8 (a ticket counter) are zero before the first call and are left zero.
+ * n_valid (device int32, or NULL): a PADDED batch -- only the first *n_valid pairs of the B = rows / 2
+ * are real (abn_gather_pairs writes such batches: zero rows behind the real ones, tower 2 starting at
+ * row B); the others contribute no loss term and their d loss / d z is zero, so nothing of them reaches
+ * a gradient, and avg divides by *n_valid.  One captured step then serves every batch size of a bucket
+ * (the reference's batches of 8 word pairs have a different number of frame pairs every step,
+ * abnet3/dataloader.py:248-255).  loss_accum (device double, or NULL): the call's loss is also added to
+ * it -- the epoch's running sum the reference keeps on the host (abnet3/trainer.py:242). */
 int64_t abn_tower_backward_loss_ws_bytes(int64_t rows);
 int abn_tower_backward_loss(const abn_tower_desc* t, const float* x1, const float* x2, const void* y,
                             int y_dtype, int loss_kind, float margin, int avg, int64_t rows,
                             const float* ws, float* scratch, int64_t scratch_floats,
-                            float* loss_out, void* loss_ws, void* stream);
+                            float* loss_out, void* loss_ws, const int32_t* n_valid,
+                            double* loss_accum, void* stream);
 
 /* Finishes an abn_tower_backward that ran with defer_reduce = 1 (same descriptor, rows and
  * scratch): sums the split-K slabs in their fixed order, writes the gradients to dW / db AND
@@ -328,9 +336,25 @@ int abn_softmax_rows_backward(const float* a, const float* da, int64_t rows, int
 int abn_gather_rows(const float* table, const int64_t* idx, int64_t n, int64_t D,
                     float* out, void* stream);
 
+/* One training batch of frame pairs, gathered straight into the layout a (captured) train step reads
+ * (abnet3/dataloader.py:204-205,227-233 + the vstack / permutation of :248-255, with the index lists
+ * prepared once per dataset): x12 is [2 n_pad, D] --
+ *   x12[r]         = table[idx1[first + r]]   (tower 1),   x12[n_pad + r] = table[idx2[first + r]]   (tower 2)
+ * for r < n, zero rows for n <= r < n_pad.  labels (device, `label_bytes` per element: 8 = the float64 /
+ * int64 labels of the loaders; may be NULL together with y_out): y_out[r] = labels[first + r], zero
+ * padding.  n_valid (device int32, may be NULL) receives n: abn_tower_backward_loss's n_valid. */
+int abn_gather_pairs(const float* table, int64_t D, const int64_t* idx1, const int64_t* idx2,
+                     int64_t first, int64_t n, int64_t n_pad, const void* labels,
+                     int32_t label_bytes, float* x12, void* y_out, int32_t* n_valid, void* stream);
+
 /* FeaturesGenerator.stack_fbanks, abnet3/features.py:135-159 */
 int abn_stack_frames(const float* feats, int64_t T, int64_t D, int32_t nframes,
                      float* out, void* stream);
+/* ... for a batch of utterances laid end to end in one [T, D] table (what the reference's
+ * h5features_feats2stackedfeats loop does file by file, features.py:299-320): utt_frame_off =
+ * cumulative frame counts, device int64 [n_utts + 1]; the window never crosses an utterance boundary. */
+int abn_stack_frames_batched(const float* feats, const int64_t* utt_frame_off, int64_t n_utts,
+                             int64_t T, int64_t D, int32_t nframes, float* out, void* stream);
 
 /* FeaturesGenerator.mean_variance_normalisation / mean_var_norm_per_file,
  * abnet3/features.py:205-244, :263-297: mean = np.mean, std = np.std over axis 0
@@ -345,7 +369,9 @@ int abn_mvn_apply(const float* feats, int64_t T, int64_t D, const float* mean,
 
 /* FeaturesGenerator.do_fbank, abnet3/features.py:99-114 (-> third-party
  * spectral.Spectral): int16 or fp32 mono samples -> [nframes, nfilt] log mel
- * energies.  melbank: [nfft/2+1, nfilt] fp32 weights (host side builds it,
+ * energies (framing of that package's Sphinx-III lineage: a frame's pre-emphasis starts from the
+ * last sample of the previous frame, a tail frame repeats its samples cyclically;
+ * oracle/features_np.py).  melbank: [nfft/2+1, nfilt] fp32 weights (host side builds it,
  * abnet3_amd/features.py), window: [wlen] fp32.  band: [nfilt][2] int32 (device), first and
  * last bin with a non-zero weight of every filter; with it (and nfft = 1024, the
  * reference's value, nfilt <= 64) a frame is one wavefront's real-input FFT and a sparse mel
@@ -354,6 +380,17 @@ int abn_fbank(const void* samples, int sample_is_i16, int64_t nsamples,
               int32_t wlen, double fshift, int32_t nfft, int32_t nfilt,
               float alpha, const float* window, const float* melbank, const int32_t* band,
               int64_t nframes, float* out, void* stream);
+
+/* ... for a batch of utterances in ONE launch (the reference's h5features_compute loop calls do_fbank
+ * file by file, features.py:160-203): the utterances' samples laid end to end in `samples`,
+ * utt_sample_off / utt_frame_off = cumulative sample / frame counts (device int64 [n_utts + 1],
+ * frames of utterance u = int(len_u / fshift + 1)); out [nframes = utt_frame_off[n_utts], nfilt].
+ * Every utterance is framed on its own, as if abn_fbank had been called on it alone. */
+int abn_fbank_batched(const void* samples, int sample_is_i16, const int64_t* utt_sample_off,
+                      const int64_t* utt_frame_off, int64_t n_utts, int32_t wlen, double fshift,
+                      int32_t nfft, int32_t nfilt, float alpha, const float* window,
+                      const float* melbank, const int32_t* band, int64_t nframes, float* out,
+                      void* stream);
 
 /* do_deltas / do_deltasdeltas of the same call (abnet3/features.py:110-111 -> spectral):
  * the slope over +-4 frames, out[t] = sum_{n=1..4} n (x[t+n] - x[t-n]) / 60, the sequence

@@ -14,10 +14,17 @@ algorithm of that package's lineage (the CMU Sphinx-III `mfcc.py` front end its
 parameter names come from) and IS the definition the HIP kernel is tested
 against:
   frames:   nfr = int(len(sig)/fshift + 1), fshift = fs/frate, frame t starts
-            at round(t*fshift), wlen = int(0.025*fs) samples, zero-padded tail
-  pre-emph: y[i] = x[i] - alpha*x[i-1] over the zero-padded frame; the history
-            of its first sample is the previous sample of the signal (0 before
-            the first one), and the first padded sample still sees -alpha*last
+            at round(t*fshift), wlen = int(0.025*fs) samples.  A frame cut
+            short by the end of the signal is np.resize()d to wlen -- its
+            samples repeated CYCLICALLY (the lineage's `frame[wlen:] = 0` that
+            follows is a no-op); an empty last frame is zeros
+  pre-emph: y[0] = x[0] - alpha*prior, y[i] = x[i] - alpha*x[i-1] inside the
+            frame, where prior = the LAST sample of the previous (overlapping,
+            resized) frame, 0 for the first frame -- the lineage keeps
+            `self.prior = frame[-1]` between frames; do_fbank builds a new
+            Spectral per file (abnet3/features.py:101-113), so it starts at 0.
+            (Rounds 1-2 of this build zero-padded the tail and took x[start-1]
+            as the history: one sample per frame / the last two frames differ.)
   window:   numpy.hamming(wlen) (symmetric)
   power:    |rfft(frame, nfft)|^2, nfft=1024 -> 513 bins
   mel bank: 40 triangular filters between lowerf=133.3333 Hz and
@@ -89,6 +96,15 @@ def frame_count(nsamples, fs, frate=100):
     return int(nsamples / (float(fs) / frate) + 1)
 
 
+def frame_samples(sig, t, fshift, wl):
+    """Frame t of the signal, wl samples (see the module docstring: cyclic np.resize of a short tail)."""
+    start = int(round(t * fshift))
+    frame = sig[start:min(len(sig), start + wl)]
+    if len(frame) < wl:
+        frame = np.resize(frame, wl)
+    return frame
+
+
 def fbank(sig, fs, nfilt=40, alpha=0.97, frate=100, wlen=0.025, nfft=1024,
           dtype=np.float64):
     """Log mel filterbank energies, float32 [nfr, nfilt] (do_fbank's result).
@@ -102,12 +118,11 @@ def fbank(sig, fs, nfilt=40, alpha=0.97, frate=100, wlen=0.025, nfft=1024,
     filt = mel_filterbank(fs, nfft, nfilt)
     nfr = frame_count(len(sig), fs, frate)
     out = np.zeros((nfr, nfilt), dtype=np.float32)
-    # the signal extended by zeros on both sides: x~[-1] = 0, x~[len...] = 0
-    ext = np.concatenate(([0.0], sig, np.zeros(wl + 1)))
+    prior = 0.0
     for t in range(nfr):
-        start = int(round(t * fshift))
-        frame = ext[start + 1:start + 1 + wl]
-        prev = ext[start:start + wl]
+        frame = frame_samples(sig, t, fshift, wl)
+        prev = np.concatenate(([prior], frame[:-1]))
+        prior = frame[-1]
         pre = ((frame - alpha * prev) * win).astype(dtype)
         spec = np.fft.rfft(pre.astype(np.float64), nfft)
         power = (spec.real * spec.real + spec.imag * spec.imag).astype(dtype)
