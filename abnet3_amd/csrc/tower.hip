@@ -18,6 +18,7 @@
 #include "opt_rule.h"
 #include "tower_fused.h"
 #include "tower_planes.h"
+#include "tower_wide.h"
 
 namespace abn {
 
@@ -43,6 +44,8 @@ static Switches read_switches()
     s.bf16x3_planes = !off("ABN_BF16X3_PLANES");
     s.bwd_pair = !off("ABN_BWD_PAIR");
     s.gemm_tile = getenv("ABN_GEMM_TILE") ? atoi(getenv("ABN_GEMM_TILE")) : -1;
+    s.wide = !off("ABN_WIDE");
+    s.wide_max_rows = getenv("ABN_WIDE_MAX_ROWS") ? atoll(getenv("ABN_WIDE_MAX_ROWS")) : -1;
     s.dtw_f40 = !off("ABN_DTW_F40");
     s.dtw_pc = !off("ABN_DTW_PC");
     return s;
@@ -683,9 +686,10 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t r = o; o += align_up(n, 64); return r; };
     L.x = take(rows * t->dims[0]);
+    const int64_t vrows = bn_vrows(rows, n_calls);       // every call padded to whole 32-row workgroups (tower_wide.h, BatchNorm launches)
     for (int l = 0; l < t->n_layers; ++l) {
         const int64_t w = t->dims[l + 1];
-        L.a[l] = take(rows * w);
+        L.a[l] = take(vrows * w);
         if (t->batch_norm) {
             L.xhat[l] = take(rows * w);
             L.mean[l] = take(n_calls * w);
@@ -709,7 +713,7 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
         const int np = planes_of(t->precision);
         L.wpack = take(make_pack_layout(t).bytes / 4);
         if (!t->forward_only)                                      // (last in the workspace: an inference call simply asks for less)
-            for (int l = 0; l < t->n_layers; ++l) L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, t->batch_norm ? bn_vrows(rows, n_calls) : rows, np) / 4);
+            for (int l = 0; l < t->n_layers; ++l) L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, vrows, np) / 4);
     }
     L.total = o;
     return L;
@@ -718,21 +722,46 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
 // Whether the planes kernels (tower_planes.h) take a call.  Forward and backward must agree (the forward then
 // leaves the hidden activations in the transposed images only): both ask here.
 enum { PLANES_TRAIN = 0, PLANES_EVAL_FORWARD = 1 };      // a forward in train mode or any backward | a forward with train == 0
-static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws,
-                        int mode = PLANES_TRAIN)
+enum { PLANES_NONE = 0, PLANES_CHAIN = 1, PLANES_WIDE = 2 };
+
+// Workgroups per 32-row block of the layer-per-launch kernels (tower_wide.h) for a batch of `vrows` virtual
+// rows: as many as keep the grid within one wave of workgroups over the 256 CUs; 0 = too many rows, the
+// single-launch chains take the batch (from ~80 row blocks on every CU has a chain workgroup anyway).
+static int wide_groups(int64_t vrows)
 {
-    if (!switches().planes || !switches().fused) return false;
+    const int64_t cap = switches().wide_max_rows >= 0 ? switches().wide_max_rows : 2560;
+    if (!switches().wide || vrows > cap || vrows < PL_ROWS) return 0;
+    const int64_t nrb = vrows / PL_ROWS;
+    const int64_t G = 256 / nrb;
+    return (int)(G < 1 ? 1 : (G > WD_MAXG ? WD_MAXG : G));
+}
+
+static int planes_kind(const abn_tower_desc* t, int64_t rows, int64_t n_calls, const float* x1, const float* x2, const float* ws,
+                       int mode = PLANES_TRAIN, bool allow_wide = true)
+{
+    if (!switches().planes || !switches().fused) return PLANES_NONE;
+    // BatchNorm: only the inference forward (running statistics), and only when no backward will follow
+    if (!(mode == PLANES_EVAL_FORWARD && t->forward_only ? planes_dims_ok(t) : planes_shape_ok(t))) return PLANES_NONE;
+    if (!aligned16(x1) || (x2 && !aligned16(x2)) || !aligned16(ws)) return PLANES_NONE;
+    bool any_mask = false;
+    for (int l = 0; l < t->n_layers; ++l) {
+        if (!aligned16(t->W[l]) || !aligned16(t->b[l]) || (t->drop_mask[l] && !aligned16(t->drop_mask[l]))) return PLANES_NONE;
+        any_mask = any_mask || t->drop_mask[l] != nullptr;
+    }
+    // small batches: one launch per layer, the output blocks dealt over several workgroups per 32 rows
+    // (dropout there comes from the per-forward seed only; mask tensors stay with the chains)
+    if (allow_wide && !t->batch_norm && !any_mask && n_calls >= 1 && rows % n_calls == 0 && wide_groups(bn_vrows(rows, n_calls)) > 0) return PLANES_WIDE;
     // a workgroup walks its 32 rows through every layer in ~50 us whatever the batch; from a few workgroups
     // up that beats the per-layer GEMMs (tools/rows_sweep.py, tools/fwd_rows_sweep.py: C2 train step 0.148 vs
     // 0.180 ms at 512 rows, 0.234 vs 0.331 at 8192; forward alone 62 vs 94 us at 5000 rows)
     const int64_t min_rows = switches().fused_min_rows >= 0 ? switches().fused_min_rows : 256;
-    if (rows < min_rows || rows > (1LL << 20)) return false;                                // (32-bit byte offsets inside one image)
-    // BatchNorm: only the inference forward (running statistics), and only when no backward will follow
-    if (!(mode == PLANES_EVAL_FORWARD && t->forward_only ? planes_dims_ok(t) : planes_shape_ok(t))) return false;
-    if (!aligned16(x1) || (x2 && !aligned16(x2)) || !aligned16(ws)) return false;
-    for (int l = 0; l < t->n_layers; ++l)
-        if (!aligned16(t->W[l]) || !aligned16(t->b[l]) || (t->drop_mask[l] && !aligned16(t->drop_mask[l]))) return false;
-    return true;
+    if (rows < min_rows || rows > (1LL << 20)) return PLANES_NONE;                          // (32-bit byte offsets inside one image)
+    return PLANES_CHAIN;
+}
+static bool planes_path(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws,
+                        int mode = PLANES_TRAIN, int64_t n_calls = 1)
+{
+    return planes_kind(t, rows, n_calls, x1, x2, ws, mode) != PLANES_NONE;
 }
 
 // The training forward and the backward of a BatchNorm tower, one operand-plane launch per layer
@@ -746,7 +775,7 @@ static bool bn_train_planes_path(const abn_tower_desc* t, int64_t rows, int64_t 
     (void)n_calls;                                  // (any split of the rows into calls: workgroups are cut per call)
     abn_tower_desc u = *t;
     u.batch_norm = 0;
-    return planes_path(&u, rows, x1, x2, ws);
+    return planes_kind(&u, rows, 1, x1, x2, ws, PLANES_TRAIN, false) != PLANES_NONE;
 }
 
 static int check_desc(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
@@ -797,7 +826,10 @@ static int planes_split_count(int64_t rows, int64_t out_dim, int64_t in_dim)
     // twice as fine: at C2 every CU then gets one heavy workgroup (32 row steps) and one light one (8) -- with
     // 16-step light ones half the CUs idled through the launch's tail
     int64_t s = (128 + tiles - 1) / tiles;
-    const int64_t by_rows = rows / 128 < 1 ? 1 : rows / 128;
+    // (rows rounded up to 64: a Siamese batch of n pairs and the same batch padded to ceil32(n) pairs -- the
+    // captured steps of the trainer's planned passes -- get the same slices, hence bit-identical gradients)
+    const int64_t r64 = (rows + 63) / 64 * 64;
+    const int64_t by_rows = r64 / 128 < 1 ? 1 : r64 / 128;
     const int64_t cap = shape == 0 ? MAX_SPLITS : 2 * MAX_SPLITS;
     if (s > by_rows) s = by_rows;
     if (s > cap) s = cap;
@@ -824,8 +856,8 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
     int64_t maxw = 0, o = 0, packed = 0;
     for (int l = 0; l <= t->n_layers; ++l) maxw = t->dims[l] > maxw ? t->dims[l] : maxw;
     auto take = [&](int64_t n) { int64_t r = o; o += align_up(n, 64); return r; };
-    B.dz[0] = take(rows * maxw);
-    B.dz[1] = take(rows * maxw);
+    B.dz[0] = take((rows + 8 * PL_ROWS) * maxw);         // (virtual rows: up to 8 calls, each padded to 32 rows)
+    B.dz[1] = take((rows + 8 * PL_ROWS) * maxw);
     B.bn_s1 = take(8 * maxw);
     B.bn_s2 = take(8 * maxw);
     B.bn_part = take(2 * 8 * BN_MAX_CHUNKS * 2 * maxw);
@@ -843,7 +875,7 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
     }
     B.slabs = take(B.slab_stride * smax);
     for (int l = 0; l < t->n_layers; ++l)
-        B.dzp[l] = planes_dims_ok(t) ? take(pl_timage_bytes(t->dims[l + 1], t->batch_norm ? rows + 8 * PL_ROWS : rows, planes_of(t->precision)) / 4) : -1;
+        B.dzp[l] = planes_dims_ok(t) ? take(pl_timage_bytes(t->dims[l + 1], rows + 8 * PL_ROWS, planes_of(t->precision)) / 4) : -1;
     B.bn_wg = planes_dims_ok(t) && t->batch_norm ? take((rows / PL_ROWS + 9) * 2 * PL_MAXW) : -1;     // (up to 8 calls, each padded)
     B.total = o;
     return B;
@@ -1079,6 +1111,89 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
     return ABN_OK;
 }
 
+// Backward of a forward that went through the layer-per-launch kernels (same predicate): per layer, top down,
+// one wide_dgrad_layer_kernel (the top one forms dZ_top -- from d_out or from the pair loss); then every
+// layer's weight gradient in the shared launch and the slab reduction.
+static int wide_backward(const abn_tower_desc* t, const float* d_out, const LossArgs* loss, int64_t rows, int64_t n_calls,
+                         const Layout& L, const BwdLayout& B, const float* ws, float* scratch, float* dx, hipStream_t st)
+{
+    const int nl = t->n_layers, top = nl - 1;
+    const int np = planes_of(t->precision);
+    ABN_REQUIRE((loss || aligned16(d_out)) && aligned16(scratch) && (!dx || aligned16(dx)),
+                "tower_backward: d_out / scratch / dx must be 16-byte aligned");
+    ABN_REQUIRE(!loss || n_calls == 2, "tower_backward_loss: two forward_once calls");
+    const PackLayout PL = make_pack_layout(t);
+    const char* const image = t->wpack ? reinterpret_cast<const char*>(t->wpack) : reinterpret_cast<const char*>(ws + L.wpack);
+    static bool attr_set[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = (dev >= 0 && dev < 16) ? dev : 0;
+    if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_dgrad_layer_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wd_lds_bytes(1));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_dgrad_layer_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wd_lds_bytes(3));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<1>());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<3>());
+        attr_set[dev] = true;
+    }
+    const int64_t rpc = rows / n_calls;
+    const int64_t wpc = bn_wgs_per_call(rows, n_calls), nrb = n_calls * wpc;
+    const int G = wide_groups(nrb * PL_ROWS);
+    ABN_REQUIRE(G > 0, "tower_backward: too many rows for the layer-per-launch kernels");
+    const int last = dx ? 0 : 1;                      // the lowest layer a data-gradient launch runs for
+    int cur = 0;
+    for (int l = top; l >= last || l == top; --l) {
+        WideBwdP q = {};
+        q.l = l; q.top = top;
+        q.N = (int)t->dims[l + 1]; q.K = (int)t->dims[l];
+        q.act_prev = t->act;
+        q.rows_call = (int)rpc; q.n_calls = (int)n_calls; q.wpc = (int)wpc;
+        const int nblk = pl_blocks(q.K);
+        q.G = G < nblk ? G : nblk;
+        q.dz_in = l < top ? scratch + B.dz[cur] : nullptr;
+        q.wpt = (l >= 1 || dx) ? image + PL.wpt[l] : nullptr;
+        q.a_prev = l >= 1 ? ws + L.a[l - 1] : nullptr;
+        q.dz_out = (l >= 1 && l - 1 >= last) ? scratch + B.dz[cur ^ 1] : nullptr;
+        q.dzp_top = reinterpret_cast<char*>(scratch + B.dzp[top]);
+        q.dzp_out = l >= 1 ? reinterpret_cast<char*>(scratch + B.dzp[l - 1]) : nullptr;
+        q.tp_steps = 2 * nrb;
+        q.dx = dx;
+        q.drop_seed = reinterpret_cast<const unsigned long long*>(t->drop_seed);
+        q.drop_p = t->drop_p;
+        if (l == top) {
+            q.d_out = loss ? nullptr : d_out;
+            q.d_out_is_dz = t->d_out_is_dz;
+            q.a_top = ws + L.a[top];
+            q.act_top = t->last_act;
+            if (loss) {
+                q.loss_kind = loss->kind; q.y_dtype = loss->y_dtype; q.y = loss->y;
+                q.margin = (double)loss->margin;
+                q.scale = loss->avg ? 1.0 / (double)rpc : 1.0;
+                q.loss_counter = reinterpret_cast<unsigned*>(loss->ws);
+                q.loss_partial = reinterpret_cast<double*>(reinterpret_cast<char*>(loss->ws) + 8);
+                q.loss_out = loss->loss_out;
+                q.n_valid = loss->n_valid;
+                q.loss_accum = loss->loss_accum;
+            }
+        }
+        const dim3 grid((unsigned)(nrb * q.G));
+        if (np == 3) hipLaunchKernelGGL(wide_dgrad_layer_kernel<3>, grid, dim3(PL_NT), wd_lds_bytes(3), st, q);
+        else hipLaunchKernelGGL(wide_dgrad_layer_kernel<1>, grid, dim3(PL_NT), wd_lds_bytes(1), st, q);
+        if (l < top || q.dz_out) cur ^= (q.dz_out ? 1 : 0);
+        if (l == 0) break;
+    }
+    int n_wg = 0;
+    WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
+    w.tp_steps = 2 * nrb;
+    if (np == 3) hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
+    else hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
+    ABN_CHECK_LAUNCH("tower_backward (layer per launch)");
+    if (t->defer_reduce) return ABN_OK;               // abn_tower_reduce_step finishes the job
+    const ReduceTable rt = make_reduce_table(t, B);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, scratch + B.slabs, rt);
+    ABN_CHECK_LAUNCH("slab_reduce");
+    return ABN_OK;
+}
+
 }  // namespace abn
 
 using namespace abn;
@@ -1102,7 +1217,8 @@ int64_t abn_tower_out_offset(const abn_tower_desc* t, int64_t rows, int64_t n_ca
 
 // Diagnostics / tests only (not in the header): float offset of one of the operand-fragment images
 // -- which = 0 packed W_l, 1 packed W_l^T, 2 transposed planes [input of layer l | 1] (all in the
-// forward workspace), 3 transposed planes of dZ_l (in the backward scratch), 4 a BatchNorm layer's z_l -- or -1.
+// forward workspace), 3 transposed planes of dZ_l (in the backward scratch), 4 a BatchNorm layer's z_l, 5 the
+// row-major output of layer l -- or -1.
 int64_t abn_debug_planes_offset(const abn_tower_desc* t, int64_t rows, int64_t n_calls, int which, int l)
 {
     if (check_desc(t, rows, n_calls) != ABN_OK || l < 0 || l >= t->n_layers) return -1;
@@ -1110,6 +1226,7 @@ int64_t abn_debug_planes_offset(const abn_tower_desc* t, int64_t rows, int64_t n
     const Layout L = make_layout(t, rows, n_calls);
     if (which == 2) return L.tp[l];
     if (which == 4) return L.xhat[l];            // BatchNorm: z_l (bn_fwd_layer_kernel) / xhat_l (per-layer kernels)
+    if (which == 5) return L.a[l];               // row-major output of layer l (layer-per-launch kernels: virtual rows; per-layer GEMMs)
     if (which != 0 && which != 1) return -1;
     const PackLayout P = make_pack_layout(t);
     // relative to abn_tower_desc.wpack when the caller keeps one, else to the workspace
@@ -1118,7 +1235,7 @@ int64_t abn_debug_planes_offset(const abn_tower_desc* t, int64_t rows, int64_t n
 
 // Diagnostics / tests only (not in the header): which kernels the last abn_tower_forward
 // launched (process-wide: autograd runs backwards on its own thread) -- 0 per-layer, 1 the fp32 fused tower, 2 / 3 / 4 the operand-plane tower: for a backward,
-// inference, inference with BatchNorm.
+// inference, inference with BatchNorm; 5 BatchNorm's one launch per layer; 6 the layer-per-launch kernels of tower_wide.h.
 static std::atomic<int> last_forward_path{-1};
 int abn_debug_last_forward_path(void) { return last_forward_path; }
 // ... and its last abn_tower_backward: 0 per-layer, 2 the operand-plane chain + weight-gradient launches, 5 BatchNorm's
@@ -1176,11 +1293,12 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         fusable = aligned16(t->W[l]) && (!t->drop_mask[l] || !train || aligned16(t->drop_mask[l]));
     const int pmode = train ? PLANES_TRAIN : PLANES_EVAL_FORWARD;
     const bool bn_train = train && bn_train_planes_path(t, rows, n_calls, x1, x2, ws);
-    if (t->drop_seed && train && !bn_train && !planes_path(t, rows, x1, x2, ws, pmode)) {
+    const int kind = planes_kind(t, rows, n_calls, x1, x2, ws, pmode);
+    if (t->drop_seed && train && !bn_train && kind == PLANES_NONE) {
         for (int l = 0; l < t->n_layers; ++l)
             if (!t->drop_mask[l]) { set_error("tower_forward: in-kernel dropout (drop_seed) needs the operand-plane kernels: pass drop_mask tensors"); return ABN_E_UNSUPPORTED; }
     }
-    if (bn_train || planes_path(t, rows, x1, x2, ws, pmode)) {
+    if (bn_train || kind != PLANES_NONE) {
         const int np = planes_of(t->precision);
         PackTable pk = {};
         PlanesFwdP f = {};
@@ -1232,6 +1350,43 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         if (repack) {
             if (np == 3) hipLaunchKernelGGL(pack_planes_kernel<3>, pgrid, dim3(256), 0, st, pk);
             else hipLaunchKernelGGL(pack_planes_kernel<1>, pgrid, dim3(256), 0, st, pk);
+        }
+        if (!bn_train && kind == PLANES_WIDE) {
+            static bool wd_attr_set[16] = {};
+            if (!wd_attr_set[dev]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_fwd_layer_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wd_lds_bytes(1));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_fwd_layer_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wd_lds_bytes(3));
+                wd_attr_set[dev] = true;
+            }
+            const int nl = t->n_layers;
+            const int64_t wpc = bn_wgs_per_call(rows, n_calls), nrb = n_calls * wpc;
+            const int G = wide_groups(nrb * PL_ROWS);
+            const bool keep = !t->forward_only;              // transposed images for a backward
+            for (int l = 0; l < nl; ++l) {
+                WideFwdP q = {};
+                q.l = l; q.last = l == nl - 1;
+                q.K = (int)t->dims[l]; q.N = (int)t->dims[l + 1];
+                q.act = f.act[l];
+                q.rows_call = (int)rpc; q.n_calls = (int)n_calls; q.wpc = (int)wpc;
+                const int nblk = pl_blocks(q.N);
+                q.G = G < nblk ? G : nblk;
+                q.x1 = x1; q.x2 = x2;
+                q.a_prev = l >= 1 ? ws + L.a[l - 1] : nullptr;
+                q.wp = f.wp[l];
+                q.b = t->b[l];
+                q.a_out = q.last ? nullptr : ws + L.a[l];
+                q.out = q.last ? ws + L.a[l] : nullptr;
+                q.tp_in = keep && l == 0 ? reinterpret_cast<char*>(ws + L.tp[0]) : nullptr;
+                q.tp_out = keep && !q.last ? reinterpret_cast<char*>(ws + L.tp[l + 1]) : nullptr;
+                q.tp_steps = 2 * nrb;
+                q.drop_seed = f.drop_seed; q.drop_p = f.drop_p;
+                const dim3 wgrid((unsigned)(nrb * q.G));
+                if (np == 3) hipLaunchKernelGGL(wide_fwd_layer_kernel<3>, wgrid, dim3(PL_NT), wd_lds_bytes(3), st, q);
+                else hipLaunchKernelGGL(wide_fwd_layer_kernel<1>, wgrid, dim3(PL_NT), wd_lds_bytes(1), st, q);
+            }
+            ABN_CHECK_LAUNCH("tower_forward (layer per launch)");
+            last_forward_path = 6;
+            return ABN_OK;
         }
         if (bn_train) {
             static bool bn_attr_set[16] = {};
@@ -1413,7 +1568,11 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     // The forward that filled `ws` went through the planes kernels (same predicate): its workspace
     // holds W^T and the weight-gradient operands as operand fragments.  Two launches: the data
     // gradient chain (one workgroup per 32 rows, all layers), then every layer's weight gradient.
-    if (planes_path(t, rows, x1, x2, ws)) { last_backward_path = 2; return planes_backward(t, d_out, nullptr, rows, L, B, ws, scratch, dx, st); }
+    {
+        const int kind = planes_kind(t, rows, n_calls, x1, x2, ws);
+        if (kind == PLANES_WIDE) { last_backward_path = 6; return wide_backward(t, d_out, nullptr, rows, n_calls, L, B, ws, scratch, dx, st); }
+        if (kind == PLANES_CHAIN) { last_backward_path = 2; return planes_backward(t, d_out, nullptr, rows, L, B, ws, scratch, dx, st); }
+    }
     if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) { last_backward_path = 5; return bn_planes_backward(t, d_out, rows, n_calls, L, B, ws, scratch, dx, st); }
     last_backward_path = 0;
 
@@ -1523,7 +1682,7 @@ int abn_debug_tower_backward_part(const abn_tower_desc* t, const float* x1, cons
     int rc = check_desc(t, rows, n_calls);
     if (rc != ABN_OK) return rc;
     ABN_REQUIRE(x1 && d_out && ws && scratch && (part == PLANES_BWD_DGRAD || part == PLANES_BWD_WGRAD), "tower_backward_part: bad argument");
-    if (rows == 0 || !planes_path(t, rows, x1, x2, ws)) { set_error("tower_backward_part: operand-plane towers only"); return ABN_E_UNSUPPORTED; }
+    if (rows == 0 || planes_kind(t, rows, n_calls, x1, x2, ws) != PLANES_CHAIN) { set_error("tower_backward_part: single-launch operand-plane towers only"); return ABN_E_UNSUPPORTED; }
     const Layout L = make_layout(t, rows, n_calls);
     const BwdLayout B = make_bwd_layout(t, rows);
     if (scratch_floats < B.total) { set_error("tower_backward_part: scratch too small"); return ABN_E_WORKSPACE; }
@@ -1548,7 +1707,8 @@ int abn_tower_backward_loss(const abn_tower_desc* t, const float* x1, const floa
     ABN_REQUIRE(y_dtype >= ABN_Y_I8 && y_dtype <= ABN_Y_F64, "tower_backward_loss: unknown label dtype %d", y_dtype);
     ABN_REQUIRE(loss_kind != ABN_LOSS_COSMARGIN || (margin >= 0.0f && margin <= 1.0f), "tower_backward_loss: margin outside [0,1]");
     for (int l = 0; l < t->n_layers; ++l) ABN_REQUIRE(t->dW[l] && t->db[l], "tower_backward_loss: layer %d has null gradient buffers", l);
-    if (rows == 0 || !planes_path(t, rows, x1, x2, ws)) {
+    const int kind = rows == 0 ? PLANES_NONE : planes_kind(t, rows, 2, x1, x2, ws);
+    if (kind == PLANES_NONE) {
         set_error("tower_backward_loss: only for towers the operand-plane kernels take (bf16x3 / bf16, no BatchNorm, "
                   "widths <= 512 and multiples of 4, enough rows): use abn_pair_loss_dz + abn_tower_backward");
         return ABN_E_UNSUPPORTED;
@@ -1557,6 +1717,7 @@ int abn_tower_backward_loss(const abn_tower_desc* t, const float* x1, const floa
     const BwdLayout B = make_bwd_layout(t, rows);
     if (scratch_floats < B.total) { set_error("tower_backward_loss: scratch too small"); return ABN_E_WORKSPACE; }
     LossArgs la = {y, y_dtype, loss_kind, avg, margin, loss_out, loss_ws, n_valid, loss_accum};
+    if (kind == PLANES_WIDE) return wide_backward(t, nullptr, &la, rows, 2, L, B, ws, scratch, nullptr, (hipStream_t)stream);
     return planes_backward(t, nullptr, &la, rows, L, B, ws, scratch, nullptr, (hipStream_t)stream);
 }
 

@@ -384,10 +384,10 @@ def test_end_to_end_pipeline_trains(tmp_path, monkeypatch):
     e2e = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(e2e)
     monkeypatch.setattr(sys, 'argv', ['end_to_end.py', '--utts', '12', '--words', '6', '--pairs', '120',
-                                      '--epochs', '4', '--hidden', '128', '--batch', '1024',
+                                      '--epochs', '8', '--hidden', '128', '--batch', '256',
                                       '--out', str(tmp_path / 'e2e')])
     trainer, emb = e2e.main()
-    assert len(trainer.train_losses) == 5 and np.isfinite(trainer.train_losses).all()
+    assert len(trainer.train_losses) == 9 and np.isfinite(trainer.train_losses).all()
     assert trainer.train_losses[-1] < trainer.train_losses[0]
     assert emb[0].shape[1] == 100 and np.isfinite(emb[0]).all()
 

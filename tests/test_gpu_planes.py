@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 def planes_forced(monkeypatch):
     monkeypatch.setenv('ABN_FUSED_MIN_ROWS', '0')
     monkeypatch.setenv('ABN_PLANES', '1')
+    monkeypatch.setenv('ABN_WIDE', '0')          # (small batches would take the layer-per-launch kernels: tests/test_gpu_wide.py)
 
 
 def dev(a):
