@@ -44,6 +44,7 @@ static Switches read_switches()
     s.bf16x3_planes = !off("ABN_BF16X3_PLANES");
     s.bwd_pair = !off("ABN_BWD_PAIR");
     s.gemm_tile = getenv("ABN_GEMM_TILE") ? atoi(getenv("ABN_GEMM_TILE")) : -1;
+    s.wgrad_rows_per_slab = getenv("ABN_WGRAD_ROWS_PER_SLAB") ? atoll(getenv("ABN_WGRAD_ROWS_PER_SLAB")) : -1;
     s.wide = !off("ABN_WIDE");
     s.wide_max_rows = getenv("ABN_WIDE_MAX_ROWS") ? atoll(getenv("ABN_WIDE_MAX_ROWS")) : -1;
     s.dtw_f40 = !off("ABN_DTW_F40");
@@ -829,7 +830,8 @@ static int planes_split_count(int64_t rows, int64_t out_dim, int64_t in_dim)
     // (rows rounded up to 64: a Siamese batch of n pairs and the same batch padded to ceil32(n) pairs -- the
     // captured steps of the trainer's planned passes -- get the same slices, hence bit-identical gradients)
     const int64_t r64 = (rows + 63) / 64 * 64;
-    const int64_t by_rows = r64 / 128 < 1 ? 1 : r64 / 128;
+    const int64_t per = switches().wgrad_rows_per_slab > 0 ? switches().wgrad_rows_per_slab : 128;
+    const int64_t by_rows = r64 / per < 1 ? 1 : r64 / per;
     const int64_t cap = shape == 0 ? MAX_SPLITS : 2 * MAX_SPLITS;
     if (s > by_rows) s = by_rows;
     if (s > cap) s = cap;
@@ -1380,6 +1382,9 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 q.tp_out = keep && !q.last ? reinterpret_cast<char*>(ws + L.tp[l + 1]) : nullptr;
                 q.tp_steps = 2 * nrb;
                 q.drop_seed = f.drop_seed; q.drop_p = f.drop_p;
+#ifdef ABN_STAMPS
+                q.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
+#endif
                 const dim3 wgrid((unsigned)(nrb * q.G));
                 if (np == 3) hipLaunchKernelGGL(wide_fwd_layer_kernel<3>, wgrid, dim3(PL_NT), wd_lds_bytes(3), st, q);
                 else hipLaunchKernelGGL(wide_fwd_layer_kernel<1>, wgrid, dim3(PL_NT), wd_lds_bytes(1), st, q);

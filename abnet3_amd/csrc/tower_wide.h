@@ -53,27 +53,95 @@ struct WideShare {
 };
 
 // 32 rows of a row-major fp32 matrix (row pointer per lane, null = a zero row) -> operand fragments in img for
-// pl_steps(K) steps.  emit(kb, f): called by the wave that built block kb's two fragments.
+// pl_steps(K) steps.  emit(kb, f): called by the wave that built block kb's two fragments.  A wave's loads (up to
+// two 32-feature blocks: K <= 512) are all issued before the first conversion: one round trip, not one per block.
 template <int NP, class Emit>
 __device__ __forceinline__ void wide_stage_rows(const float* __restrict__ src, int K, char* __restrict__ img, int wave, int lane, Emit&& emit)
 {
     const int h = lane >> 5;
     const int blocks = pl_steps(K) / 2;
-    for (int kb = wave; kb < blocks; kb += PL_WAVES) {
-        Frag<NP> f[2];
+    f32x4 v[2][2][2];                                   // [block of this wave][step of the block][half]
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int kb = wave + PL_WAVES * u;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
-            const int s = 2 * kb + t2;
-            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-            const int c0 = 16 * s + 4 * h, c1 = c0 + 8;
-            if (src && c0 < K) v0 = *reinterpret_cast<const f32x4*>(src + c0);
-            if (src && c1 < K) v1 = *reinterpret_cast<const f32x4*>(src + c1);
-            f[t2] = make_frag<NP>(v0, v1);
-            store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
+            const int c0 = 16 * (2 * kb + t2) + 4 * h, c1 = c0 + 8;
+            v[u][t2][0] = v[u][t2][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (src && kb < blocks && c0 < K) v[u][t2][0] = *reinterpret_cast<const f32x4*>(src + c0);
+            if (src && kb < blocks && c1 < K) v[u][t2][1] = *reinterpret_cast<const f32x4*>(src + c1);
         }
-        emit(kb, f);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int kb = wave + PL_WAVES * u;
+        if (kb < blocks) {
+            Frag<NP> f[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                f[t2] = make_frag<NP>(v[u][t2][0], v[u][t2][1]);
+                store_frag<NP>(img + (int64_t)(2 * kb + t2) * (NP * 1024) + lane * 16, f[t2]);
+            }
+            emit(kb, f);
+        }
     }
 }
+
+// planes_kloop (tower_planes.h) in two halves: the first PL_DEPTH steps' weight loads are issued BEFORE the
+// workgroup stages its input rows (the weights do not depend on them), so the two round trips overlap
+// (measured at 485 pairs of 280-d frames: forward launches 11.5 -> 9.8 us, data-gradient launches 11.4 -> 10.4;
+// a ring of 8 steps, or the rows' loads in front of the ring's, were both slower: the launch is bound by what
+// one CU can pull from its L2 -- 192 KB of weights + 64 KB of rows per workgroup -- not by a latency).
+template <int NP>
+struct WideRing {
+    __amdgpu_buffer_rsrc_t rs;
+    int wv;
+    v4i wq[PL_DEPTH][NP];
+    __device__ __forceinline__ void issue(const char* __restrict__ image, int nblk, int nsteps, int blk, int s_first, int lane)
+    {
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(image), 0, nblk * nsteps * (NP * 1024), 0x00020000);
+        wv = ((blk < nblk ? blk : nblk - 1) * nsteps + s_first) * (NP * 1024) + lane * 16;
+#pragma unroll
+        for (int i = 0; i < PL_DEPTH; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                wq[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, wv, (i * NP + pl) * 1024, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+    __device__ __forceinline__ void run(f32x16& acc, const char* __restrict__ img, int s_first, int my_steps, int lane)
+    {
+        const char* ab = img + (int64_t)s_first * (NP * 1024) + lane * 16;
+        bf16x8 af[2][NP];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(ab + pl * 1024);
+        for (int s0 = 0; s0 < my_steps; s0 += PL_DEPTH) {
+#pragma unroll
+            for (int i = 0; i < PL_DEPTH; ++i) {
+                const int s = s0 + i;
+                const int s1 = s + 1 < my_steps ? s + 1 : s;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) af[(i + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(ab + (s1 * NP + pl) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8* a = af[i & 1];
+                if constexpr (NP == 3) {
+                    constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, AP[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first, as planes_kloop
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[i][WP[t]]), a[AP[t]], acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[i][0]), a[0], acc, 0, 0, 0);
+                }
+                asm volatile("" : "+v"(acc) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const int sn = s + PL_DEPTH < my_steps ? s + PL_DEPTH : my_steps - 1;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) wq[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, wv, (sn * NP + pl) * 1024, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+};
 
 // The waves of one block add their slices: slices kpart >= 1 park their accumulators, slice 0 adds them in order.
 __device__ __forceinline__ void wide_park(const WideShare& ws, const f32x16& acc, float* __restrict__ part, int lane)
@@ -113,7 +181,16 @@ struct WideFwdP {
     int64_t tp_steps;
     const unsigned long long* drop_seed;
     float drop_p;
+#ifdef ABN_STAMPS
+    unsigned long long* stamps;
+#endif
 };
+
+#ifdef ABN_STAMPS
+#define WSTAMP(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[((size_t)p.l * 1024 + blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(slot) do {} while (0)
+#endif
 
 template <int NP>
 __global__ __launch_bounds__(PL_NT) void wide_fwd_layer_kernel(WideFwdP p)
@@ -134,6 +211,20 @@ __global__ __launch_bounds__(PL_NT) void wide_fwd_layer_kernel(WideFwdP p)
     bf16x8 idf[2];
     make_identity(idf, lane);
 
+    WSTAMP(0);
+    const int nblk = pl_blocks(N), nsteps = pl_steps(K);
+    const WideShare ws(wave, g, p.G, nblk, nsteps);
+    WideRing<NP> ring;
+    if (ws.active) ring.issue(p.wp, nblk, nsteps, ws.blk, ws.s_first, lane);      // the weights do not wait for the rows
+    f32x4 b4[4] = {};
+    if (ws.active && ws.kpart == 0 && p.b) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int n = 32 * ws.blk + 4 * h + 8 * gq;
+            b4[gq] = *reinterpret_cast<const f32x4*>(p.b + (n < N ? n : N - 4));
+        }
+    }
+
     const float* src;
     if (p.l == 0) src = !row_ok ? nullptr : (p.x2 && call >= 1 ? p.x2 + (arow - p.rows_call) * K : p.x1 + arow * K);
     else src = p.a_prev + (int64_t)vrow * K;
@@ -147,24 +238,18 @@ __global__ __launch_bounds__(PL_NT) void wide_fwd_layer_kernel(WideFwdP p)
         Frag<NP> z[2] = {};
         emit_planes<NP>(tp_in + ((int64_t)(K / 32) * p.tp_steps + 2 * rb) * tile_bytes<NP>(), z, idf, lane, 0, rows_left);
     }
+    WSTAMP(1);
     __syncthreads();
+    WSTAMP(2);
 
-    const int nblk = pl_blocks(N), nsteps = pl_steps(K);
-    const WideShare ws(wave, g, p.G, nblk, nsteps);
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-    f32x4 b4[4] = {};
-    if (ws.active && ws.kpart == 0 && p.b) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int n = 32 * ws.blk + 4 * h + 8 * gq;
-            b4[gq] = *reinterpret_cast<const f32x4*>(p.b + (n < N ? n : N - 4));
-        }
-    }
-    if (ws.active) planes_kloop<NP, 1>(&acc, p.wp, nblk, nsteps, img, ws.blk, ws.s_first, ws.my_steps, lane);
+    if (ws.active) ring.run(acc, img, ws.s_first, ws.my_steps, lane);
+    WSTAMP(3);
     wide_park(ws, acc, part, lane);
     __syncthreads();
+    WSTAMP(4);
     if (ws.active && ws.kpart == 0) {
         wide_collect(ws, acc, part, lane);
         const DropGen drop = make_drop(p.drop_seed, p.drop_p, p.l);
@@ -208,6 +293,7 @@ __global__ __launch_bounds__(PL_NT) void wide_fwd_layer_kernel(WideFwdP p)
         Frag<NP> z[2] = {};
         emit_planes<NP>(p.tp_out + ((int64_t)nblk * p.tp_steps + 2 * rb) * tile_bytes<NP>(), z, idf, lane, 0, rows_left);
     }
+    WSTAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -263,6 +349,10 @@ __global__ __launch_bounds__(PL_NT) void wide_dgrad_layer_kernel(WideBwdP p)
     const int N = p.N, K = p.K;
     bf16x8 idf[2];
     make_identity(idf, lane);
+    const int nblk = pl_blocks(K), nsteps = pl_steps(N);
+    const WideShare ws(wave, g, p.G, nblk, nsteps);
+    WideRing<NP> ring;
+    if (p.wpt && ws.active) ring.issue(p.wpt, nblk, nsteps, ws.blk, ws.s_first, lane);      // the weights do not wait for dZ_l
 
     if (p.l == p.top) {
         // ---- dZ of the last layer for this workgroup's 32 rows (every one of the row block's G workgroups forms it)
@@ -412,8 +502,6 @@ __global__ __launch_bounds__(PL_NT) void wide_dgrad_layer_kernel(WideBwdP p)
     __syncthreads();
     if (!p.wpt) return;                                // a one-layer tower without an input gradient: dZ_top was all there is
 
-    const int nblk = pl_blocks(K), nsteps = pl_steps(N);
-    const WideShare ws(wave, g, p.G, nblk, nsteps);
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
@@ -425,7 +513,7 @@ __global__ __launch_bounds__(PL_NT) void wide_dgrad_layer_kernel(WideBwdP p)
             av[gq] = *reinterpret_cast<const f32x4*>(p.a_prev + (int64_t)vrow * K + (k < K ? k : K - 4));
         }
     }
-    if (ws.active) planes_kloop<NP, 1>(&acc, p.wpt, nblk, nsteps, img, ws.blk, ws.s_first, ws.my_steps, lane);
+    if (ws.active) ring.run(acc, img, ws.s_first, ws.my_steps, lane);
     wide_park(ws, acc, part, lane);
     __syncthreads();
     if (!(ws.active && ws.kpart == 0)) return;

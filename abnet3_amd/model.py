@@ -777,7 +777,7 @@ class SiameseNetwork(_HipNetwork):
         for p, g in zip(seg.params, grads):
             p.grad = g
 
-    def direct_backward_loss(self, state, y, loss_kind, margin, avg, defer_reduce=False, n_valid=None, loss_accum=None):
+    def direct_backward_loss(self, state, y, loss_kind, margin, avg, defer_reduce=False, n_valid=None, loss_accum=None, loss_ws=None):
         """loss(emb1, emb2, y) and its backward in the backward's own launches (abn_tower_backward_loss:
         the data-gradient chain computes the pair loss and d loss / d z of the output layer in its first
         phase).  Returns the 0-dim loss, or None when the library does not take this tower that way
@@ -800,7 +800,11 @@ class SiameseNetwork(_HipNetwork):
         scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
         scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32, device=y.device)
         loss = torch.empty((), dtype=torch.float32, device=y.device)
-        lws = _scratch(lib.abn_tower_backward_loss_ws_bytes(rows), y.device)
+        # the loss scratch (a ticket counter every call leaves zero + per-workgroup partial sums): the caller's own
+        # buffer -- a captured step keeps one outside the graph instead of a memset node per replay -- or the
+        # per-stream one
+        need = lib.abn_tower_backward_loss_ws_bytes(rows)
+        lws = loss_ws if loss_ws is not None and loss_ws.numel() >= need else _scratch(need, y.device)
         rc = lib.abn_tower_backward_loss(
             _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(y), _lib.Y_DTYPE[y.dtype], _lib.LOSS[loss_kind],
             float(margin), int(bool(avg)), rows, _lib.ptr(sv.ws), _lib.ptr(scratch), scratch_floats, _lib.ptr(loss),

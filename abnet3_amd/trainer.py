@@ -503,6 +503,7 @@ class TrainerSiamese(TrainerBuilder):
             st = self._buckets = {}
             self._bucket_pool = torch.cuda.graph_pool_handle()
             self._loss_acc = torch.zeros((), dtype=torch.float64, device=plan.table.device)
+            self._loss_ws = torch.zeros(1 << 16, dtype=torch.uint8, device=plan.table.device)     # (ticket + partial sums of the in-backward loss)
         key = (npad, plan.table.shape[1], plan.labels.dtype)
         b = st.get(key)
         if b is None:
@@ -520,7 +521,8 @@ class TrainerSiamese(TrainerBuilder):
         opt.zero_grad()
         defer = self.world_size == 1 and net.can_defer_reduce(state)
         loss_value = net.direct_backward_loss(state, b['y'], type(self.loss).__name__, getattr(self.loss, 'margin', 0.0),
-                                              self.loss.avg, defer_reduce=defer, n_valid=b['nv'], loss_accum=self._loss_acc)
+                                              self.loss.avg, defer_reduce=defer, n_valid=b['nv'], loss_accum=self._loss_acc,
+                                              loss_ws=self._loss_ws)
         return loss_value
 
     def _bucket_finish(self):

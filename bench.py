@@ -549,6 +549,71 @@ def fbank_bench(torch, seconds=3000, fs=16000, cpu_seconds=600):
     return res
 
 
+def pipeline_bench(torch, n_utts, n_pairs, epochs, with_cpu):
+    """BASELINE.json configs[4] on this GPU (tools/c5_pipeline.py): synthetic ZeroSpeech-shaped corpus (16 kHz, 2-10 s
+    utterances, Zipfian word types, sampler-format word pairs, 70 / 30 split) -> batched filterbanks -> mean / variance
+    normalisation -> 7-frame stacking (280-d) -> DTW mining -> TrainerSiamese over OriginalDataLoader (8 word pairs per
+    batch: the reference's canonical loader, test/data/buckeye.yaml:21-26) and over FramesDataLoader (4096 frame pairs)
+    -> embedding of every utterance.  Per-stage seconds and frame pairs / s of the training passes; with the CPU
+    baselines the oracles' rates for the same stages on a bounded slice of the same corpus."""
+    import numpy as np
+    from tools import c5_pipeline
+    out, kept, dc, corpus, (train_pairs, dev_pairs) = c5_pipeline.run(n_utts=n_utts, n_pairs=n_pairs, epochs=epochs, keep=True)
+    for kind in out['training']:
+        st = out['training'][kind]
+        st['losses_decrease'] = bool(st['train_losses'][-1] < st['train_losses'][0])
+    if with_cpu:
+        from oracle import dtw_oracle, features_np, torch_ref
+        cpu = {'kind': 'port', 'cores_train': None}
+        # filterbanks: the numpy restatement, one core, the first utterances (~60 s of audio)
+        t0, frames, k = time.perf_counter(), 0, 0
+        while k < len(corpus.waves) and time.perf_counter() - t0 < 4.0:
+            frames += features_np.fbank(corpus.waves[k], corpus.fs).shape[0]
+            k += 1
+        cpu['fbank_frames_per_s'] = round(frames / (time.perf_counter() - t0), 1)
+        cpu['fbank_sample'] = 'first %d utterances (%d frames), oracle/features_np.py, 1 core' % (k, frames)
+        # DTW mining: oracle/dtw.c on the stacked 280-d features of the first 'same' pairs, one core
+        table = dc.table.cpu().numpy()
+        same = [p for p in train_pairs if p[6] == 'same'][:400]
+        o1, n1, o2, n2 = [], [], [], []
+        for f1, s1, e1, f2, s2, e2, _ in same:
+            (a0, na), (b0, nb) = dc.token(f1, s1, e1), dc.token(f2, s2, e2)
+            o1.append(a0); n1.append(na); o2.append(b0); n2.append(nb)
+        o1, o2 = np.asarray(o1, dtype=np.int64), np.asarray(o2, dtype=np.int64)
+        n1, n2 = np.asarray(n1, dtype=np.int32), np.asarray(n2, dtype=np.int32)
+        t0 = time.perf_counter()
+        dtw_oracle.dtw_batch(table, o1, n1, table, o2, n2, int((n1 + n2).max()))
+        dt = time.perf_counter() - t0
+        cells = int((n1.astype(np.int64) * n2).sum())
+        cpu['dtw_cells_per_s'] = round(cells / dt, 1)
+        cpu['dtw_sample'] = '%d same pairs of the training set (%d cells of 280-d frames, %.2f s), oracle/dtw.c, 1 core' % (len(same), cells, dt)
+        # training: the torch-CPU restatement on the first batches of the OriginalDataLoader plan (ragged sizes)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        torch.set_num_threads(max(1, min(16, avail)))
+        plan = kept['original'][1].plan(True)
+        batches = [tuple(t.cpu() for t in plan.materialise(b)) for b in plan.order[:60]]
+        net = torch_ref.build(seed=0, **c5_pipeline.C5_NET)
+        opt = torch.optim.Adadelta(net.parameters(), lr=0.1)
+        net.train()
+        for b in batches[:3]:
+            torch_ref.train_step(net, opt, *b)
+        t0, pairs, k = time.perf_counter(), 0, 0
+        while time.perf_counter() - t0 < 6.0:
+            b = batches[k % len(batches)]
+            torch_ref.train_step(net, opt, *b)
+            pairs += len(b[2])
+            k += 1
+        dt = time.perf_counter() - t0
+        cpu['train_frame_pairs_per_s'] = round(pairs / dt, 1)
+        cpu['cores_train'] = torch.get_num_threads()
+        cpu['train_sample'] = '%d steps over the first %d batches of the same OriginalDataLoader plan (%.1f s), oracle/torch_ref.py' % (k, len(batches), dt)
+        out['cpu_baseline'] = cpu
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -558,6 +623,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtw-pairs', type=int, default=10000,
                     help='token pairs per GPU for the DTW leg (0 = skip)')
+    ap.add_argument('--pipeline-utts', type=int, default=2000, help='utterances of the C5 pipeline leg (0 = skip; N = 1 only)')
     ap.add_argument('--graph', action='store_true',
                     help='replay a captured hipGraph per step instead of the eager direct step')
     ap.add_argument('--no-graph', action='store_true', help='(default; kept for old command lines)')
@@ -683,6 +749,8 @@ def main():
             out['dtw'] = dtw
         if world == 1 and not args.no_cpu_baseline:
             out['fbank'] = fbank_bench(torch)
+        if world == 1 and args.pipeline_utts > 0:
+            out['pipeline'] = pipeline_bench(torch, args.pipeline_utts, 25 * args.pipeline_utts, 2, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

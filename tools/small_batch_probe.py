@@ -64,6 +64,19 @@ def main():
             g = step.graph
             t = timed(lambda i: g.replay())
             row += '  bare replay %.1f us' % (t * 1e6)
+        if mode in ('both', 'plan'):
+            # the trainer's planned passes: one gather launch + one replay of the bucket's captured step
+            import numpy as np
+            from abnet3_amd.dataloader import BatchPlan
+            table = torch.randn(20000, 280, device='cuda')
+            nb = 64
+            idx1 = torch.randint(0, 20000, (nb * B,), device='cuda')
+            idx2 = torch.randint(0, 20000, (nb * B,), device='cuda')
+            lab = ((torch.rand(nb * B, device='cuda') > 0.5).double() * 2 - 1)
+            plan = BatchPlan(table, idx1, idx2, lab, np.arange(nb + 1) * B, list(range(nb)))
+            tr._planned_step(plan, 0)
+            t = timed(lambda i: tr._planned_step(plan, i % nb))
+            row += '  planned step %.1f us (%.2f M pairs/s)' % (t * 1e6, B / t / 1e6)
         print(row, flush=True)
 
 
