@@ -51,6 +51,7 @@ SYMBOLS = {
     'abn_pair_loss_ws_bytes': (_i64, [_i64]),
     'abn_pair_loss': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, C.c_int,
                                  _f32, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    'abn_pair_loss_padded': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'abn_pair_loss_dz': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, C.c_int, _f32, C.c_int, C.c_int,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'abn_optimizer_step': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _f32,

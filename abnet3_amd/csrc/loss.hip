@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
                                                         int act, const float* __restrict__ mask1,
                                                         const float* __restrict__ mask2,
                                                         double* __restrict__ partial, unsigned* __restrict__ counter,
-                                                        float* __restrict__ loss_out)
+                                                        float* __restrict__ loss_out, const int* __restrict__ n_valid,
+                                                        double* __restrict__ loss_accum)
 {
     __shared__ double row_term[ROWS_PER_BLOCK];
     __shared__ double sh[256];
@@ -56,7 +57,10 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
     const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + sub;
     double term = 0.0;
-    if (row < B) {
+    // a padded batch (n_valid): only the first *n_valid pairs are real, a mean loss divides by their number
+    const int64_t Bv = n_valid ? (int64_t)*n_valid : B;
+    if (n_valid && scale != 1.0) scale = 1.0 / (double)(Bv > 0 ? Bv : 1);
+    if (row < B && row < Bv) {
         const float* a = e1 + row * D;
         const float* b = e2 + row * D;
         double dot = 0.0, s11 = 0.0, s22 = 0.0;
@@ -137,6 +141,9 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
             }
         }
     }
+    else if (row < B && de1) {                          // a padded pair: no gradient
+        for (int c = l; c < D; c += 32) { de1[row * D + c] = 0.0f; de2[row * D + c] = 0.0f; }
+    }
     if (l == 0) row_term[sub] = term;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -170,7 +177,9 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        *loss_out = (float)(sh[0] * scale);
+        const float lv = (float)(sh[0] * scale);
+        *loss_out = lv;
+        if (loss_accum) *loss_accum += (double)lv;          // (one thread per call, calls in stream order)
         __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next call
     }
 }
@@ -189,7 +198,7 @@ int64_t abn_pair_loss_ws_bytes(int64_t B)
 
 static int pair_loss_impl(const float* e1, const float* e2, const void* y, int y_dtype, int64_t B, int64_t D, int kind,
                           float margin, int avg, float* loss_out, float* de1, float* de2, int act, const float* mask1,
-                          const float* mask2, void* ws, void* stream)
+                          const float* mask2, void* ws, void* stream, const int32_t* n_valid = nullptr, double* loss_accum = nullptr)
 {
     ABN_REQUIRE(e1 && e2 && y && loss_out && ws, "pair_loss: null pointer");
     ABN_REQUIRE((de1 == nullptr) == (de2 == nullptr), "pair_loss: de1/de2 must both be given or both be NULL");
@@ -208,10 +217,10 @@ static int pair_loss_impl(const float* e1, const float* e2, const void* y, int y
     double* partial = (double*)((char*)ws + 8);
     if (vec)
         hipLaunchKernelGGL(pair_loss_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, e1, e2, y, y_dtype, B,
-                           (int)D, kind, (double)margin, scale, de1, de2, act, mask1, mask2, partial, counter, loss_out);
+                           (int)D, kind, (double)margin, scale, de1, de2, act, mask1, mask2, partial, counter, loss_out, n_valid, loss_accum);
     else
         hipLaunchKernelGGL(pair_loss_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, e1, e2, y, y_dtype, B,
-                           (int)D, kind, (double)margin, scale, de1, de2, act, mask1, mask2, partial, counter, loss_out);
+                           (int)D, kind, (double)margin, scale, de1, de2, act, mask1, mask2, partial, counter, loss_out, n_valid, loss_accum);
     ABN_CHECK_LAUNCH("pair_loss");
     return ABN_OK;
 }
@@ -221,6 +230,14 @@ int abn_pair_loss(const float* e1, const float* e2, const void* y, int y_dtype, 
 {
     return pair_loss_impl(e1, e2, y, y_dtype, B, D, kind, margin, avg, loss_out, de1, de2, ABN_ACT_NONE, nullptr, nullptr, ws,
                           stream);
+}
+
+int abn_pair_loss_padded(const float* e1, const float* e2, const void* y, int y_dtype, int64_t B, int64_t D, int kind,
+                         float margin, int avg, const int32_t* n_valid, float* loss_out, double* loss_accum, float* de1,
+                         float* de2, void* ws, void* stream)
+{
+    return pair_loss_impl(e1, e2, y, y_dtype, B, D, kind, margin, avg, loss_out, de1, de2, ABN_ACT_NONE, nullptr, nullptr, ws,
+                          stream, n_valid, loss_accum);
 }
 
 int abn_pair_loss_dz(const float* e1, const float* e2, const void* y, int y_dtype, int64_t B, int64_t D, int kind,

@@ -727,7 +727,7 @@ class SiameseNetwork(_HipNetwork):
     def direct_ok(self):
         return self._last_act != 'softmax'
 
-    def direct_forward(self, x1, x2):
+    def direct_forward(self, x1, x2, forward_only=False):
         """forward(x1, x2) in the current mode without building an autograd graph:
         ([2B, out] embeddings of both towers, state for direct_backward).  Dispatching
         one backward through torch's autograd engine costs ~150 us of host time per
@@ -736,7 +736,7 @@ class SiameseNetwork(_HipNetwork):
         seg = self._segment_list()[0]
         rows = 2 * x1.shape[0]
         masks = self._draw_dropout_masks(rows, x1.device) if self.training else None
-        out, sv = _segment_forward(seg, masks, 2, x1, x2)
+        out, sv = _segment_forward(seg, masks, 2, x1, x2, forward_only=forward_only)
         return out, (seg, sv, _GradPass(self))
 
     def direct_dz_info(self, state):

@@ -480,7 +480,7 @@ class TrainerSiamese(TrainerBuilder):
     # same multiple of BUCKET pairs.  Padded rows contribute no loss and no gradient (abn_tower_backward_loss,
     # n_valid).  planned_passes = False switches back to the plain iterator.
     BUCKET = 32              # pairs: a tower call is padded to whole 32-row workgroups anyway
-    MIN_BUCKET = 128         # the operand-plane kernels start at 256 rows (both towers)
+    MIN_BUCKET = 32          # (the layer-per-launch kernels of csrc/tower_wide.h take any number of 32-row workgroups)
     MAX_BUCKET_GRAPHS = 96
 
     def _planned(self, train_mode):
@@ -587,15 +587,65 @@ class TrainerSiamese(TrainerBuilder):
         b['graph'] = (graph, [p_.grad for p_ in net.live_parameters()], getattr(net, '_last_grad_flat', None), pending)
         return True
 
+    def _planned_eval(self, plan, bid):
+        """loss(network(batch)) of batch `bid` without gradients, in the network's current mode, added to the
+        accumulator: one gather launch + one replay of the bucket's captured [forward, pair loss]."""
+        lib = _lib.load()
+        first, n = plan.span(bid)
+        if n == 0:
+            raise ValueError('need at least one array to concatenate')
+        b = self._bucket_state(self._bucket(n), plan)
+        _lib.check(lib.abn_gather_pairs(_lib.ptr(plan.table), plan.table.shape[1], _lib.ptr(plan.idx1), _lib.ptr(plan.idx2),
+                                        first, n, b['npad'], _lib.ptr(plan.labels), plan.labels.element_size(),
+                                        _lib.ptr(b['x12']), _lib.ptr(b['y']), _lib.ptr(b['nv']), _lib.stream()),
+                   'abn_gather_pairs')
+        key = 'eval_train' if self.network.training else 'eval'
+        if b.get(key) is not None:
+            b[key].replay()
+            return
+
+        def body():
+            net, npad = self.network, b['npad']
+            emb, _ = net.direct_forward(b['x12'][:npad], b['x12'][npad:], forward_only=True)
+            loss_value = torch.empty((), dtype=torch.float32, device=emb.device)
+            D = emb.shape[1]
+            _lib.check(lib.abn_pair_loss_padded(
+                _lib.ptr(emb), _lib.ptr(emb[npad:]), _lib.ptr(b['y']), _lib.Y_DTYPE[b['y'].dtype], npad, D,
+                _lib.LOSS[type(self.loss).__name__], float(getattr(self.loss, 'margin', 0.0)), int(bool(self.loss.avg)),
+                _lib.ptr(b['nv']), _lib.ptr(loss_value), _lib.ptr(self._loss_acc), None, None, _lib.ptr(self._loss_ws),
+                _lib.stream()), 'abn_pair_loss_padded')
+        with torch.no_grad():
+            body()
+            if sum(1 for v in self._buckets.values() for k in ('graph', 'eval', 'eval_train') if v.get(k) is not None) >= 3 * self.MAX_BUCKET_GRAPHS:
+                return
+            graph = torch.cuda.CUDAGraph()
+            gc_was_enabled = gc.isenabled()
+            gc.disable()
+            try:
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, pool=self._bucket_pool):
+                    body()
+            finally:
+                if gc_was_enabled:
+                    gc.enable()
+        b[key] = graph
+
+    def _run_planned_eval(self, plan, loss_sum):
+        """A pass without gradients over a plan (the dev pass, or the untrained first training pass)."""
+        if not plan.order:
+            return 0
+        self._bucket_state(self._bucket(plan.span(plan.order[0])[1]), plan)
+        self._loss_acc.zero_()
+        for bid in plan.order:
+            self._planned_eval(plan, bid)
+        loss_sum.add_(self._loss_acc)
+        return len(plan.order)
+
     def _run_planned(self, plan, do_training, loss_sum):
         """The training pass over a plan; adds the batches' losses to `loss_sum` (device float64) and returns
         the number of batches, or None when the padded form is refused (nothing has been stepped then)."""
         if not do_training:
-            n = 0
-            for minibatch in plan:
-                loss_sum.add_(self.train_step(minibatch, False))
-                n += 1
-            return n
+            return self._run_planned_eval(plan, loss_sum)
         if not plan.order:
             return 0
         self._bucket_state(self._bucket(plan.span(plan.order[0])[1]), plan)      # (creates the accumulator)
@@ -689,9 +739,12 @@ class TrainerSiamese(TrainerBuilder):
         self.network.eval()
         with torch.no_grad():
             plan = self._planned(False)
-            for minibatch in (plan if plan is not None else self._batches(False)):
-                num_batches_dev += 1
-                dev_loss.add_(self.give_batch_to_network(minibatch))
+            if plan is not None:
+                num_batches_dev = self._run_planned_eval(plan, dev_loss)
+            else:
+                for minibatch in self._batches(False):
+                    num_batches_dev += 1
+                    dev_loss.add_(self.give_batch_to_network(minibatch))
 
         if timed:
             torch.cuda.synchronize()

@@ -255,6 +255,15 @@ int abn_pair_loss(const float* e1, const float* e2, const void* y, int y_dtype,
                   int64_t B, int64_t D, int kind, float margin, int avg,
                   float* loss_out, float* de1, float* de2, void* ws,
                   void* stream);
+/* abn_pair_loss on a PADDED batch (see abn_gather_pairs / abn_tower_backward_loss): only the first *n_valid
+ * (device int32, NULL = all B) pairs are real -- the others add nothing to the loss and get zero gradient
+ * rows, a mean loss divides by *n_valid -- and the loss is also added to *loss_accum (device double, may be
+ * NULL): the evaluation pass of a trainer whose batches sit in bucket-sized static buffers
+ * (abnet3/trainer.py:244-248: the dev loss summed over the batches). */
+int abn_pair_loss_padded(const float* e1, const float* e2, const void* y, int y_dtype,
+                         int64_t B, int64_t D, int kind, float margin, int avg,
+                         const int32_t* n_valid, float* loss_out, double* loss_accum,
+                         float* de1, float* de2, void* ws, void* stream);
 /* The same with the output layer's activation derivative (and dropout multipliers, mask1 /
  * mask2 [B, D] or NULL) folded in: e1 / e2 are the tower's outputs act(z), and dz1 / dz2
  * receive d loss / d z = d loss / d e * act'(e) [* mask] -- the first step of

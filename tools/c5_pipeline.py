@@ -158,7 +158,10 @@ def main():
     ap.add_argument('--no-plan', action='store_true', help='the plain batch iterator instead of planned passes (A/B)')
     args = ap.parse_args()
     loaders = ('original', 'frames') if args.loader == 'both' else (args.loader,)
-    print(json.dumps(run(args.utts, args.pairs, args.epochs, loaders, planned=not args.no_plan)), flush=True)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):            # (the trainer prints its losses: the JSON line stands alone on stdout)
+        out = run(args.utts, args.pairs, args.epochs, loaders, planned=not args.no_plan)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
