@@ -46,10 +46,22 @@ def pytest_configure(config):
                 procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'),
                                                str(r), '2', port, out], stdout=log, stderr=subprocess.STDOUT))
             DP_JOB.update(procs=procs, out=out)
+            # ... and bench.py --gpus 2 the way the driver starts it for N > 1 (torch.distributed.run's
+            # environment), two fresh ranks sharing GPU 0 over gloo: tests/test_gpu_dp.py reads rank 0's JSON line
+            port = str(_free_port())
+            bprocs = []
+            for r in range(2):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                           ABN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+                log = open(out + '.bench%d.log' % r, 'w')
+                bprocs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                                                '--repeats', '2', '--dtw-pairs', '200', '--pipeline-utts', '0'],
+                                               stdout=log, stderr=subprocess.STDOUT, env=env))
+            DP_JOB.update(bench=bprocs)
 
 
 def pytest_unconfigure(config):
-    for p in DP_JOB.get('procs', []):
+    for p in DP_JOB.get('procs', []) + DP_JOB.get('bench', []):
         if p.poll() is None:
             p.kill()
 

@@ -87,6 +87,20 @@ def main():
             firsts.append(a[0].cpu().numpy())
         res['words.ep%d.sizes' % ep] = np.array(sizes)
         res['words.ep%d.first' % ep] = np.stack(firsts) if firsts else np.zeros((0, 40), np.float32)
+    # --- (3) planned passes (batch plans + captured steps) under the process group
+    np.random.seed(3000 + rank)
+    torch.manual_seed(5)
+    pl = OriginalDataLoader('unused', 'unused', batch_size=2)
+    pl.set_data(feats, times, train, devp)
+    net = SiameseNetwork(input_dim=40, num_hidden_layers=1, hidden_dim=64, output_dim=32, p_dropout=0.0, activation_layer='sigmoid',
+                         output_path='/tmp/abn_dp_planned_%d' % rank)
+    tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1, num_epochs=3, patience=5,
+                        dataloader=pl, log_dir='/tmp/abn_runs_dp')
+    tr.train()
+    res['planned.train_losses'] = np.array(tr.train_losses)
+    res['planned.graphs'] = np.array(sum(1 for v in getattr(tr, '_buckets', {}).values() if v['graph'] is not None))
+    for k, p in net.named_parameters():
+        res['planned.p.' + k] = p.detach().cpu().numpy()
     np.savez(out + '.rank%d.npz' % rank, **res)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -117,3 +117,42 @@ def test_word_pair_loader_shards_batches_by_rank(ranks):
             r, k = i % 2, i // 2
             assert ranks[r]['words.ep%d.sizes' % ep][k] == ref[i][0]
             assert (ranks[r]['words.ep%d.first' % ep][k] == ref[i][1]).all()
+
+
+def test_bench_runs_as_two_ranks():
+    """bench.py --gpus 2 exactly as the driver launches it for N > 1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    the environment), rehearsed with two fresh processes on GPU 0 over gloo: barriers, the MAX over ranks of the
+    timed region, rank 0's single JSON line."""
+    import json
+    job = conftest.DP_JOB
+    if not job.get('bench'):
+        pytest.skip('the bench ranks were not started (run with -m gpu on a GPU box)')
+    logs = []
+    for r, p in enumerate(job['bench']):
+        try:
+            rc = p.wait(timeout=900)
+        except Exception:
+            p.kill()
+            rc = -9
+        logs.append(open(job['out'] + '.bench%d.log' % r).read())
+        assert rc == 0, 'bench rank %d failed (%s):\n%s' % (r, rc, logs[-1][-3000:])
+    lines = [l for l in logs[0].splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1 and not [l for l in logs[1].splitlines() if l.startswith('{"metric"')]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_pairs'] == 8192 and out['config']['parallelism'] == 'dp2'
+    assert out['steps'] == 5 and out['warmup'] == 2 and out['scaling'] == 'weak' and out['higher_is_better'] is True
+    assert np.isfinite(out['value']) and out['value'] > 0 and np.isfinite(out['last_loss'])
+    assert abs(out['value'] - 8192 / (out['ms_per_step'] * 1e-3)) <= 1e-3 * out['value']
+    assert 'cpu_baseline' not in out and out['dtw']['pairs_per_gpu'] == 200
+
+
+def test_planned_passes_under_two_ranks(ranks):
+    """An epoch of planned passes (captured forward + backward per bucket, the gradient all-reduce and the
+    optimizer outside the graph) on two ranks: the replicas stay bit-identical and the loss falls."""
+    for k in ranks[0]:
+        if k.startswith('planned.p.'):
+            assert (ranks[0][k] == ranks[1][k]).all(), k
+    for r in ranks:
+        tl = r['planned.train_losses']
+        assert np.isfinite(tl).all() and len(tl) == 4 and tl[-1] < tl[0]
+        assert int(r['planned.graphs']) >= 1
