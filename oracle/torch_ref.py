@@ -93,3 +93,28 @@ def train_step(net, opt, x1, x2, y, kind='coscos2', margin=0.5, avg=False):
     loss.backward()
     opt.step()
     return loss
+
+
+def run_steps(kw, seed, batches, n_steps, dtype=torch.float32, optimizer='adadelta', lr=0.1, kind='coscos2', margin=0.5,
+              avg=False):
+    """`n_steps` train steps of a seeded network on `batches` (cycled), in `dtype`: torch.float32 is what the
+    reference executes; torch.float64 is the same sequence of operations in double -- the yardstick the fp32
+    results of the reference AND of the HIP kernels are measured against (tests/test_gpu_timed_path.py: both are
+    fp32-grade approximations of it; at the Siamese initialisation, where cos sits in [0.99998, 0.999997], they
+    differ from each other by more than either differs from the truth).  The float64 network starts from the
+    float32 initial weights (the seed's draw), exactly.
+    Returns (losses, first-step gradients {key: array}, parameters after the steps {key: array})."""
+    net = build(seed=seed, **kw)
+    if dtype == torch.float64:
+        net = net.double()
+    opt = {'adadelta': lambda p: torch.optim.Adadelta(p, lr=lr), 'sgd': lambda p: torch.optim.SGD(p, lr=lr, momentum=0.9)}[optimizer](net.parameters())
+    net.train()
+    losses, grads0 = [], None
+    for s in range(n_steps):
+        x1, x2, y = batches[s % len(batches)]
+        y = torch.as_tensor(y)
+        loss = train_step(net, opt, x1.to(dtype), x2.to(dtype), y, kind, margin, avg)
+        losses.append(float(loss.detach()))
+        if s == 0:
+            grads0 = {k: p.grad.detach().numpy().copy() for k, p in net.named_parameters()}
+    return losses, grads0, {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err, check_grads, check_params
+from conftest import is_pre_bn_bias, load_golden, rel_err, check_grads, check_params
 
 pytestmark = pytest.mark.gpu
 
@@ -138,6 +138,59 @@ def test_c2_timed_step_five_adadelta_steps_vs_reference(bn, mode):
         v = v.double().cpu()
         assert np.allclose([float(v.sum()), float(v.abs().sum())], g['after_chk.' + k],
                            rtol=1e-4, atol=1e-3), k
+
+
+@pytest.mark.parametrize('bn', [0, 1])
+def test_c2_backward_judged_against_float64(bn):
+    """The C2 step's gradients and its parameters after five Adadelta steps, HIP and reference both measured
+    against the SAME sequence of operations in float64 (oracle/torch_ref.run_steps: the float32 run there is what
+    the reference executes -- its checksums are the fixture's -- the float64 run the truth both approximate).  At
+    this initialisation (cos in [0.99998, 0.999997]) the reference's own fp32 gradients sit 6e-6 .. 3e-4 from the
+    truth, the output layer's worst; the HIP gradients must be no further from it than the reference's are
+    (factor 1.5 + 3e-6 of the tensor's largest entry for the tensors the reference gets almost exactly; factor 4
+    with BatchNorm, whose float32 batch statistics add rounding of their own on both sides), and so must the
+    parameters after the five steps."""
+    from oracle import torch_ref
+    g = load_golden('train_c2_bn%d.npz' % bn)
+    kw = ast.literal_eval(str(g['kw']))
+    batches = [torch_ref.make_inputs(4096, 40, 20 + s) for s in range(2)]
+    l64, g64, p64 = torch_ref.run_steps(kw, 2, batches, 5, torch.float64)
+    l32, g32, p32 = torch_ref.run_steps(kw, 2, batches, 5, torch.float32)
+    for k in g32:        # the float32 run IS the reference's: the fixture's checksums (produced by the reference itself,
+        if is_pre_bn_bias(k, bool(bn)):
+            continue
+        gg = g32[k].astype(np.float64)          # on another machine: another BLAS, another order of sums -- the reference's
+        ref_sum, ref_abs, ref_max = [float(v) for v in g['gchk.' + k]]      # fp32 gradients move by 1e-4 of a tensor's mass)
+        assert abs(gg.sum() - ref_sum) <= 3e-4 * ref_abs and abs(np.abs(gg).sum() - ref_abs) <= 3e-4 * ref_abs, k
+        assert abs(np.abs(gg).max() - ref_max) <= 3e-4 * max(ref_max, 1e-2 * float(g['gchk.output_layer.0.weight'][2])), k
+    net, _ = cuda_net(g, seed=2, prefix=None)
+    tr = trainer(net, 'coscos2', 0, 'adadelta')
+    dev_batches = [(a.cuda(), b.cuda(), torch.from_numpy(y).cuda()) for a, b, y in batches]
+    net.train()
+    losses = []
+    for s in range(5):
+        losses.append(float(tr.train_step(dev_batches[s % 2], True)))
+        if s == 0:
+            ghip = {k: q.grad.double().cpu().numpy() for k, q in net.named_parameters()}
+    err = lambda a, t: float(np.abs(a.astype(np.float64) - t).max() / max(np.abs(t).max(), 1e-30))
+    gmax = max(np.abs(v).max() for v in g64.values())
+    worst, factor = 0.0, (4.0 if bn else 1.5)
+    for k in g64:
+        if is_pre_bn_bias(k, bool(bn)):           # mathematically zero: rounding noise on every side
+            assert np.abs(ghip[k]).max() <= 1e-4 * gmax, k
+            continue
+        e_hip, e_ref = err(ghip[k], g64[k]), err(g32[k], g64[k])
+        worst = max(worst, e_hip / max(e_ref, 1e-12))
+        assert e_hip <= factor * e_ref + 3e-6, (k, e_hip, e_ref)
+    # losses: each within the reference's own distance from the truth (+ 1e-6 relative)
+    for a, b, c in zip(losses, l32, l64):
+        assert abs(a - c) <= abs(b - c) + 2e-6 * abs(c), (a, b, c)
+    sd = {k: v.double().cpu().numpy() for k, v in net.state_dict().items()}
+    for k in p64:
+        if 'num_batches' in k or is_pre_bn_bias(k, bool(bn)) or 'running' in k:
+            continue
+        e_hip, e_ref = err(sd[k], p64[k]), err(p32[k], p64[k])
+        assert e_hip <= factor * e_ref + 3e-6, (k, e_hip, e_ref)
 
 
 class _ListLoader(object):
