@@ -251,14 +251,15 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
         // pre-emphasis y[n] = x[n] - alpha x[n-1] inside the frame; element 0's history is the previous frame's
         // last element (FrameSrc).  Whole frames -- all but an utterance's last two -- read their samples directly.
         if (cur.avail >= wlen) {
+            // element 0's history: the previous frame (whole too: it starts earlier) ends at sample prev_start + wlen - 1
+            const int64_t i_prior = fr > 0 ? (int64_t)rint((double)(fr - 1) * fshift) + wlen - 1 : -1;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int n0 = 2 * (j + 64 * r);
                 float a = 0.0f, b = 0.0f, c = 0.0f;                  // x[n0 - 1], x[n0], x[n0 + 1]
                 if (n0 < wlen) {
                     const int64_t i = cur.start + n0;
-                    // n0 == 0: the previous frame (whole too: it starts earlier) ends at sample prev_start + wlen - 1
-                    const int64_t ia = n0 > 0 ? i - 1 : (fr > 0 ? (int64_t)rint((double)(fr - 1) * fshift) + wlen - 1 : -1);
+                    const int64_t ia = n0 > 0 ? i - 1 : i_prior;
                     a = ia >= 0 ? cur.raw(ia) : 0.0f;
                     b = cur.raw(i);
                     c = n0 + 1 < wlen ? cur.raw(i + 1) : 0.0f;
