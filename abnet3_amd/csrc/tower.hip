@@ -233,6 +233,11 @@ struct ReduceTable {
     float* dW[ABN_MAX_LAYERS];
     float* db[ABN_MAX_LAYERS];
     int64_t total;
+    // tensors whose gradient is already final in the flat gradient buffer (BatchNorm's gamma / beta): the fused
+    // reduction + optimizer launch steps them too (float offsets into the flat buffers, element counts)
+    int n_extra;
+    int64_t extra_off[2 * ABN_MAX_LAYERS];
+    int32_t extra_n[2 * ABN_MAX_LAYERS];
 };
 
 // sum_s slab[s][0..3] in a FIXED order: four interleaved partial sums (s mod 4), combined as
@@ -334,6 +339,11 @@ __global__ void slab_reduce_step_kernel(const float* __restrict__ slabs, ReduceT
             params[idx] = opt_update(o, params[idx], s[e], s1, s2, idx);
         }
     }
+    for (int x = 0; x < t.n_extra; ++x)
+        for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < t.extra_n[x]; j += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t idx = t.extra_off[x] + j;
+            params[idx] = opt_update(o, params[idx], grads[idx], s1, s2, idx);
+        }
 }
 
 constexpr float BN_EPS = 1e-5f;
@@ -870,7 +880,9 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
     B.slab_stride = align_up(packed, 64);
     int smax = 1;
     for (int l = 0; l < t->n_layers; ++l) {
-        B.splits[l] = planes_shape_ok(t) ? planes_split_count(rows, t->dims[l + 1], t->dims[l]) : split_count(rows, t->dims[l + 1], t->dims[l]);
+        // (one count whichever kernels run the backward of a tower the operand-plane kernels could take: abn_tower_reduce_step
+        // is told the descriptor and the row count only)
+        B.splits[l] = planes_dims_ok(t) ? planes_split_count(rows, t->dims[l + 1], t->dims[l]) : split_count(rows, t->dims[l + 1], t->dims[l]);
         B.psplits[l] = planes_dims_ok(t) ? planes_split_count(rows, t->dims[l + 1], t->dims[l]) : B.splits[l];
         smax = B.splits[l] > smax ? B.splits[l] : smax;
         smax = B.psplits[l] > smax ? B.psplits[l] : smax;
@@ -966,7 +978,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     const int np = planes_of(t->precision);
     const int64_t rpc = rows / n_calls;
     ABN_REQUIRE(aligned16(d_out) && aligned16(scratch) && (!dx || aligned16(dx)), "tower_backward: d_out / scratch / dx must be 16-byte aligned");
-    ABN_REQUIRE(!t->d_out_is_dz && !t->defer_reduce, "tower_backward: d_out_is_dz / defer_reduce cannot be combined with batch_norm");
+    ABN_REQUIRE(!t->d_out_is_dz, "tower_backward: d_out_is_dz cannot be combined with batch_norm");
     BwdLayout B = B0;
     for (int l = 0; l < nl; ++l) B.splits[l] = B0.psplits[l];
     const PackLayout PL = make_pack_layout(t);
@@ -1029,9 +1041,11 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     w.tp_steps = tp_steps;
     if (np == 3) hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
     else hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
+    ABN_CHECK_LAUNCH("tower_backward (BatchNorm, planes)");
+    if (t->defer_reduce) return ABN_OK;               // abn_tower_reduce_step finishes the job (the slabs of THIS launch: psplits)
     const ReduceTable rt = make_reduce_table(t, B);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, scratch + B.slabs, rt);
-    ABN_CHECK_LAUNCH("tower_backward (BatchNorm, planes)");
+    ABN_CHECK_LAUNCH("slab_reduce");
     return ABN_OK;
 }
 
@@ -1667,10 +1681,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             cur ^= 1;
         }
     }
-    if (t->defer_reduce) {
-        ABN_REQUIRE(!t->batch_norm, "tower_backward: defer_reduce cannot be combined with batch_norm");
-        return ABN_OK;                           // abn_tower_reduce_step finishes the job
-    }
+    if (t->defer_reduce) return ABN_OK;          // abn_tower_reduce_step finishes the job
     const ReduceTable rt = make_reduce_table(t, B);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, slabs, rt);
     ABN_CHECK_LAUNCH("slab_reduce");
@@ -1732,18 +1743,24 @@ int abn_tower_reduce_step(const abn_tower_desc* t, int64_t rows, const float* sc
 {
     int rc = check_desc(t, rows, 1);
     if (rc != ABN_OK) return rc;
-    ABN_REQUIRE(!t->batch_norm, "tower_reduce_step: not with batch_norm (its gradients do not come in slabs)");
     ABN_REQUIRE(kind >= ABN_OPT_SGD && kind <= ABN_OPT_RMSPROP, "tower_reduce_step: unknown optimizer %d", kind);
     ABN_REQUIRE(scratch && params && grads && state1, "tower_reduce_step: null pointer");
     ABN_REQUIRE(state2 || (kind != ABN_OPT_ADADELTA && kind != ABN_OPT_ADAM), "tower_reduce_step: state2 required");
     ABN_REQUIRE(step >= 1 && n >= 1, "tower_reduce_step: bad n/step");
     const BwdLayout B = make_bwd_layout(t, rows);
     if (scratch_floats < B.total) { set_error("tower_reduce_step: scratch too small"); return ABN_E_WORKSPACE; }
-    const ReduceTable rt = make_reduce_table(t, B);
+    ReduceTable rt = make_reduce_table(t, B);
     for (int l = 0; l < t->n_layers; ++l) {      // every gradient tensor must lie inside the flat buffers
         ABN_REQUIRE(t->dW[l] && t->db[l] && t->dW[l] >= grads && t->dW[l] + rt.nW[l] <= grads + n && t->db[l] >= grads &&
                         t->db[l] + rt.nb[l] <= grads + n,
                     "tower_reduce_step: layer %d's gradients are not inside the flat buffer", l);
+        if (t->batch_norm) {                     // gamma / beta: their gradients are final already, the same launch steps them
+            ABN_REQUIRE(t->dbn_w[l] && t->dbn_b[l] && t->dbn_w[l] >= grads && t->dbn_w[l] + rt.nb[l] <= grads + n &&
+                            t->dbn_b[l] >= grads && t->dbn_b[l] + rt.nb[l] <= grads + n,
+                        "tower_reduce_step: layer %d's BatchNorm gradients are not inside the flat buffer", l);
+            rt.extra_off[rt.n_extra] = t->dbn_w[l] - grads; rt.extra_n[rt.n_extra++] = (int32_t)rt.nb[l];
+            rt.extra_off[rt.n_extra] = t->dbn_b[l] - grads; rt.extra_n[rt.n_extra++] = (int32_t)rt.nb[l];
+        }
     }
     hipLaunchKernelGGL(slab_reduce_step_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        scratch + B.slabs, rt, make_optp(kind, lr, hp0, hp1, eps, step, grad_scale), params, grads, state1,

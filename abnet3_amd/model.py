@@ -757,9 +757,9 @@ class SiameseNetwork(_HipNetwork):
 
     def can_defer_reduce(self, state):
         """True when direct_backward may leave the split-K reduction to the optimizer's
-        launch (abn_tower_reduce_step): no BatchNorm, and one segment owns every live parameter."""
+        launch (abn_tower_reduce_step): one segment owns every live parameter."""
         seg = state[0]
-        return (not seg.batch_norm and os.environ.get('ABN_FUSED_STEP') != '0'      # (the variable: A/B runs)
+        return (os.environ.get('ABN_FUSED_STEP') != '0'      # (the variable: A/B runs)
                 and len(seg.params) == len(self.live_parameters()))
 
     def direct_backward(self, state, d_out, d_out_is_dz=False, defer_reduce=False):

@@ -100,8 +100,8 @@ typedef struct abn_tower_desc {
      * Not with batch_norm (its backward needs d loss / d a). */
     int32_t d_out_is_dz;
     /* backward only: leave the weight gradients as unreduced split-K slabs in `scratch`; the
-     * caller finishes with abn_tower_reduce_step (reduction + optimizer step in one launch).
-     * Not with batch_norm. */
+     * caller finishes with abn_tower_reduce_step (reduction + optimizer step in one launch;
+     * BatchNorm's gamma / beta gradients are final either way). */
     int32_t defer_reduce;
     /* Optional persistent image of the weights as MFMA operand fragments (default arithmetic):
      * wpack = abn_tower_wpack_floats() floats owned by the caller, zero before the first use, or
@@ -202,7 +202,8 @@ int abn_tower_backward_loss(const abn_tower_desc* t, const float* x1, const floa
  * scratch): sums the split-K slabs in their fixed order, writes the gradients to dW / db AND
  * applies abn_optimizer_step's update to the same elements -- one launch for what is otherwise
  * the slab reduction followed by the optimizer step (abnet3/trainer.py:239-240 back to back, no
- * gradient exchange in between: single process).  params / grads / state1 / state2 are the flat
+ * gradient exchange in between: single process).  With batch_norm the BatchNorm tensors (whose gradients
+ * the backward wrote directly) are stepped by the same launch.  params / grads / state1 / state2 are the flat
  * buffers (n floats each) that hold every tensor of the descriptor at the same offsets: element j
  * of layer l's weight lives at (dW[l] - grads) + j in all four. */
 int abn_tower_reduce_step(const abn_tower_desc* t, int64_t rows, const float* scratch,

@@ -281,13 +281,15 @@ def test_strided_inputs_are_accepted():
 
 
 @pytest.mark.parametrize('oname', ['sgd', 'adadelta', 'adam', 'adagrad', 'RMSprop'])
-def test_fused_reduce_and_step_equals_the_two_launches_bit_for_bit(oname, monkeypatch):
+@pytest.mark.parametrize('fixture', ['train_c1_bn0.npz', 'train_c1_bn1.npz', 'train_mid_bn1.npz'])
+def test_fused_reduce_and_step_equals_the_two_launches_bit_for_bit(oname, fixture, monkeypatch):
     """abn_tower_reduce_step (split-K reduction + optimizer update in one launch, what
     train_step uses in a single process without BatchNorm) against slab_reduce followed by
     abn_optimizer_step: same summation order, same update arithmetic -> identical bits in
     the gradients, the parameters and the optimizer state after three steps."""
-    g = load_golden('train_c1_bn0.npz')
-    batch = (dev(g['x1']), dev(g['x2']), dev(g['y']))
+    g = load_golden(fixture)          # (with BatchNorm: its gamma / beta are stepped by the same launch)
+    sfx = '' if 'x1' in g else '.0'
+    batch = (dev(g['x1' + sfx]), dev(g['x2' + sfx]), dev(g['y' + sfx]))
     runs = []
     for fused in ('1', '0'):
         monkeypatch.setenv('ABN_FUSED_STEP', fused)
