@@ -103,7 +103,7 @@ def _traffic(kernel):
     """HBM bytes per launch from the TCC counters (FETCH_SIZE x2 per the gfx950
     correction + WRITE_SIZE), collected by tools/collect_traffic.sh in separate
     --pmc passes and committed under profiles/."""
-    for rnd in ('r02', 'r01'):
+    for rnd in ('r03', 'r02', 'r01'):
         try:
             t = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc_traffic.json' % rnd)))
             for name, v in t.items():
@@ -212,7 +212,7 @@ def planes_roofline(torch, net, reps=20):
     if e['traffic']:
         gbs = e['traffic'] / (e['avg_launch_us'] * 1e-6) / 1e9
         out['hbm'] = {'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
-                      'note': 'measured TCC traffic per launch (profiles/r02_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, '
+                      'note': 'measured TCC traffic per launch (profiles/r03_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, '
                               'Infinity-Cache hits included) / launch time'}
     for key, v in entries.items():
         if key != dominant:

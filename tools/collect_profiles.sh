@@ -3,22 +3,31 @@
 #   1. rocprofv3 --kernel-trace --stats of the default bench.py command (kernel durations)
 #   2. FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (kernel-trace only) -> HBM bytes per launch
 #   3. SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / SQ_WAVE_CYCLES / SQ_INSTS_VALU ... pass (matrix-core and VALU use)
-#   tools/collect_profiles.sh r02      (results under gpurun_out/prof_r02*, summaries copied by the caller)
+#   4. the same for the small-batch step (planned passes, 485 pairs of 280-d frames: tools/small_batch_probe.py)
+#   tools/collect_profiles.sh r03      (results under gpurun_out/r03*, summaries copied by the caller)
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-args="--steps 100 --warmup 20 --no-cpu-baseline"
+args="--steps 100 --warmup 20 --no-cpu-baseline --pipeline-utts 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py $args > $out/stats.log 2>&1
+echo stats done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/traffic/fetch -- python3 $root/bench.py $args > $out/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/traffic/write -- python3 $root/bench.py $args > $out/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $out/sq -- python3 $root/bench.py $args > $out/sq.log 2>&1
 # filterbank leg (bench runs it only with the CPU baselines): its own passes
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/traffic_fb/fetch -- python3 $root/tools/fbank_time.py 3000 > $out/fb_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/traffic_fb/write -- python3 $root/tools/fbank_time.py 3000 > $out/fb_write.log 2>&1
+export MODE=plan PAIRS=485
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/small_stats -- python3 $root/tools/small_batch_probe.py > $out/small_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/traffic_small/fetch -- python3 $root/tools/small_batch_probe.py > $out/small_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/traffic_small/write -- python3 $root/tools/small_batch_probe.py > $out/small_write.log 2>&1
+echo small done
 cd $root
+python3 tools/prof_summary.py $out/small_stats 12 > $out/small_batch_kernel_stats.txt
+python3 tools/traffic_summary.py $out/traffic_small > $out/traffic_small.txt
 python3 tools/prof_summary.py $out/stats 20 > $out/kernel_stats.txt
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 python3 tools/traffic_summary.py $out/traffic > $out/traffic.txt
