@@ -65,7 +65,7 @@ SYMBOLS = {
     'abn_cosine_distance_f64': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     'abn_arccos_f32': (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
     'abn_gather_rows': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
-    'abn_gather_pairs': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    'abn_gather_pairs': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     'abn_stack_frames': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
     'abn_stack_frames_batched': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     'abn_mvn_ws_bytes': (_i64, [_i64, _i64]),

@@ -73,7 +73,7 @@ __global__ void stack_frames_batched_kernel(const float* __restrict__ in, const 
 // rows n .. n_pad - 1 of both halves zero; labels copied (padding 0); *n_valid = n.
 // One 16-byte piece per thread (D % 4 == 0) or one element.
 template <bool VEC>
-__global__ void gather_pairs_kernel(const float* __restrict__ table, int D, const int64_t* __restrict__ idx1,
+__global__ void gather_pairs_kernel(const float* __restrict__ table, int64_t table_rows, int D, const int64_t* __restrict__ idx1,
                                     const int64_t* __restrict__ idx2, int64_t first, int n, int n_pad,
                                     const char* __restrict__ labels, int label_bytes, float* __restrict__ x12,
                                     char* __restrict__ y_out, int32_t* __restrict__ n_valid)
@@ -86,10 +86,14 @@ __global__ void gather_pairs_kernel(const float* __restrict__ table, int D, cons
         const int tower = row >= n_pad, r = row - tower * n_pad;
         if (VEC) {
             float4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < n) v = reinterpret_cast<const float4*>(table + (tower ? idx2 : idx1)[first + r] * D)[c];
+            if (r < n) {
+                const int64_t src = (tower ? idx2 : idx1)[first + r];
+                if ((uint64_t)src < (uint64_t)table_rows) v = reinterpret_cast<const float4*>(table + src * D)[c];      // (a row outside the table reads as zeros)
+            }
             reinterpret_cast<float4*>(x12 + (int64_t)row * D)[c] = v;
         } else {
-            x12[(int64_t)row * D + c] = r < n ? table[(tower ? idx2 : idx1)[first + r] * D + c] : 0.0f;
+            const int64_t src = r < n ? (tower ? idx2 : idx1)[first + r] : -1;
+            x12[(int64_t)row * D + c] = (uint64_t)src < (uint64_t)table_rows ? table[src * D + c] : 0.0f;
         }
     }
     const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -218,19 +222,19 @@ int abn_stack_frames_batched(const float* feats, const int64_t* utt_frame_off, i
     return ABN_OK;
 }
 
-int abn_gather_pairs(const float* table, int64_t D, const int64_t* idx1, const int64_t* idx2, int64_t first, int64_t n,
+int abn_gather_pairs(const float* table, int64_t table_rows, int64_t D, const int64_t* idx1, const int64_t* idx2, int64_t first, int64_t n,
                      int64_t n_pad, const void* labels, int32_t label_bytes, float* x12, void* y_out, int32_t* n_valid,
                      void* stream)
 {
-    ABN_REQUIRE(D >= 1 && D < (1 << 20) && first >= 0 && n >= 0 && n_pad >= n && n_pad < (1 << 24), "gather_pairs: bad shape");
+    ABN_REQUIRE(D >= 1 && D < (1 << 20) && table_rows >= 0 && first >= 0 && n >= 0 && n_pad >= n && n_pad < (1 << 24), "gather_pairs: bad shape");
     ABN_REQUIRE((labels == nullptr) == (y_out == nullptr) && (!labels || (label_bytes >= 1 && label_bytes <= 8)), "gather_pairs: labels / y_out / label_bytes");
     if (n_pad == 0) return ABN_OK;
     ABN_REQUIRE(table && idx1 && idx2 && x12, "gather_pairs: null pointer");
     const bool vec = D % 4 == 0 && aligned16(table) && aligned16(x12);
     const int64_t work = 2 * n_pad * (vec ? D / 4 : D);
-    if (vec) hipLaunchKernelGGL(gather_pairs_kernel<true>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, table, (int)D, idx1, idx2,
+    if (vec) hipLaunchKernelGGL(gather_pairs_kernel<true>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, table, table_rows, (int)D, idx1, idx2,
                                 first, (int)n, (int)n_pad, (const char*)labels, (int)label_bytes, x12, (char*)y_out, n_valid);
-    else hipLaunchKernelGGL(gather_pairs_kernel<false>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, table, (int)D, idx1, idx2,
+    else hipLaunchKernelGGL(gather_pairs_kernel<false>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, table, table_rows, (int)D, idx1, idx2,
                             first, (int)n, (int)n_pad, (const char*)labels, (int)label_bytes, x12, (char*)y_out, n_valid);
     ABN_CHECK_LAUNCH("gather_pairs");
     return ABN_OK;

@@ -137,10 +137,13 @@ class BatchPlan(object):
     (abn_gather_pairs) into the buffers of a captured step; materialise(b) gives the tensors the plain
     iterator yields."""
 
-    def __init__(self, table, idx1, idx2, labels, offsets, order):
+    def __init__(self, table, idx1, idx2, labels, offsets, order, has_arrays=None):
         self.table, self.idx1, self.idx2, self.labels = table, idx1, idx2, labels
         self.offsets = np.asarray(offsets, dtype=np.int64)
         self.order = [int(b) for b in order]
+        # batches none of whose word pairs survived (the reference's np.vstack([]) raises ValueError,
+        # dataloader.py:247) as opposed to batches of zero frames (empty tokens: an empty batch comes out)
+        self.has_arrays = has_arrays
 
     def __len__(self):
         return len(self.order)
@@ -151,7 +154,7 @@ class BatchPlan(object):
 
     def materialise(self, b):
         first, n = self.span(b)
-        if n == 0:
+        if n == 0 and (self.has_arrays is None or not self.has_arrays[b]):
             raise ValueError('need at least one array to concatenate')
         sl = slice(first, first + n)
         return (gather_rows(self.table, self.idx1[sl]), gather_rows(self.table, self.idx2[sl]), self.labels[sl])
@@ -542,7 +545,7 @@ class OriginalDataLoader(DataLoader):
             i1, i2, y = empty, empty, torch.zeros(0, dtype=torch.float64, device=dev)
         # (statistics_training counts a pair every time an epoch visits it: plan() adds these per visited batch)
         counts = np.array([[sum(1 for e in pb if e[0] == 1), sum(1 for e in pb if e[0] == -1)] for pb in per_batch], dtype=np.int64).reshape(nb, 2)
-        store = (i1, i2, y, np.asarray(offsets, dtype=np.int64), counts)
+        store = (i1, i2, y, np.asarray(offsets, dtype=np.int64), counts, np.array([len(pb) > 0 for pb in per_batch], dtype=bool))
         if not hasattr(self, '_plans'):
             self._plans = {}
         self._plans[mode] = (pairs, len(pairs), store)
@@ -559,7 +562,7 @@ class OriginalDataLoader(DataLoader):
         if self.shuffle_between_epochs:
             self._shuffle_pairs(pairs)
             getattr(self, '_plans', {}).pop(mode, None)      # the batches' composition changed
-        i1, i2, y, offsets, counts = self._plan_store(mode)
+        i1, i2, y, offsets, counts, has_arrays = self._plan_store(mode)
         selected = self._select_batches(len(offsets) - 1, train_mode)
         order = [int(b) for b in selected]
         if order:
@@ -569,7 +572,7 @@ class OriginalDataLoader(DataLoader):
             # (np.random.seed(0); np.random.permutation(n), dataloader.py:248-249): so does the plan
             np.random.seed(0)
             np.random.permutation(int(offsets[order[-1] + 1] - offsets[order[-1]]))
-        return BatchPlan(self.features.table, i1, i2, y, offsets, order)
+        return BatchPlan(self.features.table, i1, i2, y, offsets, order, has_arrays)
 
     @staticmethod
     def _shuffle_pairs(pairs):

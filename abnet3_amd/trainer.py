@@ -499,7 +499,11 @@ class TrainerSiamese(TrainerBuilder):
 
     def _bucket_state(self, npad, plan):
         st = getattr(self, '_buckets', None)
+        flat_ptr = self.network.flat_parameters().data_ptr()
+        if st is not None and self._bucket_flat_ptr != flat_ptr:
+            st = None                        # the parameters were re-homed (.cuda() / .to()): every captured step is stale
         if st is None:
+            self._bucket_flat_ptr = flat_ptr
             st = self._buckets = {}
             self._bucket_pool = torch.cuda.graph_pool_handle()
             self._loss_acc = torch.zeros((), dtype=torch.float64, device=plan.table.device)
@@ -536,10 +540,11 @@ class TrainerSiamese(TrainerBuilder):
         form for this network (the caller falls back to the iterator for good)."""
         lib = _lib.load()
         first, n = plan.span(bid)
-        if n == 0:
-            raise ValueError('need at least one array to concatenate')      # (the reference's np.vstack([]))
+        if n == 0:        # no arrays: ValueError like the reference's np.vstack([]); zero frames: the iterator's (empty) step
+            self._loss_acc.add_(self.train_step(plan.materialise(bid), True))
+            return True
         b = self._bucket_state(self._bucket(n), plan)
-        _lib.check(lib.abn_gather_pairs(_lib.ptr(plan.table), plan.table.shape[1], _lib.ptr(plan.idx1), _lib.ptr(plan.idx2),
+        _lib.check(lib.abn_gather_pairs(_lib.ptr(plan.table), plan.table.shape[0], plan.table.shape[1], _lib.ptr(plan.idx1), _lib.ptr(plan.idx2),
                                         first, n, b['npad'], _lib.ptr(plan.labels), plan.labels.element_size(),
                                         _lib.ptr(b['x12']), _lib.ptr(b['y']), _lib.ptr(b['nv']), _lib.stream()),
                    'abn_gather_pairs')
@@ -567,7 +572,6 @@ class TrainerSiamese(TrainerBuilder):
         if len([1 for v in self._buckets.values() if v['graph'] is not None]) >= self.MAX_BUCKET_GRAPHS:
             return True
         steps_before = opt.step_count
-        acc_keep = self._loss_acc.clone()
         graph = torch.cuda.CUDAGraph()
         gc_was_enabled = gc.isenabled()
         gc.disable()                          # (see make_graphed_step)
@@ -582,7 +586,6 @@ class TrainerSiamese(TrainerBuilder):
             if gc_was_enabled:
                 gc.enable()
         opt.step_count = steps_before
-        self._loss_acc.copy_(acc_keep)
         net = self.network
         b['graph'] = (graph, [p_.grad for p_ in net.live_parameters()], getattr(net, '_last_grad_flat', None), pending)
         return True
@@ -593,9 +596,11 @@ class TrainerSiamese(TrainerBuilder):
         lib = _lib.load()
         first, n = plan.span(bid)
         if n == 0:
-            raise ValueError('need at least one array to concatenate')
+            with torch.no_grad():
+                self._loss_acc.add_(self.give_batch_to_network(plan.materialise(bid)))
+            return
         b = self._bucket_state(self._bucket(n), plan)
-        _lib.check(lib.abn_gather_pairs(_lib.ptr(plan.table), plan.table.shape[1], _lib.ptr(plan.idx1), _lib.ptr(plan.idx2),
+        _lib.check(lib.abn_gather_pairs(_lib.ptr(plan.table), plan.table.shape[0], plan.table.shape[1], _lib.ptr(plan.idx1), _lib.ptr(plan.idx2),
                                         first, n, b['npad'], _lib.ptr(plan.labels), plan.labels.element_size(),
                                         _lib.ptr(b['x12']), _lib.ptr(b['y']), _lib.ptr(b['nv']), _lib.stream()),
                    'abn_gather_pairs')

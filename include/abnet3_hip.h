@@ -352,8 +352,9 @@ int abn_gather_rows(const float* table, const int64_t* idx, int64_t n, int64_t D
  *   x12[r]         = table[idx1[first + r]]   (tower 1),   x12[n_pad + r] = table[idx2[first + r]]   (tower 2)
  * for r < n, zero rows for n <= r < n_pad.  labels (device, `label_bytes` per element: 8 = the float64 /
  * int64 labels of the loaders; may be NULL together with y_out): y_out[r] = labels[first + r], zero
- * padding.  n_valid (device int32, may be NULL) receives n: abn_tower_backward_loss's n_valid. */
-int abn_gather_pairs(const float* table, int64_t D, const int64_t* idx1, const int64_t* idx2,
+ * padding.  n_valid (device int32, may be NULL) receives n: abn_tower_backward_loss's n_valid.  An index outside
+ * [0, table_rows) reads as a zero row. */
+int abn_gather_pairs(const float* table, int64_t table_rows, int64_t D, const int64_t* idx1, const int64_t* idx2,
                      int64_t first, int64_t n, int64_t n_pad, const void* labels,
                      int32_t label_bytes, float* x12, void* y_out, int32_t* n_valid, void* stream);
 

@@ -90,7 +90,7 @@ def test_gather_pairs_against_indexing():
                 x12 = torch.full((2 * npad, D), 7.0, device='cuda')
                 yo = torch.full((npad,), 3, dtype=ydt, device='cuda')
                 nv = torch.zeros(1, dtype=torch.int32, device='cuda')
-                _lib.check(lib.abn_gather_pairs(_lib.ptr(table), D, _lib.ptr(i1), _lib.ptr(i2), first, n, npad, _lib.ptr(y), 8,
+                _lib.check(lib.abn_gather_pairs(_lib.ptr(table), table.shape[0], D, _lib.ptr(i1), _lib.ptr(i2), first, n, npad, _lib.ptr(y), 8,
                                                 _lib.ptr(x12), _lib.ptr(yo), _lib.ptr(nv), _lib.stream()), 'gather_pairs')
                 assert int(nv) == n
                 assert torch.equal(x12[:n], table[i1[first:first + n]]) and torch.equal(x12[npad:npad + n], table[i2[first:first + n]])
@@ -188,6 +188,31 @@ def test_planned_passes_train_like_the_iterator(small_corpus, opt, tmp_path):
     tol = 2e-4 if opt == 'adam' else 2e-5
     for k in p_a:
         assert rel_err(p_a[k], p_b[k]) < tol, (k, rel_err(p_a[k], p_b[k]))
+
+
+def test_a_batch_without_frames_raises_like_the_reference(small_corpus, tmp_path):
+    """Eight word pairs that are all skipped (start > end, abnet3/dataloader.py:179,210): the reference's np.vstack([])
+    raises ValueError from the iterator (:247); so do the plan's materialise() and the planned pass."""
+    from abnet3_amd.loss import coscos2
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.trainer import TrainerSiamese
+    dl = _loader('original', small_corpus)
+    name = small_corpus[0].names[0]
+    dl.pairs['train'] = [(name, 2.0, 1.0, name, 3.0, 2.5, 'diff')] * 8 + dl.pairs['train'][:8]
+    np.random.seed(0)
+    with pytest.raises(ValueError):
+        list(dl.batch_iterator(True))
+    np.random.seed(0)
+    with pytest.raises(ValueError):
+        list(dl.plan(True))
+    torch.manual_seed(0)
+    net = SiameseNetwork(input_dim=280, num_hidden_layers=0, hidden_dim=64, output_dim=32, p_dropout=0.0, activation_layer='sigmoid',
+                         output_path=str(tmp_path / 'net'))
+    tr = TrainerSiamese(network=net, loss=coscos2(avg=False), num_epochs=1, optimizer_type='sgd', lr=0.01, dataloader=dl,
+                        log_dir=str(tmp_path / 'runs'))
+    tr.train_losses, tr.dev_losses = [], []
+    with pytest.raises(ValueError):
+        tr.optimize_model(do_training=True)
 
 
 def test_padded_step_masks_the_padding():
