@@ -536,8 +536,8 @@ class TrainerSiamese(TrainerBuilder):
         opt.step()
 
     def _planned_step(self, plan, bid):
-        """One training step on batch `bid` of the plan; returns False when the library refuses the padded
-        form for this network (the caller falls back to the iterator for good)."""
+        """One training step on batch `bid` of the plan; returns False (nothing stepped) when the library refuses
+        the padded form for this network / batch size: the caller then takes the iterator's step on the batch."""
         lib = _lib.load()
         first, n = plan.span(bid)
         if n == 0:        # no arrays: ValueError like the reference's np.vstack([]); zero frames: the iterator's (empty) step
@@ -648,7 +648,7 @@ class TrainerSiamese(TrainerBuilder):
 
     def _run_planned(self, plan, do_training, loss_sum):
         """The training pass over a plan; adds the batches' losses to `loss_sum` (device float64) and returns
-        the number of batches, or None when the padded form is refused (nothing has been stepped then)."""
+        the number of batches."""
         if not do_training:
             return self._run_planned_eval(plan, loss_sum)
         if not plan.order:
@@ -656,11 +656,13 @@ class TrainerSiamese(TrainerBuilder):
         self._bucket_state(self._bucket(plan.span(plan.order[0])[1]), plan)      # (creates the accumulator)
         self._loss_acc.zero_()
         for k, bid in enumerate(plan.order):
-            if not self._planned_step(plan, bid):
+            if getattr(self, '_plan_refused', False) or not self._planned_step(plan, bid):
+                # the library does not take this network / batch in the padded form (exact-fp32 arithmetic, odd widths,
+                # a tiny batch with the layer-per-launch kernels switched off): the iterator's step on the same batch;
+                # refused on the very first batch = refused for good (the next passes do not ask again)
                 if k == 0:
                     self._plan_refused = True
-                    return None
-                raise RuntimeError('abnet3_amd: the padded step was refused in the middle of a pass')
+                self._loss_acc.add_(self.train_step(plan.materialise(bid), True))
         loss_sum.add_(self._loss_acc)
         return len(plan.order)
 
@@ -725,12 +727,10 @@ class TrainerSiamese(TrainerBuilder):
             t_pass = time.perf_counter()
         self.network.train()
         plan = self._planned(True)
-        done = self._run_planned(plan, do_training, train_loss) if plan is not None else None
-        if done is not None:
-            num_batches_train = done
+        if plan is not None:
+            num_batches_train = self._run_planned(plan, do_training, train_loss)
         else:
-            it = iter(plan) if plan is not None else self._batches(True)     # (a refused plan: the same batches, as tensors)
-            for minibatch in it:
+            for minibatch in self._batches(True):
                 # fp64 accumulator += fp32 loss in ONE launch (add_ promotes the operand)
                 if do_training:
                     train_loss.add_(self.train_step_auto(minibatch))

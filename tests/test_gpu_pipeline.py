@@ -296,3 +296,29 @@ def test_c5_pipeline_on_a_corpus_of_its_shape(tmp_path):
         assert st['embeddings_finite'] and st['train_frame_pairs_per_s'] > 0
         assert kept[kind][2].shape == (dc.total, 100)
     assert out['training']['original']['mean_frame_pairs_per_batch'] > 100
+
+
+def test_planned_passes_fall_back_batch_by_batch(small_corpus, tmp_path, monkeypatch):
+    """A network the padded step does not take (exact-fp32 arithmetic): the planned pass steps every batch through the
+    iterator's path -- same batches, same order -- and later passes do not ask again."""
+    from abnet3_amd.loss import coscos2
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.trainer import TrainerSiamese
+    res = []
+    for planned in (True, False):
+        dl = _loader('original', small_corpus)
+        np.random.seed(0)
+        torch.manual_seed(0)
+        net = SiameseNetwork(input_dim=280, num_hidden_layers=0, hidden_dim=64, output_dim=32, p_dropout=0.0, activation_layer='sigmoid',
+                             output_path=str(tmp_path / ('n%d' % planned)))
+        net.precision = 'fp32'
+        tr = TrainerSiamese(network=net, loss=coscos2(avg=True), num_epochs=1, patience=5, optimizer_type='sgd', lr=0.01, dataloader=dl,
+                            log_dir=str(tmp_path / 'runs'))
+        tr.planned_passes = planned
+        tr.train()
+        if planned:
+            assert tr._plan_refused and not any(v['graph'] for v in tr._buckets.values())
+        res.append((list(tr.train_losses), {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}))
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-6)
+    for k in res[0][1]:
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k
