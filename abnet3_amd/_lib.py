@@ -131,8 +131,13 @@ def reload_switches():
 E_UNSUPPORTED = -4
 
 
+_ON_ERROR = []        # callables run when a library call fails (loss.py: scratch whose "left zero" ticket may be dirty now)
+
+
 def check(rc, what):
     if rc != 0:
+        for hook in _ON_ERROR:
+            hook()
         msg = load().abn_last_error()
         raise HipLibraryError('%s failed (%d): %s' % (
             what, rc, msg.decode('utf-8', 'replace') if msg else ''))

@@ -33,6 +33,8 @@ def unit_grad(device):
 
 
 _WS = {}          # (device index, stream) -> zero-initialised scratch (partial sums + ticket counter)
+# a failed launch may leave a ticket counter non-zero: the cached buffers are dropped (and zeroed afresh on the next call)
+_lib._ON_ERROR.append(_WS.clear)
 
 
 def _scratch(nbytes, device):
