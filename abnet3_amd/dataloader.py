@@ -325,16 +325,12 @@ class OriginalDataLoader(DataLoader):
         else:
             shares = [(mine, lens, g1, g2)]
         for keys, lens, g1, g2 in shares:
-            start = 0
-            for key, ln in zip(keys, lens):
-                ln = int(ln)
-                if ln == 0:
-                    # an empty token or a NaN distance: the reference's try/except
-                    # drops the pair (dataloader.py:188-191)
-                    self._align[key] = None
-                else:
-                    self._align[key] = (g1[start:start + ln], g2[start:start + ln])
-                start += ln
+            lens = [int(v) for v in lens]
+            v1, v2 = torch.split(g1, lens), torch.split(g2, lens)      # (one call: thousands of views)
+            for key, ln, a, b in zip(keys, lens, v1, v2):
+                # ln == 0: an empty token or a NaN distance: the reference's try/except
+                # drops the pair (dataloader.py:188-191)
+                self._align[key] = (a, b) if ln else None
 
     def prefetch_alignments(self):
         """Aligns every 'same' pair of the train and dev sets up front, in one
@@ -493,7 +489,7 @@ class OriginalDataLoader(DataLoader):
                 al = self._align.get((f1, s1, e1, f2, s2, e2, False))
                 if al is None:
                     continue
-                per_batch[b].append((1, al, len(al[0]), len(al[0])))
+                per_batch[b].append((1, al, al[0].shape[0], al[0].shape[0]))
             for f1, s1, e1, f2, s2, e2, _ in diff:
                 if (s1 > e1) or (s2 > e2):
                     continue
@@ -517,7 +513,7 @@ class OriginalDataLoader(DataLoader):
             offs_d = np.concatenate(([0], np.cumsum(lens_d)))
             both = torch.from_numpy(np.concatenate(d1 + d2)).to(dev)
             dd1, dd2 = both[:both.numel() // 2], both[both.numel() // 2:]
-        parts1, parts2, labels, perm, offsets, row0 = [], [], [], [], [0], 0
+        parts1, parts2, lab_kind, lab_n, perm, offsets, row0 = [], [], [], [], [], [0], 0
         for b in range(nb):
             n, rows = 0, 0
             for kind, payload, ln, nlab in per_batch[b]:
@@ -525,7 +521,7 @@ class OriginalDataLoader(DataLoader):
                     parts1.append(payload[0]); parts2.append(payload[1])
                 else:
                     parts1.append(dd1[offs_d[payload]:offs_d[payload] + ln]); parts2.append(dd2[offs_d[payload]:offs_d[payload] + ln])
-                labels.append(np.full(nlab, float(kind)))
+                lab_kind.append(float(kind)); lab_n.append(nlab)
                 n += nlab
                 rows += ln
             # the reference permutes len(y) = n indices and applies them to the rows AND the labels
@@ -540,7 +536,7 @@ class OriginalDataLoader(DataLoader):
             perm_lab = np.concatenate([p[1] for p in perm])
             perm_d = torch.from_numpy(perm_rows).to(dev)
             i1, i2 = torch.cat(parts1)[perm_d], torch.cat(parts2)[perm_d]
-            y = torch.from_numpy(np.concatenate(labels)[perm_lab]).to(dev)
+            y = torch.from_numpy(np.repeat(np.asarray(lab_kind), np.asarray(lab_n, dtype=np.int64))[perm_lab]).to(dev)
         else:
             i1, i2, y = empty, empty, torch.zeros(0, dtype=torch.float64, device=dev)
         # (statistics_training counts a pair every time an epoch visits it: plan() adds these per visited batch)
