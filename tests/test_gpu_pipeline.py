@@ -322,3 +322,37 @@ def test_planned_passes_fall_back_batch_by_batch(small_corpus, tmp_path, monkeyp
     assert np.allclose(res[0][0], res[1][0], rtol=1e-6)
     for k in res[0][1]:
         assert np.array_equal(res[0][1][k], res[1][1][k]), k
+
+
+def test_planned_steps_redraw_their_dropout(small_corpus, tmp_path):
+    """p_dropout > 0 in planned passes: the per-forward seed is drawn inside the captured step, so every replay
+    drops other units (two replays of one batch with a zero learning rate give different losses); an evaluation
+    in eval mode does not."""
+    from abnet3_amd.loss import coscos2
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.trainer import TrainerSiamese
+    dl = _loader('original', small_corpus)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    net = SiameseNetwork(input_dim=280, num_hidden_layers=1, hidden_dim=128, output_dim=32, p_dropout=0.3, activation_layer='sigmoid',
+                         output_path=str(tmp_path / 'net'))
+    tr = TrainerSiamese(network=net, loss=coscos2(avg=False), num_epochs=1, optimizer_type='sgd', lr=0.0, momentum=0.0, dataloader=dl,
+                        log_dir=str(tmp_path / 'runs'))
+    plan = dl.plan(True)
+    bid = plan.order[0]
+    net.train()
+    tr._bucket_state(tr._bucket(plan.span(bid)[1]), plan)
+    losses = []
+    for _ in range(4):                      # eager first, then replays of the captured step
+        tr._loss_acc.zero_()
+        assert tr._planned_step(plan, bid)
+        losses.append(float(tr._loss_acc))
+    assert any(v['graph'] is not None for v in tr._buckets.values())
+    assert len(set(losses)) == 4, losses
+    net.eval()
+    ev = []
+    for _ in range(3):
+        tr._loss_acc.zero_()
+        tr._planned_eval(plan, bid)
+        ev.append(float(tr._loss_acc))
+    assert ev[0] == ev[1] == ev[2]
