@@ -18,7 +18,7 @@ MAX_LAYERS = 16
 
 ACT = {'none': 0, None: 0, 'sigmoid': 1, 'relu': 2, 'tanh': 3}
 LOSS = {'coscos2': 0, 'cosmargin': 1}
-PRECISION = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
+PRECISION = {'fp32': 0, 'bf16': 1, 'bf16x3': 2, 'f16x2': 3}
 OPT = {'sgd': 0, 'adadelta': 1, 'adam': 2, 'adagrad': 3, 'RMSprop': 4}
 Y_DTYPE = {torch.int8: 0, torch.int32: 1, torch.int64: 2, torch.float32: 3,
            torch.float64: 4}

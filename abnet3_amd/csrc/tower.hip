@@ -654,11 +654,29 @@ struct Layout {
     // precision 1 / 2 without BN (tower_planes.h): the weights and their transposes as MFMA operand
     // fragments, and the weight-gradient operands [x | 1], [a_l | 1] as transposed planes
     int64_t wpack, tp[ABN_MAX_LAYERS];   // wpack: the PackLayout image (unless the caller keeps a persistent one)
+    int64_t amax[ABN_MAX_LAYERS];        // fp16 x 2: tp[l]'s maxima per 32-row block (the weight-gradient launch's scales)
     int64_t bn_wg;                       // per-workgroup column statistics of bn_fwd_layer_kernel ([rows / 32][3][PL_MAXW])
     int64_t total;
 };
 
-static inline int planes_of(int precision) { return precision == 2 ? 3 : 1; }
+// operand planes of a tower's arithmetic: bf16 one, bf16 x 3 three, fp16 x 2 two (BatchNorm towers: the bf16 x 3 launches)
+static inline int planes_of(const abn_tower_desc* t) { return t->precision == 3 && !t->batch_norm ? 2 : (t->precision >= 2 ? 3 : 1); }
+// one of a kernel's three instantiations (operand planes)
+#define PL_LAUNCH(np, KERNEL, grid, block, lds, st, ...)                                             \
+    do {                                                                                             \
+        if ((np) == 3) hipLaunchKernelGGL(KERNEL<3>, grid, block, lds, st, __VA_ARGS__);             \
+        else if ((np) == 2) hipLaunchKernelGGL(KERNEL<2>, grid, block, lds, st, __VA_ARGS__);        \
+        else hipLaunchKernelGGL(KERNEL<1>, grid, block, lds, st, __VA_ARGS__);                       \
+    } while (0)
+#define PL_LDS_ATTR(KERNEL, BYTES)                                                                                                       \
+    do {                                                                                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES(1))); \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES(2))); \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES(3))); \
+    } while (0)
+static inline size_t wgrad_lds_of(int np) { return np == 3 ? wgrad_lds_bytes<3>() : (np == 2 ? wgrad_lds_bytes<2>() : wgrad_lds_bytes<1>()); }
+// the arithmetic the GEMM kernels (gemm_f32.h, tower_fused.h) run a precision in: fp16 x 2 exists on the operand planes only
+static inline int gemm_prec(int precision) { return precision > 2 ? 2 : precision; }
 // BatchNorm launches: workgroups of 32 rows never straddle two forward_once calls, so the row axis of the
 // transposed images is padded per call
 static inline int64_t bn_wgs_per_call(int64_t rows, int64_t n_calls) { return (rows / n_calls + PL_ROWS - 1) / PL_ROWS; }
@@ -681,7 +699,7 @@ static PackLayout make_pack_layout(const abn_tower_desc* t)
 {
     PackLayout P = {};
     if (!planes_dims_ok(t)) return P;
-    const int np = planes_of(t->precision);
+    const int np = planes_of(t);
     int64_t o = 0;
     for (int l = 0; l < t->n_layers; ++l) {
         P.wp[l] = o; o += pl_image_bytes(t->dims[l + 1], t->dims[l], np);
@@ -716,15 +734,18 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
         for (int l = 1; l <= t->n_layers; ++l) maxw = t->dims[l] > maxw ? t->dims[l] : maxw;
         L.bn_part = take(2 * n_calls * bn_chunks(rows / n_calls) * 2 * maxw);      // doubles = 2 floats each
     }
-    for (int l = 0; l < t->n_layers; ++l) L.tp[l] = -1;
+    for (int l = 0; l < t->n_layers; ++l) L.tp[l] = L.amax[l] = -1;
     L.wpack = -1;
     L.bn_wg = -1;
     if (planes_dims_ok(t) && t->batch_norm && !t->forward_only) L.bn_wg = take((n_calls * bn_wgs_per_call(rows, n_calls) + 1) * 3 * PL_MAXW);
     if (planes_dims_ok(t)) {
-        const int np = planes_of(t->precision);
+        const int np = planes_of(t);
         L.wpack = take(make_pack_layout(t).bytes / 4);
         if (!t->forward_only)                                      // (last in the workspace: an inference call simply asks for less)
-            for (int l = 0; l < t->n_layers; ++l) L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, vrows, np) / 4);
+            for (int l = 0; l < t->n_layers; ++l) {
+                L.tp[l] = take(pl_timage_bytes(t->dims[l] + 1, vrows, np) / 4);
+                if (np == 2) L.amax[l] = take(pl_amax_floats(vrows));
+            }
     }
     L.total = o;
     return L;
@@ -737,14 +758,25 @@ enum { PLANES_NONE = 0, PLANES_CHAIN = 1, PLANES_WIDE = 2 };
 
 // Workgroups per 32-row block of the layer-per-launch kernels (tower_wide.h) for a batch of `vrows` virtual
 // rows: as many as keep the grid within one wave of workgroups over the 256 CUs; 0 = too many rows, the
-// single-launch chains take the batch (from ~80 row blocks on every CU has a chain workgroup anyway).
-static int wide_groups(int64_t vrows)
+// single-launch chains take the batch (measured, 280 -> 500 x 2 -> 100: layer per launch 151 / 172 / 180 / 202 us at
+// 1024 / 1280 / 1536 / 2048 pairs against the chains' 175 / 182 / 187 / 195).
+static int wide_groups(int64_t vrows, int max_blocks = 2 * WD_MAXG)
 {
-    const int64_t cap = switches().wide_max_rows >= 0 ? switches().wide_max_rows : 2560;
+    const int64_t cap = switches().wide_max_rows >= 0 ? switches().wide_max_rows : 3072;
     if (!switches().wide || vrows > cap || vrows < PL_ROWS) return 0;
     const int64_t nrb = vrows / PL_ROWS;
-    const int64_t G = 256 / nrb;
-    return (int)(G < 1 ? 1 : (G > WD_MAXG ? WD_MAXG : G));
+    int64_t G = 256 / nrb;
+    G = G < 1 ? 1 : (G > WD_MAXG ? WD_MAXG : G);
+    // a workgroup's eight waves take at most one output block each (WideShare): the widest layer's blocks
+    // must fit 8 x G
+    if ((max_blocks + G - 1) / G > PL_WAVES) return 0;
+    return (int)G;
+}
+static int wide_groups_for(const abn_tower_desc* t, int64_t vrows)
+{
+    int64_t maxw = 0;
+    for (int l = 0; l <= t->n_layers; ++l) maxw = t->dims[l] > maxw ? t->dims[l] : maxw;
+    return wide_groups(vrows, pl_blocks(maxw));
 }
 
 static int planes_kind(const abn_tower_desc* t, int64_t rows, int64_t n_calls, const float* x1, const float* x2, const float* ws,
@@ -761,7 +793,7 @@ static int planes_kind(const abn_tower_desc* t, int64_t rows, int64_t n_calls, c
     }
     // small batches: one launch per layer, the output blocks dealt over several workgroups per 32 rows
     // (dropout there comes from the per-forward seed only; mask tensors stay with the chains)
-    if (allow_wide && !t->batch_norm && !any_mask && n_calls >= 1 && rows % n_calls == 0 && wide_groups(bn_vrows(rows, n_calls)) > 0) return PLANES_WIDE;
+    if (allow_wide && !t->batch_norm && !any_mask && n_calls >= 1 && rows % n_calls == 0 && wide_groups_for(t, bn_vrows(rows, n_calls)) > 0) return PLANES_WIDE;
     // a workgroup walks its 32 rows through every layer in ~50 us whatever the batch; from a few workgroups
     // up that beats the per-layer GEMMs (tools/rows_sweep.py, tools/fwd_rows_sweep.py: C2 train step 0.148 vs
     // 0.180 ms at 512 rows, 0.234 vs 0.331 at 8192; forward alone 62 vs 94 us at 5000 rows)
@@ -793,7 +825,7 @@ static int check_desc(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
 {
     ABN_REQUIRE(t != nullptr, "tower: null descriptor");
     ABN_REQUIRE(t->n_layers >= 1 && t->n_layers <= ABN_MAX_LAYERS, "tower: n_layers=%d out of range", t->n_layers);
-    ABN_REQUIRE(t->precision >= 0 && t->precision <= 2, "tower: precision=%d (0 = fp32, 1 = bf16 operands, 2 = bf16 x 3)", t->precision);
+    ABN_REQUIRE(t->precision >= 0 && t->precision <= 3, "tower: precision=%d (0 = fp32, 1 = bf16 operands, 2 = bf16 x 3, 3 = fp16 x 2)", t->precision);
     ABN_REQUIRE(rows >= 0 && n_calls >= 1 && rows % n_calls == 0, "tower: rows=%lld not divisible by n_calls=%lld",
                 (long long)rows, (long long)n_calls);
     for (int l = 0; l <= t->n_layers; ++l)
@@ -858,6 +890,7 @@ struct BwdLayout {
     int splits[ABN_MAX_LAYERS];
     int psplits[ABN_MAX_LAYERS];     // BatchNorm: the slabs of the operand-plane weight-gradient launch (bn_planes_backward)
     int64_t dzp[ABN_MAX_LAYERS];     // tower_planes.h: transposed planes of dZ_l
+    int64_t amax_dz[ABN_MAX_LAYERS]; // fp16 x 2: their maxima per 32-row block
     int64_t bn_wg;                   // bn_bwd_layer_kernel's per-workgroup sums ([rows / 32][2][PL_MAXW])
     int64_t total;
 };
@@ -888,8 +921,10 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
         smax = B.psplits[l] > smax ? B.psplits[l] : smax;
     }
     B.slabs = take(B.slab_stride * smax);
-    for (int l = 0; l < t->n_layers; ++l)
-        B.dzp[l] = planes_dims_ok(t) ? take(pl_timage_bytes(t->dims[l + 1], rows + 8 * PL_ROWS, planes_of(t->precision)) / 4) : -1;
+    for (int l = 0; l < t->n_layers; ++l) {
+        B.dzp[l] = planes_dims_ok(t) ? take(pl_timage_bytes(t->dims[l + 1], rows + 8 * PL_ROWS, planes_of(t)) / 4) : -1;
+        B.amax_dz[l] = planes_dims_ok(t) && planes_of(t) == 2 ? take(pl_amax_floats(rows + 8 * PL_ROWS)) : -1;
+    }
     B.bn_wg = planes_dims_ok(t) && t->batch_norm ? take((rows / PL_ROWS + 9) * 2 * PL_MAXW) : -1;     // (up to 8 calls, each padded)
     B.total = o;
     return B;
@@ -947,6 +982,8 @@ static WgradP make_wgrad(const abn_tower_desc* t, int64_t rows, const Layout& L,
         WgradLayer& W = w.L[w.n_layers++];
         W.dzp = reinterpret_cast<const char*>(scratch + B.dzp[l]);
         W.ap = reinterpret_cast<const char*>(ws + L.tp[l]);
+        W.amax_dz = B.amax_dz[l] >= 0 ? scratch + B.amax_dz[l] : nullptr;
+        W.amax_a = L.amax[l] >= 0 ? ws + L.amax[l] : nullptr;
         W.N = (int)t->dims[l + 1]; W.K = (int)t->dims[l];
         W.nblk = pl_blocks(W.N); W.kblk = pl_blocks(W.K + 1);
         int bn, bk;
@@ -975,7 +1012,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
                               const BwdLayout& B0, const float* ws, float* scratch, float* dx, hipStream_t st)
 {
     const int nl = t->n_layers;
-    const int np = planes_of(t->precision);
+    const int np = planes_of(t);
     const int64_t rpc = rows / n_calls;
     ABN_REQUIRE(aligned16(d_out) && aligned16(scratch) && (!dx || aligned16(dx)), "tower_backward: d_out / scratch / dx must be 16-byte aligned");
     ABN_REQUIRE(!t->d_out_is_dz, "tower_backward: d_out_is_dz cannot be combined with batch_norm");
@@ -1056,7 +1093,7 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
                            const BwdLayout& B, const float* ws, float* scratch, float* dx, hipStream_t st, int part = PLANES_BWD_ALL)
 {
     const int nl = t->n_layers;
-    const int np = planes_of(t->precision);
+    const int np = planes_of(t);
     PlanesBwdP b = {};
     b.n_layers = nl;
     b.rows = (int)rows;
@@ -1092,6 +1129,7 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
         b.mask[l] = t->drop_mask[l];
         b.wpt[l] = image + PL.wpt[l];
         b.dzp[l] = reinterpret_cast<char*>(scratch + B.dzp[l]);
+        b.amax_dz[l] = B.amax_dz[l] >= 0 ? scratch + B.amax_dz[l] : nullptr;
     }
     int n_wg = 0;
     const WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
@@ -1100,25 +1138,14 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
     (void)hipGetDevice(&dev);
     dev = (dev >= 0 && dev < 16) ? dev : 0;
     if (!bw_attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_dgrad_planes_kernel<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(1));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tower_dgrad_planes_kernel<3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(3));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<1>());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<3>());
+        PL_LDS_ATTR(tower_dgrad_planes_kernel, pl_lds_bytes);
+        PL_LDS_ATTR(wgrad_planes_kernel, wgrad_lds_of);
         bw_attr_set[dev] = true;
     }
     const dim3 cgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
     const bool do_dgrad = part != PLANES_BWD_WGRAD, do_wgrad = part != PLANES_BWD_DGRAD;
-    if (np == 3) {
-        if (do_dgrad) hipLaunchKernelGGL(tower_dgrad_planes_kernel<3>, cgrid, dim3(PL_NT), pl_lds_bytes(3), st, b);
-        if (do_wgrad) hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
-    } else {
-        if (do_dgrad) hipLaunchKernelGGL(tower_dgrad_planes_kernel<1>, cgrid, dim3(PL_NT), pl_lds_bytes(1), st, b);
-        if (do_wgrad) hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
-    }
+    if (do_dgrad) PL_LAUNCH(np, tower_dgrad_planes_kernel, cgrid, dim3(PL_NT), pl_lds_bytes(np), st, b);
+    if (do_wgrad) PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_of(np), st, w);
     ABN_CHECK_LAUNCH("tower_backward (planes)");
     if (t->defer_reduce) return ABN_OK;      // abn_tower_reduce_step finishes the job
     const ReduceTable rt = make_reduce_table(t, B);
@@ -1134,7 +1161,7 @@ static int wide_backward(const abn_tower_desc* t, const float* d_out, const Loss
                          const Layout& L, const BwdLayout& B, const float* ws, float* scratch, float* dx, hipStream_t st)
 {
     const int nl = t->n_layers, top = nl - 1;
-    const int np = planes_of(t->precision);
+    const int np = planes_of(t);
     ABN_REQUIRE((loss || aligned16(d_out)) && aligned16(scratch) && (!dx || aligned16(dx)),
                 "tower_backward: d_out / scratch / dx must be 16-byte aligned");
     ABN_REQUIRE(!loss || n_calls == 2, "tower_backward_loss: two forward_once calls");
@@ -1145,15 +1172,13 @@ static int wide_backward(const abn_tower_desc* t, const float* d_out, const Loss
     (void)hipGetDevice(&dev);
     dev = (dev >= 0 && dev < 16) ? dev : 0;
     if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_dgrad_layer_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wd_lds_bytes(1));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_dgrad_layer_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wd_lds_bytes(3));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<1>());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<3>());
+        PL_LDS_ATTR(wide_dgrad_layer_kernel, wd_lds_bytes);
+        PL_LDS_ATTR(wgrad_planes_kernel, wgrad_lds_of);
         attr_set[dev] = true;
     }
     const int64_t rpc = rows / n_calls;
     const int64_t wpc = bn_wgs_per_call(rows, n_calls), nrb = n_calls * wpc;
-    const int G = wide_groups(nrb * PL_ROWS);
+    const int G = wide_groups_for(t, nrb * PL_ROWS);
     ABN_REQUIRE(G > 0, "tower_backward: too many rows for the layer-per-launch kernels");
     const int last = dx ? 0 : 1;                      // the lowest layer a data-gradient launch runs for
     int cur = 0;
@@ -1171,6 +1196,7 @@ static int wide_backward(const abn_tower_desc* t, const float* d_out, const Loss
         q.dz_out = (l >= 1 && l - 1 >= last) ? scratch + B.dz[cur ^ 1] : nullptr;
         q.dzp_top = reinterpret_cast<char*>(scratch + B.dzp[top]);
         q.dzp_out = l >= 1 ? reinterpret_cast<char*>(scratch + B.dzp[l - 1]) : nullptr;
+        if (np == 2) { q.amax_top = scratch + B.amax_dz[top]; q.amax_out = l >= 1 ? scratch + B.amax_dz[l - 1] : nullptr; }
         q.tp_steps = 2 * nrb;
         q.dx = dx;
         q.drop_seed = reinterpret_cast<const unsigned long long*>(t->drop_seed);
@@ -1192,16 +1218,14 @@ static int wide_backward(const abn_tower_desc* t, const float* d_out, const Loss
             }
         }
         const dim3 grid((unsigned)(nrb * q.G));
-        if (np == 3) hipLaunchKernelGGL(wide_dgrad_layer_kernel<3>, grid, dim3(PL_NT), wd_lds_bytes(3), st, q);
-        else hipLaunchKernelGGL(wide_dgrad_layer_kernel<1>, grid, dim3(PL_NT), wd_lds_bytes(1), st, q);
+        PL_LAUNCH(np, wide_dgrad_layer_kernel, grid, dim3(PL_NT), wd_lds_bytes(np), st, q);
         if (l < top || q.dz_out) cur ^= (q.dz_out ? 1 : 0);
         if (l == 0) break;
     }
     int n_wg = 0;
     WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
     w.tp_steps = 2 * nrb;
-    if (np == 3) hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
-    else hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
+    PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_of(np), st, w);
     ABN_CHECK_LAUNCH("tower_backward (layer per launch)");
     if (t->defer_reduce) return ABN_OK;               // abn_tower_reduce_step finishes the job
     const ReduceTable rt = make_reduce_table(t, B);
@@ -1315,7 +1339,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
             if (!t->drop_mask[l]) { set_error("tower_forward: in-kernel dropout (drop_seed) needs the operand-plane kernels: pass drop_mask tensors"); return ABN_E_UNSUPPORTED; }
     }
     if (bn_train || kind != PLANES_NONE) {
-        const int np = planes_of(t->precision);
+        const int np = planes_of(t);
         PackTable pk = {};
         PlanesFwdP f = {};
         f.n_layers = t->n_layers;
@@ -1339,15 +1363,20 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
             J.W = t->W[l]; J.N = (int)t->dims[l + 1]; J.K = (int)t->dims[l]; J.transposed = 0;
             J.nblk = pl_blocks(J.N); J.nsteps = pl_steps(J.K);
             J.tile0 = pk.n_tiles; J.dst = PL.wp[l];
+            J.blk0 = pk.n_blocks;
             pk.n_tiles += J.nblk * J.nsteps;
+            pk.n_blocks += J.nblk;
             {                                    // W_l^T for the backward's data-gradient chain (l = 0: d loss / d input)
                 PackJob& T = pk.job[pk.n_jobs++];
                 T.W = t->W[l]; T.N = J.N; T.K = J.K; T.transposed = 1;
                 T.nblk = pl_blocks(T.K); T.nsteps = pl_steps(T.N);
                 T.tile0 = pk.n_tiles; T.dst = PL.wpt[l];
+                T.blk0 = pk.n_blocks;
                 pk.n_tiles += T.nblk * T.nsteps;
+                pk.n_blocks += T.nblk;
             }
             f.tp[l] = (t->forward_only || t->batch_norm) ? nullptr : reinterpret_cast<char*>(ws + L.tp[l]);     // (inference: nothing kept for a backward)
+            f.amax[l] = f.tp[l] && L.amax[l] >= 0 ? ws + L.amax[l] : nullptr;
             if (t->batch_norm) { f.bn_rm[l] = t->bn_rm[l]; f.bn_rv[l] = t->bn_rv[l]; f.bn_w[l] = t->bn_w[l]; f.bn_b[l] = t->bn_b[l]; }
         }
         f.tp_steps = pl_row_steps(rows);
@@ -1365,18 +1394,18 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         const dim3 fgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
         if (repack) {
             if (np == 3) hipLaunchKernelGGL(pack_planes_kernel<3>, pgrid, dim3(256), 0, st, pk);
+            else if (np == 2) hipLaunchKernelGGL(pack_planes_scaled_kernel, dim3((unsigned)pk.n_blocks), dim3(PL_NT), 0, st, pk);
             else hipLaunchKernelGGL(pack_planes_kernel<1>, pgrid, dim3(256), 0, st, pk);
         }
         if (!bn_train && kind == PLANES_WIDE) {
             static bool wd_attr_set[16] = {};
             if (!wd_attr_set[dev]) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_fwd_layer_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wd_lds_bytes(1));
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_fwd_layer_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wd_lds_bytes(3));
+                PL_LDS_ATTR(wide_fwd_layer_kernel, wd_lds_bytes);
                 wd_attr_set[dev] = true;
             }
             const int nl = t->n_layers;
             const int64_t wpc = bn_wgs_per_call(rows, n_calls), nrb = n_calls * wpc;
-            const int G = wide_groups(nrb * PL_ROWS);
+            const int G = wide_groups_for(t, nrb * PL_ROWS);
             const bool keep = !t->forward_only;              // transposed images for a backward
             for (int l = 0; l < nl; ++l) {
                 WideFwdP q = {};
@@ -1394,14 +1423,14 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 q.out = q.last ? ws + L.a[l] : nullptr;
                 q.tp_in = keep && l == 0 ? reinterpret_cast<char*>(ws + L.tp[0]) : nullptr;
                 q.tp_out = keep && !q.last ? reinterpret_cast<char*>(ws + L.tp[l + 1]) : nullptr;
+                if (np == 2 && keep) { q.amax_in = ws + L.amax[0]; q.amax_out = q.last ? nullptr : ws + L.amax[l + 1]; }
                 q.tp_steps = 2 * nrb;
                 q.drop_seed = f.drop_seed; q.drop_p = f.drop_p;
 #ifdef ABN_STAMPS
                 q.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
 #endif
                 const dim3 wgrid((unsigned)(nrb * q.G));
-                if (np == 3) hipLaunchKernelGGL(wide_fwd_layer_kernel<3>, wgrid, dim3(PL_NT), wd_lds_bytes(3), st, q);
-                else hipLaunchKernelGGL(wide_fwd_layer_kernel<1>, wgrid, dim3(PL_NT), wd_lds_bytes(1), st, q);
+                PL_LAUNCH(np, wide_fwd_layer_kernel, wgrid, dim3(PL_NT), wd_lds_bytes(np), st, q);
             }
             ABN_CHECK_LAUNCH("tower_forward (layer per launch)");
             last_forward_path = 6;
@@ -1450,20 +1479,23 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         const bool infer = t->batch_norm || (t->forward_only && !f.drop_seed && !train);
         const int mode = t->batch_norm ? PL_INFER_BN : infer ? PL_INFER : PL_TRAIN;
         const size_t lds = t->batch_norm ? pl_lds_bytes_bn(np) : pl_lds_bytes(np);
-        const void* kernels[2][3] = {
+        const void* kernels[3][3] = {
             {reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_TRAIN>), reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_INFER>),
              reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_INFER_BN>)},
+            {reinterpret_cast<const void*>(tower_fwd_planes_kernel<2, PL_TRAIN>), reinterpret_cast<const void*>(tower_fwd_planes_kernel<2, PL_INFER>),
+             nullptr},
             {reinterpret_cast<const void*>(tower_fwd_planes_kernel<3, PL_TRAIN>), reinterpret_cast<const void*>(tower_fwd_planes_kernel<3, PL_INFER>),
              reinterpret_cast<const void*>(tower_fwd_planes_kernel<3, PL_INFER_BN>)}};
         if (!pl_attr_set[dev]) {
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 3; ++a)
                 for (int m = 0; m < 3; ++m)
-                    (void)hipFuncSetAttribute(kernels[a][m], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)(m == PL_INFER_BN ? pl_lds_bytes_bn(a ? 3 : 1) : pl_lds_bytes(a ? 3 : 1)));
+                    if (kernels[a][m])
+                        (void)hipFuncSetAttribute(kernels[a][m], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)(m == PL_INFER_BN ? pl_lds_bytes_bn(a + 1) : pl_lds_bytes(a + 1)));
             pl_attr_set[dev] = true;
         }
         void* kargs[] = {&f};
-        (void)hipLaunchKernel(kernels[np == 3][mode], fgrid, dim3(PL_NT), kargs, lds, st);
+        (void)hipLaunchKernel(kernels[np - 1][mode], fgrid, dim3(PL_NT), kargs, lds, st);
         last_forward_path = 2 + mode;
         ABN_CHECK_LAUNCH("tower_fwd_planes");
         return ABN_OK;
@@ -1473,7 +1505,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         f.n_layers = t->n_layers;
         f.rows = (int)rows;
         f.rows_call = (int)rpc;
-        f.bf16 = t->precision;
+        f.bf16 = gemm_prec(t->precision);
         f.x1 = x1; f.x2 = x2;
         f.x_copy = x2 ? ws + L.x : nullptr;
         for (int l = 0; l <= t->n_layers; ++l) f.dims[l] = (int)t->dims[l];
@@ -1531,7 +1563,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         p.a_vec = aligned16(in) && (K % 4 == 0);
         p.b_vec = aligned16(t->W[l]) && (K % 4 == 0);
         p.ones_col = -1;
-        p.bf16 = t->precision;
+        p.bf16 = gemm_prec(t->precision);
         if (!t->batch_norm) {
             p.C = a; p.ldc = N; p.act = act;
             rc = launch_gemm<true, true, EPI_FWD>(p, 1, st);
@@ -1639,7 +1671,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
         pw.M = Nout; pw.N = Kin + 1; pw.K = (int)rows;
         pw.k_chunk = (int)align_up((rows + B.splits[l] - 1) / B.splits[l], BK);
         pw.ones_col = Kin;
-        pw.bf16 = t->precision;
+        pw.bf16 = gemm_prec(t->precision);
         pw.a_vec = aligned16(dz) && (Nout % 4 == 0);
         pw.b_vec = aligned16(a_in) && (Kin % 4 == 0);
         // slices past the end of the reduction write zero slabs (k range empty)
@@ -1659,7 +1691,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
             p.a_vec = aligned16(dz) && (Nout % 4 == 0);
             p.b_vec = aligned16(t->W[l]) && (Kin % 4 == 0);
             p.ones_col = -1;
-            p.bf16 = t->precision;
+            p.bf16 = gemm_prec(t->precision);
             if (l > 0 && !t->batch_norm) { p.aux = ws + L.a[l - 1]; p.ldaux = Kin; p.act = t->act; p.mask = t->drop_mask[l - 1]; }
             rc = launch_bwd_pair(pw, B.splits[l], p, st);
             if (rc != ABN_OK) return rc;
@@ -1859,7 +1891,7 @@ int abn_linear_backward_prec(const float* dz, const float* W, const float* a_in,
                              int64_t out_dim, int act_prev, int precision, float* dW, float* db, float* dx,
                              float* scratch, int64_t scratch_floats, void* stream)
 {
-    ABN_REQUIRE(precision >= 0 && precision <= 2, "linear_backward: precision=%d (0 = fp32, 1 = bf16, 2 = bf16 x 3)", precision);
+    ABN_REQUIRE(precision >= 0 && precision <= 3, "linear_backward: precision=%d (0 = fp32, 1 = bf16, 2 = bf16 x 3, 3 = fp16 x 2: run as bf16 x 3 here)", precision);
     ABN_REQUIRE(dz && W && a_in && dx && scratch && ((dW == nullptr) == (db == nullptr)), "linear_backward: null pointer");
     ABN_REQUIRE(rows >= 1 && rows < (1LL << 30) && in_dim >= 1 && out_dim >= 1 && in_dim < (1 << 24) && out_dim < (1 << 24),
                 "linear_backward: bad shape");
@@ -1887,7 +1919,7 @@ int abn_linear_backward_prec(const float* dz, const float* W, const float* a_in,
     pd.aux = act_prev == ABN_ACT_NONE ? nullptr : a_in; pd.ldaux = in_dim; pd.act = act_prev; pd.ones_col = -1;
     pd.a_vec = aligned16(dz) && (out_dim % 4 == 0);
     pd.b_vec = aligned16(W) && (in_dim % 4 == 0);
-    pw.bf16 = pd.bf16 = precision;
+    pw.bf16 = pd.bf16 = gemm_prec(precision);
     int rc = launch_bwd_pair(pw, splits, pd, st);
     if (rc != ABN_OK) return rc;
     if (!dW) return ABN_OK;                      // slabs left unreduced in scratch: the pair grid alone (kernel timing)

@@ -57,20 +57,27 @@ constexpr int PL_DEPTH = PL_DEPTH_OVERRIDE;
 constexpr int PL_DEPTH = 4;                       // weight steps in flight per wave (registers)
 #endif
 constexpr int PL_PART_BYTES = 4 * 16 * 64 * 4;    // K-split hand-over: 4 waves x one accumulator block
+// fp16 x 2 (NP == 2): per-lane partial maxima of the workgroup's 32 rows [8 waves][64 lanes], then one table of
+// the rows' inverse scales per wave [8][32]
+constexpr int PL_SC_BYTES = PL_WAVES * 64 * 4 + PL_WAVES * 32 * 4;
+constexpr int PL_AMAX = 32;                       // floats per 32-row block in an image's table of maxima (wgrad's scales)
 
 __host__ __device__ inline int pl_steps(int64_t contraction) { return ((int)((contraction + 15) / 16) + PL_DEPTH - 1) / PL_DEPTH * PL_DEPTH; }
 __host__ __device__ inline int pl_blocks(int64_t features) { return (int)((features + 31) / 32); }
+// (np == 2: one inverse scale per 32-row block behind the fragments)
 static inline int64_t pl_image_bytes(int64_t features, int64_t contraction, int np)
 {
-    return (int64_t)pl_blocks(features) * pl_steps(contraction) * np * 1024;
+    return (int64_t)pl_blocks(features) * pl_steps(contraction) * np * 1024 + (np == 2 ? (pl_blocks(features) * 4 + 255) / 256 * 256 : 0);
 }
 // batch-row steps of the transposed (weight-gradient) images: two per 32-row workgroup
 static inline int64_t pl_row_steps(int64_t rows) { return (rows + PL_ROWS - 1) / PL_ROWS * 2; }
-// bytes of one (block, row step) tile of a transposed image: 64 lanes x 8 fp32 (bf16 x 3) or 8 bf16 (bf16)
-template <int NP> constexpr int tile_bytes() { return NP == 3 ? 2048 : 1024; }
-static inline int64_t pl_timage_bytes(int64_t features, int64_t rows, int np) { return (int64_t)pl_blocks(features) * pl_row_steps(rows) * (np == 3 ? 2048 : 1024); }
+// bytes of one (block, row step) tile of a transposed image: 64 lanes x 8 fp32 (bf16 x 3, fp16 x 2) or 8 bf16 (bf16)
+template <int NP> constexpr int tile_bytes() { return NP >= 2 ? 2048 : 1024; }
+static inline int64_t pl_timage_bytes(int64_t features, int64_t rows, int np) { return (int64_t)pl_blocks(features) * pl_row_steps(rows) * (np >= 2 ? 2048 : 1024); }
+// floats of an image's table of maxima: PL_AMAX per 32-row block
+static inline int64_t pl_amax_floats(int64_t rows) { return pl_row_steps(rows) / 2 * PL_AMAX; }
 constexpr int PL_BIAS_BYTES = PL_WAVES * 64 * 4;   // a wave's 64 bias values, parked in LDS across its k-loop
-static inline size_t pl_lds_bytes(int np) { return (size_t)PL_MAXSTEPS * np * 1024 + PL_PART_BYTES + PL_BIAS_BYTES; }
+static inline size_t pl_lds_bytes(int np) { return (size_t)PL_MAXSTEPS * np * 1024 + PL_PART_BYTES + PL_SC_BYTES + PL_BIAS_BYTES; }
 // the inference forward of a BatchNorm tower parks four more per-feature vectors beside the bias
 static inline size_t pl_lds_bytes_bn(int np) { return pl_lds_bytes(np) + 4 * PL_BIAS_BYTES; }
 
@@ -83,15 +90,54 @@ static inline size_t pl_lds_bytes_bn(int np) { return pl_lds_bytes(np) + 4 * PL_
 // ---------------------------------------------------------------------------------------------
 // fragments
 // ---------------------------------------------------------------------------------------------
-template <int NP> struct Frag { bf16x8 p[NP]; };
+template <int NP> struct Frag { bf16x8 p[NP]; };        // (NP == 2: the 16 bytes are eight fp16 values)
+
+// fp16 x 2 (NP == 2): an fp32 value u = s x (s a power of two that puts the largest |x| of the operand row in
+// [2^14, 2^15)) as hi + lo, hi = fp16(u), lo = fp16(u - hi): 22 significant bits, the difference exact in fp32.
+// A product is summed from lo.hi + hi.lo + hi.hi (dropped: lo.lo <= 2^-22 of it) on v_mfma_f32_32x32x16_f16 --
+// three MFMAs per 16 k and block where bf16 x 3 issues six, two planes to stream instead of three -- and the
+// accumulator is multiplied by the two inverse scales (exact) in the epilogue.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// scale of an operand row whose largest magnitude is m (>= 0), and its inverse
+__device__ __forceinline__ void scale_of(float m, float& s, float& inv)
+{
+    unsigned e = __float_as_uint(m) >> 23;
+    e = e > 240u ? 240u : e;
+    const bool tiny = e < 27u;                          // zero rows, and magnitudes whose products are below fp32 anyway
+    s = tiny ? 1.0f : __uint_as_float((268u - e) << 23);
+    inv = tiny ? 1.0f : __uint_as_float((e - 14u) << 23);
+}
 
 template <int NP>
-__device__ __forceinline__ Frag<NP> make_frag(const f32x4& v0, const f32x4& v1)
+__device__ __forceinline__ f32x16 pl_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c)
+{
+    if constexpr (NP == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// the products of one k-step, smallest terms first: plane of the A operand, plane of the B operand
+template <int NP> struct Products;
+template <> struct Products<1> { static constexpr int N = 1; static constexpr int A[1] = {0}, B[1] = {0}; };
+template <> struct Products<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0}; };
+template <> struct Products<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}, B[6] = {0, 2, 1, 0, 1, 0}; };
+
+template <int NP>
+__device__ __forceinline__ Frag<NP> make_frag(const f32x4& v0, const f32x4& v1, float scale = 1.0f)
 {
     Frag<NP> f;
     if constexpr (NP == 3) {
         const bf16x8x3 s = split_bf16x3(v0, v1);
         f.p[0] = s.hi; f.p[1] = s.mid; f.p[2] = s.lo;
+    } else if constexpr (NP == 2) {
+        f16x8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float u = (i < 4 ? v0[i] : v1[i - 4]) * scale;
+            const _Float16 h = (_Float16)u;
+            hi[i] = h;
+            lo[i] = (_Float16)(u - (float)h);
+        }
+        f.p[0] = __builtin_bit_cast(bf16x8, hi); f.p[1] = __builtin_bit_cast(bf16x8, lo);
     } else {
         f.p[0] = pack_bf16(v0, v1);
     }
@@ -106,27 +152,74 @@ __device__ __forceinline__ void store_frag(char* dst, const Frag<NP>& f)
 }
 
 template <int NP>
-__device__ __forceinline__ void write_frag(char* dst, const f32x4& v0, const f32x4& v1)
+__device__ __forceinline__ void write_frag(char* dst, const f32x4& v0, const f32x4& v1, float scale = 1.0f)
 {
-    store_frag<NP>(dst, make_frag<NP>(v0, v1));
+    store_frag<NP>(dst, make_frag<NP>(v0, v1, scale));
+}
+
+// largest magnitude of a lane's eight values
+__device__ __forceinline__ float absmax8(const f32x4& v0, const f32x4& v1)
+{
+    float m = fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3])));
+    return fmaxf(m, fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// The fp16 x 2 scales of a workgroup's 32 rows.  Every lane has parked the largest magnitude it holds of row
+// lane & 31 in sc[wave][lane] (a workgroup barrier since): the row's scale and inverse for this lane, the inverse
+// also in this wave's table (emit_planes reads it back as the 16-byte pieces the transposed tile wants).
+__device__ __forceinline__ float row_scales(float* __restrict__ sc, int wave, int lane, float& s, float& inv)
+{
+    const int r = lane & 31;
+    float m = 0.0f;
+#pragma unroll
+    for (int w = 0; w < PL_WAVES; ++w) m = fmaxf(m, fmaxf(sc[w * 64 + r], sc[w * 64 + 32 + r]));
+    scale_of(m, s, inv);
+    float* const tab = sc + PL_WAVES * 64 + wave * 32;
+    tab[r] = inv;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");        // (this wave's own LDS accesses complete in order)
+    __builtin_amdgcn_wave_barrier();
+    return m;
+}
+// An image's maxima for the weight-gradient launch: PL_AMAX floats per 32-row block -- here the block's one maximum
+// (every feature of the image) and zeros.  m: this lane's row maximum; floor: 1 for the images with a column of ones.
+__device__ __forceinline__ void store_amax_rows(float* __restrict__ amax_rb, float m, float floor_, int lane)
+{
+    const float M = fmaxf(wave_max(m), floor_);
+    if (lane < PL_AMAX) amax_rb[lane] = lane == 0 ? M : 0.0f;
 }
 
 // B operand of the transposing product: element j of lane (c, h) in step s is 1 where the (permuted)
 // k index 16 s + 8 (j >> 2) + 4 h + (j & 3) equals the column c
+template <int NP>
 __device__ __forceinline__ void make_identity(bf16x8 idf[2], int lane)
 {
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
+        if constexpr (NP == 2) {
+            f16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) idf[s][j] = (__bf16)((16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) == c ? 1.0f : 0.0f);
+            for (int j = 0; j < 8; ++j) o[j] = (_Float16)((16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) == c ? 1.0f : 0.0f);
+            idf[s] = __builtin_bit_cast(bf16x8, o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) idf[s][j] = (__bf16)((16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) == c ? 1.0f : 0.0f);
+        }
+    }
 }
 
 // One 32-feature block of one workgroup (32 batch rows), held as the two k-steps' fragments f[0], f[1]
 // (lane = batch row), written transposed: dst -> timage[block][this workgroup's first row step].
 // ones_c >= 0: that column of the block is the appended column of ones (rows below rows_left only).
+// inv_tab (fp16 x 2): the 32 rows' inverse scales (LDS) -- the image holds the values themselves, hi + lo unscaled.
 template <int NP>
-__device__ __forceinline__ void emit_planes(char* dst, const Frag<NP> f[2], const bf16x8 idf[2], int lane, int ones_c, int rows_left)
+__device__ __forceinline__ void emit_planes(char* dst, const Frag<NP> f[2], const bf16x8 idf[2], int lane, int ones_c, int rows_left,
+                                            const float* __restrict__ inv_tab = nullptr)
 {
     const int c = lane & 31, h = lane >> 5;
     f32x16 t;                  // t[q] of lane (c, h) = feature c of batch row (q & 3) + 8 (q >> 2) + 4 h
@@ -135,10 +228,18 @@ __device__ __forceinline__ void emit_planes(char* dst, const Frag<NP> f[2], cons
         f32x16 u;
 #pragma unroll
         for (int q = 0; q < 16; ++q) u[q] = 0.0f;
-        u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0].p[pl], idf[0], u, 0, 0, 0);
-        u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1].p[pl], idf[1], u, 0, 0, 0);
+        u = pl_mfma<NP>(f[0].p[pl], idf[0], u);
+        u = pl_mfma<NP>(f[1].p[pl], idf[1], u);
         if (pl == 0) t = u;
-        else t += u;           // hi + mid, then + lo: exact, the three terms do not overlap
+        else t += u;           // hi + mid, then + lo: exact, the terms do not overlap
+    }
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 iv = *reinterpret_cast<const f32x4*>(inv_tab + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[4 * g + e] *= iv[e];
+        }
     }
     if (c == ones_c) {
 #pragma unroll
@@ -146,7 +247,7 @@ __device__ __forceinline__ void emit_planes(char* dst, const Frag<NP> f[2], cons
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        if constexpr (NP == 3) {       // tile = [elements 0..3 | 4..7][lane][4 floats]: two lane-linear 1 KB halves
+        if constexpr (NP >= 2) {       // tile = [elements 0..3 | 4..7][lane][4 floats]: two lane-linear 1 KB halves
             char* o = dst + s * 2048 + lane * 16;
             *reinterpret_cast<f32x4*>(o) = f32x4{t[8 * s], t[8 * s + 1], t[8 * s + 2], t[8 * s + 3]};
             *reinterpret_cast<f32x4*>(o + 1024) = f32x4{t[8 * s + 4], t[8 * s + 5], t[8 * s + 6], t[8 * s + 7]};
@@ -167,13 +268,13 @@ __device__ __forceinline__ int tgather_row_offset(int r)
 {
     // r = 16 s' + 8 (j >> 2) + 4 h' + (j & 3)
     const int sp = r >> 4, jh = (r >> 3) & 1, jl = r & 3, hp = (r >> 2) & 1;
-    if constexpr (NP == 3) return sp * 2048 + jh * 1024 + hp * 32 * 16 + jl * 4;      // + c * 16
+    if constexpr (NP >= 2) return sp * 2048 + jh * 1024 + hp * 32 * 16 + jl * 4;      // + c * 16
     else return sp * 1024 + hp * 32 * 16 + (4 * jh + jl) * 2;                         // + c * 16
 }
 template <int NP>
 __device__ __forceinline__ float tgather(const char* tile_pair, int row_off, int c)
 {
-    if constexpr (NP == 3) return *reinterpret_cast<const float*>(tile_pair + row_off + c * 16);
+    if constexpr (NP >= 2) return *reinterpret_cast<const float*>(tile_pair + row_off + c * 16);
     else return (float)*reinterpret_cast<const __bf16*>(tile_pair + row_off + c * 16);
 }
 
@@ -189,10 +290,11 @@ struct PackJob {
                            // 1: operand rows are input features, sum over n (backward, W^T)
     int nblk, nsteps;
     int tile0;             // first tile (block, step) of this job in the launch
+    int blk0;              // first 32-row block of this job in the launch (pack_planes_scaled_kernel: a workgroup per block)
     int64_t dst;           // byte offset of the image
 };
 struct PackTable {
-    int n_jobs, n_tiles;
+    int n_jobs, n_tiles, n_blocks;
     char* base;
     PackJob job[2 * ABN_MAX_LAYERS];
 };
@@ -226,6 +328,71 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(PackTable t)
         }
     }
     write_frag<NP>(t.base + J.dst + ((int64_t)local * NP) * 1024 + lane * 16, v0, v1);
+}
+
+// fp16 x 2: a workgroup per 32-row block of an image.  Its waves take the block's steps (at most four each: K <=
+// 512) into registers, agree on the block's largest magnitude through LDS, and write the fragments scaled by the
+// block's power of two; the inverse goes behind the image's fragments (one float per block), where the chains'
+// epilogues pick it up.  One pass over the weights, no launch of its own for the maxima.
+__global__ __launch_bounds__(PL_NT) void pack_planes_scaled_kernel(PackTable t)
+{
+    __shared__ float wmax[PL_WAVES];
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    int jn = 0;
+    while (jn + 1 < t.n_jobs && b >= t.job[jn + 1].blk0) ++jn;
+    const PackJob& J = t.job[jn];
+    const int nb = b - J.blk0;
+    const int rows_a = J.transposed ? J.K : J.N;     // operand rows in the matrix
+    const int len_c = J.transposed ? J.N : J.K;      // length of the sum (a multiple of 4)
+    const int a = 32 * nb + r;                       // operand row
+    const int ac = a < rows_a ? a : rows_a - 1;
+    constexpr int SPW = PL_MAXSTEPS / PL_WAVES;      // steps per wave
+    // (every load from a clamped address, the padding selected away afterwards: conditional stores into v would
+    // carry the whole array through each branch)
+    f32x4 v[SPW][2];
+    float m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+        const int s = wave + PL_WAVES * i;
+        const bool live = s < J.nsteps && a < rows_a;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = 16 * s + 4 * h + 8 * u;
+            const int cc = c < len_c ? c : len_c - 4;
+            f32x4 x;
+            if (!J.transposed) {
+                x = *reinterpret_cast<const f32x4*>(J.W + (int64_t)ac * J.K + cc);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = J.W[(int64_t)(cc + e) * J.K + ac];
+            }
+            const bool ok = live && c < len_c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][u][e] = ok ? x[e] : 0.0f;
+        }
+        m = fmaxf(m, absmax8(v[i][0], v[i][1]));
+    }
+    m = wave_max(m);
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < PL_WAVES; ++w) m = fmaxf(m, wmax[w]);
+    float sc, inv;
+    scale_of(m, sc, inv);
+    char* const image = t.base + J.dst;
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+        const int s = wave + PL_WAVES * i;
+        if (s < J.nsteps) write_frag<2>(image + ((int64_t)(nb * J.nsteps + s) * 2) * 1024 + lane * 16, v[i][0], v[i][1], sc);
+    }
+    if (threadIdx.x == 0) reinterpret_cast<float*>(image + (int64_t)J.nblk * J.nsteps * 2048)[nb] = inv;
+}
+// the inverse scale of block blk of a packed image (fp16 x 2)
+__device__ __forceinline__ float packed_inv(const char* __restrict__ image, int nblk, int nsteps, int blk)
+{
+    return reinterpret_cast<const float*>(image + (int64_t)nblk * nsteps * 2048)[blk < nblk ? blk : nblk - 1];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -275,19 +442,12 @@ __device__ __forceinline__ void planes_kloop(f32x16* acc, const char* __restrict
             for (int pl = 0; pl < NP; ++pl) af[(i + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(ab + (s1 * NP + pl) * 1024);
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8* a = af[i & 1];
-            if constexpr (NP == 3) {
-                // smallest terms first (gemm_f32.h); the blocks alternate so that consecutive MFMAs are independent
-                constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, AP[6] = {0, 2, 1, 0, 1, 0};
+            // smallest terms first (gemm_f32.h); the blocks alternate so that consecutive MFMAs are independent
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int j = 0; j < BPW; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[i][j][WP[t]]), a[AP[t]], acc[j], 0, 0, 0);
-            } else {
+            for (int t = 0; t < Products<NP>::N; ++t)
 #pragma unroll
                 for (int j = 0; j < BPW; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[i][j][0]), a[0], acc[j], 0, 0, 0);
-            }
+                    acc[j] = pl_mfma<NP>(__builtin_bit_cast(bf16x8, wq[i][j][Products<NP>::A[t]]), a[Products<NP>::B[t]], acc[j]);
             // (pure MFMA nodes float across a sched_barrier at instruction selection: the empty asm
             // ties the accumulators, and with them every MFMA of the step, in front of the refills)
 #pragma unroll
@@ -397,6 +557,7 @@ struct PlanesFwdP {
     // outputs of layer l < n_layers - 1
     char* tp[ABN_MAX_LAYERS];
     int64_t tp_steps;              // row steps of those images (pl_row_steps(rows))
+    float* amax[ABN_MAX_LAYERS];   // fp16 x 2: tp[l]'s maxima, PL_AMAX floats per 32-row block (the weight-gradient launch's scales)
     const unsigned long long* drop_seed;   // in-kernel dropout for the layers without a mask tensor (null: off)
     float drop_p;
     // BatchNorm with running statistics (the BN instantiation only: inference), after the bias and before the
@@ -435,10 +596,11 @@ __device__ __forceinline__ float half_wave_sum(float v)
     return v;
 }
 
+// ainv (fp16 x 2): the inverse scale of this lane's row in img -- in: the layer's input, out: its output.
 template <int NP, int BPW, int KS, int MODE = PL_TRAIN>
 __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* __restrict__ img,
                                              float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0,
-                                             int row_end = -1)
+                                             float& ainv, int row_end = -1)
 {
     constexpr bool BN = MODE == PL_INFER_BN, INFER = MODE == PL_INFER || MODE == PL_INFER_BN, BNT = MODE == PL_BN_TRAIN;
     const int rows_lim = row_end >= 0 ? row_end : p.rows;      // (BatchNorm training: the end of the workgroup's forward_once call)
@@ -461,6 +623,9 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     // k-loop, parked in a per-wave LDS slot after it and read back as the 16-byte pieces the
     // accumulator layout wants (32 registers held across the k-loop spilled the bf16 x 3 kernel).
     float bias_lane = 0.0f, bn_lane[4] = {0.0f, 1.0f, 1.0f, 0.0f};      // running mean, running variance, gamma, beta
+    float cinv[BPW];                                   // fp16 x 2: what turns an accumulator into the product
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) cinv[j] = NP == 2 && ws.active ? packed_inv(p.wp[l], nblk, nsteps, blk0 + j) * ainv : 1.0f;
     {
         const float* __restrict__ bias = p.b[l];
         const int n = 32 * blk0 + lane;
@@ -481,7 +646,8 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     const bool masked = mask || drop.on;
     const int gr = row0 + r;
     const bool row_ok = gr < rows_lim;
-    float* const bias_s = part + PL_PART_BYTES / 4 + wave * 64;
+    float* const sc = part + PL_PART_BYTES / 4;                // fp16 x 2: row maxima and inverse scales
+    float* const bias_s = part + (PL_PART_BYTES + PL_SC_BYTES) / 4 + wave * 64;
     bias_s[lane] = bias_lane;
     if (BN) {
         bias_s[PL_BIAS_BYTES / 4 + lane] = bn_lane[0];
@@ -528,7 +694,7 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc[j][4 * g + e] + b4[e];
+                        float v = (NP == 2 ? acc[j][4 * g + e] * cinv[j] : acc[j][4 * g + e]) + b4[e];
                         if (BN) v = ((v - mu4[e]) * is4[e]) * ga4[e] + be4[e];
                         if (masked) v *= m4[e];
                         acc[j][4 * g + e] = live ? act_apply(v, ACT) : 0.0f;
@@ -537,8 +703,22 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
                 }
         });
     };
+    // fp16 x 2: a layer whose output is multiplied again agrees on its rows' scales -- every lane parks the largest
+    // magnitude it holds of its row in front of the barrier (K-split layers: behind it, and a second barrier)
+    const bool rescale = NP == 2 && !BNT && l + 1 < p.n_layers;
+    auto park_max = [&]() {
+        float m = 0.0f;
+        if (ws.active && ws.khalf == 0) {
+#pragma unroll
+            for (int j = 0; j < BPW; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) m = fmaxf(m, fabsf(acc[j][q]));
+        }
+        sc[wave * 64 + lane] = m;
+    };
     if (KS == 1) {
         if (ws.active) finish();
+        if (rescale) park_max();
     } else if (ws.active && ws.khalf == 1) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) part[((wave & 3) * 16 + q) * 64 + lane] = acc[0][q];
@@ -551,6 +731,15 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
         for (int q = 0; q < 16; ++q) acc[0][q] += part[(wave * 16 + q) * 64 + lane];
         finish();
     }
+    float osc = 1.0f;                              // this lane's row: the scale of the output fragments
+    if (rescale) {
+        if (KS == 2) { park_max(); __syncthreads(); }
+        float oinv;
+        const float m = row_scales(sc, wave, lane, osc, oinv);
+        ainv = oinv;
+        if (!INFER && wave == 0) store_amax_rows(p.amax[l + 1] + (int64_t)blockIdx.x * PL_AMAX, m, 1.0f, lane);
+    }
+    const float* const inv_tab = sc + PL_WAVES * 64 + wave * 32;
     float* __restrict__ out = p.out[l];
     char* const tp = !INFER && !BNT && l + 1 < p.n_layers ? p.tp[l + 1] : nullptr;
     if (BNT && ws.active && ws.khalf == 0) {
@@ -594,8 +783,8 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
                 for (int t2 = 0; t2 < 2; ++t2) {
                     const f32x4 v0 = {acc[j][8 * t2], acc[j][8 * t2 + 1], acc[j][8 * t2 + 2], acc[j][8 * t2 + 3]};
                     const f32x4 v1 = {acc[j][8 * t2 + 4], acc[j][8 * t2 + 5], acc[j][8 * t2 + 6], acc[j][8 * t2 + 7]};
-                    if (!BNT) {
-                        f[t2] = make_frag<NP>(v0, v1);
+                    if (!BNT && (NP != 2 || rescale)) {
+                        f[t2] = make_frag<NP>(v0, v1, osc);
                         store_frag<NP>(img + (int64_t)(2 * blk + t2) * (NP * 1024) + lane * 16, f[t2]);
                     }
                     const int n = 32 * blk + 16 * t2 + 4 * h;
@@ -604,13 +793,13 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
                 }
                 if (tp)
                     emit_planes<NP>(tp + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
-                                    blk == N / 32 ? N % 32 : -1, rows_lim - row0);
+                                    blk == N / 32 ? N % 32 : -1, rows_lim - row0, inv_tab);
             }
         }
     }
     if (tp && N % 32 == 0 && wave == PL_WAVES - 1) {       // the column of ones opens a block of its own
         Frag<NP> z[2] = {};
-        emit_planes<NP>(tp + ((int64_t)nblk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, rows_lim - row0);
+        emit_planes<NP>(tp + ((int64_t)nblk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, rows_lim - row0, inv_tab);
     }
     PSTAMPF(6 + 5 * l);
     // steps of the next layer's padding that no block of this layer covers
@@ -627,8 +816,8 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
 // The input rows of a workgroup -> operand fragments in img (+ the concatenated copy, + the transposed image
 // for the weight gradient).
 template <int NP, bool INFER>
-__device__ __forceinline__ void planes_input_stage(const PlanesFwdP& p, char* __restrict__ img, const bf16x8* idf, int wave,
-                                                   int lane, int row0, int row_end = -1)
+__device__ __forceinline__ void planes_input_stage(const PlanesFwdP& p, char* __restrict__ img, float* __restrict__ part,
+                                                   const bf16x8* idf, int wave, int lane, int row0, float& ainv, int row_end = -1)
 {
     const int rows_lim = row_end >= 0 ? row_end : p.rows;
     const int r = lane & 31, h = lane >> 5;
@@ -640,31 +829,77 @@ __device__ __forceinline__ void planes_input_stage(const PlanesFwdP& p, char* __
     const int gr = row0 + r;
     const float* src = nullptr;
     if (gr < rows_lim) src = (p.x2 && gr >= p.rows_call) ? p.x2 + (int64_t)(gr - p.rows_call) * D0 : p.x1 + (int64_t)gr * D0;
-    for (int kb = wave; kb < blocks0; kb += PL_WAVES) {
-        Frag<NP> f[2];
+    float* const sc = part + PL_PART_BYTES / 4;
+    const float* const inv_tab = sc + PL_WAVES * 64 + wave * 32;
+    if constexpr (NP == 2) {
+        // fp16 x 2: a wave's (up to two) blocks wait in registers until the workgroup has agreed on the rows' scales
+        f32x4 v[2][2][2];                               // [block of this wave][step of the block][half]
+        float m = 0.0f;
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const int s = 2 * kb + t2;
-            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-            const int c0 = 16 * s + 4 * h, c1 = c0 + 8;
-            if (src && c0 < D0) {
-                v0 = *reinterpret_cast<const f32x4*>(src + c0);
-                if (p.x_copy) *reinterpret_cast<f32x4*>(p.x_copy + (int64_t)gr * D0 + c0) = v0;
+        for (int u = 0; u < 2; ++u) {
+            const int kb = wave + PL_WAVES * u;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int c0 = 16 * (2 * kb + t2) + 4 * h, c1 = c0 + 8;
+                v[u][t2][0] = v[u][t2][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (src && kb < blocks0 && c0 < D0) {
+                    v[u][t2][0] = *reinterpret_cast<const f32x4*>(src + c0);
+                    if (p.x_copy) *reinterpret_cast<f32x4*>(p.x_copy + (int64_t)gr * D0 + c0) = v[u][t2][0];
+                }
+                if (src && kb < blocks0 && c1 < D0) {
+                    v[u][t2][1] = *reinterpret_cast<const f32x4*>(src + c1);
+                    if (p.x_copy) *reinterpret_cast<f32x4*>(p.x_copy + (int64_t)gr * D0 + c1) = v[u][t2][1];
+                }
+                m = fmaxf(m, absmax8(v[u][t2][0], v[u][t2][1]));
             }
-            if (src && c1 < D0) {
-                v1 = *reinterpret_cast<const f32x4*>(src + c1);
-                if (p.x_copy) *reinterpret_cast<f32x4*>(p.x_copy + (int64_t)gr * D0 + c1) = v1;
-            }
-            f[t2] = make_frag<NP>(v0, v1);
-            store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
         }
-        if (!INFER && p.tp[0] && kb < pl_blocks(D0 + 1))
-            emit_planes<NP>(p.tp[0] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
-                            kb == D0 / 32 ? D0 % 32 : -1, rows_lim - row0);
+        sc[wave * 64 + lane] = m;
+        __syncthreads();
+        float osc;
+        m = row_scales(sc, wave, lane, osc, ainv);
+        if (!INFER && p.tp[0] && wave == 0) store_amax_rows(p.amax[0] + (int64_t)blockIdx.x * PL_AMAX, m, 1.0f, lane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kb = wave + PL_WAVES * u;
+            if (kb < blocks0) {
+                Frag<NP> f[2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    f[t2] = make_frag<NP>(v[u][t2][0], v[u][t2][1], osc);
+                    store_frag<NP>(img + (int64_t)(2 * kb + t2) * (NP * 1024) + lane * 16, f[t2]);
+                }
+                if (!INFER && p.tp[0] && kb < pl_blocks(D0 + 1))
+                    emit_planes<NP>(p.tp[0] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
+                                    kb == D0 / 32 ? D0 % 32 : -1, rows_lim - row0, inv_tab);
+            }
+        }
+    } else {
+        for (int kb = wave; kb < blocks0; kb += PL_WAVES) {
+            Frag<NP> f[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int s = 2 * kb + t2;
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                const int c0 = 16 * s + 4 * h, c1 = c0 + 8;
+                if (src && c0 < D0) {
+                    v0 = *reinterpret_cast<const f32x4*>(src + c0);
+                    if (p.x_copy) *reinterpret_cast<f32x4*>(p.x_copy + (int64_t)gr * D0 + c0) = v0;
+                }
+                if (src && c1 < D0) {
+                    v1 = *reinterpret_cast<const f32x4*>(src + c1);
+                    if (p.x_copy) *reinterpret_cast<f32x4*>(p.x_copy + (int64_t)gr * D0 + c1) = v1;
+                }
+                f[t2] = make_frag<NP>(v0, v1);
+                store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
+            }
+            if (!INFER && p.tp[0] && kb < pl_blocks(D0 + 1))
+                emit_planes<NP>(p.tp[0] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
+                                kb == D0 / 32 ? D0 % 32 : -1, rows_lim - row0);
+        }
     }
     if (!INFER && p.tp[0] && pl_blocks(D0 + 1) > blocks0 && wave == PL_WAVES - 1) {     // D0 % 32 == 0 and no padding block to hold the ones
         Frag<NP> z[2] = {};
-        emit_planes<NP>(p.tp[0] + ((int64_t)(D0 / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, rows_lim - row0);
+        emit_planes<NP>(p.tp[0] + ((int64_t)(D0 / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, rows_lim - row0, inv_tab);
     }
 }
 
@@ -679,18 +914,19 @@ __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row0 = blockIdx.x * PL_ROWS;
     bf16x8 idf[2];
-    make_identity(idf, lane);
+    make_identity<NP>(idf, lane);
     PSTAMPF(0);
 
-    planes_input_stage<NP, INFER>(p, img, idf, wave, lane, row0);
+    float ainv = 1.0f;
+    planes_input_stage<NP, INFER>(p, img, part, idf, wave, lane, row0, ainv);
     PSTAMPF(1);
     __syncthreads();
 
     for (int l = 0; l < p.n_layers; ++l) {
         const int nblk = (p.dims[l + 1] + 31) / 32;
-        if (nblk > PL_WAVES) planes_layer<NP, 2, 1, MODE>(p, l, img, part, idf, wave, lane, row0);
-        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, MODE>(p, l, img, part, idf, wave, lane, row0);
-        else planes_layer<NP, 1, 2, MODE>(p, l, img, part, idf, wave, lane, row0);
+        if (nblk > PL_WAVES) planes_layer<NP, 2, 1, MODE>(p, l, img, part, idf, wave, lane, row0, ainv);
+        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, MODE>(p, l, img, part, idf, wave, lane, row0, ainv);
+        else planes_layer<NP, 1, 2, MODE>(p, l, img, part, idf, wave, lane, row0, ainv);
     }
     PSTAMPF(2 + 5 * p.n_layers);
 }
@@ -728,10 +964,11 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
     const int row_end = (call + 1) * p.rows_call;
     const int l = q.l;
     bf16x8 idf[2];
-    make_identity(idf, lane);
+    make_identity<NP>(idf, lane);
+    float ainv = 1.0f;                                 // (fp16 x 2 does not reach the BatchNorm launches)
 
     if (l == 0) {
-        planes_input_stage<NP, false>(p, img, idf, wave, lane, row0, row_end);
+        planes_input_stage<NP, false>(p, img, part, idf, wave, lane, row0, ainv, row_end);
     } else {
         // the four per-feature vectors of this workgroup's call, parked in the (idle) K-split buffer
         const int K = p.dims[l];
@@ -785,9 +1022,9 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
     __syncthreads();
 
     const int nblk = (p.dims[l + 1] + 31) / 32;
-    if (nblk > PL_WAVES) planes_layer<NP, 2, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, row_end);
-    else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, row_end);
-    else planes_layer<NP, 1, 2, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, row_end);
+    if (nblk > PL_WAVES) planes_layer<NP, 2, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, ainv, row_end);
+    else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, ainv, row_end);
+    else planes_layer<NP, 1, 2, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, ainv, row_end);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -806,6 +1043,7 @@ struct PlanesBwdP {
     const float* mask[ABN_MAX_LAYERS];
     const char* wpt[ABN_MAX_LAYERS];      // packed W_l^T images, l >= 1
     char* dzp[ABN_MAX_LAYERS];            // out: transposed planes of dZ_l (dims[l+1] features)
+    float* amax_dz[ABN_MAX_LAYERS];       // fp16 x 2: dzp[l]'s maxima, PL_AMAX floats per 32-row block
     int64_t tp_steps;
     const unsigned long long* drop_seed;  // the forward's in-kernel dropout, regenerated here (null: off)
     float drop_p;
@@ -830,7 +1068,7 @@ struct PlanesBwdP {
 // dZ_{l-1} from dZ_l (in img, pl_steps(dims[l+1]) steps): output features = the dims[l] inputs of layer l
 template <int NP, int BPW, int KS>
 __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, char* __restrict__ img,
-                                                   float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0)
+                                                   float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0, float& ainv)
 {
     const int N = p.dims[l + 1], K = p.dims[l];        // sum over N, K output features
     const int nsteps = pl_steps(N), nblk = (K + 31) / 32;
@@ -843,6 +1081,9 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
     for (int j = 0; j < BPW; ++j)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+    float cinv[BPW];                                   // fp16 x 2: what turns an accumulator into the product
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) cinv[j] = NP == 2 && ws.active ? packed_inv(p.wpt[l], nblk, nsteps, blk0 + j) * ainv : 1.0f;
     if (ws.active) planes_kloop<NP, BPW>(acc, p.wpt[l], nblk, nsteps, img, blk0, ws.s_first, ws.my_steps, lane);
 
     const float* __restrict__ mask = l >= 1 ? p.mask[l - 1] : nullptr;
@@ -871,6 +1112,12 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
         }
     }
     auto finish = [&]() {
+        if constexpr (NP == 2) {
+#pragma unroll
+            for (int j = 0; j < BPW; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[j][q] *= cinv[j];
+        }
         if (l == 0) return;                          // d loss / d input: the plain product
         with_act(p.act[l - 1], [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
@@ -888,8 +1135,21 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
                 }
         });
     };
+    float* const sc = part + PL_PART_BYTES / 4;
+    const bool rescale = NP == 2 && l >= 1;        // dZ_{l-1} is written transposed (and multiplied again)
+    auto park_max = [&]() {
+        float m = 0.0f;
+        if (ws.active && ws.khalf == 0) {
+#pragma unroll
+            for (int j = 0; j < BPW; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) m = fmaxf(m, fabsf(acc[j][q]));
+        }
+        sc[wave * 64 + lane] = m;
+    };
     if (KS == 1) {
         if (ws.active) finish();
+        if (rescale) park_max();
     } else if (ws.active && ws.khalf == 1) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) part[((wave & 3) * 16 + q) * 64 + lane] = acc[0][q];
@@ -900,6 +1160,15 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
         for (int q = 0; q < 16; ++q) acc[0][q] += part[(wave * 16 + q) * 64 + lane];
         finish();
     }
+    float osc = 1.0f;
+    if (rescale) {
+        if (KS == 2) { park_max(); __syncthreads(); }
+        float oinv;
+        const float m = row_scales(sc, wave, lane, osc, oinv);
+        ainv = oinv;
+        if (wave == 0) store_amax_rows(p.amax_dz[l - 1] + (int64_t)blockIdx.x * PL_AMAX, m, 0.0f, lane);
+    }
+    const float* const inv_tab = sc + PL_WAVES * 64 + wave * 32;
     if (ws.active && ws.khalf == 0) {
 #pragma unroll
         for (int j = 0; j < BPW; ++j) {
@@ -915,11 +1184,11 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
                         if (row_ok && k < K) *reinterpret_cast<f32x4*>(p.dx + (int64_t)gr * K + k) = v0;
                         if (row_ok && k + 8 < K) *reinterpret_cast<f32x4*>(p.dx + (int64_t)gr * K + k + 8) = v1;
                     } else {
-                        f[t2] = make_frag<NP>(v0, v1);
+                        f[t2] = make_frag<NP>(v0, v1, osc);
                         store_frag<NP>(img + (int64_t)(2 * blk + t2) * (NP * 1024) + lane * 16, f[t2]);
                     }
                 }
-                if (l >= 1) emit_planes<NP>(p.dzp[l - 1] + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane, -1, 0);
+                if (l >= 1) emit_planes<NP>(p.dzp[l - 1] + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane, -1, 0, inv_tab);
             }
         }
     }
@@ -946,7 +1215,7 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
     const int top = p.n_layers - 1;
     const int NT = p.dims[top + 1];
     bf16x8 idf[2];
-    make_identity(idf, lane);
+    make_identity<NP>(idf, lane);
 
     // the pair loss, when it rides along: per-row coefficients of d loss / d e = partner * inv - self * kself
     double* const coef = reinterpret_cast<double*>(part);          // [32][2]  (the K-split buffer is idle here)
@@ -1052,58 +1321,99 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
     const float* const self_row = p.a_top + (int64_t)(row_ok ? gr : 0) * NT;
     const float* const partner_row = p.a_top + (int64_t)(row_ok && with_loss ? (my_tower ? gr - p.B : gr + p.B) : 0) * NT;
     const double my_inv = with_loss ? coef[2 * r] : 0.0, my_k = with_loss ? coef[2 * r + 1] : 0.0;
-    for (int kb = wave; kb < blocks_t; kb += PL_WAVES) {
-        Frag<NP> f[2];
+    // one 16-feature step of dZ_top for this lane's row
+    auto top_step = [&](int s, f32x4* v) {
+        v[0] = v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const int s = 2 * kb + t2;
-            f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int u = 0; u < 2; ++u) {
+            const int c = 16 * s + 4 * h + 8 * u;
+            if (row_ok && c < NT) {
+                if (with_loss) {
+                    const f32x4 es = *reinterpret_cast<const f32x4*>(self_row + c);
+                    const f32x4 ep = *reinterpret_cast<const f32x4*>(partner_row + c);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int c = 16 * s + 4 * h + 8 * u;
-                if (row_ok && c < NT) {
-                    if (with_loss) {
-                        const f32x4 es = *reinterpret_cast<const f32x4*>(self_row + c);
-                        const f32x4 ep = *reinterpret_cast<const f32x4*>(partner_row + c);
+                    for (int e = 0; e < 4; ++e) {
+                        float o = (float)(ep[e] * my_inv - es[e] * my_k);
+                        if (p.act[top] != ACT_NONE) o *= act_grad(es[e], p.act[top]);
+                        v[u][e] = o;
+                    }
+                    if (mask || drop_top.on) {
+                        const f32x4 m = mask ? *reinterpret_cast<const f32x4*>(mask + (int64_t)gr * NT + c) : drop4(drop_top, gr, c);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float o = (float)(ep[e] * my_inv - es[e] * my_k);
-                            if (p.act[top] != ACT_NONE) o *= act_grad(es[e], p.act[top]);
-                            v[u][e] = o;
-                        }
+                        for (int e = 0; e < 4; ++e) v[u][e] *= m[e];
+                    }
+                } else {
+                    v[u] = *reinterpret_cast<const f32x4*>(p.d_out + (int64_t)gr * NT + c);
+                    if (!p.d_out_is_dz) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(p.a_top + (int64_t)gr * NT + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[u][e] *= act_grad(a[e], p.act[top]);
                         if (mask || drop_top.on) {
                             const f32x4 m = mask ? *reinterpret_cast<const f32x4*>(mask + (int64_t)gr * NT + c) : drop4(drop_top, gr, c);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[u][e] *= m[e];
                         }
-                    } else {
-                        v[u] = *reinterpret_cast<const f32x4*>(p.d_out + (int64_t)gr * NT + c);
-                        if (!p.d_out_is_dz) {
-                            const f32x4 a = *reinterpret_cast<const f32x4*>(p.a_top + (int64_t)gr * NT + c);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[u][e] *= act_grad(a[e], p.act[top]);
-                            if (mask || drop_top.on) {
-                                const f32x4 m = mask ? *reinterpret_cast<const f32x4*>(mask + (int64_t)gr * NT + c) : drop4(drop_top, gr, c);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[u][e] *= m[e];
-                            }
-                        }
                     }
                 }
             }
-            f[t2] = make_frag<NP>(v[0], v[1]);
-            store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
         }
-        if (kb < pl_blocks(NT))
-            emit_planes<NP>(p.dzp[top] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane, -1, 0);
+    };
+    float ainv = 1.0f;
+    if constexpr (NP == 2) {
+        // fp16 x 2: a wave's (up to two) blocks wait in registers until the workgroup has agreed on the rows' scales
+        float* const sc = part + PL_PART_BYTES / 4;
+        f32x4 v[2][2][2];
+        float m = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int kb = wave + PL_WAVES * u;
+                v[u][t2][0] = v[u][t2][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kb < blocks_t) top_step(2 * kb + t2, v[u][t2]);
+                m = fmaxf(m, absmax8(v[u][t2][0], v[u][t2][1]));
+            }
+        sc[wave * 64 + lane] = m;
+        __syncthreads();
+        float osc;
+        m = row_scales(sc, wave, lane, osc, ainv);
+        if (wave == 0) store_amax_rows(p.amax_dz[top] + (int64_t)blockIdx.x * PL_AMAX, m, 0.0f, lane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kb = wave + PL_WAVES * u;
+            if (kb < blocks_t) {
+                Frag<NP> f[2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    f[t2] = make_frag<NP>(v[u][t2][0], v[u][t2][1], osc);
+                    store_frag<NP>(img + (int64_t)(2 * kb + t2) * (NP * 1024) + lane * 16, f[t2]);
+                }
+                if (kb < pl_blocks(NT))
+                    emit_planes<NP>(p.dzp[top] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane, -1, 0,
+                                    sc + PL_WAVES * 64 + wave * 32);
+            }
+        }
+    } else {
+        for (int kb = wave; kb < blocks_t; kb += PL_WAVES) {
+            Frag<NP> f[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                f32x4 v[2];
+                top_step(2 * kb + t2, v);
+                f[t2] = make_frag<NP>(v[0], v[1]);
+                store_frag<NP>(img + (int64_t)(2 * kb + t2) * (NP * 1024) + lane * 16, f[t2]);
+            }
+            if (kb < pl_blocks(NT))
+                emit_planes<NP>(p.dzp[top] + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane, -1, 0);
+        }
     }
     __syncthreads();
 
     for (int l = top; l >= (p.dx ? 0 : 1); --l) {
         const int nblk = (p.dims[l] + 31) / 32;
-        if (nblk > PL_WAVES) planes_dgrad_layer<NP, 2, 1>(p, l, img, part, idf, wave, lane, row0);
-        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l + 1]) % (2 * PL_DEPTH) != 0) planes_dgrad_layer<NP, 1, 1>(p, l, img, part, idf, wave, lane, row0);
-        else planes_dgrad_layer<NP, 1, 2>(p, l, img, part, idf, wave, lane, row0);
+        if (nblk > PL_WAVES) planes_dgrad_layer<NP, 2, 1>(p, l, img, part, idf, wave, lane, row0, ainv);
+        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l + 1]) % (2 * PL_DEPTH) != 0) planes_dgrad_layer<NP, 1, 1>(p, l, img, part, idf, wave, lane, row0, ainv);
+        else planes_dgrad_layer<NP, 1, 2>(p, l, img, part, idf, wave, lane, row0, ainv);
     }
 }
 
@@ -1223,7 +1533,7 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
     const int row_end = (call + 1) * q.rows_call;
     const int N = q.N;
     bf16x8 idf[2];
-    make_identity(idf, lane);
+    make_identity<NP>(idf, lane);
 
     // the per-feature vectors of this workgroup's call, parked in the (still idle) K-split buffer
     const float nf = (float)q.rows_call;
@@ -1313,7 +1623,7 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
 // load: 3-4 us).  bf16 x 3: the fp32 tiles (2 KB) are fetched into REGISTERS four row steps ahead, split
 // once by the wave that fetched them -- not by the four / two waves that multiply them: that was 116 us,
 // VALU-bound -- and written as three planes (3 KB per block) into a ring of four LDS stages.
-template <int NP> constexpr int wg_stages() { return NP == 3 ? 4 : 6; }
+template <int NP> constexpr int wg_stages() { return NP >= 2 ? 4 : 6; }
 constexpr int WG_REG_DEPTH = 4;
 constexpr int WG_MAX_BLOCKS = 12;                 // operand blocks of one row step (shape 0: 8 + 4)
 struct WgradLayer {
@@ -1326,6 +1636,8 @@ struct WgradLayer {
     int splits;            // slabs this layer's sum over the rows is cut into
     int first_wg;          // workgroups [first_wg, first_wg + tiles_n * tiles_k * splits) belong to this layer
     int64_t slab_off;      // float offset of this layer's packed (dW | db) region inside a slab
+    const float* amax_dz;  // fp16 x 2: the two images' maxima, PL_AMAX floats per 32-row block (a slab's scales)
+    const float* amax_a;
 };
 struct WgradP {
     int n_layers;          // in launch order
@@ -1363,7 +1675,7 @@ static inline void wgrad_shape(int nblk, int kblk, int* shape, int* bn, int* bk)
 }
 
 template <int NP>
-constexpr size_t wgrad_lds_bytes() { return (size_t)wg_stages<NP>() * WG_MAX_BLOCKS * (NP == 3 ? 3072 : 1024); }
+constexpr size_t wgrad_lds_bytes() { return (size_t)wg_stages<NP>() * WG_MAX_BLOCKS * (NP * 1024) + (NP == 2 ? 128 : 0); }
 
 template <int NP, int TN, int TK, int WN, int WK>
 __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L, char* __restrict__ smem, int nb0, int kb0,
@@ -1377,7 +1689,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
     constexpr int STAGE = NB * FR;
     constexpr int WG_STAGES = wg_stages<NP>();
     static_assert(NB <= WG_MAX_BLOCKS, "LDS stage");
-    constexpr int PSTAGE = NB * 3072;                    // bf16 x 3: one LDS stage = [block][plane][1 KB]
+    constexpr int PSTAGE = NB * NP * 1024;               // bf16 x 3, fp16 x 2: one LDS stage = [block][plane][1 KB]
     const int wn = wave % WN, wk = wave / WN;
     // this wave's share of the DMA: operand blocks wave, wave + 8, ... below NB (n_mine of them: the wait
     // for "my part of step c" counts this wave's own instructions)
@@ -1433,14 +1745,14 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
     };
     struct Frags { bf16x8 a[TN][NP], b[TK][NP]; };
     auto read_frags = [&](Frags& f, int c) {
-        if constexpr (NP == 3) {
+        if constexpr (NP >= 2) {
             const char* st = smem + (c % WG_STAGES) * PSTAGE + lane * 16;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i) f.a[i][pl] = *reinterpret_cast<const bf16x8*>(st + (wn * TN + i) * 3072 + pl * 1024);
+                for (int i = 0; i < TN; ++i) f.a[i][pl] = *reinterpret_cast<const bf16x8*>(st + (wn * TN + i) * (NP * 1024) + pl * 1024);
 #pragma unroll
-                for (int j = 0; j < TK; ++j) f.b[j][pl] = *reinterpret_cast<const bf16x8*>(st + (BN + wk * TK + j) * 3072 + pl * 1024);
+                for (int j = 0; j < TK; ++j) f.b[j][pl] = *reinterpret_cast<const bf16x8*>(st + (BN + wk * TK + j) * (NP * 1024) + pl * 1024);
             }
         } else {
             const char* st = smem + (c % WG_STAGES) * STAGE + lane * 16;
@@ -1455,25 +1767,17 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         for (int i = 0; i < TN; ++i) for (int j = 0; j < TK; ++j) acc[i][j][0] += (float)f.a[i][0][0] * (float)f.b[j][0][1];
         return;
 #endif
-        if constexpr (NP == 3) {
-            constexpr int AP[6] = {2, 0, 1, 1, 0, 0}, BP[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int u = 0; u < 6; ++u)
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TK; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][AP[u]], f.b[j][BP[u]], acc[i][j], 0, 0, 0);
-        } else {
+        for (int u = 0; u < Products<NP>::N; ++u)
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TK; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][0], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = pl_mfma<NP>(f.a[i][Products<NP>::A[u]], f.b[j][Products<NP>::B[u]], acc[i][j]);
     };
     Frags fr[2];
-    if constexpr (NP == 3) {
+    float out_inv = 1.0f;                                // fp16 x 2: what turns an accumulator into the sum
+    if constexpr (NP >= 2) {
         // Register ring: slot k % 4 holds this wave's share of step k's fp32 tiles, fetched four steps before
         // it is split (raw buffer loads: the compiler counts their vmcnt and leaves them where they stand).
         // The share is the same for every wave -- one whole tile (operand block `wave`) and one 1 KB half of
@@ -1498,6 +1802,29 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(image_of(hb)), 0, (int)(p.tp_steps * FR), 0x00020000);
         v4i rq[WG_REG_DEPTH][3];
         const int n4 = (n_steps + 3) / 4 * 4;
+        // fp16 x 2: one power of two per operand for this slab's rows, from the maxima the chains left per 32-row block
+        float sc_whole = 1.0f, sc_half = 1.0f;
+        if constexpr (NP == 2) {
+            float* const red = reinterpret_cast<float*>(smem + WG_STAGES * WG_MAX_BLOCKS * (NP * 1024));      // [2][8]
+            const int rb0 = s_begin >> 1, cnt = (((s_end + 1) >> 1) - rb0) * PL_AMAX;
+            float md = 0.0f, ma = 0.0f;
+            for (int i = threadIdx.x; i < cnt; i += PL_NT) {
+                md = fmaxf(md, L.amax_dz[(int64_t)rb0 * PL_AMAX + i]);
+                ma = fmaxf(ma, L.amax_a[(int64_t)rb0 * PL_AMAX + i]);
+            }
+            md = wave_max(md); ma = wave_max(ma);
+            if (lane == 0) { red[wave] = md; red[8 + wave] = ma; }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < PL_WAVES; ++w) { md = fmaxf(md, red[w]); ma = fmaxf(ma, red[8 + w]); }
+            float sd, sa, id, ia;
+            scale_of(md, sd, id);
+            scale_of(ma, sa, ia);
+            out_inv = id * ia;
+            sc_whole = wave < BN ? sd : sa;              // this wave's whole tile: operand block `wave`
+            sc_half = sa;                                // (blocks 8 .. NB-1 are activation blocks in every shape)
+            static_assert(BN <= PL_WAVES, "the half tiles are activation blocks");
+        }
         auto load = [&](int slot, int k) {
             const int off = step_at(k) * FR;
 #ifdef WEXP_NOLOAD
@@ -1518,21 +1845,34 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
             const f32x4 v1 = real ? __builtin_bit_cast(f32x4, rq[slot][1]) : z4;
             const f32x4 v2 = real ? __builtin_bit_cast(f32x4, rq[slot][2]) : z4;
             char* const st = smem + (k % WG_STAGES) * PSTAGE + lane * 16;
-            store_frag<3>(st + wave * 3072, make_frag<3>(v0, v1));
+            store_frag<NP>(st + wave * (NP * 1024), make_frag<NP>(v0, v1, sc_whole));
             // the half tile: four values -> 8 bytes per plane
-            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-            bf16x4 ph, pm, pl;
+            char* const sh = st + hb * (NP * 1024) + hh * 8;
+            if constexpr (NP == 3) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 ph, pm, pl;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const __bf16 hq = (__bf16)v2[e];
-                const float r1 = v2[e] - (float)hq;
-                const __bf16 mq = (__bf16)r1;
-                ph[e] = hq; pm[e] = mq; pl[e] = (__bf16)(r1 - (float)mq);
+                for (int e = 0; e < 4; ++e) {
+                    const __bf16 hq = (__bf16)v2[e];
+                    const float r1 = v2[e] - (float)hq;
+                    const __bf16 mq = (__bf16)r1;
+                    ph[e] = hq; pm[e] = mq; pl[e] = (__bf16)(r1 - (float)mq);
+                }
+                *reinterpret_cast<bf16x4*>(sh) = ph;
+                *reinterpret_cast<bf16x4*>(sh + 1024) = pm;
+                *reinterpret_cast<bf16x4*>(sh + 2048) = pl;
+            } else {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                f16x4 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = v2[e] * sc_half;
+                    const _Float16 hq = (_Float16)u;
+                    ph[e] = hq; pl[e] = (_Float16)(u - (float)hq);
+                }
+                *reinterpret_cast<f16x4*>(sh) = ph;
+                *reinterpret_cast<f16x4*>(sh + 1024) = pl;
             }
-            char* const sh = st + hb * 3072 + hh * 8;
-            *reinterpret_cast<bf16x4*>(sh) = ph;
-            *reinterpret_cast<bf16x4*>(sh + 1024) = pm;
-            *reinterpret_cast<bf16x4*>(sh + 2048) = pl;
         };
         if (n_steps > 0) {
 #pragma unroll
@@ -1551,9 +1891,9 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
                 convert((i + 2) & 3, c + 2);
                 mfmas(fr[i & 1]);       // (a wave whose blocks are all padding multiplies clamped copies: nothing of it is stored)
 #pragma unroll
-                for (int g = 0; g < TN * TK * 6; ++g) {
+                for (int g = 0; g < TN * TK * Products<NP>::N; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, NP == 2 ? 6 : 4, 0);
                 }
                 load((i + 2) & 3, c + 6);
             }
@@ -1595,7 +1935,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int n = 32 * (nb0 + wn * TN + i) + (q & 3) + 8 * (q >> 2) + 4 * h;
-                    if (n < L.N) slab[k < L.K ? (int64_t)n * L.K + k : (int64_t)L.N * L.K + n] = acc[i][j][q];
+                    if (n < L.N) slab[k < L.K ? (int64_t)n * L.K + k : (int64_t)L.N * L.K + n] = NP == 2 ? acc[i][j][q] * out_inv : acc[i][j][q];
                 }
         }
     }

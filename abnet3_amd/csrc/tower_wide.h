@@ -25,7 +25,9 @@ namespace abn {
 constexpr int WD_MAXG = 8;
 constexpr int WD_PART_BYTES = 7 * 16 * 64 * 4;          // up to 7 hand-over tiles (one block shared by 8 waves)
 constexpr int WD_COEF_BYTES = 1024;                     // the pair loss's per-row coefficients (top dgrad launch)
-static inline size_t wd_lds_bytes(int np) { return (size_t)PL_MAXSTEPS * np * 1024 + WD_PART_BYTES + WD_COEF_BYTES; }
+static inline size_t wd_lds_bytes(int np) { return (size_t)PL_MAXSTEPS * np * 1024 + WD_PART_BYTES + WD_COEF_BYTES + PL_SC_BYTES; }
+// fp16 x 2: the row maxima / inverse-scale tables (row_scales, tower_planes.h) behind the hand-over tiles
+template <int NP> __device__ __forceinline__ float* wd_scales(char* smem) { return reinterpret_cast<float*>(smem + PL_MAXSTEPS * NP * 1024 + WD_PART_BYTES + WD_COEF_BYTES); }
 
 // Which block a wave sums and which steps of it.  The workgroup owns blocks g, g + G, ... of the layer's
 // nblk (nbw of them); its 8 waves are dealt `per` to a block, each taking a contiguous run of the
@@ -55,12 +57,16 @@ struct WideShare {
 // 32 rows of a row-major fp32 matrix (row pointer per lane, null = a zero row) -> operand fragments in img for
 // pl_steps(K) steps.  emit(kb, f): called by the wave that built block kb's two fragments.  A wave's loads (up to
 // two 32-feature blocks: K <= 512) are all issued before the first conversion: one round trip, not one per block.
+// fp16 x 2: the workgroup first agrees on its rows' scales (one more barrier); returns the lane's row maximum, ainv its
+// row's inverse scale.
 template <int NP, class Emit>
-__device__ __forceinline__ void wide_stage_rows(const float* __restrict__ src, int K, char* __restrict__ img, int wave, int lane, Emit&& emit)
+__device__ __forceinline__ float wide_stage_rows(const float* __restrict__ src, int K, char* __restrict__ img, float* __restrict__ sc,
+                                                 int wave, int lane, float& ainv, Emit&& emit)
 {
     const int h = lane >> 5;
     const int blocks = pl_steps(K) / 2;
     f32x4 v[2][2][2];                                   // [block of this wave][step of the block][half]
+    float m = 0.0f;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int kb = wave + PL_WAVES * u;
@@ -70,7 +76,14 @@ __device__ __forceinline__ void wide_stage_rows(const float* __restrict__ src, i
             v[u][t2][0] = v[u][t2][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (src && kb < blocks && c0 < K) v[u][t2][0] = *reinterpret_cast<const f32x4*>(src + c0);
             if (src && kb < blocks && c1 < K) v[u][t2][1] = *reinterpret_cast<const f32x4*>(src + c1);
+            if constexpr (NP == 2) m = fmaxf(m, absmax8(v[u][t2][0], v[u][t2][1]));
         }
+    }
+    float osc = 1.0f;
+    if constexpr (NP == 2) {
+        sc[wave * 64 + lane] = m;
+        __syncthreads();
+        m = row_scales(sc, wave, lane, osc, ainv);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -79,12 +92,30 @@ __device__ __forceinline__ void wide_stage_rows(const float* __restrict__ src, i
             Frag<NP> f[2];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
-                f[t2] = make_frag<NP>(v[u][t2][0], v[u][t2][1]);
+                f[t2] = make_frag<NP>(v[u][t2][0], v[u][t2][1], osc);
                 store_frag<NP>(img + (int64_t)(2 * kb + t2) * (NP * 1024) + lane * 16, f[t2]);
             }
             emit(kb, f);
         }
     }
+    return m;
+}
+
+// fp16 x 2, a finishing wave's 32 x 32 block on its way out transposed: the scale of each row from the block's own
+// values (both lane halves of a row agree), the inverse in this wave's table for emit_planes; returns the block's maximum.
+__device__ __forceinline__ float wide_block_scale(const f32x16& acc, float* __restrict__ sc, int wave, int lane, float& osc)
+{
+    float m = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) m = fmaxf(m, fabsf(acc[q]));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float oinv;
+    scale_of(m, osc, oinv);
+    float* const tab = sc + PL_WAVES * 64 + wave * 32;
+    tab[lane & 31] = oinv;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    return wave_max(m);
 }
 
 // planes_kloop (tower_planes.h) in two halves: the first PL_DEPTH steps' weight loads are issued BEFORE the
@@ -124,14 +155,9 @@ struct WideRing {
                 for (int pl = 0; pl < NP; ++pl) af[(i + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(ab + (s1 * NP + pl) * 1024);
                 __builtin_amdgcn_sched_barrier(0);
                 const bf16x8* a = af[i & 1];
-                if constexpr (NP == 3) {
-                    constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, AP[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first, as planes_kloop
 #pragma unroll
-                    for (int t = 0; t < 6; ++t)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[i][WP[t]]), a[AP[t]], acc, 0, 0, 0);
-                } else {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[i][0]), a[0], acc, 0, 0, 0);
-                }
+                for (int t = 0; t < Products<NP>::N; ++t)               // smallest terms first, as planes_kloop
+                    acc = pl_mfma<NP>(__builtin_bit_cast(bf16x8, wq[i][Products<NP>::A[t]]), a[Products<NP>::B[t]], acc);
                 asm volatile("" : "+v"(acc) :: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 const int sn = s + PL_DEPTH < my_steps ? s + PL_DEPTH : my_steps - 1;
@@ -178,6 +204,8 @@ struct WideFwdP {
     float* out;                    // last layer: [rows, N] at the caller's row indices
     char* tp_in;                   // l == 0: transposed image of [x | 1] (null: nothing kept for a backward)
     char* tp_out;                  // l < last: transposed image of [a_l | 1] (null: inference)
+    float* amax_in;                // fp16 x 2: the images' maxima (PL_AMAX floats per 32-row block, tower_planes.h)
+    float* amax_out;
     int64_t tp_steps;
     const unsigned long long* drop_seed;
     float drop_p;
@@ -209,7 +237,9 @@ __global__ __launch_bounds__(PL_NT) void wide_fwd_layer_kernel(WideFwdP p)
     const int64_t arow = (int64_t)call * p.rows_call + lb * PL_ROWS + r;   // the caller's row index
     const int K = p.K, N = p.N;
     bf16x8 idf[2];
-    make_identity(idf, lane);
+    make_identity<NP>(idf, lane);
+    float* const sc = wd_scales<NP>(pl_smem);
+    const float* const inv_tab = sc + PL_WAVES * 64 + wave * 32;
 
     WSTAMP(0);
     const int nblk = pl_blocks(N), nsteps = pl_steps(K);
@@ -229,14 +259,20 @@ __global__ __launch_bounds__(PL_NT) void wide_fwd_layer_kernel(WideFwdP p)
     if (p.l == 0) src = !row_ok ? nullptr : (p.x2 && call >= 1 ? p.x2 + (arow - p.rows_call) * K : p.x1 + arow * K);
     else src = p.a_prev + (int64_t)vrow * K;
     char* const tp_in = p.l == 0 ? p.tp_in : nullptr;
-    wide_stage_rows<NP>(src, K, img, wave, lane, [&](int kb, const Frag<NP>* f) {
+    float ainv = 1.0f;
+    const float in_max = wide_stage_rows<NP>(src, K, img, sc, wave, lane, ainv, [&](int kb, const Frag<NP>* f) {
         // the input's transposed image (weight gradient of layer 0): the row block's G workgroups share the blocks
         if (tp_in && kb < pl_blocks(K + 1) && kb % p.G == g)
-            emit_planes<NP>(tp_in + ((int64_t)kb * p.tp_steps + 2 * rb) * tile_bytes<NP>(), f, idf, lane, kb == K / 32 ? K % 32 : -1, rows_left);
+            emit_planes<NP>(tp_in + ((int64_t)kb * p.tp_steps + 2 * rb) * tile_bytes<NP>(), f, idf, lane, kb == K / 32 ? K % 32 : -1, rows_left, inv_tab);
     });
     if (tp_in && pl_blocks(K + 1) > pl_steps(K) / 2 && wave == PL_WAVES - 1 && (K / 32) % p.G == g) {   // K % 32 == 0, no padding block for the ones
         Frag<NP> z[2] = {};
-        emit_planes<NP>(tp_in + ((int64_t)(K / 32) * p.tp_steps + 2 * rb) * tile_bytes<NP>(), z, idf, lane, 0, rows_left);
+        emit_planes<NP>(tp_in + ((int64_t)(K / 32) * p.tp_steps + 2 * rb) * tile_bytes<NP>(), z, idf, lane, 0, rows_left, inv_tab);
+    }
+    if (NP == 2 && tp_in && g == 0 && wave == 0) store_amax_rows(p.amax_in + (int64_t)rb * PL_AMAX, in_max, 1.0f, lane);
+    if (NP == 2 && p.tp_out && g == 0 && wave == PL_WAVES - 1) {           // the blocks this layer's image does not have
+        const int first = pl_blocks(N + 1) + lane;
+        if (first < PL_AMAX) p.amax_out[(int64_t)rb * PL_AMAX + first] = 0.0f;
     }
     WSTAMP(1);
     __syncthreads();
@@ -254,6 +290,11 @@ __global__ __launch_bounds__(PL_NT) void wide_fwd_layer_kernel(WideFwdP p)
         wide_collect(ws, acc, part, lane);
         const DropGen drop = make_drop(p.drop_seed, p.drop_p, p.l);
         const int blk = ws.blk;
+        if constexpr (NP == 2) {
+            const float cinv = packed_inv(p.wp, nblk, nsteps, blk) * ainv;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] *= cinv;
+        }
         with_act(p.act, [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
 #pragma unroll
@@ -271,6 +312,11 @@ __global__ __launch_bounds__(PL_NT) void wide_fwd_layer_kernel(WideFwdP p)
             }
         });
         Frag<NP> f[2];
+        float osc = 1.0f;
+        if (NP == 2 && p.tp_out) {
+            const float bm = wide_block_scale(acc, sc, wave, lane, osc);
+            if (lane == 0) p.amax_out[(int64_t)rb * PL_AMAX + blk] = blk == N / 32 ? fmaxf(bm, 1.0f) : bm;      // (the column of ones)
+        }
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             const f32x4 v0 = {acc[8 * t2], acc[8 * t2 + 1], acc[8 * t2 + 2], acc[8 * t2 + 3]};
@@ -284,14 +330,15 @@ __global__ __launch_bounds__(PL_NT) void wide_fwd_layer_kernel(WideFwdP p)
                 if (n < N) *reinterpret_cast<f32x4*>(p.out + arow * N + n) = v0;
                 if (n + 8 < N) *reinterpret_cast<f32x4*>(p.out + arow * N + n + 8) = v1;
             }
-            if (p.tp_out) f[t2] = make_frag<NP>(v0, v1);
+            if (p.tp_out) f[t2] = make_frag<NP>(v0, v1, osc);
         }
         if (p.tp_out)
-            emit_planes<NP>(p.tp_out + ((int64_t)blk * p.tp_steps + 2 * rb) * tile_bytes<NP>(), f, idf, lane, blk == N / 32 ? N % 32 : -1, rows_left);
+            emit_planes<NP>(p.tp_out + ((int64_t)blk * p.tp_steps + 2 * rb) * tile_bytes<NP>(), f, idf, lane, blk == N / 32 ? N % 32 : -1, rows_left, inv_tab);
     }
     if (p.tp_out && N % 32 == 0 && wave == PL_WAVES - 1 && nblk % p.G == g) {       // the column of ones opens a block of its own
         Frag<NP> z[2] = {};
-        emit_planes<NP>(p.tp_out + ((int64_t)nblk * p.tp_steps + 2 * rb) * tile_bytes<NP>(), z, idf, lane, 0, rows_left);
+        emit_planes<NP>(p.tp_out + ((int64_t)nblk * p.tp_steps + 2 * rb) * tile_bytes<NP>(), z, idf, lane, 0, rows_left, inv_tab);
+        if (NP == 2 && lane == 0) p.amax_out[(int64_t)rb * PL_AMAX + nblk] = 1.0f;
     }
     WSTAMP(5);
 }
@@ -312,6 +359,8 @@ struct WideBwdP {
     float* dz_out;                 // [virtual rows, K] (null: nobody reads it row-major)
     char* dzp_top;                 // l == top: out, transposed image of dZ_top
     char* dzp_out;                 // l >= 1: out, transposed image of dZ_{l-1}
+    float* amax_top;               // fp16 x 2: the images' maxima (PL_AMAX floats per 32-row block)
+    float* amax_out;
     int64_t tp_steps;
     float* dx;                     // l == 0: [rows, K] at the caller's row indices
     const unsigned long long* drop_seed;
@@ -348,7 +397,10 @@ __global__ __launch_bounds__(PL_NT) void wide_dgrad_layer_kernel(WideBwdP p)
     const int64_t arow = (int64_t)call * p.rows_call + lb * PL_ROWS + r;
     const int N = p.N, K = p.K;
     bf16x8 idf[2];
-    make_identity(idf, lane);
+    make_identity<NP>(idf, lane);
+    float* const sc = wd_scales<NP>(pl_smem);
+    const float* const inv_tab = sc + PL_WAVES * 64 + wave * 32;
+    float ainv = 1.0f;
     const int nblk = pl_blocks(K), nsteps = pl_steps(N);
     const WideShare ws(wave, g, p.G, nblk, nsteps);
     WideRing<NP> ring;
@@ -452,55 +504,96 @@ __global__ __launch_bounds__(PL_NT) void wide_dgrad_layer_kernel(WideBwdP p)
         const float* const self_row = p.a_top + (row_ok ? arow : 0) * N;
         const float* const partner_row = p.a_top + (row_ok && with_loss ? (call ? arow - B : arow + B) : 0) * N;
         const double my_inv = with_loss ? coef[2 * r] : 0.0, my_k = with_loss ? coef[2 * r + 1] : 0.0;
-        for (int kb = wave; kb < blocks_t; kb += PL_WAVES) {
-            Frag<NP> f[2];
+        // one 16-feature step of dZ_top for this lane's row
+        auto top_step = [&](int s, f32x4* v) {
+            v[0] = v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                const int s = 2 * kb + t2;
-                f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            for (int u = 0; u < 2; ++u) {
+                const int c = 16 * s + 4 * h + 8 * u;
+                if (row_ok && c < N) {
+                    const f32x4 es = *reinterpret_cast<const f32x4*>(self_row + c);
+                    if (with_loss) {
+                        const f32x4 ep = *reinterpret_cast<const f32x4*>(partner_row + c);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int c = 16 * s + 4 * h + 8 * u;
-                    if (row_ok && c < N) {
-                        const f32x4 es = *reinterpret_cast<const f32x4*>(self_row + c);
-                        if (with_loss) {
-                            const f32x4 ep = *reinterpret_cast<const f32x4*>(partner_row + c);
+                        for (int e = 0; e < 4; ++e) {
+                            float o = (float)(ep[e] * my_inv - es[e] * my_k);
+                            if (p.act_top != ACT_NONE) o *= act_grad(es[e], p.act_top);
+                            v[u][e] = o;
+                        }
+                        if (drop_top.on) {
+                            const f32x4 m = drop4(drop_top, vrow, c);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float o = (float)(ep[e] * my_inv - es[e] * my_k);
-                                if (p.act_top != ACT_NONE) o *= act_grad(es[e], p.act_top);
-                                v[u][e] = o;
-                            }
+                            for (int e = 0; e < 4; ++e) v[u][e] *= m[e];
+                        }
+                    } else {
+                        v[u] = *reinterpret_cast<const f32x4*>(p.d_out + arow * N + c);
+                        if (!p.d_out_is_dz) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[u][e] *= act_grad(es[e], p.act_top);
                             if (drop_top.on) {
                                 const f32x4 m = drop4(drop_top, vrow, c);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[u][e] *= m[e];
                             }
-                        } else {
-                            v[u] = *reinterpret_cast<const f32x4*>(p.d_out + arow * N + c);
-                            if (!p.d_out_is_dz) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[u][e] *= act_grad(es[e], p.act_top);
-                                if (drop_top.on) {
-                                    const f32x4 m = drop4(drop_top, vrow, c);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[u][e] *= m[e];
-                                }
-                            }
                         }
                     }
                 }
-                f[t2] = make_frag<NP>(v[0], v[1]);
-                store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
             }
-            if (kb < pl_blocks(N) && kb % p.G == g)
-                emit_planes<NP>(p.dzp_top + ((int64_t)kb * p.tp_steps + 2 * rb) * tile_bytes<NP>(), f, idf, lane, -1, 0);
+        };
+        if constexpr (NP == 2) {
+            f32x4 v[2][2][2];
+            float m = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int kb = wave + PL_WAVES * u;
+                    v[u][t2][0] = v[u][t2][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (kb < blocks_t) top_step(2 * kb + t2, v[u][t2]);
+                    m = fmaxf(m, absmax8(v[u][t2][0], v[u][t2][1]));
+                }
+            sc[wave * 64 + lane] = m;
+            __syncthreads();
+            float osc;
+            m = row_scales(sc, wave, lane, osc, ainv);
+            if (g == 0 && wave == 0) store_amax_rows(p.amax_top + (int64_t)rb * PL_AMAX, m, 0.0f, lane);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kb = wave + PL_WAVES * u;
+                if (kb < blocks_t) {
+                    Frag<NP> f[2];
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        f[t2] = make_frag<NP>(v[u][t2][0], v[u][t2][1], osc);
+                        store_frag<NP>(img + (int64_t)(2 * kb + t2) * (NP * 1024) + lane * 16, f[t2]);
+                    }
+                    if (kb < pl_blocks(N) && kb % p.G == g)
+                        emit_planes<NP>(p.dzp_top + ((int64_t)kb * p.tp_steps + 2 * rb) * tile_bytes<NP>(), f, idf, lane, -1, 0, inv_tab);
+                }
+            }
+        } else {
+            for (int kb = wave; kb < blocks_t; kb += PL_WAVES) {
+                Frag<NP> f[2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    f32x4 v[2];
+                    top_step(2 * kb + t2, v);
+                    f[t2] = make_frag<NP>(v[0], v[1]);
+                    store_frag<NP>(img + (int64_t)(2 * kb + t2) * (NP * 1024) + lane * 16, f[t2]);
+                }
+                if (kb < pl_blocks(N) && kb % p.G == g)
+                    emit_planes<NP>(p.dzp_top + ((int64_t)kb * p.tp_steps + 2 * rb) * tile_bytes<NP>(), f, idf, lane, -1, 0);
+            }
         }
     } else {
-        wide_stage_rows<NP>(p.dz_in + (int64_t)vrow * N, N, img, wave, lane, [&](int, const Frag<NP>*) {});
+        wide_stage_rows<NP>(p.dz_in + (int64_t)vrow * N, N, img, sc, wave, lane, ainv, [&](int, const Frag<NP>*) {});
     }
     __syncthreads();
     if (!p.wpt) return;                                // a one-layer tower without an input gradient: dZ_top was all there is
+    if (NP == 2 && p.l >= 1 && g == 0 && wave == PL_WAVES - 1) {           // the blocks dZ_{l-1}'s image does not have
+        const int first = nblk + lane;
+        if (first < PL_AMAX) p.amax_out[(int64_t)rb * PL_AMAX + first] = 0.0f;
+    }
 
     f32x16 acc;
 #pragma unroll
@@ -519,6 +612,11 @@ __global__ __launch_bounds__(PL_NT) void wide_dgrad_layer_kernel(WideBwdP p)
     if (!(ws.active && ws.kpart == 0)) return;
     wide_collect(ws, acc, part, lane);
     const int blk = ws.blk;
+    if constexpr (NP == 2) {
+        const float cinv = packed_inv(p.wpt, nblk, nsteps, blk) * ainv;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] *= cinv;
+    }
     if (p.l >= 1) {
         const DropGen drop = make_drop(p.drop_seed, p.drop_p, p.l - 1);
         with_act(p.act_prev, [&](auto tag) {
@@ -539,6 +637,11 @@ __global__ __launch_bounds__(PL_NT) void wide_dgrad_layer_kernel(WideBwdP p)
         });
     }
     Frag<NP> f[2];
+    float osc = 1.0f;
+    if (NP == 2 && p.l >= 1) {
+        const float bm = wide_block_scale(acc, sc, wave, lane, osc);
+        if (lane == 0) p.amax_out[(int64_t)rb * PL_AMAX + blk] = bm;
+    }
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
         const f32x4 v0 = {acc[8 * t2], acc[8 * t2 + 1], acc[8 * t2 + 2], acc[8 * t2 + 3]};
@@ -552,10 +655,10 @@ __global__ __launch_bounds__(PL_NT) void wide_dgrad_layer_kernel(WideBwdP p)
                 if (k < K) *reinterpret_cast<f32x4*>(p.dz_out + (int64_t)vrow * K + k) = v0;
                 if (k + 8 < K) *reinterpret_cast<f32x4*>(p.dz_out + (int64_t)vrow * K + k + 8) = v1;
             }
-            f[t2] = make_frag<NP>(v0, v1);
+            f[t2] = make_frag<NP>(v0, v1, osc);
         }
     }
-    if (p.l >= 1) emit_planes<NP>(p.dzp_out + ((int64_t)blk * p.tp_steps + 2 * rb) * tile_bytes<NP>(), f, idf, lane, -1, 0);
+    if (p.l >= 1) emit_planes<NP>(p.dzp_out + ((int64_t)blk * p.tp_steps + 2 * rb) * tile_bytes<NP>(), f, idf, lane, -1, 0, inv_tab);
 }
 
 }  // namespace abn

@@ -30,7 +30,7 @@ ref_e = a.detach().numpy()
 ref_g = {k + s: getattr(ref[i], s[1:]).grad.numpy() for i, k in zip((0, 2, 4, 6), keys) for s in ('.weight', '.bias')}
 
 def rel(u, v): return float(np.abs(u - v).max() / np.abs(v).max())
-for prec in ('fp32', 'bf16x3', 'bf16'):
+for prec in ('fp32', 'bf16x3', 'f16x2', 'bf16'):
     net = copy.deepcopy(base).cuda(); net.precision = prec
     tr = TrainerSiamese(network=net, loss=coscos2(avg=False), optimizer_type='adadelta', lr=0.1, dataloader=None, log_dir='/tmp/abn_runs')
     net.eval()
