@@ -737,7 +737,7 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
         float oinv;
         const float m = row_scales(sc, wave, lane, osc, oinv);
         ainv = oinv;
-        if (!INFER && wave == 0) store_amax_rows(p.amax[l + 1] + (int64_t)blockIdx.x * PL_AMAX, m, 1.0f, lane);
+        if (!INFER && p.tp[l + 1] && wave == 0) store_amax_rows(p.amax[l + 1] + (int64_t)blockIdx.x * PL_AMAX, m, 1.0f, lane);      // (a forward nothing is kept of: no images)
     }
     const float* const inv_tab = sc + PL_WAVES * 64 + wave * 32;
     float* __restrict__ out = p.out[l];

@@ -177,3 +177,10 @@ def check_loss_grads(de1, de2, ref1, ref2, lname, tag=''):
         for mine, ref in ((de1[r], ref1[r]), (de2[r], ref2[r])):
             scale = max(np.abs(ref).max(), 1e-30)
             assert np.abs(mine - ref).max() <= 2e-5 * scale, (r, tag)
+
+
+@pytest.fixture(params=['bf16x3', 'f16x2'])
+def split(request):
+    """The two split arithmetics of the operand-plane kernels (SiameseNetwork.precision): three bf16 terms with six
+    products, two scaled fp16 terms with three -- a test that takes this fixture runs once in each."""
+    return request.param

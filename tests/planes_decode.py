@@ -15,8 +15,16 @@ def perm16():
 
 
 def decode(buf_u16, nblk, nsteps, np_):
-    """image [nblk][nsteps][np][64 lanes][8] bf16 -> float64 matrix [32 nblk operand rows][16 nsteps sum index]"""
-    img = bf16_to_f32(buf_u16[:nblk * nsteps * np_ * 512].reshape(nblk, nsteps, np_, 2, 32, 8)).astype(np.float64).sum(axis=2)
+    """image [nblk][nsteps][np][64 lanes][8] bf16 -> float64 matrix [32 nblk operand rows][16 nsteps sum index].
+    np_ = 2 (fp16 x 2): the planes are fp16 values of the scaled tensor, one inverse scale (fp32) per 32-row
+    block behind the fragments."""
+    if np_ == 2:
+        n = nblk * nsteps * 2 * 512
+        img = buf_u16[:n].view(np.float16).reshape(nblk, nsteps, 2, 2, 32, 8).astype(np.float64).sum(axis=2)
+        inv = buf_u16[n:n + 2 * nblk].view(np.float32).astype(np.float64)
+        img = img * inv[:, None, None, None, None]
+    else:
+        img = bf16_to_f32(buf_u16[:nblk * nsteps * np_ * 512].reshape(nblk, nsteps, np_, 2, 32, 8)).astype(np.float64).sum(axis=2)
     out = np.zeros((nblk * 32, nsteps * 16))
     P = perm16()
     for h in range(2):
@@ -29,7 +37,7 @@ def decode(buf_u16, nblk, nsteps, np_):
 def decode_t(buf_u16, nblk, nsteps, np_):
     """Transposed image (tower_planes.h emit_planes) -> float64 matrix [32 nblk features][16 nsteps batch rows].
     np_ = 1: [nblk][nsteps][64 lanes][8 bf16], the layout decode() reads with one plane.
-    np_ = 3: [nblk][nsteps][elements 0..3 | 4..7][64 lanes][4 fp32]."""
+    np_ = 3, 2: [nblk][nsteps][elements 0..3 | 4..7][64 lanes][4 fp32]."""
     if np_ == 1:
         return decode(buf_u16, nblk, nsteps, 1)
     f = buf_u16[:nblk * nsteps * 1024].view(np.float32).reshape(nblk, nsteps, 2, 2, 32, 4).astype(np.float64)

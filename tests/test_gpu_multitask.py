@@ -13,7 +13,7 @@ from conftest import load_golden, rel_err, check_grads, check_params
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=['bf16x3', 'fp32'])
+@pytest.fixture(autouse=True, params=['bf16x3', 'f16x2', 'fp32'])
 def tower_precision(request, monkeypatch):
     """Every test of this file runs on both parity-grade arithmetics of the tower GEMMs: the
     default bf16 x 3 split products and the exact-fp32 MFMA (SiameseNetwork.precision)."""

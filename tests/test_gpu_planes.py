@@ -51,7 +51,7 @@ SHAPES = [  # (input, hidden layers, hidden, output, B)
 ]
 
 
-@pytest.mark.parametrize('precision,tol,gtol', [('bf16x3', 1e-5, 1e-4), ('bf16', 3e-2, None)])
+@pytest.mark.parametrize('precision,tol,gtol', [('bf16x3', 1e-5, 1e-4), ('f16x2', 1e-5, 1e-4), ('bf16', 3e-2, None)])
 @pytest.mark.parametrize('act', ['sigmoid', 'tanh', 'relu'])
 @pytest.mark.parametrize('shape', SHAPES)
 def test_forward_loss_and_gradients_against_the_oracle(shape, act, precision, tol, gtol):
@@ -84,7 +84,7 @@ def test_forward_loss_and_gradients_against_the_oracle(shape, act, precision, to
     assert rel_err(e2.detach().cpu().numpy(), o2) < tol
     assert abs(float(lv.detach()) - ol) <= 10 * tol * abs(ol) + 1e-6
     grads = {k: q.grad.cpu().numpy() for k, q in net.named_parameters()}
-    if precision == 'bf16x3':
+    if precision != 'bf16':
         check_grads(grads, og, spec.param_keys(), False, tol=gtol)
     else:
         # 8-bit operands under a loss whose gradient is a difference of near-equal vectors: the
@@ -101,16 +101,16 @@ def test_forward_loss_and_gradients_against_the_oracle(shape, act, precision, to
                         log_dir='/tmp/abn_runs')
     tr.train_step((dev(x1), dev(x2), dev(y)), True)
     for k, q in net.named_parameters():
-        assert rel_err(q.grad.cpu().numpy(), grads[k], floor=1e-30) < (1e-6 if precision == 'bf16x3' else 1e-5), k
+        assert rel_err(q.grad.cpu().numpy(), grads[k], floor=1e-30) < (1e-6 if precision != 'bf16' else 1e-5), k
 
 
-def test_input_gradient_through_the_chain():
+def test_input_gradient_through_the_chain(split):
     """x.requires_grad: the data-gradient chain runs one product further (dX = dZ_0 W_0)."""
     import abnet3_amd.loss as L
     from oracle import siamese_np as O
     kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=72, output_dim=36, activation_layer='tanh',
               p_dropout=0.0, batch_norm=False)
-    net, spec, p = build(kw, seed=6, precision='bf16x3')
+    net, spec, p = build(kw, seed=6, precision=split)
     B = 45
     rng = np.random.default_rng(6)
     x1n, x2n = rng.standard_normal((B, 40)).astype(np.float32), rng.standard_normal((B, 40)).astype(np.float32)
@@ -129,14 +129,14 @@ def test_input_gradient_through_the_chain():
     check_grads({k: q.grad.cpu().numpy() for k, q in net.named_parameters()}, og, spec.param_keys(), False, tol=1e-4)
 
 
-def test_dropout_masks_scale_both_chains():
+def test_dropout_masks_scale_both_chains(split):
     """train mode with p_dropout: the masks multiply the pre-activations in the forward epilogue and the data
     gradient in the backward chain (abnet3/model.py:137,148,157 Dropout between Linear and the activation)."""
     import abnet3_amd.loss as L
     from oracle import siamese_np as O
     kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=100, output_dim=36, activation_layer='sigmoid',
               p_dropout=0.3, batch_norm=False)
-    net, spec, p = build(kw, seed=9, precision='bf16x3')
+    net, spec, p = build(kw, seed=9, precision=split)
     B = 50
     rng = np.random.default_rng(9)
     x1 = rng.standard_normal((B, 40)).astype(np.float32)
@@ -162,7 +162,7 @@ def test_dropout_masks_scale_both_chains():
     check_grads({k: q.grad.cpu().numpy() for k, q in net.named_parameters()}, og, spec.param_keys(), False, tol=1e-4)
 
 
-@pytest.mark.parametrize('precision,NP', [('bf16x3', 3), ('bf16', 1)])
+@pytest.mark.parametrize('precision,NP', [('bf16x3', 3), ('f16x2', 2), ('bf16', 1)])
 def test_operand_images_decode_to_their_tensors(precision, NP):
     """The packed weights (both orientations), the transposed planes of every layer input with their column of
     ones, and the transposed planes of every dZ, read back from the forward workspace / backward scratch."""
@@ -196,7 +196,7 @@ def test_operand_images_decode_to_their_tensors(precision, NP):
     dz = [None, None, dz_top.double().cpu().numpy()]
     for l in (2, 1):
         dz[l - 1] = (dz[l] @ Ws[l]) * acts[l] * (1 - acts[l])
-    eps = 2.0 ** -22 if NP == 3 else 2.0 ** -8           # three bf16 terms carry 24 bits, one carries 8
+    eps = 2.0 ** -22 if NP == 3 else (2.0 ** -21 if NP == 2 else 2.0 ** -8)    # three bf16 terms carry 24 bits, two fp16 22 (of the block's / row's largest), one bf16 8
     steps = lambda c: ((c + 15) // 16 + 3) // 4 * 4
     row_steps = (R + 31) // 32 * 2
     for l in range(3):
@@ -210,7 +210,7 @@ def test_operand_images_decode_to_their_tensors(precision, NP):
         assert np.array_equal(d[dims[l], :R], np.ones(R)) and np.abs(d[dims[l], R:]).max(initial=0) == 0
         assert np.abs(d[dims[l] + 1:]).max(initial=0) == 0
         d = decode_t(sc16[2 * fn(ctypes.byref(desc), R, 2, 3, l):], (dims[l + 1] + 31) // 32, row_steps, NP)
-        tol = 3e-6 if NP == 3 else 3e-2
+        tol = 3e-6 if NP >= 2 else 3e-2
         assert np.abs(d[:dims[l + 1], :R] - dz[l].T).max() <= tol * np.abs(dz[l]).max(), l
         assert np.abs(d[:, R:]).max(initial=0) == 0          # rows past the batch contribute nothing
 
@@ -218,7 +218,7 @@ def test_operand_images_decode_to_their_tensors(precision, NP):
 @pytest.mark.parametrize('lname,avg', [('coscos2', False), ('coscos2', True), ('cosmargin', True), ('cosmargin', False)])
 @pytest.mark.parametrize('B,ydtype,act,p_drop', [(4096, torch.int64, 'sigmoid', 0.0), (33, torch.float32, 'tanh', 0.0),
                                                (70, torch.int8, 'sigmoid', 0.25), (48, torch.float64, 'relu', 0.0)])
-def test_pair_loss_inside_the_backward_equals_the_two_calls(lname, avg, B, ydtype, act, p_drop, monkeypatch):
+def test_pair_loss_inside_the_backward_equals_the_two_calls(lname, avg, B, ydtype, act, p_drop, monkeypatch, split):
     """abn_tower_backward_loss (TrainerSiamese.train_step's path): the data-gradient chain computes the pair loss
     and d loss / d z in its first phase.  Against abn_pair_loss_dz + abn_tower_backward on the same forward: loss
     and every gradient agree to rounding (the per-pair arithmetic is the same, fp64)."""
@@ -227,7 +227,7 @@ def test_pair_loss_inside_the_backward_equals_the_two_calls(lname, avg, B, ydtyp
               activation_layer=act, p_dropout=p_drop, batch_norm=False)
     if act == 'relu':
         kw['last_non_linearity'] = None
-    net, spec, p = build(kw, seed=B, precision='bf16x3')
+    net, spec, p = build(kw, seed=B, precision=split)
     loss = getattr(L, lname)(avg=avg) if lname == 'coscos2' else L.cosmargin(avg=avg, margin=0.3)
     rng = np.random.default_rng(B)
     x1, x2 = dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32))
@@ -258,7 +258,7 @@ def test_pair_loss_inside_the_backward_equals_the_two_calls(lname, avg, B, ydtyp
 
 
 @pytest.mark.parametrize('oname', ['adadelta', 'sgd'])
-def test_persistent_weight_image_follows_every_kind_of_update(oname, monkeypatch):
+def test_persistent_weight_image_follows_every_kind_of_update(oname, monkeypatch, split):
     """abn_tower_desc.wpack: the forward skips its pack launch while the image is known to match the
     parameters (repeated forwards with unchanged weights).  Optimizer launches, torch-side writes and
     state_dict loads must make the next forward rebuild it.  Every variant against the same run without the image."""
@@ -273,7 +273,7 @@ def test_persistent_weight_image_follows_every_kind_of_update(oname, monkeypatch
     outs = []
     for wpack in ('1', '0'):
         monkeypatch.setenv('ABN_WPACK', wpack)
-        net, _, _ = build(kw, seed=1, precision='bf16x3')
+        net, _, _ = build(kw, seed=1, precision=split)
         tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type=oname, lr=0.05, dataloader=None,
                             log_dir='/tmp/abn_runs')
         net.train()
@@ -315,7 +315,7 @@ def test_persistent_weight_image_follows_every_kind_of_update(oname, monkeypatch
         assert rel_err(outs[0][2][k], outs[1][2][k]) < 1e-6, k
 
 
-@pytest.mark.parametrize('precision,NP', [('bf16x3', 3)])
+@pytest.mark.parametrize('precision,NP', [('bf16x3', 3), ('f16x2', 2)])
 def test_dropout_drawn_inside_the_kernels(precision, NP, monkeypatch):
     """p_dropout > 0 without mask tensors (abn_tower_desc.drop_seed): the multipliers are a hash of (seed, layer,
     row, feature) evaluated in the forward epilogue and again in the backward.  Recovered from the activations
@@ -472,7 +472,7 @@ def test_batch_norm_inference_forward_against_the_oracle(shape, act, precision, 
         eg.sum().backward()
 
 
-@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('precision', ['bf16x3', 'f16x2', 'bf16'])
 @pytest.mark.parametrize('shape', SHAPES)
 def test_inference_instantiation_equals_the_training_forward(shape, precision):
     """torch.no_grad() forwards run the instantiation without dropout and transposed images: same arithmetic,
@@ -728,11 +728,11 @@ def test_batch_norm_dropout_train_mode_without_gradients(tmp_path):
     assert len(tr.train_losses) == 3 and all(np.isfinite(tr.train_losses))
 
 
-def test_persistent_weight_image_sees_writes_behind_torch():
+def test_persistent_weight_image_sees_writes_behind_torch(split):
     """Writes that do not bump the parameters' version counters -- init_weight_method's .data writes, a copy into
     the flat buffer (what parallel.broadcast_parameters does) -- still invalidate the persistent weight image."""
     kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=64, output_dim=32, activation_layer='tanh', p_dropout=0.0)
-    net, _, _ = build(kw, seed=11, precision='bf16x3')
+    net, _, _ = build(kw, seed=11, precision=split)
     net.eval()
     x = dev(np.random.default_rng(0).standard_normal((64, 40)).astype(np.float32))
     with torch.no_grad():
@@ -742,7 +742,7 @@ def test_persistent_weight_image_sees_writes_behind_torch():
         net.apply(net.init_weight_method)                      # layer.weight.data / bias.data writes
         b = net.forward_once(x).clone()
         assert not torch.equal(a, b)
-        fresh, _, _ = build(kw, seed=11, precision='bf16x3')
+        fresh, _, _ = build(kw, seed=11, precision=split)
         fresh.eval()
         fresh.load_state_dict(net.state_dict())
         assert torch.equal(fresh.forward_once(x), b)

@@ -20,7 +20,7 @@ def _lib():
     return L, L.load()
 
 
-@pytest.mark.parametrize('precision,tol,gtol', [('bf16x3', 1e-5, 1e-4), ('bf16', 6e-2, None)])      # (bf16: ~3 digits per product, four 280..500-wide layers)
+@pytest.mark.parametrize('precision,tol,gtol', [('bf16x3', 1e-5, 1e-4), ('f16x2', 1e-5, 1e-4), ('bf16', 6e-2, None)])      # (bf16: ~3 digits per product, four 280..500-wide layers)
 @pytest.mark.parametrize('act', ['sigmoid', 'tanh', 'relu'])
 @pytest.mark.parametrize('shape', SHAPES + [(280, 2, 500, 100, 300), (40, 2, 500, 100, 40), (64, 1, 512, 128, 97)])
 def test_forward_loss_and_gradients_against_the_oracle(shape, act, precision, tol, gtol):
@@ -55,7 +55,7 @@ def test_forward_loss_and_gradients_against_the_oracle(shape, act, precision, to
     assert rel_err(e1.detach().cpu().numpy(), o1) < tol and rel_err(e2.detach().cpu().numpy(), o2) < tol
     assert abs(float(lv.detach()) - ol) <= 10 * tol * abs(ol) + 1e-6
     grads = {k: q.grad.cpu().numpy() for k, q in net.named_parameters()}
-    if precision == 'bf16x3':
+    if precision != 'bf16':
         check_grads(grads, og, spec.param_keys(), False, tol=gtol)
     else:
         for k in spec.param_keys()[-2:]:
@@ -67,14 +67,14 @@ def test_forward_loss_and_gradients_against_the_oracle(shape, act, precision, to
     assert lib.abn_debug_last_backward_path() == 6
     assert abs(float(lv2) - float(lv.detach())) <= 1e-6 * abs(float(lv2))
     for k, q in net.named_parameters():
-        assert rel_err(q.grad.cpu().numpy(), grads[k], floor=1e-30) < (1e-6 if precision == 'bf16x3' else 1e-5), k
+        assert rel_err(q.grad.cpu().numpy(), grads[k], floor=1e-30) < (1e-6 if precision != 'bf16' else 1e-5), k
 
 
 @pytest.mark.parametrize('rows', [1, 31, 33, 100, 257])
-def test_forward_once_and_inference(rows):
+def test_forward_once_and_inference(rows, split):
     """One call of any row count; torch.no_grad() (nothing kept for a backward) gives the same bits."""
     kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=100, output_dim=36, activation_layer='tanh', p_dropout=0.0)
-    net, spec, p = build(kw, seed=rows, precision='bf16x3')
+    net, spec, p = build(kw, seed=rows, precision=split)
     from oracle import siamese_np as O
     x = np.random.default_rng(rows).standard_normal((rows, 40)).astype(np.float32)
     lib = _lib()[1]
@@ -90,7 +90,7 @@ def test_forward_once_and_inference(rows):
 
 
 @pytest.mark.parametrize('B,hid,d_in', [(333, 500, 280), (1024, 128, 280), (1200, 128, 40), (640, 500, 280), (130, 64, 40)])
-def test_agrees_with_the_single_launch_chains(B, hid, d_in, monkeypatch):
+def test_agrees_with_the_single_launch_chains(B, hid, d_in, monkeypatch, split):
     """The same step on the chains (ABN_WIDE=0) and on the layer-per-launch kernels (8, 4, 3 and 2 workgroups per
     row block): equal up to the order of the sums."""
     kw = dict(input_dim=d_in, num_hidden_layers=2, hidden_dim=hid, output_dim=100, activation_layer='sigmoid', p_dropout=0.0)
@@ -101,7 +101,7 @@ def test_agrees_with_the_single_launch_chains(B, hid, d_in, monkeypatch):
     res = []
     for wide in ('1', '0'):
         monkeypatch.setenv('ABN_WIDE', wide)
-        net, _, _ = build(kw, seed=7, precision='bf16x3')
+        net, _, _ = build(kw, seed=7, precision=split)
         net.train()
         emb, st = net.direct_forward(x1, x2)
         assert _lib()[1].abn_debug_last_forward_path() == (6 if wide == '1' else 2)
@@ -113,11 +113,11 @@ def test_agrees_with_the_single_launch_chains(B, hid, d_in, monkeypatch):
         assert rel_err(ga[k].cpu().numpy(), gb[k].cpu().numpy(), floor=1e-6 * float(gb[k].abs().max()) + 1e-30) < 2e-4, k
 
 
-def test_input_gradient():
+def test_input_gradient(split):
     import abnet3_amd.loss as L
     from oracle import siamese_np as O
     kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=72, output_dim=36, activation_layer='tanh', p_dropout=0.0)
-    net, spec, p = build(kw, seed=6, precision='bf16x3')
+    net, spec, p = build(kw, seed=6, precision=split)
     B = 45
     rng = np.random.default_rng(6)
     x1n, x2n = rng.standard_normal((B, 40)).astype(np.float32), rng.standard_normal((B, 40)).astype(np.float32)
@@ -137,13 +137,13 @@ def test_input_gradient():
     check_grads({k: q.grad.cpu().numpy() for k, q in net.named_parameters()}, og, spec.param_keys(), False, tol=1e-4)
 
 
-def test_one_layer_tower_and_a_linear_output():
+def test_one_layer_tower_and_a_linear_output(split):
     import abnet3_amd.loss as L
     from oracle import siamese_np as O
     for nh, last in ((0, 'default'), (1, None)):
         kw = dict(input_dim=40, num_hidden_layers=nh, hidden_dim=64, output_dim=32, activation_layer='sigmoid', p_dropout=0.0,
                   last_non_linearity=last)
-        net, spec, p = build(kw, seed=3, precision='bf16x3')
+        net, spec, p = build(kw, seed=3, precision=split)
         B = 70
         rng = np.random.default_rng(3)
         x1, x2 = rng.standard_normal((B, 40)).astype(np.float32), rng.standard_normal((B, 40)).astype(np.float32)
@@ -163,12 +163,12 @@ def test_one_layer_tower_and_a_linear_output():
 
 @pytest.mark.parametrize('avg', [False, True])
 @pytest.mark.parametrize('n', [150, 97, 320])
-def test_a_padded_batch_is_bit_identical_to_the_batch(n, avg):
+def test_a_padded_batch_is_bit_identical_to_the_batch(n, avg, split):
     """n pairs, and the same pairs followed by zero rows up to the next multiple of 32 with the count of real
     pairs in a device word: the same loss and the same gradients, bit for bit (every call is padded to whole
     32-row workgroups anyway, so the two run the same arithmetic in the same order)."""
     kw = dict(input_dim=280, num_hidden_layers=2, hidden_dim=500, output_dim=100, activation_layer='sigmoid', p_dropout=0.0)
-    net, _, _ = build(kw, seed=1, precision='bf16x3')
+    net, _, _ = build(kw, seed=1, precision=split)
     net.train()
     rng = np.random.default_rng(n)
     npad = (n + 31) // 32 * 32
@@ -193,7 +193,7 @@ def test_a_padded_batch_is_bit_identical_to_the_batch(n, avg):
         assert torch.equal(q.grad, ga[k]), k
 
 
-def test_dropout_from_the_seed_matches_its_masks(monkeypatch):
+def test_dropout_from_the_seed_matches_its_masks(monkeypatch, split):
     """p_dropout > 0 without mask tensors: the multipliers are a hash of (seed, layer, row, feature) in the forward
     epilogues and again in the data-gradient launches.  The masks are recovered from the row-major outputs (a dropped
     tanh unit is an exact zero) and fed back as tensors (which run on the single-launch chains): same embeddings,
@@ -202,7 +202,7 @@ def test_dropout_from_the_seed_matches_its_masks(monkeypatch):
     lib = LIB.load()
     p_drop = 0.25
     kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=96, output_dim=32, activation_layer='tanh', p_dropout=p_drop)
-    net, _, _ = build(kw, seed=3, precision='bf16x3')
+    net, _, _ = build(kw, seed=3, precision=split)
     net.train()
     rng = np.random.default_rng(8)
     B = 128
@@ -239,12 +239,12 @@ def test_dropout_from_the_seed_matches_its_masks(monkeypatch):
         assert rel_err(q.grad.cpu().numpy(), grads[k].cpu().numpy(), floor=1e-6 * float(grads[k].abs().max()) + 1e-30) < 1e-4, k
 
 
-def test_eight_calls_of_ragged_length():
+def test_eight_calls_of_ragged_length(split):
     """abn_tower_forward's n_calls (up to 8 forward_once calls in one launch sequence), each padded on its own."""
     from abnet3_amd import _lib as LIB, model as M
     from oracle import siamese_np as O
     kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=64, output_dim=32, activation_layer='sigmoid', p_dropout=0.0)
-    net, spec, p = build(kw, seed=2, precision='bf16x3')
+    net, spec, p = build(kw, seed=2, precision=split)
     net.train()
     x = np.random.default_rng(0).standard_normal((8 * 19, 40)).astype(np.float32)
     seg = net._segment_list()[0]
