@@ -458,14 +458,17 @@ class _HipNetwork(NetworkBuilder):
         self._generation = getattr(self, '_generation', 0)
         self._live_cache = None
         # Arithmetic of the tower GEMMs (abn_tower_desc.precision):
-        #   'bf16x3' (default)  every fp32 operand split into three bf16 terms, six bf16 MFMA
-        #                       products per operand pair, fp32 accumulation: as close to a float64
-        #                       evaluation as fp32 itself is (measured), passes every golden test
-        #                       at the 1e-5 bar, not bit-identical to a sequential fp32 chain;
+        #   'f16x2' (default)   every fp32 operand scaled by a power of two (per operand row / 32-row weight block)
+        #                       and split into two fp16 terms (22 significant bits), three fp16 MFMA products per
+        #                       operand pair, fp32 accumulation: as close to a float64 evaluation as the
+        #                       reference's own fp32 (measured), passes every golden test at the 1e-5 bar;
+        #                       BatchNorm towers run its launches in 'bf16x3';
+        #   'bf16x3'            every fp32 operand split into three bf16 terms (24 bits, no scales), six bf16 MFMA
+        #                       products per operand pair: same grade, ~20 % slower;
         #   'fp32'              exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): one fp32 fma chain per
         #                       output, bit-for-bit what a CPU computes in that order;
         #   'bf16'              operands rounded to bf16 once: ~3 digits, outside the parity bar.
-        self.precision = os.environ.get('ABNET3_PRECISION', 'bf16x3')
+        self.precision = os.environ.get('ABNET3_PRECISION', 'f16x2')
         assert self.precision in _lib.PRECISION, self.precision
 
     def _segments(self):

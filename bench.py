@@ -9,11 +9,13 @@ Workload (BASELINE.json configs[1] / SURVEY.md section 8 "C2"): SiameseNetwork
 40 -> 500 x2 -> 100 (input_dim=40, num_hidden_layers=2, hidden_dim=500,
 output_dim=100, sigmoid, no BN, dropout 0), coscos2(avg=False), Adadelta(lr=0.1),
 4096 synthetic frame pairs per GPU per step.  Tower arithmetic: the package default,
-"bf16x3" -- every fp32 operand split into three bf16 terms, six bf16 MFMA products
-per operand pair, fp32 accumulation: fp32-grade results (every golden parity test
-passes at the 1e-5 bar) on the bf16 matrix cores BASELINE.json names; the exact-fp32
-MFMA mode of the same step is timed beside it (`f32_exact_mode`), and so is the plain
-bf16 mode (outside the parity bar).  One step = what TrainerSiamese.train_step runs:
+"f16x2" -- every fp32 operand scaled by a power of two and split into two fp16 terms
+(22 significant bits), three fp16 MFMA products per operand pair, fp32 accumulation:
+fp32-grade results (every golden parity test passes at the 1e-5 bar, as far from a
+float64 evaluation as the reference's own fp32) on the 16-bit matrix cores
+BASELINE.json names; the bf16 x 3 split (six bf16 products, round 2's headline), the
+exact-fp32 MFMA mode and the plain bf16 mode (outside the parity bar) of the same step
+are timed beside it.  One step = what TrainerSiamese.train_step runs:
 forward of both towers, pair loss, backward, [RCCL all-reduce of the flat gradient
 bucket], optimizer.  Inputs are resident in HBM before the timed region.
 
@@ -42,7 +44,10 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 # bf16 x 3 spends six bf16 MFMA products per algorithmic fp32 product: its matrix-core roof,
 # in algorithmic FLOP/s, is the bf16 peak / 6
 X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
-PREC_CODE = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
+# fp16 x 2 spends three fp16 MFMA products (the F16 forms take the bf16 forms' cycles): peak / 3
+F16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
+PLANES = {'bf16x3': 3, 'f16x2': 2, 'bf16': 1}
+PREC_CODE = {'fp32': 0, 'bf16': 1, 'bf16x3': 2, 'f16x2': 3}
 # MACs per tower row: fwd 570 000, wgrad 570 000, dgrad 550 000
 FLOP_PER_PAIR = 2 * 2 * (570000 + 570000 + 550000)
 
@@ -65,7 +70,7 @@ def kernel_names(prec):
     if prec == 'fp32':
         return ('void abn::tower_fwd_fused_kernel<0>(abn::FusedFwdP)',
                 'void abn::gemm_bwd_pair_kernel<128, 64, 0>(abn::GemmP, int, abn::GemmP)')
-    planes = 3 if prec == 'bf16x3' else 1
+    planes = PLANES[prec]
     return ('void abn::tower_fwd_planes_kernel<%d, 0>(abn::PlanesFwdP)' % planes,
             'void abn::wgrad_planes_kernel<%d>(abn::WgradP)' % planes)
 
@@ -115,7 +120,7 @@ def _traffic(kernel):
 
 
 def planes_roofline(torch, net, reps=20):
-    """precision bf16x3 / bf16 (csrc/tower_planes.h): the step is three launches of similar length -- the
+    """precision f16x2 / bf16x3 / bf16 (csrc/tower_planes.h): the step is three launches of similar length -- the
     forward chain, the data-gradient chain, the weight gradients -- plus the fused reduction + optimizer.
     The line's top level is whichever of the three took LONGEST in this run, the other two follow under their
     names; `whole_step` (added by main) is the timed loop's own figure against the same roof.  wgrad_planes_kernel: every
@@ -127,12 +132,12 @@ def planes_roofline(torch, net, reps=20):
     pack_planes_kernel a step's forward starts with); `forward_backward_sequence_us` is the three in the
     step's order.  Algorithmic FLOPs: weight gradients 2 * 8192 * sum_l N_l (K_l + 1), the chains
     2 * 8192 * sum_l N_l K_l (the data-gradient chain without the first layer).
-    Roof: the dense bf16 MFMA peak divided by the bf16 products each algorithmic product costs (six
-    for bf16x3: 2500 / 6 = 416.7 TFLOP/s algorithmic; one for bf16).  Both peaks assume the 2.4 GHz
+    Roof: the dense 16-bit MFMA peak divided by the MFMA products each algorithmic product costs (three fp16
+    products for f16x2: 2500 / 3 = 833.3 TFLOP/s algorithmic; six for bf16x3: 416.7; one for bf16).  Both peaks assume the 2.4 GHz
     boost clock; under this workload the chip holds ~1.6-1.8 GHz (s_memtime against wall clock,
     tools/probes/mfma_peak.hip).  `hbm` gives the dominant launch's measured TCC traffic over its time."""
     prec = net.precision
-    peak = {'bf16x3': X3_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS}[prec]
+    peak = {'bf16x3': X3_PEAK_TFLOPS, 'f16x2': F16X2_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS}[prec]
     fwd_name, wgrad_name = kernel_names(prec)
     dims = [40, 500, 500, 500, 100]
     rows = 2 * BATCH
@@ -181,7 +186,7 @@ def planes_roofline(torch, net, reps=20):
     fl_w = 2.0 * rows * sum(dims[l + 1] * (dims[l] + 1) for l in range(4))
     fl_d = 2.0 * rows * sum(dims[l + 1] * dims[l] for l in range(1, 4))
     fl_f = 2.0 * rows * sum(dims[l + 1] * dims[l] for l in range(4))
-    planes = 3 if prec == 'bf16x3' else 1
+    planes = PLANES[prec]
     launches = {
         'weight_gradients': (wgrad_name, 'wgrad_planes_kernel<%d>' % planes, times['wgrad'], fl_w,
                              "all four layers' weight and bias gradients, one launch"),
@@ -204,8 +209,10 @@ def planes_roofline(torch, net, reps=20):
     out = {'bound': 'mfma', 'achieved': e['achieved'], 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': e['frac'],
            'traffic': e['traffic'], 'arithmetic': prec,
            'peak_note': {'bf16x3': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per algorithmic product',
+                         'f16x2': 'dense fp16 MFMA 2500 TFLOP/s / 3 fp16 products per algorithmic product',
                          'bf16': 'dense bf16 MFMA'}[prec],
            'frac_of_fp32_mfma_peak': round(e['achieved'] / FP32_MFMA_PEAK_TFLOPS, 4),
+           'frac_of_bf16x3_peak': round(e['achieved'] / X3_PEAK_TFLOPS, 4),
            'dominant': dominant,
            'kernel': e['kernel'], 'avg_launch_us': e['avg_launch_us'],
            'flop_per_launch': e['flop_per_launch']}
@@ -700,6 +707,9 @@ def main():
             net.precision = keep
             err_default = float((torch.cat(net.forward_pair_rows(x12)) - ref).abs().max() / ref.abs().max())
             net.train()
+    x3 = mode_bench(torch, trainer, net, pool, args, world, 'bf16x3',
+                    'fp32 operands split into 3 bf16 terms, 6 bf16 MFMA products per operand pair: parity-grade, the default of rounds 2-3') \
+        if net.precision != 'bf16x3' else None
     f32x = mode_bench(torch, trainer, net, pool, args, world, 'fp32',
                       'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): one sequential fp32 fma chain per output, round 1\'s headline arithmetic')
     bf16 = mode_bench(torch, trainer, net, pool, args, world, 'bf16',
@@ -717,15 +727,21 @@ def main():
             'repeats': len(elapsed_all),
             'ms_per_step_min_max': [round(min(elapsed_all) / args.steps * 1e3, 4), round(max(elapsed_all) / args.steps * 1e3, 4)],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16x3' if net.precision == 'bf16x3' else {'fp32': 'f32', 'bf16': 'bf16'}[net.precision],
+            'dtype': {'fp32': 'f32', 'bf16': 'bf16', 'bf16x3': 'bf16x3', 'f16x2': 'f16x2'}[net.precision],
             'data': 'synthetic',
             'config': {'workload': 'C2: SiameseNetwork 40->500x2->100 sigmoid, coscos2(avg=False), '
                                    'Adadelta(0.1), 4096 frame pairs per GPU per step, 40-d N(0,1) frames',
                        'pairs_per_gpu': BATCH, 'global_pairs': BATCH * world,
                        'parallelism': 'dp%d' % world, 'graph_replay': bool(args.graph),
-                       'arithmetic': 'bf16x3: fp32 operands split into 3 bf16 terms, 6 bf16 MFMA products per '
-                                     'operand pair, fp32 accumulate / storage / loss / optimizer; parity-grade '
-                                     '(all golden tests at 1e-5), see f32_exact_mode for the exact-fp32 MFMA step',
+                       'arithmetic': {'f16x2': 'f16x2: fp32 operands scaled by a power of two per row / block and split into 2 fp16 '
+                                               'terms (22 bits), 3 fp16 MFMA products per operand pair, fp32 accumulate / storage / '
+                                               'loss / optimizer; parity-grade (all golden tests at 1e-5; no further from float64 '
+                                               'than the reference\'s fp32), see bf16x3_mode / f32_exact_mode for the same step in '
+                                               'the other parity-grade arithmetics',
+                                      'bf16x3': 'bf16x3: fp32 operands split into 3 bf16 terms, 6 bf16 MFMA products per '
+                                                'operand pair, fp32 accumulate / storage / loss / optimizer; parity-grade '
+                                                '(all golden tests at 1e-5), see f32_exact_mode for the exact-fp32 MFMA step'
+                                      }.get(net.precision, net.precision),
                        'max_rel_err_embeddings_vs_exact_f32': err_default},
             'tflops_whole_step': round(value * FLOP_PER_PAIR / 1e12, 2),
             'last_loss': last_loss,
@@ -740,6 +756,8 @@ def main():
             cb = cpu_baseline(torch)
             out['cpu_baseline'] = cb
             out['gpu_over_cpu'] = round(value / cb['value'], 1)
+        if x3 is not None:
+            out['bf16x3_mode'] = x3
         out['f32_exact_mode'] = f32x
         if bf16 is not None:
             out['bf16_throughput_mode'] = bf16
