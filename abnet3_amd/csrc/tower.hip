@@ -659,8 +659,8 @@ struct Layout {
     int64_t total;
 };
 
-// operand planes of a tower's arithmetic: bf16 one, bf16 x 3 three, fp16 x 2 two (BatchNorm towers: the bf16 x 3 launches)
-static inline int planes_of(const abn_tower_desc* t) { return t->precision == 3 && !t->batch_norm ? 2 : (t->precision >= 2 ? 3 : 1); }
+// operand planes of a tower's arithmetic: bf16 one, bf16 x 3 three, fp16 x 2 two
+static inline int planes_of(const abn_tower_desc* t) { return t->precision == 3 ? 2 : (t->precision == 2 ? 3 : 1); }
 // one of a kernel's three instantiations (operand planes)
 #define PL_LAUNCH(np, KERNEL, grid, block, lds, st, ...)                                             \
     do {                                                                                             \
@@ -1025,10 +1025,8 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     (void)hipGetDevice(&dev);
     dev = (dev >= 0 && dev < 16) ? dev : 0;
     if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_layer_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(1));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_layer_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(3));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<1>());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes<3>());
+        PL_LDS_ATTR(bn_bwd_layer_kernel, pl_lds_bytes);
+        PL_LDS_ATTR(wgrad_planes_kernel, wgrad_lds_of);
         attr_set[dev] = true;
     }
     const int wgs_per_call = (int)bn_wgs_per_call(rows, n_calls);
@@ -1060,13 +1058,13 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
         q.drop_seed = reinterpret_cast<const unsigned long long*>(t->drop_seed);
         q.drop_p = t->drop_p;
         q.dzp = reinterpret_cast<char*>(scratch + B.dzp[l]);
+        q.amax_dz = B.amax_dz[l] >= 0 ? scratch + B.amax_dz[l] : nullptr;
         q.tp_steps = tp_steps;
         q.wpt = (l >= 1 || dx) ? image + PL.wpt[l] : nullptr;
         q.da_prev = l >= 1 ? scratch + B.dz[cur ^ 1] : dx;
         if (l >= 1) { q.z_prev = ws + L.xhat[l - 1]; q.mean_prev = ws + L.mean[l - 1]; q.invstd_prev = ws + L.invstd[l - 1];
                       q.gamma_prev = t->bn_w[l - 1]; q.beta_prev = t->bn_b[l - 1]; q.part_out = part; }
-        if (np == 3) hipLaunchKernelGGL(bn_bwd_layer_kernel<3>, cgrid, dim3(PL_NT), pl_lds_bytes(3), st, q);
-        else hipLaunchKernelGGL(bn_bwd_layer_kernel<1>, cgrid, dim3(PL_NT), pl_lds_bytes(1), st, q);
+        PL_LAUNCH(np, bn_bwd_layer_kernel, cgrid, dim3(PL_NT), pl_lds_bytes(np), st, q);
         if (l >= 1) {
             hipLaunchKernelGGL(bn_bwd_finish_wg_kernel, dim3((unsigned)((q.K + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, part, wgs_per_call,
                                q.K, (int)n_calls, s1, s2, t->dbn_w[l - 1], t->dbn_b[l - 1]);
@@ -1076,8 +1074,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     int n_wg = 0;
     WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
     w.tp_steps = tp_steps;
-    if (np == 3) hipLaunchKernelGGL(wgrad_planes_kernel<3>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<3>(), st, w);
-    else hipLaunchKernelGGL(wgrad_planes_kernel<1>, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_bytes<1>(), st, w);
+    PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_of(np), st, w);
     ABN_CHECK_LAUNCH("tower_backward (BatchNorm, planes)");
     if (t->defer_reduce) return ABN_OK;               // abn_tower_reduce_step finishes the job (the slabs of THIS launch: psplits)
     const ReduceTable rt = make_reduce_table(t, B);
@@ -1131,6 +1128,7 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
         b.dzp[l] = reinterpret_cast<char*>(scratch + B.dzp[l]);
         b.amax_dz[l] = B.amax_dz[l] >= 0 ? scratch + B.amax_dz[l] : nullptr;
     }
+    b.wbase = image; b.wbytes = PL.bytes;
     int n_wg = 0;
     const WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
     static bool bw_attr_set[16] = {};
@@ -1352,6 +1350,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         const bool repack = !(t->wpack && t->wpack_valid);
         ABN_REQUIRE(aligned16(image), "tower_forward: wpack must be 16-byte aligned");
         pk.base = image;
+        f.wbase = image; f.wbytes = PL.bytes;
         for (int l = 0; l <= t->n_layers; ++l) f.dims[l] = (int)t->dims[l];
         for (int l = 0; l < t->n_layers; ++l) {
             f.act[l] = (l == t->n_layers - 1) ? t->last_act : t->act;
@@ -1439,10 +1438,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         if (bn_train) {
             static bool bn_attr_set[16] = {};
             if (!bn_attr_set[dev]) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_fwd_layer_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(1));
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_fwd_layer_kernel<3>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl_lds_bytes(3));
+                PL_LDS_ATTR(bn_fwd_layer_kernel, pl_lds_bytes);
                 bn_attr_set[dev] = true;
             }
             f.bn_part = ws + L.bn_wg;
@@ -1454,13 +1450,13 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 PlanesFwdP fl = f;
                 for (int i = 0; i < nl; ++i) { fl.tp[i] = nullptr; fl.out[i] = nullptr; }
                 fl.tp[l] = reinterpret_cast<char*>(ws + L.tp[l]);        // [a_{l-1} | 1] transposed: the weight gradient's operand
+                fl.amax[l] = L.amax[l] >= 0 ? ws + L.amax[l] : nullptr;
                 fl.act[l] = ACT_NONE;                          // z_l leaves the launch as it is; act[l - 1] is applied on the way in
                 fl.out[l] = ws + L.xhat[l];                    // (z lands where xhat will live)
                 BnTrainP q = {};
                 q.l = l;
                 if (l > 0) { q.mean = ws + L.mean[l - 1]; q.invstd = ws + L.invstd[l - 1]; q.z_prev = ws + L.xhat[l - 1]; q.a_prev = nullptr; }
-                if (np == 3) hipLaunchKernelGGL(bn_fwd_layer_kernel<3>, bgrid, dim3(PL_NT), pl_lds_bytes(3), st, fl, q);
-                else hipLaunchKernelGGL(bn_fwd_layer_kernel<1>, bgrid, dim3(PL_NT), pl_lds_bytes(1), st, fl, q);
+                PL_LAUNCH(np, bn_fwd_layer_kernel, bgrid, dim3(PL_NT), pl_lds_bytes(np), st, fl, q);
                 const int N = (int)t->dims[l + 1];
                 hipLaunchKernelGGL(bn_stats_finish_wg_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, ws + L.bn_wg,
                                    (int)wpc, rpc, N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l],
@@ -1483,7 +1479,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
             {reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_TRAIN>), reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_INFER>),
              reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_INFER_BN>)},
             {reinterpret_cast<const void*>(tower_fwd_planes_kernel<2, PL_TRAIN>), reinterpret_cast<const void*>(tower_fwd_planes_kernel<2, PL_INFER>),
-             nullptr},
+             reinterpret_cast<const void*>(tower_fwd_planes_kernel<2, PL_INFER_BN>)},
             {reinterpret_cast<const void*>(tower_fwd_planes_kernel<3, PL_TRAIN>), reinterpret_cast<const void*>(tower_fwd_planes_kernel<3, PL_INFER>),
              reinterpret_cast<const void*>(tower_fwd_planes_kernel<3, PL_INFER_BN>)}};
         if (!pl_attr_set[dev]) {

@@ -398,34 +398,56 @@ __device__ __forceinline__ float packed_inv(const char* __restrict__ image, int 
 // ---------------------------------------------------------------------------------------------
 // the chains' k-loop
 // ---------------------------------------------------------------------------------------------
-// acc[j] += image block (blk0 + j) x img, over steps s_first .. s_first + my_steps (a multiple of PL_DEPTH)
-template <int NP, int BPW>
-__device__ __forceinline__ void planes_kloop(f32x16* acc, const char* __restrict__ image, int nblk, int nsteps,
-                                             const char* __restrict__ img, int blk0, int s_first, int my_steps, int lane)
+// The weight ring of a wave: PL_DEPTH steps of (up to) two blocks, in registers.  It is filled with raw buffer loads:
+// the compiler counts their vmcnt itself, and -- unlike plain loads, which InstCombine sinks through the loop's phi
+// right in front of their MFMAs -- they stay where the pipeline puts them, PL_DEPTH steps ahead.
+// A chain keeps ONE ring through its layers (rs spans the whole packed image, offsets are relative to it): where the
+// next layer gives the wave the same share (two blocks, all steps), the last PL_DEPTH refills of a layer fetch the
+// next layer's first steps instead of repeats nobody reads -- they are in flight through the epilogue, OLDER than its
+// image stores, so the next k-loop starts without a round trip (`filled`).
+// (measured at C2, fp16 x 2: 0.1851-0.1866 ms / step with the hand-over against 0.1848-0.1850 without -- the k-loops
+// are bound by what the 32 CUs of an XCD pull from its L2, a round trip less per layer changes nothing, and the ring
+// held through the epilogue spills: off unless built with -DPL_HANDOVER_ON)
+#ifdef PL_HANDOVER_ON
+constexpr bool PL_HANDOVER = true;
+#else
+constexpr bool PL_HANDOVER = false;
+#endif
+template <int NP>
+struct WeightRing {
+    __amdgpu_buffer_rsrc_t rs;
+    v4i wq[PL_DEPTH][2][NP];
+    bool filled;
+};
+template <int NP>
+__device__ __forceinline__ void ring_open(WeightRing<NP>& ring, const char* base, int64_t bytes)
 {
-    // The weight ring is filled with raw buffer loads: the compiler counts their vmcnt itself, and --
-    // unlike plain loads, which InstCombine sinks through the loop's phi right in front of their
-    // MFMAs -- they stay where the pipeline puts them, PL_DEPTH steps ahead.
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(image), 0, nblk * nsteps * (NP * 1024), 0x00020000);
-    int wv[BPW];
-#pragma unroll
-    for (int j = 0; j < BPW; ++j) {
-        const int blk = blk0 + j < nblk ? blk0 + j : nblk - 1;        // an odd block count leaves the last wave half idle
-        wv[j] = (blk * nsteps + s_first) * (NP * 1024) + lane * 16;
-    }
+    ring.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)bytes, 0x00020000);
+    ring.filled = false;
+}
+
+// acc[j] += block j x img over my_steps steps (a multiple of PL_DEPTH).  wv[j]: byte offset (from the ring's base) of
+// block j's first step for this lane; dnext[j] (wave-uniform): what to add to reach the block the wave takes in the
+// next layer (chain_next), whose first PL_DEPTH steps the ring holds on return.
+template <int NP, int BPW>
+__device__ __forceinline__ void ring_kloop(f32x16* acc, WeightRing<NP>& ring, const int* wv, const int* dnext, bool chain_next,
+                                           const char* __restrict__ img, int s_first, int my_steps, int lane)
+{
     const char* ab = img + (int64_t)s_first * (NP * 1024) + lane * 16;
-    v4i wq[PL_DEPTH][BPW][NP];
+    const __amdgpu_buffer_rsrc_t rs = ring.rs;
+    if (!ring.filled) {
 #pragma unroll
-    for (int i = 0; i < PL_DEPTH; ++i)
+        for (int i = 0; i < PL_DEPTH; ++i)
 #pragma unroll
-        for (int j = 0; j < BPW; ++j)
+            for (int j = 0; j < BPW; ++j)
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                // (fenced one by one: the in-order vmcnt the compiler derives for the loop is the worst of
-                // the loop's own order and this one)
-                wq[i][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, wv[j], (i * NP + pl) * 1024, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int pl = 0; pl < NP; ++pl) {
+                    // (fenced one by one: the in-order vmcnt the compiler derives for the loop is the worst of
+                    // the loop's own order and this one)
+                    ring.wq[i][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, wv[j], (i * NP + pl) * 1024, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    }
     // activation fragments: read one step ahead, into alternating register sets
     bf16x8 af[2][NP];
 #pragma unroll
@@ -447,21 +469,42 @@ __device__ __forceinline__ void planes_kloop(f32x16* acc, const char* __restrict
             for (int t = 0; t < Products<NP>::N; ++t)
 #pragma unroll
                 for (int j = 0; j < BPW; ++j)
-                    acc[j] = pl_mfma<NP>(__builtin_bit_cast(bf16x8, wq[i][j][Products<NP>::A[t]]), a[Products<NP>::B[t]], acc[j]);
+                    acc[j] = pl_mfma<NP>(__builtin_bit_cast(bf16x8, ring.wq[i][j][Products<NP>::A[t]]), a[Products<NP>::B[t]], acc[j]);
             // (pure MFMA nodes float across a sched_barrier at instruction selection: the empty asm
             // ties the accumulators, and with them every MFMA of the step, in front of the refills)
 #pragma unroll
             for (int j = 0; j < BPW; ++j) asm volatile("" : "+v"(acc[j]) :: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            // refill the slot for step s + PL_DEPTH (clamped: the last PL_DEPTH loads are repeats nobody reads)
-            const int sn = s + PL_DEPTH < my_steps ? s + PL_DEPTH : my_steps - 1;
+            // refill the slot for step s + PL_DEPTH; past this layer's last step: the next layer's step i (chain_next),
+            // else a repeat nobody reads
+            const bool past = s + PL_DEPTH >= my_steps;
 #pragma unroll
-            for (int j = 0; j < BPW; ++j)
+            for (int j = 0; j < BPW; ++j) {
+                const int so = past ? (chain_next ? dnext[j] + i * (NP * 1024) : (my_steps - 1) * (NP * 1024)) : (s + PL_DEPTH) * (NP * 1024);
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) wq[i][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, wv[j], (sn * NP + pl) * 1024, 0);
+                for (int pl = 0; pl < NP; ++pl) ring.wq[i][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, wv[j], so + pl * 1024, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    ring.filled = chain_next;
+}
+
+// one layer's k-loop on a ring of its own (the launches that hold one layer: BatchNorm's data gradient)
+template <int NP, int BPW>
+__device__ __forceinline__ void planes_kloop(f32x16* acc, const char* __restrict__ image, int nblk, int nsteps,
+                                             const char* __restrict__ img, int blk0, int s_first, int my_steps, int lane)
+{
+    WeightRing<NP> ring;
+    ring_open(ring, image, (int64_t)nblk * nsteps * (NP * 1024));
+    int wv[BPW], dnext[BPW];
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+        const int blk = blk0 + j < nblk ? blk0 + j : nblk - 1;        // an odd block count leaves the last wave half idle
+        wv[j] = (blk * nsteps + s_first) * (NP * 1024) + lane * 16;
+        dnext[j] = 0;
+    }
+    ring_kloop<NP, BPW>(acc, ring, wv, dnext, false, img, s_first, my_steps, lane);
 }
 
 // which blocks and steps a wave sums in a layer with `nblk` output blocks (KS = 2, at most 4 blocks:
@@ -549,6 +592,8 @@ struct PlanesFwdP {
     const float* x2;               // may be null: all rows in x1
     float* x_copy;                 // [rows, dims[0]] concatenated copy for the backward (may be null)
     const char* wp[ABN_MAX_LAYERS];   // packed forward image of layer l
+    const char* wbase;                // the packed images' common buffer (wp[l] - wbase fits an int) and its size
+    int64_t wbytes;
     const float* b[ABN_MAX_LAYERS];
     const float* mask[ABN_MAX_LAYERS];
     float* out[ABN_MAX_LAYERS];    // [rows, dims[l+1]] post-activation outputs, row-major: the last layer's (the others' may be null)
@@ -600,7 +645,7 @@ __device__ __forceinline__ float half_wave_sum(float v)
 template <int NP, int BPW, int KS, int MODE = PL_TRAIN>
 __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* __restrict__ img,
                                              float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0,
-                                             float& ainv, int row_end = -1)
+                                             float& ainv, WeightRing<NP>& ring, int row_end = -1)
 {
     constexpr bool BN = MODE == PL_INFER_BN, INFER = MODE == PL_INFER || MODE == PL_INFER_BN, BNT = MODE == PL_BN_TRAIN;
     const int rows_lim = row_end >= 0 ? row_end : p.rows;      // (BatchNorm training: the end of the workgroup's forward_once call)
@@ -635,7 +680,31 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
             bn_lane[0] = p.bn_rm[l][nc]; bn_lane[1] = p.bn_rv[l][nc]; bn_lane[2] = p.bn_w[l][nc]; bn_lane[3] = p.bn_b[l][nc];
         }
     }
-    if (ws.active) planes_kloop<NP, BPW>(acc, p.wp[l], nblk, nsteps, img, blk0, ws.s_first, ws.my_steps, lane);
+    {
+        // the ring is handed on where the next layer gives every wave the same share (two blocks, all steps)
+        bool chain_next = false;
+        int nblk2 = 1, nsteps2 = 0, ioff2 = 0;
+        if constexpr (PL_HANDOVER && NP <= 2 && BPW == 2 && KS == 1 && !BNT) {
+            if (l + 1 < p.n_layers) {
+                nblk2 = (p.dims[l + 2] + 31) / 32;
+                nsteps2 = pl_steps(N);
+                ioff2 = (int)(p.wp[l + 1] - p.wbase);
+                chain_next = nblk2 > PL_WAVES;
+            }
+        }
+        if (!ws.active) ring.filled = false;
+        const int ioff = (int)(p.wp[l] - p.wbase);
+        int wv[BPW], dnext[BPW];
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int blk = blk0 + j < nblk ? blk0 + j : nblk - 1;        // an odd block count leaves the last wave half idle
+            const int o = ioff + (blk * nsteps + ws.s_first) * (NP * 1024);
+            const int blk2 = blk0 + j < nblk2 ? blk0 + j : nblk2 - 1;
+            wv[j] = o + lane * 16;
+            dnext[j] = ioff2 + blk2 * nsteps2 * (NP * 1024) - o;
+        }
+        if (ws.active) ring_kloop<NP, BPW>(acc, ring, wv, dnext, chain_next, img, ws.s_first, ws.my_steps, lane);
+    }
     PSTAMPF(3 + 5 * l);
 
     // epilogue.  Register q of block j is output feature 32 (blk0 + j) + (q & 3) + 8 (q >> 2) + 4 h of
@@ -918,15 +987,17 @@ __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
     PSTAMPF(0);
 
     float ainv = 1.0f;
+    WeightRing<NP> ring;
+    ring_open(ring, p.wbase, p.wbytes);
     planes_input_stage<NP, INFER>(p, img, part, idf, wave, lane, row0, ainv);
     PSTAMPF(1);
     __syncthreads();
 
     for (int l = 0; l < p.n_layers; ++l) {
         const int nblk = (p.dims[l + 1] + 31) / 32;
-        if (nblk > PL_WAVES) planes_layer<NP, 2, 1, MODE>(p, l, img, part, idf, wave, lane, row0, ainv);
-        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, MODE>(p, l, img, part, idf, wave, lane, row0, ainv);
-        else planes_layer<NP, 1, 2, MODE>(p, l, img, part, idf, wave, lane, row0, ainv);
+        if (nblk > PL_WAVES) planes_layer<NP, 2, 1, MODE>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
+        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, MODE>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
+        else planes_layer<NP, 1, 2, MODE>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
     }
     PSTAMPF(2 + 5 * p.n_layers);
 }
@@ -965,7 +1036,9 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
     const int l = q.l;
     bf16x8 idf[2];
     make_identity<NP>(idf, lane);
-    float ainv = 1.0f;                                 // (fp16 x 2 does not reach the BatchNorm launches)
+    float ainv = 1.0f;
+    WeightRing<NP> ring;
+    ring_open(ring, p.wbase, p.wbytes);
 
     if (l == 0) {
         planes_input_stage<NP, false>(p, img, part, idf, wave, lane, row0, ainv, row_end);
@@ -986,45 +1059,86 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
         const float* const zrow = q.z_prev + (int64_t)(row_ok ? gr : row0) * K;
         float* const arow = q.a_prev ? q.a_prev + (int64_t)gr * K : nullptr;
         char* const tp = p.tp[l];
+        float* const sc = part + PL_PART_BYTES / 4;
+        const float* const inv_tab = sc + PL_WAVES * 64 + wave * 32;
         with_act(p.act[l - 1], [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
-            for (int kb = wave; kb < blocks; kb += PL_WAVES) {
-                Frag<NP> f[2];
+            // one 16-feature step of the normalised, activated input for this lane's row
+            auto in_step = [&](int s, f32x4* v) {
+                v[0] = v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) {
-                    const int s = 2 * kb + t2;
-                    f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                for (int u = 0; u < 2; ++u) {
+                    const int c = 16 * s + 4 * h + 8 * u;
+                    if (c < K && row_ok) {
+                        const f32x4 z4 = *reinterpret_cast<const f32x4*>(zrow + c);
+                        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean_s + c), is = *reinterpret_cast<const f32x4*>(is_s + c);
+                        const f32x4 ga = *reinterpret_cast<const f32x4*>(ga_s + c), be = *reinterpret_cast<const f32x4*>(be_s + c);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int c = 16 * s + 4 * h + 8 * u;
-                        if (c < K && row_ok) {
-                            const f32x4 z4 = *reinterpret_cast<const f32x4*>(zrow + c);
-                            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean_s + c), is = *reinterpret_cast<const f32x4*>(is_s + c);
-                            const f32x4 ga = *reinterpret_cast<const f32x4*>(ga_s + c), be = *reinterpret_cast<const f32x4*>(be_s + c);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[u][e] = act_apply(((z4[e] - mu[e]) * is[e]) * ga[e] + be[e], ACT);
-                            if (arow) *reinterpret_cast<f32x4*>(arow + c) = v[u];
-                        }
+                        for (int e = 0; e < 4; ++e) v[u][e] = act_apply(((z4[e] - mu[e]) * is[e]) * ga[e] + be[e], ACT);
+                        if (arow) *reinterpret_cast<f32x4*>(arow + c) = v[u];
                     }
-                    f[t2] = make_frag<NP>(v[0], v[1]);
-                    store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
                 }
-                if (tp && kb < pl_blocks(K + 1))
-                    emit_planes<NP>(tp + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
-                                    kb == K / 32 ? K % 32 : -1, row_end - row0);
+            };
+            if constexpr (NP == 2) {
+                // fp16 x 2: a wave's (up to two) blocks wait in registers until the workgroup has agreed on the rows' scales
+                f32x4 v[2][2][2];
+                float m = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        const int kb = wave + PL_WAVES * u;
+                        v[u][t2][0] = v[u][t2][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (kb < blocks) in_step(2 * kb + t2, v[u][t2]);
+                        m = fmaxf(m, absmax8(v[u][t2][0], v[u][t2][1]));
+                    }
+                sc[wave * 64 + lane] = m;
+                __syncthreads();
+                float osc;
+                m = row_scales(sc, wave, lane, osc, ainv);
+                if (tp && wave == 0) store_amax_rows(p.amax[l] + (int64_t)blockIdx.x * PL_AMAX, m, 1.0f, lane);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kb = wave + PL_WAVES * u;
+                    if (kb < blocks) {
+                        Frag<NP> f[2];
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            f[t2] = make_frag<NP>(v[u][t2][0], v[u][t2][1], osc);
+                            store_frag<NP>(img + (int64_t)(2 * kb + t2) * (NP * 1024) + lane * 16, f[t2]);
+                        }
+                        if (tp && kb < pl_blocks(K + 1))
+                            emit_planes<NP>(tp + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
+                                            kb == K / 32 ? K % 32 : -1, row_end - row0, inv_tab);
+                    }
+                }
+            } else {
+                for (int kb = wave; kb < blocks; kb += PL_WAVES) {
+                    Frag<NP> f[2];
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        f32x4 v[2];
+                        in_step(2 * kb + t2, v);
+                        f[t2] = make_frag<NP>(v[0], v[1]);
+                        store_frag<NP>(img + (int64_t)(2 * kb + t2) * (NP * 1024) + lane * 16, f[t2]);
+                    }
+                    if (tp && kb < pl_blocks(K + 1))
+                        emit_planes<NP>(tp + ((int64_t)kb * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
+                                        kb == K / 32 ? K % 32 : -1, row_end - row0);
+                }
             }
         });
         if (tp && pl_blocks(K + 1) > blocks && wave == PL_WAVES - 1) {      // K % 32 == 0 and no padding block to hold the ones
             Frag<NP> z[2] = {};
-            emit_planes<NP>(tp + ((int64_t)(K / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, row_end - row0);
+            emit_planes<NP>(tp + ((int64_t)(K / 32) * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, row_end - row0, inv_tab);
         }
     }
     __syncthreads();
 
     const int nblk = (p.dims[l + 1] + 31) / 32;
-    if (nblk > PL_WAVES) planes_layer<NP, 2, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, ainv, row_end);
-    else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, ainv, row_end);
-    else planes_layer<NP, 1, 2, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, ainv, row_end);
+    if (nblk > PL_WAVES) planes_layer<NP, 2, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, ainv, ring, row_end);
+    else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, ainv, ring, row_end);
+    else planes_layer<NP, 1, 2, PL_BN_TRAIN>(p, l, img, part, idf, wave, lane, row0, ainv, ring, row_end);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1042,6 +1156,8 @@ struct PlanesBwdP {
     float* dx;                            // optional [rows, dims[0]]: gradient w.r.t. the inputs (needs wpt[0])
     const float* mask[ABN_MAX_LAYERS];
     const char* wpt[ABN_MAX_LAYERS];      // packed W_l^T images, l >= 1
+    const char* wbase;                    // the packed images' common buffer and its size
+    int64_t wbytes;
     char* dzp[ABN_MAX_LAYERS];            // out: transposed planes of dZ_l (dims[l+1] features)
     float* amax_dz[ABN_MAX_LAYERS];       // fp16 x 2: dzp[l]'s maxima, PL_AMAX floats per 32-row block
     int64_t tp_steps;
@@ -1068,7 +1184,8 @@ struct PlanesBwdP {
 // dZ_{l-1} from dZ_l (in img, pl_steps(dims[l+1]) steps): output features = the dims[l] inputs of layer l
 template <int NP, int BPW, int KS>
 __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, char* __restrict__ img,
-                                                   float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0, float& ainv)
+                                                   float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0, float& ainv,
+                                                   WeightRing<NP>& ring)
 {
     const int N = p.dims[l + 1], K = p.dims[l];        // sum over N, K output features
     const int nsteps = pl_steps(N), nblk = (K + 31) / 32;
@@ -1084,7 +1201,31 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
     float cinv[BPW];                                   // fp16 x 2: what turns an accumulator into the product
 #pragma unroll
     for (int j = 0; j < BPW; ++j) cinv[j] = NP == 2 && ws.active ? packed_inv(p.wpt[l], nblk, nsteps, blk0 + j) * ainv : 1.0f;
-    if (ws.active) planes_kloop<NP, BPW>(acc, p.wpt[l], nblk, nsteps, img, blk0, ws.s_first, ws.my_steps, lane);
+    {
+        // the ring is handed on where the next layer down gives every wave the same share (two blocks, all steps)
+        bool chain_next = false;
+        int nblk2 = 1, nsteps2 = 0, ioff2 = 0;
+        if constexpr (PL_HANDOVER && NP <= 2 && BPW == 2 && KS == 1) {
+            if (l - 1 >= (p.dx ? 0 : 1)) {
+                nblk2 = (p.dims[l - 1] + 31) / 32;
+                nsteps2 = pl_steps(K);
+                ioff2 = (int)(p.wpt[l - 1] - p.wbase);
+                chain_next = nblk2 > PL_WAVES;
+            }
+        }
+        if (!ws.active) ring.filled = false;
+        const int ioff = (int)(p.wpt[l] - p.wbase);
+        int wv[BPW], dnext[BPW];
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int blk = blk0 + j < nblk ? blk0 + j : nblk - 1;
+            const int o = ioff + (blk * nsteps + ws.s_first) * (NP * 1024);
+            const int blk2 = blk0 + j < nblk2 ? blk0 + j : nblk2 - 1;
+            wv[j] = o + lane * 16;
+            dnext[j] = ioff2 + blk2 * nsteps2 * (NP * 1024) - o;
+        }
+        if (ws.active) ring_kloop<NP, BPW>(acc, ring, wv, dnext, chain_next, img, ws.s_first, ws.my_steps, lane);
+    }
 
     const float* __restrict__ mask = l >= 1 ? p.mask[l - 1] : nullptr;
     const DropGen drop = make_drop(l >= 1 && !mask ? p.drop_seed : nullptr, p.drop_p, l - 1);
@@ -1409,11 +1550,13 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
     }
     __syncthreads();
 
+    WeightRing<NP> ring;
+    ring_open(ring, p.wbase, p.wbytes);
     for (int l = top; l >= (p.dx ? 0 : 1); --l) {
         const int nblk = (p.dims[l] + 31) / 32;
-        if (nblk > PL_WAVES) planes_dgrad_layer<NP, 2, 1>(p, l, img, part, idf, wave, lane, row0, ainv);
-        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l + 1]) % (2 * PL_DEPTH) != 0) planes_dgrad_layer<NP, 1, 1>(p, l, img, part, idf, wave, lane, row0, ainv);
-        else planes_dgrad_layer<NP, 1, 2>(p, l, img, part, idf, wave, lane, row0, ainv);
+        if (nblk > PL_WAVES) planes_dgrad_layer<NP, 2, 1>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
+        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l + 1]) % (2 * PL_DEPTH) != 0) planes_dgrad_layer<NP, 1, 1>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
+        else planes_dgrad_layer<NP, 1, 2>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
     }
 }
 
@@ -1441,6 +1584,7 @@ struct BnBwdP {
     const unsigned long long* drop_seed;   // the forward's in-kernel dropout, regenerated here (null: off; mask wins)
     float drop_p;
     char* dzp;                     // out: transposed planes of dz_l
+    float* amax_dz;                // fp16 x 2: dzp's maxima, PL_AMAX floats per 32-row block
     int64_t tp_steps;
     const char* wpt;               // packed W_l^T (null: no product -- layer 0 without an input gradient)
     float* da_prev;                // out [rows][K]: d loss / d a_{l-1}, or d loss / d input for l == 0
@@ -1454,7 +1598,7 @@ struct BnBwdP {
 
 template <int NP, int BPW, int KS>
 __device__ __forceinline__ void bn_dgrad_product(const BnBwdP& q, char* __restrict__ img, float* __restrict__ part, int wave,
-                                                 int lane, int row0, int row_end, int call)
+                                                 int lane, int row0, int row_end, int call, float ainv)
 {
     const int N = q.N, K = q.K;                       // sum over N, K output features
     const int nsteps = pl_steps(N), nblk = (K + 31) / 32;
@@ -1476,6 +1620,14 @@ __device__ __forceinline__ void bn_dgrad_product(const BnBwdP& q, char* __restri
     if (KS == 2) {
 #pragma unroll
         for (int x = 0; x < 16; ++x) acc[0][x] += part[(wave * 16 + x) * 64 + lane];
+    }
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const float cinv = packed_inv(q.wpt, nblk, nsteps, blk0 + j) * ainv;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) acc[j][x] *= cinv;
+        }
     }
     const int gr = row0 + r;
     const bool row_ok = gr < row_end;
@@ -1558,51 +1710,92 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
     const float* const zrow = q.z + (int64_t)grc * N;
     const float* const mrow = q.mask ? q.mask + (int64_t)grc * N : nullptr;
     const DropGen drop = make_drop(q.mask ? nullptr : q.drop_seed, q.drop_p, q.l);
+    float* const sc = part + PL_PART_BYTES / 4;
+    float ainv = 1.0f;
     with_act(q.act_l, [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
-        for (int kb = wave; kb < blocks; kb += PL_WAVES) {
-            Frag<NP> f[2];
+        // one 16-feature step of dz_l for this lane's row
+        auto dz_step = [&](int s, f32x4* v) {
+            v[0] = v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                const int s = 2 * kb + t2;
-                f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            for (int u = 0; u < 2; ++u) {
+                const int c = 16 * s + 4 * h + 8 * u;
+                if (c < N && row_ok) {
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + c), z4 = *reinterpret_cast<const f32x4*>(zrow + c);
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(mu_s + c), is = *reinterpret_cast<const f32x4*>(is_s + c);
+                    f32x4 xh;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int c = 16 * s + 4 * h + 8 * u;
-                    if (c < N && row_ok) {
-                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + c), z4 = *reinterpret_cast<const f32x4*>(zrow + c);
-                        const f32x4 mu = *reinterpret_cast<const f32x4*>(mu_s + c), is = *reinterpret_cast<const f32x4*>(is_s + c);
-                        f32x4 xh;
+                    for (int e = 0; e < 4; ++e) xh[e] = (z4[e] - mu[e]) * is[e];
+                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(k_s + c), ga = *reinterpret_cast<const f32x4*>(ga_s + c);
+                    const f32x4 be = *reinterpret_cast<const f32x4*>(be_s + c);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(s1_s + c), a2 = *reinterpret_cast<const f32x4*>(s2_s + c);
+                    f32x4 m4 = {1.f, 1.f, 1.f, 1.f};
+                    if (mrow) m4 = *reinterpret_cast<const f32x4*>(mrow + c);
+                    else if (drop.on) m4 = drop4(drop, gr, c);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) xh[e] = (z4[e] - mu[e]) * is[e];
-                        const f32x4 k4 = *reinterpret_cast<const f32x4*>(k_s + c), ga = *reinterpret_cast<const f32x4*>(ga_s + c);
-                        const f32x4 be = *reinterpret_cast<const f32x4*>(be_s + c);
-                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(s1_s + c), a2 = *reinterpret_cast<const f32x4*>(s2_s + c);
-                        f32x4 m4 = {1.f, 1.f, 1.f, 1.f};
-                        if (mrow) m4 = *reinterpret_cast<const f32x4*>(mrow + c);
-                        else if (drop.on) m4 = drop4(drop, gr, c);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float a = act_apply(xh[e] * ga[e] + be[e], ACT);
-                            const float dy = d4[e] * act_grad(a, ACT);
-                            v[u][e] = k4[e] * (nf * dy - a1[e] - xh[e] * a2[e]) * m4[e];
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = act_apply(xh[e] * ga[e] + be[e], ACT);
+                        const float dy = d4[e] * act_grad(a, ACT);
+                        v[u][e] = k4[e] * (nf * dy - a1[e] - xh[e] * a2[e]) * m4[e];
                     }
                 }
-                f[t2] = make_frag<NP>(v[0], v[1]);
-                store_frag<NP>(img + (int64_t)s * (NP * 1024) + lane * 16, f[t2]);
             }
-            if (kb < pl_blocks(N))
-                emit_planes<NP>(q.dzp + ((int64_t)kb * q.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane, -1, 0);
+        };
+        if constexpr (NP == 2) {
+            // fp16 x 2: a wave's (up to two) blocks wait in registers until the workgroup has agreed on the rows' scales
+            f32x4 v[2][2][2];
+            float m = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int kb = wave + PL_WAVES * u;
+                    v[u][t2][0] = v[u][t2][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (kb < blocks) dz_step(2 * kb + t2, v[u][t2]);
+                    m = fmaxf(m, absmax8(v[u][t2][0], v[u][t2][1]));
+                }
+            sc[wave * 64 + lane] = m;
+            __syncthreads();
+            float osc;
+            m = row_scales(sc, wave, lane, osc, ainv);
+            if (wave == 0) store_amax_rows(q.amax_dz + (int64_t)blockIdx.x * PL_AMAX, m, 0.0f, lane);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kb = wave + PL_WAVES * u;
+                if (kb < blocks) {
+                    Frag<NP> f[2];
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        f[t2] = make_frag<NP>(v[u][t2][0], v[u][t2][1], osc);
+                        store_frag<NP>(img + (int64_t)(2 * kb + t2) * (NP * 1024) + lane * 16, f[t2]);
+                    }
+                    if (kb < pl_blocks(N))
+                        emit_planes<NP>(q.dzp + ((int64_t)kb * q.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane, -1, 0,
+                                        sc + PL_WAVES * 64 + wave * 32);
+                }
+            }
+        } else {
+            for (int kb = wave; kb < blocks; kb += PL_WAVES) {
+                Frag<NP> f[2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    f32x4 v[2];
+                    dz_step(2 * kb + t2, v);
+                    f[t2] = make_frag<NP>(v[0], v[1]);
+                    store_frag<NP>(img + (int64_t)(2 * kb + t2) * (NP * 1024) + lane * 16, f[t2]);
+                }
+                if (kb < pl_blocks(N))
+                    emit_planes<NP>(q.dzp + ((int64_t)kb * q.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane, -1, 0);
+            }
         }
     });
     __syncthreads();
     if (!q.wpt) return;
 
     const int nblk = (q.K + 31) / 32;
-    if (nblk > PL_WAVES) bn_dgrad_product<NP, 2, 1>(q, img, part, wave, lane, row0, row_end, call);
-    else if (nblk > PL_WAVES / 2 || pl_steps(N) % (2 * PL_DEPTH) != 0) bn_dgrad_product<NP, 1, 1>(q, img, part, wave, lane, row0, row_end, call);
-    else bn_dgrad_product<NP, 1, 2>(q, img, part, wave, lane, row0, row_end, call);
+    if (nblk > PL_WAVES) bn_dgrad_product<NP, 2, 1>(q, img, part, wave, lane, row0, row_end, call, ainv);
+    else if (nblk > PL_WAVES / 2 || pl_steps(N) % (2 * PL_DEPTH) != 0) bn_dgrad_product<NP, 1, 1>(q, img, part, wave, lane, row0, row_end, call, ainv);
+    else bn_dgrad_product<NP, 1, 2>(q, img, part, wave, lane, row0, row_end, call, ainv);
 }
 
 // ---------------------------------------------------------------------------------------------

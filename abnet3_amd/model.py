@@ -462,7 +462,6 @@ class _HipNetwork(NetworkBuilder):
         #                       and split into two fp16 terms (22 significant bits), three fp16 MFMA products per
         #                       operand pair, fp32 accumulation: as close to a float64 evaluation as the
         #                       reference's own fp32 (measured), passes every golden test at the 1e-5 bar;
-        #                       BatchNorm towers run its launches in 'bf16x3';
         #   'bf16x3'            every fp32 operand split into three bf16 terms (24 bits, no scales), six bf16 MFMA
         #                       products per operand pair: same grade, ~20 % slower;
         #   'fp32'              exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): one fp32 fma chain per

@@ -410,7 +410,7 @@ def test_two_seeded_runs_are_bit_identical():
     assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
 
 
-@pytest.mark.parametrize('precision,tol', [('bf16x3', 1e-5), ('bf16', 3e-2)])
+@pytest.mark.parametrize('precision,tol', [('bf16x3', 1e-5), ('f16x2', 1e-5), ('bf16', 3e-2)])
 @pytest.mark.parametrize('act', ['sigmoid', 'tanh', 'relu'])
 @pytest.mark.parametrize('shape', SHAPES[:5])
 def test_batch_norm_inference_forward_against_the_oracle(shape, act, precision, tol, monkeypatch):
@@ -456,7 +456,7 @@ def test_batch_norm_inference_forward_against_the_oracle(shape, act, precision, 
     monkeypatch.setenv('ABN_PLANES', '1')
     o, _ = O.tower_forward(p, x, spec, False)
     # (8-bit operands: the normalisation multiplies a layer's rounding error by up to gamma / sqrt(running_var))
-    tol = tol if precision == 'bf16x3' else 3 * tol
+    tol = tol if precision != 'bf16' else 3 * tol
     assert rel_err(e, o) < tol
     assert rel_err(e, ref) < tol
     assert rel_err(e1.cpu().numpy(), o) < tol and rel_err(e2.cpu().numpy(), o[::-1]) < tol
@@ -507,7 +507,7 @@ BN_SHAPES = [  # (input, hidden layers, hidden, output, B): whole and ragged wor
 @pytest.mark.parametrize('p_drop', [0.0, 0.25])
 @pytest.mark.parametrize('act', ['sigmoid', 'tanh', 'relu'])
 @pytest.mark.parametrize('shape', BN_SHAPES)
-def test_batch_norm_training_step_against_the_oracle(shape, act, p_drop):
+def test_batch_norm_training_step_against_the_oracle(shape, act, p_drop, split):
     """Linear -> Dropout -> BatchNorm -> activation in training: one operand-plane launch per layer, the
     batch statistics from per-workgroup column sums.  Embeddings, loss, running statistics and every
     gradient against the numpy oracle, with shared dropout masks."""
@@ -517,7 +517,7 @@ def test_batch_norm_training_step_against_the_oracle(shape, act, p_drop):
     d_in, nh, hid, d_out, B = shape
     kw = dict(input_dim=d_in, num_hidden_layers=nh, hidden_dim=hid, output_dim=d_out, activation_layer=act,
               p_dropout=p_drop, batch_norm=True)
-    net, _, _ = build(kw, seed=B + 3, precision='bf16x3')
+    net, _, _ = build(kw, seed=B + 3, precision=split)
     spec = O.TowerSpec(d_in, nh, hid, d_out, act, True)
     rng = np.random.default_rng(B + nh)
     with torch.no_grad():           # affine parameters away from 1 / 0, a bias that shifts the column means
@@ -562,7 +562,7 @@ def test_batch_norm_training_step_against_the_oracle(shape, act, p_drop):
     check_grads(grads, og, spec.param_keys(), not p_drop, tol=2e-4)
 
 
-def test_batch_norm_input_gradient_and_fallbacks(monkeypatch):
+def test_batch_norm_input_gradient_and_fallbacks(monkeypatch, split):
     """d loss / d input through the BatchNorm launches (layer 0's product with W_0), against the per-layer kernels,
     with ragged calls (50 rows each: a whole and a short workgroup per call); a single ragged forward_once call."""
     from abnet3_amd import _lib
@@ -575,7 +575,7 @@ def test_batch_norm_input_gradient_and_fallbacks(monkeypatch):
     res = []
     for planes in ('1', '0'):
         monkeypatch.setenv('ABN_BN_PLANES', planes)
-        net, _, _ = build(kw, seed=9, precision='bf16x3')
+        net, _, _ = build(kw, seed=9, precision=split)
         net.train()
         a, b = dev(x1).requires_grad_(True), dev(x2).requires_grad_(True)
         e1, e2 = net(a, b)
@@ -591,7 +591,7 @@ def test_batch_norm_input_gradient_and_fallbacks(monkeypatch):
     outs = []
     for planes in ('1', '0'):
         monkeypatch.setenv('ABN_BN_PLANES', planes)
-        net, _, _ = build(kw, seed=9, precision='bf16x3')
+        net, _, _ = build(kw, seed=9, precision=split)
         net.train()
         e = net.forward_once(dev(x1[:37]))
         assert _lib.load().abn_debug_last_forward_path() == (5 if planes == '1' else 0)
@@ -641,7 +641,7 @@ def test_batch_norm_training_in_the_bf16_arithmetic(monkeypatch):
         assert abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < 0.1, k
 
 
-def test_batch_norm_with_dropout_drawn_inside_the_kernels():
+def test_batch_norm_with_dropout_drawn_inside_the_kernels(split):
     """p_dropout > 0 on a BatchNorm tower: the per-layer launches hash the same per-forward seed as the
     single-launch chains (forward epilogue, regenerated by the backward).  The masks are recovered from the
     pre-normalisation values the forward leaves (a dropped entry is an exact zero) and fed back as tensors:
@@ -650,7 +650,7 @@ def test_batch_norm_with_dropout_drawn_inside_the_kernels():
     p_drop = 0.25
     kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=96, output_dim=32, activation_layer='tanh', p_dropout=p_drop,
               batch_norm=True)
-    net, _, _ = build(kw, seed=3, precision='bf16x3')
+    net, _, _ = build(kw, seed=3, precision=split)
     net.train()
     rng = np.random.default_rng(8)
     B = 128                                                     # 256 rows: whole workgroups for every call count
@@ -692,7 +692,7 @@ def test_batch_norm_with_dropout_drawn_inside_the_kernels():
         assert rel_err(q.grad.cpu().numpy(), grads[k].cpu().numpy(), floor=1e-6 * float(grads[k].abs().max()) + 1e-30) < 1e-5, k
 
 
-def test_batch_norm_dropout_train_mode_without_gradients(tmp_path):
+def test_batch_norm_dropout_train_mode_without_gradients(tmp_path, split):
     """The reference's standard configuration (batch_norm=True, p_dropout=0.1): TrainerBuilder.train() starts with
     optimize_model(do_training=False) -- net.train() under torch.no_grad() (abnet3/trainer.py:137,226-235).  A
     forward that keeps nothing for a backward cannot use the BatchNorm training launches, so the dropout probe
@@ -703,7 +703,7 @@ def test_batch_norm_dropout_train_mode_without_gradients(tmp_path):
     from abnet3_amd.trainer import TrainerSiamese
     kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=96, output_dim=32, activation_layer='sigmoid', p_dropout=0.1,
               batch_norm=True, output_path=str(tmp_path / 'net'))
-    net, _, _ = build(kw, seed=5, precision='bf16x3')
+    net, _, _ = build(kw, seed=5, precision=split)
     rng = np.random.default_rng(2)
     B = 160                                                    # 320 rows: the planes kernels take it by themselves
     batch = (dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32)),

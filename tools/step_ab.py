@@ -31,7 +31,7 @@ for rep in range(2):
     for s in settings:
         env = dict(os.environ)
         for kv in s.split():
-            k, v = kv.split('=')
+            k, v = kv.split('=', 1)
             env[k] = v
         out = subprocess.run([sys.executable, '-c', CHILD], env=env, capture_output=True, text=True)
         res[s].append(out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-200:])
