@@ -439,9 +439,12 @@ __global__ void bn_stats_finish_kernel(const double* __restrict__ part, int nchu
 // A block = 64 columns x 16 groups of workgroups: every group adds its share in order, thread group 0 the
 // sixteen group sums in order (one thread per column walking 128 workgroups alone took 18 us).
 constexpr int BN_WG_GROUPS = 16;
+// sums_out (cross-replica statistics, abn_tower_desc.bn_sync_world): the launch stops at [call][sum z | sum z^2][C] in
+// float64 -- the caller all-reduces them and bn_stats_from_sums_kernel finishes.
 __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
     const float* __restrict__ part, int wgs_per_call, int64_t rows_per_call, int C, int n_calls, float* __restrict__ mean,
-    float* __restrict__ invstd, float* __restrict__ var_out, float* __restrict__ rm, float* __restrict__ rv)
+    float* __restrict__ invstd, float* __restrict__ var_out, float* __restrict__ rm, float* __restrict__ rv,
+    double* __restrict__ sums_out)
 {
     __shared__ double sa[BN_WG_GROUPS][64], sb[BN_WG_GROUPS][64];
     const int tx = threadIdx.x & 63, kg = threadIdx.x >> 6;
@@ -469,7 +472,11 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
         sa[kg][tx] = a;
         sb[kg][tx] = b;
         __syncthreads();
-        if (ok && kg == 0) {
+        if (ok && kg == 0 && sums_out) {
+            for (int k = 1; k < BN_WG_GROUPS; ++k) { a += sa[k][tx]; b += sb[k][tx]; }
+            sums_out[((int64_t)g * 2) * C + c] = a;
+            sums_out[((int64_t)g * 2 + 1) * C + c] = b;
+        } else if (ok && kg == 0) {
             for (int k = 1; k < BN_WG_GROUPS; ++k) { a += sa[k][tx]; b += sb[k][tx]; }
             const double n = (double)rows_per_call;
             const double m = a / n;
@@ -483,10 +490,45 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
             v_run = (1.0f - BN_MOMENTUM) * v_run + BN_MOMENTUM * ((float)var * unb);
         }
     }
-    if (ok && kg == 0) {
+    if (ok && kg == 0 && !sums_out) {
         rm[c] = m_run;
         rv[c] = v_run;
     }
+}
+
+// ... from the (all-reduced) sums over n_stat rows per call: mean, biased variance, invstd, the running statistics
+// (one momentum update per call, in call order, unbiased variance), as above
+__global__ void bn_stats_from_sums_kernel(const double* __restrict__ sums, int64_t n_stat, int C, int n_calls, float* __restrict__ mean,
+                                          float* __restrict__ invstd, float* __restrict__ var_out, float* __restrict__ rm,
+                                          float* __restrict__ rv)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float m_run = rm[c], v_run = rv[c];
+    const float unb = n_stat > 1 ? (float)((double)n_stat / (double)(n_stat - 1)) : 1.0f;
+    for (int g = 0; g < n_calls; ++g) {
+        const double n = (double)n_stat;
+        const double m = sums[((int64_t)g * 2) * C + c] / n;
+        double var = sums[((int64_t)g * 2 + 1) * C + c] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const int64_t idx = (int64_t)g * C + c;
+        mean[idx] = (float)m;
+        var_out[idx] = (float)var;
+        invstd[idx] = 1.0f / sqrtf((float)var + BN_EPS);
+        m_run = (1.0f - BN_MOMENTUM) * m_run + BN_MOMENTUM * (float)m;
+        v_run = (1.0f - BN_MOMENTUM) * v_run + BN_MOMENTUM * ((float)var * unb);
+    }
+    rm[c] = m_run;
+    rv[c] = v_run;
+}
+// ... and the backward's s1 = sum dy, s2 = sum dy xhat from theirs ([call][s1 | s2][C] float64)
+__global__ void bn_bwd_from_sums_kernel(const double* __restrict__ sums, int C, int n_calls, float* __restrict__ s1o, float* __restrict__ s2o)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_calls * C) return;
+    const int g = idx / C, c = idx % C;
+    s1o[idx] = (float)sums[((int64_t)g * 2) * C + c];
+    s2o[idx] = (float)sums[((int64_t)g * 2 + 1) * C + c];
 }
 
 // backward: s1 = sum dy, s2 = sum dy * xhat per (call, column)
@@ -605,7 +647,7 @@ __global__ __launch_bounds__(512) void bn_bwd_sums_wg_kernel(const float* __rest
 __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_bwd_finish_wg_kernel(const float* __restrict__ part, int wgs_per_call,
                                                                              int C, int n_calls, float* __restrict__ s1o,
                                                                              float* __restrict__ s2o, float* __restrict__ dgamma,
-                                                                             float* __restrict__ dbeta)
+                                                                             float* __restrict__ dbeta, double* __restrict__ sums_out)
 {
     __shared__ double sa[BN_WG_GROUPS][64], sb[BN_WG_GROUPS][64];
     const int tx = threadIdx.x & 63, kg = threadIdx.x >> 6;
@@ -630,8 +672,13 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_bwd_finish_wg_kernel(con
         __syncthreads();
         if (ok && kg == 0) {
             for (int k = 1; k < BN_WG_GROUPS; ++k) { a += sa[k][tx]; b += sb[k][tx]; }
-            s1o[(int64_t)g * C + c] = (float)a;
-            s2o[(int64_t)g * C + c] = (float)b;
+            if (sums_out) {        // (cross-replica statistics: s1 / s2 follow from the all-reduced sums; d gamma, d beta stay this replica's)
+                sums_out[((int64_t)g * 2) * C + c] = a;
+                sums_out[((int64_t)g * 2 + 1) * C + c] = b;
+            } else {
+                s1o[(int64_t)g * C + c] = (float)a;
+                s2o[(int64_t)g * C + c] = (float)b;
+            }
             sg += (float)b;
             sbeta += (float)a;
         }
@@ -1034,17 +1081,30 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     const int64_t tp_steps = 2 * n_calls * wgs_per_call;      // (the images' row axis is padded per call)
     float* const part = scratch + B.bn_wg;
     float* const s1 = scratch + B.bn_s1, * const s2 = scratch + B.bn_s2;
+    // cross-replica statistics: the sums leave as float64, are all-reduced by the caller's function, and come back as s1 / s2
+    const bool sync = t->bn_sync_world > 1;
+    ABN_REQUIRE(!sync || t->bn_sync_fn, "tower_backward: bn_sync_world = %d without bn_sync_fn", t->bn_sync_world);
+    double* const sums = reinterpret_cast<double*>(scratch + B.bn_part);
+    auto finish_sums = [&](int C, float* dgamma, float* dbeta) -> int {
+        hipLaunchKernelGGL(bn_bwd_finish_wg_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, part, wgs_per_call, C,
+                           (int)n_calls, s1, s2, dgamma, dbeta, sync ? sums : static_cast<double*>(nullptr));
+        if (!sync) return ABN_OK;
+        if (t->bn_sync_fn(t->bn_sync_ctx, sums, n_calls * 2 * C, st) != 0) { set_error("tower_backward: bn_sync_fn failed"); return ABN_E_LAUNCH; }
+        hipLaunchKernelGGL(bn_bwd_from_sums_kernel, dim3(grid_for(n_calls * C)), dim3(256), 0, st, sums, C, (int)n_calls, s1, s2);
+        return ABN_OK;
+    };
     {
         const int N = (int)t->dims[nl];
         hipLaunchKernelGGL(bn_bwd_sums_wg_kernel, cgrid, dim3(512), 0, st, d_out, ws + L.xhat[nl - 1], ws + L.mean[nl - 1],
                            ws + L.invstd[nl - 1], t->bn_w[nl - 1], t->bn_b[nl - 1], t->last_act, N, rpc, part);
-        hipLaunchKernelGGL(bn_bwd_finish_wg_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, part, wgs_per_call, N,
-                           (int)n_calls, s1, s2, t->dbn_w[nl - 1], t->dbn_b[nl - 1]);
+        const int rc = finish_sums(N, t->dbn_w[nl - 1], t->dbn_b[nl - 1]);
+        if (rc != ABN_OK) return rc;
     }
     int cur = 0;
     for (int l = nl - 1; l >= 0; --l) {
         BnBwdP q = {};
         q.l = l; q.rows = (int)rows; q.rows_call = (int)rpc;
+        q.n_stat = (float)(rpc * (sync ? t->bn_sync_world : 1));
         q.N = (int)t->dims[l + 1]; q.K = (int)t->dims[l];
         q.act_l = (l == nl - 1) ? t->last_act : t->act;
         q.act_prev = t->act;
@@ -1066,8 +1126,8 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
                       q.gamma_prev = t->bn_w[l - 1]; q.beta_prev = t->bn_b[l - 1]; q.part_out = part; }
         PL_LAUNCH(np, bn_bwd_layer_kernel, cgrid, dim3(PL_NT), pl_lds_bytes(np), st, q);
         if (l >= 1) {
-            hipLaunchKernelGGL(bn_bwd_finish_wg_kernel, dim3((unsigned)((q.K + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, part, wgs_per_call,
-                               q.K, (int)n_calls, s1, s2, t->dbn_w[l - 1], t->dbn_b[l - 1]);
+            const int rc = finish_sums(q.K, t->dbn_w[l - 1], t->dbn_b[l - 1]);
+            if (rc != ABN_OK) return rc;
             cur ^= 1;
         }
     }
@@ -1331,6 +1391,10 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         fusable = aligned16(t->W[l]) && (!t->drop_mask[l] || !train || aligned16(t->drop_mask[l]));
     const int pmode = train ? PLANES_TRAIN : PLANES_EVAL_FORWARD;
     const bool bn_train = train && bn_train_planes_path(t, rows, n_calls, x1, x2, ws);
+    if (train && t->batch_norm && t->bn_sync_world > 1 && !bn_train) {
+        set_error("tower_forward: cross-replica BatchNorm statistics (bn_sync_world) need the operand-plane launches");
+        return ABN_E_UNSUPPORTED;
+    }
     const int kind = planes_kind(t, rows, n_calls, x1, x2, ws, pmode);
     if (t->drop_seed && train && !bn_train && kind == PLANES_NONE) {
         for (int l = 0; l < t->n_layers; ++l)
@@ -1458,9 +1522,18 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 if (l > 0) { q.mean = ws + L.mean[l - 1]; q.invstd = ws + L.invstd[l - 1]; q.z_prev = ws + L.xhat[l - 1]; q.a_prev = nullptr; }
                 PL_LAUNCH(np, bn_fwd_layer_kernel, bgrid, dim3(PL_NT), pl_lds_bytes(np), st, fl, q);
                 const int N = (int)t->dims[l + 1];
+                const bool sync = t->bn_sync_world > 1;
+                ABN_REQUIRE(!sync || t->bn_sync_fn, "tower_forward: bn_sync_world = %d without bn_sync_fn", t->bn_sync_world);
+                double* const sums = reinterpret_cast<double*>(ws + L.bn_part);       // (the per-layer kernels' partials: idle here)
                 hipLaunchKernelGGL(bn_stats_finish_wg_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, ws + L.bn_wg,
                                    (int)wpc, rpc, N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l],
-                                   t->bn_rm[l], t->bn_rv[l]);
+                                   t->bn_rm[l], t->bn_rv[l], sync ? sums : static_cast<double*>(nullptr));
+                if (sync) {
+                    if (t->bn_sync_fn(t->bn_sync_ctx, sums, n_calls * 2 * N, st) != 0) { set_error("tower_forward: bn_sync_fn failed"); return ABN_E_LAUNCH; }
+                    hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, sums,
+                                       rpc * t->bn_sync_world, N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l],
+                                       t->bn_rm[l], t->bn_rv[l]);
+                }
             }
             const int N = (int)t->dims[nl];
             const float* z = ws + L.xhat[nl - 1];      // (stays un-normalised, like every layer's: the backward normalises again)
@@ -1621,6 +1694,10 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
         if (kind == PLANES_CHAIN) { last_backward_path = 2; return planes_backward(t, d_out, nullptr, rows, L, B, ws, scratch, dx, st); }
     }
     if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) { last_backward_path = 5; return bn_planes_backward(t, d_out, rows, n_calls, L, B, ws, scratch, dx, st); }
+    if (t->batch_norm && t->bn_sync_world > 1) {
+        set_error("tower_backward: cross-replica BatchNorm statistics (bn_sync_world) need the operand-plane launches");
+        return ABN_E_UNSUPPORTED;
+    }
     last_backward_path = 0;
 
     int cur = 0;

@@ -114,7 +114,8 @@ class _Segment(object):
         step's host cost)."""
         net = self.net
         net.flat_parameters()
-        key = (net._flat.data_ptr(), net._generation, net.precision)
+        sync = getattr(net, 'bn_sync', None) if self.batch_norm else None
+        key = (net._flat.data_ptr(), net._generation, net.precision, id(sync))
         cached = getattr(self, '_desc_cache', None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -127,6 +128,9 @@ class _Segment(object):
         d.last_act = _lib.ACT[self.last_act]
         d.batch_norm = int(self.batch_norm)
         d.precision = _lib.PRECISION[net.precision]
+        if sync is not None and sync.world > 1:       # cross-replica BatchNorm statistics (parallel.BatchNormSync)
+            d.bn_sync_world = sync.world
+            d.bn_sync_fn = sync.fn
         d.dims[0] = self.input_dim
         grad_slots = []                      # (field, layer, float offset in the flat buffers)
         offs = self.offsets()                # in the order of self.params
@@ -297,6 +301,8 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
     if ws_floats < 0:
         _lib.check(-1, 'abn_tower_ws_floats')
     ws = torch.empty(max(ws_floats, 1), dtype=torch.float32, device=x1.device)
+    if desc.bn_sync_world > 1:
+        net.bn_sync.buffers = [ws]
     _lib.check(lib.abn_tower_forward(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2),
                                      rows, n_calls, int(train), _lib.ptr(ws),
                                      _lib.stream()), 'abn_tower_forward')
@@ -334,6 +340,8 @@ def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False, def
     scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32, device=d_out.device)
     dx = torch.empty(rows, seg.input_dim, dtype=torch.float32,
                      device=d_out.device) if need_dx else None
+    if desc.bn_sync_world > 1:
+        seg.net.bn_sync.buffers = [sv.ws, scratch]
     _lib.check(lib.abn_tower_backward(
         _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(d_out), rows,
         sv.n_calls, _lib.ptr(sv.ws), _lib.ptr(scratch), scratch_floats,

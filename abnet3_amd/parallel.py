@@ -155,3 +155,40 @@ def all_gather_varlen(t):
     parts = [torch.empty_like(mine) for _ in range(ws)]
     dist.all_gather(parts, mine)
     return [p[:n_].to(t.device) for p, n_ in zip(parts, lens)]
+
+
+class BatchNormSync:
+    """Cross-replica BatchNorm statistics (SURVEY.md 8e's exact mode; abn_tower_desc.bn_sync_*): with
+    `SiameseNetwork.bn_sync = BatchNormSync()` a TRAINING forward / backward of a BatchNorm tower all-reduces
+    each layer's per-call [sum z, sum z^2] (forward) and [sum dy, sum dy xhat] (backward), float64, over the
+    replicas, and normalises with world x rows rows: R replicas on B pairs each then step exactly like one
+    process on R B pairs (tests/test_gpu_dp.py).  The library calls back between two launches, once per layer
+    and direction, with a device pointer into a buffer this object was shown (`buffers`): the collective runs
+    on torch's current stream, the stream the launches are on.  Default (bn_sync None): per-replica statistics,
+    as torch's DistributedDataParallel without SyncBatchNorm."""
+
+    def __init__(self, group=None):
+        from . import _lib
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.buffers = []              # the float32 tensors (forward workspace, backward scratch) of the call in flight
+        self.calls = 0
+        self._cb = _lib.ALLREDUCE_FN(self._allreduce)      # (kept alive with the object)
+        self.fn = _lib.C.cast(self._cb, _lib.C.c_void_p).value
+
+    def _allreduce(self, ctx, ptr, n, stream):
+        try:
+            for t in self.buffers:
+                base = t.data_ptr()
+                if base <= ptr and ptr + 8 * n <= base + t.numel() * t.element_size() and (ptr - base) % 8 == 0:
+                    off = (ptr - base) // 4
+                    v = t.view(-1)[off:off + 2 * n].view(torch.float64)
+                    if self.world > 1:
+                        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+                    self.calls += 1
+                    return 0
+            return 1
+        except Exception:              # (an exception must not unwind through the C frames)
+            import traceback
+            traceback.print_exc()
+            return 2

@@ -125,7 +125,7 @@ class TrainerBuilder:
                  optimizer_type='sgd', lr=0.001, momentum=0.9, cuda=True,
                  seed=0, dataloader=None, log_dir=None,
                  feature_generator=None,
-                 checkpoints=False):
+                 checkpoints=False, sync_batch_norm=False):
         self.network = network
         self.loss = loss
         self.num_epochs = num_epochs
@@ -169,6 +169,11 @@ class TrainerBuilder:
             # one RNG state on all ranks to start from; what an epoch visits is
             # broadcast from rank 0 anyway (parallel.py, the loaders' batch_iterator)
             parallel.seed_all(self.seed)
+            # BatchNorm statistics over ALL replicas' rows (off: every replica normalises with its own, like torch's
+            # DistributedDataParallel without SyncBatchNorm): R replicas then step like one process on the whole batch
+            if sync_batch_norm and getattr(self.network, 'batch_norm', False):
+                self.network.bn_sync = parallel.BatchNormSync()
+        self.sync_batch_norm = bool(sync_batch_norm)
 
     def params(self):
         params = copy.copy(self.__dict__)

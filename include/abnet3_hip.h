@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 14
+#define ABN_ABI_VERSION 15
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -56,7 +56,11 @@ enum { ABN_OPT_SGD = 0, ABN_OPT_ADADELTA = 1, ABN_OPT_ADAM = 2,
        ABN_OPT_ADAGRAD = 3, ABN_OPT_RMSPROP = 4 };
 
 /* abn_tower_desc.precision: arithmetic of the tower GEMMs (see the field's comment) */
-enum { ABN_PREC_F32 = 0, ABN_PREC_BF16 = 1, ABN_PREC_BF16X3 = 2 };
+enum { ABN_PREC_F32 = 0, ABN_PREC_BF16 = 1, ABN_PREC_BF16X3 = 2, ABN_PREC_F16X2 = 3 };
+
+/* abn_tower_desc.bn_sync_fn: SUM-all-reduces n float64 values at a DEVICE pointer in place over the replicas, in the
+ * stream's order (torch.distributed.all_reduce / ncclAllReduce on that stream); returns 0 on success. */
+typedef int (*abn_allreduce_fn)(void* ctx, void* device_doubles, int64_t n, void* stream);
 
 int abn_abi_version(void);
 const char* abn_last_error(void);          /* host string, thread-local */
@@ -93,7 +97,12 @@ typedef struct abn_tower_desc {
      * else (storage, BatchNorm, loss, optimizer) still fp32.  NOT within the 1e-5 bar.
      * 2 = bf16 x 3: every operand split into three bf16 terms, six bf16 MFMAs per product
      * block: fp32-grade results (as close to a float64 evaluation as mode 0 is) that are not
-     * bit-identical to mode 0. */
+     * bit-identical to mode 0.
+     * 3 = fp16 x 2 (the Python classes' default): every operand scaled by a power of two (per operand row /
+     * 32-row weight block) and split into two fp16 terms (22 significant bits), three fp16 MFMAs per product
+     * block, the scales taken out again in the epilogue (exactly): the same grade at half the MFMAs and two
+     * thirds of the operand stream.  On the operand-plane kernels only; where a call falls back to the GEMM
+     * kernels it runs as mode 2. */
     int32_t precision;
     /* backward only: d_out already IS d loss / d z of the output layer (abn_pair_loss_dz), so
      * the activation derivative / dropout step in front of the last layer's GEMMs is skipped.
@@ -129,6 +138,16 @@ typedef struct abn_tower_desc {
     const void* drop_seed;
     float drop_p;
     int32_t reserved2_;
+    /* Cross-replica BatchNorm statistics (data-parallel training; SURVEY.md 8e's exact mode): bn_sync_world > 1
+     * makes a TRAINING forward / backward of a BatchNorm tower sum its per-call statistics -- [sum z, sum z^2] per
+     * layer in the forward, [sum dy, sum dy xhat] in the backward, float64 -- over the replicas through bn_sync_fn
+     * (called on the host between two launches, once per layer and direction) and normalise with
+     * bn_sync_world x rows_per_call rows: R replicas on B rows each then step like one process on R B rows.
+     * 0 / 1: per-replica statistics.  Operand-plane launches only (ABN_E_UNSUPPORTED otherwise). */
+    int32_t bn_sync_world;
+    int32_t reserved3_;
+    abn_allreduce_fn bn_sync_fn;
+    void* bn_sync_ctx;
 } abn_tower_desc;
 
 /* Workspace of one forward call (what the backward needs: the saved activations, for the

@@ -101,6 +101,30 @@ def main():
     res['planned.graphs'] = np.array(sum(1 for v in getattr(tr, '_buckets', {}).values() if v['graph'] is not None))
     for k, p in net.named_parameters():
         res['planned.p.' + k] = p.detach().cpu().numpy()
+    # --- (4) BatchNorm with cross-replica statistics (TrainerBuilder(sync_batch_norm=True)): each rank steps on its
+    # half of a 2B batch; the test compares with one process on the whole batch
+    gb = load_golden('train_mid_bn1.npz')
+    kwb = ast.literal_eval(str(gb['kw']))
+    rngb = np.random.default_rng(321)
+    Bb = 1024
+    xb1 = rngb.standard_normal((Bb, 40)).astype(np.float32)
+    xb2 = (xb1 + 0.5 * rngb.standard_normal((Bb, 40))).astype(np.float32)
+    yb = rngb.choice([1.0, -1.0], Bb)
+    hb = Bb // world
+    slb = slice(rank * hb, rank * hb + hb)
+    for sync in (True, False):
+        net = SiameseNetwork(output_path='/tmp/abn_dp_bn_%d' % rank, **kwb)
+        net.load_state_dict({k[2:]: torch.from_numpy(v.copy()) for k, v in gb.items() if k.startswith('p.')})
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1,
+                            dataloader=None, log_dir='/tmp/abn_runs_dp', sync_batch_norm=sync)
+        net.train()
+        batch = (torch.from_numpy(xb1[slb]).cuda(), torch.from_numpy(xb2[slb]).cuda(), torch.from_numpy(yb[slb]).cuda())
+        losses = [float(tr.train_step(batch, True)) for _ in range(3)]
+        tag = 'bn.sync%d' % int(sync)
+        res[tag + '.losses'] = np.array(losses)
+        res[tag + '.calls'] = np.array(net.bn_sync.calls if sync else 0)
+        for k, v in net.state_dict().items():
+            res[tag + '.p.' + k] = v.detach().cpu().numpy()
     np.savez(out + '.rank%d.npz' % rank, **res)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
