@@ -233,6 +233,7 @@ struct ReduceTable {
     float* dW[ABN_MAX_LAYERS];
     float* db[ABN_MAX_LAYERS];
     int64_t total;
+    int64_t begin;                   // first packed element this launch reduces (a layer boundary; 0: all of [0, total))
     // tensors whose gradient is already final in the flat gradient buffer (BatchNorm's gamma / beta): the fused
     // reduction + optimizer launch steps them too (float offsets into the flat buffers, element counts)
     int n_extra;
@@ -272,7 +273,7 @@ __device__ __forceinline__ f32x4 sum_slabs(const float* __restrict__ src, int S,
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, ReduceTable t)
 {
     const int64_t n4 = (t.total + 3) / 4;
-    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4;
+    for (int64_t q = t.begin / 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4;
          q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = 4 * q;
         int l = 0;
@@ -1011,7 +1012,7 @@ struct LossArgs {
 // Every layer's weight-gradient tiles for one wgrad_planes_kernel launch: operands = the transposed images
 // the forward (ws + L.tp[l]) and the data-gradient launches (scratch + B.dzp[l]) left.
 static WgradP make_wgrad(const abn_tower_desc* t, int64_t rows, const Layout& L, const BwdLayout& B, const float* ws,
-                         float* scratch, int* n_wg_out)
+                         float* scratch, int* n_wg_out, int l_first = 0, int l_end = ABN_MAX_LAYERS)
 {
     const int nl = t->n_layers;
     WgradP w = {};
@@ -1026,6 +1027,7 @@ static WgradP make_wgrad(const abn_tower_desc* t, int64_t rows, const Layout& L,
     int n_wg = 0;
     for (int i = 0; i < nl; ++i) {
         const int l = order[i];
+        if (l < l_first || l >= l_end) continue;        // (abn_tower_desc.wgrad_part: one half of the layers)
         WgradLayer& W = w.L[w.n_layers++];
         W.dzp = reinterpret_cast<const char*>(scratch + B.dzp[l]);
         W.ap = reinterpret_cast<const char*>(ws + L.tp[l]);
@@ -1050,6 +1052,25 @@ static WgradP make_wgrad(const abn_tower_desc* t, int64_t rows, const Layout& L,
     }
     *n_wg_out = n_wg;
     return w;
+}
+
+// abn_tower_desc.wgrad_part / wgrad_split -> [first, end) layers whose weight gradients this call computes and reduces
+static int wgrad_range(const abn_tower_desc* t, int* l_first, int* l_end)
+{
+    *l_first = 0; *l_end = t->n_layers;
+    if (t->wgrad_part == 0) return ABN_OK;
+    ABN_REQUIRE(t->wgrad_part == 1 || t->wgrad_part == 2, "tower_backward: wgrad_part=%d", t->wgrad_part);
+    ABN_REQUIRE(t->wgrad_split >= 0 && t->wgrad_split <= t->n_layers, "tower_backward: wgrad_split=%d", t->wgrad_split);
+    ABN_REQUIRE(!t->defer_reduce, "tower_backward: wgrad_part cannot be combined with defer_reduce");
+    if (t->wgrad_part == 1) *l_first = t->wgrad_split;
+    else *l_end = t->wgrad_split;
+    return ABN_OK;
+}
+static void reduce_range(ReduceTable& rt, const abn_tower_desc* t, const BwdLayout& B, int l_first, int l_end)
+{
+    rt.begin = B.off[l_first < t->n_layers ? l_first : t->n_layers - 1];
+    if (l_first >= t->n_layers) rt.begin = rt.total;
+    if (l_end < t->n_layers) rt.total = B.off[l_end];
 }
 
 // Backward of a BatchNorm tower whose forward went through bn_fwd_layer_kernel (same predicate): per layer,
@@ -1189,8 +1210,11 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
         b.amax_dz[l] = B.amax_dz[l] >= 0 ? scratch + B.amax_dz[l] : nullptr;
     }
     b.wbase = image; b.wbytes = PL.bytes;
+    int l_first, l_end;
+    { const int rc = wgrad_range(t, &l_first, &l_end); if (rc != ABN_OK) return rc; }
+    if (t->wgrad_part == 2) part = PLANES_BWD_WGRAD;      // (the data-gradient launch ran with part 1)
     int n_wg = 0;
-    const WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
+    const WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg, l_first, l_end);
     static bool bw_attr_set[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1203,11 +1227,13 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
     const dim3 cgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
     const bool do_dgrad = part != PLANES_BWD_WGRAD, do_wgrad = part != PLANES_BWD_DGRAD;
     if (do_dgrad) PL_LAUNCH(np, tower_dgrad_planes_kernel, cgrid, dim3(PL_NT), pl_lds_bytes(np), st, b);
-    if (do_wgrad) PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_of(np), st, w);
+    if (do_wgrad && n_wg > 0) PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_of(np), st, w);
     ABN_CHECK_LAUNCH("tower_backward (planes)");
     if (t->defer_reduce) return ABN_OK;      // abn_tower_reduce_step finishes the job
-    const ReduceTable rt = make_reduce_table(t, B);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, scratch + B.slabs, rt);
+    ReduceTable rt = make_reduce_table(t, B);
+    reduce_range(rt, t, B, l_first, l_end);
+    if (rt.total > rt.begin)
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total - rt.begin + 3) / 4)), dim3(256), 0, st, scratch + B.slabs, rt);
     ABN_CHECK_LAUNCH("slab_reduce");
     return ABN_OK;
 }
@@ -1238,9 +1264,11 @@ static int wide_backward(const abn_tower_desc* t, const float* d_out, const Loss
     const int64_t wpc = bn_wgs_per_call(rows, n_calls), nrb = n_calls * wpc;
     const int G = wide_groups_for(t, nrb * PL_ROWS);
     ABN_REQUIRE(G > 0, "tower_backward: too many rows for the layer-per-launch kernels");
+    int l_first, l_end;
+    { const int rc = wgrad_range(t, &l_first, &l_end); if (rc != ABN_OK) return rc; }
     const int last = dx ? 0 : 1;                      // the lowest layer a data-gradient launch runs for
     int cur = 0;
-    for (int l = top; l >= last || l == top; --l) {
+    for (int l = top; (l >= last || l == top) && t->wgrad_part != 2; --l) {
         WideBwdP q = {};
         q.l = l; q.top = top;
         q.N = (int)t->dims[l + 1]; q.K = (int)t->dims[l];
@@ -1281,13 +1309,15 @@ static int wide_backward(const abn_tower_desc* t, const float* d_out, const Loss
         if (l == 0) break;
     }
     int n_wg = 0;
-    WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
+    WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg, l_first, l_end);
     w.tp_steps = 2 * nrb;
-    PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_of(np), st, w);
+    if (n_wg > 0) PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_of(np), st, w);
     ABN_CHECK_LAUNCH("tower_backward (layer per launch)");
     if (t->defer_reduce) return ABN_OK;               // abn_tower_reduce_step finishes the job
-    const ReduceTable rt = make_reduce_table(t, B);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, st, scratch + B.slabs, rt);
+    ReduceTable rt = make_reduce_table(t, B);
+    reduce_range(rt, t, B, l_first, l_end);
+    if (rt.total > rt.begin)
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((rt.total - rt.begin + 3) / 4)), dim3(256), 0, st, scratch + B.slabs, rt);
     ABN_CHECK_LAUNCH("slab_reduce");
     return ABN_OK;
 }
@@ -1692,6 +1722,10 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
         const int kind = planes_kind(t, rows, n_calls, x1, x2, ws);
         if (kind == PLANES_WIDE) { last_backward_path = 6; return wide_backward(t, d_out, nullptr, rows, n_calls, L, B, ws, scratch, dx, st); }
         if (kind == PLANES_CHAIN) { last_backward_path = 2; return planes_backward(t, d_out, nullptr, rows, L, B, ws, scratch, dx, st); }
+    }
+    if (t->wgrad_part != 0) {
+        set_error("tower_backward: wgrad_part needs the operand-plane launches of a tower without BatchNorm");
+        return ABN_E_UNSUPPORTED;
     }
     if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) { last_backward_path = 5; return bn_planes_backward(t, d_out, rows, n_calls, L, B, ws, scratch, dx, st); }
     if (t->batch_norm && t->bn_sync_world > 1) {

@@ -787,7 +787,8 @@ class SiameseNetwork(_HipNetwork):
         for p, g in zip(seg.params, grads):
             p.grad = g
 
-    def direct_backward_loss(self, state, y, loss_kind, margin, avg, defer_reduce=False, n_valid=None, loss_accum=None, loss_ws=None):
+    def direct_backward_loss(self, state, y, loss_kind, margin, avg, defer_reduce=False, n_valid=None, loss_accum=None, loss_ws=None,
+                             wgrad_split=None):
         """loss(emb1, emb2, y) and its backward in the backward's own launches (abn_tower_backward_loss:
         the data-gradient chain computes the pair loss and d loss / d z of the output layer in its first
         phase).  Returns the 0-dim loss, or None when the library does not take this tower that way
@@ -807,6 +808,8 @@ class SiameseNetwork(_HipNetwork):
             return None
         grad_buf, grads = grad_pass.views(seg)
         desc = seg.descriptor(with_grads=True, grad_buf=grad_buf, masks=sv.masks, d_out_is_dz=True, defer_reduce=defer_reduce)
+        if wgrad_split is not None:              # data-parallel overlap: this call stops after the upper layers' gradients
+            desc.wgrad_part, desc.wgrad_split = 1, int(wgrad_split)
         scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
         scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32, device=y.device)
         loss = torch.empty((), dtype=torch.float32, device=y.device)
@@ -826,11 +829,31 @@ class SiameseNetwork(_HipNetwork):
             return None
         _lib.check(rc, 'abn_tower_backward_loss')
         self._pending_reduce = (desc, rows, scratch, scratch_floats, grad_buf, seg) if defer_reduce else None
+        self._pending_lower = (desc, rows, scratch, scratch_floats, sv) if wgrad_split is not None else None
         for p, g in zip(seg.params, grads):
             p.grad = g
         return loss
 
     _fused_loss_refused = None
+
+    def direct_backward_lower(self):
+        """The second half of a direct_backward_loss(..., wgrad_split=s): the weight gradients of the layers below s
+        (abn_tower_desc.wgrad_part = 2, same workspace and scratch).  Between the two calls the caller starts the
+        all-reduce of the upper layers' gradients (TrainerSiamese.train_step under torch.distributed)."""
+        desc, rows, scratch, scratch_floats, sv = self._pending_lower
+        self._pending_lower = None
+        desc.wgrad_part = 2
+        _lib.check(_lib.load().abn_tower_backward(
+            _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(sv.ws), rows,
+            sv.n_calls, _lib.ptr(sv.ws), _lib.ptr(scratch), scratch_floats, _lib.ptr(None), _lib.stream()), 'abn_tower_backward')
+
+    def grad_split_offset(self, state, layer):
+        """Float offset inside the flat gradient buffer where the gradients of the tower's layers >= `layer` begin
+        (the buffer holds the parameters in layer order: the upper layers are its tail)."""
+        seg = state[0]
+        offs = seg.offsets()
+        per_layer = len(seg.params) // len(seg.blocks)
+        return int(offs[layer * per_layer])
 
     def take_pending_reduce(self):
         """The unfinished reduction a direct_backward(defer_reduce=True) left (or None); clears it."""

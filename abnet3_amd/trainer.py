@@ -315,6 +315,18 @@ class TrainerSiamese(TrainerBuilder):
         else:
             loss_value.backward()
 
+    overlap_allreduce = True          # data-parallel steps: two gradient buckets, the first all-reduce under the rest of the backward
+
+    def _overlap_split(self, state):
+        """The layer the data-parallel backward is cut at (None: one call, one all-reduce): towers of >= 3 layers whose
+        parameters all live in ONE segment of the flat buffer, no BatchNorm; the upper bucket = the top half of the layers."""
+        net = self.network
+        seg = state[0]
+        if (not self.overlap_allreduce or getattr(net, 'batch_norm', False) or len(seg.blocks) < 3
+                or len(seg.params) != 2 * len(seg.blocks) or len(list(net.parameters())) != len(seg.params)):
+            return None
+        return (len(seg.blocks) + 1) // 2
+
     def _loss_is_mean(self):
         """Data-parallel gradient exchange: a mean loss averages over ranks, a
         summed loss sums."""
@@ -338,9 +350,24 @@ class TrainerSiamese(TrainerBuilder):
             # single process: nothing happens between backward and step, so the split-K
             # reduction of the weight gradients rides in the optimizer's launch
             defer = self.world_size == 1 and self.network.can_defer_reduce(state)
+            # data-parallel: the backward in two calls, the all-reduce of the upper layers' gradients in flight while the
+            # lower layers' are computed (two buckets of the flat gradient buffer; abn_tower_desc.wgrad_part)
+            split = self._overlap_split(state) if self.world_size > 1 else None
             # the pair loss inside the backward's first launch, where the library offers it
             loss_value = self.network.direct_backward_loss(
-                state, y_batch, type(self.loss).__name__, getattr(self.loss, 'margin', 0.0), self.loss.avg, defer_reduce=defer)
+                state, y_batch, type(self.loss).__name__, getattr(self.loss, 'margin', 0.0), self.loss.avg, defer_reduce=defer,
+                wgrad_split=split)
+            if loss_value is not None and split is not None:
+                flat = self.network.flat_grad()
+                cut = self.network.grad_split_offset(state, split)
+                work = [torch.distributed.all_reduce(flat[cut:], op=torch.distributed.ReduceOp.SUM, async_op=True)]
+                self.network.direct_backward_lower()
+                work.append(torch.distributed.all_reduce(flat[:cut], op=torch.distributed.ReduceOp.SUM, async_op=True))
+                for w in work:
+                    w.wait()
+                self.optimizer.grad_scale = 1.0 / self.world_size if self._loss_is_mean() else 1.0
+                self.optimizer.step()
+                return loss_value.detach()
             if loss_value is not None:
                 pass
             elif info is not None:    # loss gradient and the output layer's act' (+ dropout) in ONE launch

@@ -126,7 +126,12 @@ typedef struct abn_tower_desc {
      * would store for one (the default arithmetic writes more than half of its bytes for the
      * backward).  A backward after such a forward reads garbage. */
     int32_t forward_only;
-    int32_t reserved_;
+    /* backward only, data-parallel overlap (operand-plane launches without BatchNorm; ABN_E_UNSUPPORTED elsewhere):
+     * the backward in two calls on the same workspace and scratch so that the caller can start the all-reduce of the
+     * upper layers' gradients while the lower layers' are still being computed.  0 = everything (default);
+     * 1 = the data-gradient launches and the weight gradients (with their slab reduction) of layers >= wgrad_split;
+     * 2 = the weight gradients (and reduction) of layers < wgrad_split -- after a part-1 call, no defer_reduce. */
+    int32_t wgrad_part;
     void* wpack;
     /* Dropout drawn inside the kernels instead of read from drop_mask (default arithmetic only;
      * where drop_mask[l] is given it wins): drop_seed = device pointer to one uint64 the caller
@@ -145,7 +150,7 @@ typedef struct abn_tower_desc {
      * bn_sync_world x rows_per_call rows: R replicas on B rows each then step like one process on R B rows.
      * 0 / 1: per-replica statistics.  Operand-plane launches only (ABN_E_UNSUPPORTED otherwise). */
     int32_t bn_sync_world;
-    int32_t reserved3_;
+    int32_t wgrad_split;                   /* see wgrad_part */
     abn_allreduce_fn bn_sync_fn;
     void* bn_sync_ctx;
 } abn_tower_desc;

@@ -57,6 +57,29 @@ def main():
             for k, p in net.named_parameters():
                 res[tag + '.p.' + k] = p.detach().cpu().numpy()
 
+    # --- (1b) the same with 1600 pairs per rank: the single-launch chains instead of the layer-per-launch kernels, the
+    # backward in two calls with the upper layers' all-reduce in flight under the second (abn_tower_desc.wgrad_part)
+    rngc = np.random.default_rng(77)
+    Bc = 3200
+    xc1 = rngc.standard_normal((Bc, 40)).astype(np.float32)
+    xc2 = (xc1 + 0.3 * rngc.standard_normal((Bc, 40))).astype(np.float32)
+    yc = rngc.choice([1.0, -1.0], Bc)
+    hc = Bc // world
+    slc = slice(rank * hc, rank * hc + hc)
+    for overlap in (True, False):
+        net = SiameseNetwork(output_path='/tmp/abn_dp_c_%d' % rank, **kw)
+        net.load_state_dict({k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith('p.')})
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1,
+                            dataloader=None, log_dir='/tmp/abn_runs_dp')
+        tr.overlap_allreduce = overlap
+        net.train()
+        batch = (torch.from_numpy(xc1[slc]).cuda(), torch.from_numpy(xc2[slc]).cuda(), torch.from_numpy(yc[slc]).cuda())
+        losses = [float(tr.train_step(batch, True)) for _ in range(3)]
+        tag = 'chain.overlap%d' % int(overlap)
+        res[tag + '.losses'] = np.array(losses)
+        for k, p in net.named_parameters():
+            res[tag + '.p.' + k] = p.detach().cpu().numpy()
+
     # --- (2) loaders shard themselves: disjoint, complete, one shared order
     gl = load_golden('frames_loader.npz')
     feats = {k[5:]: v for k, v in gl.items() if k.startswith('feat.')}

@@ -68,6 +68,38 @@ def test_two_ranks_equal_one_process_on_the_full_batch(ranks, avg, oname, lr):
         assert (ranks[0][tag + '.p.' + k] == ranks[1][tag + '.p.' + k]).all()     # replicas stay bit-identical
 
 
+def test_two_bucket_backward_equals_the_single_call(ranks):
+    """Data-parallel steps cut the backward in two (abn_tower_desc.wgrad_part): data gradients + the upper layers' weight
+    gradients, all-reduce of that bucket started, the lower layers' weight gradients, second all-reduce.  1600 pairs per
+    rank (the single-launch chains): bit-identical to the one-call, one-all-reduce step, and equal to one process on the
+    3200 pairs."""
+    import abnet3_amd.loss as L
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.trainer import TrainerSiamese
+    g = load_golden('train_mid_bn0.npz')
+    kw = ast.literal_eval(str(g['kw']))
+    rng = np.random.default_rng(77)
+    x1 = rng.standard_normal((3200, 40)).astype(np.float32)
+    x2 = (x1 + 0.3 * rng.standard_normal((3200, 40))).astype(np.float32)
+    y = rng.choice([1.0, -1.0], 3200)
+    net = SiameseNetwork(output_path='/tmp/abn_dp_c_single', **kw)
+    net.load_state_dict({k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith('p.')})
+    tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1,
+                        dataloader=None, log_dir='/tmp/abn_runs_dp')
+    net.train()
+    batch = (torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), torch.from_numpy(y).cuda())
+    losses = [float(tr.train_step(batch, True)) for _ in range(3)]
+    for r in ranks:
+        assert (r['chain.overlap1.losses'] == r['chain.overlap0.losses']).all()
+    total = ranks[0]['chain.overlap1.losses'] + ranks[1]['chain.overlap1.losses']
+    assert np.allclose(total, losses, rtol=2e-6), (total, losses)
+    for k, p in net.named_parameters():
+        mine = p.detach().cpu().numpy()
+        for r in ranks:
+            assert (r['chain.overlap1.p.' + k] == r['chain.overlap0.p.' + k]).all(), k
+            assert rel_err(r['chain.overlap1.p.' + k], mine, floor=0.05) < 2e-6, k
+
+
 def test_batch_norm_with_cross_replica_statistics_equals_one_process(ranks):
     """TrainerBuilder(sync_batch_norm=True) -> parallel.BatchNormSync -> abn_tower_desc.bn_sync_*: every BatchNorm layer's
     per-call [sum z, sum z^2] (forward) and [sum dy, sum dy xhat] (backward) are all-reduced between two launches, so two
