@@ -403,6 +403,9 @@ class TrainerSiamese(TrainerBuilder):
         torch.distributed the gradient all-reduce and the optimizer stay
         outside the graph (fwd + bwd are captured).  Adam's bias correction is
         host-computed per step, so its optimizer launch also stays outside."""
+        if getattr(getattr(self.network, 'bn_sync', None), 'world', 1) > 1:
+            raise NotImplementedError('abnet3_amd: a step with cross-replica BatchNorm statistics calls back to the host '
+                                      'between launches (parallel.BatchNormSync) and cannot be captured into a graph')
         static, fwd_loss = self._graph_inputs(example_batch)
         opt = self.optimizer
         capture_opt = (self.world_size == 1 and isinstance(opt, FlatOptimizer)
@@ -486,7 +489,8 @@ class TrainerSiamese(TrainerBuilder):
         drives the kernels without autograd the eager step is within 20 % of the
         replayed one even at 100 frame pairs (and ahead of it from ~500-wide towers
         on, where the three input copies of a replay cost more than its launches)."""
-        if not getattr(self, 'graph_steps', False) or not isinstance(self.optimizer, FlatOptimizer):
+        if (not getattr(self, 'graph_steps', False) or not isinstance(self.optimizer, FlatOptimizer)
+                or getattr(getattr(self.network, 'bn_sync', None), 'world', 1) > 1):
             return self.train_step(batch, True)
         if not hasattr(self, '_graphs'):
             self._graphs, self._shape_seen = {}, {}

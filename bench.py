@@ -768,7 +768,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['fbank'] = fbank_bench(torch)
         if world == 1 and args.pipeline_utts > 0:
-            out['pipeline'] = pipeline_bench(torch, args.pipeline_utts, 25 * args.pipeline_utts, 2, not args.no_cpu_baseline)
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):      # (the trainer reports its epochs like the reference: not on this line's stream)
+                out['pipeline'] = pipeline_bench(torch, args.pipeline_utts, 25 * args.pipeline_utts, 2, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
