@@ -71,7 +71,9 @@ struct GemmP {
 // was spending 6-10 us per layer there (s_memtime stamps).
 __device__ __forceinline__ float fast_sigmoid(float z)
 {
-    return __frcp_rn(1.0f + __expf(-z));
+    // (v_rcp_f32: 1 ulp; the correctly rounded __frcp_rn is a ten-instruction division sequence, a third of this
+    // function -- and a sigmoid is read to 1e-5 here)
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-z));
 }
 
 __device__ __forceinline__ float act_apply(float z, int act)

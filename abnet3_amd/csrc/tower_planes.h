@@ -703,7 +703,11 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
             wv[j] = o + lane * 16;
             dnext[j] = ioff2 + blk2 * nsteps2 * (NP * 1024) - o;
         }
+#ifdef PL_EXP_HALFWAVES
+        if (ws.active && (wave < 4 || BPW != 2)) ring_kloop<NP, BPW>(acc, ring, wv, dnext, chain_next, img, ws.s_first, ws.my_steps, lane);
+#else
         if (ws.active) ring_kloop<NP, BPW>(acc, ring, wv, dnext, chain_next, img, ws.s_first, ws.my_steps, lane);
+#endif
     }
     PSTAMPF(3 + 5 * l);
 
