@@ -1577,7 +1577,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         // inference (no mask, no seed, nothing kept for a backward) has its own, lighter instantiations
         const bool infer = t->batch_norm || (t->forward_only && !f.drop_seed && !train);
         const int mode = t->batch_norm ? PL_INFER_BN : infer ? PL_INFER : PL_TRAIN;
-        const size_t lds = t->batch_norm ? pl_lds_bytes_bn(np) : pl_lds_bytes(np);
+        const size_t lds = t->batch_norm ? pl_lds_bytes_bn(np) : pl_lds_bytes_stag(np);      // (the layers may stagger: two operand images)
         const void* kernels[3][3] = {
             {reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_TRAIN>), reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_INFER>),
              reinterpret_cast<const void*>(tower_fwd_planes_kernel<1, PL_INFER_BN>)},
@@ -1590,7 +1590,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 for (int m = 0; m < 3; ++m)
                     if (kernels[a][m])
                         (void)hipFuncSetAttribute(kernels[a][m], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)(m == PL_INFER_BN ? pl_lds_bytes_bn(a + 1) : pl_lds_bytes(a + 1)));
+                                                  (int)(m == PL_INFER_BN ? pl_lds_bytes_bn(a + 1) : pl_lds_bytes_stag(a + 1)));
             pl_attr_set[dev] = true;
         }
         void* kargs[] = {&f};

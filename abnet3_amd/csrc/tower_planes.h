@@ -77,7 +77,7 @@ static inline int64_t pl_timage_bytes(int64_t features, int64_t rows, int np) { 
 // floats of an image's table of maxima: PL_AMAX per 32-row block
 static inline int64_t pl_amax_floats(int64_t rows) { return pl_row_steps(rows) / 2 * PL_AMAX; }
 constexpr int PL_BIAS_BYTES = PL_WAVES * 64 * 4;   // a wave's 64 bias values, parked in LDS across its k-loop
-static inline size_t pl_lds_bytes(int np) { return (size_t)PL_MAXSTEPS * np * 1024 + PL_PART_BYTES + PL_SC_BYTES + PL_BIAS_BYTES; }
+__host__ __device__ inline size_t pl_lds_bytes(int np) { return (size_t)PL_MAXSTEPS * np * 1024 + PL_PART_BYTES + PL_SC_BYTES + PL_BIAS_BYTES; }
 // the inference forward of a BatchNorm tower parks four more per-feature vectors beside the bias
 static inline size_t pl_lds_bytes_bn(int np) { return pl_lds_bytes(np) + 4 * PL_BIAS_BYTES; }
 
@@ -641,13 +641,94 @@ __device__ __forceinline__ float half_wave_sum(float v)
     return v;
 }
 
-// ainv (fp16 x 2): the inverse scale of this lane's row in img -- in: the layer's input, out: its output.
+// ---------------------------------------------------------------------------------------------
+// Staggered layers.  A chain's wide layers (more than eight output blocks: two per wave) are bound by the operand
+// stream -- a CU pulls the packed layer through its L1 at ~45 B/clk whether four or eight waves ask for it
+// (tools/planes_stamps.py with PL_EXP_HALFWAVES) -- and between two k-loops ~18 k cycles of epilogue, image writes and
+// barriers pass with no load in flight.  Where two such layers follow each other the workgroup therefore runs as TWO
+// GROUPS of four waves (one per SIMD each: waves 0-3 own blocks 0-7, waves 4-7 the rest) that drift half a layer apart:
+// a group leaves its blocks in the OTHER operand image (two images: fp16 x 2 and bf16 only), publishes its rows' scales
+// and a counter, and goes on; the next layer's k-loop walks the lower group's sixteen steps first, then the upper
+// group's, waiting for each half's counter and rescaling the accumulators in between (each half has its own power of
+// two per row: exact).  One group's epilogue then runs under the other group's stream.  No workgroup barrier inside a
+// run; the last layer of a run ends with the ordinary epilogue (uniform scales, barriers).
+// ---------------------------------------------------------------------------------------------
+// MEASURED (C2, fp16 x 2, same box, tools/step_ab.py): forward chain staggered 0.1744-0.1757 ms / step against 0.1762-0.1772
+// in phase; with the upper group held back until the lower one is through its first half (the lag that makes one group's
+// epilogue fall under the other's stream) 0.1768-0.1779: a group streaming alone gets 45 B/clk through the CU's L1, both
+// together 58 -- what the overlap hides, the lone stream loses.  Off unless built with -DPL_STAGGER_ON (the forward chain
+// only; every planes / timed-path test passes with it on).
+#ifdef PL_STAGGER_ON
+constexpr bool PL_STAGGER = true;
+#else
+constexpr bool PL_STAGGER = false;
+#endif
+constexpr int PL_HS_BYTES = 2 * 2 * 2 * 32 * 4;                       // [layer parity][half][scale | inverse][row]
+constexpr int PL_CNT_BYTES = (ABN_MAX_LAYERS + 1) * 2 * 2 * 4;        // [layer][group][maxima parked | blocks in the image]
+// LDS of a kernel whose layers may stagger: the second image, the halves' scales and the counters behind everything else
+static inline size_t pl_lds_bytes_stag(int np) { return pl_lds_bytes(np) + (PL_STAGGER && np <= 2 ? (size_t)PL_MAXSTEPS * np * 1024 + PL_HS_BYTES + PL_CNT_BYTES : 0); }
+struct Stag {
+    char* img0;            // the two operand images (selected, not indexed: an indexed member puts the struct in scratch)
+    char* img1;
+    int cur;               // which of them holds the next layer's input
+    __device__ __forceinline__ char* in() const { return cur ? img1 : img0; }
+    __device__ __forceinline__ char* out() const { return cur ? img0 : img1; }
+    float* hs;
+    int* cnt;
+    bool in_halves;        // img[cur] was left by a staggered epilogue: per-half scales and counters
+};
+__device__ __forceinline__ void stag_open(Stag& st, char* smem, int np, int tid)
+{
+    st.img0 = smem;
+    st.img1 = smem + pl_lds_bytes(np);
+    st.hs = reinterpret_cast<float*>(st.img1 + PL_MAXSTEPS * np * 1024);
+    st.cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(st.hs) + PL_HS_BYTES);
+    st.cur = 0;
+    st.in_halves = false;
+    if (tid < PL_CNT_BYTES / 4) st.cnt[tid] = 0;       // (a workgroup barrier follows before the first layer)
+}
+// one wave's arrival at a counter / waiting for `need` arrivals (the waves of a workgroup are co-resident: a spin is safe)
+__device__ __forceinline__ void stag_arrive(int* c, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // (this wave's LDS writes first)
+    if (lane == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void stag_wait(int* c, int need)
+{
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// waves of group g that own a block of a layer with nblk output blocks (two blocks per wave)
+__device__ __forceinline__ int stag_group_waves(int nblk, int g)
+{
+    const int w = (nblk + 1) / 2 - 4 * g;
+    return w < 0 ? 0 : (w > 4 ? 4 : w);
+}
+
+template <int NP, int BPW, int KS, int MODE>
+__device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* __restrict__ img,
+                                             float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0,
+                                             float& ainv, WeightRing<NP>& ring, int row_end, Stag& st, bool stag_on, bool out_halves);
+// (a layer outside any staggered run)
 template <int NP, int BPW, int KS, int MODE = PL_TRAIN>
 __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* __restrict__ img,
                                              float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0,
                                              float& ainv, WeightRing<NP>& ring, int row_end = -1)
 {
+    Stag none = {};
+    planes_layer<NP, BPW, KS, MODE>(p, l, img, part, idf, wave, lane, row0, ainv, ring, row_end, none, false, false);
+}
+
+// ainv (fp16 x 2): the inverse scale of this lane's row in img -- in: the layer's input, out: its output.
+// st / out_halves: staggered layers (two blocks per wave only) -- img is st.in(); out_halves: this layer's
+// consumer is staggered too (the output goes to the other image with per-half scales, no barrier).
+template <int NP, int BPW, int KS, int MODE>
+__device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* __restrict__ img,
+                                             float* __restrict__ part, const bf16x8* idf, int wave, int lane, int row0,
+                                             float& ainv, WeightRing<NP>& ring, int row_end, Stag& st, bool stag_on, bool out_halves)
+{
     constexpr bool BN = MODE == PL_INFER_BN, INFER = MODE == PL_INFER || MODE == PL_INFER_BN, BNT = MODE == PL_BN_TRAIN;
+    constexpr bool STAGC = PL_STAGGER && BPW == 2 && KS == 1 && NP <= 2 && (MODE == PL_TRAIN || MODE == PL_INFER);
     const int rows_lim = row_end >= 0 ? row_end : p.rows;      // (BatchNorm training: the end of the workgroup's forward_once call)
     const int K = p.dims[l], N = p.dims[l + 1];
     const int nsteps = pl_steps(K), nblk = (N + 31) / 32;
@@ -670,7 +751,7 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     float bias_lane = 0.0f, bn_lane[4] = {0.0f, 1.0f, 1.0f, 0.0f};      // running mean, running variance, gamma, beta
     float cinv[BPW];                                   // fp16 x 2: what turns an accumulator into the product
 #pragma unroll
-    for (int j = 0; j < BPW; ++j) cinv[j] = NP == 2 && ws.active ? packed_inv(p.wp[l], nblk, nsteps, blk0 + j) * ainv : 1.0f;
+    for (int j = 0; j < BPW; ++j) cinv[j] = NP == 2 && ws.active ? packed_inv(p.wp[l], nblk, nsteps, blk0 + j) : 1.0f;
     {
         const float* __restrict__ bias = p.b[l];
         const int n = 32 * blk0 + lane;
@@ -703,11 +784,43 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
             wv[j] = o + lane * 16;
             dnext[j] = ioff2 + blk2 * nsteps2 * (NP * 1024) - o;
         }
+        float cin = ainv;                          // the inverse scale the sum ends up in
+        bool done = false;
+        if constexpr (STAGC) {
+            if (stag_on && st.in_halves) {
+                // the input's two halves: the lower group's steps, then the upper group's, each behind its counter
+                done = true;
+                if (ws.active) {
+                    constexpr int SPLIT = 2 * PL_WAVES;                       // steps the lower group's eight blocks cover
+                    const float* const hsin = st.hs + (l & 1) * 128;
+                    int* const cnt = st.cnt + l * 4;
+                    const int nb_in = (K + 31) / 32;
+                    int dn[BPW], wv2[BPW];
+#pragma unroll
+                    for (int j = 0; j < BPW; ++j) { dn[j] = SPLIT * (NP * 1024); wv2[j] = wv[j] + SPLIT * (NP * 1024); }
+                    stag_wait(&cnt[1], stag_group_waves(nb_in, 0));
+                    const float inv0 = hsin[32 + r];
+                    ring_kloop<NP, BPW>(acc, ring, wv, dn, true, img, 0, SPLIT, lane);
+                    stag_wait(&cnt[3], stag_group_waves(nb_in, 1));
+                    if constexpr (NP == 2) {
+                        const float f = hsin[64 + r] * inv0;                  // (powers of two: exact)
+#pragma unroll
+                        for (int j = 0; j < BPW; ++j)
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) acc[j][q] *= f;
+                        cin = hsin[96 + r];
+                    }
+                    ring_kloop<NP, BPW>(acc, ring, wv2, dnext, chain_next, img, SPLIT, nsteps - SPLIT, lane);
+                }
+            }
+        }
 #ifdef PL_EXP_HALFWAVES
-        if (ws.active && (wave < 4 || BPW != 2)) ring_kloop<NP, BPW>(acc, ring, wv, dnext, chain_next, img, ws.s_first, ws.my_steps, lane);
+        if (!done && ws.active && (wave < 4 || BPW != 2)) ring_kloop<NP, BPW>(acc, ring, wv, dnext, chain_next, img, ws.s_first, ws.my_steps, lane);
 #else
-        if (ws.active) ring_kloop<NP, BPW>(acc, ring, wv, dnext, chain_next, img, ws.s_first, ws.my_steps, lane);
+        if (!done && ws.active) ring_kloop<NP, BPW>(acc, ring, wv, dnext, chain_next, img, ws.s_first, ws.my_steps, lane);
 #endif
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) cinv[j] *= cin;
     }
     PSTAMPF(3 + 5 * l);
 
@@ -789,6 +902,86 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
         }
         sc[wave * 64 + lane] = m;
     };
+    if constexpr (STAGC) {
+        if (stag_on && out_halves) {
+            // staggered epilogue: this group's blocks go to the other image under scales of the group's own, no barrier
+            const int g = wave >> 2;
+            char* const img_out = st.out();
+            int* const cnt_out = st.cnt + (l + 1) * 4 + 2 * g;
+            float* const hs_out = st.hs + ((l + 1) & 1) * 128 + 64 * g;
+            float* const tab = sc + PL_WAVES * 64 + wave * 32;
+            char* const tp_s = !INFER ? p.tp[l + 1] : nullptr;
+            if (ws.active) {
+                finish();
+                float osc_s = 1.0f;
+                if constexpr (NP == 2) {
+                    float m = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < BPW; ++j)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) m = fmaxf(m, fabsf(acc[j][q]));
+                    sc[wave * 64 + lane] = m;
+                    const int gw = stag_group_waves(nblk, g);
+                    stag_arrive(&cnt_out[0], lane);
+                    stag_wait(&cnt_out[0], gw);
+                    m = 0.0f;
+                    for (int w = 4 * g; w < 4 * g + gw; ++w) m = fmaxf(m, fmaxf(sc[w * 64 + r], sc[w * 64 + 32 + r]));
+                    float oinv;
+                    scale_of(m, osc_s, oinv);
+                    tab[r] = oinv;
+                    if ((wave & 3) == 0) {
+                        hs_out[r] = osc_s;
+                        hs_out[32 + r] = oinv;
+                        if (tp_s) {                    // the image's maxima: one slot per group (the column of ones: >= 1)
+                            const float M = fmaxf(wave_max(m), 1.0f);
+                            float* const am = p.amax[l + 1] + (int64_t)blockIdx.x * PL_AMAX;
+                            if (g == 0) { if (lane < PL_AMAX && lane != 1) am[lane] = lane == 0 ? M : 0.0f; }
+                            else if (lane == 1) am[1] = M;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int j = 0; j < BPW; ++j) {
+                    const int blk = blk0 + j;
+                    if (blk < nblk) {
+                        Frag<NP> f[2];
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            const f32x4 v0 = {acc[j][8 * t2], acc[j][8 * t2 + 1], acc[j][8 * t2 + 2], acc[j][8 * t2 + 3]};
+                            const f32x4 v1 = {acc[j][8 * t2 + 4], acc[j][8 * t2 + 5], acc[j][8 * t2 + 6], acc[j][8 * t2 + 7]};
+                            f[t2] = make_frag<NP>(v0, v1, osc_s);
+                            store_frag<NP>(img_out + (int64_t)(2 * blk + t2) * (NP * 1024) + lane * 16, f[t2]);
+                        }
+                        if (tp_s)
+                            emit_planes<NP>(tp_s + ((int64_t)blk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), f, idf, lane,
+                                            blk == N / 32 ? N % 32 : -1, rows_lim - row0, tab);
+                    }
+                }
+                if (wave == PL_WAVES / 2) {            // the upper group's first wave: the next layer's padding steps
+                    const bf16x8 z = {};
+                    for (int s2 = 2 * nblk; s2 < pl_steps(N); ++s2)
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<bf16x8*>(img_out + ((int64_t)s2 * NP + pl) * 1024 + lane * 16) = z;
+                }
+                stag_arrive(&cnt_out[1], lane);
+            }
+            if (tp_s && N % 32 == 0 && wave == PL_WAVES - 1) {       // the column of ones opens a block of its own
+                Frag<NP> z[2] = {};
+                if (!ws.active) {                  // (zeros times this wave's table: it must hold numbers)
+                    tab[r] = 1.0f;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                emit_planes<NP>(tp_s + ((int64_t)nblk * p.tp_steps + 2 * blockIdx.x) * tile_bytes<NP>(), z, idf, lane, 0, rows_lim - row0, tab);
+            }
+            st.cur ^= 1;
+            st.in_halves = true;
+            PSTAMPF(6 + 5 * l);
+            return;
+        }
+    }
     if (KS == 1) {
         if (ws.active) finish();
         if (rescale) park_max();
@@ -799,6 +992,7 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
     PSTAMPF(4 + 5 * l);
     __syncthreads();                               // every wave is done reading img
     PSTAMPF(5 + 5 * l);
+    if constexpr (STAGC) { if (stag_on) st.in_halves = false; }
     if (KS == 2 && ws.active && ws.khalf == 0) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[0][q] += part[(wave * 16 + q) * 64 + lane];
@@ -993,15 +1187,27 @@ __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
     float ainv = 1.0f;
     WeightRing<NP> ring;
     ring_open(ring, p.wbase, p.wbytes);
+    constexpr bool STAG = PL_STAGGER && NP <= 2 && (MODE == PL_TRAIN || MODE == PL_INFER);
+    Stag st;
+    if constexpr (STAG) stag_open(st, pl_smem, NP, threadIdx.x);
     planes_input_stage<NP, INFER>(p, img, part, idf, wave, lane, row0, ainv);
     PSTAMPF(1);
     __syncthreads();
 
     for (int l = 0; l < p.n_layers; ++l) {
         const int nblk = (p.dims[l + 1] + 31) / 32;
-        if (nblk > PL_WAVES) planes_layer<NP, 2, 1, MODE>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
-        else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, MODE>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
-        else planes_layer<NP, 1, 2, MODE>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
+        if constexpr (STAG) {
+            char* const cur = st.in();
+            // (a wide layer whose consumer is wide too leaves its output staggered)
+            const bool out_halves = nblk > PL_WAVES && l + 1 < p.n_layers && (p.dims[l + 2] + 31) / 32 > PL_WAVES;
+            if (nblk > PL_WAVES) planes_layer<NP, 2, 1, MODE>(p, l, cur, part, idf, wave, lane, row0, ainv, ring, -1, st, true, out_halves);
+            else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, MODE>(p, l, cur, part, idf, wave, lane, row0, ainv, ring);
+            else planes_layer<NP, 1, 2, MODE>(p, l, cur, part, idf, wave, lane, row0, ainv, ring);
+        } else {
+            if (nblk > PL_WAVES) planes_layer<NP, 2, 1, MODE>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
+            else if (nblk > PL_WAVES / 2 || pl_steps(p.dims[l]) % (2 * PL_DEPTH) != 0) planes_layer<NP, 1, 1, MODE>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
+            else planes_layer<NP, 1, 2, MODE>(p, l, img, part, idf, wave, lane, row0, ainv, ring);
+        }
     }
     PSTAMPF(2 + 5 * p.n_layers);
 }
