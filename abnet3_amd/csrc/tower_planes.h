@@ -2192,7 +2192,14 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         // Iteration c, behind ONE barrier: split step c + 2 into LDS stage (c + 2) % 4 and refill its slot
         // with step c + 6; read step c + 1's fragments (second register set); step c's MFMAs.  The loop
         // runs to a multiple of four steps: steps past the end are written as zeros.
-        static_assert(WG_REG_DEPTH == 4 && WG_STAGES == 4, "slot / stage arithmetic below");
+        static_assert(WG_STAGES == 4, "stage arithmetic below");
+        // register ring depth: steps in flight ahead of the split (fp16 x 2 has the registers for eight, -DWG_DEPTH2=8:
+        // 0.1747 against 0.1735 ms / step with four -- the loads are not what is exposed)
+#ifndef WG_DEPTH2
+#define WG_DEPTH2 4
+#endif
+        constexpr int RD = NP == 2 ? WG_DEPTH2 : WG_REG_DEPTH;
+        static_assert(RD == 4 || RD == 8, "slot arithmetic below");
         static_assert(NB > PL_WAVES && NB <= 12, "one whole tile per wave plus halves of the rest");
         constexpr int NHALF = 2 * (NB - PL_WAVES);                 // 1 KB halves of the tiles 8 .. NB-1 (8: one each; 4: shared, written twice)
         const int hb = PL_WAVES + ((wave % NHALF) >> 1), hh = wave & 1;          // this wave's half: tile hb, elements 4 hh .. 4 hh + 3
@@ -2204,8 +2211,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         };
         const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(image_of(wave)), 0, (int)(p.tp_steps * FR), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(image_of(hb)), 0, (int)(p.tp_steps * FR), 0x00020000);
-        v4i rq[WG_REG_DEPTH][3];
-        const int n4 = (n_steps + 3) / 4 * 4;
+        v4i rq[RD][3];
+        const int n4 = (n_steps + RD - 1) / RD * RD;
         // fp16 x 2: one power of two per operand for this slab's rows, from the maxima the chains left per 32-row block
         float sc_whole = 1.0f, sc_half = 1.0f;
         if constexpr (NP == 2) {
@@ -2280,26 +2287,26 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         };
         if (n_steps > 0) {
 #pragma unroll
-            for (int k = 0; k < WG_REG_DEPTH; ++k) load(k, k);
-            convert(0, 0); load(0, 4);
-            convert(1, 1); load(1, 5);
+            for (int k = 0; k < RD; ++k) load(k, k);
+            convert(0, 0); load(0, RD);
+            convert(1, 1); load(1, RD + 1);
             __syncthreads();
             read_frags(fr[0], 0);
         }
-        for (int c0 = 0; c0 < n4; c0 += 4) {
+        for (int c0 = 0; c0 < n4; c0 += RD) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RD; ++i) {
                 const int c = c0 + i;
                 __syncthreads();        // step c + 1's planes are in LDS for everybody; nobody still reads stage (c + 2) % 4
                 read_frags(fr[(i + 1) & 1], c + 1);
-                convert((i + 2) & 3, c + 2);
+                convert((i + 2) & (RD - 1), c + 2);
                 mfmas(fr[i & 1]);       // (a wave whose blocks are all padding multiplies clamped copies: nothing of it is stored)
 #pragma unroll
                 for (int g = 0; g < TN * TK * Products<NP>::N; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, NP == 2 ? 6 : 4, 0);
                 }
-                load((i + 2) & 3, c + 6);
+                load((i + 2) & (RD - 1), c + 2 + RD);
             }
         }
     } else {
