@@ -454,11 +454,16 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
     float m_run = 0.0f, v_run = 0.0f;
     if (ok && kg == 0) { m_run = rm[c]; v_run = rv[c]; }
     const float unb = rows_per_call > 1 ? (float)((double)rows_per_call / (double)(rows_per_call - 1)) : 1.0f;
-    const int per = (wgs_per_call + BN_WG_GROUPS - 1) / BN_WG_GROUPS;
-    for (int g = 0; g < n_calls; ++g) {
+    // the sixteen thread groups are dealt over the calls (two calls: eight groups each), so that every call's loads are in
+    // flight together: one round trip for the launch instead of one per call (6.8 -> ~5 us at C2); each group adds its share
+    // of a call's workgroups in order, thread group 0 the group sums of every call in order
+    const int gpc = n_calls < BN_WG_GROUPS ? BN_WG_GROUPS / n_calls : 1;          // groups per call
+    const int per = (wgs_per_call + gpc - 1) / gpc;
+    for (int g0 = 0; g0 < n_calls; g0 += BN_WG_GROUPS / gpc) {
+        const int g = g0 + kg / gpc, sub = kg % gpc;
         double a = 0.0, b = 0.0;
-        const int k0 = kg * per, k1 = min(k0 + per, wgs_per_call);
-        if (ok) {
+        if (ok && g < n_calls) {
+            const int k0 = sub * per, k1 = min(k0 + per, wgs_per_call);
 #pragma unroll 8
             for (int k = k0; k < k1; ++k) {           // fixed order; the loads are independent
                 const float* src = part + (int64_t)(g * wgs_per_call + k) * (3 * PL_MAXW);
@@ -469,26 +474,31 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
                 b += sq + 2.0 * cc * sd + nk * cc * cc;
             }
         }
-        __syncthreads();                              // (the previous call's sums have been read)
+        __syncthreads();                              // (the previous round's sums have been read)
         sa[kg][tx] = a;
         sb[kg][tx] = b;
         __syncthreads();
-        if (ok && kg == 0 && sums_out) {
-            for (int k = 1; k < BN_WG_GROUPS; ++k) { a += sa[k][tx]; b += sb[k][tx]; }
-            sums_out[((int64_t)g * 2) * C + c] = a;
-            sums_out[((int64_t)g * 2 + 1) * C + c] = b;
-        } else if (ok && kg == 0) {
-            for (int k = 1; k < BN_WG_GROUPS; ++k) { a += sa[k][tx]; b += sb[k][tx]; }
-            const double n = (double)rows_per_call;
-            const double m = a / n;
-            double var = b / n - m * m;
-            if (var < 0.0) var = 0.0;
-            const int64_t idx = (int64_t)g * C + c;
-            mean[idx] = (float)m;
-            var_out[idx] = (float)var;
-            invstd[idx] = 1.0f / sqrtf((float)var + BN_EPS);
-            m_run = (1.0f - BN_MOMENTUM) * m_run + BN_MOMENTUM * (float)m;
-            v_run = (1.0f - BN_MOMENTUM) * v_run + BN_MOMENTUM * ((float)var * unb);
+        if (ok && kg == 0) {
+            for (int q = 0; q < BN_WG_GROUPS / gpc && g0 + q < n_calls; ++q) {
+                const int gq = g0 + q;
+                double ta = 0.0, tb = 0.0;
+                for (int k = 0; k < gpc; ++k) { ta += sa[q * gpc + k][tx]; tb += sb[q * gpc + k][tx]; }
+                if (sums_out) {
+                    sums_out[((int64_t)gq * 2) * C + c] = ta;
+                    sums_out[((int64_t)gq * 2 + 1) * C + c] = tb;
+                    continue;
+                }
+                const double n = (double)rows_per_call;
+                const double m = ta / n;
+                double var = tb / n - m * m;
+                if (var < 0.0) var = 0.0;
+                const int64_t idx = (int64_t)gq * C + c;
+                mean[idx] = (float)m;
+                var_out[idx] = (float)var;
+                invstd[idx] = 1.0f / sqrtf((float)var + BN_EPS);
+                m_run = (1.0f - BN_MOMENTUM) * m_run + BN_MOMENTUM * (float)m;
+                v_run = (1.0f - BN_MOMENTUM) * v_run + BN_MOMENTUM * ((float)var * unb);
+            }
         }
     }
     if (ok && kg == 0 && !sums_out) {
@@ -654,12 +664,14 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_bwd_finish_wg_kernel(con
     const int tx = threadIdx.x & 63, kg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     const bool ok = c < C;
-    const int per = (wgs_per_call + BN_WG_GROUPS - 1) / BN_WG_GROUPS;
+    const int gpc = n_calls < BN_WG_GROUPS ? BN_WG_GROUPS / n_calls : 1;          // thread groups per call (bn_stats_finish_wg_kernel)
+    const int per = (wgs_per_call + gpc - 1) / gpc;
     float sg = 0.0f, sbeta = 0.0f;
-    for (int g = 0; g < n_calls; ++g) {
+    for (int g0 = 0; g0 < n_calls; g0 += BN_WG_GROUPS / gpc) {
+        const int g = g0 + kg / gpc, sub = kg % gpc;
         double a = 0.0, b = 0.0;
-        const int k0 = kg * per, k1 = min(k0 + per, wgs_per_call);
-        if (ok) {
+        if (ok && g < n_calls) {
+            const int k0 = sub * per, k1 = min(k0 + per, wgs_per_call);
 #pragma unroll 8
             for (int k = k0; k < k1; ++k) {
                 const float* src = part + (int64_t)(g * wgs_per_call + k) * (2 * PL_MAXW);
@@ -672,16 +684,20 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_bwd_finish_wg_kernel(con
         sb[kg][tx] = b;
         __syncthreads();
         if (ok && kg == 0) {
-            for (int k = 1; k < BN_WG_GROUPS; ++k) { a += sa[k][tx]; b += sb[k][tx]; }
-            if (sums_out) {        // (cross-replica statistics: s1 / s2 follow from the all-reduced sums; d gamma, d beta stay this replica's)
-                sums_out[((int64_t)g * 2) * C + c] = a;
-                sums_out[((int64_t)g * 2 + 1) * C + c] = b;
-            } else {
-                s1o[(int64_t)g * C + c] = (float)a;
-                s2o[(int64_t)g * C + c] = (float)b;
+            for (int q = 0; q < BN_WG_GROUPS / gpc && g0 + q < n_calls; ++q) {
+                const int gq = g0 + q;
+                double ta = 0.0, tb = 0.0;
+                for (int k = 0; k < gpc; ++k) { ta += sa[q * gpc + k][tx]; tb += sb[q * gpc + k][tx]; }
+                if (sums_out) {        // (cross-replica statistics: s1 / s2 follow from the all-reduced sums; d gamma, d beta stay this replica's)
+                    sums_out[((int64_t)gq * 2) * C + c] = ta;
+                    sums_out[((int64_t)gq * 2 + 1) * C + c] = tb;
+                } else {
+                    s1o[(int64_t)gq * C + c] = (float)ta;
+                    s2o[(int64_t)gq * C + c] = (float)tb;
+                }
+                sg += (float)tb;
+                sbeta += (float)ta;
             }
-            sg += (float)b;
-            sbeta += (float)a;
         }
     }
     if (ok && kg == 0) {
