@@ -201,6 +201,18 @@ def planes_roofline(torch, net, reps=20):
         entries[key] = {'kernel': '%s  (%s; alone, back to back from one hipGraph)' % (name, what),
                         'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / peak, 4),
                         'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl, 'traffic': _traffic(short)}
+    # What the chains are actually bound by: every workgroup of 32 rows pulls the whole packed layer through
+    # its CU's L1 from the XCD's L2 -- bytes per launch = workgroups x packed weight image --, at most 64 B/clk per CU.
+    steps = lambda c: ((c + 15) // 16 + 3) // 4 * 4
+    blocks = lambda f: (f + 31) // 32
+    img_f = sum(blocks(dims[l + 1]) * steps(dims[l]) for l in range(4)) * planes * 1024
+    img_d = sum(blocks(dims[l]) * steps(dims[l + 1]) for l in range(1, 4)) * planes * 1024
+    for key, img in (('forward', img_f), ('dgrad_chain', img_d)):
+        tb = img * (rows // 32) / (entries[key]['avg_launch_us'] * 1e-6) / 1e12
+        entries[key]['operand_stream'] = {'bytes_per_workgroup': img, 'workgroups': rows // 32, 'achieved_TB_s_from_L2': round(tb, 2),
+                                          'peak_TB_s': round(256 * 64 * 2.4e9 / 1e12, 1),
+                                          'note': 'packed weights streamed L2 -> L1 by every workgroup; peak = 256 CUs x 64 B/clk x 2.4 GHz '
+                                                  '(the k-loops run at 45-58 B/clk per CU; the rest of a launch is epilogue without loads)'}
     # The line's top level is whichever of the three launches took LONGEST in this run (alone, back to back: against
     # the in-step durations of the committed rocprofv3 trace this reads the chains 8-15 % high and the weight
     # gradients ~5 % low, so the top-level fraction is the conservative one); the other two follow under their names.
