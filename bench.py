@@ -228,6 +228,8 @@ def planes_roofline(torch, net, reps=20):
            'dominant': dominant,
            'kernel': e['kernel'], 'avg_launch_us': e['avg_launch_us'],
            'flop_per_launch': e['flop_per_launch']}
+    if 'operand_stream' in e:
+        out['operand_stream'] = e['operand_stream']
     if e['traffic']:
         gbs = e['traffic'] / (e['avg_launch_us'] * 1e-6) / 1e9
         out['hbm'] = {'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
