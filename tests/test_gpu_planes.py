@@ -750,3 +750,25 @@ def test_persistent_weight_image_sees_writes_behind_torch(split):
         c = net.forward_once(x).clone()
         fresh.load_state_dict(net.state_dict())
         assert torch.equal(fresh.forward_once(x), c) and not torch.equal(b, c)
+
+
+def test_two_part_backward_is_refused_where_it_cannot_run(split):
+    """abn_tower_desc.wgrad_part (the data-parallel backward in two calls) exists on the operand-plane launches of towers
+    without BatchNorm; a BatchNorm tower's backward says so instead of running half a backward."""
+    from abnet3_amd import _lib, model as M
+    kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=96, output_dim=32, activation_layer='sigmoid',
+              p_dropout=0.0, batch_norm=True)
+    net, _, _ = build(kw, seed=21, precision=split)
+    rng = np.random.default_rng(21)
+    x1, x2 = dev(rng.standard_normal((160, 40)).astype(np.float32)), dev(rng.standard_normal((160, 40)).astype(np.float32))
+    net.train()
+    out, (seg, sv, gp) = net.direct_forward(x1, x2)
+    plain = seg.descriptor
+
+    def two_part(*a, **k):
+        d = plain(*a, **k)
+        d.wgrad_part, d.wgrad_split = 1, 1
+        return d
+    seg.descriptor = two_part
+    with pytest.raises(_lib.HipLibraryError, match='wgrad_part'):
+        M._segment_backward(seg, sv, torch.randn_like(out), gp, False)

@@ -197,3 +197,20 @@ def test_multitask_surface_host_side(tmp_path):
     assert dl.same_speaker(spk, 'u2', 'u3') and not dl.same_speaker(spk, 'u1', 'u2')
     ml = MultiTaskDataLoader('p', 'f', fid2spk_file='x', speaker_match='equal')
     assert ml.same_speaker(spk, 'u0', 'u1') and not ml.same_speaker(spk, 'u0', 'u2')
+
+
+def test_batch_norm_sync_callback_finds_the_buffer_a_pointer_lies_in():
+    """parallel.BatchNormSync hands the library a C callback (abn_allreduce_fn); the library calls it with a raw device
+    pointer into a buffer the object was shown.  Host logic only: the pointer -> tensor view lookup and its refusals
+    (the collective itself runs in tests/test_gpu_dp.py under two ranks)."""
+    import torch
+    from abnet3_amd import parallel
+    s = parallel.BatchNormSync()
+    assert s.world == 1 and s.fn
+    a, b = torch.zeros(64, dtype=torch.float32), torch.zeros(32, dtype=torch.float32)
+    s.buffers = [a, b]
+    assert s._allreduce(None, b.data_ptr() + 16, 4, None) == 0 and s.calls == 1        # 4 doubles = floats 4 .. 11 of b
+    assert s._allreduce(None, a.data_ptr(), 32, None) == 0 and s.calls == 2            # the whole of a
+    assert s._allreduce(None, a.data_ptr() + 8, 32, None) == 1                         # runs past the end of a
+    assert s._allreduce(None, b.data_ptr() + 4, 2, None) == 1                          # not 8-byte aligned
+    assert s._allreduce(None, 12345, 1, None) == 1 and s.calls == 2                    # in nobody's buffer
