@@ -2214,7 +2214,9 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         v4i rq[RD][3];
         const int n4 = (n_steps + RD - 1) / RD * RD;
         // fp16 x 2: one power of two per operand for this slab's rows, from the maxima the chains left per 32-row block
+        // (looked up behind the first tile loads: one round trip, not two, before the first split)
         float sc_whole = 1.0f, sc_half = 1.0f;
+        auto slab_scales = [&]() {
         if constexpr (NP == 2) {
             float* const red = reinterpret_cast<float*>(smem + WG_STAGES * WG_MAX_BLOCKS * (NP * 1024));      // [2][8]
             const int rb0 = s_begin >> 1, cnt = (((s_end + 1) >> 1) - rb0) * PL_AMAX;
@@ -2236,6 +2238,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
             sc_half = sa;                                // (blocks 8 .. NB-1 are activation blocks in every shape)
             static_assert(BN <= PL_WAVES, "the half tiles are activation blocks");
         }
+        };
         auto load = [&](int slot, int k) {
             const int off = step_at(k) * FR;
 #ifdef WEXP_NOLOAD
@@ -2288,6 +2291,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         if (n_steps > 0) {
 #pragma unroll
             for (int k = 0; k < RD; ++k) load(k, k);
+            slab_scales();
             convert(0, 0); load(0, RD);
             convert(1, 1); load(1, RD + 1);
             __syncthreads();
