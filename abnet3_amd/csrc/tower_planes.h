@@ -2180,7 +2180,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
                     acc[i][j] = pl_mfma<NP>(f.a[i][Products<NP>::A[u]], f.b[j][Products<NP>::B[u]], acc[i][j]);
     };
     Frags fr[2];
-    float out_inv = 1.0f;                                // fp16 x 2: what turns an accumulator into the sum
+    float out_inv = 1.0f, out_inv_ones = 1.0f;           // fp16 x 2: what turns an accumulator into the sum (the bias column: below)
     if constexpr (NP >= 2) {
         // Register ring: slot k % 4 holds this wave's share of step k's fp32 tiles, fetched four steps before
         // it is split (raw buffer loads: the compiler counts their vmcnt and leaves them where they stand).
@@ -2234,8 +2234,14 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
             scale_of(md, sd, id);
             scale_of(ma, sa, ia);
             out_inv = id * ia;
-            sc_whole = wave < BN ? sd : sa;              // this wave's whole tile: operand block `wave`
-            sc_half = sa;                                // (blocks 8 .. NB-1 are activation blocks in every shape)
+            out_inv_ones = id;
+            // The column of ones (the bias gradient) keeps a scale of its own, 1: under the activations' scale it would
+            // sink into fp16's subnormals once the activations are ~1e5 and more (an unbounded activation on large inputs;
+            // the lane holding that column converts with 1 and its sums leave with the dZ inverse alone).
+            const bool ones_lane = (lane & 31) == L.K % 32;
+            const int ones_blk = L.K / 32 - kb0 + BN;    // its operand block in this tile (if it has it)
+            sc_whole = wave < BN ? sd : (ones_lane && wave == ones_blk ? 1.0f : sa);      // this wave's whole tile: operand block `wave`
+            sc_half = ones_lane && hb == ones_blk ? 1.0f : sa;                            // (blocks 8 .. NB-1 are activation blocks in every shape)
             static_assert(BN <= PL_WAVES, "the half tiles are activation blocks");
         }
         };
@@ -2350,7 +2356,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int n = 32 * (nb0 + wn * TN + i) + (q & 3) + 8 * (q >> 2) + 4 * h;
-                    if (n < L.N) slab[k < L.K ? (int64_t)n * L.K + k : (int64_t)L.N * L.K + n] = NP == 2 ? acc[i][j][q] * out_inv : acc[i][j][q];
+                    if (n < L.N) slab[k < L.K ? (int64_t)n * L.K + k : (int64_t)L.N * L.K + n] = NP == 2 ? acc[i][j][q] * (k < L.K ? out_inv : out_inv_ones) : acc[i][j][q];
                 }
         }
     }

@@ -772,3 +772,65 @@ def test_two_part_backward_is_refused_where_it_cannot_run(split):
     seg.descriptor = two_part
     with pytest.raises(_lib.HipLibraryError, match='wgrad_part'):
         M._segment_backward(seg, sv, torch.randn_like(out), gp, False)
+
+
+@pytest.mark.parametrize('rows', [300, 4096])        # the layer-per-launch kernels / the single-launch chains
+@pytest.mark.parametrize('act', ['relu', 'sigmoid'])
+def test_f16x2_scales_follow_the_data(rows, act, split, monkeypatch):
+    """The split arithmetics under extreme ranges -- fp16 x 2 lives on its power-of-two scales (per batch row, per 32-row
+    weight block, per slab of the weight gradient; the column of ones that yields the bias gradient keeps a scale of its
+    own).  Inputs whose rows differ by ten orders of magnitude, zero rows, weight blocks six orders of magnitude apart
+    under an unbounded activation (activations up to 1e9), a loss gradient of 1e-9: embeddings (per row) and every
+    gradient tensor against a float64 evaluation, as close as at ordinary ranges."""
+    monkeypatch.setenv('ABN_WIDE', '1' if rows < 1000 else '0')
+    kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=288, output_dim=64, activation_layer=act,
+              p_dropout=0.0, batch_norm=False)
+    if act == 'relu':
+        kw['last_non_linearity'] = None
+    rng = np.random.default_rng(rows)
+    x = rng.standard_normal((rows, 40)).astype(np.float32)
+    # rows from 1e-6 to 1e4 (a sigmoid is not driven into saturation: its derivative a (1 - a) from a float32 a is then
+    # noise in the reference's arithmetic too -- rows up to 3)
+    x *= (10.0 ** rng.uniform(-6, 4 if act == 'relu' else 0.5, size=(rows, 1))).astype(np.float32)
+    x[::17] = 0.0                                                             # and zero rows
+    net, _, _ = build(kw, seed=3, precision=split)
+    with torch.no_grad():
+        for k, q in net.named_parameters():
+            if k.endswith('weight') and act == 'relu':
+                sc = torch.ones(q.shape[0], 1, device=q.device)
+                sc[32:64] = 1e-3
+                sc[64:96] = 1e3
+                q.mul_(sc)
+        net.weights_changed_behind_torch()
+    g = (rng.standard_normal((rows, 64)) * 1e-9).astype(np.float32)
+    net.train()
+    e = net.forward_once(dev(x))
+    e.backward(dev(g))
+    # the same network in float64 on the CPU
+    Ws = [q.detach().double().cpu() for k, q in net.named_parameters() if k.endswith('weight')]
+    bs = [q.detach().double().cpu() for k, q in net.named_parameters() if k.endswith('bias')]
+    for t in Ws + bs:
+        t.requires_grad_(True)
+    h = torch.from_numpy(x).double()
+    for l in range(4):
+        h = h @ Ws[l].T + bs[l]
+        if act == 'sigmoid':
+            h = torch.sigmoid(h)
+        elif l < 3:
+            h = torch.relu(h)
+    h.backward(torch.from_numpy(g).double())
+    ref = h.detach().numpy()
+    got = e.detach().cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    rmax = np.abs(ref).max(axis=1, keepdims=True)          # a row of 1e-6 inputs is judged against its own size
+    ok = rmax[:, 0] > 0
+    assert (np.abs(got - ref)[ok] / rmax[ok]).max() < 1e-5
+    grads = [q.grad.double().cpu().numpy() for k, q in net.named_parameters()]
+    refs = [t for pair in zip(Ws, bs) for t in pair]
+    for (k, _), mine, r in zip(net.named_parameters(), grads, refs):
+        d = np.abs(mine - r.grad.numpy()) / np.abs(r.grad.numpy()).max()
+        # (ReLU: a pre-activation that cancels to ~0 may take the other side of relu' in another arithmetic -- one row's
+        # term in one feature's gradients; the bias is zero here, such rows exist)
+        allowed = max(1, d.size // 2000) if act == 'relu' else 0
+        assert (d > 2e-5).sum() <= allowed, (k, d.max(), int((d > 2e-5).sum()))
+        assert d.max() < 2e-2, (k, d.max())
