@@ -1194,7 +1194,7 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
     b.d_out = d_out;
     b.d_out_is_dz = t->d_out_is_dz;
     b.tp_steps = pl_row_steps(rows);
-    ABN_REQUIRE((loss || aligned16(d_out)) && aligned16(scratch) && (!dx || aligned16(dx)),
+    ABN_REQUIRE((loss || t->wgrad_part == 2 || aligned16(d_out)) && aligned16(scratch) && (!dx || aligned16(dx)),
                 "tower_backward: d_out / scratch / dx must be 16-byte aligned");
     b.loss_kind = -1;
     b.B = (int)rows;                             // (no tower boundary inside the rows unless the loss rides along)
@@ -1262,7 +1262,7 @@ static int wide_backward(const abn_tower_desc* t, const float* d_out, const Loss
 {
     const int nl = t->n_layers, top = nl - 1;
     const int np = planes_of(t);
-    ABN_REQUIRE((loss || aligned16(d_out)) && aligned16(scratch) && (!dx || aligned16(dx)),
+    ABN_REQUIRE((loss || t->wgrad_part == 2 || aligned16(d_out)) && aligned16(scratch) && (!dx || aligned16(dx)),
                 "tower_backward: d_out / scratch / dx must be 16-byte aligned");
     ABN_REQUIRE(!loss || n_calls == 2, "tower_backward_loss: two forward_once calls");
     const PackLayout PL = make_pack_layout(t);
@@ -1714,7 +1714,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
 {
     int rc = check_desc(t, rows, n_calls);
     if (rc != ABN_OK) return rc;
-    ABN_REQUIRE(x1 && d_out && ws && scratch, "tower_backward: null pointer");
+    ABN_REQUIRE(x1 && (d_out || t->wgrad_part == 2) && ws && scratch, "tower_backward: null pointer");      // (part 2 reads no d_out)
     for (int l = 0; l < t->n_layers; ++l) {
         ABN_REQUIRE(t->dW[l] && t->db[l], "tower_backward: layer %d has null gradient buffers", l);
         if (t->batch_norm) ABN_REQUIRE(t->dbn_w[l] && t->dbn_b[l], "tower_backward: layer %d has null BN gradient buffers", l);

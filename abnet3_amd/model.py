@@ -844,7 +844,7 @@ class SiameseNetwork(_HipNetwork):
         self._pending_lower = None
         desc.wgrad_part = 2
         _lib.check(_lib.load().abn_tower_backward(
-            _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(sv.ws), rows,
+            _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(None), rows,
             sv.n_calls, _lib.ptr(sv.ws), _lib.ptr(scratch), scratch_floats, _lib.ptr(None), _lib.stream()), 'abn_tower_backward')
 
     def grad_split_offset(self, state, layer):

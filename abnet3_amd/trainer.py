@@ -322,10 +322,12 @@ class TrainerSiamese(TrainerBuilder):
         parameters all live in ONE segment of the flat buffer, no BatchNorm; the upper bucket = the top half of the layers."""
         net = self.network
         seg = state[0]
-        if (not self.overlap_allreduce or getattr(net, 'batch_norm', False) or len(seg.blocks) < 3
-                or len(seg.params) != 2 * len(seg.blocks) or len(list(net.parameters())) != len(seg.params)):
+        if not self.overlap_allreduce or getattr(net, 'batch_norm', False) or len(seg.blocks) < 3:
             return None
-        return (len(seg.blocks) + 1) // 2
+        one = getattr(self, '_one_segment', None)           # (the parameter walk once, not per step)
+        if one is None or one[0] is not seg:
+            one = self._one_segment = (seg, len(seg.params) == 2 * len(seg.blocks) and len(list(net.parameters())) == len(seg.params))
+        return (len(seg.blocks) + 1) // 2 if one[1] else None
 
     def _loss_is_mean(self):
         """Data-parallel gradient exchange: a mean loss averages over ranks, a

@@ -130,7 +130,8 @@ typedef struct abn_tower_desc {
      * the backward in two calls on the same workspace and scratch so that the caller can start the all-reduce of the
      * upper layers' gradients while the lower layers' are still being computed.  0 = everything (default);
      * 1 = the data-gradient launches and the weight gradients (with their slab reduction) of layers >= wgrad_split;
-     * 2 = the weight gradients (and reduction) of layers < wgrad_split -- after a part-1 call, no defer_reduce. */
+     * 2 = the weight gradients (and reduction) of layers < wgrad_split -- after a part-1 call (d_out is not read and may be
+     * NULL), no defer_reduce. */
     int32_t wgrad_part;
     void* wpack;
     /* Dropout drawn inside the kernels instead of read from drop_mask (default arithmetic only;
