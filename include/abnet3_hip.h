@@ -112,7 +112,7 @@ typedef struct abn_tower_desc {
      * caller finishes with abn_tower_reduce_step (reduction + optimizer step in one launch;
      * BatchNorm's gamma / beta gradients are final either way). */
     int32_t defer_reduce;
-    /* Optional persistent image of the weights as MFMA operand fragments (default arithmetic):
+    /* Optional persistent image of the weights as MFMA operand fragments (the split arithmetics, precision 1-3):
      * wpack = abn_tower_wpack_floats() floats owned by the caller, zero before the first use, or
      * NULL (the forward then builds the image inside its workspace every call).  wpack_valid != 0:
      * the caller vouches that the image matches W as it stands -- it does after a forward that
@@ -134,7 +134,7 @@ typedef struct abn_tower_desc {
      * NULL), no defer_reduce. */
     int32_t wgrad_part;
     void* wpack;
-    /* Dropout drawn inside the kernels instead of read from drop_mask (default arithmetic only;
+    /* Dropout drawn inside the kernels instead of read from drop_mask (the split arithmetics only;
      * where drop_mask[l] is given it wins): drop_seed = device pointer to one uint64 the caller
      * draws per forward (NULL: off), drop_p = nn.Dropout's p.  The multiplier of element
      * (layer, row, feature) is a hash of (seed, layer, row, feature): 0 with probability p
@@ -260,7 +260,8 @@ int abn_linear_backward(const float* dz, const float* W, const float* a_in, int6
                         float* db, float* dx, float* scratch, int64_t scratch_floats,
                         void* stream);
 /* ... in the arithmetic abn_tower_desc.precision names (0 exact fp32 = abn_linear_backward,
- * 1 bf16 operands, 2 bf16 x 3): the grid abn_tower_backward issues for that network.  dW and db
+ * 1 bf16 operands, 2 bf16 x 3, 3 = run as 2: fp16 x 2 exists on the operand planes only): the grid abn_tower_backward
+ * issues for that network.  dW and db
  * both NULL: only that grid runs and the split-K slabs stay unreduced in scratch (bench.py times
  * the grid alone this way). */
 int abn_linear_backward_prec(const float* dz, const float* W, const float* a_in, int64_t rows,
