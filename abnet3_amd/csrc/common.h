@@ -44,6 +44,7 @@ struct Switches {
     int64_t wgrad_rows_per_slab;   // ABN_WGRAD_ROWS_PER_SLAB: fewest batch rows one split-K slab of the weight gradients sums (default 128)
     bool wide;                // ABN_WIDE=0: small batches on the single-launch chains / per-layer GEMMs, not tower_wide.h
     int64_t wide_max_rows;    // ABN_WIDE_MAX_ROWS: most (virtual) rows the layer-per-launch kernels take, -1 = default
+    int wide_max_groups;      // ABN_WIDE_MAXG: most workgroups per 32-row block of a layer-per-launch kernel (1 .. 8, default 8)
 };
 const Switches& switches();
 void reload_switches();

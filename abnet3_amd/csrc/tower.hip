@@ -47,6 +47,8 @@ static Switches read_switches()
     s.wgrad_rows_per_slab = getenv("ABN_WGRAD_ROWS_PER_SLAB") ? atoll(getenv("ABN_WGRAD_ROWS_PER_SLAB")) : -1;
     s.wide = !off("ABN_WIDE");
     s.wide_max_rows = getenv("ABN_WIDE_MAX_ROWS") ? atoll(getenv("ABN_WIDE_MAX_ROWS")) : -1;
+    s.wide_max_groups = getenv("ABN_WIDE_MAXG") ? atoi(getenv("ABN_WIDE_MAXG")) : WD_MAXG;
+    if (s.wide_max_groups < 1 || s.wide_max_groups > WD_MAXG) s.wide_max_groups = WD_MAXG;
     s.dtw_f40 = !off("ABN_DTW_F40");
     s.dtw_pc = !off("ABN_DTW_PC");
     return s;
@@ -830,7 +832,7 @@ static int wide_groups(int64_t vrows, int max_blocks = 2 * WD_MAXG)
     if (!switches().wide || vrows > cap || vrows < PL_ROWS) return 0;
     const int64_t nrb = vrows / PL_ROWS;
     int64_t G = 256 / nrb;
-    G = G < 1 ? 1 : (G > WD_MAXG ? WD_MAXG : G);
+    G = G < 1 ? 1 : (G > switches().wide_max_groups ? switches().wide_max_groups : G);
     // a workgroup's eight waves take at most one output block each (WideShare): the widest layer's blocks
     // must fit 8 x G
     if ((max_blocks + G - 1) / G > PL_WAVES) return 0;
