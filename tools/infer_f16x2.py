@@ -3,7 +3,7 @@ import sys, time; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(
 import torch, bench
 from abnet3_amd.model import SiameseNetwork
 for bn in (False, True):
-  for prec in ('f16x2','bf16x3'):
+  for prec in ('bf16x3','f16x2','bf16x3'):
     torch.manual_seed(0)
     net = SiameseNetwork(output_path='/tmp/abn_inf', **dict(bench.C2, batch_norm=bn)).cuda(); net.precision=prec; net.eval()
     x = torch.randn(8192, 40, device='cuda')
