@@ -747,6 +747,7 @@ def main():
                                    'Adadelta(0.1), 4096 frame pairs per GPU per step, 40-d N(0,1) frames',
                        'pairs_per_gpu': BATCH, 'global_pairs': BATCH * world,
                        'parallelism': 'dp%d' % world, 'graph_replay': bool(args.graph),
+                       'dp_gradient_buckets': (2 if world > 1 and trainer.overlap_allreduce else 1),   # (the first all-reduce under the rest of the backward)
                        'arithmetic': {'f16x2': 'f16x2: fp32 operands scaled by a power of two per row / block and split into 2 fp16 '
                                                'terms (22 bits), 3 fp16 MFMA products per operand pair, fp32 accumulate / storage / '
                                                'loss / optimizer; parity-grade (all golden tests at 1e-5; no further from float64 '
