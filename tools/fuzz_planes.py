@@ -26,6 +26,7 @@ def run(cases, seed, verbose=True):
       B = int(rng.choice([1, 7, 31, 32, 33, 100, 257, 300, 700, 1500, 2100]))
       pair = bool(rng.integers(0, 2))
       wide = int(rng.integers(0, 2))
+      want_dx = bool(rng.integers(0, 3) == 0)            # the input's gradient too (the data-gradient chain one product further)
       os.environ['ABN_WIDE'] = str(wide)
       reload_sw()
       kw = dict(input_dim=d_in, num_hidden_layers=nh, hidden_dim=hid, output_dim=d_out, activation_layer=act, p_dropout=0.0, batch_norm=bn)
@@ -39,16 +40,19 @@ def run(cases, seed, verbose=True):
           net = SiameseNetwork(**kw).cuda()
           net.precision = prec
           net.train()
+          xa = x1.clone().requires_grad_(want_dx)
           if pair:
-              e1, e2 = net(x1, x2)
+              e1, e2 = net(xa, x2)
               e = torch.cat([e1, e2])
           else:
-              e = net.forward_once(x1)
+              e = net.forward_once(xa)
           if 'g' not in outs:
               outs['g'] = torch.from_numpy(rng.standard_normal(tuple(e.shape)).astype(np.float32)).cuda() * 1e-2
           e.backward(outs['g'])
-          outs[prec] = (e.detach().double().cpu().numpy(), {k: q.grad.double().cpu().numpy() for k, q in net.named_parameters() if q.grad is not None},
-                        lib.abn_debug_last_forward_path())
+          grads = {k: q.grad.double().cpu().numpy() for k, q in net.named_parameters() if q.grad is not None}
+          if want_dx:
+              grads['d input'] = xa.grad.double().cpu().numpy()
+          outs[prec] = (e.detach().double().cpu().numpy(), grads, lib.abn_debug_last_forward_path())
       e32, g32, _ = outs['fp32']
       for prec in ('f16x2', 'bf16x3'):
           e, g, path = outs[prec]
