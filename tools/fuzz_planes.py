@@ -32,8 +32,14 @@ def run(cases, seed, verbose=True):
       kw = dict(input_dim=d_in, num_hidden_layers=nh, hidden_dim=hid, output_dim=d_out, activation_layer=act, p_dropout=0.0, batch_norm=bn)
       if act == 'relu':
           kw['last_non_linearity'] = None
-      x1 = torch.from_numpy(rng.standard_normal((B, d_in)).astype(np.float32)).cuda()
-      x2 = torch.from_numpy(rng.standard_normal((B, d_in)).astype(np.float32)).cuda()
+      xa1, xa2 = rng.standard_normal((B, d_in)).astype(np.float32), rng.standard_normal((B, d_in)).astype(np.float32)
+      spread = act == 'relu' and not bn and bool(rng.integers(0, 2))
+      if spread:      # rows eight orders of magnitude apart, some of them zero (a ReLU tower without BatchNorm is positive homogeneous:
+          # the exact-fp32 mode stays a fair yardstick; the embeddings are then judged row by row)
+          xa1 *= (10.0 ** rng.uniform(-5, 3, size=(B, 1))).astype(np.float32)
+          xa2 *= (10.0 ** rng.uniform(-5, 3, size=(B, 1))).astype(np.float32)
+          xa1[::13] = 0.0
+      x1, x2 = torch.from_numpy(xa1).cuda(), torch.from_numpy(xa2).cuda()
       outs = {}
       for prec in ('fp32', 'f16x2', 'bf16x3'):
           torch.manual_seed(case)
@@ -56,7 +62,12 @@ def run(cases, seed, verbose=True):
       e32, g32, _ = outs['fp32']
       for prec in ('f16x2', 'bf16x3'):
           e, g, path = outs[prec]
-          ee = np.abs(e - e32).max() / max(np.abs(e32).max(), 1e-30)
+          if spread:
+              rmax = np.abs(e32).max(axis=1, keepdims=True)
+              okr = rmax[:, 0] > 0
+              ee = float((np.abs(e - e32)[okr] / rmax[okr]).max()) if okr.any() else 0.0
+          else:
+              ee = np.abs(e - e32).max() / max(np.abs(e32).max(), 1e-30)
           worst, wk, nbad = 0.0, '', 0
           for k in g32:
               if bn and k.endswith('.bias') and k[:-5] + '.weight' in g32 and g32[k[:-5] + '.weight'].ndim == 2:
@@ -75,7 +86,7 @@ def run(cases, seed, verbose=True):
           if not ok:
               bad += 1
           line = ('%s case %3d %s in %3d hid %3d x%d out %3d %-7s bn %d B %4d pair %d wide %d path %d | emb %.1e  worst grad %.1e %s%s'
-                % ('ok ' if ok else 'BAD', case, prec, d_in, hid, nh, d_out, act, bn, B, pair, wide, path, ee, worst, wk, '' if ok else '  <<<<<'))
+                % ('ok ' if ok else 'BAD', case, prec, d_in, hid, nh, d_out, act, bn, B, pair, wide, path, ee, worst, wk, (' spread' if spread else '') + ('' if ok else '  <<<<<')))
           lines.append(line)
           if verbose or not ok:
               print(line, flush=True)
