@@ -834,3 +834,38 @@ def test_f16x2_scales_follow_the_data(rows, act, split, monkeypatch):
         allowed = max(1, d.size // 2000) if act == 'relu' else 0
         assert (d > 2e-5).sum() <= allowed, (k, d.max(), int((d > 2e-5).sum()))
         assert d.max() < 2e-2, (k, d.max())
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_two_part_backward_is_bit_identical_for_random_towers(seed, split, monkeypatch):
+    """abn_tower_desc.wgrad_part on random towers (1 .. 5 layers, random widths, the chains and the layer-per-launch kernels,
+    every cut 0 .. n_layers): the two calls leave the loss and every gradient of the one call, bit for bit."""
+    import abnet3_amd.loss as L
+    from abnet3_amd.trainer import TrainerSiamese
+    rng = np.random.default_rng(100 + seed)
+    nh = int(rng.integers(0, 4))
+    kw = dict(input_dim=int(rng.integers(2, 80)) * 4, num_hidden_layers=nh, hidden_dim=int(rng.integers(2, 128)) * 4,
+              output_dim=int(rng.integers(2, 40)) * 4, activation_layer=str(rng.choice(['sigmoid', 'tanh'])), p_dropout=0.0, batch_norm=False)
+    B = int(rng.choice([48, 300, 1700]))
+    monkeypatch.setenv('ABN_WIDE', str(int(rng.integers(0, 2))))
+    net, _, _ = build(kw, seed=seed, precision=split)
+    tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='sgd', lr=0.0, dataloader=None, log_dir='/tmp/abn_runs')
+    x1, x2 = dev(rng.standard_normal((B, kw['input_dim'])).astype(np.float32)), dev(rng.standard_normal((B, kw['input_dim'])).astype(np.float32))
+    y = dev(rng.choice([1.0, -1.0], B))
+    net.train()
+    n_layers = nh + 2
+
+    def run(cut):
+        emb, state = net.direct_forward(x1, x2)
+        tr.optimizer.zero_grad()
+        loss = net.direct_backward_loss(state, y, 'coscos2', 0.0, False, defer_reduce=False, wgrad_split=cut)
+        assert loss is not None
+        if cut is not None:
+            net.direct_backward_lower()
+        return loss.clone(), [p.grad.clone() for p in net.parameters()]
+    l0, g0 = run(None)
+    for cut in range(n_layers + 1):
+        l1, g1 = run(cut)
+        assert torch.equal(l0, l1), cut
+        for a, b in zip(g0, g1):
+            assert torch.equal(a, b), cut
