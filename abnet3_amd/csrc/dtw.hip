@@ -62,8 +62,7 @@ constexpr int BAND = 32;     // rows of token 1 a lane-half sweeps at once (one 
 constexpr int KCH = 40;      // k processed per MFMA chain segment (the 40-d filterbank frame in one piece)
 constexpr int KST = KCH / 2; // v_mfma_f32_32x32x2_f32 steps per segment
 
-// back-pointer codes
-enum { DIR_DIAG = 0, DIR_UP = 1, DIR_LEFT = 2 };
+// back-pointers: two bits per cell, (up < diag) << 1 | (left < min(diag, up)); first minimum in the order diag, up, left
 
 struct DtwP {
     const float* feats1;
@@ -81,6 +80,7 @@ struct DtwP {
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // lane l receives lane l-1's value (lanes 0 and 32 are overridden by the caller)
 __device__ __forceinline__ double wave_shr1(double v)
@@ -365,12 +365,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void dt
                 const double b1 = take_up ? up : dg;
                 const bool take_left = left < b1;
                 const double best = take_left ? left : b1;
-                const uint32_t dir = take_left ? (uint32_t)DIR_LEFT : take_up ? (uint32_t)DIR_UP : (uint32_t)DIR_DIAG;
                 const double cost = (double)dist + best;
                 const bool on = rowok && (uint32_t)j < (uint32_t)M;
                 p2 = left;
                 p1 = on ? cost : left;                                     // past the row's end the last cost stays put
-                bits |= on ? dir << (2 * ee) : 0u;
+                bits = (bits << 2) | (take_up ? 2u : 0u) | (take_left ? 1u : 0u);    // cells outside the matrix: never read
                 if (last_lane && on) bot_s[half][j & 63] = cost;
             }
             if (active) dptr[(e16 >> 4) * BAND] = bits;
@@ -419,51 +418,93 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void dt
 }
 
 // ---------------------------------------------------------------------------------------
-// Producer / consumer form of the same algorithm for 40-value frames (the hot case): a
-// workgroup is TWO wavefronts sharing two slots.
-//   wave 0 (producer)  rows -> fragments + norms, 2 x 20 MFMAs, the reference's distance per
-//                      cell on all 64 lanes: throughput code, ~170 registers, no DP state;
-//   wave 1 (consumer)  the two slots' float64 sweeps (32 lanes each): a dependency chain,
-//                      ~60 registers, plus boundary rows and back-pointer stores.
-// The producer works one block AHEAD: while the consumer sweeps round t it computes the block
-// of round t+1.  A block's 63 anti-diagonals fall into the ring half the consumer is NOT
-// reading (its first 32 diagonals: written at once) and the half it IS reading (the other 31:
-// held in registers until the consumer has finished the round -- barrier A -- then written,
-// barrier B).  Ring rows are counted by a per-slot round counter that never resets, so the
-// halves alternate across band and pair changes too.  The producer also drives the slots'
-// schedule (next block / next band / next pair from the queue) and publishes one descriptor
-// per slot and round through LDS.  Twice the wavefronts per CU at the same LDS footprint:
-// the producers keep the vector ALU fed while the consumers wait on their chains.
+// Gang form for 40-value frames (round 4; the default): a workgroup is THREE wavefronts around
+// two slots -- one producer wavefront PER SLOT and one consumer wavefront sweeping both.
+//   producer q   keeps its band's 32 rows of token 1 as MFMA fragments + norms in REGISTERS for
+//                the whole band (they are read from HBM once per band, not once per round), loads
+//                32 rows of token 2 per round, 20 MFMAs, the reference's distance on 16 cells per
+//                lane, and stores the block COLUMN-MAJOR into one of three 4 KB buffers of its
+//                slot: blk[slot][round % 3][column][row].  No diagonal skew on this side, no cells
+//                held back: one workgroup barrier per round.
+//   consumer     lane n of a half owns row n of the slot's band; at step e of round u its cell is
+//                column 32 u + e - n: block u for e >= n, block u - 1 (the buffer of the round
+//                before) for e < n -- one select of two per-lane base addresses, the rest of the
+//                address is the step's immediate offset.  A step is ~20 vector instructions: the
+//                up neighbour arrives over ONE DPP shift (the diagonal neighbour is last step's up),
+//                min3 with the oracle's tie-break is two v_min_f64 + two compares whose lane
+//                masks are shifted straight into the back-pointer word (v_addc), lane 31 stores the
+//                band's boundary row as it goes.
+// Back-pointers: 2 bits per cell, (up < diag) << 1 | (left < min(diag, up)), sixteen diagonals to a
+// dword, the FIRST of the sixteen in the top bits; cells outside the matrix hold garbage (never
+// visited by the traceback).
 // ---------------------------------------------------------------------------------------
 #ifdef ABN_DTW_STAMPS         // diagnostic build only (tools/dtw_stamps.py): cycles per phase, summed over workgroups
 __device__ unsigned long long g_dtw_cycles[16];
-#define PSTAMP(k) do { if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_dtw_cycles[k], t_ - tlast); tlast = t_; } } while (0)
+#define PSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[(k) & 3] += t_ - tlast; tlast = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PSTAMP_INIT unsigned long long tacc[4] = {0, 0, 0, 0}; unsigned long long tlast = __builtin_amdgcn_s_memtime()
+#define PSTAMP_FLUSH(base) do { if (lane == 0) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&g_dtw_cycles[(base) + k_], tacc[k_]); } while (0)
 #else
 #define PSTAMP(k) do {} while (0)
+#define PSTAMP_INIT do {} while (0)
+#define PSTAMP_FLUSH(base) do {} while (0)
 #endif
-
-struct RoundDesc {            // what a slot does in one round (LDS; written by the producer)
-    int32_t pair;             // -1: slot idle
-    int32_t N, M, nbands, nrounds, band, u;
-    int32_t v;                // the slot's running round counter (ring phase)
-    int64_t xoff, yoff, dir_off;
+constexpr int GS = 2;                                  // slots per workgroup
+struct GangDesc {                                      // what a slot does in one round (LDS; written by its producer)
+    int32_t pair;                                      // -1: slot idle
+    int32_t N, M, nbands, nrounds, band, u, pad;
+    int64_t dir_off;
 };
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void dtw_pc_kernel(DtwP P)
+// mn = min(a, b); bits = 2 bits + (a < b)
+__device__ __forceinline__ void min_lt(double a, double b, double& mn, uint32_t& bits)
 {
-    __shared__ __attribute__((aligned(16))) float ring[2][64][BAND];
-    __shared__ __attribute__((aligned(16))) float ny_s[2][BAND];
-    __shared__ double top_s[2][BAND];
-    __shared__ double bot_s[2][2 * BAND];
-    __shared__ RoundDesc desc[2][2];                   // [round parity][slot]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, n = lane & 31;
-    const int D = P.D;
+    uint32_t nb;
+    asm("v_cmp_lt_f64_e32 vcc, %3, %4\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %2, %2, vcc\n\t"
+        "v_min_f64 %0, %3, %4"
+        : "=v"(mn), "=&v"(nb)
+        : "v"(bits), "v"(a), "v"(b)
+        : "vcc");
+    bits = nb;
+}
 
-    if (wave == 0) {
-        // =========================== producer ===========================
+__device__ __forceinline__ double dpp_shr1_f64(double v)      // lane l <- lane l - 1 (lanes 0 / 32: overridden by the caller)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+#ifndef ABN_GANG_OCC
+#define ABN_GANG_OCC 4
+#endif
+#ifndef ABN_GANG_ILP
+#define ABN_GANG_ILP 0
+#endif
+#ifndef ABN_GANG_YPF
+#define ABN_GANG_YPF 1       // the producer requests its rows a round ahead
+#endif
+__global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(ABN_GANG_OCC, ABN_GANG_OCC))) void dtw_gang_kernel(DtwP P)
+{
+    __shared__ __attribute__((aligned(16))) float blk[GS][3][BAND][BAND];      // [slot][round % 3][column][row]
+    __shared__ __attribute__((aligned(16))) float ny_s[GS][BAND];
+    __shared__ double top_s[GS][BAND];
+    __shared__ GangDesc desc[2][GS];                                             // [round parity][slot]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, n = lane & 31;
+    const int D = KCH;
+    const int64_t bstride = P.mcap;                     // a boundary row: 32 doubles of slack in front (the host pads mcap)
+
+    if (wave < GS) {
+        // =========================== producer of slot `wave` ===========================
+        const int q = wave;
         bool exhausted = false;
-        auto fetch = [&](RoundDesc& d) {               // next pair of the queue (wave-uniform values)
-            d.pair = -1;
+        int pair = -1, N = 0, M = 0, nbands = 0, nrounds = 0, band = 0, u = 0;
+        int64_t xoff = 0, yoff = 0, dir_off = 0;
+        float xf[KST], nx = 1.0f;
+        uint32_t orbits = 0u;                           // OR of the distances' bit patterns: >= 0x7f800000 iff one is NaN
+        auto fetch = [&]() {                            // next pair of the queue (wave-uniform values)
+            pair = -1;
             if (exhausted) return;
             int idx = 0;
             if (lane == 0) idx = atomicAdd(P.counter, 1);
@@ -471,226 +512,243 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (idx >= P.npairs) { exhausted = true; return; }
             const int p = __builtin_amdgcn_readfirstlane(P.order[idx]);
             const PairMeta* m = P.meta + p;
-            d.pair = p;
-            d.N = __builtin_amdgcn_readfirstlane(m->n1); d.M = __builtin_amdgcn_readfirstlane(m->n2);
-            d.nbands = __builtin_amdgcn_readfirstlane(m->nbands); d.nrounds = __builtin_amdgcn_readfirstlane(m->nrounds);
-            d.xoff = readlane64(m->off1, 0) * D; d.yoff = readlane64(m->off2, 0) * D; d.dir_off = readlane64(m->dir_off, 0);
-            d.band = 0; d.u = 0;
+            pair = p;
+            N = __builtin_amdgcn_readfirstlane(m->n1); M = __builtin_amdgcn_readfirstlane(m->n2);
+            nbands = __builtin_amdgcn_readfirstlane(m->nbands); nrounds = __builtin_amdgcn_readfirstlane(m->nrounds);
+            xoff = readlane64(m->off1, 0) * D; yoff = readlane64(m->off2, 0) * D; dir_off = readlane64(m->dir_off, 0);
+            band = 0; u = 0;
         };
-        RoundDesc cur[2];                              // the block being produced (scalar registers)
-        uint32_t orbits[2] = {0u, 0u};                 // OR of the distances' bit patterns: >= 0x7f800000 iff one is NaN
-        float dreg[2][16];
-
-        // block of `cur[q]`: loads, MFMA, distances into dreg[q].  One slot at a time and the band's
-        // rows re-read every round (they are L1 / L2 hot): the kernel has to fit 128 registers so
-        // that four wavefronts share a SIMD.
-        auto produce = [&](bool have0, bool have1) {
+        auto load_x = [&]() {                           // the band's rows: fragments + norms, kept for the whole band
+            const float* xrow = P.feats1 + xoff + (int64_t)min(band * BAND + n, N - 1) * D;
+            nx = load_row40(xf, xrow, half);
+        };
+        auto publish = [&](int par) {
+            if (lane == 0) {
+                GangDesc d;
+                d.pair = pair; d.N = N; d.M = M; d.nbands = nbands; d.nrounds = nrounds; d.band = band; d.u = u; d.pad = 0;
+                d.dir_off = dir_off;
+                desc[par][q] = d;
+            }
+        };
+        // The 32 rows of token 2 of round (band, u), requested one round AHEAD: raw buffer loads (the
+        // compiler leaves them where they are written; plain loads sink to their first use), the
+        // descriptor spans the pair's token so offsets fit 32 bits.
+        u32x4 yq[10];
+        auto request_y = [&]() {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.feats2 + yoff), 0, M * (D * 4), 0x00020000);
+            const int vo = min(u * BAND + n, M - 1) * (D * 4);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if (!(q ? have1 : have0)) continue;
-                const RoundDesc& d = cur[q];
-                f32x16 acc;
+            for (int i = 0; i < 10; ++i) yq[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 16 * i, 0);
+        };
+        // the block of (band, u) into buffer `buf` from the rows requested before
+        auto produce = [&](int buf) {
+            f32x16 acc;
+            float ny;
+            {
+                // row piece by row piece: two fragment values -> two MFMAs, four squares -> numpy's eight
+                // partial sums (sumsq40's order; packed: two squares / two sums per instruction); a piece's
+                // registers are free once it is used
+                f32x2 r01, r23, r45, r67;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                float nxl, ny;
-                {
-                    float xf[KST], yf[KST];
-                    const float* yrow = P.feats2 + d.yoff + (int64_t)min(d.u * BAND + n, d.M - 1) * D;
-                    ny = load_row40(yf, yrow, half);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const float* xrow = P.feats1 + d.xoff + (int64_t)min(d.band * BAND + n, d.N - 1) * D;
-                    nxl = load_row40(xf, xrow, half);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int t = 0; t < KST; ++t)                           // A = token 2 rows (j), B = token 1 rows (i)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[t], xf[t], acc, 0, 0, 0);
+                for (int i = 0; i < 10; ++i) {
+                    const float4 v = make_float4(__uint_as_float(yq[i].x), __uint_as_float(yq[i].y), __uint_as_float(yq[i].z), __uint_as_float(yq[i].w));
+                    const float f0 = half ? v.y : v.x, f1 = half ? v.w : v.z;
+#ifndef ABN_EXP_NOMFMA
+                    if (i == 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, xf[0], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, xf[2 * i], acc, 0, 0, 0);       // A = token 2 rows (j), B = token 1 rows (i)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f1, xf[2 * i + 1], acc, 0, 0, 0);
+#else
+                    if (i == 0) for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+                    acc[i] += f0 * xf[2 * i] + f1 * xf[2 * i + 1];
+#endif
+                    const f32x2 sxy = f32x2{v.x, v.y} * f32x2{v.x, v.y}, szw = f32x2{v.z, v.w} * f32x2{v.z, v.w};
+                    if (i == 0) { r01 = sxy; r23 = szw; }
+                    else if (i == 1) { r45 = sxy; r67 = szw; }
+                    else if ((i & 1) == 0) { r01 += sxy; r23 += szw; }
+                    else { r45 += sxy; r67 += szw; }
                 }
-                if (half == 0) ny_s[q][n] = ny;
-                wave_lds_sync();                                           // ny_s (this wave's own writes)
-                const bool plain = __all(norm_is_plain(nxl) && norm_is_plain(ny));
-                uint32_t ob = 0u;
-                auto epilogue = [&](auto pl) {
+                ny = sqrtf(((r01.x + r01.y) + (r23.x + r23.y)) + ((r45.x + r45.y) + (r67.x + r67.y)));
+            }
+            if (half == 0) ny_s[q][n] = ny;
+            wave_lds_sync();                                               // ny_s (this wave's own writes)
+            const bool plain = __all(norm_is_plain(nx) && norm_is_plain(ny));
+            // accumulator c of lane (n, h) is column m = (c & 3) + 8 (c >> 2) + 4 h of the block, row n
+            float* const out = &blk[q][buf][4 * half][n];
+            uint32_t ob = 0u;
+            auto epilogue = [&](auto pl) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        const float4 ny4 = *reinterpret_cast<const float4*>(&ny_s[q][8 * g + 4 * half]);
-                        const float nyv[4] = {ny4.x, ny4.y, ny4.z, ny4.w};
-                        if constexpr (decltype(pl)::value) {          // two cells per instruction (dist_ref.h)
+                for (int g = 0; g < 4; ++g) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u * BAND + 8 * g >= M) break;                       // columns past the token's end: never read by the sweep
+                    const float4 ny4 = *reinterpret_cast<const float4*>(&ny_s[q][8 * g + 4 * half]);
+                    const float nyv[4] = {ny4.x, ny4.y, ny4.z, ny4.w};
+                    if constexpr (decltype(pl)::value) {          // four cells = two chains of packed instructions (dist_ref.h)
+#if ABN_GANG_ILP
+                        const f32x4 dv = angular_distance_plain4(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, nx, f32x4{nyv[0], nyv[1], nyv[2], nyv[3]});
+                        ob |= (__float_as_uint(dv.x) | __float_as_uint(dv.y)) | (__float_as_uint(dv.z) | __float_as_uint(dv.w));   // padded rows / columns repeat real ones: no masking needed
+                        out[(8 * g) * BAND] = dv.x;
+                        out[(8 * g + 1) * BAND] = dv.y;
+                        out[(8 * g + 2) * BAND] = dv.z;
+                        out[(8 * g + 3) * BAND] = dv.w;
+#else
 #pragma unroll
-                            for (int e = 0; e < 4; e += 2) {
-                                const f32x2 dv = angular_distance_plain2(f32x2{acc[4 * g + e], acc[4 * g + e + 1]}, nxl, f32x2{nyv[e], nyv[e + 1]});
-                                ob |= __float_as_uint(dv.x) | __float_as_uint(dv.y);      // padded rows / columns repeat real ones: no masking needed
-                                dreg[q][4 * g + e] = dv.x;
-                                dreg[q][4 * g + e + 1] = dv.y;
-                            }
-                        } else {
+                        for (int e = 0; e < 4; e += 2) {
+#ifndef ABN_EXP_NOEPI
+                            const f32x2 dv = angular_distance_plain2(f32x2{acc[4 * g + e], acc[4 * g + e + 1]}, nx, f32x2{nyv[e], nyv[e + 1]});
+#else
+                            const f32x2 dv = f32x2{acc[4 * g + e], acc[4 * g + e + 1]} * splat2(nx * 1e-3f) * f32x2{nyv[e], nyv[e + 1]};
+#endif
+                            ob |= __float_as_uint(dv.x) | __float_as_uint(dv.y);      // padded rows / columns repeat real ones: no masking needed
+                            out[(8 * g + e) * BAND] = dv.x;
+                            out[(8 * g + e + 1) * BAND] = dv.y;
+                        }
+#endif
+                    } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float dv = angular_distance_ref<false>(acc[4 * g + e], nxl, nyv[e]);
-                                ob |= __float_as_uint(dv);
-                                dreg[q][4 * g + e] = dv;
-                            }
+                        for (int e = 0; e < 4; ++e) {
+                            const float dv = angular_distance_ref<false>(acc[4 * g + e], nx, nyv[e]);
+                            ob |= __float_as_uint(dv);
+                            out[(8 * g + e) * BAND] = dv;
                         }
                     }
-                };
-                if (plain) epilogue(std::true_type{}); else epilogue(std::false_type{});
-                orbits[q] |= ob;
-            }
-        };
-        // accumulator c of lane (n, h) is column m = (c & 3) + 8 (c >> 2) + 4 h of the block: diagonal m + n
-        auto write_ring = [&](int q, bool late) {
-            const int v = cur[q].v;
-            float* rw = &ring[q][0][n];
-            const int base = ((v & 1) * BAND) + n + 4 * half;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const int mo = (c & 3) + 8 * (c >> 2);
-                const int dg = n + 4 * half + mo;                           // diagonal inside the block, 0 .. 62
-                if ((dg >= BAND) == late) rw[((base + mo) & 63) * BAND] = dreg[q][c];
-            }
-        };
-        auto finish_pair_flags = [&](int q) {          // the block just produced was the pair's last one
-            const RoundDesc& d = cur[q];
-            const bool last_block = d.band + 1 == d.nbands && (d.u + 1) * BAND >= d.M;
-            if (last_block) {
-                const bool isbad = __any(orbits[q] >= 0x7f800000u);
-                if (isbad && lane == 0) P.bad[d.pair] = 1;                  // utils.py:59: NaN (or negative) distance
-                orbits[q] = 0u;
-            }
-        };
-
-        // prologue: first pairs, their first blocks, complete in the ring before the consumer starts
-        fetch(cur[0]); cur[0].v = 0;
-        fetch(cur[1]); cur[1].v = 0;
-        if (lane == 0) { desc[0][0] = cur[0]; desc[0][1] = cur[1]; }
-        {
-            const bool h0 = cur[0].pair >= 0, h1 = cur[1].pair >= 0;
-            produce(h0, h1);
-            if (h0) { write_ring(0, false); write_ring(0, true); finish_pair_flags(0); }
-            if (h1) { write_ring(1, false); write_ring(1, true); finish_pair_flags(1); }
-        }
-        __syncthreads();                                                    // barrier B of "round -1"
-
-#ifdef ABN_DTW_STAMPS
-        unsigned long long tlast = __builtin_amdgcn_s_memtime();
-#endif
-        for (int t = 0;; ++t) {
-            if (cur[0].pair < 0 && cur[1].pair < 0) break;                  // = desc[t & 1]: the consumer sees the same
-            PSTAMP(0);
-            // next round of each slot
-            bool have[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                RoundDesc& d = cur[q];
-                if (d.pair >= 0) {
-                    const int v = d.v + 1;
-                    if (d.u + 1 < d.nrounds) d.u = d.u + 1;
-                    else if (d.band + 1 < d.nbands) { d.band = d.band + 1; d.u = 0; }
-                    else fetch(d);
-                    d.v = v;
                 }
-                have[q] = d.pair >= 0 && d.u * BAND < d.M;
+            };
+            if (plain) epilogue(std::true_type{}); else epilogue(std::false_type{});
+            orbits |= ob;
+            if (band + 1 == nbands && (u + 1) * BAND >= M) {               // the pair's last block
+                const bool isbad = __any(orbits >= 0x7f800000u);
+                if (isbad && lane == 0) P.bad[pair] = 1;                    // utils.py:59: NaN (or negative) distance
+                orbits = 0u;
             }
-            if (lane == 0) { desc[(t + 1) & 1][0] = cur[0]; desc[(t + 1) & 1][1] = cur[1]; }
-            PSTAMP(1);
-            produce(have[0], have[1]);
-            PSTAMP(2);
-            if (have[0]) write_ring(0, false);
-            if (have[1]) write_ring(1, false);
-            PSTAMP(3);
-            __syncthreads();                                                // A: the consumer has finished round t
-            PSTAMP(4);
-            if (have[0]) { write_ring(0, true); finish_pair_flags(0); }
-            if (have[1]) { write_ring(1, true); finish_pair_flags(1); }
-            __syncthreads();                                                // B: round t+1 is complete in the ring
-            PSTAMP(5);
+        };
+
+        // The wave's state is one round ahead of what it publishes: while the block of round t + 1 is
+        // computed, the rows of round t + 2 are already requested (they arrive under the epilogue and the
+        // barrier).  Iteration t = -1 is the prologue: the first pair's first block, complete before the
+        // consumer starts.
+        fetch();
+        if (pair >= 0) {
+            load_x();
+#if ABN_GANG_YPF
+            request_y();
+#endif
         }
+        PSTAMP_INIT;
+        for (int t = -1;; ++t) {
+            if (t >= 0 && desc[t & 1][0].pair < 0 && desc[t & 1][1].pair < 0) break;
+            publish((t + 1) & 1);                                           // round t + 1 of this slot
+            const bool have = pair >= 0 && u * BAND < M;
+            PSTAMP(0);
+#if !ABN_GANG_YPF
+            if (have) request_y();
+#endif
+            if (have) produce((t + 1) % 3);
+            PSTAMP(1);
+            bool newband = false;
+            if (pair >= 0) {                                                // on to round t + 2
+                if (u + 1 < nrounds) ++u;
+                else if (band + 1 < nbands) { ++band; u = 0; newband = true; }
+                else { fetch(); newband = pair >= 0; }
+            }
+            if (newband) load_x();
+#if ABN_GANG_YPF
+            if (pair >= 0 && u * BAND < M) request_y();
+#endif
+            PSTAMP(2);
+            __syncthreads();                                                // round t + 1 is complete; the consumer has finished round t
+            PSTAMP(3);
+        }
+        PSTAMP_FLUSH(0);
     } else {
         // =========================== consumer ===========================
         const double INF = __builtin_inf();
-        double* const bnd = P.bound + (int64_t)(2 * (int)blockIdx.x + half) * 2 * P.mcap;
-        double p1 = INF, p2 = INF, topprev = INF;
-        int prev_pair = -1;
-        __syncthreads();                                                    // B of "round -1": first blocks are in the ring
-#ifdef ABN_DTW_STAMPS
-        unsigned long long tlast = __builtin_amdgcn_s_memtime();
-#endif
+        double* const bnd = P.bound + (int64_t)(GS * (int)blockIdx.x + half) * 2 * bstride + 32;
+        double p1 = INF, upprev = INF;
+        uint32_t bits = 0u;
+        // the boundary values of the NEXT round, requested while this one is swept (same band: the row
+        // was finished a band ago); `pf_key` says which (pair, band, round) they belong to
+        double pf_top = INF;
+        int pf_pair = -1, pf_band = -1, pf_u = -1;
+        constexpr int PF = 4;                                               // LDS reads in flight ahead of the step that uses them
+        __syncthreads();                                                    // the first blocks are in place
+        PSTAMP_INIT;
         for (int t = 0;; ++t) {
-            const RoundDesc* dd = desc[t & 1];
-            if (dd[0].pair < 0 && dd[1].pair < 0) break;
-            PSTAMP(8);
-            const RoundDesc& d = dd[half];
-            const int pair = d.pair, N = d.N, M = d.M, nbands = d.nbands, nrounds = d.nrounds, band = d.band, u = d.u, v = d.v;
+            if (desc[t & 1][0].pair < 0 && desc[t & 1][1].pair < 0) break;
+            const GangDesc& d = desc[t & 1][half];
+            const int pair = d.pair, N = d.N, M = d.M, nbands = d.nbands, nrounds = d.nrounds, band = d.band, u = d.u;
             const bool active = pair >= 0;
             if (active && u == 0) {                      // a band starts: fresh diagonals
-                p1 = INF; p2 = INF;
-                topprev = (band == 0) ? 0.0 : INF;       // a pair starts from the virtual cell (-1, -1)
+                p1 = INF;
+                upprev = (band == 0 && n == 0) ? 0.0 : INF;      // a pair starts from the virtual cell (-1, -1)
             }
             const int i0 = band * BAND, j0 = u * BAND;
+            const double* const bin = bnd + (int64_t)((band & 1) ^ 1) * bstride;
             double topv = INF;
-            if (active && band > 0 && j0 + n < M)
-                topv = __hip_atomic_load(&bnd[(int64_t)((band & 1) ^ 1) * P.mcap + j0 + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (active && band > 0 && j0 + n < M) {
+                const bool hit = pf_pair == pair && pf_band == band && pf_u == u;
+                topv = pf_top;
+                if (!hit) topv = __hip_atomic_load(&bin[j0 + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             top_s[half][n] = topv;
             wave_lds_sync();
-            PSTAMP(9);
-            {
-                const float* rg = &ring[half][(v & 1) * BAND][n];
-                const bool rowok = active && i0 + n < N;
-                const bool feed_next = active && band + 1 < nbands;
-                const bool last_lane = n == BAND - 1 && feed_next;
-                uint32_t* dptr = P.dirs + d.dir_off + ((int64_t)(band * 2 * nrounds + 2 * u) * BAND + n);
-                for (int e16 = 0; e16 < BAND; e16 += 16) {
-                    uint32_t bits = 0u;
-#pragma unroll
-                    for (int ee = 0; ee < 16; ++ee) {
-                        const int e = e16 + ee;
-                        const int j = j0 + e - n;
-                        const float dist = rg[e * BAND];
-                        const double topc = top_s[half][e];
-                        double up = wave_shr1(p1), dg = wave_shr1(p2);
-                        if (n == 0) { up = topc; dg = topprev; topprev = topc; }
-                        const double left = p1;
-                        const bool take_up = up < dg;
-                        const double b1 = take_up ? up : dg;
-                        const bool take_left = left < b1;
-                        const double best = take_left ? left : b1;
-                        const uint32_t dir = take_left ? (uint32_t)DIR_LEFT : take_up ? (uint32_t)DIR_UP : (uint32_t)DIR_DIAG;
-                        const double cost = (double)dist + best;
-                        const bool on = rowok && (uint32_t)j < (uint32_t)M;
-                        p2 = left;
-                        p1 = on ? cost : left;
-                        bits |= on ? dir << (2 * ee) : 0u;
-                        if (last_lane && on) bot_s[half][j & 63] = cost;
-                    }
-                    if (active) dptr[(e16 >> 4) * BAND] = bits;
-                }
-                wave_lds_sync();
-                if (feed_next) {
-                    double* dst = bnd + (int64_t)(band & 1) * P.mcap;
-                    if (u >= 1) {
-                        const int j = (u - 1) * BAND + n;
-                        if (j < M) __hip_atomic_store(&dst[j], bot_s[half][j & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (u == nrounds - 1) {
-                        const int j = u * BAND + n;
-                        if (j < M) __hip_atomic_store(&dst[j], bot_s[half][j & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                if (active && u + 1 == nrounds && band + 1 == nbands && P.total_cost && n == ((N - 1) & 31))
-                    P.total_cost[pair] = p1;             // lane (N-1) % 32 holds cost(N-1, M-1)
+            PSTAMP(8);
+            if (active && band > 0 && u + 1 < nrounds) {                    // stays inside the padded row (plan_ws)
+                pf_top = __hip_atomic_load(&bin[j0 + BAND + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pf_pair = pair; pf_band = band; pf_u = u + 1;
             }
-            // a finished band's boundary row is re-read by this wavefront: write-through stores that
-            // only have to be complete; the loads bypass the L1
+            const int cur = t % 3, prev = (t + 2) % 3;
+            const float* const acur = &blk[half][cur][0][n] - n * BAND;          // + e * BAND: column e - n of this round's block
+            const float* const aprev = &blk[half][prev][BAND - 1][n] - (n - 1) * BAND;   // + e * BAND: column 32 + e - n of the block before
+            const double* const tops = top_s[half];
+            const bool rowok = active && i0 + n < N;
+            const bool feed = active && band + 1 < nbands && n == BAND - 1;     // the band's last row feeds the next band
+            double* const bout = bnd + (int64_t)(band & 1) * bstride + (j0 - (BAND - 1));
+            const int jb = j0 - n;
+            uint32_t* const dptr = P.dirs + d.dir_off + ((int64_t)(band * 2 * nrounds + 2 * u) * BAND + n);
+            float dq[PF];
+            double tq[PF];
+#pragma unroll
+            for (int e = 0; e < PF; ++e) {
+                dq[e] = (n > e ? aprev : acur)[e * BAND];
+                tq[e] = tops[e];
+            }
+#ifdef ABN_EXP_NOSWEEP
+            for (int e = 0; e < 0; ++e) {
+#else
+#pragma unroll
+            for (int e = 0; e < BAND; ++e) {
+#endif
+                const float dist = dq[e % PF];
+                const double topc = tq[e % PF];
+                if (e + PF < BAND) {
+                    dq[e % PF] = (n > e + PF ? aprev : acur)[(e + PF) * BAND];
+                    tq[e % PF] = tops[e + PF];
+                }
+                double up = dpp_shr1_f64(p1);
+                up = n == 0 ? topc : up;
+                double b1, best;
+                min_lt(up, upprev, b1, bits);            // up < diag
+                min_lt(p1, b1, best, bits);              // left < min(diag, up)
+                const double cost = (double)dist + best;
+                const bool on = rowok && (uint32_t)(jb + e) < (uint32_t)M;
+                upprev = up;
+                p1 = on ? cost : p1;                     // past the row's end the last cost stays put
+                if (feed) __hip_atomic_store(&bout[e], cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((e & 15) == 15 && active) dptr[(e >> 4) * BAND] = bits;
+            }
+            if (active && u + 1 == nrounds && band + 1 == nbands && P.total_cost && n == ((N - 1) & 31))
+                P.total_cost[pair] = p1;                 // lane (N-1) % 32 holds cost(N-1, M-1)
+            // a finished band's boundary row is re-read by this wavefront (workgroup scope: the CU's own L1 /
+            // L2 path, no write-through to memory): the stores only have to be complete
             if (__any(active && u + 1 == nrounds)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_s_waitcnt(0);
             }
+            PSTAMP(9);
+            __syncthreads();
             PSTAMP(10);
-            __syncthreads();                                                // A
-            PSTAMP(11);
-            __syncthreads();                                                // B
-            PSTAMP(12);
         }
+        PSTAMP_FLUSH(8);
     }
 }
 
@@ -701,6 +759,7 @@ extern "C" int abn_debug_dtw_cycles(unsigned long long* out16, int reset)
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(abn::g_dtw_cycles), 128) == hipSuccess ? 0 : -1;
 }
 #endif
+
 
 // Walks the back-pointers of the pairs from (N-1, M-1) to (0, 0).  The k-th cell visited is the
 // k-th from the END of the path, so the path is written right-aligned into its output row --
@@ -755,8 +814,8 @@ __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __res
             const int rr = i & 31, s = j + rr;
             if ((i >> 5) != b || rr < rlo || (s >> 4) < g - 1) break;
             const uint32_t w = win[(g - (s >> 4)) * TB_ROWS + (rr - rlo)][lane];
-            const int dir = (w >> (2 * (s & 15))) & 3;
-            if (dir == DIR_DIAG) { --i; --j; } else if (dir == DIR_UP) --i; else --j;
+            const uint32_t c = w >> (30 - 2 * (s & 15));                  // the first of a dword's sixteen diagonals sits in its top bits
+            if (c & 1u) --j; else if (c & 2u) --i; else { --i; --j; }         // left < min(diag, up); else up < diag; else diag
             ++k;
             o1[-k] = i;
             o2[-k] = j;
@@ -837,9 +896,12 @@ static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P)
             mmax = b > mmax ? b : mmax;
         }
     }
-    w.mcap = align_up(mmax, 32);
-    // persistent grid: one wavefront per workgroup, two pairs in flight per wavefront, up to 9
-    // wavefronts per CU (LDS); fewer when the boundary rows of that many slots would outgrow 256 MiB
+    // a boundary row: the longest token 2 rounded up, 32 doubles of slack in front (the gang kernel's
+    // last lane writes columns -31 .. -1 of a band's first round there) and 32 behind
+    w.mcap = align_up(mmax, 32) + 64;
+    // persistent grid, two pairs in flight per workgroup: up to 9 single-wavefront workgroups per CU
+    // (LDS) in the general kernel, 6 three-wavefront ones in the gang kernel; fewer when the boundary
+    // rows of that many slots would outgrow 256 MiB
     int64_t nwg = (P + 1) / 2;
     if (nwg > 256 * 9) nwg = 256 * 9;
     const int64_t cap = (256LL << 20) / (4 * w.mcap * 8);
@@ -962,8 +1024,11 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
         if (nwg > w.nwg) nwg = w.nwg;
         const bool vec = D % 4 == 0 && aligned16(feats1) && aligned16(feats2);
         const bool pipelined = switches().dtw_f40;     // A/B switch of the 40-d specialisation
-        const bool pc = switches().dtw_pc;              // A/B switch: producer / consumer form
-        if (vec && D == KCH && pc) hipLaunchKernelGGL(dtw_pc_kernel, dim3((unsigned)nwg), dim3(128), 0, st, P);
+        const bool gang = switches().dtw_pc;            // A/B switch: gang form (a producer per slot + one consumer)
+        if (vec && D == KCH && gang) {
+            const int64_t ng = nwg < 256 * switches().dtw_wgs_per_cu ? nwg : 256 * switches().dtw_wgs_per_cu;
+            hipLaunchKernelGGL(dtw_gang_kernel, dim3((unsigned)ng), dim3(64 * (GS + 1)), 0, st, P);
+        }
         else if (vec && D == KCH && pipelined) hipLaunchKernelGGL((dtw_fused_kernel<true, true>), dim3((unsigned)nwg), dim3(64), 0, st, P);
         else if (vec) hipLaunchKernelGGL((dtw_fused_kernel<true, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);
         else hipLaunchKernelGGL((dtw_fused_kernel<false, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);

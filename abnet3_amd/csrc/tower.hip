@@ -51,6 +51,8 @@ static Switches read_switches()
     if (s.wide_max_groups < 1 || s.wide_max_groups > WD_MAXG) s.wide_max_groups = WD_MAXG;
     s.dtw_f40 = !off("ABN_DTW_F40");
     s.dtw_pc = !off("ABN_DTW_PC");
+    s.dtw_wgs_per_cu = getenv("ABN_DTW_WGS") ? atoi(getenv("ABN_DTW_WGS")) : 6;
+    if (s.dtw_wgs_per_cu < 1 || s.dtw_wgs_per_cu > 9) s.dtw_wgs_per_cu = 6;
     return s;
 }
 static Switches g_switches = read_switches();       // (at library load: no call ever reads the environment)

@@ -1,4 +1,4 @@
-"""Phase cycles of the producer / consumer DTW kernel (library built with -DABN_DTW_STAMPS:
+"""Phase cycles of the gang DTW kernel (library built with -DABN_DTW_STAMPS:
 tools/variants.sh dtw "-DABN_DTW_STAMPS"; run with ABNET3_HIP_LIB=tools/variants/lib_ABN_DTW_STAMPS.so)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,10 +16,10 @@ raw.abn_debug_dtw_cycles(buf, 1)
 dtw_align_batch(d1, o1, n1, d2, o2, n2); torch.cuda.synchronize()
 raw.abn_debug_dtw_cycles(buf, 0)
 c = np.array(list(buf), dtype=np.float64)
-names = {0: 'P loop top (after B)', 1: 'P schedule/desc', 2: 'P produce', 3: 'P early ring writes', 4: 'P wait A', 5: 'P late writes + wait B',
-         8: 'C loop top', 9: 'C top load + stage', 10: 'C sweep + flush', 11: 'C wait A', 12: 'C wait B'}
-for grp, ks in (('producer', [0, 1, 2, 3, 4, 5]), ('consumer', [8, 9, 10, 11, 12])):
+names = {0: 'P top: exit check, publish', 1: 'P produce (wait rows, MFMA, distances)', 2: 'P advance + next rows requested', 3: 'P barrier',
+         8: 'C descriptor + boundary window', 9: 'C sweep', 10: 'C barrier'}
+for grp, ks in (('producer (lane 0 of both)', [0, 1, 2, 3]), ('consumer', [8, 9, 10])):
     tot = c[ks].sum()
     print(grp, 'total %.3e cycles' % tot)
     for k in ks:
-        print('   %-28s %5.1f %%' % (names[k], 100 * c[k] / tot))
+        print('   %-40s %5.1f %%' % (names[k], 100 * c[k] / tot))
