@@ -6,39 +6,24 @@
 // whose per-pair Python/Cython loop is the producer-side hot loop of
 // abnet3/dataloader.py:166-261 and :617-671.
 //
-// Three kernels per batch:
-//  1. dist_kernel   64x64 tiles of the angular distance matrix, one 32x32 quadrant
-//                   per wavefront on the float32 matrix cores: the MFMA
-//                   accumulates every cell as one sequential fused chain over k,
-//                   exactly the oracle's fmaf loop (= what sgemm computes behind
-//                   the reference's np.dot), and the rest of the cell -- norms in
-//                   numpy's summation order, one division, glibc's acosf, / pi --
-//                   follows the reference's statements operation by operation
-//                   (dist_ref.h), so the values are bit-identical to the C oracle
-//                   and to the reference's own output (tests/golden/cosdist_libm.npz;
-//                   the file is compiled with -ffp-contract=off).  The
-//                   matrix is written in the layout the DP reads with 16-byte
-//                   coalesced loads:
-//                     S4[g][phys(i)][e] = dist(i, 4g + e - i)
-//                   i.e. one float4 holds row i's cells on the four
-//                   anti-diagonals of group g, and phys(i) = (i % SL)*64 + i/SL
-//                   puts the SL rows a DP lane owns 64 float4s apart.
-//  2. dp_kernel<SL> one wavefront per pair sweeps the anti-diagonals with the two
-//                   previous diagonals of float64 costs in REGISTERS.  Lane l
-//                   owns the SL consecutive rows l*SL .. l*SL+SL-1, so row i-1
-//                   is the same lane's previous register and only the lane's
-//                   first row needs one wave rotation per step.  One float4
-//                   load per row serves four diagonals and is issued a whole
-//                   group (four steps) ahead; the 2-bit back-pointers of four
-//                   diagonals are packed into one byte store.
-//                   cost = D + min(diag, up, left), first minimum in that order
-//                   wins (the oracle's tie-break).
-//  3. the same kernel then walks the back-pointers from (N-1, M-1): the wave
-//                   stages a 64-row x 64-diagonal window of back-pointers in
-//                   LDS, lane 0 walks it at LDS latency (>= 30 steps per
-//                   window), and all lanes finally reverse the path into place.
-// The DP is dependency-bound (N+M-1 sequential steps per pair), not HBM-bound:
-// parallelism comes from running thousands of pairs side by side, longest first.
+// Two kernels per batch, the cost matrix never leaves the CU:
+//  1. dtw_gang_kernel (40-value frames, the hot case) / dtw_fused_kernel<VEC, F40> (any frame width):
+//     a persistent grid walks a work queue of pairs, largest first.  A pair is cut into BANDS of 32
+//     rows of token 1 (one row per lane of a half-wavefront: a SLOT) and a band into ROUNDS of 32
+//     anti-diagonals.  Per round the 32 x 32 block of angular distances of the next 32 columns comes
+//     off the float32 matrix cores -- v_mfma_f32_32x32x2_f32 accumulates every cell as ONE sequential
+//     fused chain over k, exactly the oracle's fmaf loop (= what sgemm computes behind the reference's
+//     np.dot); the rest of the cell (norms in numpy's summation order, one division, glibc's acosf,
+//     / pi) follows the reference's statements operation by operation (dist_ref.h; the file is compiled
+//     with -ffp-contract=off), so the values are bit-identical to the C oracle and to the reference's
+//     own output (tests/golden/cosdist_libm.npz) -- and the slot's 32 lanes sweep 32 anti-diagonals of
+//     float64 costs: cost = d + min(diag, up, left), the first minimum in that order wins (the oracle's
+//     tie-break).  Two bits of back-pointer per cell go to HBM, plus the last row of each band for the
+//     band below.  The gang kernel splits the two jobs over wavefronts (see there).
+//  2. dtw_traceback_kernel: one thread per pair walks the back-pointers from (N-1, M-1) and writes the
+//     path right-aligned into its output row.
+// The sweep is a dependency chain (N + M - 1 sequential steps per band), the distances are throughput
+// code: parallelism comes from thousands of pairs side by side.
 #include <stdlib.h>
 
 #include "common.h"
@@ -77,6 +62,7 @@ struct DtwP {
     int64_t mcap;
     int32_t* bad;                // [pair] set when a distance is NaN / negative (utils.py:59)
     double* total_cost;          // [pair] or NULL
+    float* ynorm;                // gang kernel: [slot][mcap] norms of the pair's token-2 rows, computed by band 0
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -533,26 +519,31 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
         // The 32 rows of token 2 of round (band, u), requested one round AHEAD: raw buffer loads (the
         // compiler leaves them where they are written; plain loads sink to their first use), the
         // descriptor spans the pair's token so offsets fit 32 bits.
+        // Band 0 of a pair takes whole rows (both halves of a lane pair load the same 160 bytes: the norm
+        // needs every value) and leaves the norms in ynorm[]; the bands below it take the norms from
+        // there and load each row 4 h bytes further on, so that a piece's .x / .z are the fragment values
+        // of BOTH halves -- no selects, no sums (the last piece's fourth value falls behind the row: never
+        // used, and behind the token the descriptor returns 0).
         u32x4 yq[10];
+        float ynq = 1.0f;
+        float* const ynorm = P.ynorm + (int64_t)(GS * (int)blockIdx.x + q) * P.mcap;
         auto request_y = [&]() {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.feats2 + yoff), 0, M * (D * 4), 0x00020000);
-            const int vo = min(u * BAND + n, M - 1) * (D * 4);
+            const int row = min(u * BAND + n, M - 1);
+            const int vo = row * (D * 4) + (band > 0 ? 4 * half : 0);
 #pragma unroll
             for (int i = 0; i < 10; ++i) yq[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 16 * i, 0);
+            if (band > 0) ynq = __hip_atomic_load(&ynorm[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         // the block of (band, u) into buffer `buf` from the rows requested before
         auto produce = [&](int buf) {
             f32x16 acc;
             float ny;
             {
-                // row piece by row piece: two fragment values -> two MFMAs, four squares -> numpy's eight
-                // partial sums (sumsq40's order; packed: two squares / two sums per instruction); a piece's
-                // registers are free once it is used
-                f32x2 r01, r23, r45, r67;
-#pragma unroll
-                for (int i = 0; i < 10; ++i) {
-                    const float4 v = make_float4(__uint_as_float(yq[i].x), __uint_as_float(yq[i].y), __uint_as_float(yq[i].z), __uint_as_float(yq[i].w));
-                    const float f0 = half ? v.y : v.x, f1 = half ? v.w : v.z;
+                // row piece by row piece: two fragment values -> two MFMAs; in band 0 also four squares ->
+                // numpy's eight partial sums (sumsq40's order; packed: two squares / two sums per instruction);
+                // a piece's registers are free once it is used
+                auto chain = [&](int i, float f0, float f1) {
 #ifndef ABN_EXP_NOMFMA
                     if (i == 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, xf[0], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, xf[2 * i], acc, 0, 0, 0);       // A = token 2 rows (j), B = token 1 rows (i)
@@ -561,13 +552,27 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                     if (i == 0) for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
                     acc[i] += f0 * xf[2 * i] + f1 * xf[2 * i + 1];
 #endif
-                    const f32x2 sxy = f32x2{v.x, v.y} * f32x2{v.x, v.y}, szw = f32x2{v.z, v.w} * f32x2{v.z, v.w};
-                    if (i == 0) { r01 = sxy; r23 = szw; }
-                    else if (i == 1) { r45 = sxy; r67 = szw; }
-                    else if ((i & 1) == 0) { r01 += sxy; r23 += szw; }
-                    else { r45 += sxy; r67 += szw; }
+                };
+                if (band == 0) {
+                    f32x2 r01, r23, r45, r67;
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        const float4 v = make_float4(__uint_as_float(yq[i].x), __uint_as_float(yq[i].y), __uint_as_float(yq[i].z), __uint_as_float(yq[i].w));
+                        chain(i, half ? v.y : v.x, half ? v.w : v.z);
+                        const f32x2 sxy = f32x2{v.x, v.y} * f32x2{v.x, v.y}, szw = f32x2{v.z, v.w} * f32x2{v.z, v.w};
+                        if (i == 0) { r01 = sxy; r23 = szw; }
+                        else if (i == 1) { r45 = sxy; r67 = szw; }
+                        else if ((i & 1) == 0) { r01 += sxy; r23 += szw; }
+                        else { r45 += sxy; r67 += szw; }
+                    }
+                    ny = sqrtf(((r01.x + r01.y) + (r23.x + r23.y)) + ((r45.x + r45.y) + (r67.x + r67.y)));
+                    if (nbands > 1 && half == 0 && u * BAND + n < M)
+                        __hip_atomic_store(&ynorm[u * BAND + n], ny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) chain(i, __uint_as_float(yq[i].x), __uint_as_float(yq[i].z));
+                    ny = ynq;
                 }
-                ny = sqrtf(((r01.x + r01.y) + (r23.x + r23.y)) + ((r45.x + r45.y) + (r67.x + r67.y)));
             }
             if (half == 0) ny_s[q][n] = ny;
             wave_lds_sync();                                               // ny_s (this wave's own writes)
@@ -768,7 +773,10 @@ extern "C" int abn_debug_dtw_cycles(unsigned long long* out16, int reset)
 // a time -- the 8 rows at and above its position, the current 16-diagonal group and the one
 // before it: two runs of 8 consecutive dwords, 16 independent loads -- into its private strip
 // of LDS and takes 8 to 17 steps from there at LDS latency.
-constexpr int TB_ROWS = 8;
+#ifndef ABN_TB_ROWS
+#define ABN_TB_ROWS 8
+#endif
+constexpr int TB_ROWS = ABN_TB_ROWS;
 __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __restrict__ meta, const int32_t* __restrict__ order,
                                                            int npairs, const uint32_t* __restrict__ dirs,
                                                            const int32_t* __restrict__ bad,
@@ -817,7 +825,7 @@ __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __res
             const uint32_t c = w >> (30 - 2 * (s & 15));                  // the first of a dword's sixteen diagonals sits in its top bits
             if (c & 1u) --j; else if (c & 2u) --i; else { --i; --j; }         // left < min(diag, up); else up < diag; else diag
             ++k;
-            o1[-k] = i;
+            o1[-k] = i;                                                   // (16-byte stores of four cells at a time were tried: 302 against 232 us)
             o2[-k] = j;
         }
     }
@@ -875,7 +883,7 @@ __global__ void arccos_kernel(const float* __restrict__ x, int64_t n, int over_p
 }
 
 struct WsPlan {
-    int64_t meta_off, order_off, bad_off, counter_off, dirs_off, bound_off, total;
+    int64_t meta_off, order_off, bad_off, counter_off, dirs_off, bound_off, ynorm_off, total;
     int64_t mcap;
     int32_t nwg;
 };
@@ -916,6 +924,7 @@ static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P)
     w.counter_off = take(4);
     w.dirs_off = take(dwords * 4);
     w.bound_off = take(2 * nwg * 2 * w.mcap * 8);
+    w.ynorm_off = take(2 * nwg * w.mcap * 4);
     w.total = o;
     return w;
 }
@@ -1020,6 +1029,7 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
         P.mcap = w.mcap;
         P.bad = (int32_t*)(base + w.bad_off);
         P.total_cost = total_cost;
+        P.ynorm = (float*)(base + w.ynorm_off);
         int64_t nwg = (nq + 1) / 2;
         if (nwg > w.nwg) nwg = w.nwg;
         const bool vec = D % 4 == 0 && aligned16(feats1) && aligned16(feats2);
