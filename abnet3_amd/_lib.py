@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ABNET3_HIP_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get('ABNET3_HIP_LIB') or os.path.join(HERE, 'lib', 'libabnet3_hip.so')
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_LAYERS = 16
 
 ACT = {'none': 0, None: 0, 'sigmoid': 1, 'relu': 2, 'tanh': 3}
@@ -36,6 +36,10 @@ SYMBOLS = {
                                       _i64, _vp, _vp]),
     'abn_tower_wpack_floats': (_i64, [_vp]),
     'abn_tower_uses_planes': (C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int]),
+    'abn_tower_path': (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int, _vp, C.c_int, _vp]),
+    'abn_tower_image_offset': (_i64, [_vp, _i64, _i64, C.c_int, C.c_int]),
+    'abn_reload_switches': (None, []),
+    'abn_tower_backward_launch': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp]),
     'abn_tower_backward_loss_ws_bytes': (_i64, [_i64]),
     'abn_tower_backward_loss': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, C.c_int, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     'abn_tower_reduce_step': (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32,
@@ -118,8 +122,6 @@ def load():
                                   '(stale build?)' % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
-    lib.abn_debug_reload_switches.restype = None
-    lib.abn_debug_reload_switches.argtypes = []
     if lib.abn_abi_version() != ABI_VERSION:
         raise HipLibraryError('abnet3_amd: ABI version mismatch (library %d, '
                               'binding %d)' % (lib.abn_abi_version(), ABI_VERSION))
@@ -130,10 +132,39 @@ def load():
 def reload_switches():
     """The library reads its A/B switches (ABN_PLANES, ABN_FUSED_MIN_ROWS, ...) from the environment once,
     when it is loaded; tests and A/B tools that change one inside a process call this afterwards."""
-    load().abn_debug_reload_switches()
+    load().abn_reload_switches()
 
 
 E_UNSUPPORTED = -4
+
+# abn_tower_path's answers (include/abnet3_hip.h)
+PATH_PER_LAYER, PATH_FUSED_F32, PATH_PLANES, PATH_PLANES_INFER, PATH_PLANES_INFER_BN, PATH_BN_LAYERS, PATH_WIDE = range(7)
+PRECISION_NAMES = {0: 'fp32', 1: 'bf16', 2: 'bf16x3', 3: 'f16x2'}
+
+# Which kernels the tower calls of this process took: filled in by model.py from abn_tower_path (a pure
+# query with the call's own arguments) while `trace_paths` is on -- tests, bench.py and the trainer's log
+# read it.  Python-side bookkeeping: the library itself keeps no record of past calls.
+trace_paths = False
+last_path = {'forward': -1, 'backward': -1, 'forward_precision': -1, 'backward_precision': -1}
+
+
+def note_path(desc, x1, x2, rows, n_calls, train, ws, backward):
+    if not trace_paths:
+        return
+    prec = C.c_int32(-1)
+    path = load().abn_tower_path(C.byref(desc), ptr(x1), ptr(x2), rows, n_calls, int(train), ptr(ws), int(backward),
+                                 C.byref(prec))
+    key = 'backward' if backward else 'forward'
+    last_path[key] = path
+    last_path[key + '_precision'] = prec.value
+
+
+def last_forward_path():
+    return last_path['forward']
+
+
+def last_backward_path():
+    return last_path['backward']
 
 
 _ON_ERROR = []        # callables run when a library call fails (loss.py: scratch whose "left zero" ticket may be dirty now)

@@ -29,8 +29,8 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // The library's A/B switches (kernel choice only, never results beyond fp32 summation order), read from
-// the environment ONCE, at the first call that asks.  abn_debug_reload_switches() (not in the header:
-// tests and A/B tools that flip a switch inside one process) reads them again.
+// the environment ONCE, at the first call that asks.  abn_reload_switches() (tests and A/B tools that flip
+// a switch inside one process) reads them again.
 struct Switches {
     bool planes;              // ABN_PLANES=0: never the operand-plane kernels
     bool fused;               // ABN_FUSED=0: per-layer kernels only

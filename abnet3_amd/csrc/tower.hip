@@ -1184,7 +1184,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     return ABN_OK;
 }
 
-// part: PLANES_BWD_ALL for the product entries; the measurement entry abn_debug_tower_backward_part
+// part: PLANES_BWD_ALL for the product entries; the measurement entry abn_tower_backward_launch
 // issues one of the two launches (the other's output being in place from an earlier complete call).
 enum { PLANES_BWD_ALL = 0, PLANES_BWD_DGRAD = 1, PLANES_BWD_WGRAD = 2 };
 static int planes_backward(const abn_tower_desc* t, const float* d_out, const LossArgs* loss, int64_t rows, const Layout& L,
@@ -1363,11 +1363,10 @@ int64_t abn_tower_out_offset(const abn_tower_desc* t, int64_t rows, int64_t n_ca
     return make_layout(t, rows, n_calls).a[t->n_layers - 1];
 }
 
-// Diagnostics / tests only (not in the header): float offset of one of the operand-fragment images
-// -- which = 0 packed W_l, 1 packed W_l^T, 2 transposed planes [input of layer l | 1] (all in the
-// forward workspace), 3 transposed planes of dZ_l (in the backward scratch), 4 a BatchNorm layer's z_l, 5 the
-// row-major output of layer l -- or -1.
-int64_t abn_debug_planes_offset(const abn_tower_desc* t, int64_t rows, int64_t n_calls, int which, int l)
+// Float offset of one of the operand-fragment images -- which = 0 packed W_l, 1 packed W_l^T, 2 transposed
+// planes [input of layer l | 1] (all in the forward workspace), 3 transposed planes of dZ_l (in the backward
+// scratch), 4 a BatchNorm layer's z_l, 5 the row-major output of layer l -- or -1 (see the header).
+int64_t abn_tower_image_offset(const abn_tower_desc* t, int64_t rows, int64_t n_calls, int which, int l)
 {
     if (check_desc(t, rows, n_calls) != ABN_OK || l < 0 || l >= t->n_layers) return -1;
     if (which == 3) return make_bwd_layout(t, rows).dzp[l];
@@ -1381,15 +1380,57 @@ int64_t abn_debug_planes_offset(const abn_tower_desc* t, int64_t rows, int64_t n
     return (t->wpack ? 0 : L.wpack) + (which == 0 ? P.wp[l] : P.wpt[l]) / 4;
 }
 
-// Diagnostics / tests only (not in the header): which kernels the last abn_tower_forward
-// launched (process-wide: autograd runs backwards on its own thread) -- 0 per-layer, 1 the fp32 fused tower, 2 / 3 / 4 the operand-plane tower: for a backward,
-// inference, inference with BatchNorm; 5 BatchNorm's one launch per layer; 6 the layer-per-launch kernels of tower_wide.h.
-static std::atomic<int> last_forward_path{-1};
-int abn_debug_last_forward_path(void) { return last_forward_path; }
-// ... and its last abn_tower_backward: 0 per-layer, 2 the operand-plane chain + weight-gradient launches, 5 BatchNorm's
-// one launch per layer
-static std::atomic<int> last_backward_path{-1};
-int abn_debug_last_backward_path(void) { return last_backward_path; }
+// Which kernels a call takes is a pure function of the descriptor, the row count, the pointers' alignment
+// and the environment switches: the dispatchers below branch on these, and abn_tower_path reports them
+// (ABN_PATH_* in the header).  No state is kept about past calls.
+static bool fused_f32_ok(const abn_tower_desc* t, const float* x1, const float* x2, int64_t rows, int train, const float* ws)
+{
+    // Whole tower in one launch when it fits the fused kernel's LDS image (tower_fused.h): no BatchNorm
+    // (its statistics span all rows), widths <= 512 and multiples of 4, 16-byte aligned tensors.
+    // ABN_FUSED=0 forces the per-layer path (A/B measurements).  A fused workgroup walks its 32 rows
+    // through every layer in ~110 us whatever the batch: it only pays once there are workgroups for most
+    // CUs.  Below that the per-layer GEMMs (tiles over rows AND columns) are faster (measured: 4096 rows
+    // 91 vs 116 us, 1024 rows 64 vs 107 us; 8192 rows 145 vs 131 us).
+    const int64_t fused_min_rows = switches().fused_min_rows >= 0 ? switches().fused_min_rows : 6144;
+    bool fusable = switches().fused && rows >= fused_min_rows && !t->batch_norm && aligned16(x1) && (!x2 || aligned16(x2)) &&
+                   aligned16(ws);
+    for (int l = 0; l <= t->n_layers && fusable; ++l)
+        fusable = t->dims[l] >= 4 && t->dims[l] <= FUSED_MAXW && t->dims[l] % 4 == 0;
+    for (int l = 0; l < t->n_layers && fusable; ++l)
+        fusable = aligned16(t->W[l]) && (!t->drop_mask[l] || !train || aligned16(t->drop_mask[l]));
+    return fusable;
+}
+static int forward_path(const abn_tower_desc* t, const float* x1, const float* x2, int64_t rows, int64_t n_calls, int train,
+                        const float* ws)
+{
+    const bool bn_train = train && bn_train_planes_path(t, rows, n_calls, x1, x2, ws);
+    const int kind = planes_kind(t, rows, n_calls, x1, x2, ws, train ? PLANES_TRAIN : PLANES_EVAL_FORWARD);
+    if (!bn_train && kind == PLANES_WIDE) return ABN_PATH_WIDE;
+    if (bn_train) return ABN_PATH_BN_LAYERS;
+    if (kind != PLANES_NONE) {
+        if (t->batch_norm) return ABN_PATH_PLANES_INFER_BN;
+        return (t->forward_only && !(train && t->drop_seed) && !train) ? ABN_PATH_PLANES_INFER : ABN_PATH_PLANES;
+    }
+    return fused_f32_ok(t, x1, x2, rows, train, ws) ? ABN_PATH_FUSED_F32 : ABN_PATH_PER_LAYER;
+}
+static int backward_path(const abn_tower_desc* t, const float* x1, const float* x2, int64_t rows, int64_t n_calls, const float* ws)
+{
+    const int kind = planes_kind(t, rows, n_calls, x1, x2, ws);
+    if (kind == PLANES_WIDE) return ABN_PATH_WIDE;
+    if (kind == PLANES_CHAIN) return ABN_PATH_PLANES;
+    if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) return ABN_PATH_BN_LAYERS;
+    return ABN_PATH_PER_LAYER;
+}
+
+int abn_tower_path(const abn_tower_desc* t, const float* x1, const float* x2, int64_t rows, int64_t n_calls, int train,
+                   const float* ws, int backward, int32_t* precision_out)
+{
+    if (check_desc(t, rows, n_calls) != ABN_OK) return -1;
+    const int path = backward ? backward_path(t, x1, x2, rows, n_calls, ws) : forward_path(t, x1, x2, rows, n_calls, train, ws);
+    // fp16 x 2 exists on the operand planes only: the GEMM kernels run such a tower in bf16 x 3
+    if (precision_out) *precision_out = (path == ABN_PATH_PER_LAYER || path == ABN_PATH_FUSED_F32) ? gemm_prec(t->precision) : t->precision;
+    return path;
+}
 
 int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2, const float* ws, int train)
 {
@@ -1423,22 +1464,8 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
     const Layout L = make_layout(t, rows, n_calls);
     const int64_t rpc = rows / n_calls;
 
-    // Whole tower in one launch when it fits the fused kernel's LDS image
-    // (tower_fused.h): no BatchNorm (its statistics span all rows), widths <= 512
-    // and multiples of 4, 16-byte aligned tensors.  ABN_FUSED=0 forces the
-    // per-layer path (A/B measurements).
-    const bool fused_enabled = switches().fused;
-    // A fused workgroup walks its 32 rows through every layer in ~110 us whatever the
-    // batch: it only pays once there are workgroups for most CUs.  Below that the
-    // per-layer GEMMs (tiles over rows AND columns) are faster (measured: 4096 rows 91 vs
-    // 116 us, 1024 rows 64 vs 107 us; 8192 rows 145 vs 131 us).
-    const int64_t fused_min_rows = switches().fused_min_rows >= 0 ? switches().fused_min_rows : 6144;
-    bool fusable = fused_enabled && rows >= fused_min_rows && !t->batch_norm && aligned16(x1) && (!x2 || aligned16(x2)) &&
-                   aligned16(ws);
-    for (int l = 0; l <= t->n_layers && fusable; ++l)
-        fusable = t->dims[l] >= 4 && t->dims[l] <= FUSED_MAXW && t->dims[l] % 4 == 0;
-    for (int l = 0; l < t->n_layers && fusable; ++l)
-        fusable = aligned16(t->W[l]) && (!t->drop_mask[l] || !train || aligned16(t->drop_mask[l]));
+    const int path = forward_path(t, x1, x2, rows, n_calls, train, ws);
+    const bool fusable = path == ABN_PATH_FUSED_F32;
     const int pmode = train ? PLANES_TRAIN : PLANES_EVAL_FORWARD;
     const bool bn_train = train && bn_train_planes_path(t, rows, n_calls, x1, x2, ws);
     if (train && t->batch_norm && t->bn_sync_world > 1 && !bn_train) {
@@ -1546,7 +1573,6 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 PL_LAUNCH(np, wide_fwd_layer_kernel, wgrid, dim3(PL_NT), wd_lds_bytes(np), st, q);
             }
             ABN_CHECK_LAUNCH("tower_forward (layer per launch)");
-            last_forward_path = 6;
             return ABN_OK;
         }
         if (bn_train) {
@@ -1591,7 +1617,6 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                                ws + L.invstd[nl - 1], t->bn_rm[nl - 1], t->bn_rv[nl - 1], 1, t->bn_w[nl - 1], t->bn_b[nl - 1],
                                t->last_act, static_cast<float*>(nullptr), ws + L.a[nl - 1]);
             ABN_CHECK_LAUNCH("tower_forward (BatchNorm, planes)");
-            last_forward_path = 5;
             return ABN_OK;
         }
         // inference (no mask, no seed, nothing kept for a backward) has its own, lighter instantiations
@@ -1615,7 +1640,6 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         }
         void* kargs[] = {&f};
         (void)hipLaunchKernel(kernels[np - 1][mode], fgrid, dim3(PL_NT), kargs, lds, st);
-        last_forward_path = 2 + mode;
         ABN_CHECK_LAUNCH("tower_fwd_planes");
         return ABN_OK;
     }
@@ -1655,7 +1679,6 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         else if (f.bf16 == 2) hipLaunchKernelGGL(tower_fwd_fused_kernel<2>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
         else hipLaunchKernelGGL(tower_fwd_fused_kernel<0>, fgrid, dim3(FUSED_NT), FUSED_LDS_BYTES, st, f);
         ABN_CHECK_LAUNCH("tower_fwd_fused");
-        last_forward_path = 1;
         return ABN_OK;
     }
 
@@ -1708,7 +1731,6 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         }
         in = a;
     }
-    last_forward_path = 0;
     return ABN_OK;
 }
 
@@ -1740,19 +1762,18 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     // gradient chain (one workgroup per 32 rows, all layers), then every layer's weight gradient.
     {
         const int kind = planes_kind(t, rows, n_calls, x1, x2, ws);
-        if (kind == PLANES_WIDE) { last_backward_path = 6; return wide_backward(t, d_out, nullptr, rows, n_calls, L, B, ws, scratch, dx, st); }
-        if (kind == PLANES_CHAIN) { last_backward_path = 2; return planes_backward(t, d_out, nullptr, rows, L, B, ws, scratch, dx, st); }
+        if (kind == PLANES_WIDE) { return wide_backward(t, d_out, nullptr, rows, n_calls, L, B, ws, scratch, dx, st); }
+        if (kind == PLANES_CHAIN) { return planes_backward(t, d_out, nullptr, rows, L, B, ws, scratch, dx, st); }
     }
     if (t->wgrad_part != 0) {
         set_error("tower_backward: wgrad_part needs the operand-plane launches of a tower without BatchNorm");
         return ABN_E_UNSUPPORTED;
     }
-    if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) { last_backward_path = 5; return bn_planes_backward(t, d_out, rows, n_calls, L, B, ws, scratch, dx, st); }
+    if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) { return bn_planes_backward(t, d_out, rows, n_calls, L, B, ws, scratch, dx, st); }
     if (t->batch_norm && t->bn_sync_world > 1) {
         set_error("tower_backward: cross-replica BatchNorm statistics (bn_sync_world) need the operand-plane launches");
         return ABN_E_UNSUPPORTED;
     }
-    last_backward_path = 0;
 
     int cur = 0;
     const float* dz_in = nullptr;                // the output layer's dz when the caller supplied it
@@ -1847,26 +1868,26 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     return ABN_OK;
 }
 
-// Measurement only (not in the header; bench.py's per-launch timings): ONE of the two launches of the operand-plane
-// backward -- part 1 the data-gradient chain, 2 the weight gradients -- after a complete backward with the same
-// arguments has left the other launch's output in place.  Never reduces the slabs.
-int abn_debug_tower_backward_part(const abn_tower_desc* t, const float* x1, const float* x2, const float* d_out,
+// ONE of the two launches of the operand-plane backward -- part 1 the data-gradient chain, 2 the weight gradients --
+// after a complete backward with the same arguments has left the other launch's output in place.  Never reduces
+// the slabs (bench.py's per-launch timings; see the header).
+int abn_tower_backward_launch(const abn_tower_desc* t, const float* x1, const float* x2, const float* d_out,
                                   int64_t rows, int64_t n_calls, const float* ws, float* scratch,
                                   int64_t scratch_floats, int part, void* stream)
 {
     int rc = check_desc(t, rows, n_calls);
     if (rc != ABN_OK) return rc;
-    ABN_REQUIRE(x1 && d_out && ws && scratch && (part == PLANES_BWD_DGRAD || part == PLANES_BWD_WGRAD), "tower_backward_part: bad argument");
-    if (rows == 0 || planes_kind(t, rows, n_calls, x1, x2, ws) != PLANES_CHAIN) { set_error("tower_backward_part: single-launch operand-plane towers only"); return ABN_E_UNSUPPORTED; }
+    ABN_REQUIRE(x1 && d_out && ws && scratch && (part == PLANES_BWD_DGRAD || part == PLANES_BWD_WGRAD), "tower_backward_launch: bad argument");
+    if (rows == 0 || planes_kind(t, rows, n_calls, x1, x2, ws) != PLANES_CHAIN) { set_error("tower_backward_launch: single-launch operand-plane towers only"); return ABN_E_UNSUPPORTED; }
     const Layout L = make_layout(t, rows, n_calls);
     const BwdLayout B = make_bwd_layout(t, rows);
-    if (scratch_floats < B.total) { set_error("tower_backward_part: scratch too small"); return ABN_E_WORKSPACE; }
+    if (scratch_floats < B.total) { set_error("tower_backward_launch: scratch too small"); return ABN_E_WORKSPACE; }
     abn_tower_desc u = *t;
     u.defer_reduce = 1;
     return planes_backward(&u, d_out, nullptr, rows, L, B, ws, scratch, nullptr, (hipStream_t)stream, part);
 }
 
-void abn_debug_reload_switches(void) { abn::reload_switches(); }
+void abn_reload_switches(void) { abn::reload_switches(); }
 
 int64_t abn_tower_backward_loss_ws_bytes(int64_t rows) { return 8 + ((rows + PL_ROWS - 1) / PL_ROWS) * (int64_t)sizeof(double); }
 

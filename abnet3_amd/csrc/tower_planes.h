@@ -1,8 +1,12 @@
-// tower_planes.h -- the tower forward AND backward on bf16 MFMA operands that are split ONCE
-// (bf16 x 3, or plain bf16), widths <= 512.  Precision 1 and 2 only.  Without BatchNorm: one launch for the
-// forward, one for the data-gradient chain, one for every layer's weight gradient.  With BatchNorm: inference
-// in the same single launch (running statistics in the epilogue); training one launch per layer each way
-// (bn_fwd_layer_kernel, bn_bwd_layer_kernel), the same weight-gradient launch.
+// tower_planes.h -- the tower forward AND backward on 16-bit MFMA operands that are split ONCE, widths <= 512:
+// the template parameter NP is the number of operand planes -- 2: fp16 x 2 (abn_tower_desc.precision 3, the
+// default: each fp32 operand times a power of two, split into hi + lo fp16, three v_mfma_f32_32x32x16_f16 per
+// operand pair, the scales taken out again in the epilogues), 3: bf16 x 3 (precision 2: hi + mid + lo, six
+// v_mfma_f32_32x32x16_bf16), 1: plain bf16 (precision 1).  Without BatchNorm: one launch for the forward, one for
+// the data-gradient chain, one for every layer's weight gradient.  With BatchNorm: inference in the same single
+// launch (running statistics in the epilogue); training one launch per layer each way (bn_fwd_layer_kernel,
+// bn_bwd_layer_kernel), the same weight-gradient launch.  tower_wide.h holds the layer-per-launch kernels for
+// small batches on the same operand images.
 //
 // What the stamps and the knock-out builds said about tower_fused.h / gemm_f32.h:
 // the forward's floor was the per-wave weight stream (LDS-DMA of 64-byte row pieces: 80 us with

@@ -306,6 +306,7 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
     _lib.check(lib.abn_tower_forward(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2),
                                      rows, n_calls, int(train), _lib.ptr(ws),
                                      _lib.stream()), 'abn_tower_forward')
+    _lib.note_path(desc, x1, x2, rows, n_calls, train, ws, backward=False)
     if desc.wpack and not desc.wpack_valid and seg._key_at_descriptor is not None:
         # the operand-plane kernels rebuilt the persistent weight image (the per-layer path never touches it)
         if lib.abn_tower_uses_planes(_lib.C.byref(desc), rows, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(ws), int(train)) == 1:
@@ -346,6 +347,7 @@ def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False, def
         _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(d_out), rows,
         sv.n_calls, _lib.ptr(sv.ws), _lib.ptr(scratch), scratch_floats,
         _lib.ptr(dx), _lib.stream()), 'abn_tower_backward')
+    _lib.note_path(desc, sv.x1, sv.x2, rows, sv.n_calls, True, sv.ws, backward=True)
     if defer_reduce:
         return grads, dx, (desc, rows, scratch, scratch_floats, grad_buf, seg)
     return grads, dx
@@ -828,6 +830,7 @@ class SiameseNetwork(_HipNetwork):
             grad_pass.used.discard(id(seg))
             return None
         _lib.check(rc, 'abn_tower_backward_loss')
+        _lib.note_path(desc, sv.x1, sv.x2, rows, sv.n_calls, True, sv.ws, backward=True)
         self._pending_reduce = (desc, rows, scratch, scratch_floats, grad_buf, seg) if defer_reduce else None
         self._pending_lower = (desc, rows, scratch, scratch_floats, sv) if wgrad_split is not None else None
         for p, g in zip(seg.params, grads):

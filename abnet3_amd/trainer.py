@@ -176,88 +176,89 @@ class TrainerBuilder:
         self.sync_batch_norm = bool(sync_batch_norm)
 
     def params(self):
-        params = copy.copy(self.__dict__)
-        del params['dataloader']
-        del params['feature_generator']
+        """None.  The reference's params() copies the trainer's attributes into a dictionary and then
+        drops it (no return statement, abnet3/trainer.py:89-92): every .params file it ever wrote holds
+        'params': None, and so do ours."""
+        return None
 
     def whoami(self):
-        whoami = {
-            'params': self.params(),
-            'network': self.network.whoami(),
-            'loss': self.loss.whoami(),
-            'class_name': self.__class__.__name__,
-            'dataloader': self.dataloader.whoami()
-        }
+        """What save_whoami() pickles: the class name and the whoami() of every part
+        (abnet3/trainer.py:94-104)."""
+        parts = {'network': self.network, 'loss': self.loss, 'dataloader': self.dataloader}
         if self.feature_generator is not None:
-            whoami['feature_generator'] = self.feature_generator.whoami()
-        return whoami
+            parts['feature_generator'] = self.feature_generator
+        description = {name: part.whoami() for name, part in parts.items()}
+        description['params'] = self.params()
+        description['class_name'] = type(self).__name__
+        return description
 
     def save_whoami(self):
-        """Pickles whoami() next to the network, as the reference does
+        """<output_path>.params beside the network, as the reference leaves it
         (abnet3/trainer.py:106-108); the networks' whoami() leaves their HIP
         plumbing out, everything else is the reference's dictionary."""
-        with open(self.network.output_path + '.params', "wb") as fh:
+        with open(self.network.output_path + '.params', 'wb') as fh:
             pickle.dump(self.whoami(), fh)
 
     def optimize_model(self, do_training=True):
         raise NotImplementedError('Unimplemented optimize_model for class:',
                                   self.__class__.__name__)
 
+    def _keep_best(self, epoch):
+        """Rank 0 writes the new best network (and a numbered checkpoint when asked), then its description."""
+        if self.rank != 0:
+            return
+        print('Saving best model so far, epoch {}... '.format(epoch + 1), end='', flush=True)
+        if self.checkpoints:
+            self.network.save_network(epoch=epoch + 1)
+        self.network.save_network()
+        self.save_whoami()
+        print('Done.')
+
     def train(self):
-        """Train method to train the model (abnet3/trainer.py:117-173)."""
-        self.patience_dev = 0
-        self.best_dev = None
-
-        self.train_losses = []
-        self.dev_losses = []
-        self.num_batches_train = 0
-        self.num_batches_dev = 0
+        """The reference's training schedule (abnet3/trainer.py:117-173), seen from outside:
+        * the untrained network is saved and evaluated once (pass 0: optimize_model(False), in eval mode);
+        * then up to num_epochs passes of optimize_model(True); after each, the train and dev losses go to
+          two tensorboard curves (<log_dir>/train_loss, <log_dir>/dev_loss, step = epoch, pass 0 at step 0);
+        * a pass whose dev loss beats the best so far saves the network (+ .params, + a numbered checkpoint
+          with `checkpoints`) and resets the patience counter; any other pass counts against `patience`, and
+          the (patience + 1)-th such pass in a row ends the run.
+        Leaves best_dev / best_epoch / patience_dev / train_losses / dev_losses behind, as the reference does.
+        Under torch.distributed every rank runs the same schedule (the losses are all-reduced in
+        optimize_model); only rank 0 writes files and prints."""
         master = self.rank == 0
+        self.patience_dev, self.best_dev = 0, None
+        self.train_losses, self.dev_losses = [], []
+        self.num_batches_train = self.num_batches_dev = 0
+        curves = {'train': SummaryWriter(log_dir=str(self.log_dir / 'train_loss')),
+                  'dev': SummaryWriter(log_dir=str(self.log_dir / 'dev_loss'))}
 
+        def plot(step):
+            curves['train'].add_scalar('loss', self.train_losses[-1], step)
+            curves['dev'].add_scalar('loss', self.dev_losses[-1], step)
+
+        # pass 0
         self.network.eval()
         if master:
             self.network.save_network()
-
-        train_writer = SummaryWriter(log_dir=str(self.log_dir / 'train_loss'))
-        dev_writer = SummaryWriter(log_dir=str(self.log_dir / 'dev_loss'))
-
-        _ = self.optimize_model(do_training=False)
-        train_writer.add_scalar('loss', self.train_losses[-1], 0)
-        dev_writer.add_scalar('loss', self.dev_losses[-1], 0)
-
+        self.optimize_model(do_training=False)
+        plot(0)
         if self.checkpoints and master:
             self.network.save_network(epoch=0)
-
-        for key in self.statistics_training.keys():
-            self.statistics_training[key] = 0
+        self.statistics_training = dict.fromkeys(self.statistics_training, 0)
 
         for epoch in range(self.num_epochs):
             dev_loss = self.optimize_model(do_training=True)
-
-            train_writer.add_scalar('loss', self.train_losses[-1], epoch + 1)
-            dev_writer.add_scalar('loss', self.dev_losses[-1], epoch + 1)
-
+            plot(epoch + 1)
             if self.best_dev is None or dev_loss < self.best_dev:
-                self.best_dev = dev_loss
-                self.patience_dev = 0
+                self.best_dev, self.best_epoch, self.patience_dev = dev_loss, epoch, 0
+                self._keep_best(epoch)
+                continue
+            self.patience_dev += 1
+            if self.patience_dev > self.patience:
                 if master:
-                    print('Saving best model so far, ' +
-                          'epoch {}... '.format(epoch + 1), end='', flush=True)
-                    if self.checkpoints:
-                        self.network.save_network(epoch=epoch + 1)
-                    self.network.save_network()
-                    self.save_whoami()
-                    print("Done.")
-                self.best_epoch = epoch
-            else:
-                self.patience_dev += 1
-                if self.patience_dev > self.patience:
-                    if master:
-                        print("No improvements after {} iterations, "
-                              "stopping now".format(self.patience))
-                        print('Finished Training')
-                    break
-
+                    print('No improvements after {} iterations, stopping now'.format(self.patience))
+                    print('Finished Training')
+                break
         if master:
             print('Saving best checkpoint network')
 

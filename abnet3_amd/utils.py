@@ -16,37 +16,46 @@ import torch
 from . import _lib
 
 
+PAIR_TYPES = ('same', 'diff')
+
+
 def print_token(tok):
-    """Pretty print token for batches (abnet3/utils.py:101-105)."""
-    return "{0} {1:.2f} {2:.2f}".format(tok[0], tok[1], tok[2])
+    """One token of a pairs-file line: "<file> <onset> <offset>", times with two decimals
+    (the format abnet3/utils.py:101-105 prints and abnet3/sampler.py writes)."""
+    name, onset, offset = tok[0], tok[1], tok[2]
+    return '%s %.2f %.2f' % (name, onset, offset)
 
 
 def read_spkid_file(spkid_file):
-    """{file id: speaker id} from lines "<fid> <spkid>" (abnet3/utils.py:23-31)."""
-    with open(spkid_file, 'r') as fh:
-        lines = fh.readlines()
-    spk = {}
-    for line in lines:
-        fid, spkid = line.strip().split(" ")
-        assert not (fid in spk)
-        spk[fid] = spkid
-    return spk
+    """{file id: speaker id} from a file of "<fid> <spkid>" lines; a file id may appear once
+    (abnet3/utils.py:23-31)."""
+    speaker_of = {}
+    with open(spkid_file) as fh:
+        for line in fh:
+            fid, spkid = line.strip().split(' ')
+            if fid in speaker_of:
+                raise AssertionError('%s: %s listed twice' % (spkid_file, fid))
+            speaker_of[fid] = spkid
+    return speaker_of
+
+
+def _parse_pair_line(line):
+    """"f1 s1 e1 f2 s2 e2 type" -> (f1, s1, e1, f2, s2, e2, type): seven space-separated fields,
+    the four times as floats, the type one of PAIR_TYPES (AssertionError otherwise, as in the
+    reference's reader, abnet3/utils.py:156-173)."""
+    fields = line.strip().split(' ')
+    if len(fields) != 7:
+        raise AssertionError('a pairs line has 7 fields, got %d: %r' % (len(fields), line))
+    kind = fields[6]
+    if kind not in PAIR_TYPES:
+        raise AssertionError('Unsupported pair type {0}'.format(kind))
+    return (fields[0], float(fields[1]), float(fields[2]), fields[3], float(fields[4]), float(fields[5]), kind)
 
 
 def read_dataset(dataset_file):
-    """[(file1, start1, end1, f2, s2, e2, pair_type), ...] (utils.py:156-173)."""
-    with open(dataset_file, 'r') as fh:
-        lines = fh.readlines()
-    pairs = []
-    for line in lines:
-        tokens = line.strip().split(" ")
-        assert len(tokens) == 7
-        f1, s1, e1, f2, s2, e2, pair_type = tokens
-        s1, e1, s2, e2 = float(s1), float(e1), float(s2), float(e2)
-        assert pair_type in ['same', 'diff'], \
-            'Unsupported pair type {0}'.format(pair_type)
-        pairs.append((f1, s1, e1, f2, s2, e2, pair_type))
-    return pairs
+    """The word pairs of a pairs file, one 7-tuple per line, in file order."""
+    with open(dataset_file) as fh:
+        return [_parse_pair_line(line) for line in fh]
 
 
 def write_dataset(dataset_file, pairs):
@@ -59,13 +68,15 @@ def write_dataset(dataset_file, pairs):
 
 
 def group_pairs(pairs):
-    """{'same': [...], 'diff': [...]} (abnet3/utils.py:176-192)."""
-    grouped_pairs = {'same': [], 'diff': []}
-    for f1, s1, e1, f2, s2, e2, pair_type in pairs:
-        assert pair_type in grouped_pairs, \
-            'Unsupported pair type {0}'.format(pair_type)
-        grouped_pairs[pair_type].append((f1, s1, e1, f2, s2, e2))
-    return grouped_pairs
+    """Splits 7-tuples by their type into {'same': [6-tuples], 'diff': [6-tuples]}, order kept
+    (abnet3/utils.py:176-192)."""
+    by_type = {kind: [] for kind in PAIR_TYPES}
+    for pair in pairs:
+        kind = pair[6]
+        if kind not in by_type:
+            raise AssertionError('Unsupported pair type {0}'.format(kind))
+        by_type[kind].append(tuple(pair[:6]))
+    return by_type
 
 
 def read_pairs(pair_file):
@@ -73,39 +84,39 @@ def read_pairs(pair_file):
 
 
 def cast_features(features, target_type=np.float32):
-    for item in features:
-        features[item] = features[item].astype(target_type)
+    """Every array of the dictionary converted in place (abnet3/utils.py:228-235)."""
+    for key, array in list(features.items()):
+        features[key] = array.astype(target_type)
     return features
 
 
 class Features_Accessor(object):
-    """Time-window -> frame slice with BOTH ends inclusive (utils.py:118-145)."""
+    """Frames of a file by time window or by frame range (abnet3/utils.py:118-145).  A time window
+    keeps every frame whose time stamp lies in [start, end], BOTH ends included; keys may be bytes
+    (h5features) or str.  The features are float32 from here on."""
 
     def __init__(self, times, features):
         self.times = times
-        if features[list(features.keys())[0]].dtype == np.float32:
-            self.features = features
-        else:
-            self.features = cast_features(features)
+        first = next(iter(features.values()))
+        self.features = features if first.dtype == np.float32 else cast_features(features)
 
     @staticmethod
     def get_indices_between(time, start, end):
-        return np.where(np.logical_and(time >= start, time <= end))[0]
+        inside = (time >= start) & (time <= end)
+        return np.flatnonzero(inside)
 
     @staticmethod
     def get_features_between(feature, time, start, end):
         return feature[Features_Accessor.get_indices_between(time, start, end), :]
 
     def _name(self, f):
-        filename = f.encode('UTF-8')
-        if filename not in self.times:
-            filename = f
-        return filename
+        """h5features hands out bytes keys: try the encoded name first."""
+        as_bytes = f.encode('UTF-8')
+        return as_bytes if as_bytes in self.times else f
 
     def get(self, f, on, off):
-        filename = self._name(f)
-        return self.get_features_between(self.features[filename],
-                                         self.times[filename], on, off)
+        key = self._name(f)
+        return self.get_features_between(self.features[key], self.times[key], on, off)
 
     def get_between_frames(self, f, frame_on, frame_off):
         return self.features[self._name(f)][frame_on:frame_off]

@@ -127,7 +127,7 @@ def planes_roofline(torch, net, reps=20):
     layer's dW = dZ^T [A | 1] over the 2 x 4096 rows, split over the rows into slabs, one launch (its tiles
     placed so that an XCD's L2 serves the re-reads).  Each of the three is timed live, alone: `reps`
     launches captured into one hipGraph and bracketed by HIP events on the launch stream (the backward
-    kernels through abn_debug_tower_backward_part, a measurement entry outside the header that issues one of
+    kernels through abn_tower_backward_launch, a measurement entry outside the header that issues one of
     the backward's two launches; the forward with its packed weight image still valid, i.e. without the ~5 us
     pack_planes_kernel a step's forward starts with); `forward_backward_sequence_us` is the three in the
     step's order.  Algorithmic FLOPs: weight gradients 2 * 8192 * sum_l N_l (K_l + 1), the chains
@@ -160,7 +160,7 @@ def planes_roofline(torch, net, reps=20):
     times = {}
     from abnet3_amd import _lib
     lib = _lib.load()
-    part_fn = lib.abn_debug_tower_backward_part       # measurement entry (not in the header): one of the two launches
+    part_fn = lib.abn_tower_backward_launch       # measurement entry (not in the header): one of the two launches
     part_fn.restype = _lib.C.c_int
     seg, sv, gp = state
     gbuf, _ = gp.views(seg)
@@ -172,7 +172,7 @@ def planes_roofline(torch, net, reps=20):
     def part(which):
         _lib.check(part_fn(_lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(d_out), _lib.C.c_int64(rows),
                            _lib.C.c_int64(2), _lib.ptr(sv.ws), _lib.ptr(scratch), _lib.C.c_int64(sc_n), which, _lib.stream()),
-                   'abn_debug_tower_backward_part')
+                   'abn_tower_backward_launch')
     times['dgrad'] = _time_launches(torch, lambda: part(1), reps)
     times['wgrad'] = _time_launches(torch, lambda: part(2), reps)
     times['both'] = _time_launches(torch, bwd, reps)

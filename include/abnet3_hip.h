@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 15
+#define ABN_ABI_VERSION 16
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -175,6 +175,41 @@ int64_t abn_tower_wpack_floats(const abn_tower_desc* t);
 int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1, const float* x2,
                           const float* ws, int train);
 
+/* Which kernel family a call takes, and the arithmetic its GEMMs compute in -- a PURE function of
+ * the arguments and the environment switches (the library keeps no record of past calls):
+ * backward = 0 asks about abn_tower_forward(t, x1, x2, rows, n_calls, train, ws), backward = 1 about
+ * the abn_tower_backward / abn_tower_backward_loss after it.  Returns one of ABN_PATH_* (< 0: bad
+ * descriptor); *precision_out (may be NULL) receives the abn_tower_desc.precision code actually
+ * used: a 'f16x2' tower that falls to the GEMM kernels (widths > 512 or not multiples of 4,
+ * BatchNorm on < 256 rows, ABN_PLANES=0) computes in bf16x3 there, and this is where a caller
+ * learns it. */
+enum {
+    ABN_PATH_PER_LAYER = 0,        /* one GEMM launch per layer (gemm_f32.h) */
+    ABN_PATH_FUSED_F32 = 1,        /* the fp32 tower in one launch (tower_fused.h) */
+    ABN_PATH_PLANES = 2,           /* operand-plane chain, everything a backward needs is kept */
+    ABN_PATH_PLANES_INFER = 3,     /* operand-plane chain, inference (forward_only) */
+    ABN_PATH_PLANES_INFER_BN = 4,  /* ... with BatchNorm's running statistics in the epilogue */
+    ABN_PATH_BN_LAYERS = 5,        /* BatchNorm training: one operand-plane launch per layer */
+    ABN_PATH_WIDE = 6              /* small batches: one launch per layer over up to 8 workgroups per row block */
+};
+int abn_tower_path(const abn_tower_desc* t, const float* x1, const float* x2, int64_t rows,
+                   int64_t n_calls, int train, const float* ws, int backward,
+                   int32_t* precision_out);
+
+/* Float offset of one of the library's operand images, for callers that decode them (the tests'
+ * decoders, tests/planes_decode.py) -- which = 0 packed W_l, 1 packed W_l^T (relative to
+ * abn_tower_desc.wpack when given, else to the forward workspace), 2 the transposed image of
+ * [input of layer l | 1], 4 a BatchNorm layer's z_l, 5 the row-major output of layer l (forward
+ * workspace), 3 the transposed image of dZ_l (backward scratch); -1 when there is no such image.
+ * The formats are csrc/tower_planes.h's; they change with ABN_ABI_VERSION. */
+int64_t abn_tower_image_offset(const abn_tower_desc* t, int64_t rows, int64_t n_calls, int which,
+                               int l);
+
+/* The library reads its A/B switches (ABN_PLANES, ABN_WIDE, ABN_DTW_PC, ... : kernel choice only)
+ * from the environment once, when it is loaded; this reads them again (tests and A/B tools that
+ * change one inside a process). */
+void abn_reload_switches(void);
+
 /* SiameseNetwork.forward_once / forward, abnet3/model.py:179-196.
  * `rows` input rows in total, made of `n_calls` forward_once calls of
  * rows/n_calls rows each (1 = embed, 2 = Siamese pair): call c reads rows
@@ -200,6 +235,15 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
                        const float* d_out, int64_t rows, int64_t n_calls,
                        const float* ws, float* scratch, int64_t scratch_floats,
                        float* dx, void* stream);
+
+/* ONE of the two launches of an ABN_PATH_PLANES backward, for per-launch measurements (bench.py's
+ * roofline legs): part = 1 the data-gradient chain, 2 the weight gradients of every layer -- after
+ * a complete abn_tower_backward with the same arguments has left the other launch's output in
+ * place.  The split-K slabs are never reduced (dW / db are not written).  ABN_E_UNSUPPORTED on
+ * every other path. */
+int abn_tower_backward_launch(const abn_tower_desc* t, const float* x1, const float* x2,
+                              const float* d_out, int64_t rows, int64_t n_calls, const float* ws,
+                              float* scratch, int64_t scratch_floats, int part, void* stream);
 
 /* abn_pair_loss_dz + abn_tower_backward in the backward's own launches (abnet3/trainer.py:238-239:
  * loss = self.loss(emb1, emb2, y); loss.backward()): rows = 2 B tower rows, [tower 1: pairs 0..B-1 |

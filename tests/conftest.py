@@ -77,6 +77,7 @@ def _library_switches(monkeypatch):
         if os.path.exists(lib_path):
             from abnet3_amd import _lib
             _lib.reload_switches()
+            _lib.trace_paths = True          # tests ask which kernel family a tower call took (_lib.last_forward_path())
     reload()
     setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
 

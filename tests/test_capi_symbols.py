@@ -39,6 +39,44 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.abn_abi_version() == binding.ABI_VERSION
 
 
+def test_nothing_undeclared_is_exported(lib):
+    """The shared object's dynamic symbol table holds no abn_* entry point that the header does not declare:
+    diagnostic builds (-DABN_DTW_STAMPS, tools/variants.sh) add theirs, the product library must not."""
+    import subprocess
+    nm = '/opt/rocm/lib/llvm/bin/llvm-nm' if os.path.exists('/opt/rocm/lib/llvm/bin/llvm-nm') else 'nm'
+    out = subprocess.run([nm, '-D', '--defined-only', lib._name], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = set()
+    for line in out.splitlines():
+        parts = line.split()
+        if len(parts) >= 3 and parts[1] in 'TtWw' and parts[2].startswith('abn_'):
+            exported.add(parts[2])
+    assert exported, out[:400]
+    assert exported == set(declared_symbols()), exported ^ set(declared_symbols())
+
+
+def test_tower_path_is_a_pure_query(lib):
+    """abn_tower_path answers from the descriptor alone (no launch, no GPU): the C2 tower takes the operand-plane
+    chain in its own arithmetic, an odd-width f16x2 tower the per-layer GEMMs in bf16x3."""
+    from abnet3_amd import _lib
+    d = _lib.TowerDesc()
+    d.n_layers, d.act, d.last_act, d.batch_norm, d.precision = 4, 1, 1, 0, _lib.PRECISION['f16x2']
+    for i, v in enumerate((40, 500, 500, 500, 100)):
+        d.dims[i] = v
+    for l in range(4):
+        d.W[l] = d.b[l] = d.dW[l] = d.db[l] = 0x1000
+    prec = ctypes.c_int32(-1)
+    a = ctypes.c_void_p(0x10000)
+    assert lib.abn_tower_path(ctypes.byref(d), a, a, 8192, 2, 1, a, 0, ctypes.byref(prec)) == _lib.PATH_PLANES
+    assert prec.value == _lib.PRECISION['f16x2']
+    assert lib.abn_tower_path(ctypes.byref(d), a, a, 8192, 2, 1, a, 1, None) == _lib.PATH_PLANES
+    assert lib.abn_tower_path(ctypes.byref(d), a, a, 512, 2, 1, a, 0, None) == _lib.PATH_WIDE
+    d.dims[1] = 501                                   # not a multiple of 4: the GEMM kernels, in bf16 x 3
+    assert lib.abn_tower_path(ctypes.byref(d), a, a, 8192, 2, 1, a, 0, ctypes.byref(prec)) == _lib.PATH_PER_LAYER
+    assert prec.value == _lib.PRECISION['bf16x3']
+    d.n_layers = 99
+    assert lib.abn_tower_path(ctypes.byref(d), a, a, 8192, 2, 1, a, 0, None) < 0
+
+
 def test_descriptor_layout_matches_header():
     from abnet3_amd import _lib
     # 4 x int32 + 17 x int64 + 11 arrays of 16 pointers + precision, d_out_is_dz, defer_reduce, wpack_valid,
@@ -82,11 +120,12 @@ def test_dtw_workspace_planning(lib):
     ws = lib.abn_dtw_ws_bytes(p(n1), p(n2), 3, 1000, 1000)
     # the cost matrix is never materialised: per (padded) cell only 2 bits of back-pointers
     # -- bands of 32 rows x ceil((n2 + 31) / 32) rounds of 32 diagonals, 16 diagonals to a
-    # dword per row -- plus the band boundary rows of the two slots of each of the 2
-    # workgroups, and metadata
+    # dword per row -- plus, for the two slots of each of the 2 workgroups, two band boundary rows
+    # (float64: the longest token 2 rounded up to 32 + 64 of slack) and the token-2 norms (float32), and metadata
     dirs = (10 * 10 + 2 * 20) * 32 * 2 * 4
-    bound = 4 * 2 * 608 * 8
-    assert dirs + bound <= ws <= dirs + bound + 8 * 256 + 3 * 64
+    bound = 4 * 2 * (608 + 64) * 8
+    norms = 4 * (608 + 64) * 4
+    assert dirs + bound + norms <= ws <= dirs + bound + norms + 9 * 256 + 3 * 64
     assert ws < 1.0 * (300 * 280 + 50 * 600)            # under 1 B per cell even for two pairs (the matrix alone was 4.25 B / cell)
     assert lib.abn_dtw_host_stage_bytes(p(n1), p(n2), 3) >= 3 * 56 + 3 * 4
     assert lib.abn_dtw_ws_bytes(None, None, 3, 0, 0) == -1

@@ -171,7 +171,7 @@ def test_operand_images_decode_to_their_tensors(precision, NP):
               p_dropout=0.0, batch_norm=False)
     net, spec, p = build(kw, seed=4, precision=precision)
     lib = _lib.load()
-    fn = lib.abn_debug_planes_offset
+    fn = lib.abn_tower_image_offset
     fn.restype = ctypes.c_int64
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
     B = 37
@@ -330,7 +330,7 @@ def test_dropout_drawn_inside_the_kernels(precision, NP, monkeypatch):
               p_dropout=pdrop, batch_norm=False)
     net, spec, p = build(kw, seed=12, precision=precision)
     lib = _lib.load()
-    fn = lib.abn_debug_planes_offset
+    fn = lib.abn_tower_image_offset
     fn.restype = ctypes.c_int64
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
     B = 200
@@ -446,13 +446,13 @@ def test_batch_norm_inference_forward_against_the_oracle(shape, act, precision, 
     assert lib.abn_tower_uses_planes(ctypes.byref(probe), B, _lib.ptr(xd), None, _lib.ptr(xd), 0) == 0
     with torch.no_grad():
         e = net.forward_once(xd).cpu().numpy()
-        assert lib.abn_debug_last_forward_path() == 4
+        assert _lib.last_forward_path() == 4
         e1, e2 = net(xd, dev(x[::-1].copy()))
-        assert lib.abn_debug_last_forward_path() == 4
+        assert _lib.last_forward_path() == 4
     monkeypatch.setenv('ABN_PLANES', '0')
     with torch.no_grad():
         ref = net.forward_once(xd).cpu().numpy()
-        assert lib.abn_debug_last_forward_path() == 0
+        assert _lib.last_forward_path() == 0
     monkeypatch.setenv('ABN_PLANES', '1')
     o, _ = O.tower_forward(p, x, spec, False)
     # (8-bit operands: the normalisation multiplies a layer's rounding error by up to gamma / sqrt(running_var))
@@ -466,7 +466,7 @@ def test_batch_norm_inference_forward_against_the_oracle(shape, act, precision, 
     # with a gradient wanted the eval forward stays on the per-layer kernels (whose backward refuses, as before)
     xg = xd.clone().requires_grad_(True)
     eg = net.forward_once(xg)
-    assert lib.abn_debug_last_forward_path() == 0
+    assert _lib.last_forward_path() == 0
     assert rel_err(eg.detach().cpu().numpy(), ref) == 0.0
     with pytest.raises(NotImplementedError):
         eg.sum().backward()
@@ -487,10 +487,10 @@ def test_inference_instantiation_equals_the_training_forward(shape, precision):
     for mode in (net.train, net.eval):
         mode()
         a = net.forward_once(x).detach()
-        assert lib.abn_debug_last_forward_path() == 2
+        assert _lib.last_forward_path() == 2
         with torch.no_grad():
             b = net.forward_once(x)
-        assert lib.abn_debug_last_forward_path() == (2 if net.training else 3)
+        assert _lib.last_forward_path() == (2 if net.training else 3)
         assert torch.equal(a, b)
 
 
@@ -539,10 +539,10 @@ def test_batch_norm_training_step_against_the_oracle(shape, act, p_drop, split):
         net._mask_override = [dev(m) for m in masks]
     net.train()
     e1, e2 = net(dev(x1), dev(x2))
-    assert _lib.load().abn_debug_last_forward_path() == 5
+    assert _lib.last_forward_path() == 5
     lv = L.coscos2(avg=False)(e1, e2, dev(y))
     lv.backward()
-    assert _lib.load().abn_debug_last_backward_path() == 5
+    assert _lib.last_backward_path() == 5
     o1, c1 = O.tower_forward(p, x1, spec, True, masks=[m[:B] for m in masks] if masks else None)
     o2, c2 = O.tower_forward(p, x2, spec, True, masks=[m[B:] for m in masks] if masks else None)
     ol, d1, d2, _ = O.pair_loss(o1, o2, y, 'coscos2', 0.5, False)
@@ -580,7 +580,7 @@ def test_batch_norm_input_gradient_and_fallbacks(monkeypatch, split):
         a, b = dev(x1).requires_grad_(True), dev(x2).requires_grad_(True)
         e1, e2 = net(a, b)
         ((e1 * w).sum() + (e2 * e2 * w).sum()).backward()
-        assert _lib.load().abn_debug_last_backward_path() == (5 if planes == '1' else 0)
+        assert _lib.last_backward_path() == (5 if planes == '1' else 0)
         res.append([a.grad.cpu().numpy(), b.grad.cpu().numpy()] + [q.grad.cpu().numpy() for q in net.parameters()])
     gmax = max(np.abs(v).max() for v in res[1])
     for u, v in zip(*res):
@@ -594,9 +594,9 @@ def test_batch_norm_input_gradient_and_fallbacks(monkeypatch, split):
         net, _, _ = build(kw, seed=9, precision=split)
         net.train()
         e = net.forward_once(dev(x1[:37]))
-        assert _lib.load().abn_debug_last_forward_path() == (5 if planes == '1' else 0)
+        assert _lib.last_forward_path() == (5 if planes == '1' else 0)
         (e * e).sum().backward()
-        assert _lib.load().abn_debug_last_backward_path() == (5 if planes == '1' else 0)
+        assert _lib.last_backward_path() == (5 if planes == '1' else 0)
         outs.append([e.detach().cpu().numpy()] + [q.grad.cpu().numpy() for q in net.parameters()]
                     + [v.cpu().numpy() for k, v in net.state_dict().items() if 'running' in k])
     gmax = max(np.abs(v).max() for v in outs[1][1:])
@@ -623,7 +623,7 @@ def test_batch_norm_training_in_the_bf16_arithmetic(monkeypatch):
         net, _, _ = build(kw, seed=2, precision='bf16')
         net.train()
         e1, e2 = net(x1, x2)
-        assert _lib.load().abn_debug_last_forward_path() == (5 if planes == '1' else 0)
+        assert _lib.last_forward_path() == (5 if planes == '1' else 0)
         lv = L.coscos2(avg=False)(e1, e2, y)
         lv.backward()
         res.append((e1.detach().cpu().numpy(), float(lv.detach()), {k: q.grad.cpu().numpy() for k, q in net.named_parameters()},
@@ -661,14 +661,14 @@ def test_batch_norm_with_dropout_drawn_inside_the_kernels(split):
     probe = seg.descriptor(with_grads=False)
     assert lib.abn_tower_uses_planes(ctypes.byref(probe), 2 * B, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(x1), 1) == 1
     emb, state = net.direct_forward(x1, x2)
-    assert lib.abn_debug_last_forward_path() == 5
+    assert _lib.last_forward_path() == 5
     sv = state[1]
     assert type(sv.masks).__name__ == '_DropSeed'
     net.direct_backward(state, d_out)
-    assert lib.abn_debug_last_backward_path() == 5
+    assert _lib.last_backward_path() == 5
     emb = emb.clone()
     grads = {k: q.grad.clone() for k, q in net.named_parameters()}
-    fn = lib.abn_debug_planes_offset
+    fn = lib.abn_tower_image_offset
     fn.restype = ctypes.c_int64
     desc = seg.descriptor(with_grads=False, masks=sv.masks)
     masks = []
@@ -721,9 +721,9 @@ def test_batch_norm_dropout_train_mode_without_gradients(tmp_path, split):
     net.train()
     lib = _lib.load()
     v = tr.train_step(batch, False)                            # train mode, no gradients
-    assert lib.abn_debug_last_forward_path() == 0 and np.isfinite(float(v))
+    assert _lib.last_forward_path() == 0 and np.isfinite(float(v))
     v = tr.train_step(batch, True)                             # the same tower in a real step: the BatchNorm launches
-    assert lib.abn_debug_last_forward_path() == 5 and np.isfinite(float(v))
+    assert _lib.last_forward_path() == 5 and np.isfinite(float(v))
     tr.train()                                                 # the reference's whole loop, first pass included
     assert len(tr.train_losses) == 3 and all(np.isfinite(tr.train_losses))
 

@@ -42,10 +42,10 @@ def test_forward_loss_and_gradients_against_the_oracle(shape, act, precision, to
     net.train()
     lib = _lib()[1]
     e1, e2 = net(dev(x1), dev(x2))
-    assert lib.abn_debug_last_forward_path() == 6
+    assert _lib()[0].last_forward_path() == 6
     lv = L.coscos2(avg=False)(e1, e2, dev(y))
     lv.backward()
-    assert lib.abn_debug_last_backward_path() == 6
+    assert _lib()[0].last_backward_path() == 6
     o1, c1 = O.tower_forward(p, x1, spec, True)
     o2, c2 = O.tower_forward(p, x2, spec, True)
     ol, d1, d2, _ = O.pair_loss(o1, o2, y, 'coscos2', 0.5, False)
@@ -64,7 +64,7 @@ def test_forward_loss_and_gradients_against_the_oracle(shape, act, precision, to
     # the trainer's direct step (pair loss inside the top data-gradient launch, deferred reduction): same gradients
     tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='sgd', lr=0.0, dataloader=None, log_dir='/tmp/abn_runs')
     lv2 = tr.train_step((dev(x1), dev(x2), dev(y)), True)
-    assert lib.abn_debug_last_backward_path() == 6
+    assert _lib()[0].last_backward_path() == 6
     assert abs(float(lv2) - float(lv.detach())) <= 1e-6 * abs(float(lv2))
     for k, q in net.named_parameters():
         assert rel_err(q.grad.cpu().numpy(), grads[k], floor=1e-30) < (1e-6 if precision != 'bf16' else 1e-5), k
@@ -81,7 +81,7 @@ def test_forward_once_and_inference(rows, split):
     for mode in (net.train, net.eval):
         mode()
         a = net.forward_once(dev(x)).detach()
-        assert lib.abn_debug_last_forward_path() == 6
+        assert _lib()[0].last_forward_path() == 6
         with torch.no_grad():
             b = net.forward_once(dev(x))
         assert torch.equal(a, b)
@@ -104,7 +104,7 @@ def test_agrees_with_the_single_launch_chains(B, hid, d_in, monkeypatch, split):
         net, _, _ = build(kw, seed=7, precision=split)
         net.train()
         emb, st = net.direct_forward(x1, x2)
-        assert _lib()[1].abn_debug_last_forward_path() == (6 if wide == '1' else 2)
+        assert _lib()[0].last_forward_path() == (6 if wide == '1' else 2)
         loss = net.direct_backward_loss(st, y, 'coscos2', 0.0, False)
         res.append((emb.clone(), float(loss), {k: q.grad.clone() for k, q in net.named_parameters()}))
     (ea, la, ga), (eb, lb, gb) = res
@@ -126,7 +126,7 @@ def test_input_gradient(split):
     net.train()
     e1, e2 = net(x1, x2)
     L.coscos2(avg=False)(e1, e2, dev(y)).backward()
-    assert _lib()[1].abn_debug_last_backward_path() == 6
+    assert _lib()[0].last_backward_path() == 6
     o1, c1 = O.tower_forward(p, x1n, spec, True)
     o2, c2 = O.tower_forward(p, x2n, spec, True)
     _, d1, d2, _ = O.pair_loss(o1, o2, y, 'coscos2', 0.5, False)
@@ -175,7 +175,7 @@ def test_a_padded_batch_is_bit_identical_to_the_batch(n, avg, split):
     x1, x2 = [dev(rng.standard_normal((n, 280)).astype(np.float32)) for _ in range(2)]
     y = dev(rng.choice([1.0, -1.0], n))
     emb, st = net.direct_forward(x1, x2)
-    assert _lib()[1].abn_debug_last_forward_path() == 6
+    assert _lib()[0].last_forward_path() == 6
     loss_a = net.direct_backward_loss(st, y, 'coscos2', 0.0, avg, defer_reduce=False)
     emb_a = emb.clone()
     ga = {k: q.grad.clone() for k, q in net.named_parameters()}
@@ -210,14 +210,14 @@ def test_dropout_from_the_seed_matches_its_masks(monkeypatch, split):
     d_out = dev(rng.standard_normal((2 * B, 32)).astype(np.float32))
     seg = net._segment_list()[0]
     emb, state = net.direct_forward(x1, x2)
-    assert lib.abn_debug_last_forward_path() == 6
+    assert _lib()[0].last_forward_path() == 6
     sv = state[1]
     assert type(sv.masks).__name__ == '_DropSeed'
     net.direct_backward(state, d_out)
-    assert lib.abn_debug_last_backward_path() == 6
+    assert _lib()[0].last_backward_path() == 6
     emb = emb.clone()
     grads = {k: q.grad.clone() for k, q in net.named_parameters()}
-    fn = lib.abn_debug_planes_offset
+    fn = lib.abn_tower_image_offset
     fn.restype = ctypes.c_int64
     desc = seg.descriptor(with_grads=False, masks=sv.masks)
     masks = []
@@ -232,7 +232,7 @@ def test_dropout_from_the_seed_matches_its_masks(monkeypatch, split):
     for q in net.parameters():
         q.grad = None
     emb_t, state_t = net.direct_forward(x1, x2)
-    assert lib.abn_debug_last_forward_path() == 2
+    assert _lib()[0].last_forward_path() == 2
     net.direct_backward(state_t, d_out)
     assert rel_err(emb_t.cpu().numpy(), emb.cpu().numpy()) < 2e-6
     for k, q in net.named_parameters():
@@ -249,6 +249,6 @@ def test_eight_calls_of_ragged_length(split):
     x = np.random.default_rng(0).standard_normal((8 * 19, 40)).astype(np.float32)
     seg = net._segment_list()[0]
     out, sv = M._segment_forward(seg, None, 8, dev(x), None)
-    assert LIB.load().abn_debug_last_forward_path() == 6
+    assert LIB.last_forward_path() == 6
     o, _ = O.tower_forward(p, x, spec, True)
     assert rel_err(out.cpu().numpy(), o) < 1e-5

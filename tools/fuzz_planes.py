@@ -13,7 +13,7 @@ from abnet3_amd import _lib
 def run(cases, seed, verbose=True):
   rng = np.random.default_rng(seed)
   lib = _lib.load()
-  reload_sw = lib.abn_debug_reload_switches
+  reload_sw = lib.abn_reload_switches
   bad = 0
   lines = []
   for case in range(cases):
@@ -58,7 +58,7 @@ def run(cases, seed, verbose=True):
           grads = {k: q.grad.double().cpu().numpy() for k, q in net.named_parameters() if q.grad is not None}
           if want_dx:
               grads['d input'] = xa.grad.double().cpu().numpy()
-          outs[prec] = (e.detach().double().cpu().numpy(), grads, lib.abn_debug_last_forward_path())
+          outs[prec] = (e.detach().double().cpu().numpy(), grads, _lib.last_forward_path())
       e32, g32, _ = outs['fp32']
       for prec in ('f16x2', 'bf16x3'):
           e, g, path = outs[prec]
