@@ -6,6 +6,7 @@ Mirrors (file:line relative to the reference checkout)
   dtw_align_batch     (new) the same for a whole batch of token pairs at once
   Features_Accessor   abnet3/utils.py:118-145   host slicing semantics
   read_dataset / group_pairs / read_pairs   abnet3/utils.py:156-208
+  read_vad_file       abnet3/utils.py:238-254
   print_token         abnet3/utils.py:101-105   (pairs-file number format)
 """
 import ctypes
@@ -81,6 +82,21 @@ def group_pairs(pairs):
 
 def read_pairs(pair_file):
     return group_pairs(read_dataset(pair_file))
+
+
+def read_vad_file(path):
+    """{file: [[start, end], ...]} from a voice-activity file: a header line, then "file,start,stop" lines
+    (the ZeroSpeech 2015 format the reference reads, abnet3/utils.py:238-254); windows keep file order."""
+    windows = {}
+    with open(path) as fh:
+        next(fh, None)                                   # header
+        for line in fh:
+            line = line.strip()
+            if not line:
+                continue
+            name, start, stop = line.split(',')
+            windows.setdefault(name, []).append([float(start), float(stop)])
+    return windows
 
 
 def cast_features(features, target_type=np.float32):

@@ -374,6 +374,53 @@ def test_mean_variance_normalisation(per_channel, per_file):
         assert np.abs(out['a'] - ref).max() < 1e-5
 
 
+def _mvn_case(g, name):
+    from abnet3_amd.utils import read_vad_file
+    items = ['file1', 'file2']
+    feats = {k: g['%s.x%d' % (name, i)] for i, k in enumerate(items)}
+    times = {k: g['%s.t%d' % (name, i)] for i, k in enumerate(items)}
+    vad = None
+    if str(g[name + '.vad']):
+        import tempfile
+        with tempfile.NamedTemporaryFile('w', suffix='.vad', delete=False) as fh:
+            fh.write(str(g[name + '.vad']))
+        vad = read_vad_file(fh.name)
+        os.unlink(fh.name)
+    return items, feats, times, vad, bool(int(g[name + '.per_file']))
+
+
+@pytest.mark.parametrize('per_channel', [1, 0])
+@pytest.mark.parametrize('name', ['global', 'per_file', 'global_vad', 'per_file_vad'])
+def test_normalisation_cases_of_the_reference_test(golden, name, per_channel):
+    """G10 (tests/golden/mvn.npz): the four cases of the reference's test/test_features.py:37-281 -- its literal
+    inputs and VAD file, the frames its VAD keeps, the statistics and outputs it asserts -- through abn_mvn_stats /
+    abn_mvn_apply (FeaturesGenerator.normalize_features).  The reference's bars: statistics pytest.approx (1e-6
+    relative), outputs pytest.approx, and zero mean / unit deviation of the normalised data to 1e-6."""
+    from abnet3_amd.features import FeaturesGenerator
+    g = golden('mvn.npz')
+    items, feats, times, vad, per_file = _mvn_case(g, name)
+    tag = '%s.pc%d' % (name, per_channel)
+    fg = FeaturesGenerator(normalization=True, norm_per_file=per_file, norm_per_channel=bool(per_channel))
+    out, stats = fg.normalize_features(feats, times, vad)
+    if per_file:
+        assert [s[0] for s in stats] == items                       # meansvars[i][0] == 'file<i+1>'
+        for i, (f, mean, std) in enumerate(stats):
+            assert np.allclose(np.atleast_1d(mean), g['%s.mean%d' % (tag, i)], rtol=1e-6, atol=1e-7), (f, mean)
+            assert np.allclose(np.atleast_1d(std), g['%s.std%d' % (tag, i)], rtol=1e-6), (f, std)
+    else:
+        assert np.allclose(np.atleast_1d(stats[0]), g[tag + '.mean'], rtol=1e-6, atol=1e-7)
+        assert np.allclose(np.atleast_1d(stats[1]), g[tag + '.std'], rtol=1e-6)
+    for i, f in enumerate(items):
+        assert out[f].dtype == np.float32
+        assert np.allclose(out[f], g['%s.out%d' % (tag, i)], rtol=1e-6, atol=1e-6), f
+    if vad is None:        # "check that the new file has 0 mean and 1 variance" (per file, or over the whole set)
+        sets = [out[f] for f in items] if per_file else [np.vstack([out[f] for f in items])]
+        for data in sets:
+            axis = 0 if per_channel else None
+            assert np.allclose(np.mean(data.astype(np.float64), axis=axis), 0.0, atol=1e-6)
+            assert np.allclose(np.std(data.astype(np.float64), axis=axis), 1.0, atol=1e-6)
+
+
 def test_end_to_end_pipeline_trains(tmp_path, monkeypatch):
     """BASELINE.json configs[4] in miniature: fbank -> normalise -> stack -> DTW
     pair mining -> Siamese training -> embedding; the loss must go down."""

@@ -104,6 +104,14 @@ def test_c2_timed_step_five_adadelta_steps_vs_reference(bn, mode):
         x1, x2, y = torch_ref.make_inputs(4096, 40, 20 + s)
         batches.append((x1.cuda(), x2.cuda(), torch.from_numpy(y).cuda()))
     net.train()
+    # the timed path's own forward (direct_forward: no autograd) on the first batch: all 2 x 4096 rows
+    from test_gpu_siamese import check_all_embedding_rows
+    emb, _ = net.direct_forward(batches[0][0], batches[0][1])
+    check_all_embedding_rows(g, emb[:4096], emb[4096:])
+    if bn:      # that forward moved BatchNorm's running statistics: start again from the seed
+        net, kw = cuda_net(g, seed=2, prefix=None)
+        tr = trainer(net, 'coscos2', 0, 'adadelta')
+        net.train()
 
     def check_first_gradient():
         gmax = max(float(g['gchk.' + k][2]) for k, _ in net.named_parameters())
@@ -131,6 +139,7 @@ def test_c2_timed_step_five_adadelta_steps_vs_reference(bn, mode):
     else:
         step = tr.make_graphed_step(batches[0], warmup=1)     # its warm-up step is step 1
         losses = [float(step.warmup_loss)] + [float(step(batches[s % 2])) for s in range(1, 5)]
+    assert abs(losses[0] - g['losses'][0]) <= 1e-5 * abs(g['losses'][0]), (losses[0], g['losses'][0])      # step 0: nothing has drifted yet
     assert np.allclose(losses, g['losses'], rtol=2e-5), (losses, g['losses'])
     for k, v in net.state_dict().items():
         if 'num_batches' in k or (bn and k.endswith('bias')) or 'running_mean' in k:

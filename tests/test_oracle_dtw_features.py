@@ -217,3 +217,48 @@ def test_deltas_definition():
     assert np.allclose(d[0], manual0, atol=1e-6)
     dd = F.fbank_with_deltas(np.zeros(4000, dtype=np.int16), 16000)
     assert dd.shape == (26, 120) and np.allclose(dd[:, 40:], 0.0)
+
+
+@pytest.mark.parametrize('per_channel', [1, 0])
+@pytest.mark.parametrize('name', ['global', 'per_file', 'global_vad', 'per_file_vad'])
+def test_mvn_restatement_on_the_reference_tests_cases(name, per_channel):
+    """G10: oracle/features_np.mvn + the host-side VAD windows (utils.read_vad_file, Features_Accessor) on the literal
+    cases of the reference's test/test_features.py:37-281 -- kept frames, statistics and outputs as that test asserts
+    them (the fixture's kept-frame counts come from the reference's own filter_vad_* functions)."""
+    import os
+    import tempfile
+    from abnet3_amd.utils import read_vad_file, Features_Accessor
+    g = load_golden('mvn.npz')
+    items = ['file1', 'file2']
+    feats = [g['%s.x%d' % (name, i)].astype(np.float64) for i in range(2)]
+    times = [g['%s.t%d' % (name, i)] for i in range(2)]
+    vad = None
+    if str(g[name + '.vad']):
+        with tempfile.NamedTemporaryFile('w', suffix='.vad', delete=False) as fh:
+            fh.write(str(g[name + '.vad']))
+        vad = read_vad_file(fh.name)
+        os.unlink(fh.name)
+        assert vad == {'file1': [[0.0025, 0.5], [0.7525, 1.0]]}
+    keep = []
+    for f, x, t in zip(items, feats, times):
+        if vad is not None and f in vad:
+            rows = np.concatenate([Features_Accessor.get_indices_between(t, s, e) for s, e in vad[f]])
+            keep.append(x[rows])
+        else:
+            keep.append(x)
+    tag = '%s.pc%d' % (name, per_channel)
+    if int(g[name + '.per_file']):
+        for i, x in enumerate(feats):
+            assert keep[i].shape[0] == int(g['%s.kept%d' % (tag, i)])
+            out, mean, std = F.mvn(x, bool(per_channel), stats_on=keep[i])
+            assert np.array_equal(np.atleast_1d(mean), g['%s.mean%d' % (tag, i)])
+            assert np.array_equal(np.atleast_1d(std), g['%s.std%d' % (tag, i)])
+            assert np.array_equal(out, g['%s.out%d' % (tag, i)])
+    else:
+        allf = np.vstack(keep)
+        assert allf.shape[0] == int(g[tag + '.kept'])
+        for i, x in enumerate(feats):
+            out, mean, std = F.mvn(x, bool(per_channel), stats_on=allf)
+            assert np.allclose(np.atleast_1d(mean), g[tag + '.mean'], rtol=1e-15)
+            assert np.allclose(np.atleast_1d(std), g[tag + '.std'], rtol=1e-15)
+            assert np.allclose(out, g['%s.out%d' % (tag, i)], rtol=1e-14, atol=1e-15)

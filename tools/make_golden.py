@@ -27,6 +27,14 @@ Fixture sets:
                   matrices large enough for OpenBLAS's regular sgemm kernel: what the
                   oracle and the HIP kernel reproduce bit for bit, plus the per-pair
                   drop decisions (AssertionError) for near-duplicate tokens
+  G10 mvn        the four normalisation cases of the reference's own test/test_features.py:37-281
+                  (global / per file, with and without a VAD, per channel and over the whole spectrum),
+                  re-enacted in memory: the inputs are that test's literals, the VAD file is read and
+                  applied by the reference's read_vad_file / filter_vad_* (pure numpy, importable), the
+                  expected statistics and outputs are the expressions that test asserts
+  G11 gridsearch  the `default_params` of the reference's test/data/buckeye.yaml as a dictionary, and what
+                  the reference's own classes make of it when built the way gridsearch.py:145-202 builds them
+                  (which keyword arguments they accept, parameter count, state_dict keys, optimizer class)
   G9 frames_loader  FramesDataLoader.load_all_frames / load_batch / batch_iterator
                   (shuffles, batch slicing, max_batches_per_epoch wrap-around) and
                   OriginalDataLoader.add_tcl_to_batch / temporal_coherence_loss
@@ -308,6 +316,13 @@ def g4_train_mid(abnet3):
             if s == 0:
                 out['e1_rows'] = e1.detach().numpy()[:8].copy()
                 out['e2_rows'] = e2.detach().numpy()[-8:].copy()
+                # every one of the 2 x 4096 embedding rows, as two float64 checksums per row (sum, sum |.|),
+                # and each tensor's sum / sum |.| / max |.|
+                for name, e in (('e1', e1), ('e2', e2)):
+                    ed = e.detach().double()
+                    out[name + '_rowsum'] = ed.sum(dim=1).numpy().copy()
+                    out[name + '_rowabs'] = ed.abs().sum(dim=1).numpy().copy()
+                    out[name + '_chk'] = np.array([float(ed.sum()), float(ed.abs().sum()), float(ed.abs().max())])
                 for k, p in net.named_parameters():
                     g = p.grad.detach()
                     out['gchk.' + k] = np.array(
@@ -666,9 +681,133 @@ def g9_frames_loader(abnet3):
     np.savez_compressed(os.path.join(OUT, 'frames_loader.npz'), **out)
 
 
+def g10_mvn(abnet3):
+    """G10: mean / variance normalisation as the reference's test states it (test/test_features.py:37-281).
+    h5features / h5py are absent, so FeaturesGenerator.mean_variance_normalisation itself cannot run; what the
+    reference's test pins is re-enacted: its literal inputs, the frames a VAD keeps (the reference's own
+    read_vad_file + filter_vad_one_file / filter_vad_whole_dataset on its own Features_Accessor), the statistics it
+    asserts (np.mean / np.std of the kept frames, axis 0 or None) and the output it asserts
+    ((feature - mean) / (std + eps), abnet3/features.py:240,293)."""
+    import tempfile
+    from abnet3.features import FeaturesGenerator
+    from abnet3.utils import read_vad_file, Features_Accessor
+    out = {}
+    t = lambda n: np.arange(n, dtype=float) * 0.01 + 0.0025
+    vad_text = "file,start,stop\nfile1,0.0025,0.5000\nfile1,0.7525,1.000\n"
+    with tempfile.NamedTemporaryFile('w', suffix='.vad', delete=False) as fh:
+        fh.write(vad_text)
+    vad = read_vad_file(fh.name)
+    os.unlink(fh.name)
+    cases = {
+        # test_normalization (:37-85)
+        'global': ([np.full((100, 40), 1.0), np.full((150, 40), 2.0)], False, None),
+        # test_normalization_per_file (:87-140)
+        'per_file': ([np.vstack([np.full((100, 40), 1.), np.full((100, 40), -1.)]),
+                      np.vstack([np.full((100, 40), 1.), np.full((100, 40), 2.)])], True, None),
+        # test_normalization_with_VAD (:142-204)
+        'global_vad': ([np.vstack([np.full((50, 40), 1.0), np.full((50, 40), -1.0)]),
+                        np.vstack([np.full((50, 40), 1.0), np.full((50, 40), -1.0)])], False, vad),
+        # test_norm_per_file_with_VAD (:206-281)
+        'per_file_vad': ([np.vstack([np.full((50, 40), 1.0), np.full((50, 40), -1.0)]),
+                          np.vstack([np.full((50, 40), 1.0), np.full((50, 40), -1.0)])], True, vad),
+    }
+    items = ['file1', 'file2']
+    fg = FeaturesGenerator()
+    for name, (features, per_file, vad_data) in cases.items():
+        times = [t(f.shape[0]) for f in features]
+        for i, f in enumerate(features):
+            out['%s.x%d' % (name, i)] = f.astype(np.float32)
+            out['%s.t%d' % (name, i)] = times[i]
+        out[name + '.per_file'] = np.array(int(per_file))
+        out[name + '.vad'] = np.array(vad_text if vad_data is not None else '')
+        eps = np.finfo(features[0].dtype).eps
+        for per_channel in (1, 0):
+            axis = 0 if per_channel else None
+            tag = '%s.pc%d' % (name, per_channel)
+            if per_file:
+                for i, (f, tm) in enumerate(zip(features, times)):
+                    kept = f
+                    if vad_data is not None and items[i] in vad_data:
+                        kept = fg.filter_vad_one_file(f, tm, vad_data[items[i]])
+                    mean, std = np.mean(kept, axis=axis), np.std(kept, axis=axis)
+                    out['%s.kept%d' % (tag, i)] = np.array(kept.shape[0])
+                    out['%s.mean%d' % (tag, i)] = np.atleast_1d(mean)
+                    out['%s.std%d' % (tag, i)] = np.atleast_1d(std)
+                    out['%s.out%d' % (tag, i)] = (f - mean) / (std + eps)
+            else:
+                acc = Features_Accessor({k: tm for k, tm in zip(items, times)},
+                                        {k: f.astype(np.float32) for k, f in zip(items, features)})
+                if vad_data is not None:
+                    fg.filter_vad_whole_dataset(acc, vad_data)
+                kept = np.vstack(list(acc.features.values())).astype(np.float64)
+                mean, std = np.mean(kept, axis=axis), np.std(kept, axis=axis)
+                out[tag + '.kept'] = np.array(kept.shape[0])
+                out[tag + '.mean'] = np.atleast_1d(mean)
+                out[tag + '.std'] = np.atleast_1d(std)
+                for i, f in enumerate(features):
+                    out['%s.out%d' % (tag, i)] = (f - mean) / (std + eps)
+    # the literals the reference's test spells out
+    assert int(out['global_vad.pc1.kept']) == 75 + 100 and int(out['per_file_vad.pc1.kept0']) == 75
+    assert np.allclose(out['per_file.pc0.mean1'], 1.5) and np.allclose(out['per_file.pc0.mean0'], 0.0)
+    np.savez_compressed(os.path.join(OUT, 'mvn.npz'), **out)
+
+
+def g11_gridsearch(abnet3):
+    """G11: the caller's side of the boundary.  GridSearch.run_single_experiment (gridsearch.py:145-202) builds every
+    object as getattr(abnet3.<module>, cfg['class'])(**cfg['arguments']) after injecting a few arguments; the
+    fixture holds the reference's own test configuration (test/data/buckeye.yaml -> default_params, as data) and
+    what the reference's classes are when built from it on this machine (sampler excluded: out of scope; the
+    reference's trainer needs tensorboardX's SummaryWriter only inside train())."""
+    import inspect
+    import json
+    import yaml
+    import abnet3.trainer
+    import abnet3.embedder
+    with open(os.path.join(REF, 'test', 'data', 'buckeye.yaml')) as fh:
+        params = yaml.safe_load(fh)['default_params']
+    exp = '/tmp/abnet3_g11'
+    info = {}
+
+    def build(module, section, inject):
+        cfg = params[section]
+        cls = getattr(module, cfg['class'])
+        args = dict(cfg['arguments'] or {})
+        args.update(inject)
+        accepted = set(inspect.signature(cls.__init__).parameters) - {'self'}
+        has_var_kw = any(p.kind == p.VAR_KEYWORD for p in inspect.signature(cls.__init__).parameters.values())
+        rejected = sorted(k for k in args if k not in accepted and not has_var_kw)
+        info[section + '.rejected_kwargs'] = rejected
+        return cls(**{k: v for k, v in args.items() if k not in rejected})
+
+    features = build(abnet3.features, 'features', {})
+    model = build(abnet3.model, 'model', {'output_path': os.path.join(exp, 'network')})
+    loss = build(abnet3.loss, 'loss', {})
+    dataloader = build(abnet3.dataloader, 'dataloader',
+                       {'pairs_path': os.path.join(exp, 'pairs'), 'features_path': features.output_path})
+    trainer = build(abnet3.trainer, 'trainer', {'network': model, 'loss': loss, 'dataloader': dataloader,
+                                                'log_dir': os.path.join(exp, 'logs')})
+    embedder = build(abnet3.embedder, 'embedder', {'network': model, 'output_path': os.path.join(exp, 'embeddings.h5f'),
+                                                   'feature_path': features.output_path,
+                                                   'network_path': model.output_path + '.pth'})
+    info['model.n_parameters'] = int(sum(p.numel() for p in model.parameters()))
+    info['model.state_dict_keys'] = list(model.state_dict().keys())
+    info['model.whoami_keys'] = sorted(model.whoami().keys())
+    info['loss.class'] = type(loss).__name__
+    info['loss.whoami_keys'], info['loss.avg'] = sorted(loss.whoami().keys()), bool(loss.avg)
+    info['trainer.optimizer'] = type(trainer.optimizer).__name__
+    info['trainer.lr'] = trainer.optimizer.param_groups[0]['lr']
+    info['trainer.num_epochs'], info['trainer.patience'] = trainer.num_epochs, trainer.patience
+    info['dataloader.batch_size'] = dataloader.batch_size
+    info['dataloader.num_max_minibatches'] = dataloader.num_max_minibatches
+    info['embedder.batch_size'] = embedder.batch_size
+    info['features.run'] = features.run
+    with open(os.path.join(OUT, 'gridsearch_buckeye.json'), 'w') as fh:
+        json.dump({'default_params': params, 'reference': info}, fh, indent=1, sort_keys=True)
+
+
 ALL = {'G1': g1_tower, 'G2': g2_train_c1, 'G3': g3_loss_edge,
        'G4': g4_train_mid, 'G5': g5_cosdist, 'G6': g6_stack, 'G7': g7_frames,
-       'G8': g8_multitask, 'G5L': g5l_cosdist_libm, 'G9': g9_frames_loader}
+       'G8': g8_multitask, 'G5L': g5l_cosdist_libm, 'G9': g9_frames_loader, 'G10': g10_mvn, 'G11': g11_gridsearch}
 
 
 def main():
