@@ -745,6 +745,9 @@ static inline int planes_of(const abn_tower_desc* t) { return t->precision == 3 
 static inline size_t wgrad_lds_of(int np) { return np == 3 ? wgrad_lds_bytes<3>() : (np == 2 ? wgrad_lds_bytes<2>() : wgrad_lds_bytes<1>()); }
 // the arithmetic the GEMM kernels (gemm_f32.h, tower_fused.h) run a precision in: fp16 x 2 exists on the operand planes only
 static inline int gemm_prec(int precision) { return precision > 2 ? 2 : precision; }
+// cross-replica BatchNorm statistics are on: a function to sum them with, for a group of bn_sync_world >= 1 replicas
+// (a group of one: the function's reduction is the identity, the launches are the group's)
+static inline bool bn_sync_on(const abn_tower_desc* t) { return t->bn_sync_fn != nullptr && t->bn_sync_world >= 1; }
 // BatchNorm launches: workgroups of 32 rows never straddle two forward_once calls, so the row axis of the
 // transposed images is padded per call
 static inline int64_t bn_wgs_per_call(int64_t rows, int64_t n_calls) { return (rows / n_calls + PL_ROWS - 1) / PL_ROWS; }
@@ -1123,7 +1126,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     float* const part = scratch + B.bn_wg;
     float* const s1 = scratch + B.bn_s1, * const s2 = scratch + B.bn_s2;
     // cross-replica statistics: the sums leave as float64, are all-reduced by the caller's function, and come back as s1 / s2
-    const bool sync = t->bn_sync_world > 1;
+    const bool sync = bn_sync_on(t);
     ABN_REQUIRE(!sync || t->bn_sync_fn, "tower_backward: bn_sync_world = %d without bn_sync_fn", t->bn_sync_world);
     double* const sums = reinterpret_cast<double*>(scratch + B.bn_part);
     auto finish_sums = [&](int C, float* dgamma, float* dbeta) -> int {
@@ -1468,7 +1471,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
     const bool fusable = path == ABN_PATH_FUSED_F32;
     const int pmode = train ? PLANES_TRAIN : PLANES_EVAL_FORWARD;
     const bool bn_train = train && bn_train_planes_path(t, rows, n_calls, x1, x2, ws);
-    if (train && t->batch_norm && t->bn_sync_world > 1 && !bn_train) {
+    if (train && t->batch_norm && bn_sync_on(t) && !bn_train) {
         set_error("tower_forward: cross-replica BatchNorm statistics (bn_sync_world) need the operand-plane launches");
         return ABN_E_UNSUPPORTED;
     }
@@ -1598,7 +1601,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 if (l > 0) { q.mean = ws + L.mean[l - 1]; q.invstd = ws + L.invstd[l - 1]; q.z_prev = ws + L.xhat[l - 1]; q.a_prev = nullptr; }
                 PL_LAUNCH(np, bn_fwd_layer_kernel, bgrid, dim3(PL_NT), pl_lds_bytes(np), st, fl, q);
                 const int N = (int)t->dims[l + 1];
-                const bool sync = t->bn_sync_world > 1;
+                const bool sync = bn_sync_on(t);
                 ABN_REQUIRE(!sync || t->bn_sync_fn, "tower_forward: bn_sync_world = %d without bn_sync_fn", t->bn_sync_world);
                 double* const sums = reinterpret_cast<double*>(ws + L.bn_part);       // (the per-layer kernels' partials: idle here)
                 hipLaunchKernelGGL(bn_stats_finish_wg_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, ws + L.bn_wg,
@@ -1770,7 +1773,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
         return ABN_E_UNSUPPORTED;
     }
     if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) { return bn_planes_backward(t, d_out, rows, n_calls, L, B, ws, scratch, dx, st); }
-    if (t->batch_norm && t->bn_sync_world > 1) {
+    if (t->batch_norm && bn_sync_on(t)) {
         set_error("tower_backward: cross-replica BatchNorm statistics (bn_sync_world) need the operand-plane launches");
         return ABN_E_UNSUPPORTED;
     }

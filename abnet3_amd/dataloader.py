@@ -269,7 +269,7 @@ class OriginalDataLoader(DataLoader):
         (pair k goes to rank k % R), each rank aligns its share and the index lists
         are all-gathered, so that every rank ends up with every alignment."""
         rank, ws = parallel.world()
-        exchange = exchange and ws > 1
+        exchange = exchange and parallel.active()
         keys, queued = [], set()
         for p in same_pairs:
             key = tuple(p) + (frames,)

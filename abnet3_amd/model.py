@@ -128,7 +128,7 @@ class _Segment(object):
         d.last_act = _lib.ACT[self.last_act]
         d.batch_norm = int(self.batch_norm)
         d.precision = _lib.PRECISION[net.precision]
-        if sync is not None and sync.world > 1:       # cross-replica BatchNorm statistics (parallel.BatchNormSync)
+        if sync is not None and sync.world >= 1:      # cross-replica BatchNorm statistics (parallel.BatchNormSync)
             d.bn_sync_world = sync.world
             d.bn_sync_fn = sync.fn
         d.dims[0] = self.input_dim
@@ -262,7 +262,7 @@ class _DropSeed(object):
 
 class _Saved(object):
     """What a segment's forward leaves for its backward."""
-    __slots__ = ('x1', 'x2', 'ws', 'masks', 'n_calls', 'train', 'rows')
+    __slots__ = ('x1', 'x2', 'ws', 'masks', 'n_calls', 'train', 'rows', 'bn_synced')
 
 
 def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
@@ -297,11 +297,30 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
         else:
             masks = seg.masks_of(masks.net._draw_mask_tensors(rows, x1.device))
     desc = seg.descriptor(with_grads=False, masks=masks, forward_only=forward_only)
+    synced = False
+    if train and seg.batch_norm and desc.bn_sync_fn:
+        # Cross-replica statistics exist on the one-launch-per-layer BatchNorm kernels, and those are the kernels of
+        # a forward that keeps what a backward needs.  A train-mode pass under torch.no_grad() (TrainerBuilder.train's
+        # first pass, abnet3/trainer.py:137) asks for them too: the replicas' running statistics must move together.
+        # Where the library would not take that path (fewer than 256 rows: OriginalDataLoader's short ragged batches;
+        # odd widths) the call falls back to per-replica statistics, said once -- not an error.
+        desc = _lib.TowerDesc.from_buffer_copy(desc)
+        desc.forward_only = 0
+        if lib.abn_tower_path(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2), rows, n_calls, 1, _lib.ptr(x1), 0, None) == _lib.PATH_BN_LAYERS:
+            synced = True
+        else:
+            desc.forward_only = int(forward_only)
+            desc.bn_sync_fn, desc.bn_sync_world = None, 0
+            if not getattr(net, '_warned_bn_sync_fallback', False):
+                net._warned_bn_sync_fallback = True
+                import warnings
+                warnings.warn('abnet3_amd: sync_batch_norm: a batch of %d rows does not run on the per-layer BatchNorm '
+                              'launches that carry the cross-replica statistics; such batches use per-replica statistics' % rows)
     ws_floats = lib.abn_tower_ws_floats(_lib.C.byref(desc), rows, n_calls)
     if ws_floats < 0:
         _lib.check(-1, 'abn_tower_ws_floats')
     ws = torch.empty(max(ws_floats, 1), dtype=torch.float32, device=x1.device)
-    if desc.bn_sync_world > 1:
+    if synced:
         net.bn_sync.buffers = [ws]
     _lib.check(lib.abn_tower_forward(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2),
                                      rows, n_calls, int(train), _lib.ptr(ws),
@@ -317,6 +336,7 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
     out = ws[off:off + rows * seg.output_dim].view(rows, seg.output_dim)
     sv = _Saved()
     sv.x1, sv.x2, sv.ws, sv.masks, sv.n_calls, sv.train, sv.rows = x1, x2, ws, masks, n_calls, train, rows
+    sv.bn_synced = synced
     return out, sv
 
 
@@ -341,7 +361,9 @@ def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False, def
     scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32, device=d_out.device)
     dx = torch.empty(rows, seg.input_dim, dtype=torch.float32,
                      device=d_out.device) if need_dx else None
-    if desc.bn_sync_world > 1:
+    if desc.bn_sync_fn and not sv.bn_synced:      # the forward fell back to per-replica statistics: so does its backward
+        desc.bn_sync_fn, desc.bn_sync_world = None, 0
+    if desc.bn_sync_fn:
         seg.net.bn_sync.buffers = [sv.ws, scratch]
     _lib.check(lib.abn_tower_backward(
         _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(d_out), rows,
@@ -632,7 +654,8 @@ class _HipNetwork(NetworkBuilder):
     # buffers, ctypes descriptors and caches -- not part of the description of the
     # network and not picklable
     _HIP_STATE = ('_flat', '_last_grad_flat', '_offsets', '_segs', '_mask_override',
-                  '_generation', '_live_cache', '_weights_epoch', '_pending_reduce', '_fused_loss_refused')
+                  '_generation', '_live_cache', '_weights_epoch', '_pending_reduce', '_fused_loss_refused',
+                  '_pending_lower', 'bn_sync')
 
     def whoami(self):
         """Output description for the neural network and all parameters

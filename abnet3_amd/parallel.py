@@ -33,13 +33,23 @@ def world():
     return 0, 1
 
 
+def active():
+    """Is this a data-parallel run -- do the collectives below execute?  Yes with more than one rank; and with a
+    process group of ONE rank when ABN_DP_SINGLE_RANK=1: every exchange then runs on the real backend (RCCL on the
+    single GPU of a test box) and is the identity, so the run must equal a run without a group bit for bit
+    (tests/test_gpu_dp.py::test_one_rank_on_rccl)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('ABN_DP_SINGLE_RANK') == '1'
+
+
 def init_from_env(backend=None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* if the
     process was launched by torch.distributed.run; returns (rank, world, local)."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if ws > 1 and not dist.is_initialized():
+    if (ws > 1 or os.environ.get('ABN_DP_SINGLE_RANK') == '1') and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
@@ -72,7 +82,7 @@ def all_reduce_gradients(flat_grad, loss_is_mean):
     R ranks x B pairs equal one process with R*B pairs: 1 for a summed loss
     (avg=False, the canonical configuration), 1/R for a mean loss (avg=True)."""
     _, ws = world()
-    if ws == 1:
+    if not active():
         return 1.0
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / ws if loss_is_mean else 1.0
@@ -111,16 +121,14 @@ def shard_batches(iterator, rank, ws, drop_tail=True):
 
 
 def broadcast_parameters(flat_params, src=0):
-    _, ws = world()
-    if ws > 1:
+    if active():
         dist.broadcast(flat_params, src=src)
 
 
 def broadcast_array(arr, src=0):
     """int64 numpy array, same length on every rank -> rank `src`'s values."""
-    _, ws = world()
     arr = np.ascontiguousarray(arr, dtype=np.int64)
-    if ws == 1 or arr.size == 0:
+    if not active() or arr.size == 0:
         return arr
     t = torch.from_numpy(arr.copy()).to(_comm_device())
     dist.broadcast(t, src=src)
@@ -129,9 +137,8 @@ def broadcast_array(arr, src=0):
 
 def all_reduce_min(arr):
     """int64 numpy array, same length on every rank -> elementwise minimum over the ranks."""
-    _, ws = world()
     arr = np.ascontiguousarray(arr, dtype=np.int64)
-    if ws == 1 or arr.size == 0:
+    if not active() or arr.size == 0:
         return arr
     t = torch.from_numpy(arr.copy()).to(_comm_device())
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -142,7 +149,7 @@ def all_gather_varlen(t):
     """1-d tensors of rank-dependent length -> list of every rank's tensor (on t's
     device), in rank order."""
     rank, ws = world()
-    if ws == 1:
+    if not active():
         return [t]
     dev = _comm_device()
     n = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
@@ -171,6 +178,7 @@ class BatchNormSync:
         from . import _lib
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.collective = active()     # (False: no process group -- the sums take the same path, nobody to add them up with)
         self.buffers = []              # the float32 tensors (forward workspace, backward scratch) of the call in flight
         self.calls = 0
         self._cb = _lib.ALLREDUCE_FN(self._allreduce)      # (kept alive with the object)
@@ -183,7 +191,7 @@ class BatchNormSync:
                 if base <= ptr and ptr + 8 * n <= base + t.numel() * t.element_size() and (ptr - base) % 8 == 0:
                     off = (ptr - base) // 4
                     v = t.view(-1)[off:off + 2 * n].view(torch.float64)
-                    if self.world > 1:
+                    if self.collective:
                         dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
                     self.calls += 1
                     return 0

@@ -140,6 +140,7 @@ class TrainerBuilder:
         self.feature_generator = feature_generator
         self.checkpoints = checkpoints
         self.rank, self.world_size = parallel.world()
+        self.dp = parallel.active()         # the collectives of a data-parallel step execute (parallel.active)
 
         if not cuda:
             warnings.warn('abnet3_amd has no CPU path: cuda=False is ignored and '
@@ -162,7 +163,7 @@ class TrainerBuilder:
         else:
             self.optimizer = FlatOptimizer(self.network, optimizer_type, self.lr,
                                            self.momentum)
-        if self.world_size > 1:
+        if self.dp:
             parallel.broadcast_parameters(self.network.flat_parameters())
             if hasattr(self.network, 'weights_changed_behind_torch'):
                 self.network.weights_changed_behind_torch()      # (a rank that already ran a forward holds a stale image)
@@ -352,10 +353,10 @@ class TrainerSiamese(TrainerBuilder):
             self.optimizer.zero_grad()
             # single process: nothing happens between backward and step, so the split-K
             # reduction of the weight gradients rides in the optimizer's launch
-            defer = self.world_size == 1 and self.network.can_defer_reduce(state)
+            defer = not self.dp and self.network.can_defer_reduce(state)
             # data-parallel: the backward in two calls, the all-reduce of the upper layers' gradients in flight while the
             # lower layers' are computed (two buckets of the flat gradient buffer; abn_tower_desc.wgrad_part)
-            split = self._overlap_split(state) if self.world_size > 1 else None
+            split = self._overlap_split(state) if self.dp else None
             # the pair loss inside the backward's first launch, where the library offers it
             loss_value = self.network.direct_backward_loss(
                 state, y_batch, type(self.loss).__name__, getattr(self.loss, 'margin', 0.0), self.loss.avg, defer_reduce=defer,
@@ -379,15 +380,24 @@ class TrainerSiamese(TrainerBuilder):
             else:
                 loss_value, de = self.loss.value_and_grad(emb[:n], emb[n:], y_batch)
                 self.network.direct_backward(state, de.view(2 * n, -1), defer_reduce=defer)
-            if self.world_size > 1:
-                self.optimizer.grad_scale = parallel.all_reduce_gradients(
-                    self.network.flat_grad(), self._loss_is_mean())
+            if self.dp:
+                if split is not None:
+                    # the library did not take the loss into the backward on THIS rank (row count, alignment): the
+                    # other ranks may have -- the same two collectives in the same order, whatever path ran here
+                    flat = self.network.flat_grad()
+                    cut = self.network.grad_split_offset(state, split)
+                    torch.distributed.all_reduce(flat[cut:], op=torch.distributed.ReduceOp.SUM)
+                    torch.distributed.all_reduce(flat[:cut], op=torch.distributed.ReduceOp.SUM)
+                    self.optimizer.grad_scale = 1.0 / self.world_size if self._loss_is_mean() else 1.0
+                else:
+                    self.optimizer.grad_scale = parallel.all_reduce_gradients(
+                        self.network.flat_grad(), self._loss_is_mean())
             self.optimizer.step()
         elif do_training:
             loss_value = self.give_batch_to_network(batch)
             self.optimizer.zero_grad()
             self._backward(loss_value)
-            if self.world_size > 1:
+            if self.dp:
                 self.optimizer.grad_scale = parallel.all_reduce_gradients(
                     self.network.flat_grad(), self._loss_is_mean())
             self.optimizer.step()
@@ -406,12 +416,12 @@ class TrainerSiamese(TrainerBuilder):
         torch.distributed the gradient all-reduce and the optimizer stay
         outside the graph (fwd + bwd are captured).  Adam's bias correction is
         host-computed per step, so its optimizer launch also stays outside."""
-        if getattr(getattr(self.network, 'bn_sync', None), 'world', 1) > 1:
+        if getattr(self.network, 'bn_sync', None) is not None:
             raise NotImplementedError('abnet3_amd: a step with cross-replica BatchNorm statistics calls back to the host '
                                       'between launches (parallel.BatchNormSync) and cannot be captured into a graph')
         static, fwd_loss = self._graph_inputs(example_batch)
         opt = self.optimizer
-        capture_opt = (self.world_size == 1 and isinstance(opt, FlatOptimizer)
+        capture_opt = (not self.dp and isinstance(opt, FlatOptimizer)
                        and opt.kind != 'adam')
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -470,7 +480,7 @@ class TrainerSiamese(TrainerBuilder):
             if capture_opt:
                 opt.step_count += 1
             else:
-                if self.world_size > 1:
+                if self.dp:
                     opt.grad_scale = parallel.all_reduce_gradients(
                         self.network.flat_grad(), self._loss_is_mean())
                 opt.step()
@@ -493,7 +503,7 @@ class TrainerSiamese(TrainerBuilder):
         replayed one even at 100 frame pairs (and ahead of it from ~500-wide towers
         on, where the three input copies of a replay cost more than its launches)."""
         if (not getattr(self, 'graph_steps', False) or not isinstance(self.optimizer, FlatOptimizer)
-                or getattr(getattr(self.network, 'bn_sync', None), 'world', 1) > 1):
+                or getattr(self.network, 'bn_sync', None) is not None):
             return self.train_step(batch, True)
         if not hasattr(self, '_graphs'):
             self._graphs, self._shape_seen = {}, {}
@@ -562,7 +572,7 @@ class TrainerSiamese(TrainerBuilder):
         x12 = b['x12']
         emb, state = net.direct_forward(x12[:npad], x12[npad:])
         opt.zero_grad()
-        defer = self.world_size == 1 and net.can_defer_reduce(state)
+        defer = not self.dp and net.can_defer_reduce(state)
         loss_value = net.direct_backward_loss(state, b['y'], type(self.loss).__name__, getattr(self.loss, 'margin', 0.0),
                                               self.loss.avg, defer_reduce=defer, n_valid=b['nv'], loss_accum=self._loss_acc,
                                               loss_ws=self._loss_ws)
@@ -570,7 +580,7 @@ class TrainerSiamese(TrainerBuilder):
 
     def _bucket_finish(self):
         opt = self.optimizer
-        if self.world_size > 1:
+        if self.dp:
             opt.grad_scale = parallel.all_reduce_gradients(self.network.flat_grad(), self._loss_is_mean())
         opt.step()
 
@@ -588,7 +598,7 @@ class TrainerSiamese(TrainerBuilder):
                                         _lib.ptr(b['x12']), _lib.ptr(b['y']), _lib.ptr(b['nv']), _lib.stream()),
                    'abn_gather_pairs')
         opt = self.optimizer
-        in_graph_opt = self.world_size == 1 and opt.kind != 'adam'      # (Adam's bias correction is host arithmetic per step)
+        in_graph_opt = not self.dp and opt.kind != 'adam'      # (Adam's bias correction is host arithmetic per step)
         if b['graph'] is not None:
             g, grads, flat, pending = b['graph']
             g.replay()
@@ -796,7 +806,7 @@ class TrainerSiamese(TrainerBuilder):
         sums = torch.stack([train_loss, dev_loss])
         counts = torch.tensor([num_batches_train, num_batches_dev], dtype=torch.float64,
                               device=dev_)
-        if self.world_size > 1:
+        if self.dp:
             torch.distributed.all_reduce(sums)
             torch.distributed.all_reduce(counts)
         train_loss, dev_loss = [float(v) for v in sums.cpu()]      # one sync per epoch

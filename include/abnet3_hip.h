@@ -144,12 +144,13 @@ typedef struct abn_tower_desc {
     const void* drop_seed;
     float drop_p;
     int32_t reserved2_;
-    /* Cross-replica BatchNorm statistics (data-parallel training; SURVEY.md 8e's exact mode): bn_sync_world > 1
+    /* Cross-replica BatchNorm statistics (data-parallel training; SURVEY.md 8e's exact mode): bn_sync_fn != NULL with bn_sync_world >= 1
+     * (a group of ONE replica is a group: its reduction is the identity, the launches are the group's)
      * makes a TRAINING forward / backward of a BatchNorm tower sum its per-call statistics -- [sum z, sum z^2] per
      * layer in the forward, [sum dy, sum dy xhat] in the backward, float64 -- over the replicas through bn_sync_fn
      * (called on the host between two launches, once per layer and direction) and normalise with
      * bn_sync_world x rows_per_call rows: R replicas on B rows each then step like one process on R B rows.
-     * 0 / 1: per-replica statistics.  Operand-plane launches only (ABN_E_UNSUPPORTED otherwise). */
+     * bn_sync_fn NULL or bn_sync_world 0: per-replica statistics.  Operand-plane launches only (ABN_E_UNSUPPORTED otherwise). */
     int32_t bn_sync_world;
     int32_t wgrad_split;                   /* see wgrad_part */
     abn_allreduce_fn bn_sync_fn;

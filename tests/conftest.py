@@ -58,10 +58,16 @@ def pytest_configure(config):
                                                 '--repeats', '2', '--dtw-pairs', '200', '--pipeline-utts', '0'],
                                                stdout=log, stderr=subprocess.STDOUT, env=env))
             DP_JOB.update(bench=bprocs)
+            # ... and ONE rank on the real backend (RCCL, a process group of one on this box's single GPU): it waits for
+            # the four processes above to leave the card first (a box allows few processes on its GPU at once)
+            log = open(out + '.rccl.log', 'w')
+            wait = [str(p.pid) for p in procs + bprocs]
+            DP_JOB.update(rccl=subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'rccl_worker.py'), str(_free_port()), out] + wait,
+                                                stdout=log, stderr=subprocess.STDOUT))
 
 
 def pytest_unconfigure(config):
-    for p in DP_JOB.get('procs', []) + DP_JOB.get('bench', []):
+    for p in DP_JOB.get('procs', []) + DP_JOB.get('bench', []) + ([DP_JOB['rccl']] if 'rccl' in DP_JOB else []):
         if p.poll() is None:
             p.kill()
 

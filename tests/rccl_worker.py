@@ -1,0 +1,148 @@
+"""ONE rank on the real backend: torch.distributed's 'nccl' (= RCCL on ROCm) with a process group of one, on the
+single GPU of a test box.  Started as a FRESH process by conftest.py (before pytest touches the GPU); waits for the
+other helper processes to leave the card, then runs every data-parallel code path twice -- without a process group,
+and under the one-rank RCCL group with ABN_DP_SINGLE_RANK=1 (parallel.active(): the collectives execute, and over
+one rank each is the identity) -- and writes both results; tests/test_gpu_dp.py::test_one_rank_on_rccl compares
+them bit for bit.
+
+    python tests/rccl_worker.py PORT OUT_PREFIX [PID_TO_WAIT_FOR ...]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def wait_for(pids, limit=600.0):
+    t0 = time.time()
+    while time.time() - t0 < limit and any(os.path.exists('/proc/%s' % p) and
+                                            open('/proc/%s/stat' % p).read().split(')')[-1].split()[0] != 'Z' for p in pids):
+        time.sleep(0.5)
+
+
+def main():
+    port, out = sys.argv[1], sys.argv[2]
+    wait_for(sys.argv[3:])
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', ABN_DP_SINGLE_RANK='1')
+    import ast
+    import warnings
+    import numpy as np
+    import torch
+    from abnet3_amd import parallel
+    import abnet3_amd.loss as L
+    from abnet3_amd.model import SiameseNetwork
+    from abnet3_amd.trainer import TrainerSiamese
+    from abnet3_amd.dataloader import OriginalDataLoader
+    from conftest import load_golden
+    res = {}
+
+    g = load_golden('train_mid_bn0.npz')
+    kw = ast.literal_eval(str(g['kw']))
+    gb = load_golden('train_mid_bn1.npz')
+    kwb = ast.literal_eval(str(gb['kw']))
+    gl = load_golden('frames_loader.npz')
+    feats = {k[5:]: v for k, v in gl.items() if k.startswith('feat.')}
+    times = {k: np.arange(len(v)) * 0.01 + 0.0025 for k, v in feats.items()}
+
+    def parse(line):
+        t = str(line).split(' ')
+        return (t[0], float(t[1]), float(t[2]), t[3], float(t[4]), float(t[5]), t[6])
+    train = [parse(l) for l in gl['train_pairs']]
+    devp = [parse(l) for l in gl['dev_pairs']]
+
+    def run(tag):
+        grouped = parallel.active()
+        # (1) the single-launch chains, 1600 pairs: the backward in two calls, the upper bucket's all-reduce in
+        # flight under the second (async_op on RCCL's own stream), then the lower bucket's
+        rng = np.random.default_rng(77)
+        B = 1600
+        x1 = rng.standard_normal((B, 40)).astype(np.float32)
+        x2 = (x1 + 0.3 * rng.standard_normal((B, 40))).astype(np.float32)
+        y = rng.choice([1.0, -1.0], B)
+        net = SiameseNetwork(output_path='/tmp/abn_rccl_c', **kw)
+        net.load_state_dict({k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith('p.')})
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1,
+                            dataloader=None, log_dir='/tmp/abn_runs_rccl')
+        assert tr.dp == grouped and tr.overlap_allreduce
+        net.train()
+        batch = (torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), torch.from_numpy(y).cuda())
+        res[tag + '.chain.losses'] = np.array([float(tr.train_step(batch, True)) for _ in range(3)])
+        for k, p in net.named_parameters():
+            res[tag + '.chain.p.' + k] = p.detach().cpu().numpy()
+        # (2) BatchNorm with the statistics going through BatchNormSync (one all-reduce per layer, call pair and
+        # direction, on the launch stream)
+        rngb = np.random.default_rng(321)
+        Bb = 512
+        xb1 = rngb.standard_normal((Bb, 40)).astype(np.float32)
+        xb2 = (xb1 + 0.5 * rngb.standard_normal((Bb, 40))).astype(np.float32)
+        yb = rngb.choice([1.0, -1.0], Bb)
+        net = SiameseNetwork(output_path='/tmp/abn_rccl_bn', **kwb)
+        net.load_state_dict({k[2:]: torch.from_numpy(v.copy()) for k, v in gb.items() if k.startswith('p.')})
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1,
+                            dataloader=None, log_dir='/tmp/abn_runs_rccl', sync_batch_norm=True)
+        if not grouped:
+            net.bn_sync = parallel.BatchNormSync()          # the same launches, nobody to add the sums up with
+        assert net.bn_sync.collective == grouped
+        net.train()
+        batch = (torch.from_numpy(xb1).cuda(), torch.from_numpy(xb2).cuda(), torch.from_numpy(yb).cuda())
+        res[tag + '.bn.losses'] = np.array([float(tr.train_step(batch, True)) for _ in range(3)])
+        res[tag + '.bn.calls'] = np.array(net.bn_sync.calls)
+        for k, v in net.state_dict().items():
+            res[tag + '.bn.p.' + k] = v.detach().cpu().numpy()
+        # (3) TrainerBuilder.train() on planned passes (batch plans + captured steps; under a group the all-reduce and
+        # the optimizer stay outside the graph)
+        np.random.seed(3000)
+        torch.manual_seed(5)
+        pl = OriginalDataLoader('unused', 'unused', batch_size=2)
+        pl.set_data(feats, times, train, devp)
+        net = SiameseNetwork(input_dim=40, num_hidden_layers=1, hidden_dim=64, output_dim=32, p_dropout=0.0,
+                             activation_layer='sigmoid', output_path='/tmp/abn_rccl_planned')
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1, num_epochs=3,
+                            patience=5, dataloader=pl, log_dir='/tmp/abn_runs_rccl')
+        parallel.seed_all(0)           # (what a trainer under a process group does in its constructor: same start for both runs)
+        tr.train()
+        res[tag + '.planned.train_losses'] = np.array(tr.train_losses)
+        res[tag + '.planned.graphs'] = np.array(sum(1 for v in getattr(tr, '_buckets', {}).values() if v['graph'] is not None))
+        for k, p in net.named_parameters():
+            res[tag + '.planned.p.' + k] = p.detach().cpu().numpy()
+        # (4) TrainerBuilder.train() with sync_batch_norm=True on ragged word-pair batches (mostly < 256 rows: those
+        # fall back to per-replica statistics, said once; the first pass runs train mode under no_grad; rank 0 pickles
+        # the description with the BatchNormSync object on the network)
+        np.random.seed(4000)
+        torch.manual_seed(6)
+        pl = OriginalDataLoader('unused', 'unused', batch_size=2)
+        pl.set_data(feats, times, train, devp)
+        net = SiameseNetwork(input_dim=40, num_hidden_layers=1, hidden_dim=64, output_dim=32, p_dropout=0.0,
+                             activation_layer='sigmoid', batch_norm=True, output_path='/tmp/abn_rccl_bn_train')
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1, num_epochs=2,
+                            patience=5, dataloader=pl, log_dir='/tmp/abn_runs_rccl', sync_batch_norm=True)
+        if not grouped:
+            net.bn_sync = parallel.BatchNormSync()
+        parallel.seed_all(0)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter('always')
+            tr.train()
+        res[tag + '.bntrain.train_losses'] = np.array(tr.train_losses)
+        res[tag + '.bntrain.warned'] = np.array(sum('per-replica statistics' in str(w.message) for w in caught))
+        res[tag + '.bntrain.params_file'] = np.array(int(os.path.exists(net.output_path + '.params')))
+        for k, v in net.state_dict().items():
+            res[tag + '.bntrain.p.' + k] = v.detach().cpu().numpy()
+
+    run('plain')
+    assert not parallel.active()
+    parallel.init_from_env('nccl')
+    assert parallel.active() and torch.distributed.get_backend() == 'nccl' and torch.distributed.get_world_size() == 1
+    run('rccl')
+    res['backend'] = np.array(torch.distributed.get_backend())
+    np.savez(out + '.rccl.npz', **res)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    print('rccl worker done', flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -227,3 +227,40 @@ def test_planned_passes_under_two_ranks(ranks):
         tl = r['planned.train_losses']
         assert np.isfinite(tl).all() and len(tl) == 4 and tl[-1] < tl[0]
         assert int(r['planned.graphs']) >= 1
+
+
+def test_one_rank_on_rccl():
+    """The data-parallel step on the REAL backend: torch.distributed 'nccl' = RCCL with a process group of one on this
+    box's single GPU (tests/rccl_worker.py, a fresh process).  Every collective of the step executes -- the two
+    gradient buckets (the first all-reduce asynchronous, under the lower layers' weight gradients), BatchNormSync's
+    per-layer float64 all-reduces on the launch stream, the planned passes with the optimizer outside the graph, the
+    parameter broadcast, the loaders' agreements -- and over one rank each is the identity: the run equals the run
+    without a process group BIT FOR BIT.  (No scaling is measured here: that takes the driver's 8-GPU node.)"""
+    job = conftest.DP_JOB
+    if 'rccl' not in job:
+        pytest.skip('the RCCL worker was not started (run with -m gpu on a GPU box)')
+    p = job['rccl']
+    try:
+        rc = p.wait(timeout=900)
+    except Exception:
+        p.kill()
+        rc = -9
+    log = open(job['out'] + '.rccl.log').read()
+    assert rc == 0, 'RCCL worker failed (%s):\n%s' % (rc, log[-4000:])
+    r = dict(np.load(job['out'] + '.rccl.npz'))
+    assert str(r['backend']) == 'nccl'
+    keys = sorted(k[6:] for k in r if k.startswith('plain.'))
+    assert keys and keys == sorted(k[5:] for k in r if k.startswith('rccl.'))
+    off = {}
+    for k in keys:
+        a, b = r['plain.' + k], r['rccl.' + k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        if not np.array_equal(a, b, equal_nan=False):
+            off[k] = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
+    assert not off, off
+    # the paths that were meant to run, ran
+    assert int(r['rccl.bn.calls']) >= 3 * 2 * 3        # 3 steps x (forward + backward) x one all-reduce per BatchNorm layer
+    assert int(r['rccl.planned.graphs']) >= 1
+    assert r['rccl.planned.train_losses'][-1] < r['rccl.planned.train_losses'][0]
+    assert int(r['rccl.bntrain.warned']) == 1 and int(r['rccl.bntrain.params_file']) == 1
+    assert np.isfinite(r['rccl.bntrain.train_losses']).all()
