@@ -108,7 +108,7 @@ def _traffic(kernel):
     """HBM bytes per launch from the TCC counters (FETCH_SIZE x2 per the gfx950
     correction + WRITE_SIZE), collected by tools/collect_traffic.sh in separate
     --pmc passes and committed under profiles/."""
-    for rnd in ('r03', 'r02', 'r01'):
+    for rnd in ('r04', 'r03', 'r02', 'r01'):
         try:
             t = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc_traffic.json' % rnd)))
             for name, v in t.items():
@@ -223,6 +223,10 @@ def planes_roofline(torch, net, reps=20):
            'peak_note': {'bf16x3': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per algorithmic product',
                          'f16x2': 'dense fp16 MFMA 2500 TFLOP/s / 3 fp16 products per algorithmic product',
                          'bf16': 'dense bf16 MFMA'}[prec],
+           # the same launch priced both ways, so that rounds stay comparable: `frac` = executed-MFMA utilisation
+           # (algorithmic FLOP/s over the dense 16-bit peak divided by the MFMA products one algorithmic product
+           # costs in this arithmetic); `frac_of_dense_16bit_peak` = algorithmic FLOP/s over the raw 2500 TFLOP/s
+           'frac_of_dense_16bit_peak': round(e['achieved'] / BF16_MFMA_PEAK_TFLOPS, 4),
            'frac_of_fp32_mfma_peak': round(e['achieved'] / FP32_MFMA_PEAK_TFLOPS, 4),
            'frac_of_bf16x3_peak': round(e['achieved'] / X3_PEAK_TFLOPS, 4),
            'dominant': dominant,
@@ -233,7 +237,7 @@ def planes_roofline(torch, net, reps=20):
     if e['traffic']:
         gbs = e['traffic'] / (e['avg_launch_us'] * 1e-6) / 1e9
         out['hbm'] = {'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
-                      'note': 'measured TCC traffic per launch (profiles/r03_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, '
+                      'note': 'measured TCC traffic per launch (profiles/r04_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, '
                               'Infinity-Cache hits included) / launch time'}
     for key, v in entries.items():
         if key != dominant:
@@ -496,21 +500,30 @@ def dtw_bench(torch, P, rank, world, reps=3, cpu_pairs=4000):
            'cells_per_gpu': cells, 'ms': round(best * 1e3, 3), 'dropped_pairs': dropped,
            # SURVEY.md 8d names the vector ALU as the binding unit: per cell one CORRECTLY ROUNDED
            # division, glibc's acosf (two polynomials, a second division), a division by pi -- the
-           # reference's arithmetic operation by operation, ~55 VALU instructions -- then the
-           # float64 three-way minimum (~25); the dot products run on the fp32 matrix cores.  The
-           # HBM figure (algorithmic bytes: inputs (N+M)*40*4 + paths <= (N+M)*8) sits beside it;
-           # `traffic` = measured bytes per call (TCC counters, profiles/), ~0.3 B per cell: the
-           # cost matrix never leaves the CU, only 2-bit back-pointers and the paths do.
+           # reference's arithmetic operation by operation -- then the float64 three-way minimum; the dot
+           # products run on the fp32 matrix cores (same rate as the packed vector fma: 32 MAC / clk / SIMD).
+           # `roofline` prices SURVEY's 100 FLOP per cell against the fp32 vector peak.  `hbm`: MEASURED bytes per
+           # call (TCC counters collected under rocprofv3, profiles/) over this run's time -- what the kernel
+           # really pulls -- beside the ALGORITHMIC bytes (inputs once (N+M)*40*4, paths <= (N+M)*8): the
+           # cost matrix never leaves the CU, 2-bit back-pointers and the paths are the writes, the fetches
+           # are token 2's rows once per 32-row band of token 1.
            'roofline': {'bound': 'valu', 'achieved': round(cells * 100.0 / best / 1e12, 2), 'peak': 157.3,
                         'unit': 'TFLOP/s', 'flop_per_cell': 100,
-                        'note': 'VALU-bound: exact division / acosf / pi per cell (all 64 lanes) + N+M-1 sequential '
-                                'anti-diagonals of f64 selects per pair (32 lanes per pair); dot products on the fp32 '
-                                'matrix cores; one fused kernel, matrix kept in LDS',
-                        'traffic': _traffic('dtw_pc_kernel'),
-                        'hbm': {'achieved': round((int((n1.astype(np.int64) + n2).sum()) * 168) / best / 1e9, 2),
-                                'peak': 8000.0, 'unit': 'GB/s'}}}
+                        'note': 'VALU-bound: exact division / acosf / pi per cell (all 64 lanes of a producer wavefront per '
+                                'slot) + N+M-1 sequential anti-diagonals of f64 min / add per band (32 lanes per pair, ~20 '
+                                'instructions per step in the consumer wavefront); dot products on the fp32 matrix cores; '
+                                'one fused kernel, the matrix stays in LDS',
+                        'traffic': _traffic('dtw_gang_kernel')}}
+    alg_bytes = int((n1.astype(np.int64) + n2).sum()) * 168
+    meas = out['roofline']['traffic']
+    out['roofline']['hbm'] = {
+        'measured_bytes_per_call': meas, 'algorithmic_bytes_per_call': alg_bytes, 'peak': 8000.0, 'unit': 'GB/s',
+        'achieved': round(meas / best / 1e9, 2) if meas else None,                       # measured traffic / this run's time
+        'algorithmic_achieved': round(alg_bytes / best / 1e9, 2),
+        'bytes_per_cell_measured': round(meas / cells, 3) if meas else None,
+        'bytes_per_cell_algorithmic': round(alg_bytes / cells, 3)}
     out['roofline']['frac'] = round(out['roofline']['achieved'] / 157.3, 4)
-    out['roofline']['hbm']['frac'] = round(out['roofline']['hbm']['achieved'] / 8000.0, 5)
+    out['roofline']['hbm']['frac'] = round(out['roofline']['hbm']['achieved'] / 8000.0, 5) if meas else None
     if rank == 0 and world == 1:
         from oracle import dtw_oracle
         q = min(cpu_pairs, P)
@@ -674,6 +687,10 @@ def main():
     pool = make_pool(seed=rank, device=dev)    # rank r sees its own pairs
     net.train()
     step = make_stepper(trainer, pool, args.graph)
+    from abnet3_amd import _lib as _L
+    _L.trace_paths = True                      # one untimed step records which kernel family / arithmetic the step takes
+    step(0)
+    _L.trace_paths = False
 
     # untimed, and independent of --warmup: let clocks, allocator and code caches settle
     # (a short `--steps 20 --warmup 5` run otherwise times the first 8 ms after start-up)
@@ -766,7 +783,15 @@ def main():
         # reduction + optimizer, every gap): the number the per-launch fractions have to be read beside
         out['roofline']['whole_step'] = {'achieved': round(value * FLOP_PER_PAIR / world / 1e12, 2), 'unit': 'TFLOP/s',
                                          'frac': round(value * FLOP_PER_PAIR / world / 1e12 / out['roofline']['peak'], 4),
+                                         'frac_of_dense_16bit_peak': round(value * FLOP_PER_PAIR / world / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                                          'ms_per_step': round(elapsed / args.steps * 1e3, 4)}
+        # the arithmetic the step's launches really ran in (abn_tower_path: a 'f16x2' tower that falls to the GEMM
+        # kernels computes in bf16x3 there; C2 stays on the operand planes)
+        from abnet3_amd import _lib as _L
+        if _L.last_path['forward'] >= 0:
+            out['config']['kernel_path'] = {'forward': _L.last_path['forward'], 'backward': _L.last_path['backward'],
+                                            'forward_arithmetic': _L.PRECISION_NAMES.get(_L.last_path['forward_precision']),
+                                            'backward_arithmetic': _L.PRECISION_NAMES.get(_L.last_path['backward_precision'])}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(torch)
             out['cpu_baseline'] = cb
