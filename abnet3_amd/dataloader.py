@@ -128,6 +128,53 @@ class DeviceCorpus(object):
         return self.offset[k] + lo, max(0, hi - lo)
 
 
+class AlignCache(object):
+    """The DTW alignments of a loader: key (f1, s1, e1, f2, s2, e2, frames) -> (idx1, idx2) global-row index tensors on
+    the device, or None for a dropped pair (an empty token, a NaN distance: dataloader.py:188-191).  A batched DTW call
+    returns its paths as two FLAT device tensors; the cache keeps those and, per key, where its path sits in them
+    (`span`: chunk, first element, length) -- the per-key views are made when somebody asks for one (the iterator, the
+    tests), not for all of a dataset's 10^4 pairs at once, and a batch plan gathers straight from the flat tensors."""
+
+    def __init__(self):
+        self.span = {}
+        self.chunks = []                     # [(g1, g2)]: flat int64 device tensors of one share of one align_pairs call
+
+    def add_chunk(self, g1, g2):
+        self.chunks.append((g1, g2))
+        return len(self.chunks) - 1
+
+    def put(self, key, chunk, start, n):
+        self.span[key] = (chunk, start, n) if n else None
+
+    def _views(self, sp):
+        if sp is None:
+            return None
+        c, st, n = sp
+        g1, g2 = self.chunks[c]
+        return g1[st:st + n], g2[st:st + n]
+
+    def __contains__(self, key):
+        return key in self.span
+
+    def __len__(self):
+        return len(self.span)
+
+    def __getitem__(self, key):
+        return self._views(self.span[key])
+
+    def get(self, key, default=None):
+        if key not in self.span:
+            return default
+        return self._views(self.span[key])
+
+    def items(self):
+        for key, sp in self.span.items():
+            yield key, self._views(sp)
+
+    def keys(self):
+        return self.span.keys()
+
+
 class BatchPlan(object):
     """Every batch of a dataset as index lists in HBM: batch b is the frame pairs
     [offsets[b], offsets[b + 1]) of (idx1, idx2, labels) -- global rows of `table` and the pair labels,
@@ -188,7 +235,7 @@ class OriginalDataLoader(DataLoader):
         self.tcl = tcl
         self.train_files = None
         self.pairs = {'train': None, 'dev': None}
-        self._align = {}              # (f1,s1,e1,f2,s2,e2) -> (idx1, idx2) | None
+        self._align = AlignCache()    # (f1,s1,e1,f2,s2,e2,frames) -> (idx1, idx2) | None
 
     def __getstate__(self):
         return (self.pairs_path, self.features_path, self.statistics_training,
@@ -325,12 +372,13 @@ class OriginalDataLoader(DataLoader):
         else:
             shares = [(mine, lens, g1, g2)]
         for keys, lens, g1, g2 in shares:
-            lens = [int(v) for v in lens]
-            v1, v2 = torch.split(g1, lens), torch.split(g2, lens)      # (one call: thousands of views)
-            for key, ln, a, b in zip(keys, lens, v1, v2):
+            lens = np.asarray(lens, dtype=np.int64)
+            chunk = self._align.add_chunk(g1, g2)
+            starts = np.cumsum(lens) - lens
+            for key, st, ln in zip(keys, starts.tolist(), lens.tolist()):
                 # ln == 0: an empty token or a NaN distance: the reference's try/except
                 # drops the pair (dataloader.py:188-191)
-                self._align[key] = (a, b) if ln else None
+                self._align.put(key, chunk, st, ln)
 
     def prefetch_alignments(self):
         """Aligns every 'same' pair of the train and dev sets up front, in one
@@ -466,7 +514,12 @@ class OriginalDataLoader(DataLoader):
         """(idx1, idx2, labels, offsets) of EVERY batch of self.pairs[mode] -- batch b = pairs
         [b * batch_size, (b + 1) * batch_size) -- built once per pairs list: the content of a batch never
         changes between epochs (alignments are cached, the permutation is seeded with 0 every time), only
-        which batches an epoch visits and in which order does."""
+        which batches an epoch visits and in which order does.
+        One pass over the pairs collects, per ENTRY of a batch (frames_from_pairs_device's order: the batch's same
+        pairs, then its diff pairs), where its rows sit in one flat source -- the DTW calls' flat path tensors for a
+        same pair, a host-built index run for a diff pair -- and how many rows / labels it has; everything after that
+        is array arithmetic: one gather index for the whole dataset, the per-batch seed-0 permutations applied to it,
+        one upload, two device gathers."""
         pairs = self.pairs[mode]
         cached = getattr(self, '_plans', {}).get(mode)
         if cached is not None and cached[0] is pairs and cached[1] == len(pairs):
@@ -474,74 +527,89 @@ class OriginalDataLoader(DataLoader):
         self.align_pairs([p[:6] for p in pairs if p[6] == 'same'], exchange=True)
         dev = self.features.table.device
         bs = self.batch_size
-        nb = (len(pairs) + bs - 1) // bs
-        d1, d2 = [], []
-        # frames_from_pairs_device's loop, for all batches at once: same pairs first, then diff pairs
-        per_batch = [[] for _ in range(nb)]  # [(+1 | -1, the aligned index lists | position in d1 / d2, rows, labels)]
-        for b in range(nb):
-            chunk = pairs[b * bs:(b + 1) * bs]
-            same = [p for p in chunk if p[6] == 'same']
-            diff = [p for p in chunk if p[6] == 'diff']
-            assert len(same) + len(diff) == len(chunk), 'Unsupported pair type'
-            for f1, s1, e1, f2, s2, e2, _ in same:
-                if (s1 > e1) or (s2 > e2):
+        P = len(pairs)
+        nb = (P + bs - 1) // bs
+        span, token = self._align.span, self.features.token
+        chunk_base = np.concatenate(([0], np.cumsum([c[0].numel() for c in self._align.chunks]))).astype(np.int64)
+        n_aligned = int(chunk_base[-1])
+        # entries: (batch, 0 same | 1 diff, offset in the source, rows, labels); diff runs are appended behind the paths
+        e_batch, e_kind, e_off, e_rows, e_lab = [], [], [], [], []
+        d_a0, d_b0, d_m = [], [], []             # diff pairs cut to the shorter token: runs a0 .. a0 + m, b0 .. b0 + m
+        d1, d2 = [], []                          # align_different_words: explicit index arrays
+        d_total = 0
+        adw = self.align_different_words
+        for i, (f1, s1, e1, f2, s2, e2, kind) in enumerate(pairs):
+            if (s1 > e1) or (s2 > e2):
+                assert kind in ('same', 'diff'), 'Unsupported pair type'
+                continue
+            if kind == 'same':
+                sp = span.get((f1, s1, e1, f2, s2, e2, False))
+                if sp is None:
                     continue
-                al = self._align.get((f1, s1, e1, f2, s2, e2, False))
-                if al is None:
-                    continue
-                per_batch[b].append((1, al, al[0].shape[0], al[0].shape[0]))
-            for f1, s1, e1, f2, s2, e2, _ in diff:
-                if (s1 > e1) or (s2 > e2):
-                    continue
-                (a0, n1), (b0, n2) = self._token(f1, s1, e1, False), self._token(f2, s2, e2, False)
-                if self.align_different_words:
-                    if n2 < n1:
-                        mn0, mnl, mx0, mxl = b0, n2, a0, n1
-                    else:
-                        mn0, mnl = a0, n1
-                        mx0, mxl = (b0, n2) if n2 > n1 else (a0, n1)
-                    mapping = np.rint(np.linspace(0, mnl - 1, num=mxl)).astype(int)
-                    w1, w2 = mx0 + np.arange(mxl), mn0 + mapping
+                e_batch.append(i // bs); e_kind.append(0); e_off.append(chunk_base[sp[0]] + sp[1]); e_rows.append(sp[2]); e_lab.append(sp[2])
+                continue
+            assert kind == 'diff', 'Unsupported pair type'
+            (a0, n1), (b0, n2) = token(f1, s1, e1), token(f2, s2, e2)
+            if adw:
+                # the shorter word is stretched along the diagonal (dataloader.py:216-225); ties keep the FIRST, like min() / max()
+                if n2 < n1:
+                    mn0, mnl, mx0, mxl = b0, n2, a0, n1
                 else:
-                    m = min(n1, n2)
-                    w1, w2 = a0 + np.arange(m), b0 + np.arange(m)
-                # (the labels count min(n1, n2) frames, dataloader.py:231, whatever the number of rows is)
-                per_batch[b].append((-1, len(d1), len(w1), min(n1, n2)))
-                d1.append(w1.astype(np.int64)); d2.append(w2.astype(np.int64))
-        if d1:
-            lens_d = np.array([len(w) for w in d1], dtype=np.int64)
-            offs_d = np.concatenate(([0], np.cumsum(lens_d)))
-            both = torch.from_numpy(np.concatenate(d1 + d2)).to(dev)
-            dd1, dd2 = both[:both.numel() // 2], both[both.numel() // 2:]
-        parts1, parts2, lab_kind, lab_n, perm, offsets, row0 = [], [], [], [], [], [0], 0
-        for b in range(nb):
-            n, rows = 0, 0
-            for kind, payload, ln, nlab in per_batch[b]:
-                if kind == 1:
-                    parts1.append(payload[0]); parts2.append(payload[1])
-                else:
-                    parts1.append(dd1[offs_d[payload]:offs_d[payload] + ln]); parts2.append(dd2[offs_d[payload]:offs_d[payload] + ln])
-                lab_kind.append(float(kind)); lab_n.append(nlab)
-                n += nlab
-                rows += ln
+                    mn0, mnl = a0, n1
+                    mx0, mxl = (b0, n2) if n2 > n1 else (a0, n1)
+                mapping = np.rint(np.linspace(0, mnl - 1, num=mxl)).astype(int)
+                d1.append((mx0 + np.arange(mxl)).astype(np.int64)); d2.append((mn0 + mapping).astype(np.int64))
+                rows = mxl
+            else:
+                rows = min(n1, n2)
+                d_a0.append(a0); d_b0.append(b0); d_m.append(rows)
+            # (the labels count min(n1, n2) frames, dataloader.py:231, whatever the number of rows is)
+            e_batch.append(i // bs); e_kind.append(1); e_off.append(n_aligned + d_total); e_rows.append(rows); e_lab.append(min(n1, n2))
+            d_total += rows
+        E = len(e_batch)
+        e_batch = np.asarray(e_batch, dtype=np.int64)
+        e_kind = np.asarray(e_kind, dtype=np.int64)
+        e_off = np.asarray(e_off, dtype=np.int64)
+        e_rows = np.asarray(e_rows, dtype=np.int64)
+        e_lab = np.asarray(e_lab, dtype=np.int64)
+        # a batch's same pairs come before its diff pairs, each kind in file order
+        order = np.argsort(e_batch * 2 + e_kind, kind='stable')
+        e_batch, e_kind, e_off, e_rows, e_lab = e_batch[order], e_kind[order], e_off[order], e_rows[order], e_lab[order]
+        rows_b = np.bincount(e_batch, weights=e_rows, minlength=nb).astype(np.int64) if E else np.zeros(nb, dtype=np.int64)
+        lab_b = np.bincount(e_batch, weights=e_lab, minlength=nb).astype(np.int64) if E else np.zeros(nb, dtype=np.int64)
+        offsets = np.concatenate(([0], np.cumsum(lab_b))).astype(np.int64)
+        row0 = np.cumsum(rows_b) - rows_b
+        empty = torch.zeros(0, dtype=torch.int64, device=dev)
+        if E:
+            # the diff pairs' index runs (host arithmetic, one upload), behind the aligned paths in the flat source
+            if adw:
+                dd1 = np.concatenate(d1) if d1 else np.zeros(0, dtype=np.int64)
+                dd2 = np.concatenate(d2) if d2 else np.zeros(0, dtype=np.int64)
+            else:
+                m = np.asarray(d_m, dtype=np.int64)
+                ramp = np.arange(int(m.sum()), dtype=np.int64) - np.repeat(np.cumsum(m) - m, m)
+                dd1 = np.repeat(np.asarray(d_a0, dtype=np.int64), m) + ramp
+                dd2 = np.repeat(np.asarray(d_b0, dtype=np.int64), m) + ramp
+            both = torch.from_numpy(np.concatenate((dd1, dd2))).to(dev)
+            src1 = torch.cat([c[0] for c in self._align.chunks] + [both[:dd1.size]])
+            src2 = torch.cat([c[1] for c in self._align.chunks] + [both[dd1.size:]])
+            R = int(e_rows.sum())
+            gidx = np.repeat(e_off - (np.cumsum(e_rows) - e_rows), e_rows) + np.arange(R, dtype=np.int64)
             # the reference permutes len(y) = n indices and applies them to the rows AND the labels
             # (dataloader.py:247-255): with align_different_words a batch can hold more rows than labels,
             # and the permutation then draws from its first n rows
-            perm.append((row0 + self._seed0_permutation(n), offsets[-1] + self._seed0_permutation(n)))
-            offsets.append(offsets[-1] + n)
-            row0 += rows
-        empty = torch.zeros(0, dtype=torch.int64, device=dev)
-        if parts1:
-            perm_rows = np.concatenate([p[0] for p in perm])
-            perm_lab = np.concatenate([p[1] for p in perm])
-            perm_d = torch.from_numpy(perm_rows).to(dev)
-            i1, i2 = torch.cat(parts1)[perm_d], torch.cat(parts2)[perm_d]
-            y = torch.from_numpy(np.repeat(np.asarray(lab_kind), np.asarray(lab_n, dtype=np.int64))[perm_lab]).to(dev)
+            perm = self._seed0_permutation
+            perms = [perm(int(n)) for n in lab_b]
+            perm_rows = np.concatenate([r0 + q for r0, q in zip(row0.tolist(), perms)])
+            perm_lab = np.concatenate([o + q for o, q in zip(offsets[:-1].tolist(), perms)])
+            take = torch.from_numpy(gidx[perm_rows]).to(dev)
+            i1, i2 = src1[take], src2[take]
+            y = torch.from_numpy(np.repeat(np.where(e_kind == 0, 1.0, -1.0), e_lab)[perm_lab]).to(dev)
         else:
             i1, i2, y = empty, empty, torch.zeros(0, dtype=torch.float64, device=dev)
         # (statistics_training counts a pair every time an epoch visits it: plan() adds these per visited batch)
-        counts = np.array([[sum(1 for e in pb if e[0] == 1), sum(1 for e in pb if e[0] == -1)] for pb in per_batch], dtype=np.int64).reshape(nb, 2)
-        store = (i1, i2, y, np.asarray(offsets, dtype=np.int64), counts, np.array([len(pb) > 0 for pb in per_batch], dtype=bool))
+        counts = np.stack([np.bincount(e_batch[e_kind == 0], minlength=nb), np.bincount(e_batch[e_kind == 1], minlength=nb)], axis=1).astype(np.int64).reshape(nb, 2)
+        store = (i1, i2, y, offsets, counts, counts.sum(axis=1) > 0)
         if not hasattr(self, '_plans'):
             self._plans = {}
         self._plans[mode] = (pairs, len(pairs), store)
@@ -652,35 +720,45 @@ class FramesDataLoader(OriginalDataLoader):
         pairs = group_pairs(pairs)
         self.align_pairs(pairs['same'], exchange=True)     # DTW work split over the ranks
         dev = self.features.table.device
-        i1, i2, ys = [], [], []
+        # where every kept pair's rows sit in one flat source (the DTW calls' flat path tensors, then the diff pairs'
+        # index runs): one gather index for the dataset instead of a view and a label array per pair
+        span, token = self._align.span, self.features.token
+        chunk_base = np.concatenate(([0], np.cumsum([c[0].numel() for c in self._align.chunks]))).astype(np.int64)
+        s_off, s_len = [], []
         for f1, s1, e1, f2, s2, e2 in pairs['same']:
             if (s1 > e1) or (s2 > e2):
                 continue
-            al = self._align.get((f1, s1, e1, f2, s2, e2, False))
-            if al is None:
+            sp = span.get((f1, s1, e1, f2, s2, e2, False))
+            if sp is None:
                 continue
-            i1.append(al[0]); i2.append(al[1])
-            ys.append(np.ones(len(al[0]), dtype=np.int64))
-            self.statistics_training['SameType'] += 1
-        d1, d2 = [], []                       # diff pairs: host index ranges, one upload for all
+            s_off.append(chunk_base[sp[0]] + sp[1]); s_len.append(sp[2])
+        self.statistics_training['SameType'] += len(s_len)
+        d_a0, d_b0, d_m = [], [], []          # diff pairs: index runs cut to the shorter token
         for f1, s1, e1, f2, s2, e2 in pairs['diff']:
             if (s1 > e1) or (s2 > e2):
                 continue
-            (a0, n1), (b0, n2) = self.features.token(f1, s1, e1), self.features.token(f2, s2, e2)
-            m = min(n1, n2)
-            d1.append(np.arange(a0, a0 + m, dtype=np.int64))
-            d2.append(np.arange(b0, b0 + m, dtype=np.int64))
-            ys.append(-np.ones(m, dtype=np.int64))
-            self.statistics_training['DiffType'] += 1
-        if d1:
-            both = torch.from_numpy(np.concatenate(d1 + d2)).to(dev)
-            i1.append(both[:both.numel() // 2])
-            i2.append(both[both.numel() // 2:])
-        if not i1:
+            (a0, n1), (b0, n2) = token(f1, s1, e1), token(f2, s2, e2)
+            d_a0.append(a0); d_b0.append(b0); d_m.append(min(n1, n2))
+        self.statistics_training['DiffType'] += len(d_m)
+        if not s_len and not d_m:
             z = torch.zeros(0, dtype=torch.int64, device=dev)
             return z, z, z
-        i1, i2 = torch.cat(i1), torch.cat(i2)
-        y = torch.from_numpy(np.concatenate(ys)).to(dev)
+        s_off, s_len = np.asarray(s_off, dtype=np.int64), np.asarray(s_len, dtype=np.int64)
+        m = np.asarray(d_m, dtype=np.int64)
+        n_same, n_diff = int(s_len.sum()), int(m.sum())
+        gidx = np.repeat(s_off - (np.cumsum(s_len) - s_len), s_len) + np.arange(n_same, dtype=np.int64)
+        ramp = np.arange(n_diff, dtype=np.int64) - np.repeat(np.cumsum(m) - m, m)
+        dd1 = np.repeat(np.asarray(d_a0, dtype=np.int64), m) + ramp
+        dd2 = np.repeat(np.asarray(d_b0, dtype=np.int64), m) + ramp
+        up = torch.from_numpy(np.concatenate((gidx, dd1, dd2))).to(dev)
+        take, r1, r2 = up[:n_same], up[n_same:n_same + n_diff], up[n_same + n_diff:]
+        if n_same:
+            src1 = torch.cat([c[0] for c in self._align.chunks]) if len(self._align.chunks) > 1 else self._align.chunks[0][0]
+            src2 = torch.cat([c[1] for c in self._align.chunks]) if len(self._align.chunks) > 1 else self._align.chunks[0][1]
+            i1, i2 = torch.cat((src1[take], r1)), torch.cat((src2[take], r2))
+        else:
+            i1, i2 = r1, r2
+        y = torch.cat((torch.ones(n_same, dtype=torch.int64, device=dev), -torch.ones(n_diff, dtype=torch.int64, device=dev)))
         return self._shuffle((i1, i2, y))
 
     @staticmethod
