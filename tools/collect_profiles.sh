@@ -4,9 +4,9 @@
 #   2. FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (kernel-trace only) -> HBM bytes per launch
 #   3. SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / SQ_WAVE_CYCLES / SQ_INSTS_VALU ... pass (matrix-core and VALU use)
 #   4. the same for the small-batch step (planned passes, 485 pairs of 280-d frames: tools/small_batch_probe.py)
-#   tools/collect_profiles.sh r03      (results under gpurun_out/r03*, summaries copied by the caller)
+#   tools/collect_profiles.sh r04      (results under gpurun_out/r03*, summaries copied by the caller)
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
