@@ -50,6 +50,42 @@ struct Switches {
 const Switches& switches();
 void reload_switches();
 
+// ---------------------------------------------------------------------------------------------------------
+// "The last workgroup adds up": every workgroup publishes one float64 partial and draws a ticket; the one that
+// draws the last ticket sums all partials in a FIXED order (deterministic, unlike an atomic sum).  Used by the
+// pair loss (loss.hip) and by the loss phases of the data-gradient launches (tower_planes.h, tower_wide.h).
+//
+// What has to hold: when a workgroup reads ticket n - 1, the other n - 1 partials are visible to it.
+//  * C++ memory model form (-DABN_STRICT_FENCES): the ticket is an acq_rel read-modify-write at agent scope.  On
+//    gfx942 / gfx950 a release at agent scope is `buffer_wbl2 sc1` -- write back EVERY dirty line of this XCD's L2 --
+//    and an acquire `buffer_inv sc1`: with the 3 MB of loss gradients a workgroup has just written that is a
+//    cache-wide flush per workgroup (pair_loss_kernel, 4096 pairs, rocprofv3: 17.6 us against 11.7; tools/loss_fence_ab.py).
+//  * Default form: the partial is stored with a relaxed AGENT-scope atomic store -- per the AMDGPU memory model
+//    (LLVM AMDGPUUsage, gfx942 table: "store atomic monotonic agent: global_store sc1=1") a write-through to the
+//    level all XCDs share --, `s_waitcnt vmcnt(0)` then holds the wave until that store is acknowledged, and only
+//    then is the ticket drawn -- itself a relaxed agent-scope atomic, executed at that same level.  The partials are
+//    read back with relaxed agent-scope atomic loads (sc1: they bypass the non-coherent levels).  The only thing a
+//    release would add is the write-back of the workgroup's OTHER (non-atomic) stores, which the summing workgroup
+//    never reads.  The signal fences keep the compiler from moving the store or the ticket across the drain.
+// Both forms give the same bits (the sum's order is fixed); tools/variants.sh builds the strict one for comparison.
+__device__ __forceinline__ bool abn_ticket_publish(double* slot, double value, unsigned* counter, unsigned n_tickets)
+{
+    __hip_atomic_store(slot, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef ABN_STRICT_FENCES
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    return ticket == n_tickets - 1;
+}
+__device__ __forceinline__ double abn_ticket_partial(const double* slot)
+{
+    return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -150,26 +150,14 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
         double s = 0.0;
 #pragma unroll
         for (int i = 0; i < ROWS_PER_BLOCK; ++i) s += row_term[i];
-        // write-through store, then the ticket: the workgroup that draws the last ticket sums
-        // all partials in a FIXED order (deterministic, unlike an atomic sum) -- the second
-        // launch this used to take
-        // (a write-through store that is drained before the ticket is drawn, read back with
-        // loads that bypass the L1: no release / acquire fence, which would write back and
-        // invalidate whole caches once per workgroup -- measured 23 us instead of 9 for this kernel)
-        __hip_atomic_store(&partial[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (compiler: keep the partial's store in front of the drain and the ticket behind it -- a signal fence costs no
-        // instruction; hardware: the store is write-through and s_waitcnt waits for its acknowledgement)
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        __builtin_amdgcn_s_waitcnt(0);
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = ticket == gridDim.x - 1;
+        // the workgroup that draws the last ticket sums all partials in a fixed order (common.h: abn_ticket_publish)
+        is_last = abn_ticket_publish(&partial[blockIdx.x], s, counter, gridDim.x);
     }
     __syncthreads();
     if (!is_last) return;
     const int64_t n = gridDim.x;
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += abn_ticket_partial(&partial[i]);
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {

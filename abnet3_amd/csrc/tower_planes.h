@@ -113,6 +113,23 @@ __device__ __forceinline__ void scale_of(float m, float& s, float& inv)
     inv = tiny ? 1.0f : __uint_as_float((e - 14u) << 23);
 }
 
+// Two values at once, two instructions per value: hi = fp16(s x) is ONE v_fma_mix (the product s x is exact -- s is a
+// power of two -- so the fused multiply-add rounds once, to fp16: the same number as (_Float16)(s * x)), lo =
+// fp16(s x - hi) another one (the difference is exact in fp32), both written straight into their half of the packed
+// register.  (The compiler finds this form for some of the call sites and a seven-instruction one -- multiply,
+// packed convert, two conversions back, packed fma, packed convert -- for others; the weight-gradient launch, whose
+// vector instructions compete with its MFMAs for the same issue cycles, converts twelve values per lane and step.)
+typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_f16x2_pair(float s, float a, float b, uint32_t& hi, uint32_t& lo)
+{
+    uint32_t h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(s), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(s), "v"(b));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(s), "v"(a), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(s), "v"(b), "v"(h));
+    hi = h; lo = l;
+}
+
 template <int NP>
 __device__ __forceinline__ f32x16 pl_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c)
 {
@@ -133,13 +150,13 @@ __device__ __forceinline__ Frag<NP> make_frag(const f32x4& v0, const f32x4& v1, 
         const bf16x8x3 s = split_bf16x3(v0, v1);
         f.p[0] = s.hi; f.p[1] = s.mid; f.p[2] = s.lo;
     } else if constexpr (NP == 2) {
-        f16x8 hi, lo;
+        u32x4p hi, lo;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float u = (i < 4 ? v0[i] : v1[i - 4]) * scale;
-            const _Float16 h = (_Float16)u;
-            hi[i] = h;
-            lo[i] = (_Float16)(u - (float)h);
+        for (int i = 0; i < 4; ++i) {
+            const float a = i < 2 ? v0[2 * i] : v1[2 * i - 4], b = i < 2 ? v0[2 * i + 1] : v1[2 * i - 3];
+            uint32_t h, l;
+            split_f16x2_pair(scale, a, b, h, l);
+            hi[i] = h; lo[i] = l;
         }
         f.p[0] = __builtin_bit_cast(bf16x8, hi); f.p[1] = __builtin_bit_cast(bf16x8, lo);
     } else {
@@ -1641,20 +1658,12 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
         if (threadIdx.x == 0) {
             double sum = 0.0;
             for (int i = 0; i < 32; ++i) sum += term_s[i];
-            // (write-through store drained before the ticket, partials read back past the L1: loss.hip)
-            __hip_atomic_store(&p.loss_partial[blockIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (compiler: keep the partial's store in front of the drain and the ticket behind it -- a signal fence costs no
-            // instruction; hardware: the store is write-through and s_waitcnt waits for its acknowledgement)
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            __builtin_amdgcn_s_waitcnt(0);
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            const unsigned ticket = __hip_atomic_fetch_add(p.loss_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *is_last_s = ticket == gridDim.x - 1;
+            *is_last_s = abn_ticket_publish(&p.loss_partial[blockIdx.x], sum, p.loss_counter, gridDim.x);      // (common.h)
         }
         __syncthreads();
         if (*is_last_s && wave == 0) {                            // the last workgroup to arrive: fixed-order sum of all partials
             double sum = 0.0;
-            for (int i = lane; i < (int)gridDim.x; i += 64) sum += __hip_atomic_load(&p.loss_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = lane; i < (int)gridDim.x; i += 64) sum += abn_ticket_partial(&p.loss_partial[i]);
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
             if (lane == 0) {
@@ -2265,11 +2274,15 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
 #endif
             const bool real = k < n_steps;
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 v0 = real ? __builtin_bit_cast(f32x4, rq[slot][0]) : z4;
-            const f32x4 v1 = real ? __builtin_bit_cast(f32x4, rq[slot][1]) : z4;
-            const f32x4 v2 = real ? __builtin_bit_cast(f32x4, rq[slot][2]) : z4;
+            // steps past the slab's end (the loop runs in fours) contribute zeros: for fp16 x 2 through a ZERO SCALE
+            // -- the loads are clamped re-reads of real, finite values -- instead of twelve selects per lane and step
+            const bool by_scale = NP == 2;
+            const f32x4 v0 = real || by_scale ? __builtin_bit_cast(f32x4, rq[slot][0]) : z4;
+            const f32x4 v1 = real || by_scale ? __builtin_bit_cast(f32x4, rq[slot][1]) : z4;
+            const f32x4 v2 = real || by_scale ? __builtin_bit_cast(f32x4, rq[slot][2]) : z4;
+            const float scw = real ? sc_whole : 0.0f, sch = real ? sc_half : 0.0f;
             char* const st = smem + (k % WG_STAGES) * PSTAGE + lane * 16;
-            store_frag<NP>(st + wave * (NP * 1024), make_frag<NP>(v0, v1, sc_whole));
+            store_frag<NP>(st + wave * (NP * 1024), make_frag<NP>(v0, v1, NP == 2 ? scw : sc_whole));
             // the half tile: four values -> 8 bytes per plane
             char* const sh = st + hb * (NP * 1024) + hh * 8;
             if constexpr (NP == 3) {
@@ -2286,16 +2299,11 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
                 *reinterpret_cast<bf16x4*>(sh + 1024) = pm;
                 *reinterpret_cast<bf16x4*>(sh + 2048) = pl;
             } else {
-                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-                f16x4 ph, pl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float u = v2[e] * sc_half;
-                    const _Float16 hq = (_Float16)u;
-                    ph[e] = hq; pl[e] = (_Float16)(u - (float)hq);
-                }
-                *reinterpret_cast<f16x4*>(sh) = ph;
-                *reinterpret_cast<f16x4*>(sh + 1024) = pl;
+                uint2 ph, pl;
+                split_f16x2_pair(sch, v2[0], v2[1], ph.x, pl.x);
+                split_f16x2_pair(sch, v2[2], v2[3], ph.y, pl.y);
+                *reinterpret_cast<uint2*>(sh) = ph;
+                *reinterpret_cast<uint2*>(sh + 1024) = pl;
             }
         };
         if (n_steps > 0) {

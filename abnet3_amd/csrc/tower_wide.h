@@ -477,17 +477,12 @@ __global__ __launch_bounds__(PL_NT) void wide_dgrad_layer_kernel(WideBwdP p)
                 if (threadIdx.x == 0) {
                     double sum = 0.0;
                     for (int i = 0; i < 32; ++i) sum += term_s[i];
-                    __hip_atomic_store(&p.loss_partial[lb], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                    __builtin_amdgcn_s_waitcnt(0);
-                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                    const unsigned ticket = __hip_atomic_fetch_add(p.loss_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *is_last_s = ticket == (unsigned)p.wpc - 1;
+                    *is_last_s = abn_ticket_publish(&p.loss_partial[lb], sum, p.loss_counter, (unsigned)p.wpc);      // (common.h)
                 }
                 __syncthreads();
                 if (*is_last_s && wave == 0) {
                     double sum = 0.0;
-                    for (int i = lane; i < p.wpc; i += 64) sum += __hip_atomic_load(&p.loss_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int i = lane; i < p.wpc; i += 64) sum += abn_ticket_partial(&p.loss_partial[i]);
 #pragma unroll
                     for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
                     if (lane == 0) {

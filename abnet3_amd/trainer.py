@@ -557,6 +557,19 @@ class TrainerSiamese(TrainerBuilder):
             self._bucket_pool = torch.cuda.graph_pool_handle()
             self._loss_acc = torch.zeros((), dtype=torch.float64, device=plan.table.device)
             self._loss_ws = torch.zeros(1 << 16, dtype=torch.uint8, device=plan.table.device)     # (ticket + partial sums of the in-backward loss)
+            # a failed or aborted launch may leave the ticket counter non-zero, and every later planned step or replay
+            # would then elect the wrong "last" workgroup: on a library error the scratch and the graphs that captured
+            # its address are dropped (the next pass allocates and captures afresh)
+            import weakref
+            me = weakref.ref(self)
+
+            def _drop_planned_state():
+                t = me()
+                if t is not None:
+                    t.__dict__.pop('_loss_ws', None)
+                    t.__dict__.pop('_buckets', None)
+                    t.__dict__.pop('_eval_buckets', None)
+            _lib._ON_ERROR.append(_drop_planned_state)
         key = (npad, plan.table.shape[1], plan.labels.dtype)
         b = st.get(key)
         if b is None:
