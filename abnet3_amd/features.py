@@ -223,6 +223,65 @@ class FeaturesGenerator:
         times = {k: np.arange(int(n), dtype=float) * 0.01 + 0.0025 for k, n in zip(names, nfr)}
         return table, names, nfr, times
 
+    def generate(self):
+        """The file-level entry point the gridsearch calls (abnet3/features.py:365-404, gridsearch.py:206-215): the wav
+        files of `self.files` (a directory or a list) -> filterbanks -> [normalisation] -> [stacking] ->
+        `self.output_path`, an h5features file with one item per wav (its basename), frame times
+        0.0025 + 0.01 k (features.py:195) and float32 features.  The stages run on the whole corpus in HBM
+        (features_from_waves: one launch per stage; the reference's two temporary h5features files do not exist);
+        statistics over a VAD's frames only and injected statistics (load_mean_variance_path) go through
+        normalize_features; save_mean_variance_path is honoured.  Needs the h5features package for the output
+        (absent from the build image: features_from_waves is the in-memory form)."""
+        import os
+        from scipy.io import wavfile
+        if self.method != 'fbanks':
+            raise ValueError("Method %s not authorized." % self.method if self.method != 'mfcc' else
+                             "abnet3_amd: method 'mfcc' is not on the accelerated path (filterbanks only)")
+        files = self.files
+        if isinstance(files, str):
+            if not os.path.isdir(files):
+                raise ValueError("files must be a directory or a list of files")
+            files = [os.path.join(files, f) for f in sorted(os.listdir(files)) if f.endswith('.wav')]
+        try:
+            import h5features
+        except ImportError:
+            raise ImportError('FeaturesGenerator.generate() writes an h5features file like the reference; the '
+                              'h5features package is not installed.  Use features_from_waves() on in-memory audio.')
+        names, waves, rate = [], [], None
+        for f in files:
+            srate, sound = wavfile.read(f)
+            if rate is not None and srate != rate:
+                raise ValueError('abnet3_amd: %s is sampled at %d Hz, the files before it at %d' % (f, srate, rate))
+            rate = srate
+            names.append(os.path.basename(os.path.splitext(f)[0]))
+            waves.append(sound)
+        special = self.normalization and (self.vad_file is not None or self.load_mean_variance_path is not None)
+        keep_norm, keep_stack = self.normalization, self.stack
+        if special or (self.normalization and self.save_mean_variance_path):
+            self.normalization = self.stack = False          # filterbanks only; the other stages follow below
+        try:
+            table, names, nfr, times = self.features_from_waves(waves, rate, names)
+        finally:
+            self.normalization, self.stack = keep_norm, keep_stack
+        offs = np.concatenate(([0], np.cumsum(nfr))).astype(np.int64)
+        if special or (self.normalization and self.save_mean_variance_path):
+            from .utils import read_vad_file
+            feats = {k: table[offs[i]:offs[i + 1]].cpu().numpy() for i, k in enumerate(names)}
+            params = self.load_mean_variance(self.load_mean_variance_path) if self.load_mean_variance_path is not None else None
+            vad = read_vad_file(self.vad_file) if self.vad_file is not None else None
+            feats, stats = self.normalize_features(feats, times, vad, params)
+            if self.save_mean_variance_path and not self.norm_per_file:
+                self.save_mean_variance(np.atleast_1d(stats[0]), np.atleast_1d(stats[1]), self.save_mean_variance_path)
+            if self.stack:
+                feats = {k: self.stack_fbanks(v, nframes=self.nframes) for k, v in feats.items()}
+            arrays = [np.ascontiguousarray(feats[k], dtype=np.float32) for k in names]
+        else:
+            host = table.cpu().numpy()
+            arrays = [host[offs[i]:offs[i + 1]] for i in range(len(names))]
+        if os.path.dirname(self.output_path):
+            os.makedirs(os.path.dirname(self.output_path), exist_ok=True)
+        h5features.write(self.output_path, '/features/', names, [times[k] for k in names], arrays)
+
     def do_fbank(self, fname):
         """Compute standard filterbanks from a wav file (features.py:99-114)."""
         from scipy.io import wavfile
