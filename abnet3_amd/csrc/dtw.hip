@@ -954,30 +954,20 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
     ABN_REQUIRE(feats1 && feats2 && off1_host && n1_host && off2_host && n2_host && path1 && path2 && path_len && ws &&
                     host_stage,
                 "dtw: null pointer");
-    int64_t maxlen = 0;
-    for (int64_t p = 0; p < npairs; ++p) {
-        ABN_REQUIRE(n1_host[p] >= 0 && n2_host[p] >= 0, "dtw: negative token length at pair %lld", (long long)p);
-        ABN_REQUIRE(off1_host[p] >= 0 && off1_host[p] + n1_host[p] <= rows1 && off2_host[p] >= 0 &&
-                        off2_host[p] + n2_host[p] <= rows2,
-                    "dtw: pair %lld reads outside the feature arrays", (long long)p);
-        const int64_t need = (int64_t)n1_host[p] + n2_host[p] - 1;
-        maxlen = need > maxlen ? need : maxlen;
-    }
-    ABN_REQUIRE(path_stride >= maxlen, "dtw: path_stride %lld < longest possible path %lld", (long long)path_stride,
-                (long long)maxlen);
-    ABN_REQUIRE(rows1 * D < (1LL << 62) && rows2 * D < (1LL << 62), "dtw: feature array too large");
-    const WsPlan w = plan_ws(n1_host, n2_host, npairs);
-    if (ws_bytes < w.total) { set_error("dtw: workspace too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)w.total); return ABN_E_WORKSPACE; }
     const int64_t meta_bytes = align_up(npairs * (int64_t)sizeof(PairMeta), 256);
     if (host_stage_bytes < meta_bytes + align_up(npairs * 4, 256)) { set_error("dtw: host staging buffer too small"); return ABN_E_WORKSPACE; }
-
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)ws;
     PairMeta* hm = (PairMeta*)host_stage;
     int32_t* hord = (int32_t*)((char*)host_stage + meta_bytes);
-    int64_t dwords = 0;
+    // one pass over the pairs: validation, the pairs' metadata, the longest path
+    int64_t maxlen = 0, dwords = 0;
     for (int64_t p = 0; p < npairs; ++p) {
         const int64_t a = n1_host[p], b = n2_host[p];
+        ABN_REQUIRE(a >= 0 && b >= 0, "dtw: negative token length at pair %lld", (long long)p);
+        ABN_REQUIRE(off1_host[p] >= 0 && off1_host[p] + a <= rows1 && off2_host[p] >= 0 && off2_host[p] + b <= rows2,
+                    "dtw: pair %lld reads outside the feature arrays", (long long)p);
+        maxlen = a + b - 1 > maxlen ? a + b - 1 : maxlen;
         hm[p].off1 = off1_host[p]; hm[p].off2 = off2_host[p];
         hm[p].n1 = (int32_t)a; hm[p].n2 = (int32_t)b;
         hm[p].dir_off = dwords;
@@ -985,6 +975,11 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
         hm[p].nrounds = (int32_t)((b + 2 * BAND - 1) / BAND);
         if (a > 0 && b > 0) dwords += (int64_t)hm[p].nbands * 2 * hm[p].nrounds * BAND;
     }
+    ABN_REQUIRE(path_stride >= maxlen, "dtw: path_stride %lld < longest possible path %lld", (long long)path_stride,
+                (long long)maxlen);
+    ABN_REQUIRE(rows1 * D < (1LL << 62) && rows2 * D < (1LL << 62), "dtw: feature array too large");
+    const WsPlan w = plan_ws(n1_host, n2_host, npairs);
+    if (ws_bytes < w.total) { set_error("dtw: workspace too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)w.total); return ABN_E_WORKSPACE; }
     // Work queue: largest pairs first (the short ones fill the tail), empty pairs never queued.
     // A counting sort over the number of rounds a pair needs (clamped: the order among giants is free).
     int64_t nq = 0;

@@ -259,10 +259,10 @@ def dtw_align_batch(feats1, off1, n1, feats2, off2, n2):
     stride = int(max(1, (n1.astype(np.int64) + n2).max() - 1)) if P else 1
     path1 = torch.empty(P, stride, dtype=torch.int32, device=dev)
     path2 = torch.empty(P, stride, dtype=torch.int32, device=dev)
-    plen = torch.zeros(P, dtype=torch.int32, device=dev)
-    cost = torch.zeros(P, dtype=torch.float64, device=dev)
     if P == 0:
-        return DtwBatchResult(path1, path2, plen, cost)
+        return DtwBatchResult(path1, path2, torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.float64, device=dev))
+    plen = torch.empty(P, dtype=torch.int32, device=dev)         # (abn_dtw_batched clears both: dropped and empty pairs keep 0)
+    cost = torch.empty(P, dtype=torch.float64, device=dev)
     vp = ctypes.c_void_p
     a = lambda arr: arr.ctypes.data_as(vp)
     ws_bytes = lib.abn_dtw_ws_bytes(a(n1), a(n2), P, feats1.shape[0], feats2.shape[0])
