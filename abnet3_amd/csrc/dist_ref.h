@@ -276,97 +276,6 @@ __device__ __forceinline__ f32x2 angular_distance_plain2(f32x2 dot, float nx, f3
     return div_pi2(acosf_ref2(div_normal2(dot, splat2(nx) * ny)));
 }
 
-// ---------------------------------------------------------------------------------------
-// ... and on FOUR cells: the same statements on 4-vectors, which the compiler issues as two
-// independent chains of packed instructions -- a wave alone on its SIMD is bound by the latency
-// of the dependent chain, two chains fill the gaps.  Element by element the same operations.
-// ---------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-typedef int32_t i32x4v __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
-__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ u32x4v bits4(f32x4 v) { return __builtin_bit_cast(u32x4v, v); }
-__device__ __forceinline__ f32x4 float4_of(u32x4v v) { return __builtin_bit_cast(f32x4, v); }
-__device__ __forceinline__ bool any4(i32x4v c) { return (c.x | c.y | c.z | c.w) != 0; }
-
-__device__ __forceinline__ f32x4 div_normal4(f32x4 a, f32x4 b)
-{
-    f32x4 y = f32x4{__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y), __builtin_amdgcn_rcpf(b.z), __builtin_amdgcn_rcpf(b.w)};
-    const f32x4 e = fma4(-b, y, splat4(1.0f));
-    y = fma4(e, y, y);
-    f32x4 q = a * y;
-    f32x4 r = fma4(-b, q, a);
-    q = fma4(r, y, q);
-    r = fma4(-b, q, a);
-    return fma4(r, y, q);
-}
-
-__device__ __forceinline__ f32x4 sqrt_normal4(f32x4 x)
-{
-    const f32x4 s = f32x4{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y), __builtin_amdgcn_sqrtf(x.z), __builtin_amdgcn_sqrtf(x.w)};
-    const f32x4 sdn = float4_of(bits4(s) - 1u), sup = float4_of(bits4(s) + 1u);
-    const f32x4 rdn = fma4(-sdn, s, x), rup = fma4(-sup, s, x);
-    f32x4 t = (splat4(0.0f) >= rdn) ? sdn : s;
-    t = (splat4(0.0f) < rup) ? sup : t;
-    return t;
-}
-
-__device__ __forceinline__ f32x4 div_pi4(f32x4 a)
-{
-    const f32x4 pi_f = splat4(bits_f32(0x40490fdbu)), inv_pi = splat4(bits_f32(0x3ea2f983u));
-    const f32x4 q = a * inv_pi;
-    const f32x4 r = fma4(-q, pi_f, a);
-    return fma4(r, inv_pi, q);
-}
-
-__device__ __forceinline__ f32x4 acosf_ref4(f32x4 x)
-{
-    const f32x4 one = splat4(1.0f);
-    const f32x4 pi = splat4(bits_f32(0x40490fdau)), pio2_hi = splat4(bits_f32(0x3fc90fdau)), pio2_lo = splat4(bits_f32(0x33a22168u));
-    const f32x4 pS0 = splat4(bits_f32(0x3e2aaaabu)), pS1 = splat4(-bits_f32(0x3ea6b090u)), pS2 = splat4(bits_f32(0x3e4e0aa8u)),
-                pS3 = splat4(-bits_f32(0x3d241146u)), pS4 = splat4(bits_f32(0x3a4f7f04u)), pS5 = splat4(bits_f32(0x3811ef08u));
-    const f32x4 qS1 = splat4(-bits_f32(0x4019d139u)), qS2 = splat4(bits_f32(0x4001572du)), qS3 = splat4(-bits_f32(0x3f303361u)),
-                qS4 = splat4(bits_f32(0x3d9dc62eu));
-    const u32x4v hx = bits4(x), ix = hx & 0x7fffffffu;
-    const f32x4 ax = float4_of(ix);
-    const i32x4v small = ix < 0x3f000000u;
-    const f32x4 z = small ? x * x : (one - ax) * splat4(0.5f);
-    const f32x4 p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-    const f32x4 q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-    const f32x4 r = div_normal4(p, q);
-    f32x4 res = pio2_hi - (x - (pio2_lo - x * r));
-    if (__any(any4(~small))) {
-        const f32x4 s = sqrt_normal4(z);
-        const f32x4 wn = r * s - pio2_lo;
-        const f32x4 neg = pi - splat4(2.0f) * (s + wn);
-        f32x4 big = neg;
-        const i32x4v posb = (~small) & (__builtin_bit_cast(i32x4v, hx) >= 0);
-        if (__any(any4(posb))) {
-            const f32x4 df = float4_of(bits4(s) & 0xfffff000u);
-            const f32x4 c = div_normal4(z - df * df, s + df);
-            const f32x4 wp = r * s + c;
-            big = posb ? splat4(2.0f) * (df + wp) : neg;
-        }
-        res = small ? res : big;
-    }
-    const i32x4v tiny = ix <= 0x32800000u, ge1 = ix >= 0x3f800000u;
-    if (__any(any4(tiny | ge1))) {
-        res = tiny ? pio2_hi + pio2_lo : res;
-        const f32x4 at1 = (__builtin_bit_cast(i32x4v, hx) > 0) ? splat4(0.0f) : pi + splat4(2.0f) * pio2_lo;
-        res = (ix == 0x3f800000u) ? at1 : res;
-        res = (ix > 0x3f800000u) ? splat4(__builtin_nanf("")) : res;
-    }
-    return res;
-}
-
-// four cells of one row of x (norm nx) against four rows of y: the PLAIN path of angular_distance_ref
-__device__ __forceinline__ f32x4 angular_distance_plain4(f32x4 dot, float nx, f32x4 ny)
-{
-    return div_pi4(acosf_ref4(div_normal4(dot, splat4(nx) * ny)));
-}
-
 // is the norm inside the range angular_distance_ref<true> is valid for?
 __device__ __forceinline__ bool norm_is_plain(float v) { return v >= 9.094947e-13f && v <= 1.0995116e12f; }
 

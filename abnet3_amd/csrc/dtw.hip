@@ -465,9 +465,6 @@ __device__ __forceinline__ double dpp_shr1_f64(double v)      // lane l <- lane 
 #ifndef ABN_GANG_OCC
 #define ABN_GANG_OCC 4
 #endif
-#ifndef ABN_GANG_ILP
-#define ABN_GANG_ILP 0
-#endif
 #ifndef ABN_GANG_YPF
 #define ABN_GANG_YPF 1       // the producer requests its rows a round ahead
 #endif
@@ -587,15 +584,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                     if (u * BAND + 8 * g >= M) break;                       // columns past the token's end: never read by the sweep
                     const float4 ny4 = *reinterpret_cast<const float4*>(&ny_s[q][8 * g + 4 * half]);
                     const float nyv[4] = {ny4.x, ny4.y, ny4.z, ny4.w};
-                    if constexpr (decltype(pl)::value) {          // four cells = two chains of packed instructions (dist_ref.h)
-#if ABN_GANG_ILP
-                        const f32x4 dv = angular_distance_plain4(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, nx, f32x4{nyv[0], nyv[1], nyv[2], nyv[3]});
-                        ob |= (__float_as_uint(dv.x) | __float_as_uint(dv.y)) | (__float_as_uint(dv.z) | __float_as_uint(dv.w));   // padded rows / columns repeat real ones: no masking needed
-                        out[(8 * g) * BAND] = dv.x;
-                        out[(8 * g + 1) * BAND] = dv.y;
-                        out[(8 * g + 2) * BAND] = dv.z;
-                        out[(8 * g + 3) * BAND] = dv.w;
-#else
+                    if constexpr (decltype(pl)::value) {          // two cells per instruction (dist_ref.h)
 #pragma unroll
                         for (int e = 0; e < 4; e += 2) {
 #ifndef ABN_EXP_NOEPI
@@ -607,7 +596,6 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                             out[(8 * g + e) * BAND] = dv.x;
                             out[(8 * g + e + 1) * BAND] = dv.y;
                         }
-#endif
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {

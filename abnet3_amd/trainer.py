@@ -560,16 +560,17 @@ class TrainerSiamese(TrainerBuilder):
             # a failed or aborted launch may leave the ticket counter non-zero, and every later planned step or replay
             # would then elect the wrong "last" workgroup: on a library error the scratch and the graphs that captured
             # its address are dropped (the next pass allocates and captures afresh)
-            import weakref
-            me = weakref.ref(self)
+            if not getattr(self, '_error_hook', False):        # (once per trainer)
+                self._error_hook = True
+                import weakref
+                me = weakref.ref(self)
 
-            def _drop_planned_state():
-                t = me()
-                if t is not None:
-                    t.__dict__.pop('_loss_ws', None)
-                    t.__dict__.pop('_buckets', None)
-                    t.__dict__.pop('_eval_buckets', None)
-            _lib._ON_ERROR.append(_drop_planned_state)
+                def _drop_planned_state():
+                    t = me()
+                    if t is not None:
+                        t.__dict__.pop('_loss_ws', None)
+                        t.__dict__.pop('_buckets', None)
+                _lib._ON_ERROR.append(_drop_planned_state)
         key = (npad, plan.table.shape[1], plan.labels.dtype)
         b = st.get(key)
         if b is None:
