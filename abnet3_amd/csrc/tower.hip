@@ -51,6 +51,7 @@ static Switches read_switches()
     if (s.wide_max_groups < 1 || s.wide_max_groups > WD_MAXG) s.wide_max_groups = WD_MAXG;
     s.dtw_f40 = !off("ABN_DTW_F40");
     s.dtw_pc = !off("ABN_DTW_PC");
+    s.wgrad_tile128 = getenv("ABN_WGRAD_TILE128") && atoi(getenv("ABN_WGRAD_TILE128")) != 0;
     s.dtw_wgs_per_cu = getenv("ABN_DTW_WGS") ? atoi(getenv("ABN_DTW_WGS")) : 6;
     if (s.dtw_wgs_per_cu < 1 || s.dtw_wgs_per_cu > 9) s.dtw_wgs_per_cu = 6;
     return s;
@@ -930,11 +931,11 @@ static int split_count(int64_t rows, int64_t out_dim, int64_t in_dim)
 
 // The same for a tower the planes kernels can take (tower_planes.h, whichever path runs in the end):
 // their weight-gradient tiles are up to 256 x 256, so a layer needs more slices to spread over the CUs.
-static int planes_split_count(int64_t rows, int64_t out_dim, int64_t in_dim)
+static int planes_split_count(int64_t rows, int64_t out_dim, int64_t in_dim, bool np2 = false)
 {
     int shape, bn, bk;
     const int nblk = pl_blocks(out_dim), kblk = pl_blocks(in_dim + 1);
-    wgrad_shape(nblk, kblk, &shape, &bn, &bk);
+    wgrad_shape(nblk, kblk, &shape, &bn, &bk, switches().wgrad_tile128 && np2);
     const int64_t tiles = (int64_t)((nblk + bn - 1) / bn) * ((kblk + bk - 1) / bk);
     // ~128 workgroups per layer.  The light shapes (first / output layer: half-empty tiles, small slabs) may be cut
     // twice as fine: at C2 every CU then gets one heavy workgroup (32 row steps) and one light one (8) -- with
@@ -986,8 +987,8 @@ static BwdLayout make_bwd_layout(const abn_tower_desc* t, int64_t rows)
     for (int l = 0; l < t->n_layers; ++l) {
         // (one count whichever kernels run the backward of a tower the operand-plane kernels could take: abn_tower_reduce_step
         // is told the descriptor and the row count only)
-        B.splits[l] = planes_dims_ok(t) ? planes_split_count(rows, t->dims[l + 1], t->dims[l]) : split_count(rows, t->dims[l + 1], t->dims[l]);
-        B.psplits[l] = planes_dims_ok(t) ? planes_split_count(rows, t->dims[l + 1], t->dims[l]) : B.splits[l];
+        B.splits[l] = planes_dims_ok(t) ? planes_split_count(rows, t->dims[l + 1], t->dims[l], planes_of(t) == 2) : split_count(rows, t->dims[l + 1], t->dims[l]);
+        B.psplits[l] = planes_dims_ok(t) ? planes_split_count(rows, t->dims[l + 1], t->dims[l], planes_of(t) == 2) : B.splits[l];
         smax = B.splits[l] > smax ? B.splits[l] : smax;
         smax = B.psplits[l] > smax ? B.psplits[l] : smax;
     }
@@ -1059,7 +1060,7 @@ static WgradP make_wgrad(const abn_tower_desc* t, int64_t rows, const Layout& L,
         W.N = (int)t->dims[l + 1]; W.K = (int)t->dims[l];
         W.nblk = pl_blocks(W.N); W.kblk = pl_blocks(W.K + 1);
         int bn, bk;
-        wgrad_shape(W.nblk, W.kblk, &W.shape, &bn, &bk);
+        wgrad_shape(W.nblk, W.kblk, &W.shape, &bn, &bk, switches().wgrad_tile128 && planes_of(t) == 2);
         W.tiles_n = (W.nblk + bn - 1) / bn; W.tiles_k = (W.kblk + bk - 1) / bk;
         W.splits = B.splits[l];
         W.first_wg = n_wg;

@@ -2084,8 +2084,11 @@ static inline int wgrad_slots(const WgradP& p, int x)
     }
     return slots;
 }
-static inline void wgrad_shape(int nblk, int kblk, int* shape, int* bn, int* bk)
+static inline void wgrad_shape(int nblk, int kblk, int* shape, int* bn, int* bk, bool small_tiles = false)
 {
+    // shape 3 (experiment, ABN_WGRAD_TILE128=1, fp16 x 2 only): 128 x 128 tiles -- twice the tiles, so half the slabs
+    // for the same number of workgroups (half the slab bytes written and re-read), twice the row steps per workgroup
+    if (small_tiles && kblk > 2 && nblk > 4) { *shape = 3; *bn = 4; *bk = 4; return; }
     if (kblk <= 2) { *shape = 1; *bn = 8; *bk = 2; }
     else if (nblk <= 4) { *shape = 2; *bn = 4; *bk = 8; }
     else { *shape = 0; *bn = 8; *bk = 4; }
@@ -2154,7 +2157,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
     // same DMAs for every step (clamped repeats past the end), so "my part of step c + 1 has landed"
     // is vmcnt((WG_STAGES - 3) steps' worth of my DMAs).
     auto step_at = [&](int c) { return s_begin + (c < n_steps ? c : n_steps - 1); };
-    static_assert(PER_WAVE == 2, "n_mine is 1 or 2 below");
+    static_assert(PER_WAVE == 2 || NP >= 2, "n_mine is 1 or 2 below (the DMA path)");
     auto wait_steps_left = [&](auto steps_tag) {
         constexpr int S = decltype(steps_tag)::value;
         if (n_mine == 2) wait_vmcnt<S * 2 * DI>();
@@ -2213,9 +2216,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
 #endif
         constexpr int RD = NP == 2 ? WG_DEPTH2 : WG_REG_DEPTH;
         static_assert(RD == 4 || RD == 8, "slot arithmetic below");
-        static_assert(NB > PL_WAVES && NB <= 12, "one whole tile per wave plus halves of the rest");
-        constexpr int NHALF = 2 * (NB - PL_WAVES);                 // 1 KB halves of the tiles 8 .. NB-1 (8: one each; 4: shared, written twice)
-        const int hb = PL_WAVES + ((wave % NHALF) >> 1), hh = wave & 1;          // this wave's half: tile hb, elements 4 hh .. 4 hh + 3
+        static_assert(NB >= PL_WAVES && NB <= 12, "one whole tile per wave plus halves of the rest");
+        constexpr bool HALVES = NB > PL_WAVES;                     // (NB == 8, the 128 x 128 tile: every wave converts exactly one tile)
+        constexpr int NHALF = HALVES ? 2 * (NB - PL_WAVES) : 1;    // 1 KB halves of the tiles 8 .. NB-1 (8: one each; 4: shared, written twice)
+        const int hb = HALVES ? PL_WAVES + ((wave % NHALF) >> 1) : 0, hh = wave & 1;          // this wave's half: tile hb, elements 4 hh .. 4 hh + 3
         auto image_of = [&](int b) -> const char* {
             const bool is_dz = b < BN;
             const int ob = is_dz ? nb0 + b : kb0 + (b - BN);
@@ -2265,7 +2269,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
 #else
             rq[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs0, lane * 16, off, 0);
             rq[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs0, lane * 16, off + 1024, 0);
-            rq[slot][2] = __builtin_amdgcn_raw_buffer_load_b128(rs1, lane * 16, off + hh * 1024, 0);
+            if constexpr (HALVES) rq[slot][2] = __builtin_amdgcn_raw_buffer_load_b128(rs1, lane * 16, off + hh * 1024, 0);
 #endif
         };
         auto convert = [&](int slot, int k) {
@@ -2279,13 +2283,14 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
             const bool by_scale = NP == 2;
             const f32x4 v0 = real || by_scale ? __builtin_bit_cast(f32x4, rq[slot][0]) : z4;
             const f32x4 v1 = real || by_scale ? __builtin_bit_cast(f32x4, rq[slot][1]) : z4;
-            const f32x4 v2 = real || by_scale ? __builtin_bit_cast(f32x4, rq[slot][2]) : z4;
+            const f32x4 v2 = HALVES && (real || by_scale) ? __builtin_bit_cast(f32x4, rq[slot][2]) : z4;
             const float scw = real ? sc_whole : 0.0f, sch = real ? sc_half : 0.0f;
             char* const st = smem + (k % WG_STAGES) * PSTAGE + lane * 16;
             store_frag<NP>(st + wave * (NP * 1024), make_frag<NP>(v0, v1, NP == 2 ? scw : sc_whole));
             // the half tile: four values -> 8 bytes per plane
             char* const sh = st + hb * (NP * 1024) + hh * 8;
-            if constexpr (NP == 3) {
+            if constexpr (!HALVES) {
+            } else if constexpr (NP == 3) {
                 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                 bf16x4 ph, pm, pl;
 #pragma unroll
@@ -2410,7 +2415,8 @@ __global__ __launch_bounds__(PL_NT) void wgrad_planes_kernel(WgradP p)
     const int s_begin = (int)(p.tp_steps * split / L.splits), s_end = (int)(p.tp_steps * (split + 1) / L.splits);
     if (L.shape == 0) wgrad_tile<NP, 2, 2, 4, 2>(p, L, wg_smem, 8 * tn, 4 * tk, s_begin, s_end, split, wave, lane);
     else if (L.shape == 1) wgrad_tile<NP, 1, 2, 8, 1>(p, L, wg_smem, 8 * tn, 2 * tk, s_begin, s_end, split, wave, lane);
-    else wgrad_tile<NP, 2, 2, 2, 4>(p, L, wg_smem, 4 * tn, 8 * tk, s_begin, s_end, split, wave, lane);
+    else if (L.shape == 2) wgrad_tile<NP, 2, 2, 2, 4>(p, L, wg_smem, 4 * tn, 8 * tk, s_begin, s_end, split, wave, lane);
+    else if constexpr (NP == 2) wgrad_tile<NP, 1, 2, 4, 2>(p, L, wg_smem, 4 * tn, 4 * tk, s_begin, s_end, split, wave, lane);     // shape 3 (fp16 x 2 only)
 }
 
 }  // namespace abn
