@@ -41,7 +41,7 @@ struct Switches {
     bool bwd_pair;            // ABN_BWD_PAIR=0: wgrad and dgrad of a layer as two grids
     int gemm_tile;            // ABN_GEMM_TILE=0..3: force a tile shape
     bool dtw_f40, dtw_pc;     // ABN_DTW_F40=0 / ABN_DTW_PC=0: the general DTW kernels
-    bool wgrad_tile128;       // ABN_WGRAD_TILE128=1 (experiment): 128 x 128 weight-gradient tiles, half the slabs (fp16 x 2)
+    int wgrad_tile128;        // ABN_WGRAD_TILE128: 128 x 128 weight-gradient tiles (fp16 x 2) never (0) / always (1) / from 4096 rows (default)
     int dtw_wgs_per_cu;       // ABN_DTW_WGS: workgroups per CU of the gang DTW kernel's persistent grid (default 6)
     int64_t wgrad_rows_per_slab;   // ABN_WGRAD_ROWS_PER_SLAB: fewest batch rows one split-K slab of the weight gradients sums (default 128)
     bool wide;                // ABN_WIDE=0: small batches on the single-launch chains / per-layer GEMMs, not tower_wide.h

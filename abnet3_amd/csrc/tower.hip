@@ -51,7 +51,7 @@ static Switches read_switches()
     if (s.wide_max_groups < 1 || s.wide_max_groups > WD_MAXG) s.wide_max_groups = WD_MAXG;
     s.dtw_f40 = !off("ABN_DTW_F40");
     s.dtw_pc = !off("ABN_DTW_PC");
-    s.wgrad_tile128 = getenv("ABN_WGRAD_TILE128") && atoi(getenv("ABN_WGRAD_TILE128")) != 0;
+    s.wgrad_tile128 = getenv("ABN_WGRAD_TILE128") ? atoi(getenv("ABN_WGRAD_TILE128")) : -1;
     s.dtw_wgs_per_cu = getenv("ABN_DTW_WGS") ? atoi(getenv("ABN_DTW_WGS")) : 6;
     if (s.dtw_wgs_per_cu < 1 || s.dtw_wgs_per_cu > 9) s.dtw_wgs_per_cu = 6;
     return s;
@@ -744,6 +744,14 @@ static inline int planes_of(const abn_tower_desc* t) { return t->precision == 3 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES(3))); \
     } while (0)
 static inline size_t wgrad_lds_of(int np) { return np == 3 ? wgrad_lds_bytes<3>() : (np == 2 ? wgrad_lds_bytes<2>() : wgrad_lds_bytes<1>()); }
+// the launch's dynamic LDS: the largest stage ring of the table's shapes (shape 3, 8 operand blocks per row step, needs
+// 4 x 8 x 2 KB: two workgroups fit a CU)
+static inline size_t wgrad_launch_lds(int np, const WgradP& w)
+{
+    bool all3 = np == 2 && w.n_layers > 0;
+    for (int i = 0; i < w.n_layers; ++i) all3 = all3 && w.L[i].shape == 3;
+    return all3 ? (size_t)4 * 8 * 2048 + 128 : wgrad_lds_of(np);
+}
 // the arithmetic the GEMM kernels (gemm_f32.h, tower_fused.h) run a precision in: fp16 x 2 exists on the operand planes only
 static inline int gemm_prec(int precision) { return precision > 2 ? 2 : precision; }
 // cross-replica BatchNorm statistics are on: a function to sum them with, for a group of bn_sync_world >= 1 replicas
@@ -931,11 +939,18 @@ static int split_count(int64_t rows, int64_t out_dim, int64_t in_dim)
 
 // The same for a tower the planes kernels can take (tower_planes.h, whichever path runs in the end):
 // their weight-gradient tiles are up to 256 x 256, so a layer needs more slices to spread over the CUs.
+// 128 x 128 weight-gradient tiles (shape 3, fp16 x 2): from 4096 tower rows on (rows rounded up to 64 like the slices below, so
+// that a batch and its padded form agree); ABN_WGRAD_TILE128 = 0 / 1 forces never / always
+static inline bool wgrad_tile128(int64_t rows, bool np2)
+{
+    const int mode = switches().wgrad_tile128;
+    return np2 && mode != 0 && (mode > 0 || (rows + 63) / 64 * 64 >= 4096);
+}
 static int planes_split_count(int64_t rows, int64_t out_dim, int64_t in_dim, bool np2 = false)
 {
     int shape, bn, bk;
     const int nblk = pl_blocks(out_dim), kblk = pl_blocks(in_dim + 1);
-    wgrad_shape(nblk, kblk, &shape, &bn, &bk, switches().wgrad_tile128 && np2);
+    wgrad_shape(nblk, kblk, &shape, &bn, &bk, wgrad_tile128(rows, np2));
     const int64_t tiles = (int64_t)((nblk + bn - 1) / bn) * ((kblk + bk - 1) / bk);
     // ~128 workgroups per layer.  The light shapes (first / output layer: half-empty tiles, small slabs) may be cut
     // twice as fine: at C2 every CU then gets one heavy workgroup (32 row steps) and one light one (8) -- with
@@ -1060,7 +1075,7 @@ static WgradP make_wgrad(const abn_tower_desc* t, int64_t rows, const Layout& L,
         W.N = (int)t->dims[l + 1]; W.K = (int)t->dims[l];
         W.nblk = pl_blocks(W.N); W.kblk = pl_blocks(W.K + 1);
         int bn, bk;
-        wgrad_shape(W.nblk, W.kblk, &W.shape, &bn, &bk, switches().wgrad_tile128 && planes_of(t) == 2);
+        wgrad_shape(W.nblk, W.kblk, &W.shape, &bn, &bk, wgrad_tile128(rows, planes_of(t) == 2));
         W.tiles_n = (W.nblk + bn - 1) / bn; W.tiles_k = (W.kblk + bk - 1) / bk;
         W.splits = B.splits[l];
         W.first_wg = n_wg;
@@ -1179,7 +1194,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     int n_wg = 0;
     WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
     w.tp_steps = tp_steps;
-    PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_of(np), st, w);
+    PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_launch_lds(np, w), st, w);
     ABN_CHECK_LAUNCH("tower_backward (BatchNorm, planes)");
     if (t->defer_reduce) return ABN_OK;               // abn_tower_reduce_step finishes the job (the slabs of THIS launch: psplits)
     const ReduceTable rt = make_reduce_table(t, B);
@@ -1251,7 +1266,7 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
     const dim3 cgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
     const bool do_dgrad = part != PLANES_BWD_WGRAD, do_wgrad = part != PLANES_BWD_DGRAD;
     if (do_dgrad) PL_LAUNCH(np, tower_dgrad_planes_kernel, cgrid, dim3(PL_NT), pl_lds_bytes(np), st, b);
-    if (do_wgrad && n_wg > 0) PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_of(np), st, w);
+    if (do_wgrad && n_wg > 0) PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_launch_lds(np, w), st, w);
     ABN_CHECK_LAUNCH("tower_backward (planes)");
     if (t->defer_reduce) return ABN_OK;      // abn_tower_reduce_step finishes the job
     ReduceTable rt = make_reduce_table(t, B);
@@ -1335,7 +1350,7 @@ static int wide_backward(const abn_tower_desc* t, const float* d_out, const Loss
     int n_wg = 0;
     WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg, l_first, l_end);
     w.tp_steps = 2 * nrb;
-    if (n_wg > 0) PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_lds_of(np), st, w);
+    if (n_wg > 0) PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_launch_lds(np, w), st, w);
     ABN_CHECK_LAUNCH("tower_backward (layer per launch)");
     if (t->defer_reduce) return ABN_OK;               // abn_tower_reduce_step finishes the job
     ReduceTable rt = make_reduce_table(t, B);

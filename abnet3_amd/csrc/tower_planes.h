@@ -2086,9 +2086,11 @@ static inline int wgrad_slots(const WgradP& p, int x)
 }
 static inline void wgrad_shape(int nblk, int kblk, int* shape, int* bn, int* bk, bool small_tiles = false)
 {
-    // shape 3 (experiment, ABN_WGRAD_TILE128=1, fp16 x 2 only): 128 x 128 tiles -- twice the tiles, so half the slabs
-    // for the same number of workgroups (half the slab bytes written and re-read), twice the row steps per workgroup
-    if (small_tiles && kblk > 2 && nblk > 4) { *shape = 3; *bn = 4; *bk = 4; return; }
+    // shape 3 (fp16 x 2, large batches: tower.hip wgrad_tile128): 128 x 128 tiles for EVERY layer -- eight operand blocks per row
+    // step, so the launch needs 64 KB of LDS instead of 96 and TWO workgroups share a CU: the light layers' workgroups run beside
+    // the heavy ones instead of behind them, and two workgroups out of step fill each other's barrier waits (C2: -4 us per step,
+    // with BatchNorm -14; the 500 x 500 layers also write half the slab bytes).  Small batches keep the wider tiles (485 pairs: +2 us)
+    if (small_tiles) { *shape = 3; *bn = 4; *bk = 4; return; }      // (every layer: the launch then needs 64 KB of LDS, two workgroups per CU)
     if (kblk <= 2) { *shape = 1; *bn = 8; *bk = 2; }
     else if (nblk <= 4) { *shape = 2; *bn = 4; *bk = 8; }
     else { *shape = 0; *bn = 8; *bk = 4; }
@@ -2235,7 +2237,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         float sc_whole = 1.0f, sc_half = 1.0f;
         auto slab_scales = [&]() {
         if constexpr (NP == 2) {
-            float* const red = reinterpret_cast<float*>(smem + WG_STAGES * WG_MAX_BLOCKS * (NP * 1024));      // [2][8]
+            float* const red = reinterpret_cast<float*>(smem + WG_STAGES * PSTAGE);      // [2][8], behind this shape's stages
             const int rb0 = s_begin >> 1, cnt = (((s_end + 1) >> 1) - rb0) * PL_AMAX;
             float md = 0.0f, ma = 0.0f;
             for (int i = threadIdx.x; i < cnt; i += PL_NT) {

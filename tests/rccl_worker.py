@@ -16,10 +16,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
+def alive(pid):
+    """Is the process still running (a zombie waiting for its parent's wait() has left the GPU: not alive)?"""
+    try:
+        with open('/proc/%s/stat' % pid) as fh:
+            return fh.read().split(')')[-1].split()[0] != 'Z'
+    except (FileNotFoundError, ProcessLookupError, IndexError):
+        return False
+
+
 def wait_for(pids, limit=600.0):
     t0 = time.time()
-    while time.time() - t0 < limit and any(os.path.exists('/proc/%s' % p) and
-                                            open('/proc/%s/stat' % p).read().split(')')[-1].split()[0] != 'Z' for p in pids):
+    while time.time() - t0 < limit and any(alive(p) for p in pids):
         time.sleep(0.5)
 
 
