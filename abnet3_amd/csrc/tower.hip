@@ -746,11 +746,31 @@ static inline int planes_of(const abn_tower_desc* t) { return t->precision == 3 
 static inline size_t wgrad_lds_of(int np) { return np == 3 ? wgrad_lds_bytes<3>() : (np == 2 ? wgrad_lds_bytes<2>() : wgrad_lds_bytes<1>()); }
 // the launch's dynamic LDS: the largest stage ring of the table's shapes (shape 3, 8 operand blocks per row step, needs
 // 4 x 8 x 2 KB: two workgroups fit a CU)
-static inline size_t wgrad_launch_lds(int np, const WgradP& w)
+static inline bool wgrad_all128(int np, const WgradP& w)
 {
     bool all3 = np == 2 && w.n_layers > 0;
     for (int i = 0; i < w.n_layers; ++i) all3 = all3 && w.L[i].shape == 3;
-    return all3 ? (size_t)4 * 8 * 2048 + 128 : wgrad_lds_of(np);
+    return all3;
+}
+constexpr size_t WGRAD128_LDS = (size_t)4 * 8 * 2048 + 128;
+// every layer on 128 x 128 tiles: the shape's own kernel (fewer registers, 64 KB of LDS: two workgroups per CU); else the general one
+static void launch_wgrad(int np, const WgradP& w, int n_wg, hipStream_t st)
+{
+#ifndef WG128_GENERAL
+    if (wgrad_all128(np, w)) {
+        static bool attr_set[16] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev = (dev >= 0 && dev < 16) ? dev : 0;
+        if (!attr_set[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_planes128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGRAD128_LDS);
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(wgrad_planes128_kernel, dim3((unsigned)n_wg), dim3(PL_NT), WGRAD128_LDS, st, w);
+        return;
+    }
+#endif
+    PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_all128(np, w) ? WGRAD128_LDS : wgrad_lds_of(np), st, w);
 }
 // the arithmetic the GEMM kernels (gemm_f32.h, tower_fused.h) run a precision in: fp16 x 2 exists on the operand planes only
 static inline int gemm_prec(int precision) { return precision > 2 ? 2 : precision; }
@@ -1194,7 +1214,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
     int n_wg = 0;
     WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
     w.tp_steps = tp_steps;
-    PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_launch_lds(np, w), st, w);
+    launch_wgrad(np, w, n_wg, st);
     ABN_CHECK_LAUNCH("tower_backward (BatchNorm, planes)");
     if (t->defer_reduce) return ABN_OK;               // abn_tower_reduce_step finishes the job (the slabs of THIS launch: psplits)
     const ReduceTable rt = make_reduce_table(t, B);
@@ -1266,7 +1286,7 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
     const dim3 cgrid((unsigned)((rows + PL_ROWS - 1) / PL_ROWS));
     const bool do_dgrad = part != PLANES_BWD_WGRAD, do_wgrad = part != PLANES_BWD_DGRAD;
     if (do_dgrad) PL_LAUNCH(np, tower_dgrad_planes_kernel, cgrid, dim3(PL_NT), pl_lds_bytes(np), st, b);
-    if (do_wgrad && n_wg > 0) PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_launch_lds(np, w), st, w);
+    if (do_wgrad && n_wg > 0) launch_wgrad(np, w, n_wg, st);
     ABN_CHECK_LAUNCH("tower_backward (planes)");
     if (t->defer_reduce) return ABN_OK;      // abn_tower_reduce_step finishes the job
     ReduceTable rt = make_reduce_table(t, B);
@@ -1350,7 +1370,7 @@ static int wide_backward(const abn_tower_desc* t, const float* d_out, const Loss
     int n_wg = 0;
     WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg, l_first, l_end);
     w.tp_steps = 2 * nrb;
-    if (n_wg > 0) PL_LAUNCH(np, wgrad_planes_kernel, dim3((unsigned)n_wg), dim3(PL_NT), wgrad_launch_lds(np, w), st, w);
+    if (n_wg > 0) launch_wgrad(np, w, n_wg, st);
     ABN_CHECK_LAUNCH("tower_backward (layer per launch)");
     if (t->defer_reduce) return ABN_OK;               // abn_tower_reduce_step finishes the job
     ReduceTable rt = make_reduce_table(t, B);

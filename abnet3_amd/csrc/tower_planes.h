@@ -2381,18 +2381,15 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
     }
 }
 
-template <int NP>
-__global__ __launch_bounds__(PL_NT) void wgrad_planes_kernel(WgradP p)
+// blockIdx -> (layer, slab, tile) of the launch's table
+__device__ __forceinline__ bool wgrad_place(const WgradP& p, int& li, int& tn, int& tk, int& split)
 {
-    extern __shared__ __attribute__((aligned(16))) char wg_smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int li = 0, tk, tn, split;
+    li = 0;
     if (p.xcd_groups) {
         const int x = blockIdx.x & 7;
         int slot = blockIdx.x >> 3, g0 = 0;
         for (;; ++li) {
-            if (li == p.n_layers) return;          // this x has fewer slots than the grid's eighth
+            if (li == p.n_layers) return false;    // this x has fewer slots than the grid's eighth
             int first;
             const int G = p.L[li].tiles_n * p.L[li].tiles_k;
             const int cnt = wgrad_group_count(g0, p.L[li].splits, x, &first);
@@ -2401,18 +2398,45 @@ __global__ __launch_bounds__(PL_NT) void wgrad_planes_kernel(WgradP p)
                 slot %= G;
                 tk = slot % p.L[li].tiles_k;
                 tn = slot / p.L[li].tiles_k;
-                break;
+                return true;
             }
             slot -= cnt * G;
             g0 += p.L[li].splits;
         }
-    } else {
-        while (li + 1 < p.n_layers && (int)blockIdx.x >= p.L[li + 1].first_wg) ++li;
-        int local = blockIdx.x - p.L[li].first_wg;
-        tk = local % p.L[li].tiles_k; local /= p.L[li].tiles_k;
-        tn = local % p.L[li].tiles_n; local /= p.L[li].tiles_n;
-        split = local;
     }
+    while (li + 1 < p.n_layers && (int)blockIdx.x >= p.L[li + 1].first_wg) ++li;
+    int local = blockIdx.x - p.L[li].first_wg;
+    tk = local % p.L[li].tiles_k; local /= p.L[li].tiles_k;
+    tn = local % p.L[li].tiles_n; local /= p.L[li].tiles_n;
+    split = local;
+    return true;
+}
+
+// Every layer on 128 x 128 tiles (shape 3, fp16 x 2): a kernel of its own, so that its registers are counted for
+// this shape alone -- 128 instead of the general kernel's 173 -- and TWO workgroups (sixteen waves) share a CU.
+#ifndef WG128_WAVES_PER_EU
+#define WG128_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(PL_NT) __attribute__((amdgpu_waves_per_eu(WG128_WAVES_PER_EU, WG128_WAVES_PER_EU))) void wgrad_planes128_kernel(WgradP p)
+{
+    extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int li, tk, tn, split;
+    if (!wgrad_place(p, li, tn, tk, split)) return;
+    const WgradLayer& L = p.L[li];
+    const int s_begin = (int)(p.tp_steps * split / L.splits), s_end = (int)(p.tp_steps * (split + 1) / L.splits);
+    wgrad_tile<2, 1, 2, 4, 2>(p, L, wg_smem, 4 * tn, 4 * tk, s_begin, s_end, split, wave, lane);
+}
+
+template <int NP>
+__global__ __launch_bounds__(PL_NT) void wgrad_planes_kernel(WgradP p)
+{
+    extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int li, tk, tn, split;
+    if (!wgrad_place(p, li, tn, tk, split)) return;
     const WgradLayer& L = p.L[li];
     const int s_begin = (int)(p.tp_steps * split / L.splits), s_end = (int)(p.tp_steps * (split + 1) / L.splits);
     if (L.shape == 0) wgrad_tile<NP, 2, 2, 4, 2>(p, L, wg_smem, 8 * tn, 4 * tk, s_begin, s_end, split, wave, lane);
