@@ -51,6 +51,8 @@ static Switches read_switches()
     if (s.wide_max_groups < 1 || s.wide_max_groups > WD_MAXG) s.wide_max_groups = WD_MAXG;
     s.dtw_f40 = !off("ABN_DTW_F40");
     s.dtw_pc = !off("ABN_DTW_PC");
+    s.wgrad_wgs_heavy = getenv("ABN_WGRAD_WGS_HEAVY") ? atoi(getenv("ABN_WGRAD_WGS_HEAVY")) : 128;
+    s.wgrad_wgs_light = getenv("ABN_WGRAD_WGS_LIGHT") ? atoi(getenv("ABN_WGRAD_WGS_LIGHT")) : 128;
     s.wgrad_tile128 = getenv("ABN_WGRAD_TILE128") ? atoi(getenv("ABN_WGRAD_TILE128")) : -1;
     s.dtw_wgs_per_cu = getenv("ABN_DTW_WGS") ? atoi(getenv("ABN_DTW_WGS")) : 6;
     if (s.dtw_wgs_per_cu < 1 || s.dtw_wgs_per_cu > 9) s.dtw_wgs_per_cu = 6;
@@ -976,6 +978,7 @@ static int planes_split_count(int64_t rows, int64_t out_dim, int64_t in_dim, boo
     // twice as fine: at C2 every CU then gets one heavy workgroup (32 row steps) and one light one (8) -- with
     // 16-step light ones half the CUs idled through the launch's tail
     int64_t s = (128 + tiles - 1) / tiles;
+    if (shape == 3) { const int64_t want = tiles >= 16 ? switches().wgrad_wgs_heavy : switches().wgrad_wgs_light; s = (want + tiles - 1) / tiles; }
     // (rows rounded up to 64: a Siamese batch of n pairs and the same batch padded to ceil32(n) pairs -- the
     // captured steps of the trainer's planned passes -- get the same slices, hence bit-identical gradients)
     const int64_t r64 = (rows + 63) / 64 * 64;
@@ -1104,6 +1107,9 @@ static WgradP make_wgrad(const abn_tower_desc* t, int64_t rows, const Layout& L,
     }
     // (ABN_WGRAD_XCD=0: workgroups in launch order, A/B measurements)
     w.xcd_groups = switches().wgrad_xcd;
+#ifdef ABN_STAMPS
+    w.stamps = getenv("ABN_WSTAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_WSTAMP_BUF"), nullptr, 0) : nullptr;
+#endif
     if (w.xcd_groups) {
         int most = 0;
         for (int x = 0; x < 8; ++x) most = wgrad_slots(w, x) > most ? wgrad_slots(w, x) : most;

@@ -2063,6 +2063,9 @@ struct WgradP {
     int64_t slab_stride;   // floats
     int64_t tp_steps;
     int xcd_groups;        // workgroup -> (layer, slab, tile) through wgrad_place (0: in launch order, first_wg)
+#ifdef ABN_STAMPS
+    unsigned long long* stamps;     // diagnostic build: [workgroup][16] s_memtime at start / loop entry / loop exit / end, N * 1024 + K, steps, XCC_ID, HW_ID, after 16 / 32 / 48 steps
+#endif
 };
 
 // Placement.  The tiles_n * tiles_k tiles of one (layer, slab) -- a group -- read the same row steps of the
@@ -2149,6 +2152,21 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         for (int j = 0; j < TK; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+#ifdef ABN_STAMPS
+#define WSTAMP(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+    WSTAMP(0);
+    if (p.stamps && threadIdx.x == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.stamps[(size_t)blockIdx.x * 16 + 4] = (unsigned long long)(L.N * 1024 + L.K);
+        p.stamps[(size_t)blockIdx.x * 16 + 5] = (unsigned long long)(s_end - s_begin);
+        p.stamps[(size_t)blockIdx.x * 16 + 6] = xcc & 15;
+        p.stamps[(size_t)blockIdx.x * 16 + 7] = hwid;
+    }
+#else
+#define WSTAMP(slot) do {} while (0)
+#endif
 
     // blocks past the matrix are padding: a wave whose blocks all are skips the MFMAs (not the DMAs or barriers)
     const bool live = nb0 + wn * TN < L.nblk && kb0 + wk * TK < L.kblk;
@@ -2211,8 +2229,9 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         // with step c + 6; read step c + 1's fragments (second register set); step c's MFMAs.  The loop
         // runs to a multiple of four steps: steps past the end are written as zeros.
         static_assert(WG_STAGES == 4, "stage arithmetic below");
-        // register ring depth: steps in flight ahead of the split (fp16 x 2 has the registers for eight, -DWG_DEPTH2=8:
-        // 0.1747 against 0.1735 ms / step with four -- the loads are not what is exposed)
+        // register ring depth: steps in flight ahead of the split (-DWG_DEPTH2=8: 0.1747 against 0.1735 ms / step with four on the wide
+        // tiles; on the 128 x 128 kernel eight spill (52 bytes at its 128 registers: 56 against 45 us), and eight with ONE fragment set
+        // instead of two fit and give 47.2 against 47.9 with four -- the loads are not what is exposed)
 #ifndef WG_DEPTH2
 #define WG_DEPTH2 4
 #endif
@@ -2322,7 +2341,11 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
             __syncthreads();
             read_frags(fr[0], 0);
         }
+        WSTAMP(1);
         for (int c0 = 0; c0 < n4; c0 += RD) {
+#ifdef ABN_STAMPS
+            if (c0 == 16) WSTAMP(8); else if (c0 == 32) WSTAMP(9); else if (c0 == 48) WSTAMP(10);
+#endif
 #pragma unroll
             for (int i = 0; i < RD; ++i) {
                 const int c = c0 + i;
@@ -2362,6 +2385,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped repeats still target this workgroup's LDS
+    WSTAMP(2);
 
     // acc[i][j][q] of lane (c, h): row n = 32 (nb0 + wn TN + i) + (q & 3) + 8 (q >> 2) + 4 h, column k = 32 (kb0 + wk TK + j) + c
     float* const slab = p.slabs + (int64_t)split * p.slab_stride + L.slab_off;
@@ -2379,6 +2403,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, const WgradLayer& L,
                 }
         }
     }
+    WSTAMP(3);
 }
 
 // blockIdx -> (layer, slab, tile) of the launch's table
