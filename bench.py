@@ -71,8 +71,9 @@ def kernel_names(prec):
         return ('void abn::tower_fwd_fused_kernel<0>(abn::FusedFwdP)',
                 'void abn::gemm_bwd_pair_kernel<128, 64, 0>(abn::GemmP, int, abn::GemmP)')
     planes = PLANES[prec]
+    # (fp16 x 2 from 4096 tower rows on -- the bench's 8192 -- : every layer on 128 x 128 tiles, the shape's own kernel)
     return ('void abn::tower_fwd_planes_kernel<%d, 0>(abn::PlanesFwdP)' % planes,
-            'void abn::wgrad_planes_kernel<%d>(abn::WgradP)' % planes)
+            'abn::wgrad_planes128_kernel(abn::WgradP)' if prec == 'f16x2' else 'void abn::wgrad_planes_kernel<%d>(abn::WgradP)' % planes)
 
 
 def _time_launches(torch, fn, reps):
@@ -188,7 +189,7 @@ def planes_roofline(torch, net, reps=20):
     fl_f = 2.0 * rows * sum(dims[l + 1] * dims[l] for l in range(4))
     planes = PLANES[prec]
     launches = {
-        'weight_gradients': (wgrad_name, 'wgrad_planes_kernel<%d>' % planes, times['wgrad'], fl_w,
+        'weight_gradients': (wgrad_name, 'wgrad_planes128_kernel' if prec == 'f16x2' else 'wgrad_planes_kernel<%d>' % planes, times['wgrad'], fl_w,
                              "all four layers' weight and bias gradients, one launch"),
         'dgrad_chain': ('void abn::tower_dgrad_planes_kernel<%d>(abn::PlanesBwdP)' % planes,
                         'tower_dgrad_planes_kernel<%d>' % planes, times['dgrad'], fl_d, 'dZ through the three upper layers, one launch'),
@@ -513,7 +514,8 @@ def dtw_bench(torch, P, rank, world, reps=3, cpu_pairs=4000):
                                 'slot) + N+M-1 sequential anti-diagonals of f64 min / add per band (32 lanes per pair, ~20 '
                                 'instructions per step in the consumer wavefront); dot products on the fp32 matrix cores; '
                                 'one fused kernel, the matrix stays in LDS',
-                        'traffic': _traffic('dtw_gang_kernel')}}
+                        # (the committed counters are of the default workload, 10 000 pairs: no figure for another size)
+                        'traffic': _traffic('dtw_gang_kernel') if P == 10000 else None}}
     alg_bytes = int((n1.astype(np.int64) + n2).sum()) * 168
     meas = out['roofline']['traffic']
     out['roofline']['hbm'] = {
