@@ -41,7 +41,7 @@ struct Switches {
     bool bwd_pair;            // ABN_BWD_PAIR=0: wgrad and dgrad of a layer as two grids
     int gemm_tile;            // ABN_GEMM_TILE=0..3: force a tile shape
     bool dtw_f40, dtw_pc;     // ABN_DTW_F40=0 / ABN_DTW_PC=0: the general DTW kernels
-    int wgrad_tile128;        // ABN_WGRAD_TILE128: 128 x 128 weight-gradient tiles (fp16 x 2) never (0) / always (1) / from 4096 rows (default)
+    int wgrad_tile128;        // ABN_WGRAD_TILE128: 128 x 128 weight-gradient tiles (fp16 x 2) never (0) / always (1) / from 2048 rows (default)
     int dtw_wgs_per_cu;       // ABN_DTW_WGS: workgroups per CU of the gang DTW kernel's persistent grid (default 6)
     int wgrad_wgs_heavy, wgrad_wgs_light;   // ABN_WGRAD_WGS_HEAVY / _LIGHT: workgroups per layer of the 128 x 128 weight-gradient launch (tiles x slabs; >= 16 tiles: heavy)
     int64_t wgrad_rows_per_slab;   // ABN_WGRAD_ROWS_PER_SLAB: fewest batch rows one split-K slab of the weight gradients sums (default 128)

@@ -961,12 +961,13 @@ static int split_count(int64_t rows, int64_t out_dim, int64_t in_dim)
 
 // The same for a tower the planes kernels can take (tower_planes.h, whichever path runs in the end):
 // their weight-gradient tiles are up to 256 x 256, so a layer needs more slices to spread over the CUs.
-// 128 x 128 weight-gradient tiles (shape 3, fp16 x 2): from 4096 tower rows on (rows rounded up to 64 like the slices below, so
-// that a batch and its padded form agree); ABN_WGRAD_TILE128 = 0 / 1 forces never / always
+// 128 x 128 weight-gradient tiles (shape 3, fp16 x 2): from 2048 tower rows on (rows rounded up to 64 like the slices below, so
+// that a batch and its padded form agree; tools/tile128_sweep.py: 1024 rows 0.128 against 0.122 ms / step on the wide tiles, 2048 rows
+// 0.119 against 0.129, 6144 rows 0.147 against 0.158); ABN_WGRAD_TILE128 = 0 / 1 forces never / always
 static inline bool wgrad_tile128(int64_t rows, bool np2)
 {
     const int mode = switches().wgrad_tile128;
-    return np2 && mode != 0 && (mode > 0 || (rows + 63) / 64 * 64 >= 4096);
+    return np2 && mode != 0 && (mode > 0 || (rows + 63) / 64 * 64 >= 2048);
 }
 static int planes_split_count(int64_t rows, int64_t out_dim, int64_t in_dim, bool np2 = false)
 {

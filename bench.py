@@ -71,7 +71,7 @@ def kernel_names(prec):
         return ('void abn::tower_fwd_fused_kernel<0>(abn::FusedFwdP)',
                 'void abn::gemm_bwd_pair_kernel<128, 64, 0>(abn::GemmP, int, abn::GemmP)')
     planes = PLANES[prec]
-    # (fp16 x 2 from 4096 tower rows on -- the bench's 8192 -- : every layer on 128 x 128 tiles, the shape's own kernel)
+    # (fp16 x 2 from 2048 tower rows on -- the bench's 8192 -- : every layer on 128 x 128 tiles, the shape's own kernel)
     return ('void abn::tower_fwd_planes_kernel<%d, 0>(abn::PlanesFwdP)' % planes,
             'abn::wgrad_planes128_kernel(abn::WgradP)' if prec == 'f16x2' else 'void abn::wgrad_planes_kernel<%d>(abn::WgradP)' % planes)
 
