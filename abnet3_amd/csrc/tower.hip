@@ -623,16 +623,119 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ a, const float* da
 
 // bn_planes_backward's small kernels.  The output layer's sums of dy and dy * xhat per workgroup of 32 rows
 // (further down bn_bwd_layer_kernel leaves them itself): one thread per column, [workgroup][2][PL_MAXW].
+// LOSS (abn_tower_backward_loss on a BatchNorm tower): the launch also IS the pair loss -- its first phase computes, per
+// pair, the loss term and the two coefficients of d loss / d e = partner * inv - self * kself from the embeddings the
+// forward left (the arithmetic of loss.hip, fp64 per pair, as the data-gradient chain's first phase does: tower_planes.h),
+// the main loop forms d loss / d a from them instead of reading it, and stores it for the top layer's launch.
+// Rows are [call 0 = tower 1: pairs 0 .. B-1 | call 1 = tower 2]; a workgroup's 32 rows belong to one call.
+struct BnLossP {
+    const void* y;
+    int y_dtype, kind, B;
+    double margin, scale;
+    const int* n_valid;
+    double* loss_partial;          // one per workgroup
+    unsigned* loss_counter;        // ticket (zero before, zero after)
+    float* loss_out;
+    double* loss_accum;
+    const float* a_top;            // [2 B][C] the embeddings
+    float* da_out;                 // [2 B][C] d loss / d a, written here
+};
+template <bool LOSS>
 __global__ __launch_bounds__(512) void bn_bwd_sums_wg_kernel(const float* __restrict__ da, const float* __restrict__ z,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             int act, int C, int64_t rows_per_call, float* __restrict__ part)
+                                                             int act, int C, int64_t rows_per_call, float* __restrict__ part, BnLossP lp)
 {
     __shared__ float su[8][64], sv[8][64];
+    __shared__ double coef[64], term_s[32];
+    __shared__ int is_last_s;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;         // 64 columns x 8 groups of 4 rows
     const int64_t wpc = (rows_per_call + PL_ROWS - 1) / PL_ROWS;    // (bn_fwd_layer_kernel's workgroup -> rows map)
     const int64_t g = blockIdx.x / wpc;
-    const int64_t r0 = g * rows_per_call + (blockIdx.x - g * wpc) * PL_ROWS + 4 * ty, r_end = (g + 1) * rows_per_call;
+    const int64_t row0 = g * rows_per_call + (blockIdx.x - g * wpc) * PL_ROWS, r_end = (g + 1) * rows_per_call;
+    const int64_t r0 = row0 + 4 * ty;
+    if (LOSS) {
+        const int B = lp.B;
+        const int Bv = lp.n_valid ? *lp.n_valid : B;
+        const double lscale = lp.n_valid && lp.scale != 1.0 ? 1.0 / (double)(Bv > 0 ? Bv : 1) : lp.scale;
+        const int wave = ty, lane = tx;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int lr = 4 * wave + 2 * it + (lane >> 5), l = lane & 31;
+            const int64_t gr = row0 + lr;
+            double inv = 0.0, kself = 0.0, term = 0.0;
+            const int tower = (int)g;
+            const int64_t pi_ = gr < r_end ? gr - (int64_t)tower * B : 0;
+            const bool ok = gr < r_end && pi_ < Bv;
+            const float* a = lp.a_top + pi_ * C;                    // e1[pair], e2[pair]: the order loss.hip sums in
+            const float* b = lp.a_top + ((int64_t)B + pi_) * C;
+            double dot = 0.0, s11 = 0.0, s22 = 0.0;
+            for (int c = l; c < C / 4; c += 32) {
+                const float4 u = reinterpret_cast<const float4*>(a)[c];
+                const float4 v = reinterpret_cast<const float4*>(b)[c];
+                dot += (double)u.x * v.x + (double)u.y * v.y + (double)u.z * v.z + (double)u.w * v.w;
+                s11 += (double)u.x * u.x + (double)u.y * u.y + (double)u.z * u.z + (double)u.w * u.w;
+                s22 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+            }
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) {
+                dot += __shfl_xor(dot, o, 64);
+                s11 += __shfl_xor(s11, o, 64);
+                s22 += __shfl_xor(s22, o, 64);
+            }
+            if (ok) {
+                constexpr double EPS = 1e-6;
+                const double n1 = sqrt(s11), n2 = sqrt(s22);
+                const double c1 = n1 > EPS ? n1 : EPS, c2 = n2 > EPS ? n2 : EPS;
+                const double cs = dot / (c1 * c2);
+                double v = 0.0;
+                switch (lp.y_dtype) {
+                    case ABN_Y_I8: v = ((const int8_t*)lp.y)[pi_]; break;
+                    case ABN_Y_I32: v = ((const int32_t*)lp.y)[pi_]; break;
+                    case ABN_Y_I64: v = (double)((const int64_t*)lp.y)[pi_]; break;
+                    case ABN_Y_F32: v = ((const float*)lp.y)[pi_]; break;
+                    default: v = ((const double*)lp.y)[pi_]; break;
+                }
+                const int code = v == 1.0 ? 1 : (v == -1.0 ? -1 : 0);
+                double dcos;
+                if (lp.kind == ABN_LOSS_COSCOS2) {
+                    if (code == 1) { term = (1.0 - cs) * 0.5; dcos = -0.5; }
+                    else if (code == -1) { term = cs * cs; dcos = 2.0 * cs; }
+                    else { term = cs; dcos = 1.0; }
+                } else {
+                    if (code == 1) { term = 1.0 - cs; dcos = -1.0; }
+                    else if (code == -1) { const double hh = cs - lp.margin; term = hh > 0.0 ? hh : 0.0; dcos = hh >= 0.0 ? 1.0 : 0.0; }
+                    else { term = cs; dcos = 1.0; }
+                }
+                dcos *= lscale;
+                inv = dcos / (c1 * c2);
+                const double k1 = n1 > 0.0 ? dcos * cs / (c1 * n1) : 0.0;
+                const double k2 = n2 > 0.0 ? dcos * cs / (c2 * n2) : 0.0;
+                kself = tower ? k2 : k1;
+                if (tower) term = 0.0;                               // a pair's term counts once
+            }
+            if (l == 0) { coef[2 * lr] = inv; coef[2 * lr + 1] = kself; term_s[lr] = term; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double sum = 0.0;
+            for (int i = 0; i < 32; ++i) sum += term_s[i];
+            is_last_s = abn_ticket_publish(&lp.loss_partial[blockIdx.x], sum, lp.loss_counter, gridDim.x);      // (common.h)
+        }
+        __syncthreads();
+        if (is_last_s && ty == 0) {                               // the last workgroup to arrive: fixed-order sum of all partials
+            double sum = 0.0;
+            for (int i = tx; i < (int)gridDim.x; i += 64) sum += abn_ticket_partial(&lp.loss_partial[i]);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            if (tx == 0) {
+                const float lv = (float)(sum * lscale);
+                *lp.loss_out = lv;
+                if (lp.loss_accum) *lp.loss_accum += (double)lv;      // (one thread of one workgroup per call, calls in stream order)
+                __hip_atomic_store(lp.loss_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = c0 + tx;
         float u = 0.0f, v = 0.0f;
@@ -642,8 +745,17 @@ __global__ __launch_bounds__(512) void bn_bwd_sums_wg_kernel(const float* __rest
             for (int r = 0; r < 4; ++r) {
                 if (r0 + r >= r_end) break;
                 const int64_t i = (r0 + r) * C + c;
+                float dav;
+                if (LOSS) {
+                    const int lr = 4 * ty + r;
+                    const int64_t prow = g ? r0 + r - lp.B : r0 + r + lp.B;
+                    dav = (float)(lp.a_top[prow * C + c] * coef[2 * lr] - lp.a_top[i] * coef[2 * lr + 1]);
+                    lp.da_out[i] = dav;
+                } else {
+                    dav = da[i];
+                }
                 const float xh = (z[i] - mu) * is;
-                const float dy = da[i] * act_grad(act_apply(xh * ga + be, act), act);
+                const float dy = dav * act_grad(act_apply(xh * ga + be, act), act);
                 u += dy;
                 v += dy * xh;
             }
@@ -1142,14 +1254,16 @@ static void reduce_range(ReduceTable& rt, const abn_tower_desc* t, const BwdLayo
 // Backward of a BatchNorm tower whose forward went through bn_fwd_layer_kernel (same predicate): per layer,
 // top down, [bn_bwd_layer_kernel, bn_bwd_finish_wg_kernel]; then every layer's weight gradient in one launch
 // and the slab reduction.
-static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64_t rows, int64_t n_calls, const Layout& L,
+static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, const LossArgs* loss, int64_t rows, int64_t n_calls, const Layout& L,
                               const BwdLayout& B0, const float* ws, float* scratch, float* dx, hipStream_t st)
 {
     const int nl = t->n_layers;
     const int np = planes_of(t);
     const int64_t rpc = rows / n_calls;
     ABN_REQUIRE(aligned16(d_out) && aligned16(scratch) && (!dx || aligned16(dx)), "tower_backward: d_out / scratch / dx must be 16-byte aligned");
-    ABN_REQUIRE(!t->d_out_is_dz, "tower_backward: d_out_is_dz cannot be combined with batch_norm");
+    // (with the pair loss riding along there is no d_out at all: the flag, which the caller sets for the chains, says nothing here)
+    ABN_REQUIRE(!t->d_out_is_dz || loss, "tower_backward: d_out_is_dz cannot be combined with batch_norm");
+    ABN_REQUIRE(!loss || n_calls == 2, "tower_backward_loss: two forward_once calls");
     BwdLayout B = B0;
     for (int l = 0; l < nl; ++l) B.splits[l] = B0.psplits[l];
     const PackLayout PL = make_pack_layout(t);
@@ -1180,10 +1294,29 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
         hipLaunchKernelGGL(bn_bwd_from_sums_kernel, dim3(grid_for(n_calls * C)), dim3(256), 0, st, sums, C, (int)n_calls, s1, s2);
         return ABN_OK;
     };
+    // d loss / d a of the output layer: the caller's, or (the pair loss riding along) formed by the first launch from the embeddings
+    const float* da_top = d_out;
     {
         const int N = (int)t->dims[nl];
-        hipLaunchKernelGGL(bn_bwd_sums_wg_kernel, cgrid, dim3(512), 0, st, d_out, ws + L.xhat[nl - 1], ws + L.mean[nl - 1],
-                           ws + L.invstd[nl - 1], t->bn_w[nl - 1], t->bn_b[nl - 1], t->last_act, N, rpc, part);
+        BnLossP lp = {};
+        if (loss) {
+            lp.y = loss->y; lp.y_dtype = loss->y_dtype; lp.kind = loss->kind; lp.B = (int)rpc;
+            lp.margin = (double)loss->margin;
+            lp.scale = loss->avg ? 1.0 / (double)rpc : 1.0;
+            lp.n_valid = loss->n_valid;
+            lp.loss_counter = reinterpret_cast<unsigned*>(loss->ws);
+            lp.loss_partial = reinterpret_cast<double*>(reinterpret_cast<char*>(loss->ws) + 8);
+            lp.loss_out = loss->loss_out;
+            lp.loss_accum = loss->loss_accum;
+            lp.a_top = ws + L.a[nl - 1];
+            lp.da_out = scratch + B.dz[0];            // (idle until the top layer's launch has read it: that one writes dz[1])
+            da_top = lp.da_out;
+            hipLaunchKernelGGL(bn_bwd_sums_wg_kernel<true>, cgrid, dim3(512), 0, st, static_cast<const float*>(nullptr), ws + L.xhat[nl - 1],
+                               ws + L.mean[nl - 1], ws + L.invstd[nl - 1], t->bn_w[nl - 1], t->bn_b[nl - 1], t->last_act, N, rpc, part, lp);
+        } else {
+            hipLaunchKernelGGL(bn_bwd_sums_wg_kernel<false>, cgrid, dim3(512), 0, st, d_out, ws + L.xhat[nl - 1], ws + L.mean[nl - 1],
+                               ws + L.invstd[nl - 1], t->bn_w[nl - 1], t->bn_b[nl - 1], t->last_act, N, rpc, part, lp);
+        }
         const int rc = finish_sums(N, t->dbn_w[nl - 1], t->dbn_b[nl - 1]);
         if (rc != ABN_OK) return rc;
     }
@@ -1195,7 +1328,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, int64
         q.N = (int)t->dims[l + 1]; q.K = (int)t->dims[l];
         q.act_l = (l == nl - 1) ? t->last_act : t->act;
         q.act_prev = t->act;
-        q.da = (l == nl - 1) ? d_out : scratch + B.dz[cur];
+        q.da = (l == nl - 1) ? da_top : scratch + B.dz[cur];
         q.z = ws + L.xhat[l];                         // (the forward left z there, un-normalised)
         q.mean = ws + L.mean[l];
         q.invstd = ws + L.invstd[l];
@@ -1815,7 +1948,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
         set_error("tower_backward: wgrad_part needs the operand-plane launches of a tower without BatchNorm");
         return ABN_E_UNSUPPORTED;
     }
-    if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) { return bn_planes_backward(t, d_out, rows, n_calls, L, B, ws, scratch, dx, st); }
+    if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) { return bn_planes_backward(t, d_out, nullptr, rows, n_calls, L, B, ws, scratch, dx, st); }
     if (t->batch_norm && bn_sync_on(t)) {
         set_error("tower_backward: cross-replica BatchNorm statistics (bn_sync_world) need the operand-plane launches");
         return ABN_E_UNSUPPORTED;
@@ -1935,7 +2068,8 @@ int abn_tower_backward_launch(const abn_tower_desc* t, const float* x1, const fl
 
 void abn_reload_switches(void) { abn::reload_switches(); }
 
-int64_t abn_tower_backward_loss_ws_bytes(int64_t rows) { return 8 + ((rows + PL_ROWS - 1) / PL_ROWS) * (int64_t)sizeof(double); }
+// (one double per workgroup: a BatchNorm tower's launches cut the rows per forward_once call -- up to one workgroup more)
+int64_t abn_tower_backward_loss_ws_bytes(int64_t rows) { return 8 + ((rows + PL_ROWS - 1) / PL_ROWS + 2) * (int64_t)sizeof(double); }
 
 int abn_tower_backward_loss(const abn_tower_desc* t, const float* x1, const float* x2, const void* y, int y_dtype,
                             int loss_kind, float margin, int avg, int64_t rows, const float* ws, float* scratch,
@@ -1949,16 +2083,21 @@ int abn_tower_backward_loss(const abn_tower_desc* t, const float* x1, const floa
     ABN_REQUIRE(y_dtype >= ABN_Y_I8 && y_dtype <= ABN_Y_F64, "tower_backward_loss: unknown label dtype %d", y_dtype);
     ABN_REQUIRE(loss_kind != ABN_LOSS_COSMARGIN || (margin >= 0.0f && margin <= 1.0f), "tower_backward_loss: margin outside [0,1]");
     for (int l = 0; l < t->n_layers; ++l) ABN_REQUIRE(t->dW[l] && t->db[l], "tower_backward_loss: layer %d has null gradient buffers", l);
-    const int kind = rows == 0 ? PLANES_NONE : planes_kind(t, rows, 2, x1, x2, ws);
-    if (kind == PLANES_NONE) {
-        set_error("tower_backward_loss: only for towers the operand-plane kernels take (bf16x3 / bf16, no BatchNorm, "
-                  "widths <= 512 and multiples of 4, enough rows): use abn_pair_loss_dz + abn_tower_backward");
+    // a BatchNorm tower on its layer launches (per-replica statistics, all parts of the backward in this call): the loss rides in
+    // the launch that sums the output layer's dy and dy xhat
+    const bool bn = rows > 0 && t->batch_norm && bn_train_planes_path(t, rows, 2, x1, x2, ws) && !bn_sync_on(t) && t->wgrad_part == 0 &&
+                    t->dims[t->n_layers] % 4 == 0;
+    const int kind = rows == 0 || t->batch_norm ? PLANES_NONE : planes_kind(t, rows, 2, x1, x2, ws);
+    if (kind == PLANES_NONE && !bn) {
+        set_error("tower_backward_loss: only for towers the operand-plane kernels take (the split arithmetics, "
+                  "widths <= 512 and multiples of 4, enough rows; BatchNorm without cross-replica statistics): use abn_pair_loss_dz + abn_tower_backward");
         return ABN_E_UNSUPPORTED;
     }
     const Layout L = make_layout(t, rows, 2);
     const BwdLayout B = make_bwd_layout(t, rows);
     if (scratch_floats < B.total) { set_error("tower_backward_loss: scratch too small"); return ABN_E_WORKSPACE; }
     LossArgs la = {y, y_dtype, loss_kind, avg, margin, loss_out, loss_ws, n_valid, loss_accum};
+    if (bn) return bn_planes_backward(t, nullptr, &la, rows, 2, L, B, ws, scratch, nullptr, (hipStream_t)stream);
     if (kind == PLANES_WIDE) return wide_backward(t, nullptr, &la, rows, 2, L, B, ws, scratch, nullptr, (hipStream_t)stream);
     return planes_backward(t, nullptr, &la, rows, L, B, ws, scratch, nullptr, (hipStream_t)stream);
 }

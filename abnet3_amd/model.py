@@ -816,13 +816,14 @@ class SiameseNetwork(_HipNetwork):
                              wgrad_split=None):
         """loss(emb1, emb2, y) and its backward in the backward's own launches (abn_tower_backward_loss:
         the data-gradient chain computes the pair loss and d loss / d z of the output layer in its first
-        phase).  Returns the 0-dim loss, or None when the library does not take this tower that way
-        (BatchNorm, exact-fp32 arithmetic, odd widths): the caller then uses value_and_dz + direct_backward.
+        phase; a BatchNorm tower's backward in the launch that sums the output layer's dy and dy xhat).  Returns the 0-dim loss,
+        or None when the library does not take this tower that way (exact-fp32 arithmetic, odd widths, cross-replica
+        BatchNorm statistics): the caller then uses value_and_dz + direct_backward.
         n_valid (device int32 tensor): a padded batch, only the first n_valid pairs are real; loss_accum (device
         float64 tensor): the loss is also added to it (include/abnet3_hip.h)."""
         seg, sv, grad_pass = state
         rows = sv.rows
-        if (seg.batch_norm or sv.n_calls != 2 or os.environ.get('ABN_LOSS_IN_BACKWARD') == '0'      # (the variable: A/B runs)
+        if (sv.n_calls != 2 or os.environ.get('ABN_LOSS_IN_BACKWARD') == '0'      # (the variable: A/B runs)
                 or self._fused_loss_refused == (rows, self.precision)):
             return None
         from .loss import _scratch

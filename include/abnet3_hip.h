@@ -250,9 +250,10 @@ int abn_tower_backward_launch(const abn_tower_desc* t, const float* x1, const fl
  * loss = self.loss(emb1, emb2, y); loss.backward()): rows = 2 B tower rows, [tower 1: pairs 0..B-1 |
  * tower 2: pairs 0..B-1], whose embeddings the forward left in ws; the first phase of the data
  * gradient chain computes the loss and d loss / d z of the output layer (same arithmetic, fp64 per
- * pair) instead of reading d_out.  Only for towers the operand-plane kernels take (default
- * arithmetic, no BatchNorm, widths <= 512 and multiples of 4): ABN_E_UNSUPPORTED otherwise, and the
- * caller uses the two separate calls.  loss_ws: abn_tower_backward_loss_ws_bytes(rows) bytes whose
+ * pair) instead of reading d_out; for a BatchNorm tower on its layer launches (per-replica statistics,
+ * wgrad_part 0) the launch that sums the output layer's dy and dy xhat does, and leaves d loss / d a for
+ * the top layer's launch.  Only for towers the operand-plane kernels take (default arithmetic, widths <= 512
+ * and multiples of 4): ABN_E_UNSUPPORTED otherwise, and the caller uses the two separate calls.  loss_ws: abn_tower_backward_loss_ws_bytes(rows) bytes whose
  * first 8 (a ticket counter) are zero before the first call and are left zero.
  * n_valid (device int32, or NULL): a PADDED batch -- only the first *n_valid pairs of the B = rows / 2
  * are real (abn_gather_pairs writes such batches: zero rows behind the real ones, tower 2 starting at

@@ -257,6 +257,40 @@ def test_pair_loss_inside_the_backward_equals_the_two_calls(lname, avg, B, ydtyp
         assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-2 * gmax), k
 
 
+@pytest.mark.parametrize('lname,avg', [('coscos2', False), ('cosmargin', True)])
+@pytest.mark.parametrize('B,ydtype,act', [(4096, torch.int64, 'sigmoid'), (330, torch.float32, 'tanh'), (1000, torch.float64, 'relu')])
+def test_pair_loss_inside_the_batchnorm_backward_equals_the_two_calls(lname, avg, B, ydtype, act, monkeypatch, split):
+    """abn_tower_backward_loss on a BatchNorm tower: the launch that sums the output layer's dy and dy xhat per workgroup
+    also computes the pair loss and d loss / d a from the embeddings (no loss launch, no d_out tensor).  Against
+    abn_pair_loss + abn_tower_backward on the same forward: loss and every gradient (gamma / beta included) agree to
+    rounding; 330 pairs: the last workgroup of each call holds 10 rows; labels 0 among them at 1000."""
+    import abnet3_amd.loss as L
+    kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=500 if B > 2000 else 72, output_dim=100 if B > 2000 else 36,
+              activation_layer=act, p_dropout=0.0, batch_norm=True)
+    net, spec, p = build(kw, seed=B, precision=split)
+    loss = getattr(L, lname)(avg=avg) if lname == 'coscos2' else L.cosmargin(avg=avg, margin=0.3)
+    rng = np.random.default_rng(B)
+    x1, x2 = dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32))
+    y = dev(rng.choice([1, -1, 0] if B == 1000 else [1, -1], B)).to(ydtype)
+    net.train()
+    res = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('ABN_LOSS_IN_BACKWARD', fused)
+        for q in net.parameters():
+            q.grad = None
+        emb, state = net.direct_forward(x1, x2)
+        lv = net.direct_backward_loss(state, y, lname, 0.3, avg) if fused == '1' else None
+        assert (lv is not None) == (fused == '1')
+        if lv is None:
+            lv, de = loss.value_and_grad(emb[:B], emb[B:], y)
+            net.direct_backward(state, de.view(2 * B, -1))
+        res.append((float(lv), [q.grad.clone() for q in net.parameters()]))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0]) + 1e-12
+    gmax = max(float(g.abs().max()) for g in res[1][1])
+    for (k, _), a, b in zip(net.named_parameters(), res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-2 * gmax), k
+
+
 @pytest.mark.parametrize('oname', ['adadelta', 'sgd'])
 def test_persistent_weight_image_follows_every_kind_of_update(oname, monkeypatch, split):
     """abn_tower_desc.wpack: the forward skips its pack launch while the image is known to match the
