@@ -646,9 +646,8 @@ __global__ __launch_bounds__(512) void bn_bwd_sums_wg_kernel(const float* __rest
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              int act, int C, int64_t rows_per_call, float* __restrict__ part, BnLossP lp)
 {
-    __shared__ float su[8][64], sv[8][64];
+    __shared__ float su[8][4][64], sv[8][4][64];
     __shared__ double coef[64], term_s[32];
-    __shared__ int is_last_s;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;         // 64 columns x 8 groups of 4 rows
     const int64_t wpc = (rows_per_call + PL_ROWS - 1) / PL_ROWS;    // (bn_fwd_layer_kernel's workgroup -> rows map)
     const int64_t g = blockIdx.x / wpc;
@@ -717,57 +716,76 @@ __global__ __launch_bounds__(512) void bn_bwd_sums_wg_kernel(const float* __rest
             if (l == 0) { coef[2 * lr] = inv; coef[2 * lr + 1] = kself; term_s[lr] = term; }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double sum = 0.0;
-            for (int i = 0; i < 32; ++i) sum += term_s[i];
-            is_last_s = abn_ticket_publish(&lp.loss_partial[blockIdx.x], sum, lp.loss_counter, gridDim.x);      // (common.h)
+    }
+    // four chunks of 64 columns per round (C <= 256: one round): every load of a round is in flight before the first sum,
+    // one pair of barriers per round
+    for (int c00 = 0; c00 < C; c00 += 256) {
+        float u[4], v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c00 + 64 * j + tx;
+            u[j] = v[j] = 0.0f;
+            if (c < C) {
+                const float ga = gamma[c], be = beta[c], mu = mean[g * C + c], is = invstd[g * C + c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r0 + r >= r_end) break;
+                    const int64_t i = (r0 + r) * C + c;
+                    float dav;
+                    if (LOSS) {
+                        const int lr = 4 * ty + r;
+                        const int64_t prow = g ? r0 + r - lp.B : r0 + r + lp.B;
+                        dav = (float)(lp.a_top[prow * C + c] * coef[2 * lr] - lp.a_top[i] * coef[2 * lr + 1]);
+                        lp.da_out[i] = dav;
+                    } else {
+                        dav = da[i];
+                    }
+                    const float xh = (z[i] - mu) * is;
+                    const float dy = dav * act_grad(act_apply(xh * ga + be, act), act);
+                    u[j] += dy;
+                    v[j] += dy * xh;
+                }
+            }
         }
         __syncthreads();
-        if (is_last_s && ty == 0) {                               // the last workgroup to arrive: fixed-order sum of all partials
-            double sum = 0.0;
-            for (int i = tx; i < (int)gridDim.x; i += 64) sum += abn_ticket_partial(&lp.loss_partial[i]);
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
-            if (tx == 0) {
-                const float lv = (float)(sum * lscale);
-                *lp.loss_out = lv;
-                if (lp.loss_accum) *lp.loss_accum += (double)lv;      // (one thread of one workgroup per call, calls in stream order)
-                __hip_atomic_store(lp.loss_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < 4; ++j) { su[ty][j][tx] = u[j]; sv[ty][j][tx] = v[j]; }
+        __syncthreads();
+        if (ty < 4) {                         // wave j finishes chunk j: the eight row groups in order
+            const int c = c00 + 64 * ty + tx;
+            if (c < C) {
+                float a = su[0][ty][tx], b = sv[0][ty][tx];
+                for (int k = 1; k < 8; ++k) { a += su[k][ty][tx]; b += sv[k][ty][tx]; }
+                part[(int64_t)blockIdx.x * (2 * PL_MAXW) + c] = a;
+                part[(int64_t)blockIdx.x * (2 * PL_MAXW) + PL_MAXW + c] = b;
             }
         }
     }
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        const int c = c0 + tx;
-        float u = 0.0f, v = 0.0f;
-        if (c < C) {
-            const float ga = gamma[c], be = beta[c], mu = mean[g * C + c], is = invstd[g * C + c];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r0 + r >= r_end) break;
-                const int64_t i = (r0 + r) * C + c;
-                float dav;
-                if (LOSS) {
-                    const int lr = 4 * ty + r;
-                    const int64_t prow = g ? r0 + r - lp.B : r0 + r + lp.B;
-                    dav = (float)(lp.a_top[prow * C + c] * coef[2 * lr] - lp.a_top[i] * coef[2 * lr + 1]);
-                    lp.da_out[i] = dav;
-                } else {
-                    dav = da[i];
-                }
-                const float xh = (z[i] - mu) * is;
-                const float dy = dav * act_grad(act_apply(xh * ga + be, act), act);
-                u += dy;
-                v += dy * xh;
+    if (LOSS) {
+        // the loss terms: a ticket per workgroup, drawn at the END of the launch (nobody waits for its round trip but the one wave
+        // that sums when it was the last), the last workgroup to arrive adds all partials in a fixed order
+        const int Bv = lp.n_valid ? *lp.n_valid : lp.B;
+        const double lscale = lp.n_valid && lp.scale != 1.0 ? 1.0 / (double)(Bv > 0 ? Bv : 1) : lp.scale;
+        if (ty == 0) {
+            int last = 0;
+            if (tx == 0) {
+                double sum = 0.0;
+                for (int i = 0; i < 32; ++i) sum += term_s[i];
+                last = abn_ticket_publish(&lp.loss_partial[blockIdx.x], sum, lp.loss_counter, gridDim.x);      // (common.h)
             }
-        }
-        __syncthreads();
-        su[ty][tx] = u;
-        sv[ty][tx] = v;
-        __syncthreads();
-        if (ty == 0 && c < C) {
-            for (int k = 1; k < 8; ++k) { u += su[k][tx]; v += sv[k][tx]; }
-            part[(int64_t)blockIdx.x * (2 * PL_MAXW) + c] = u;
-            part[(int64_t)blockIdx.x * (2 * PL_MAXW) + PL_MAXW + c] = v;
+            last = __shfl(last, 0, 64);
+            if (last) {
+                double sum = 0.0;
+                for (int i = tx; i < (int)gridDim.x; i += 64) sum += abn_ticket_partial(&lp.loss_partial[i]);
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                if (tx == 0) {
+                    const float lv = (float)(sum * lscale);
+                    *lp.loss_out = lv;
+                    if (lp.loss_accum) *lp.loss_accum += (double)lv;      // (one thread of one workgroup per call, calls in stream order)
+                    __hip_atomic_store(lp.loss_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
 }
