@@ -111,6 +111,17 @@ def train(kind, dc, train_pairs, dev_pairs, epochs, out_dir, seed=0, planned=Tru
         'first_untrained_pass_s': round(passes[0][0] + passes[0][1], 4),
         'train_losses': [float(v) for v in trainer.train_losses], 'dev_losses': [float(v) for v in trainer.dev_losses],
     }
+    # the same mining once more, by a second loader over the same feature container (token lookups cached there, allocator and
+    # code objects warm): what a second experiment on the corpus pays
+    np.random.seed(seed)
+    dl2 = make_loader(kind, dc, train_pairs, dev_pairs, batch_size)
+    t4 = _sync()
+    dl2.load_data()
+    if kind == 'original':
+        dl2._plan_store('train')
+        dl2._plan_store('dev')
+    stats['mining_s_second_loader'] = round(_sync() - t4, 4)
+    del dl2
     if fp_epoch and train_s:
         best = min(train_s)
         stats['train_frame_pairs_per_s'] = round(fp_epoch / best, 1)
