@@ -452,7 +452,7 @@ constexpr int BN_WG_GROUPS = 16;
 __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
     const float* __restrict__ part, int wgs_per_call, int64_t rows_per_call, int C, int n_calls, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ var_out, float* __restrict__ rm, float* __restrict__ rv,
-    double* __restrict__ sums_out)
+    double* __restrict__ sums_out, const int* __restrict__ n_valid)
 {
     __shared__ double sa[BN_WG_GROUPS][64], sb[BN_WG_GROUPS][64];
     const int tx = threadIdx.x & 63, kg = threadIdx.x >> 6;
@@ -460,6 +460,9 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
     const bool ok = c < C;
     float m_run = 0.0f, v_run = 0.0f;
     if (ok && kg == 0) { m_run = rm[c]; v_run = rv[c]; }
+    // (a padded batch, abn_tower_desc.n_valid: the calls end behind their real rows; the workgroups behind the end hold zero sums)
+    const int64_t rows_alloc = rows_per_call;
+    if (n_valid) { const int64_t nv = *n_valid; rows_per_call = nv < 1 ? 1 : (nv < rows_alloc ? nv : rows_alloc); }
     const float unb = rows_per_call > 1 ? (float)((double)rows_per_call / (double)(rows_per_call - 1)) : 1.0f;
     // the sixteen thread groups are dealt over the calls (two calls: eight groups each), so that every call's loads are in
     // flight together: one round trip for the launch instead of one per call (6.8 -> ~5 us at C2); each group adds its share
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
                 const float* src = part + (int64_t)(g * wgs_per_call + k) * (3 * PL_MAXW);
                 const double sd = src[c], sq = src[PL_MAXW + c], cc = src[2 * PL_MAXW + c];
                 const int64_t left = rows_per_call - (int64_t)k * PL_ROWS;
-                const double nk = left < PL_ROWS ? (double)left : (double)PL_ROWS;      // rows of workgroup k
+                const double nk = left < PL_ROWS ? (left > 0 ? (double)left : 0.0) : (double)PL_ROWS;      // rows of workgroup k
                 a += sd + nk * cc;
                 b += sq + 2.0 * cc * sd + nk * cc * cc;
             }
@@ -573,13 +576,15 @@ __global__ void bn_apply_kernel(const float* z /* may alias xhat */, int64_t row
                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ rm, const float* __restrict__ rv, int train,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                int act, float* xhat, float* __restrict__ a)
+                                int act, float* xhat, float* __restrict__ a, const int* __restrict__ n_valid = nullptr)
 {
     const int64_t n = rows * C;
+    const int64_t nv = n_valid ? *n_valid : rows_per_call;      // (a padded batch: the rows behind every call's real ones come out as zeros)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const int64_t r = i / C;
+        if (r % rows_per_call >= nv) { a[i] = 0.0f; continue; }
         float mu, is;
         if (train) {
             const int64_t g = r / rows_per_call;
@@ -651,7 +656,8 @@ __global__ __launch_bounds__(512) void bn_bwd_sums_wg_kernel(const float* __rest
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;         // 64 columns x 8 groups of 4 rows
     const int64_t wpc = (rows_per_call + PL_ROWS - 1) / PL_ROWS;    // (bn_fwd_layer_kernel's workgroup -> rows map)
     const int64_t g = blockIdx.x / wpc;
-    const int64_t row0 = g * rows_per_call + (blockIdx.x - g * wpc) * PL_ROWS, r_end = (g + 1) * rows_per_call;
+    const int64_t nv_rows = lp.n_valid ? (*lp.n_valid < 0 ? 0 : (*lp.n_valid < rows_per_call ? *lp.n_valid : rows_per_call)) : rows_per_call;
+    const int64_t row0 = g * rows_per_call + (blockIdx.x - g * wpc) * PL_ROWS, r_end = g * rows_per_call + nv_rows;      // (a padded batch: abn_tower_desc.n_valid)
     const int64_t r0 = row0 + 4 * ty;
     if (LOSS) {
         const int B = lp.B;
@@ -1303,6 +1309,10 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, const
     // cross-replica statistics: the sums leave as float64, are all-reduced by the caller's function, and come back as s1 / s2
     const bool sync = bn_sync_on(t);
     ABN_REQUIRE(!sync || t->bn_sync_fn, "tower_backward: bn_sync_world = %d without bn_sync_fn", t->bn_sync_world);
+    // a padded batch: the descriptor's real-row count (the forward was given the same), or the loss call's
+    ABN_REQUIRE(!loss || !loss->n_valid || !t->n_valid || loss->n_valid == t->n_valid, "tower_backward_loss: two different n_valid");
+    const int32_t* const nvp = t->n_valid ? t->n_valid : (loss ? loss->n_valid : nullptr);
+    if (sync && nvp) { set_error("tower_backward: n_valid (a padded batch) cannot be combined with cross-replica BatchNorm statistics"); return ABN_E_UNSUPPORTED; }
     double* const sums = reinterpret_cast<double*>(scratch + B.bn_part);
     auto finish_sums = [&](int C, float* dgamma, float* dbeta) -> int {
         hipLaunchKernelGGL(bn_bwd_finish_wg_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, part, wgs_per_call, C,
@@ -1317,11 +1327,11 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, const
     {
         const int N = (int)t->dims[nl];
         BnLossP lp = {};
+        lp.n_valid = nvp;
         if (loss) {
             lp.y = loss->y; lp.y_dtype = loss->y_dtype; lp.kind = loss->kind; lp.B = (int)rpc;
             lp.margin = (double)loss->margin;
             lp.scale = loss->avg ? 1.0 / (double)rpc : 1.0;
-            lp.n_valid = loss->n_valid;
             lp.loss_counter = reinterpret_cast<unsigned*>(loss->ws);
             lp.loss_partial = reinterpret_cast<double*>(reinterpret_cast<char*>(loss->ws) + 8);
             lp.loss_out = loss->loss_out;
@@ -1362,6 +1372,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, const
         q.da_prev = l >= 1 ? scratch + B.dz[cur ^ 1] : dx;
         if (l >= 1) { q.z_prev = ws + L.xhat[l - 1]; q.mean_prev = ws + L.mean[l - 1]; q.invstd_prev = ws + L.invstd[l - 1];
                       q.gamma_prev = t->bn_w[l - 1]; q.beta_prev = t->bn_b[l - 1]; q.part_out = part; }
+        q.n_valid = nvp;
         PL_LAUNCH(np, bn_bwd_layer_kernel, cgrid, dim3(PL_NT), pl_lds_bytes(np), st, q);
         if (l >= 1) {
             const int rc = finish_sums(q.K, t->dbn_w[l - 1], t->dbn_b[l - 1]);
@@ -1669,6 +1680,10 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         set_error("tower_forward: cross-replica BatchNorm statistics (bn_sync_world) need the operand-plane launches");
         return ABN_E_UNSUPPORTED;
     }
+    if (train && t->batch_norm && t->n_valid && !bn_train) {
+        set_error("tower_forward: a padded batch (n_valid) through a BatchNorm tower in training needs the BatchNorm layer launches");
+        return ABN_E_UNSUPPORTED;
+    }
     const int kind = planes_kind(t, rows, n_calls, x1, x2, ws, pmode);
     if (t->drop_seed && train && !bn_train && kind == PLANES_NONE) {
         for (int l = 0; l < t->n_layers; ++l)
@@ -1793,14 +1808,16 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 BnTrainP q = {};
                 q.l = l;
                 if (l > 0) { q.mean = ws + L.mean[l - 1]; q.invstd = ws + L.invstd[l - 1]; q.z_prev = ws + L.xhat[l - 1]; q.a_prev = nullptr; }
+                q.n_valid = t->n_valid;
                 PL_LAUNCH(np, bn_fwd_layer_kernel, bgrid, dim3(PL_NT), pl_lds_bytes(np), st, fl, q);
                 const int N = (int)t->dims[l + 1];
                 const bool sync = bn_sync_on(t);
                 ABN_REQUIRE(!sync || t->bn_sync_fn, "tower_forward: bn_sync_world = %d without bn_sync_fn", t->bn_sync_world);
+                if (sync && t->n_valid) { set_error("tower_forward: n_valid (a padded batch) cannot be combined with cross-replica BatchNorm statistics"); return ABN_E_UNSUPPORTED; }
                 double* const sums = reinterpret_cast<double*>(ws + L.bn_part);       // (the per-layer kernels' partials: idle here)
                 hipLaunchKernelGGL(bn_stats_finish_wg_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * BN_WG_GROUPS), 0, st, ws + L.bn_wg,
                                    (int)wpc, rpc, N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l],
-                                   t->bn_rm[l], t->bn_rv[l], sync ? sums : static_cast<double*>(nullptr));
+                                   t->bn_rm[l], t->bn_rv[l], sync ? sums : static_cast<double*>(nullptr), t->n_valid);
                 if (sync) {
                     if (t->bn_sync_fn(t->bn_sync_ctx, sums, n_calls * 2 * N, st) != 0) { set_error("tower_forward: bn_sync_fn failed"); return ABN_E_LAUNCH; }
                     hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, sums,
@@ -1812,7 +1829,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
             const float* z = ws + L.xhat[nl - 1];      // (stays un-normalised, like every layer's: the backward normalises again)
             hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, z, rows, rpc, N, ws + L.mean[nl - 1],
                                ws + L.invstd[nl - 1], t->bn_rm[nl - 1], t->bn_rv[nl - 1], 1, t->bn_w[nl - 1], t->bn_b[nl - 1],
-                               t->last_act, static_cast<float*>(nullptr), ws + L.a[nl - 1]);
+                               t->last_act, static_cast<float*>(nullptr), ws + L.a[nl - 1], t->n_valid);
             ABN_CHECK_LAUNCH("tower_forward (BatchNorm, planes)");
             return ABN_OK;
         }
@@ -1969,6 +1986,10 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) { return bn_planes_backward(t, d_out, nullptr, rows, n_calls, L, B, ws, scratch, dx, st); }
     if (t->batch_norm && bn_sync_on(t)) {
         set_error("tower_backward: cross-replica BatchNorm statistics (bn_sync_world) need the operand-plane launches");
+        return ABN_E_UNSUPPORTED;
+    }
+    if (t->batch_norm && t->n_valid) {
+        set_error("tower_backward: a padded batch (n_valid) through a BatchNorm tower needs the BatchNorm layer launches");
         return ABN_E_UNSUPPORTED;
     }
 

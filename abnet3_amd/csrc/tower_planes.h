@@ -1247,6 +1247,7 @@ struct BnTrainP {
     const float* z_prev;    // [rows][dims[l]]: z_{l-1} (it stays: the backward normalises it again)
     float* a_prev;          // [rows][dims[l]]: act(gamma xhat + beta) out, row-major (null: not wanted)
     // (p.tp[l]: the same activations as the transposed image [a_{l-1} | 1] the weight gradient reads)
+    const int* n_valid;     // a padded batch (abn_tower_desc.n_valid): every call's rows past *n_valid do not exist for this launch
 };
 
 template <int NP>
@@ -1263,7 +1264,9 @@ __global__ __launch_bounds__(PL_NT) void bn_fwd_layer_kernel(PlanesFwdP p, BnTra
     const int wpc = (p.rows_call + PL_ROWS - 1) / PL_ROWS;
     const int call = blockIdx.x / wpc;
     const int row0 = call * p.rows_call + (blockIdx.x - call * wpc) * PL_ROWS;
-    const int row_end = (call + 1) * p.rows_call;
+    // (a padded batch: the call ends behind its real rows -- the rest are handled like the rows a short last workgroup lacks:
+    // zero rows of the images, no statistics, nothing stored; a workgroup wholly behind the end leaves zero sums)
+    const int row_end = call * p.rows_call + (q.n_valid ? min(max(*q.n_valid, 0), p.rows_call) : p.rows_call);
     const int l = q.l;
     bf16x8 idf[2];
     make_identity<NP>(idf, lane);
@@ -1818,6 +1821,7 @@ struct BnBwdP {
     const float* gamma_prev;       // [K]
     const float* beta_prev;
     float* part_out;               // out [workgroup][2][PL_MAXW]: sums over its 32 rows of dy_{l-1}, dy_{l-1} xhat_{l-1}
+    const int* n_valid;            // a padded batch (abn_tower_desc.n_valid): the statistics span *n_valid rows per call, the rows behind get dz = 0
 };
 
 template <int NP, int BPW, int KS>
@@ -1906,13 +1910,14 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
     const int wpc = (q.rows_call + PL_ROWS - 1) / PL_ROWS;        // (the forward's workgroup -> rows map)
     const int call = blockIdx.x / wpc;
     const int row0 = call * q.rows_call + (blockIdx.x - call * wpc) * PL_ROWS;
-    const int row_end = (call + 1) * q.rows_call;
+    const int nv = q.n_valid ? min(max(*q.n_valid, 0), q.rows_call) : q.rows_call;
+    const int row_end = call * q.rows_call + nv;
     const int N = q.N;
     bf16x8 idf[2];
     make_identity<NP>(idf, lane);
 
     // the per-feature vectors of this workgroup's call, parked in the (still idle) K-split buffer
-    const float nf = q.n_stat;
+    const float nf = q.n_valid ? (float)(nv > 0 ? nv : 1) : q.n_stat;
     float* const k_s = part, * const ga_s = part + PL_MAXW, * const be_s = part + 2 * PL_MAXW, * const s1_s = part + 3 * PL_MAXW,
                * const s2_s = part + 4 * PL_MAXW, * const mu_s = part + 5 * PL_MAXW, * const is_s = part + 6 * PL_MAXW;
     for (int c = threadIdx.x; c < N; c += PL_NT) {

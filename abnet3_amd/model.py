@@ -262,13 +262,14 @@ class _DropSeed(object):
 
 class _Saved(object):
     """What a segment's forward leaves for its backward."""
-    __slots__ = ('x1', 'x2', 'ws', 'masks', 'n_calls', 'train', 'rows', 'bn_synced')
+    __slots__ = ('x1', 'x2', 'ws', 'masks', 'n_calls', 'train', 'rows', 'bn_synced', 'n_valid')
 
 
-def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
+def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False, n_valid=None):
     """Raw forward of one segment (no autograd): the launch sequence of
     abn_tower_forward.  Returns ([rows, out] embeddings as a view of the workspace,
-    _Saved)."""
+    _Saved).  n_valid (device int32 tensor): a padded batch through a BatchNorm tower in training -- only the
+    first n_valid rows of every call are real (abn_tower_desc.n_valid)."""
     lib = _lib.load()
     net = seg.net
     # the reference takes strided inputs (a column slice of stacked features):
@@ -297,6 +298,11 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
         else:
             masks = seg.masks_of(masks.net._draw_mask_tensors(rows, x1.device))
     desc = seg.descriptor(with_grads=False, masks=masks, forward_only=forward_only)
+    if n_valid is not None and train and seg.batch_norm:
+        desc = _lib.TowerDesc.from_buffer_copy(desc)
+        desc.n_valid = n_valid.data_ptr()
+    else:
+        n_valid = None                   # (rows that do not see each other: nothing to tell the library)
     synced = False
     if train and seg.batch_norm and desc.bn_sync_fn:
         # Cross-replica statistics exist on the one-launch-per-layer BatchNorm kernels, and those are the kernels of
@@ -337,6 +343,7 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False):
     sv = _Saved()
     sv.x1, sv.x2, sv.ws, sv.masks, sv.n_calls, sv.train, sv.rows = x1, x2, ws, masks, n_calls, train, rows
     sv.bn_synced = synced
+    sv.n_valid = n_valid
     return out, sv
 
 
@@ -365,6 +372,8 @@ def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False, def
         desc.bn_sync_fn, desc.bn_sync_world = None, 0
     if desc.bn_sync_fn:
         seg.net.bn_sync.buffers = [sv.ws, scratch]
+    if sv.n_valid is not None:                    # (a padded batch through BatchNorm: the forward's real-row count)
+        desc.n_valid = sv.n_valid.data_ptr()
     _lib.check(lib.abn_tower_backward(
         _lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), _lib.ptr(d_out), rows,
         sv.n_calls, _lib.ptr(sv.ws), _lib.ptr(scratch), scratch_floats,
@@ -762,7 +771,7 @@ class SiameseNetwork(_HipNetwork):
     def direct_ok(self):
         return self._last_act != 'softmax'
 
-    def direct_forward(self, x1, x2, forward_only=False):
+    def direct_forward(self, x1, x2, forward_only=False, n_valid=None):
         """forward(x1, x2) in the current mode without building an autograd graph:
         ([2B, out] embeddings of both towers, state for direct_backward).  Dispatching
         one backward through torch's autograd engine costs ~150 us of host time per
@@ -771,8 +780,17 @@ class SiameseNetwork(_HipNetwork):
         seg = self._segment_list()[0]
         rows = 2 * x1.shape[0]
         masks = self._draw_dropout_masks(rows, x1.device) if self.training else None
-        out, sv = _segment_forward(seg, masks, 2, x1, x2, forward_only=forward_only)
+        out, sv = _segment_forward(seg, masks, 2, x1, x2, forward_only=forward_only, n_valid=n_valid)
         return out, (seg, sv, _GradPass(self))
+
+    def takes_padded_batch_norm(self, x12, npad):
+        """Does a TRAINING forward of this (BatchNorm) network on the padded batch x12 = [tower 1: npad rows | tower 2: npad rows]
+        run on the launches that take a real-row count (abn_tower_desc.n_valid: the BatchNorm layer launches)?"""
+        seg = self._segment_list()[0]
+        desc = seg.descriptor(with_grads=False)
+        lib = _lib.load()
+        return lib.abn_tower_path(_lib.C.byref(desc), _lib.ptr(x12[:npad]), _lib.ptr(x12[npad:]), 2 * npad, 2, 1, _lib.ptr(x12), 0,
+                                  None) == _lib.PATH_BN_LAYERS
 
     def direct_dz_info(self, state):
         """What the pair loss needs to hand back d loss / d z of the output layer itself
@@ -836,6 +854,10 @@ class SiameseNetwork(_HipNetwork):
         desc = seg.descriptor(with_grads=True, grad_buf=grad_buf, masks=sv.masks, d_out_is_dz=True, defer_reduce=defer_reduce)
         if wgrad_split is not None:              # data-parallel overlap: this call stops after the upper layers' gradients
             desc.wgrad_part, desc.wgrad_split = 1, int(wgrad_split)
+        if sv.n_valid is not None:               # (a padded batch through BatchNorm: the forward's real-row count)
+            desc.n_valid = sv.n_valid.data_ptr()
+            if n_valid is None:
+                n_valid = sv.n_valid
         scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
         scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32, device=y.device)
         loss = torch.empty((), dtype=torch.float32, device=y.device)

@@ -537,8 +537,10 @@ class TrainerSiamese(TrainerBuilder):
         dl = self.dataloader
         if not getattr(self, 'planned_passes', True) or not hasattr(dl, 'plan'):
             return None
-        if not self._direct_ok() or getattr(self.network, 'batch_norm', False):
-            return None                      # (BatchNorm: padded rows would enter the batch statistics)
+        if not self._direct_ok():
+            return None
+        if getattr(self.network, 'batch_norm', False) and getattr(self.network, 'bn_sync', None) is not None:
+            return None                      # (cross-replica statistics: the replicas' real-row counts differ)
         if getattr(self, '_plan_refused', False):
             return None
         return dl.plan(train_mode)
@@ -584,7 +586,8 @@ class TrainerSiamese(TrainerBuilder):
         """The five statements of the reference's loop (abnet3/trainer.py:236-240) on a bucket's static buffers."""
         net, opt, npad = self.network, self.optimizer, b['npad']
         x12 = b['x12']
-        emb, state = net.direct_forward(x12[:npad], x12[npad:])
+        # (BatchNorm: the batch statistics span the real rows only -- abn_tower_desc.n_valid, the device word the gather wrote)
+        emb, state = net.direct_forward(x12[:npad], x12[npad:], n_valid=b['nv'] if getattr(net, 'batch_norm', False) else None)
         opt.zero_grad()
         defer = not self.dp and net.can_defer_reduce(state)
         loss_value = net.direct_backward_loss(state, b['y'], type(self.loss).__name__, getattr(self.loss, 'margin', 0.0),
@@ -629,6 +632,8 @@ class TrainerSiamese(TrainerBuilder):
             return True
         # first batch of this bucket: the step itself runs eagerly (and warms everything up), then the same
         # launch sequence is captured for the batches to come (capturing executes nothing)
+        if getattr(self.network, 'batch_norm', False) and not self.network.takes_padded_batch_norm(b['x12'], b['npad']):
+            return False                      # (fewer than 256 rows, odd widths: no real-row count inside those kernels' statistics)
         if self._bucket_body(b) is None:
             return False
         self._bucket_finish()
@@ -713,6 +718,16 @@ class TrainerSiamese(TrainerBuilder):
         """The training pass over a plan; adds the batches' losses to `loss_sum` (device float64) and returns
         the number of batches."""
         if not do_training:
+            if getattr(self.network, 'batch_norm', False) and self.network.training:
+                # a pass without gradients in TRAIN mode (the untrained first pass, abnet3/trainer.py:137): batch statistics, and
+                # the running ones move -- the iterator's step on each of the plan's batches (only the real rows exist there)
+                if plan.order:
+                    self._bucket_state(self._bucket(max(1, plan.span(plan.order[0])[1])), plan)      # (creates the accumulator)
+                    self._loss_acc.zero_()
+                    for bid in plan.order:
+                        self._loss_acc.add_(self.train_step(plan.materialise(bid), False))
+                    loss_sum.add_(self._loss_acc)
+                return len(plan.order)
             return self._run_planned_eval(plan, loss_sum)
         if not plan.order:
             return 0

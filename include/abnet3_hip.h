@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 16
+#define ABN_ABI_VERSION 17
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -155,6 +155,15 @@ typedef struct abn_tower_desc {
     int32_t wgrad_split;                   /* see wgrad_part */
     abn_allreduce_fn bn_sync_fn;
     void* bn_sync_ctx;
+    /* A PADDED batch through a BatchNorm tower in training (device int32, or NULL: every row is real): only the first
+     * *n_valid rows of EVERY forward_once call are real (abn_gather_pairs writes such batches: zero rows behind the real
+     * ones, tower 2 starting at row rows / n_calls).  The batch statistics, the running statistics' update and the backward
+     * then span the real rows only and the padded rows get no gradient and give none, so that one captured step serves
+     * every batch size of a bucket (see abn_tower_backward_loss's n_valid: the same pointer).  The forward and the
+     * backward of a step must be given the same value.  Only on the BatchNorm layer launches (abn_tower_path =
+     * ABN_PATH_BN_LAYERS) with per-replica statistics: ABN_E_UNSUPPORTED elsewhere.  Towers without BatchNorm and
+     * inference forwards ignore it (their rows do not see each other). */
+    const int32_t* n_valid;
 } abn_tower_desc;
 
 /* Workspace of one forward call (what the backward needs: the saved activations, for the

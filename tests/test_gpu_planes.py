@@ -291,6 +291,52 @@ def test_pair_loss_inside_the_batchnorm_backward_equals_the_two_calls(lname, avg
         assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-2 * gmax), k
 
 
+@pytest.mark.parametrize('B,npad,act', [(300, 320, 'sigmoid'), (129, 160, 'tanh'), (4000, 4096, 'sigmoid'), (256, 256, 'relu')])
+def test_batchnorm_on_a_padded_batch_equals_the_unpadded_one(B, npad, act, split):
+    """abn_tower_desc.n_valid: a BatchNorm tower in training on [B real pairs | zero rows up to npad] per tower, told B through a
+    device word, against the same tower on the B pairs alone -- embeddings of the real rows, running statistics, the loss and
+    every gradient (gamma / beta included) bit for bit (the gradients: where both forms cut the same row slabs, a bucket of
+    the planned passes; to rounding otherwise): the workgroups hold the same rows either way, the statistics and
+    the backward's sums span the real rows only, the padded rows get no gradient and give none."""
+    kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=500 if B > 2000 else 72, output_dim=100 if B > 2000 else 36,
+              activation_layer=act, p_dropout=0.0, batch_norm=True)
+    rng = np.random.default_rng(B)
+    xa, xb = rng.standard_normal((B, 40)).astype(np.float32), rng.standard_normal((B, 40)).astype(np.float32)
+    y = dev(rng.choice([1, -1], B))
+    res = []
+    for padded in (False, True):
+        net, spec, p = build(kw, seed=B, precision=split)
+        net.train()
+        if padded:
+            x12 = torch.zeros(2 * npad, 40, device='cuda')
+            x12[:B], x12[npad:npad + B] = dev(xa), dev(xb)
+            yy = torch.zeros(npad, dtype=y.dtype, device='cuda')
+            yy[:B] = y
+            nv = torch.tensor([B], dtype=torch.int32, device='cuda')
+            emb, state = net.direct_forward(x12[:npad], x12[npad:], n_valid=nv)
+            lv = net.direct_backward_loss(state, yy, 'coscos2', 0.0, False, n_valid=nv)
+            e = torch.cat([emb[:B], emb[npad:npad + B]])
+            assert float(emb[B:npad].abs().sum()) == 0.0 and float(emb[npad + B:].abs().sum()) == 0.0
+        else:
+            emb, state = net.direct_forward(dev(xa), dev(xb))
+            lv = net.direct_backward_loss(state, y, 'coscos2', 0.0, False)
+            e = emb
+        assert lv is not None
+        res.append((e.clone(), float(lv), {k: v.clone() for k, v in net.state_dict().items() if 'running' in k or 'tracked' in k},
+                    {k: q.grad.clone() for k, q in net.named_parameters()}))
+    (e0, l0, s0, g0), (e1, l1, s1, g1) = res
+    assert torch.equal(e0, e1) and l0 == l1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    same_slabs = (2 * B + 63) // 64 * 64 == 2 * npad       # (the weight gradients' row slabs are cut by the row count rounded up to 64)
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for k in g0:
+        if same_slabs:
+            assert torch.equal(g0[k], g1[k]), k
+        elif float(g0[k].abs().max()) > 1e-5 * gmax:       # (a Linear bias in front of BatchNorm: a mathematically zero gradient, rounding noise)
+            assert float((g0[k] - g1[k]).abs().max()) <= 2e-6 * max(float(g0[k].abs().max()), 1e-2 * gmax), k
+
+
 @pytest.mark.parametrize('oname', ['adadelta', 'sgd'])
 def test_persistent_weight_image_follows_every_kind_of_update(oname, monkeypatch, split):
     """abn_tower_desc.wpack: the forward skips its pack launch while the image is known to match the
