@@ -633,7 +633,7 @@ class TrainerSiamese(TrainerBuilder):
         # first batch of this bucket: the step itself runs eagerly (and warms everything up), then the same
         # launch sequence is captured for the batches to come (capturing executes nothing)
         if getattr(self.network, 'batch_norm', False) and not self.network.takes_padded_batch_norm(b['x12'], b['npad']):
-            return False                      # (fewer than 256 rows, odd widths: no real-row count inside those kernels' statistics)
+            return False                      # (odd widths: the per-layer kernels, no real-row count inside their statistics)
         if self._bucket_body(b) is None:
             return False
         self._bucket_finish()

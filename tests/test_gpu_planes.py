@@ -291,7 +291,7 @@ def test_pair_loss_inside_the_batchnorm_backward_equals_the_two_calls(lname, avg
         assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-2 * gmax), k
 
 
-@pytest.mark.parametrize('B,npad,act', [(300, 320, 'sigmoid'), (129, 160, 'tanh'), (4000, 4096, 'sigmoid'), (256, 256, 'relu')])
+@pytest.mark.parametrize('B,npad,act', [(300, 320, 'sigmoid'), (129, 160, 'tanh'), (4000, 4096, 'sigmoid'), (256, 256, 'relu'), (40, 64, 'sigmoid')])
 def test_batchnorm_on_a_padded_batch_equals_the_unpadded_one(B, npad, act, split):
     """abn_tower_desc.n_valid: a BatchNorm tower in training on [B real pairs | zero rows up to npad] per tower, told B through a
     device word, against the same tower on the B pairs alone -- embeddings of the real rows, running statistics, the loss and
@@ -335,6 +335,30 @@ def test_batchnorm_on_a_padded_batch_equals_the_unpadded_one(B, npad, act, split
             assert torch.equal(g0[k], g1[k]), k
         elif float(g0[k].abs().max()) > 1e-5 * gmax:       # (a Linear bias in front of BatchNorm: a mathematically zero gradient, rounding noise)
             assert float((g0[k] - g1[k]).abs().max()) <= 2e-6 * max(float(g0[k].abs().max()), 1e-2 * gmax), k
+
+
+def test_n_valid_where_it_does_not_apply(split):
+    """abn_tower_desc.n_valid outside the BatchNorm layer launches: a BatchNorm tower with a width that is no multiple of 4
+    (the per-layer kernels: no real-row count inside their statistics) refuses it loudly, and so says the query the trainer
+    asks first; a tower without BatchNorm never sees it (its rows do not see each other: the Python layer does not pass it on)."""
+    from abnet3_amd import _lib
+    nv = torch.tensor([40], dtype=torch.int32, device='cuda')
+    x12 = torch.zeros(128, 40, device='cuda')
+    x12[:40], x12[64:104] = torch.randn(40, 40, device='cuda'), torch.randn(40, 40, device='cuda')
+    kw = dict(input_dim=40, num_hidden_layers=1, hidden_dim=72, output_dim=36, activation_layer='sigmoid', p_dropout=0.0)
+    odd, spec, p = build(dict(kw, hidden_dim=74, batch_norm=True), seed=1, precision=split)
+    odd.train()
+    assert not odd.takes_padded_batch_norm(x12, 64)
+    with pytest.raises(_lib.HipLibraryError, match='n_valid'):
+        odd.direct_forward(x12[:64], x12[64:], n_valid=nv)
+    net, spec, p = build(dict(kw, batch_norm=True), seed=1, precision=split)
+    net.train()
+    assert net.takes_padded_batch_norm(x12, 64)
+    plain, spec, p = build(dict(kw, batch_norm=False), seed=1, precision=split)
+    plain.train()
+    e0, _ = plain.direct_forward(x12[:64], x12[64:])
+    e1, st = plain.direct_forward(x12[:64], x12[64:], n_valid=nv)
+    assert torch.equal(e0, e1) and st[1].n_valid is None
 
 
 @pytest.mark.parametrize('oname', ['adadelta', 'sgd'])

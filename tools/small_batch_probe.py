@@ -4,6 +4,7 @@ hundred 280-d frame pairs per batch) spends its time: eager step, replayed hipGr
 
     python tools/small_batch_probe.py [pairs ...]           (default 96 160 320 640 1024)
     MODE=graph PAIRS=320 rocprofv3 --kernel-trace --stats -d out -- python3 tools/small_batch_probe.py
+    BATCH_NORM=1: the same tower with BatchNorm (planned passes take it since round 4)
 """
 import os
 import sys
@@ -22,7 +23,7 @@ C5 = dict(input_dim=280, num_hidden_layers=2, hidden_dim=500, output_dim=100, p_
 
 def make(B):
     torch.manual_seed(0)
-    net = SiameseNetwork(output_path='/tmp/abn_sb', **C5)
+    net = SiameseNetwork(output_path='/tmp/abn_sb', **dict(C5, batch_norm=os.environ.get('BATCH_NORM') == '1'))
     if os.environ.get('ABN_PRECISION'):
         net.precision = os.environ['ABN_PRECISION']
     tr = TrainerSiamese(network=net, loss=coscos2(avg=False), optimizer_type='adadelta', lr=0.1, dataloader=None,
