@@ -23,7 +23,7 @@ def run(cases, seed, verbose=True):
       nh = int(rng.integers(0, 5))
       act = str(rng.choice(['sigmoid', 'tanh', 'relu']))
       bn = bool(rng.integers(0, 4) == 0)
-      B = int(rng.choice([1, 7, 31, 32, 33, 100, 257, 300, 700, 1500, 2100]))
+      B = int(rng.choice([1, 7, 31, 32, 33, 100, 257, 300, 700, 1023, 1024, 1040, 1500, 2100]))
       pair = bool(rng.integers(0, 2))
       wide = int(rng.integers(0, 2))
       want_dx = bool(rng.integers(0, 3) == 0)            # the input's gradient too (the data-gradient chain one product further)
