@@ -39,6 +39,7 @@ SYMBOLS = {
     'abn_tower_path': (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int, _vp, C.c_int, _vp]),
     'abn_tower_image_offset': (_i64, [_vp, _i64, _i64, C.c_int, C.c_int]),
     'abn_reload_switches': (None, []),
+    'abn_rccl_allreduce_f64': (C.c_int, [_vp, _vp, _i64, _vp]),
     'abn_tower_backward_launch': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp]),
     'abn_tower_backward_loss_ws_bytes': (_i64, [_i64]),
     'abn_tower_backward_loss': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, C.c_int, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
@@ -91,6 +92,11 @@ class TowerDesc(C.Structure):
         for name in ('W', 'b', 'bn_w', 'bn_b', 'bn_rm', 'bn_rv', 'dW', 'db',
                      'dbn_w', 'dbn_b', 'drop_mask')] + [('precision', _i32), ('d_out_is_dz', _i32), ('defer_reduce', _i32), ('wpack_valid', _i32), ('forward_only', _i32), ('wgrad_part', _i32), ('wpack', _vp), ('drop_seed', _vp), ('drop_p', _f32), ('reserved2_', _i32),
                      ('bn_sync_world', _i32), ('wgrad_split', _i32), ('bn_sync_fn', _vp), ('bn_sync_ctx', _vp), ('n_valid', _vp)]
+
+
+class RcclCtx(C.Structure):
+    """struct abn_rccl_ctx (abn_rccl_allreduce_f64's context)"""
+    _fields_ = [('comm', _vp), ('all_reduce', _vp), ('calls', _i64)]
 
 
 # abn_allreduce_fn (abn_tower_desc.bn_sync_fn)

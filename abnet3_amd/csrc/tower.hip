@@ -2107,6 +2107,21 @@ int abn_tower_backward_launch(const abn_tower_desc* t, const float* x1, const fl
 
 void abn_reload_switches(void) { abn::reload_switches(); }
 
+// abn_tower_desc.bn_sync_fn over RCCL without a host language in between (include/abnet3_hip.h): the caller's communicator and
+// the address of ITS ncclAllReduce -- this library links no collective library
+int abn_rccl_allreduce_f64(void* ctx, void* device_doubles, int64_t n, void* stream)
+{
+    typedef int (*all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    abn_rccl_ctx* c = static_cast<abn_rccl_ctx*>(ctx);
+    if (!c || !c->comm || !c->all_reduce || !device_doubles || n < 0) { set_error("rccl_allreduce_f64: null context / buffer"); return 1; }
+    constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0;          // (ncclDataType_t / ncclRedOp_t: nccl.h)
+    const int rc = reinterpret_cast<all_reduce_t>(c->all_reduce)(device_doubles, device_doubles, (size_t)n, NCCL_FLOAT64, NCCL_SUM, c->comm,
+                                                                  (hipStream_t)stream);
+    if (rc != 0) { set_error("rccl_allreduce_f64: ncclAllReduce returned %d", rc); return 1; }
+    ++c->calls;
+    return 0;
+}
+
 // (one double per workgroup: a BatchNorm tower's launches cut the rows per forward_once call -- up to one workgroup more)
 int64_t abn_tower_backward_loss_ws_bytes(int64_t rows) { return 8 + ((rows + PL_ROWS - 1) / PL_ROWS + 2) * (int64_t)sizeof(double); }
 

@@ -131,6 +131,7 @@ class _Segment(object):
         if sync is not None and sync.world >= 1:      # cross-replica BatchNorm statistics (parallel.BatchNormSync)
             d.bn_sync_world = sync.world
             d.bn_sync_fn = sync.fn
+            d.bn_sync_ctx = getattr(sync, 'ctx', None)
         d.dims[0] = self.input_dim
         grad_slots = []                      # (field, layer, float offset in the flat buffers)
         offs = self.offsets()                # in the order of self.params

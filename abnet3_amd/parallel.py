@@ -200,3 +200,69 @@ class BatchNormSync:
             import traceback
             traceback.print_exc()
             return 2
+
+
+class RcclBatchNormSync:
+    """BatchNormSync without Python between the launches: the library's own abn_rccl_allreduce_f64 is the descriptor's
+    bn_sync_fn, its context a communicator this object creates on the RCCL torch has loaded (one ncclCommInitRank per
+    trainer; the unique id travels over the existing process group).  The per-layer all-reduces are then issued from C on
+    the launch stream -- no host round trip through the interpreter, no exception path through C frames.  Needs the
+    "nccl" backend (device memory); parallel.bn_sync() picks it there and the Python callback elsewhere (gloo tests)."""
+
+    _UID_BYTES = 128
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import _lib
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != 'nccl':
+            raise RuntimeError('RcclBatchNormSync needs an initialised "nccl" process group')
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.collective = True
+        self.buffers = []              # (kept for the interface of BatchNormSync: nothing to validate here)
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        self._rccl = C.CDLL(path)      # (the copy torch has mapped already)
+        uid = (C.c_char * self._UID_BYTES)()
+        rank = dist.get_rank(group)
+        if rank == 0 and self._rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError('ncclGetUniqueId failed')
+        words = broadcast_array(np.frombuffer(bytes(uid), dtype=np.int64).copy(), src=0) if self.world > 1 else \
+            np.frombuffer(bytes(uid), dtype=np.int64).copy()
+        C.memmove(uid, words.tobytes(), self._UID_BYTES)
+        comm = C.c_void_p()
+
+        class _Uid(C.Structure):
+            _fields_ = [('internal', C.c_char * self._UID_BYTES)]
+        u = _Uid()
+        C.memmove(C.byref(u), uid, self._UID_BYTES)
+        self._rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _Uid, C.c_int]
+        torch.cuda.synchronize()
+        rc = self._rccl.ncclCommInitRank(C.byref(comm), self.world, u, rank)
+        if rc != 0 or not comm.value:
+            raise RuntimeError('ncclCommInitRank failed (%d)' % rc)
+        self._comm = comm
+        self._ctx = _lib.RcclCtx(comm.value, C.cast(self._rccl.ncclAllReduce, C.c_void_p).value, 0)
+        self.ctx = C.addressof(self._ctx)
+        self.fn = C.cast(_lib.load().abn_rccl_allreduce_f64, C.c_void_p).value
+
+    @property
+    def calls(self):
+        return int(self._ctx.calls)
+
+    def __del__(self):
+        try:
+            if getattr(self, '_comm', None) is not None and self._comm.value:
+                self._rccl.ncclCommDestroy.argtypes = [type(self._comm)]
+                self._rccl.ncclCommDestroy(self._comm)
+                self._comm = None
+        except Exception:
+            pass
+
+
+def bn_sync(group=None):
+    """The cross-replica BatchNorm exchange for this process group: issued from C over RCCL on the "nccl" backend
+    (ABN_BN_SYNC_PY=1: the Python callback there too), the Python callback over torch.distributed otherwise."""
+    if (dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'nccl'
+            and os.environ.get('ABN_BN_SYNC_PY') != '1'):
+        return RcclBatchNormSync(group)
+    return BatchNormSync(group)

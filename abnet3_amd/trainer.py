@@ -173,7 +173,7 @@ class TrainerBuilder:
             # BatchNorm statistics over ALL replicas' rows (off: every replica normalises with its own, like torch's
             # DistributedDataParallel without SyncBatchNorm): R replicas then step like one process on the whole batch
             if sync_batch_norm and getattr(self.network, 'batch_norm', False):
-                self.network.bn_sync = parallel.BatchNormSync()
+                self.network.bn_sync = parallel.bn_sync()
         self.sync_batch_norm = bool(sync_batch_norm)
 
     def params(self):

@@ -166,6 +166,18 @@ typedef struct abn_tower_desc {
     const int32_t* n_valid;
 } abn_tower_desc;
 
+/* A ready-made abn_allreduce_fn for abn_tower_desc.bn_sync_fn over RCCL, so that no host language stands between
+ * two launches of a data-parallel BatchNorm step: ctx = an abn_rccl_ctx the caller fills once -- `comm` its ncclComm_t,
+ * `all_reduce` the address of RCCL's ncclAllReduce (the library does not link RCCL: the caller already has it loaded,
+ * e.g. torch's librccl.so) -- and the function issues ncclAllReduce(buf, buf, n, ncclFloat64, ncclSum, comm, stream)
+ * in place on the launch stream.  Returns 0, or 1 when RCCL reports an error. */
+typedef struct abn_rccl_ctx {
+    void* comm;
+    void* all_reduce;       /* ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) */
+    int64_t calls;          /* counts the all-reduces issued through this context (the caller's to read and reset) */
+} abn_rccl_ctx;
+int abn_rccl_allreduce_f64(void* ctx, void* device_doubles, int64_t n, void* stream);
+
 /* Workspace of one forward call (what the backward needs: the saved activations, for the
  * default arithmetic also the weights as MFMA operand fragments; its layout is the library's
  * own and depends on the descriptor), in floats, and the offset inside it of the

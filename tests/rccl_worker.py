@@ -95,6 +95,8 @@ def main():
         if not grouped:
             net.bn_sync = parallel.BatchNormSync()          # the same launches, nobody to add the sums up with
         assert net.bn_sync.collective == grouped
+        if grouped:                    # (on RCCL the exchange is issued from C: parallel.RcclBatchNormSync, no Python between the launches)
+            res['bn_native'] = np.array(int(type(net.bn_sync).__name__ == 'RcclBatchNormSync'))
         net.train()
         batch = (torch.from_numpy(xb1).cuda(), torch.from_numpy(xb2).cuda(), torch.from_numpy(yb).cuda())
         res[tag + '.bn.losses'] = np.array([float(tr.train_step(batch, True)) for _ in range(3)])

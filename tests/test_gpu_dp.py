@@ -260,6 +260,7 @@ def test_one_rank_on_rccl():
     assert not off, off
     # the paths that were meant to run, ran
     assert int(r['rccl.bn.calls']) >= 3 * 2 * 3        # 3 steps x (forward + backward) x one all-reduce per BatchNorm layer
+    assert int(r['bn_native']) == 1                    # ... issued by the library itself (abn_rccl_allreduce_f64), not by a Python callback
     assert int(r['rccl.planned.graphs']) >= 1
     assert r['rccl.planned.train_losses'][-1] < r['rccl.planned.train_losses'][0]
     assert int(r['rccl.bntrain.warned']) == 1 and int(r['rccl.bntrain.params_file']) == 1
