@@ -251,6 +251,9 @@ class RcclBatchNormSync:
 
     def __del__(self):
         try:
+            import sys
+            if sys.is_finalizing():        # (at interpreter exit the process group / RCCL may be gone already: the OS reclaims the communicator)
+                return
             if getattr(self, '_comm', None) is not None and self._comm.value:
                 self._rccl.ncclCommDestroy.argtypes = [type(self._comm)]
                 self._rccl.ncclCommDestroy(self._comm)
