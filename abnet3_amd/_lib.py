@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ABNET3_HIP_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get('ABNET3_HIP_LIB') or os.path.join(HERE, 'lib', 'libabnet3_hip.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 MAX_LAYERS = 16
 
 ACT = {'none': 0, None: 0, 'sigmoid': 1, 'relu': 2, 'tanh': 3}
@@ -61,6 +61,7 @@ SYMBOLS = {
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'abn_optimizer_step': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _f32,
                                       _f32, _f32, _f32, _i64, _f32, _vp]),
+    'abn_tower_sync_ws_bytes': (_i64, []),
     'abn_dtw_ws_bytes': (_i64, [_vp, _vp, _i64, _i64, _i64]),
     'abn_dtw_host_stage_bytes': (_i64, [_vp, _vp, _i64]),
     'abn_dtw_batched': (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
@@ -91,7 +92,8 @@ class TowerDesc(C.Structure):
         (name, _vp * MAX_LAYERS)
         for name in ('W', 'b', 'bn_w', 'bn_b', 'bn_rm', 'bn_rv', 'dW', 'db',
                      'dbn_w', 'dbn_b', 'drop_mask')] + [('precision', _i32), ('d_out_is_dz', _i32), ('defer_reduce', _i32), ('wpack_valid', _i32), ('forward_only', _i32), ('wgrad_part', _i32), ('wpack', _vp), ('drop_seed', _vp), ('drop_p', _f32), ('reserved2_', _i32),
-                     ('bn_sync_world', _i32), ('wgrad_split', _i32), ('bn_sync_fn', _vp), ('bn_sync_ctx', _vp), ('n_valid', _vp)]
+                     ('bn_sync_world', _i32), ('wgrad_split', _i32), ('bn_sync_fn', _vp), ('bn_sync_ctx', _vp), ('n_valid', _vp),
+                     ('bn_nbt', _vp * MAX_LAYERS), ('sync_ws', _vp)]
 
 
 class RcclCtx(C.Structure):
@@ -144,7 +146,7 @@ def reload_switches():
 E_UNSUPPORTED = -4
 
 # abn_tower_path's answers (include/abnet3_hip.h)
-PATH_PER_LAYER, PATH_FUSED_F32, PATH_PLANES, PATH_PLANES_INFER, PATH_PLANES_INFER_BN, PATH_BN_LAYERS, PATH_WIDE = range(7)
+PATH_PER_LAYER, PATH_FUSED_F32, PATH_PLANES, PATH_PLANES_INFER, PATH_PLANES_INFER_BN, PATH_BN_LAYERS, PATH_WIDE, PATH_BN_TOWER = range(8)
 PRECISION_NAMES = {0: 'fp32', 1: 'bf16', 2: 'bf16x3', 3: 'f16x2'}
 
 # Which kernels the tower calls of this process took: filled in by model.py from abn_tower_path (a pure

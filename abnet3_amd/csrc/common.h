@@ -36,6 +36,7 @@ struct Switches {
     bool fused;               // ABN_FUSED=0: per-layer kernels only
     int64_t fused_min_rows;   // ABN_FUSED_MIN_ROWS: -1 = each path's own default
     bool bn_planes;           // ABN_BN_PLANES=0: BatchNorm training on the per-layer kernels
+    bool bn_persist;          // ABN_BN_PERSIST=0: BatchNorm training one launch per layer (tower_planes.h), never the resident tower (tower_bn_persist.h)
     bool wgrad_xcd;           // ABN_WGRAD_XCD=0: weight-gradient workgroups in launch order
     bool bf16x3_planes;       // ABN_BF16X3_PLANES=0: (GEMM kernels) split per fragment instead of per tile
     bool bwd_pair;            // ABN_BWD_PAIR=0: wgrad and dgrad of a layer as two grids

@@ -180,7 +180,19 @@ __device__ __forceinline__ void dft8(cf* v)
 }
 
 constexpr int FB_WAVES = 4;            // wavefronts (frames in flight) per workgroup
-constexpr int FB_SPARSE_MAX = 2048;    // floats of LDS for the filters' non-zero weights (40 mel triangles: ~1000)
+constexpr int FB_SPARSE_Q = 24;        // 16-byte pieces of a filter's band in LDS (40 mel triangles over 513 bins: the widest spans 18)
+
+// Where element i of the wave's 512-point strip lives in LDS.  The passes read it lane-linearly (z[j + 64 r]: conflict free
+// as it stands) but WRITE it at strides of 8 elements (pass 0: z[8 j + r]: sixteen lanes on two bank pairs, 8-way) and in
+// 8-element runs 64 apart (pass 1: 2-way) -- profiles/r04_fbank_counters.txt: 40 % of the LDS-active cycles were conflicts.
+// An XOR inside each block of 8 (by the block's index / 2) spreads pass 0's lanes over all banks, an XOR of the block's
+// parity (by bit 3 of its index) separates pass 1's two runs; every 8-aligned run of 8 stays a permutation of itself, so
+// the lane-linear reads remain conflict free.  (i >> 3 = B: 8 (B ^ ((B >> 3) & 1)) + ((i & 7) ^ ((B >> 1) & 7)).)
+__device__ __forceinline__ int zsw(int i)
+{
+    const int B = i >> 3;
+    return ((B ^ ((B >> 3) & 1)) << 3) + ((i & 7) ^ ((B >> 1) & 7));
+}
 
 __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __restrict__ samples, int is_i16,
                                                                   int64_t nsamples, int wlen, double fshift, int nfilt,
@@ -191,9 +203,10 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
                                                                   const int64_t* __restrict__ utt_foff, int n_utts)
 {
     __shared__ cf zbuf[FB_WAVES][512];
-    __shared__ float pw[FB_WAVES][516];
-    __shared__ float sw[FB_SPARSE_MAX];          // the filters' non-zero weights, filter after filter
-    __shared__ int swoff[65];
+    __shared__ __attribute__((aligned(16))) float pw[FB_WAVES][516];
+    // the filters' non-zero weights as 16-byte pieces aligned to the bins' index, piece q of filter f at [q][f]: the lanes of a
+    // wave read consecutive pieces (conflict free; filter after filter, 4 bytes at a time, they met on the same banks)
+    __shared__ __attribute__((aligned(16))) float sw4[FB_SPARSE_Q][64][4];
     const int wave = threadIdx.x >> 6, j = threadIdx.x & 63;
     cf* const z = zbuf[wave];
     float* const power = pw[wave];
@@ -216,18 +229,20 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
     }
     // this lane's filter: its band of bins; the band's weights go to LDS once per workgroup
     const int blo = j < nfilt ? band[2 * j] : 1, bhi = j < nfilt ? band[2 * j + 1] : 0;
-    if (wave == 0) {
-        int off = 0;
-        for (int f = 0; f < j && f < nfilt; ++f) off += max(band[2 * f + 1] - band[2 * f] + 1, 0);
-        swoff[j] = off;
-        if (j == 63) swoff[64] = 0;
-        const int width = max(bhi - blo + 1, 0);
-        if (off + width <= FB_SPARSE_MAX)
-            for (int i = 0; i < width; ++i) sw[off + i] = melbank[(int64_t)(blo + i) * nfilt + j];
+    const int a0 = blo & ~3;                                       // the band's first piece starts at a multiple of four bins
+    const int nq = bhi >= blo ? (bhi - a0) / 4 + 1 : 0;            // pieces of this lane's band
+    const bool sparse_ok = __all(nq <= FB_SPARSE_Q && bhi <= 512);
+    const int nq_max = __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, nq));
+    if (wave == 0 && sparse_ok) {
+        for (int q = 0; q < nq_max; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = a0 + 4 * q + e;
+                sw4[q][j][e] = (q < nq && k >= blo && k <= bhi) ? melbank[(int64_t)k * nfilt + j] : 0.0f;
+            }
     }
+    if (j < 4) power[512 + j] = 0.0f;                               // (bins 513 .. 515: never written below, read under zero weights)
     __syncthreads();
-    const int myoff = swoff[j];
-    const bool sparse_ok = __all(myoff + max(bhi - blo + 1, 0) <= FB_SPARSE_MAX);
     // window taps of the samples this lane touches: elements m = j + 64 r, samples 2m, 2m+1
     float w0[8], w1[8];
 #pragma unroll
@@ -284,12 +299,12 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
         // pass 0 (sub-transform size 1): no twiddles; outputs to 8 j + r
         dft8(v);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) z[8 * j + r] = v[r];
+        for (int r = 0; r < 8; ++r) z[zsw(8 * j + r)] = v[r];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // pass 1 (size 8): k = j & 7; outputs to ((j - k) << 3) + k + 8 r
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = z[j + 64 * r];
+        for (int r = 0; r < 8; ++r) v[r] = z[zsw(j + 64 * r)];
 #pragma unroll
         for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw1[r]);
         dft8(v);
@@ -298,27 +313,27 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
         {
             const int k = j & 7, j0 = ((j - k) << 3) + k;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) z[j0 + 8 * r] = v[r];
+            for (int r = 0; r < 8; ++r) z[zsw(j0 + 8 * r)] = v[r];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // pass 2 (size 64): k = j; outputs to j + 64 r: natural order
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = z[j + 64 * r];
+        for (int r = 0; r < 8; ++r) v[r] = z[zsw(j + 64 * r)];
 #pragma unroll
         for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw2[r]);
         dft8(v);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) z[j + 64 * r] = v[r];
+        for (int r = 0; r < 8; ++r) z[zsw(j + 64 * r)] = v[r];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // split: X[k] = (Z[k] + conj Z[512-k]) / 2 - i e^{-2 pi i k / 1024} (Z[k] - conj Z[512-k]) / 2, and its mirror
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = j + 64 * q;                              // 0 .. 255
-            const cf a = z[k], b = z[(512 - k) & 511];
+            const cf a = z[zsw(k)], b = z[zsw((512 - k) & 511)];
             const cf s = {0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};        // (Z[k] + conj Z[N-k]) / 2
             const cf d = {0.5f * (a.x - b.x), 0.5f * (a.y + b.y)};        // (Z[k] - conj Z[N-k]) / 2
             const cf t = cmul(tws[q], d);                                 // w d ; -i w d = (t.y, -t.x)
@@ -329,24 +344,22 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
             power[512 - k] = xm.x * xm.x + xm.y * xm.y;            // k = 0: bin 512 = (Re Z0 - Im Z0)^2
         }
         if (j == 0) {                                              // bin 256: its own mirror, w = -i
-            const cf a = z[256];
+            const cf a = z[zsw(256)];
             power[256] = a.x * a.x + a.y * a.y;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // mel projection + log
         float e = 0.0f;
-        if (sparse_ok) {                               // four independent partial sums: the LDS reads pipeline
-            const float* pk = power + blo;
-            const float* wk = sw + myoff;
-            const int width = bhi - blo + 1;
+        if (sparse_ok) {                               // 16 bytes of the band and of its weights per step, four partial sums
+            typedef float fb4 __attribute__((ext_vector_type(4)));
             float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
-            int i = 0;
-            for (; i + 3 < width; i += 4) {
-                e0 = fmaf(pk[i], wk[i], e0); e1 = fmaf(pk[i + 1], wk[i + 1], e1);
-                e2 = fmaf(pk[i + 2], wk[i + 2], e2); e3 = fmaf(pk[i + 3], wk[i + 3], e3);
+            for (int q = 0; q < nq_max; ++q) {         // (every lane walks the widest band: past its own end the weights are zeros)
+                const fb4 pk = *reinterpret_cast<const fb4*>(power + min(a0 + 4 * q, 512));
+                const fb4 wk = *reinterpret_cast<const fb4*>(&sw4[q][j][0]);
+                e0 = fmaf(pk[0], wk[0], e0); e1 = fmaf(pk[1], wk[1], e1);
+                e2 = fmaf(pk[2], wk[2], e2); e3 = fmaf(pk[3], wk[3], e3);
             }
-            for (; i < width; ++i) e0 = fmaf(pk[i], wk[i], e0);
             e = (e0 + e1) + (e2 + e3);
         } else {
             for (int k = blo; k <= bhi; ++k) e = fmaf(power[k], melbank[(int64_t)k * nfilt + j], e);

@@ -18,6 +18,7 @@
 #include "opt_rule.h"
 #include "tower_fused.h"
 #include "tower_planes.h"
+#include "tower_bn_persist.h"
 #include "tower_wide.h"
 
 namespace abn {
@@ -40,6 +41,7 @@ static Switches read_switches()
     s.fused = !off("ABN_FUSED");
     s.fused_min_rows = getenv("ABN_FUSED_MIN_ROWS") ? atoll(getenv("ABN_FUSED_MIN_ROWS")) : -1;
     s.bn_planes = !off("ABN_BN_PLANES");
+    s.bn_persist = !off("ABN_BN_PERSIST");
     s.wgrad_xcd = !off("ABN_WGRAD_XCD");
     s.bf16x3_planes = !off("ABN_BF16X3_PLANES");
     s.bwd_pair = !off("ABN_BWD_PAIR");
@@ -354,8 +356,7 @@ __global__ void slab_reduce_step_kernel(const float* __restrict__ slabs, ReduceT
         }
 }
 
-constexpr float BN_EPS = 1e-5f;
-constexpr float BN_MOMENTUM = 0.1f;
+// (BN_EPS, BN_MOMENTUM, BN_WG_GROUPS: tower_bn_persist.h)
 
 // BatchNorm column reductions run in two deterministic stages over many workgroups
 // (the first version used 32 workgroups for the whole matrix: 150-300 us per layer).
@@ -446,7 +447,6 @@ __global__ void bn_stats_finish_kernel(const double* __restrict__ part, int nchu
 // (n = the workgroup's rows: 32, fewer in the last one of a call).
 // A block = 64 columns x 16 groups of workgroups: every group adds its share in order, thread group 0 the
 // sixteen group sums in order (one thread per column walking 128 workgroups alone took 18 us).
-constexpr int BN_WG_GROUPS = 16;
 // sums_out (cross-replica statistics, abn_tower_desc.bn_sync_world): the launch stops at [call][sum z | sum z^2][C] in
 // float64 -- the caller all-reduces them and bn_stats_from_sums_kernel finishes.
 __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
@@ -975,7 +975,10 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
     for (int l = 0; l < t->n_layers; ++l) L.tp[l] = L.amax[l] = -1;
     L.wpack = -1;
     L.bn_wg = -1;
-    if (planes_dims_ok(t) && t->batch_norm && !t->forward_only) L.bn_wg = take((n_calls * bn_wgs_per_call(rows, n_calls) + 1) * 3 * PL_MAXW);
+    if (planes_dims_ok(t) && t->batch_norm && !t->forward_only) {
+        L.bn_wg = take((n_calls * bn_wgs_per_call(rows, n_calls) + 1) * 3 * PL_MAXW);
+
+    }
     if (planes_dims_ok(t)) {
         const int np = planes_of(t);
         L.wpack = take(make_pack_layout(t).bytes / 4);
@@ -1057,6 +1060,48 @@ static bool bn_train_planes_path(const abn_tower_desc* t, int64_t rows, int64_t 
     abn_tower_desc u = *t;
     u.batch_norm = 0;
     return planes_kind(&u, rows, 1, x1, x2, ws, PLANES_TRAIN, false) != PLANES_NONE;
+}
+
+// The resident BatchNorm tower (tower_bn_persist.h: one launch per direction, grid barriers between the layers) takes a
+// training call of the BatchNorm layer launches when its grid -- one workgroup per 32 rows of a call -- is resident at once:
+// at most as many workgroups as the device has CUs (the kernels need more than half a CU's LDS and registers: one
+// workgroup per CU), at least 8 (the finishing step's share of the columns fits its LDS scratch), per-replica
+// statistics (a cross-replica exchange happens on the host, between launches), and the caller keeps a sync buffer
+// (abn_tower_desc.sync_ws: the workgroups' hand-overs and the launch counter their tags come from).  ABN_BN_PERSIST=0: never.
+static int device_cus()
+{
+    static int cus[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = (dev >= 0 && dev < 16) ? dev : 0;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 1;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+static bool bn_persist_path(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
+{
+    if (!switches().bn_persist || bn_sync_on(t) || !t->sync_ws || !aligned16(t->sync_ws)) return false;
+    const int64_t grid = n_calls * bn_wgs_per_call(rows, n_calls);
+    return grid >= 8 && grid <= device_cus() && grid <= BNP_MAX_WGS && n_calls <= BNP_MAX_CALLS;
+}
+static inline size_t bnp_lds_bytes(int np) { return pl_lds_bytes_bn(np) + 16; }      // + the barrier's LDS word
+
+// BatchNorm1d.num_batches_tracked (abnet3/model.py:139: torch's BatchNorm1d counts its training calls): += n_calls per layer
+struct NbtP { long long* p[ABN_MAX_LAYERS]; int n, add; };
+__global__ void bn_nbt_kernel(NbtP a)
+{
+    if ((int)threadIdx.x < a.n && a.p[threadIdx.x]) *a.p[threadIdx.x] += a.add;
+}
+static void launch_nbt(const abn_tower_desc* t, int64_t n_calls, hipStream_t st)
+{
+    NbtP a = {};
+    bool any = false;
+    a.n = t->n_layers; a.add = (int)n_calls;
+    for (int l = 0; l < t->n_layers; ++l) { a.p[l] = reinterpret_cast<long long*>(t->bn_nbt[l]); any = any || a.p[l]; }
+    if (any) hipLaunchKernelGGL(bn_nbt_kernel, dim3(1), dim3(64), 0, st, a);
 }
 
 static int check_desc(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
@@ -1322,6 +1367,50 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, const
         hipLaunchKernelGGL(bn_bwd_from_sums_kernel, dim3(grid_for(n_calls * C)), dim3(256), 0, st, sums, C, (int)n_calls, s1, s2);
         return ABN_OK;
     };
+    if (bn_persist_path(t, rows, n_calls)) {
+        // every layer in ONE resident launch, grid barriers in between (tower_bn_persist.h)
+        static bool bt_attr_set[16] = {};
+        if (!bt_attr_set[dev]) {
+            PL_LDS_ATTR(bn_bwd_tower_kernel, bnp_lds_bytes);
+            bt_attr_set[dev] = true;
+        }
+        BnBwdTowerP q = {};
+        q.n_layers = nl; q.rows = (int)rows; q.rows_call = (int)rpc; q.n_calls = (int)n_calls;
+        for (int l = 0; l <= nl; ++l) q.dims[l] = (int)t->dims[l];
+        for (int l = 0; l < nl; ++l) {
+            q.act[l] = (l == nl - 1) ? t->last_act : t->act;
+            q.z[l] = ws + L.xhat[l];
+            q.mean[l] = ws + L.mean[l]; q.invstd[l] = ws + L.invstd[l];
+            q.gamma[l] = t->bn_w[l]; q.beta[l] = t->bn_b[l];
+            q.dgamma[l] = t->dbn_w[l]; q.dbeta[l] = t->dbn_b[l];
+            q.mask[l] = t->drop_mask[l];
+            q.wpt[l] = image + PL.wpt[l];
+            q.dzp[l] = reinterpret_cast<char*>(scratch + B.dzp[l]);
+            q.amax_dz[l] = B.amax_dz[l] >= 0 ? scratch + B.amax_dz[l] : nullptr;
+        }
+        q.drop_seed = reinterpret_cast<const unsigned long long*>(t->drop_seed);
+        q.drop_p = t->drop_p;
+        q.wbase = image; q.wbytes = PL.bytes;
+        q.tp_steps = tp_steps;
+        q.dx = dx;
+        q.d_out = loss ? nullptr : d_out;
+        q.a_top = ws + L.a[nl - 1];
+        q.sync_ws = t->sync_ws;
+        q.sync_bytes = bnp_sync_bytes(BNP_MAX_WGS);
+        q.n_valid = nvp;
+        q.n_stat = (float)rpc;
+        q.loss_kind = -1;
+        if (loss) {
+            q.loss_kind = loss->kind; q.y = loss->y; q.y_dtype = loss->y_dtype;
+            q.margin = (double)loss->margin;
+            q.scale = loss->avg ? 1.0 / (double)rpc : 1.0;
+            q.loss_counter = reinterpret_cast<unsigned*>(loss->ws);
+            q.loss_partial = reinterpret_cast<double*>(reinterpret_cast<char*>(loss->ws) + 8);
+            q.loss_out = loss->loss_out;
+            q.loss_accum = loss->loss_accum;
+        }
+        PL_LAUNCH(np, bn_bwd_tower_kernel, cgrid, dim3(PL_NT), bnp_lds_bytes(np), st, q);
+    } else {
     // d loss / d a of the output layer: the caller's, or (the pair loss riding along) formed by the first launch from the embeddings
     const float* da_top = d_out;
     {
@@ -1379,6 +1468,7 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, const
             if (rc != ABN_OK) return rc;
             cur ^= 1;
         }
+    }
     }
     int n_wg = 0;
     WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg);
@@ -1614,7 +1704,7 @@ static int forward_path(const abn_tower_desc* t, const float* x1, const float* x
     const bool bn_train = train && bn_train_planes_path(t, rows, n_calls, x1, x2, ws);
     const int kind = planes_kind(t, rows, n_calls, x1, x2, ws, train ? PLANES_TRAIN : PLANES_EVAL_FORWARD);
     if (!bn_train && kind == PLANES_WIDE) return ABN_PATH_WIDE;
-    if (bn_train) return ABN_PATH_BN_LAYERS;
+    if (bn_train) return bn_persist_path(t, rows, n_calls) ? ABN_PATH_BN_TOWER : ABN_PATH_BN_LAYERS;
     if (kind != PLANES_NONE) {
         if (t->batch_norm) return ABN_PATH_PLANES_INFER_BN;
         return (t->forward_only && !(train && t->drop_seed) && !train) ? ABN_PATH_PLANES_INFER : ABN_PATH_PLANES;
@@ -1626,7 +1716,7 @@ static int backward_path(const abn_tower_desc* t, const float* x1, const float* 
     const int kind = planes_kind(t, rows, n_calls, x1, x2, ws);
     if (kind == PLANES_WIDE) return ABN_PATH_WIDE;
     if (kind == PLANES_CHAIN) return ABN_PATH_PLANES;
-    if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) return ABN_PATH_BN_LAYERS;
+    if (bn_train_planes_path(t, rows, n_calls, x1, x2, ws)) return bn_persist_path(t, rows, n_calls) ? ABN_PATH_BN_TOWER : ABN_PATH_BN_LAYERS;
     return ABN_PATH_PER_LAYER;
 }
 
@@ -1646,6 +1736,8 @@ int abn_tower_uses_planes(const abn_tower_desc* t, int64_t rows, const float* x1
     if (train && t->batch_norm) return bn_train_planes_path(t, rows, 1, x1, x2, ws) ? 1 : 0;
     return planes_path(t, rows, x1, x2, ws, train ? PLANES_TRAIN : PLANES_EVAL_FORWARD) ? 1 : 0;
 }
+
+int64_t abn_tower_sync_ws_bytes(void) { return bnp_sync_bytes(BNP_MAX_WGS); }
 
 int64_t abn_tower_wpack_floats(const abn_tower_desc* t)
 {
@@ -1798,6 +1890,33 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
             const int64_t wpc = bn_wgs_per_call(rows, n_calls);
             const dim3 bgrid((unsigned)(n_calls * wpc));
             f.tp_steps = 2 * n_calls * wpc;                    // (the images' row axis is padded per call)
+            if (bn_persist_path(t, rows, n_calls)) {
+                // every layer in ONE resident launch, grid barriers in between (tower_bn_persist.h)
+                static bool bt_attr_set[16] = {};
+                if (!bt_attr_set[dev]) {
+                    PL_LDS_ATTR(bn_fwd_tower_kernel, bnp_lds_bytes);
+                    bt_attr_set[dev] = true;
+                }
+                PlanesFwdP fl = f;
+                BnPersistP q = {};
+                for (int l = 0; l < nl; ++l) {
+                    fl.tp[l] = reinterpret_cast<char*>(ws + L.tp[l]);        // [a_{l-1} | 1] transposed: the weight gradient's operand
+                    fl.amax[l] = L.amax[l] >= 0 ? ws + L.amax[l] : nullptr;
+                    fl.out[l] = nullptr;
+                    q.z[l] = ws + L.xhat[l];
+                    q.mean[l] = ws + L.mean[l]; q.invstd[l] = ws + L.invstd[l]; q.var[l] = ws + L.var[l];
+                    q.rm[l] = t->bn_rm[l]; q.rv[l] = t->bn_rv[l];
+                    q.nbt[l] = reinterpret_cast<long long*>(t->bn_nbt[l]);
+                }
+                q.sync_ws = t->sync_ws;
+                q.sync_bytes = bnp_sync_bytes(BNP_MAX_WGS);
+                q.n_valid = t->n_valid;
+                q.n_calls = (int)n_calls;
+                q.a_top = ws + L.a[nl - 1];
+                PL_LAUNCH(np, bn_fwd_tower_kernel, bgrid, dim3(PL_NT), bnp_lds_bytes(np), st, fl, q);
+                ABN_CHECK_LAUNCH("tower_forward (BatchNorm, resident tower)");
+                return ABN_OK;
+            }
             for (int l = 0; l < nl; ++l) {
                 PlanesFwdP fl = f;
                 for (int i = 0; i < nl; ++i) { fl.tp[i] = nullptr; fl.out[i] = nullptr; }
@@ -1830,6 +1949,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
             hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, z, rows, rpc, N, ws + L.mean[nl - 1],
                                ws + L.invstd[nl - 1], t->bn_rm[nl - 1], t->bn_rv[nl - 1], 1, t->bn_w[nl - 1], t->bn_b[nl - 1],
                                t->last_act, static_cast<float*>(nullptr), ws + L.a[nl - 1], t->n_valid);
+            launch_nbt(t, n_calls, st);
             ABN_CHECK_LAUNCH("tower_forward (BatchNorm, planes)");
             return ABN_OK;
         }
@@ -1945,6 +2065,7 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         }
         in = a;
     }
+    if (train && t->batch_norm) { launch_nbt(t, n_calls, st); ABN_CHECK_LAUNCH("batch_norm counters"); }
     return ABN_OK;
 }
 

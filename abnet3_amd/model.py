@@ -147,6 +147,8 @@ class _Segment(object):
                 d.bn_b[l] = bn.bias.data_ptr()
                 d.bn_rm[l] = bn.running_mean.data_ptr()
                 d.bn_rv[l] = bn.running_var.data_ptr()
+                if bn.num_batches_tracked is not None and bn.num_batches_tracked.is_cuda:
+                    d.bn_nbt[l] = bn.num_batches_tracked.data_ptr()      # (the training forward counts its calls itself)
                 grad_slots += [('dbn_w', l, offs[gi]), ('dbn_b', l, offs[gi + 1])]
                 gi += 2
         # a persistent image of the weights as operand fragments (abn_tower_desc.wpack): the forward skips its
@@ -157,6 +159,11 @@ class _Segment(object):
             if n > 0:
                 self._wpack = torch.zeros(n, dtype=torch.float32, device=net._flat.device)
                 d.wpack = self._wpack.data_ptr()
+        # the resident BatchNorm tower's sync buffer (abn_tower_desc.sync_ws): zero once, the library's from then on
+        self._sync_ws = None
+        if self.batch_norm and net._flat.is_cuda and os.environ.get('ABN_BN_SYNC_WS') != '0':
+            self._sync_ws = torch.zeros(_lib.load().abn_tower_sync_ws_bytes() // 4, dtype=torch.int32, device=net._flat.device)
+            d.sync_ws = self._sync_ws.data_ptr()
         self._desc_cache = (key, d, grad_slots)
         return d
 
@@ -313,7 +320,7 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False, n_vali
         # odd widths) the call falls back to per-replica statistics, said once -- not an error.
         desc = _lib.TowerDesc.from_buffer_copy(desc)
         desc.forward_only = 0
-        if lib.abn_tower_path(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2), rows, n_calls, 1, _lib.ptr(x1), 0, None) == _lib.PATH_BN_LAYERS:
+        if lib.abn_tower_path(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2), rows, n_calls, 1, _lib.ptr(x1), 0, None) in (_lib.PATH_BN_LAYERS, _lib.PATH_BN_TOWER):
             synced = True
         else:
             desc.forward_only = int(forward_only)
@@ -337,8 +344,10 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False, n_vali
         # the operand-plane kernels rebuilt the persistent weight image (the per-layer path never touches it)
         if lib.abn_tower_uses_planes(_lib.C.byref(desc), rows, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(ws), int(train)) == 1:
             seg.wpack_matches(seg._key_at_descriptor)
-    if train and seg.batch_norm:        # one launch for all the counters
-        torch._foreach_add_([bn.num_batches_tracked for bn in seg.bn_modules()], n_calls)
+    if train and seg.batch_norm:        # (the counters the library was not given: it adds n_calls to the others itself)
+        left = [bn.num_batches_tracked for l, bn in enumerate(seg.bn_modules()) if not desc.bn_nbt[l]]
+        if left:
+            torch._foreach_add_(left, n_calls)
     off = lib.abn_tower_out_offset(_lib.C.byref(desc), rows, n_calls)
     out = ws[off:off + rows * seg.output_dim].view(rows, seg.output_dim)
     sv = _Saved()
@@ -791,7 +800,7 @@ class SiameseNetwork(_HipNetwork):
         desc = seg.descriptor(with_grads=False)
         lib = _lib.load()
         return lib.abn_tower_path(_lib.C.byref(desc), _lib.ptr(x12[:npad]), _lib.ptr(x12[npad:]), 2 * npad, 2, 1, _lib.ptr(x12), 0,
-                                  None) == _lib.PATH_BN_LAYERS
+                                  None) in (_lib.PATH_BN_LAYERS, _lib.PATH_BN_TOWER)
 
     def direct_dz_info(self, state):
         """What the pair loss needs to hand back d loss / d z of the output layer itself

@@ -38,7 +38,8 @@ C2 = dict(input_dim=40, num_hidden_layers=2, hidden_dim=500, output_dim=100,
           p_dropout=0.0, batch_norm=False, type_init='xavier_uni',
           activation_layer='sigmoid')
 BATCH = 4096
-POOL = 8
+POOL = 64                          # a fresh batch per step from a pre-generated pool of 64
+SIDE_STEPS = 50                    # fewest timed steps of a side mode (the other arithmetics, the variants) whatever --steps is
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 # bf16 x 3 spends six bf16 MFMA products per algorithmic fp32 product: its matrix-core roof,
@@ -109,7 +110,7 @@ def _traffic(kernel):
     """HBM bytes per launch from the TCC counters (FETCH_SIZE x2 per the gfx950
     correction + WRITE_SIZE), collected by tools/collect_traffic.sh in separate
     --pmc passes and committed under profiles/."""
-    for rnd in ('r04', 'r03', 'r02', 'r01'):
+    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
         try:
             t = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc_traffic.json' % rnd)))
             for name, v in t.items():
@@ -120,6 +121,22 @@ def _traffic(kernel):
     return None
 
 
+def _trace_us(kernel):
+    """(average duration in us of `kernel` inside the step, file) from the newest committed rocprofv3 --kernel-trace --stats
+    summary of this command (profiles/rNN_bench_kernel_stats.csv): which launch is dominant IN THE STEP is read there --
+    a kernel re-run alone, back to back, sees another cache than between its neighbours."""
+    import csv
+    for rnd in ('r05', 'r04', 'r03', 'r02'):
+        path = os.path.join(ROOT, 'profiles', '%s_bench_kernel_stats.csv' % rnd)
+        try:
+            for row in csv.DictReader(open(path)):
+                if kernel in row['Name'] and int(row['Calls']) >= 500:         # (the timed loop's launches, not a side mode's)
+                    return round(float(row['AverageNs']) * 1e-3, 2), 'profiles/%s_bench_kernel_stats.csv' % rnd
+        except Exception:
+            pass
+    return None, None
+
+
 def planes_roofline(torch, net, reps=20):
     """precision f16x2 / bf16x3 / bf16 (csrc/tower_planes.h): the step is three launches of similar length -- the
     forward chain, the data-gradient chain, the weight gradients -- plus the fused reduction + optimizer.
@@ -128,9 +145,9 @@ def planes_roofline(torch, net, reps=20):
     layer's dW = dZ^T [A | 1] over the 2 x 4096 rows, split over the rows into slabs, one launch (its tiles
     placed so that an XCD's L2 serves the re-reads).  Each of the three is timed live, alone: `reps`
     launches captured into one hipGraph and bracketed by HIP events on the launch stream (the backward
-    kernels through abn_tower_backward_launch, a measurement entry outside the header that issues one of
-    the backward's two launches; the forward with its packed weight image still valid, i.e. without the ~5 us
-    pack_planes_kernel a step's forward starts with); `forward_backward_sequence_us` is the three in the
+    kernels through abn_tower_backward_launch, the header's measurement entry that issues one of the backward's two
+    launches; the forward with its packed weight image still valid, i.e. without the ~6.6 us
+    pack_planes_scaled_kernel a step's forward starts with); `forward_backward_sequence_us` is the three in the
     step's order.  Algorithmic FLOPs: weight gradients 2 * 8192 * sum_l N_l (K_l + 1), the chains
     2 * 8192 * sum_l N_l K_l (the data-gradient chain without the first layer).
     Roof: the dense 16-bit MFMA peak divided by the MFMA products each algorithmic product costs (three fp16
@@ -154,14 +171,15 @@ def planes_roofline(torch, net, reps=20):
     bwd()                                           # a complete backward: both kernels' outputs are in place
 
     # Each launch alone: `reps` launches captured into one hipGraph, HIP events around its replays.  (Against the
-    # in-step durations of the rocprofv3 trace -- 68.4 / 69.4 / 70.0 us -- this reads the weight gradients ~5 % low
-    # and the two chains 8-15 % high: a step moves ~460 MB through HBM / Infinity Cache, and twenty launches of one
-    # kernel rewriting the same images see a different cache.  Events BETWEEN the launches of a real sequence add
-    # ~10 us each, and sequences with one launch left out do not subtract cleanly: both were tried.)
+    # in-step durations of the committed rocprofv3 trace -- `in_step_trace_us` beside each entry -- this reads the
+    # weight gradients a few % high or low and the two chains up to 15 % high: a step moves ~400 MB through HBM /
+    # Infinity Cache, and twenty launches of one kernel rewriting the same images see a different cache.  Events
+    # BETWEEN the launches of a real sequence add ~10 us each, and sequences with one launch left out do not subtract
+    # cleanly: both were tried.)
     times = {}
     from abnet3_amd import _lib
     lib = _lib.load()
-    part_fn = lib.abn_tower_backward_launch       # measurement entry (not in the header): one of the two launches
+    part_fn = lib.abn_tower_backward_launch       # the header's measurement entry: one of the backward's two launches
     part_fn.restype = _lib.C.c_int
     seg, sv, gp = state
     gbuf, _ = gp.views(seg)
@@ -199,9 +217,14 @@ def planes_roofline(torch, net, reps=20):
     }
     entries = {}
     for key, (name, short, t, fl, what) in launches.items():
-        entries[key] = {'kernel': '%s  (%s; alone, back to back from one hipGraph)' % (name, what),
+        in_step, trace_file = _trace_us(short)
+        entries[key] = {'kernel': '%s  (%s)' % (name, what),
                         'achieved': round(fl / t / 1e12, 2), 'frac': round(fl / t / 1e12 / peak, 4),
-                        'avg_launch_us': round(t * 1e6, 2), 'flop_per_launch': fl, 'traffic': _traffic(short)}
+                        'avg_launch_us': round(t * 1e6, 2),
+                        'avg_launch_us_is': 'this run, the launch ALONE: %d launches back to back from one hipGraph, HIP events on the launch stream' % reps,
+                        'in_step_trace_us': in_step,
+                        'in_step_trace_us_is': 'the same kernel between its neighbours in the step: committed rocprofv3 --kernel-trace --stats of this command (%s)' % trace_file,
+                        'flop_per_launch': fl, 'traffic': _traffic(short)}
     # What the chains are actually bound by: every workgroup of 32 rows pulls the whole packed layer through
     # its CU's L1 from the XCD's L2 -- bytes per launch = workgroups x packed weight image --, at most 64 B/clk per CU.
     steps = lambda c: ((c + 15) // 16 + 3) // 4 * 4
@@ -214,10 +237,16 @@ def planes_roofline(torch, net, reps=20):
                                           'peak_TB_s': round(256 * 64 * 2.4e9 / 1e12, 1),
                                           'note': 'packed weights streamed L2 -> L1 by every workgroup; peak = 256 CUs x 64 B/clk x 2.4 GHz '
                                                   '(the k-loops run at 45-58 B/clk per CU; the rest of a launch is epilogue without loads)'}
-    # The line's top level is whichever of the three launches took LONGEST in this run (alone, back to back: against
-    # the in-step durations of the committed rocprofv3 trace this reads the chains 8-15 % high and the weight
-    # gradients ~5 % low, so the top-level fraction is the conservative one); the other two follow under their names.
-    dominant = max(entries, key=lambda k: entries[k]['avg_launch_us'])
+    # The line's top level names the launch that is dominant IN THE STEP: the order is the committed rocprofv3 trace's
+    # (in_step_trace_us), its duration and fraction are this run's live measurement of that launch alone (avg_launch_us;
+    # against the trace the standalone harness reads the chains up to 15 % high: the top-level fraction is the
+    # conservative one); without a committed trace the longest standalone launch.  The other two follow under their names.
+    if all(entries[k]['in_step_trace_us'] for k in entries):
+        dominant = max(entries, key=lambda k: entries[k]['in_step_trace_us'])
+        dominant_by = 'in_step_trace_us (committed rocprofv3 trace)'
+    else:
+        dominant = max(entries, key=lambda k: entries[k]['avg_launch_us'])
+        dominant_by = 'avg_launch_us (no committed trace found)'
     e = entries[dominant]
     out = {'bound': 'mfma', 'achieved': e['achieved'], 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': e['frac'],
            'traffic': e['traffic'], 'arithmetic': prec,
@@ -230,15 +259,18 @@ def planes_roofline(torch, net, reps=20):
            'frac_of_dense_16bit_peak': round(e['achieved'] / BF16_MFMA_PEAK_TFLOPS, 4),
            'frac_of_fp32_mfma_peak': round(e['achieved'] / FP32_MFMA_PEAK_TFLOPS, 4),
            'frac_of_bf16x3_peak': round(e['achieved'] / X3_PEAK_TFLOPS, 4),
-           'dominant': dominant,
-           'kernel': e['kernel'], 'avg_launch_us': e['avg_launch_us'],
+           'dominant': dominant, 'dominant_by': dominant_by,
+           'kernel': e['kernel'], 'avg_launch_us': e['avg_launch_us'], 'avg_launch_us_is': e['avg_launch_us_is'],
+           'in_step_trace_us': e['in_step_trace_us'], 'in_step_trace_us_is': e['in_step_trace_us_is'],
            'flop_per_launch': e['flop_per_launch']}
+    if e['in_step_trace_us']:
+        out['frac_at_in_step_duration'] = round(e['flop_per_launch'] / (e['in_step_trace_us'] * 1e-6) / 1e12 / peak, 4)
     if 'operand_stream' in e:
         out['operand_stream'] = e['operand_stream']
     if e['traffic']:
         gbs = e['traffic'] / (e['avg_launch_us'] * 1e-6) / 1e9
         out['hbm'] = {'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
-                      'note': 'measured TCC traffic per launch (profiles/r04_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, '
+                      'note': 'measured TCC traffic per launch (profiles/rNN_pmc_traffic.json, the newest: FETCH_SIZE x 2 + WRITE_SIZE, '
                               'Infinity-Cache hits included) / launch time'}
     for key, v in entries.items():
         if key != dominant:
@@ -330,18 +362,23 @@ def tower_roofline(torch, net, reps=20):
     return out
 
 
-def cpu_baseline(torch, budget_s=12.0):
-    """The reference's train step as the oracle restates it with torch.nn on
-    the CPU (oracle/torch_ref.py, pinned by tests/golden/train_c2_*), timed on
-    this host's cores on a bounded sample of the same workload."""
-    from oracle import torch_ref
-    # the box's CPU share for one GPU is 16 cores (more threads than that only
-    # oversubscribe the cgroup); never more than the affinity mask allows
+def host_cores():
+    """the box's CPU share for one GPU is 16 cores (more threads than that only
+    oversubscribe the cgroup); never more than the affinity mask allows"""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(16, avail)))
+    return max(1, min(16, avail))
+
+
+def cpu_baseline(torch, budget_s=12.0, threads=None):
+    """The reference's train step as the oracle restates it with torch.nn on
+    the CPU (oracle/torch_ref.py, pinned by tests/golden/train_c2_*), timed on
+    this host's cores on a bounded sample of the same workload.  threads: all of the
+    box's share (default), or 1 (BASELINE.md section 3 lists both)."""
+    from oracle import torch_ref
+    torch.set_num_threads(threads or host_cores())
     net = torch_ref.build(seed=0, **C2)
     opt = torch.optim.Adadelta(net.parameters(), lr=0.1)
     pool = [torch_ref.make_inputs(BATCH, 40, s) for s in range(2)]
@@ -410,8 +447,8 @@ def variants_bench(torch, pool, args, rank, world):
                             dataloader=None, log_dir='/tmp/abnet3_bench_runs')
         net.train()
         step = make_stepper(tr, pool, args.graph)
-        steps = max(20, args.steps // 4)
-        for i in range(10):
+        steps = max(SIDE_STEPS, args.steps // 4)
+        for i in range(20):
             step(i)
         if world > 1:
             torch.distributed.barrier()
@@ -447,8 +484,8 @@ def mode_bench(torch, trainer, net, pool, args, world, prec, note):
     err = float((got - ref).abs().max() / ref.abs().max())
     net.train()
     step = make_stepper(trainer, pool, args.graph)
-    steps = max(20, args.steps // 2)
-    for i in range(10):
+    steps = max(SIDE_STEPS, args.steps // 2)
+    for i in range(20):
         step(i)
     if world > 1:
         torch.distributed.barrier()
@@ -540,6 +577,17 @@ def dtw_bench(torch, P, rank, world, reps=3, cpu_pairs=4000):
                                'kind': 'port', 'sample': '%d of the %d pairs (%d cells, %.1f s), oracle/dtw.c'
                                % (q, P, sub_cells, dt)}
         out['paths_bit_exact_on_sample'] = bool(exact)
+        # ... and on all of the box's cores (OpenMP over the pairs, which are independent: the same paths)
+        cores = host_cores()
+        qa = min(P, cpu_pairs * min(cores, 4))
+        cells_a = int((n1[:qa].astype(np.int64) * n2[:qa]).sum())
+        t0 = time.perf_counter()
+        a1, a2, aln, _ = dtw_oracle.dtw_batch(f1, o1[:qa], n1[:qa], f2, o2[:qa], n2[:qa], 1200, threads=cores)
+        dta = time.perf_counter() - t0
+        out['cpu_baseline_all_cores'] = {'value': round(cells_a / dta, 1), 'unit': 'cells/s', 'cores': cores, 'kind': 'port',
+                                         'sample': '%d of the %d pairs (%d cells, %.1f s), oracle/dtw.c, OpenMP over the pairs'
+                                         % (qa, P, cells_a, dta),
+                                         'same_paths_as_one_core': bool((aln[:q] == ln).all() and (a1[:q] == p1).all() and (a2[:q] == p2).all())}
     return out
 
 
@@ -624,11 +672,7 @@ def pipeline_bench(torch, n_utts, n_pairs, epochs, with_cpu):
         cpu['dtw_cells_per_s'] = round(cells / dt, 1)
         cpu['dtw_sample'] = '%d same pairs of the training set (%d cells of 280-d frames, %.2f s), oracle/dtw.c, 1 core' % (len(same), cells, dt)
         # training: the torch-CPU restatement on the first batches of the OriginalDataLoader plan (ragged sizes)
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        torch.set_num_threads(max(1, min(16, avail)))
+        torch.set_num_threads(host_cores())
         plan = kept['original'][1].plan(True)
         batches = [tuple(t.cpu() for t in plan.materialise(b)) for b in plan.order[:60]]
         net = torch_ref.build(seed=0, **c5_pipeline.C5_NET)
@@ -798,6 +842,8 @@ def main():
             cb = cpu_baseline(torch)
             out['cpu_baseline'] = cb
             out['gpu_over_cpu'] = round(value / cb['value'], 1)
+            out['cpu_baseline_1_thread'] = cpu_baseline(torch, budget_s=8.0, threads=1)
+            torch.set_num_threads(host_cores())
         if x3 is not None:
             out['bf16x3_mode'] = x3
         out['f32_exact_mode'] = f32x

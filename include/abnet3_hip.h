@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 17
+#define ABN_ABI_VERSION 18
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -164,6 +164,18 @@ typedef struct abn_tower_desc {
      * ABN_PATH_BN_LAYERS) with per-replica statistics: ABN_E_UNSUPPORTED elsewhere.  Towers without BatchNorm and
      * inference forwards ignore it (their rows do not see each other). */
     const int32_t* n_valid;
+    /* BatchNorm1d.num_batches_tracked of every layer (device int64 each, or NULL): a TRAINING forward of a batch_norm tower
+     * adds n_calls to each -- torch's BatchNorm1d counts its training calls, and the reference's forward runs forward_once
+     * twice (abnet3/model.py:194-195) -- inside the forward's own launches where it can (ABN_PATH_BN_TOWER), else in one
+     * small launch behind them.  Nothing else reads them (momentum is the fixed 0.1). */
+    void* bn_nbt[ABN_MAX_LAYERS];
+    /* Optional sync buffer of the resident BatchNorm tower (ABN_PATH_BN_TOWER): abn_tower_sync_ws_bytes() bytes, 16-byte
+     * aligned, owned by the caller, ZERO before its first use and never written by the caller afterwards; one per tower
+     * and stream (the forward and the backward of a step share it; two streams driving one tower need two).  It holds the
+     * launch counter the kernels' hand-over tags derive from and the hand-over granules themselves.  NULL: BatchNorm
+     * training runs one launch per layer (ABN_PATH_BN_LAYERS).  Should a launch ever give up on a hand-over (the grid was
+     * not resident: the outputs then read NaN) the buffer's failure word stays set: zero the buffer again. */
+    void* sync_ws;
 } abn_tower_desc;
 
 /* A ready-made abn_allreduce_fn for abn_tower_desc.bn_sync_fn over RCCL, so that no host language stands between
@@ -186,6 +198,8 @@ int64_t abn_tower_ws_floats(const abn_tower_desc* t, int64_t rows, int64_t n_cal
 int64_t abn_tower_out_offset(const abn_tower_desc* t, int64_t rows, int64_t n_calls);
 /* Scratch of one backward call (split-K slabs + the dZ of every layer), in floats. */
 int64_t abn_tower_bwd_scratch_floats(const abn_tower_desc* t, int64_t rows);
+/* Size of the optional abn_tower_desc.sync_ws buffer, in bytes (host function, no device call). */
+int64_t abn_tower_sync_ws_bytes(void);
 /* Size of the optional abn_tower_desc.wpack buffer, in floats (0: this tower has no such image). */
 int64_t abn_tower_wpack_floats(const abn_tower_desc* t);
 /* 1 when abn_tower_forward(train) / the backward after it with these arguments run on the
@@ -212,7 +226,12 @@ enum {
     ABN_PATH_PLANES_INFER = 3,     /* operand-plane chain, inference (forward_only) */
     ABN_PATH_PLANES_INFER_BN = 4,  /* ... with BatchNorm's running statistics in the epilogue */
     ABN_PATH_BN_LAYERS = 5,        /* BatchNorm training: one operand-plane launch per layer */
-    ABN_PATH_WIDE = 6              /* small batches: one launch per layer over up to 8 workgroups per row block */
+    ABN_PATH_WIDE = 6,             /* small batches: one launch per layer over up to 8 workgroups per row block */
+    ABN_PATH_BN_TOWER = 7          /* BatchNorm training: the whole tower in ONE resident launch per direction, grid barriers
+                                      between the layers (csrc/tower_bn_persist.h): batches of 256 .. 32 x (CUs of the device)
+                                      tower rows with per-replica statistics and a sync buffer (abn_tower_desc.sync_ws);
+                                      ABN_BN_PERSIST=0 keeps ABN_PATH_BN_LAYERS.  The answer therefore also depends on the
+                                      current device's CU count. */
 };
 int abn_tower_path(const abn_tower_desc* t, const float* x1, const float* x2, int64_t rows,
                    int64_t n_calls, int train, const float* ws, int backward,
@@ -242,7 +261,10 @@ void abn_reload_switches(void);
  * train == 0: running statistics.  Output: ws + abn_tower_out_offset().
  * A batch_norm tower in the default arithmetic runs one operand-plane launch per layer in
  * training (its backward likewise), and the single-launch forward with the running statistics folded in
- * when train == 0 and forward_only != 0; otherwise the per-layer kernels.  Results agree to
+ * when train == 0 and forward_only != 0; otherwise the per-layer kernels.  (ABN_PATH_BN_TOWER: where the whole grid is
+ * resident at once -- at most one workgroup of 32 rows per CU -- training runs as ONE launch per direction with grid
+ * hand-overs between the layers; a hand-over that cannot complete gives up after a bounded spin and the launch leaves NaN
+ * in the embeddings / the loss instead of hanging.)  Results agree to
  * rounding; forward and backward of one pass must see the same environment switches. */
 int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                       int64_t rows, int64_t n_calls, int train, float* ws,

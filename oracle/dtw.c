@@ -281,7 +281,27 @@ int64_t abn_oracle_dtw(const double* d, int64_t N, int64_t M, int32_t* path1,
 /* Whole batch: features -> distance -> DTW, pair p uses rows
  * [off1[p], off1[p]+n1[p]) of feats1 and likewise of feats2.  Paths are
  * written at pair-major stride `path_stride`; path_len[p]=0 marks a dropped
- * pair (NaN distance).  Used as the bench's CPU baseline ("port"). */
+ * pair (NaN distance).  Used as the bench's CPU baseline ("port").
+ * abn_oracle_dtw_batch_mt: the same over `threads` OpenMP threads -- the pairs are
+ * independent (abnet3/dataloader.py:183-191 aligns them one by one), every pair is
+ * computed by exactly one thread with the single-thread arithmetic: identical
+ * results whatever the thread count (BASELINE.md section 3's "all cores" figure). */
+static int64_t dtw_one_pair(const float* feats1, const int64_t* off1, const int32_t* n1, const float* feats2,
+                            const int64_t* off2, const int32_t* n2, int64_t p, int64_t D, int32_t* path1,
+                            int32_t* path2, int32_t* path_len, int64_t path_stride)
+{
+    int64_t N = n1[p], M = n2[p];
+    double* d = (double*)malloc(sizeof(double) * (size_t)(N * M > 0 ? N * M : 1));
+    int bad = abn_oracle_cosine_distance_f32(feats1 + off1[p] * D, N,
+                                             feats2 + off2[p] * D, M, D, d);
+    if (bad || N * M == 0) path_len[p] = 0;
+    else
+        path_len[p] = (int32_t)abn_oracle_dtw(
+            d, N, M, path1 + p * path_stride, path2 + p * path_stride, 0);
+    free(d);
+    return N * M;
+}
+
 int64_t abn_oracle_dtw_batch(const float* feats1, const int64_t* off1,
                              const int32_t* n1, const float* feats2,
                              const int64_t* off2, const int32_t* n2,
@@ -290,17 +310,22 @@ int64_t abn_oracle_dtw_batch(const float* feats1, const int64_t* off1,
                              int64_t path_stride)
 {
     int64_t cells = 0;
-    for (int64_t p = 0; p < npairs; ++p) {
-        int64_t N = n1[p], M = n2[p];
-        double* d = (double*)malloc(sizeof(double) * (size_t)(N * M > 0 ? N * M : 1));
-        int bad = abn_oracle_cosine_distance_f32(feats1 + off1[p] * D, N,
-                                                 feats2 + off2[p] * D, M, D, d);
-        if (bad || N * M == 0) path_len[p] = 0;
-        else
-            path_len[p] = (int32_t)abn_oracle_dtw(
-                d, N, M, path1 + p * path_stride, path2 + p * path_stride, 0);
-        cells += N * M;
-        free(d);
-    }
+    for (int64_t p = 0; p < npairs; ++p)
+        cells += dtw_one_pair(feats1, off1, n1, feats2, off2, n2, p, D, path1, path2, path_len, path_stride);
+    return cells;
+}
+
+int64_t abn_oracle_dtw_batch_mt(const float* feats1, const int64_t* off1,
+                                const int32_t* n1, const float* feats2,
+                                const int64_t* off2, const int32_t* n2,
+                                int64_t npairs, int64_t D, int32_t* path1,
+                                int32_t* path2, int32_t* path_len,
+                                int64_t path_stride, int threads)
+{
+    int64_t cells = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads) reduction(+ : cells)
+    for (int64_t p = 0; p < npairs; ++p)
+        cells += dtw_one_pair(feats1, off1, n1, feats2, off2, n2, p, D, path1, path2, path_len, path_stride);
     return cells;
 }

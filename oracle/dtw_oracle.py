@@ -48,6 +48,8 @@ def lib():
         L.abn_oracle_dtw_batch.restype = c.c_int64
         L.abn_oracle_dtw_batch.argtypes = [c.c_void_p] * 6 + [
             c.c_int64, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64]
+        L.abn_oracle_dtw_batch_mt.restype = c.c_int64
+        L.abn_oracle_dtw_batch_mt.argtypes = L.abn_oracle_dtw_batch.argtypes + [c.c_int]
         _lib = L
     return _lib
 
@@ -118,8 +120,9 @@ def get_dtw_alignment(feat1, feat2):
     return p1, p2
 
 
-def dtw_batch(feats1, off1, n1, feats2, off2, n2, path_stride):
-    """Batch front-end used by the CPU baseline. Returns (p1, p2, len, cells)."""
+def dtw_batch(feats1, off1, n1, feats2, off2, n2, path_stride, threads=1):
+    """Batch front-end used by the CPU baseline. Returns (p1, p2, len, cells).
+    threads > 1: OpenMP over the pairs (independent: identical results)."""
     feats1 = np.ascontiguousarray(feats1, dtype=np.float32)
     feats2 = np.ascontiguousarray(feats2, dtype=np.float32)
     off1 = np.ascontiguousarray(off1, dtype=np.int64)
@@ -130,9 +133,14 @@ def dtw_batch(feats1, off1, n1, feats2, off2, n2, path_stride):
     p1 = np.full((P, path_stride), -1, dtype=np.int32)
     p2 = np.full((P, path_stride), -1, dtype=np.int32)
     ln = np.zeros(P, dtype=np.int32)
-    cells = lib().abn_oracle_dtw_batch(_p(feats1), _p(off1), _p(n1), _p(feats2),
-                                       _p(off2), _p(n2), P, feats1.shape[1],
-                                       _p(p1), _p(p2), _p(ln), path_stride)
+    if threads > 1:
+        cells = lib().abn_oracle_dtw_batch_mt(_p(feats1), _p(off1), _p(n1), _p(feats2),
+                                              _p(off2), _p(n2), P, feats1.shape[1],
+                                              _p(p1), _p(p2), _p(ln), path_stride, int(threads))
+    else:
+        cells = lib().abn_oracle_dtw_batch(_p(feats1), _p(off1), _p(n1), _p(feats2),
+                                           _p(off2), _p(n2), P, feats1.shape[1],
+                                           _p(p1), _p(p2), _p(ln), path_stride)
     return p1, p2, ln, cells
 
 

@@ -643,10 +643,10 @@ def test_batch_norm_training_step_against_the_oracle(shape, act, p_drop, split):
         net._mask_override = [dev(m) for m in masks]
     net.train()
     e1, e2 = net(dev(x1), dev(x2))
-    assert _lib.last_forward_path() == 5
+    assert _lib.last_forward_path() in (5, 7)      # (7: the resident tower, from 8 workgroups on)
     lv = L.coscos2(avg=False)(e1, e2, dev(y))
     lv.backward()
-    assert _lib.last_backward_path() == 5
+    assert _lib.last_backward_path() in (5, 7)
     o1, c1 = O.tower_forward(p, x1, spec, True, masks=[m[:B] for m in masks] if masks else None)
     o2, c2 = O.tower_forward(p, x2, spec, True, masks=[m[B:] for m in masks] if masks else None)
     ol, d1, d2, _ = O.pair_loss(o1, o2, y, 'coscos2', 0.5, False)
@@ -684,7 +684,7 @@ def test_batch_norm_input_gradient_and_fallbacks(monkeypatch, split):
         a, b = dev(x1).requires_grad_(True), dev(x2).requires_grad_(True)
         e1, e2 = net(a, b)
         ((e1 * w).sum() + (e2 * e2 * w).sum()).backward()
-        assert _lib.last_backward_path() == (5 if planes == '1' else 0)
+        assert _lib.last_backward_path() in ((5, 7) if planes == '1' else (0,))
         res.append([a.grad.cpu().numpy(), b.grad.cpu().numpy()] + [q.grad.cpu().numpy() for q in net.parameters()])
     gmax = max(np.abs(v).max() for v in res[1])
     for u, v in zip(*res):
@@ -698,9 +698,9 @@ def test_batch_norm_input_gradient_and_fallbacks(monkeypatch, split):
         net, _, _ = build(kw, seed=9, precision=split)
         net.train()
         e = net.forward_once(dev(x1[:37]))
-        assert _lib.last_forward_path() == (5 if planes == '1' else 0)
+        assert _lib.last_forward_path() in ((5, 7) if planes == '1' else (0,))
         (e * e).sum().backward()
-        assert _lib.last_backward_path() == (5 if planes == '1' else 0)
+        assert _lib.last_backward_path() in ((5, 7) if planes == '1' else (0,))
         outs.append([e.detach().cpu().numpy()] + [q.grad.cpu().numpy() for q in net.parameters()]
                     + [v.cpu().numpy() for k, v in net.state_dict().items() if 'running' in k])
     gmax = max(np.abs(v).max() for v in outs[1][1:])
@@ -727,7 +727,7 @@ def test_batch_norm_training_in_the_bf16_arithmetic(monkeypatch):
         net, _, _ = build(kw, seed=2, precision='bf16')
         net.train()
         e1, e2 = net(x1, x2)
-        assert _lib.last_forward_path() == (5 if planes == '1' else 0)
+        assert _lib.last_forward_path() in ((5, 7) if planes == '1' else (0,))
         lv = L.coscos2(avg=False)(e1, e2, y)
         lv.backward()
         res.append((e1.detach().cpu().numpy(), float(lv.detach()), {k: q.grad.cpu().numpy() for k, q in net.named_parameters()},
@@ -765,11 +765,11 @@ def test_batch_norm_with_dropout_drawn_inside_the_kernels(split):
     probe = seg.descriptor(with_grads=False)
     assert lib.abn_tower_uses_planes(ctypes.byref(probe), 2 * B, _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(x1), 1) == 1
     emb, state = net.direct_forward(x1, x2)
-    assert _lib.last_forward_path() == 5
+    assert _lib.last_forward_path() in (5, 7)      # (7: the resident tower, from 8 workgroups on)
     sv = state[1]
     assert type(sv.masks).__name__ == '_DropSeed'
     net.direct_backward(state, d_out)
-    assert _lib.last_backward_path() == 5
+    assert _lib.last_backward_path() in (5, 7)
     emb = emb.clone()
     grads = {k: q.grad.clone() for k, q in net.named_parameters()}
     fn = lib.abn_tower_image_offset
@@ -827,7 +827,7 @@ def test_batch_norm_dropout_train_mode_without_gradients(tmp_path, split):
     v = tr.train_step(batch, False)                            # train mode, no gradients
     assert _lib.last_forward_path() == 0 and np.isfinite(float(v))
     v = tr.train_step(batch, True)                             # the same tower in a real step: the BatchNorm launches
-    assert _lib.last_forward_path() == 5 and np.isfinite(float(v))
+    assert _lib.last_forward_path() in (5, 7) and np.isfinite(float(v))
     tr.train()                                                 # the reference's whole loop, first pass included
     assert len(tr.train_losses) == 3 and all(np.isfinite(tr.train_losses))
 

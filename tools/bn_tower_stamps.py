@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Diagnostic (ABN_STAMPS build: tools/build_stamps.sh): phase timeline of the resident BatchNorm forward
+(csrc/tower_bn_persist.h), workgroup medians of s_memtime ticks (10 ns each)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+buf = torch.zeros(1024 * 128, dtype=torch.int64, device='cuda')
+os.environ['ABN_STAMP_BUF'] = str(buf.data_ptr())
+import bench
+from abnet3_amd.model import SiameseNetwork
+torch.manual_seed(0)
+net = SiameseNetwork(output_path='/tmp/abn_st', **dict(bench.C2, batch_norm=True)).cuda()
+x1, x2 = torch.randn(4096, 40, device='cuda'), torch.randn(4096, 40, device='cuda')
+net.train()
+for _ in range(10):
+    net.direct_forward(x1, x2)
+torch.cuda.synchronize()
+nl = 4
+n = 2 + 8 * nl - 1          # (the last layer returns before its slot 8)
+s = buf.cpu().numpy().reshape(1024, 128)[:256, :n].astype(np.float64)
+s -= s[:, 0].min()
+names = ['input staging']
+for l in range(nl):
+    names += ['L%d k-loop' % l, 'L%d z, sums, stores' % l, 'L%d grid barrier 1' % l, 'L%d finish' % l, 'L%d grid barrier 2' % l,
+              'L%d stats load + normalise + act' % l, 'L%d scales, image, transposed image' % l, 'L%d (gap to next)' % l]
+d = np.diff(s, axis=1)
+for i in range(n - 1):
+    print('%-40s median %8.0f   min %8.0f   max %8.0f' % (names[i], np.median(d[:, i]), d[:, i].min(), d[:, i].max()))
+print('wg start spread: median %.0f max %.0f; wg total median %.0f; last end %.0f (ticks of 10 ns)' % (np.median(s[:, 0]), s[:, 0].max(), np.median(s[:, n - 1] - s[:, 0]), s[:, n - 1].max()))
