@@ -515,20 +515,25 @@ __global__ __launch_bounds__(64 * BN_WG_GROUPS) void bn_stats_finish_wg_kernel(
         rm[c] = m_run;
         rv[c] = v_run;
     }
+    // (cross-replica statistics: this replica's rows per call travel with the sums -- the replicas' batches differ in size)
+    if (sums_out && blockIdx.x == 0 && (int)threadIdx.x < n_calls) sums_out[(int64_t)n_calls * 2 * C + threadIdx.x] = (double)rows_per_call;
 }
 
 // ... from the (all-reduced) sums over n_stat rows per call: mean, biased variance, invstd, the running statistics
 // (one momentum update per call, in call order, unbiased variance), as above
-__global__ void bn_stats_from_sums_kernel(const double* __restrict__ sums, int64_t n_stat, int C, int n_calls, float* __restrict__ mean,
+// (n: the all-reduced row count of the call, behind the sums -- the replicas' batches may differ in size; nstat_out: the same
+// as floats, for the backward's 1 / n)
+__global__ void bn_stats_from_sums_kernel(const double* __restrict__ sums, int C, int n_calls, float* __restrict__ mean,
                                           float* __restrict__ invstd, float* __restrict__ var_out, float* __restrict__ rm,
-                                          float* __restrict__ rv)
+                                          float* __restrict__ rv, float* __restrict__ nstat_out)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float m_run = rm[c], v_run = rv[c];
-    const float unb = n_stat > 1 ? (float)((double)n_stat / (double)(n_stat - 1)) : 1.0f;
     for (int g = 0; g < n_calls; ++g) {
-        const double n = (double)n_stat;
+        const double n = sums[(int64_t)n_calls * 2 * C + g];
+        const float unb = n > 1.0 ? (float)(n / (n - 1.0)) : 1.0f;
+        if (c == 0) nstat_out[g] = (float)n;
         const double m = sums[((int64_t)g * 2) * C + c] / n;
         double var = sums[((int64_t)g * 2 + 1) * C + c] / n - m * m;
         if (var < 0.0) var = 0.0;
@@ -863,6 +868,7 @@ struct Layout {
     int64_t wpack, tp[ABN_MAX_LAYERS];   // wpack: the PackLayout image (unless the caller keeps a persistent one)
     int64_t amax[ABN_MAX_LAYERS];        // fp16 x 2: tp[l]'s maxima per 32-row block (the weight-gradient launch's scales)
     int64_t bn_wg;                       // per-workgroup column statistics of bn_fwd_layer_kernel ([rows / 32][3][PL_MAXW])
+    int64_t bn_nstat;                    // cross-replica statistics: the rows a call's statistics span, per layer and call ([layer][8] floats)
     int64_t total;
 };
 
@@ -970,12 +976,14 @@ static Layout make_layout(const abn_tower_desc* t, int64_t rows, int64_t n_calls
     if (t->batch_norm) {
         int64_t maxw = 0;
         for (int l = 1; l <= t->n_layers; ++l) maxw = t->dims[l] > maxw ? t->dims[l] : maxw;
-        L.bn_part = take(2 * n_calls * bn_chunks(rows / n_calls) * 2 * maxw);      // doubles = 2 floats each
+        L.bn_part = take(2 * n_calls * bn_chunks(rows / n_calls) * 2 * maxw + 2 * n_calls);      // doubles = 2 floats each (+ the calls' row counts)
     }
     for (int l = 0; l < t->n_layers; ++l) L.tp[l] = L.amax[l] = -1;
     L.wpack = -1;
     L.bn_wg = -1;
+    L.bn_nstat = -1;
     if (planes_dims_ok(t) && t->batch_norm && !t->forward_only) {
+        L.bn_nstat = take(ABN_MAX_LAYERS * 8);
         L.bn_wg = take((n_calls * bn_wgs_per_call(rows, n_calls) + 1) * 3 * PL_MAXW);
 
     }
@@ -1441,7 +1449,8 @@ static int bn_planes_backward(const abn_tower_desc* t, const float* d_out, const
     for (int l = nl - 1; l >= 0; --l) {
         BnBwdP q = {};
         q.l = l; q.rows = (int)rows; q.rows_call = (int)rpc;
-        q.n_stat = (float)(rpc * (sync ? t->bn_sync_world : 1));
+        q.n_stat = (float)rpc;
+        q.n_stat_dev = sync ? ws + L.bn_nstat + 8 * l : nullptr;       // (cross-replica statistics: the forward's all-reduced row counts)
         q.N = (int)t->dims[l + 1]; q.K = (int)t->dims[l];
         q.act_l = (l == nl - 1) ? t->last_act : t->act;
         q.act_prev = t->act;
@@ -1938,10 +1947,10 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                                    (int)wpc, rpc, N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l],
                                    t->bn_rm[l], t->bn_rv[l], sync ? sums : static_cast<double*>(nullptr), t->n_valid);
                 if (sync) {
-                    if (t->bn_sync_fn(t->bn_sync_ctx, sums, n_calls * 2 * N, st) != 0) { set_error("tower_forward: bn_sync_fn failed"); return ABN_E_LAUNCH; }
+                    if (t->bn_sync_fn(t->bn_sync_ctx, sums, n_calls * 2 * N + n_calls, st) != 0) { set_error("tower_forward: bn_sync_fn failed"); return ABN_E_LAUNCH; }
                     hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, sums,
-                                       rpc * t->bn_sync_world, N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l],
-                                       t->bn_rm[l], t->bn_rv[l]);
+                                       N, (int)n_calls, ws + L.mean[l], ws + L.invstd[l], ws + L.var[l],
+                                       t->bn_rm[l], t->bn_rv[l], ws + L.bn_nstat + 8 * l);
                 }
             }
             const int N = (int)t->dims[nl];

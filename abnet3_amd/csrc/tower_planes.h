@@ -1796,7 +1796,8 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
 // ---------------------------------------------------------------------------------------------
 struct BnBwdP {
     int l, rows, rows_call;
-    float n_stat;                  // rows the statistics of a call span: rows_call (x the replicas whose sums were all-reduced)
+    float n_stat;                  // rows the statistics of a call span: rows_call
+    const float* n_stat_dev;       // ... or (cross-replica statistics) [n_calls] on the device: the replicas' rows, all-reduced by the forward
     int N, K;                      // dims[l + 1], dims[l]
     int act_l, act_prev;           // activations behind BatchNorm l and l - 1
     const float* da;               // [rows][N] d loss / d a_l
@@ -1917,7 +1918,7 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_layer_kernel(BnBwdP q)
     make_identity<NP>(idf, lane);
 
     // the per-feature vectors of this workgroup's call, parked in the (still idle) K-split buffer
-    const float nf = q.n_valid ? (float)(nv > 0 ? nv : 1) : q.n_stat;
+    const float nf = q.n_valid ? (float)(nv > 0 ? nv : 1) : (q.n_stat_dev ? q.n_stat_dev[call] : q.n_stat);
     float* const k_s = part, * const ga_s = part + PL_MAXW, * const be_s = part + 2 * PL_MAXW, * const s1_s = part + 3 * PL_MAXW,
                * const s2_s = part + 4 * PL_MAXW, * const mu_s = part + 5 * PL_MAXW, * const is_s = part + 6 * PL_MAXW;
     for (int c = threadIdx.x; c < N; c += PL_NT) {

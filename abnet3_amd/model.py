@@ -318,9 +318,20 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False, n_vali
         # first pass, abnet3/trainer.py:137) asks for them too: the replicas' running statistics must move together.
         # Where the library would not take that path (fewer than 256 rows: OriginalDataLoader's short ragged batches;
         # odd widths) the call falls back to per-replica statistics, said once -- not an error.
+        # The choice is the GROUP's: the ranks hold batches of different sizes (OriginalDataLoader's ragged word-pair batches),
+        # and a rank that left the exchange on its own would leave the others waiting in it -- or add its sums to another
+        # layer's.  One small all-reduce (MIN) per training forward settles it; a step being captured into a graph replays the
+        # answer of the eager step before it (its shapes are the captured ones on every rank).
         desc = _lib.TowerDesc.from_buffer_copy(desc)
         desc.forward_only = 0
-        if lib.abn_tower_path(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2), rows, n_calls, 1, _lib.ptr(x1), 0, None) in (_lib.PATH_BN_LAYERS, _lib.PATH_BN_TOWER):
+        mine = lib.abn_tower_path(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2), rows, n_calls, 1, _lib.ptr(x1), 0, None) in (_lib.PATH_BN_LAYERS, _lib.PATH_BN_TOWER)
+        if torch.cuda.is_current_stream_capturing():
+            agreed = bool(getattr(net, '_bn_sync_agreed', False)) and mine
+        else:
+            from . import parallel
+            agreed = parallel.all_agree(mine, getattr(net.bn_sync, 'group', None)) if getattr(net.bn_sync, 'collective', False) else mine
+            net._bn_sync_agreed = agreed
+        if agreed:
             synced = True
         else:
             desc.forward_only = int(forward_only)
@@ -328,8 +339,9 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False, n_vali
             if not getattr(net, '_warned_bn_sync_fallback', False):
                 net._warned_bn_sync_fallback = True
                 import warnings
-                warnings.warn('abnet3_amd: sync_batch_norm: a batch of %d rows does not run on the per-layer BatchNorm '
-                              'launches that carry the cross-replica statistics; such batches use per-replica statistics' % rows)
+                warnings.warn('abnet3_amd: sync_batch_norm: a batch of %d rows (here; the ranks decide together) does not run on the '
+                              'per-layer BatchNorm launches that carry the cross-replica statistics on every rank; such steps use '
+                              'per-replica statistics' % rows)
     ws_floats = lib.abn_tower_ws_floats(_lib.C.byref(desc), rows, n_calls)
     if ws_floats < 0:
         _lib.check(-1, 'abn_tower_ws_floats')
@@ -674,7 +686,7 @@ class _HipNetwork(NetworkBuilder):
     # network and not picklable
     _HIP_STATE = ('_flat', '_last_grad_flat', '_offsets', '_segs', '_mask_override',
                   '_generation', '_live_cache', '_weights_epoch', '_pending_reduce', '_fused_loss_refused',
-                  '_pending_lower', 'bn_sync')
+                  '_pending_lower', 'bn_sync', '_bn_sync_agreed')
 
     def whoami(self):
         """Output description for the neural network and all parameters

@@ -125,24 +125,31 @@ def broadcast_parameters(flat_params, src=0):
         dist.broadcast(flat_params, src=src)
 
 
-def broadcast_array(arr, src=0):
-    """int64 numpy array, same length on every rank -> rank `src`'s values."""
+def broadcast_array(arr, src=0, group=None):
+    """int64 numpy array, same length on every rank -> rank `src`'s values (src: a rank of `group`)."""
     arr = np.ascontiguousarray(arr, dtype=np.int64)
     if not active() or arr.size == 0:
         return arr
     t = torch.from_numpy(arr.copy()).to(_comm_device())
-    dist.broadcast(t, src=src)
+    dist.broadcast(t, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
     return t.cpu().numpy()
 
 
-def all_reduce_min(arr):
+def all_reduce_min(arr, group=None):
     """int64 numpy array, same length on every rank -> elementwise minimum over the ranks."""
     arr = np.ascontiguousarray(arr, dtype=np.int64)
     if not active() or arr.size == 0:
         return arr
     t = torch.from_numpy(arr.copy()).to(_comm_device())
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return t.cpu().numpy()
+
+
+def all_agree(flag, group=None):
+    """True iff `flag` is true on EVERY rank: how the ranks settle a choice each of them can only judge for itself (a batch
+    small enough to leave the kernels that carry the cross-replica BatchNorm sums; a library that loads) before any of them
+    enters -- or skips -- a collective.  A collective itself: every rank calls it at the same point."""
+    return bool(all_reduce_min(np.array([1 if flag else 0]), group=group)[0])
 
 
 def all_gather_varlen(t):
@@ -220,15 +227,29 @@ class RcclBatchNormSync:
         self.world = dist.get_world_size(group)
         self.collective = True
         self.buffers = []              # (kept for the interface of BatchNormSync: nothing to validate here)
-        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
-        self._rccl = C.CDLL(path)      # (the copy torch has mapped already)
+        self._comm = None
+        # RCCL as this process has it: the symbols of the image torch mapped (whatever file it came from: a torch built
+        # against a system RCCL has no torch/lib/librccl.so), else that file; ABN_RCCL_LIB names another (the tests: a
+        # path that does not exist).  Every step below that one rank can fail alone is followed by an agreement: a rank
+        # that raised while the others went on into ncclCommInitRank would leave them waiting for it.
+        self._rccl, err = None, None
+        try:
+            self._rccl = self._load_rccl(C)
+        except (OSError, AttributeError) as e:
+            err = e
+        if not all_agree(self._rccl is not None, group):
+            raise RuntimeError('RCCL could not be loaded on every rank (%s)' % (err,))
         uid = (C.c_char * self._UID_BYTES)()
         rank = dist.get_rank(group)
-        if rank == 0 and self._rccl.ncclGetUniqueId(C.byref(uid)) != 0:
-            raise RuntimeError('ncclGetUniqueId failed')
-        words = broadcast_array(np.frombuffer(bytes(uid), dtype=np.int64).copy(), src=0) if self.world > 1 else \
-            np.frombuffer(bytes(uid), dtype=np.int64).copy()
-        C.memmove(uid, words.tobytes(), self._UID_BYTES)
+        status = 0
+        if rank == 0:
+            status = int(self._rccl.ncclGetUniqueId(C.byref(uid)))
+        words = np.concatenate([[status], np.frombuffer(bytes(uid), dtype=np.int64)]).astype(np.int64)
+        if self.world > 1:
+            words = broadcast_array(words, src=0, group=group)
+        if int(words[0]) != 0:
+            raise RuntimeError('ncclGetUniqueId failed on rank 0 (%d)' % int(words[0]))
+        C.memmove(uid, words[1:].tobytes(), self._UID_BYTES)
         comm = C.c_void_p()
 
         class _Uid(C.Structure):
@@ -238,12 +259,36 @@ class RcclBatchNormSync:
         self._rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _Uid, C.c_int]
         torch.cuda.synchronize()
         rc = self._rccl.ncclCommInitRank(C.byref(comm), self.world, u, rank)
-        if rc != 0 or not comm.value:
-            raise RuntimeError('ncclCommInitRank failed (%d)' % rc)
-        self._comm = comm
+        good = rc == 0 and bool(comm.value)
+        if good:
+            self._comm = comm
+        if not all_agree(good, group):
+            self._destroy()
+            raise RuntimeError('ncclCommInitRank failed on some rank (here: %d)' % rc)
         self._ctx = _lib.RcclCtx(comm.value, C.cast(self._rccl.ncclAllReduce, C.c_void_p).value, 0)
         self.ctx = C.addressof(self._ctx)
         self.fn = C.cast(_lib.load().abn_rccl_allreduce_f64, C.c_void_p).value
+
+    @staticmethod
+    def _load_rccl(C):
+        forced = os.environ.get('ABN_RCCL_LIB')
+        candidates = [forced] if forced else [None, os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'), 'librccl.so']
+        last = None
+        for path in candidates:
+            try:
+                lib = C.CDLL(path)         # (None: the symbols already mapped into this process)
+                for name in ('ncclGetUniqueId', 'ncclCommInitRank', 'ncclAllReduce', 'ncclCommDestroy'):
+                    getattr(lib, name)
+                return lib
+            except (OSError, AttributeError) as e:
+                last = e
+        raise OSError('no RCCL with ncclAllReduce / ncclCommInitRank found (%s)' % (last,))
+
+    def _destroy(self):
+        if getattr(self, '_comm', None) is not None and self._comm.value:
+            self._rccl.ncclCommDestroy.argtypes = [type(self._comm)]
+            self._rccl.ncclCommDestroy(self._comm)
+        self._comm = None
 
     @property
     def calls(self):
@@ -254,10 +299,7 @@ class RcclBatchNormSync:
             import sys
             if sys.is_finalizing():        # (at interpreter exit the process group / RCCL may be gone already: the OS reclaims the communicator)
                 return
-            if getattr(self, '_comm', None) is not None and self._comm.value:
-                self._rccl.ncclCommDestroy.argtypes = [type(self._comm)]
-                self._rccl.ncclCommDestroy(self._comm)
-                self._comm = None
+            self._destroy()
         except Exception:
             pass
 
@@ -267,5 +309,10 @@ def bn_sync(group=None):
     (ABN_BN_SYNC_PY=1: the Python callback there too), the Python callback over torch.distributed otherwise."""
     if (dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'nccl'
             and os.environ.get('ABN_BN_SYNC_PY') != '1'):
-        return RcclBatchNormSync(group)
+        try:
+            return RcclBatchNormSync(group)
+        except (RuntimeError, OSError) as e:     # (raised on EVERY rank together: RcclBatchNormSync agrees before it raises)
+            import warnings
+            warnings.warn('abnet3_amd: the cross-replica BatchNorm exchange falls back to the Python callback '
+                          '(parallel.BatchNormSync): %s' % (e,))
     return BatchNormSync(group)

@@ -117,6 +117,15 @@ class FlatOptimizer(object):
                 'step': self.step_count, 's1': self._s1, 's2': self._s2}
 
 
+def _capture_mode():
+    """hipGraph capture mode: with a process group alive its watchdog thread polls the events of finished collectives
+    (hipEventQuery) whenever it likes -- under the default 'global' mode such a call from ANOTHER thread invalidates a capture
+    in progress (the one-rank RCCL run died in ProcessGroupNCCL's watchdog); 'thread_local' confines the check to the
+    capturing thread's own calls."""
+    import torch.distributed as dist
+    return 'thread_local' if dist.is_available() and dist.is_initialized() else 'global'
+
+
 class TrainerBuilder:
     """Generic Trainer class for ABnet3 (abnet3/trainer.py:32-201)."""
 
@@ -416,9 +425,13 @@ class TrainerSiamese(TrainerBuilder):
         torch.distributed the gradient all-reduce and the optimizer stay
         outside the graph (fwd + bwd are captured).  Adam's bias correction is
         host-computed per step, so its optimizer launch also stays outside."""
-        if getattr(self.network, 'bn_sync', None) is not None:
-            raise NotImplementedError('abnet3_amd: a step with cross-replica BatchNorm statistics calls back to the host '
-                                      'between launches (parallel.BatchNormSync) and cannot be captured into a graph')
+        bs = getattr(self.network, 'bn_sync', None)
+        if bs is not None and type(bs).__name__ != 'RcclBatchNormSync':
+            # (on RCCL the exchange is a stream-ordered ncclAllReduce issued by the library itself -- parallel.RcclBatchNormSync --
+            # and is captured like any launch; the Python callback runs torch.distributed between two launches)
+            raise NotImplementedError('abnet3_amd: a step with cross-replica BatchNorm statistics through the Python callback '
+                                      '(parallel.BatchNormSync) calls back to the host between launches and cannot be captured '
+                                      'into a graph')
         static, fwd_loss = self._graph_inputs(example_batch)
         opt = self.optimizer
         capture_opt = (not self.dp and isinstance(opt, FlatOptimizer)
@@ -440,7 +453,7 @@ class TrainerSiamese(TrainerBuilder):
         gc_was_enabled = gc.isenabled()
         gc.disable()
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=_capture_mode()):
                 loss_value = fwd_loss()
                 opt.zero_grad()
                 self._backward(loss_value)
@@ -645,7 +658,7 @@ class TrainerSiamese(TrainerBuilder):
         gc.disable()                          # (see make_graphed_step)
         try:
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph, pool=self._bucket_pool):
+            with torch.cuda.graph(graph, pool=self._bucket_pool, capture_error_mode=_capture_mode()):
                 self._bucket_body(b)
                 pending = getattr(self.network, '_pending_reduce', None)
                 if in_graph_opt:
@@ -696,7 +709,7 @@ class TrainerSiamese(TrainerBuilder):
             gc.disable()
             try:
                 torch.cuda.synchronize()
-                with torch.cuda.graph(graph, pool=self._bucket_pool):
+                with torch.cuda.graph(graph, pool=self._bucket_pool, capture_error_mode=_capture_mode()):
                     body()
             finally:
                 if gc_was_enabled:

@@ -148,8 +148,10 @@ typedef struct abn_tower_desc {
      * (a group of ONE replica is a group: its reduction is the identity, the launches are the group's)
      * makes a TRAINING forward / backward of a BatchNorm tower sum its per-call statistics -- [sum z, sum z^2] per
      * layer in the forward, [sum dy, sum dy xhat] in the backward, float64 -- over the replicas through bn_sync_fn
-     * (called on the host between two launches, once per layer and direction) and normalise with
-     * bn_sync_world x rows_per_call rows: R replicas on B rows each then step like one process on R B rows.
+     * (called on the host between two launches, once per layer and direction) and normalise with the replicas' row
+     * count, which travels with the forward's sums (n_calls more values: the replicas' batches may differ in size):
+     * R replicas on B_r rows each then step like one process on sum B_r rows.  EVERY replica of the group must make the
+     * same calls (the exchange is a collective: the caller agrees beforehand which steps take this path).
      * bn_sync_fn NULL or bn_sync_world 0: per-replica statistics.  Operand-plane launches only (ABN_E_UNSUPPORTED otherwise). */
     int32_t bn_sync_world;
     int32_t wgrad_split;                   /* see wgrad_part */

@@ -148,6 +148,35 @@ def main():
         res[tag + '.calls'] = np.array(net.bn_sync.calls if sync else 0)
         for k, v in net.state_dict().items():
             res[tag + '.p.' + k] = v.detach().cpu().numpy()
+    # --- (5) ... with batches of DIFFERENT sizes on the ranks (OriginalDataLoader's ragged word-pair batches): 384 + 640 pairs.
+    # The statistics divide by the all-reduced row count (it travels with the sums): one process on the 1024.
+    cut = [0, 384, 1024]
+    slu = slice(cut[rank], cut[rank + 1])
+    net = SiameseNetwork(output_path='/tmp/abn_dp_bnu_%d' % rank, **kwb)
+    net.load_state_dict({k[2:]: torch.from_numpy(v.copy()) for k, v in gb.items() if k.startswith('p.')})
+    tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1,
+                        dataloader=None, log_dir='/tmp/abn_runs_dp', sync_batch_norm=True)
+    net.train()
+    batch = (torch.from_numpy(xb1[slu]).cuda(), torch.from_numpy(xb2[slu]).cuda(), torch.from_numpy(yb[slu]).cuda())
+    res['bn.uneven.losses'] = np.array([float(tr.train_step(batch, True)) for _ in range(3)])
+    for k, v in net.state_dict().items():
+        res['bn.uneven.p.' + k] = v.detach().cpu().numpy()
+    # --- (6) ... and with one rank's batch too small for the launches that carry the sums (100 pairs = 200 rows on rank 0,
+    # 512 pairs on rank 1): the ranks agree (one MIN all-reduce per forward) and BOTH use per-replica statistics -- no rank
+    # waits in an exchange the other never enters
+    import warnings
+    nsm = 100 if rank == 0 else 512
+    net = SiameseNetwork(output_path='/tmp/abn_dp_bns_%d' % rank, **kwb)
+    net.load_state_dict({k[2:]: torch.from_numpy(v.copy()) for k, v in gb.items() if k.startswith('p.')})
+    tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1,
+                        dataloader=None, log_dir='/tmp/abn_runs_dp', sync_batch_norm=True)
+    net.train()
+    batch = (torch.from_numpy(xb1[:nsm]).cuda(), torch.from_numpy(xb2[:nsm]).cuda(), torch.from_numpy(yb[:nsm]).cuda())
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        res['bn.small.losses'] = np.array([float(tr.train_step(batch, True)) for _ in range(2)])
+    res['bn.small.calls'] = np.array(net.bn_sync.calls)
+    res['bn.small.warned'] = np.array(sum('per-replica statistics' in str(w.message) for w in caught))
     np.savez(out + '.rank%d.npz' % rank, **res)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

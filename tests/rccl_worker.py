@@ -142,11 +142,59 @@ def main():
         for k, v in net.state_dict().items():
             res[tag + '.bntrain.p.' + k] = v.detach().cpu().numpy()
 
+    def graphed_bn():
+        """(5) a step with cross-replica BatchNorm statistics captured into a hipGraph (on RCCL the per-layer exchange is a
+        stream-ordered ncclAllReduce issued by the library: it is captured with the launches): three replays behind the
+        capture's three warm-up steps against six eager steps of the same start."""
+        rngb = np.random.default_rng(654)
+        Bb = 512
+        xb1 = rngb.standard_normal((Bb, 40)).astype(np.float32)
+        xb2 = (xb1 + 0.5 * rngb.standard_normal((Bb, 40))).astype(np.float32)
+        yb = rngb.choice([1.0, -1.0], Bb)
+        batch = (torch.from_numpy(xb1).cuda(), torch.from_numpy(xb2).cuda(), torch.from_numpy(yb).cuda())
+        out_ = {}
+        for mode in ('eager', 'graph'):
+            net = SiameseNetwork(output_path='/tmp/abn_rccl_bng_' + mode, **kwb)
+            net.load_state_dict({k[2:]: torch.from_numpy(v.copy()) for k, v in gb.items() if k.startswith('p.')})
+            tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1,
+                                dataloader=None, log_dir='/tmp/abn_runs_rccl', sync_batch_norm=True)
+            assert type(net.bn_sync).__name__ == 'RcclBatchNormSync'
+            net.train()
+            if mode == 'eager':
+                losses = [float(tr.train_step(batch, True)) for _ in range(6)][3:]
+            else:
+                step = tr.make_graphed_step(batch, warmup=3)
+                losses = [float(step(batch)) for _ in range(3)]
+            out_[mode] = (np.array(losses), {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()})
+        res['graphbn.eager_losses'], res['graphbn.replay_losses'] = out_['eager'][0], out_['graph'][0]
+        worst = 0.0
+        for k, v in out_['eager'][1].items():
+            if k.endswith('num_batches_tracked'):
+                assert int(v) == int(out_['graph'][1][k]), k
+                continue
+            worst = max(worst, float(np.abs(out_['graph'][1][k] - v).max() / max(np.abs(v).max(), 0.05)))
+        res['graphbn.worst_param_diff'] = np.array(worst)
+
+    def forced_fallback():
+        """(6) RCCL that cannot be loaded (ABN_RCCL_LIB names a file that is not there): every rank agrees and the exchange
+        falls back to the Python callback -- a warning, not an exception out of the trainer's constructor."""
+        os.environ['ABN_RCCL_LIB'] = '/nonexistent/librccl.so'
+        try:
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter('always')
+                bs = parallel.bn_sync()
+            res['fallback.type'] = np.array(type(bs).__name__)
+            res['fallback.warned'] = np.array(sum('falls back to the Python callback' in str(w.message) for w in caught))
+        finally:
+            del os.environ['ABN_RCCL_LIB']
+
     run('plain')
     assert not parallel.active()
     parallel.init_from_env('nccl')
     assert parallel.active() and torch.distributed.get_backend() == 'nccl' and torch.distributed.get_world_size() == 1
     run('rccl')
+    graphed_bn()
+    forced_fallback()
     res['backend'] = np.array(torch.distributed.get_backend())
     np.savez(out + '.rccl.npz', **res)
     torch.distributed.barrier()

@@ -137,6 +137,22 @@ def test_batch_norm_with_cross_replica_statistics_equals_one_process(ranks):
         assert (ranks[0]['bn.sync1.p.' + k] == ranks[1]['bn.sync1.p.' + k]).all(), k     # replicas stay bit-identical
         worst_off = max(worst_off, rel_err(ranks[0]['bn.sync0.p.' + k], mine, floor=0.05))
     assert worst_off > 1e-4            # per-replica statistics are a different computation
+    # batches of different sizes on the ranks (384 + 640 pairs): still one process on the 1024 -- the row count the statistics
+    # divide by is all-reduced with the sums (every rank used to divide by ITS rows x the world size)
+    total = ranks[0]['bn.uneven.losses'] + ranks[1]['bn.uneven.losses']
+    assert np.allclose(total, losses, rtol=1e-5), (total, losses)
+    for k, v in net.state_dict().items():
+        if k.endswith('num_batches_tracked'):
+            continue
+        mine = v.detach().cpu().numpy()
+        for r in ranks:
+            e = rel_err(r['bn.uneven.p.' + k], mine, floor=0.05)
+            assert e < 2e-5, (k, e)
+        assert (ranks[0]['bn.uneven.p.' + k] == ranks[1]['bn.uneven.p.' + k]).all(), k
+    # one rank's batch below the launches that carry the sums: the ranks agree, nobody enters the exchange, both finish
+    for r in ranks:
+        assert int(r['bn.small.calls']) == 0 and np.isfinite(r['bn.small.losses']).all()
+        assert int(r['bn.small.warned']) == 1
 
 
 def _corpus():
@@ -265,3 +281,9 @@ def test_one_rank_on_rccl():
     assert r['rccl.planned.train_losses'][-1] < r['rccl.planned.train_losses'][0]
     assert int(r['rccl.bntrain.warned']) == 1 and int(r['rccl.bntrain.params_file']) == 1
     assert np.isfinite(r['rccl.bntrain.train_losses']).all()
+    # a step with cross-replica BatchNorm statistics captured into a hipGraph (the exchange is the library's own stream-ordered
+    # ncclAllReduce): its replays against eager steps of the same start
+    assert np.allclose(r['graphbn.replay_losses'], r['graphbn.eager_losses'], rtol=2e-6), (r['graphbn.replay_losses'], r['graphbn.eager_losses'])
+    assert float(r['graphbn.worst_param_diff']) < 2e-6
+    # RCCL that cannot be loaded: the Python callback, and a warning
+    assert str(r['fallback.type']) == 'BatchNormSync' and int(r['fallback.warned']) == 1
