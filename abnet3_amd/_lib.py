@@ -62,6 +62,8 @@ SYMBOLS = {
     'abn_optimizer_step': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _f32,
                                       _f32, _f32, _f32, _i64, _f32, _vp]),
     'abn_tower_sync_ws_bytes': (_i64, []),
+    'abn_oneshot_mail_bytes': (_i64, [_i32, _i64]),
+    'abn_allreduce_oneshot': (C.c_int, [_vp, _vp, _i64, _vp]),
     'abn_dtw_ws_bytes': (_i64, [_vp, _vp, _i64, _i64, _i64]),
     'abn_dtw_host_stage_bytes': (_i64, [_vp, _vp, _i64]),
     'abn_dtw_batched': (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
@@ -94,6 +96,11 @@ class TowerDesc(C.Structure):
                      'dbn_w', 'dbn_b', 'drop_mask')] + [('precision', _i32), ('d_out_is_dz', _i32), ('defer_reduce', _i32), ('wpack_valid', _i32), ('forward_only', _i32), ('wgrad_part', _i32), ('wpack', _vp), ('drop_seed', _vp), ('drop_p', _f32), ('reserved2_', _i32),
                      ('bn_sync_world', _i32), ('wgrad_split', _i32), ('bn_sync_fn', _vp), ('bn_sync_ctx', _vp), ('n_valid', _vp),
                      ('bn_nbt', _vp * MAX_LAYERS), ('sync_ws', _vp)]
+
+
+class OneShotCtx(C.Structure):
+    """struct abn_oneshot_ctx (abn_allreduce_oneshot's context)"""
+    _fields_ = [('rank', _i32), ('world', _i32), ('mail', _vp * 8), ('cap_floats', _i64)]
 
 
 class RcclCtx(C.Structure):

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'lib', 'obj')
 LIB = os.path.join(HERE, 'lib', 'libabnet3_hip.so')
-SOURCES = ['tower.hip', 'loss.hip', 'ops.hip', 'dtw.hip', 'fbank.hip']
+SOURCES = ['tower.hip', 'loss.hip', 'ops.hip', 'dtw.hip', 'fbank.hip', 'oneshot.hip']
 HEADERS = sorted(h for h in os.listdir(CSRC) if h.endswith('.h')) + [os.path.join('..', '..', 'include', 'abnet3_hip.h')]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall',
          '-Wno-unused-function']
@@ -59,7 +59,7 @@ def build(force=False, verbose=False):
             return obj, True
         return obj, False
 
-    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         results = list(ex.map(compile_one, srcs))
     objs = [o for o, _ in results]
     if force or any(c for _, c in results) or _stale(LIB, objs):

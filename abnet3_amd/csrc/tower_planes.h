@@ -1204,6 +1204,10 @@ __global__ __launch_bounds__(PL_NT) void tower_fwd_planes_kernel(PlanesFwdP p)
     bf16x8 idf[2];
     make_identity<NP>(idf, lane);
     PSTAMPF(0);
+#ifdef PL_EXP_PRIO
+    // (experiment: a static issue priority for one half of the workgroup's waves -- 1: waves 4-7, 2: waves 0-3)
+    if ((PL_EXP_PRIO == 1) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
+#endif
 
     float ainv = 1.0f;
     WeightRing<NP> ring;
@@ -1591,6 +1595,9 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
     const int NT = p.dims[top + 1];
     bf16x8 idf[2];
     make_identity<NP>(idf, lane);
+#ifdef PL_EXP_PRIO
+    if ((PL_EXP_PRIO == 1) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // the pair loss, when it rides along: per-row coefficients of d loss / d e = partner * inv - self * kself
     double* const coef = reinterpret_cast<double*>(part);          // [32][2]  (the K-split buffer is idle here)

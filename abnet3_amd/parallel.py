@@ -75,8 +75,8 @@ def seed_all(seed):
     np.random.seed(seed)
 
 
-def all_reduce_gradients(flat_grad, loss_is_mean):
-    """SUM-reduces the flat gradient bucket in place over all ranks.
+def all_reduce_gradients(flat_grad, loss_is_mean, oneshot=None):
+    """SUM-reduces the flat gradient bucket in place over all ranks (oneshot: a OneShotAllReduce to do it with).
 
     Returns the factor the optimizer must apply to the reduced gradient so that
     R ranks x B pairs equal one process with R*B pairs: 1 for a summed loss
@@ -84,7 +84,10 @@ def all_reduce_gradients(flat_grad, loss_is_mean):
     _, ws = world()
     if not active():
         return 1.0
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    if oneshot is not None:
+        oneshot.all_reduce(flat_grad)
+    else:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / ws if loss_is_mean else 1.0
 
 
@@ -169,6 +172,20 @@ def all_gather_varlen(t):
     parts = [torch.empty_like(mine) for _ in range(ws)]
     dist.all_gather(parts, mine)
     return [p[:n_].to(t.device) for p, n_ in zip(parts, lens)]
+
+
+def _mapped_library(stem):
+    """Path of the shared object whose name starts with `stem` among the images THIS process has mapped (the HIP runtime and
+    RCCL torch loaded -- wherever they came from), or None."""
+    try:
+        with open('/proc/self/maps') as fh:
+            for line in fh:
+                path = line.rsplit(' ', 1)[-1].strip()
+                if os.path.basename(path).startswith(stem):
+                    return path
+    except OSError:
+        pass
+    return None
 
 
 class BatchNormSync:
@@ -272,11 +289,13 @@ class RcclBatchNormSync:
     @staticmethod
     def _load_rccl(C):
         forced = os.environ.get('ABN_RCCL_LIB')
-        candidates = [forced] if forced else [None, os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'), 'librccl.so']
+        candidates = [forced] if forced else [_mapped_library('librccl'), os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'),
+                                              'librccl.so']
+        candidates = [c for c in candidates if c]
         last = None
         for path in candidates:
             try:
-                lib = C.CDLL(path)         # (None: the symbols already mapped into this process)
+                lib = C.CDLL(path)
                 for name in ('ncclGetUniqueId', 'ncclCommInitRank', 'ncclAllReduce', 'ncclCommDestroy'):
                     getattr(lib, name)
                 return lib
@@ -302,6 +321,111 @@ class RcclBatchNormSync:
             self._destroy()
         except Exception:
             pass
+
+
+class OneShotAllReduce:
+    """The gradient bucket's SUM all-reduce as ONE launch per rank over peer-mapped mailboxes (abn_allreduce_oneshot:
+    reduce-scatter + all-gather in two hops over all xGMI links at once, summed in rank order -- SURVEY.md section 5 / 8e)
+    instead of torch.distributed's ring.  Each rank allocates its mailbox as fine-grained device memory, exports it with
+    hipIpcGetMemHandle, gathers everybody's handle over the existing process group and maps the peers' (hipIpcOpenMemHandle).
+    Behind a switch (TrainerBuilder / ABN_ONESHOT_ALLREDUCE=1): it has run between two processes on ONE GPU only (the
+    tests), never over xGMI.  `cap_floats`: the largest bucket it will be asked to reduce."""
+
+    _HANDLE_BYTES = 64
+    _FINEGRAINED = 0x1                 # hipDeviceMallocFinegrained
+    _IPC_LAZY = 0x1                    # hipIpcMemLazyEnablePeerAccess
+
+    def __init__(self, cap_floats, group=None):
+        import ctypes as C
+        from . import _lib
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError('OneShotAllReduce needs an initialised process group')
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > 8:
+            raise RuntimeError('OneShotAllReduce: at most 8 ranks (one node)')
+        self.cap = (int(cap_floats) + 3) // 4 * 4
+        self._lib = _lib.load()
+        self._hip = C.CDLL(_mapped_library('libamdhip64') or 'libamdhip64.so')       # the HIP runtime torch has loaded
+        for name in ('hipExtMallocWithFlags', 'hipIpcGetMemHandle', 'hipIpcOpenMemHandle', 'hipIpcCloseMemHandle', 'hipFree', 'hipMemset'):
+            getattr(self._hip, name)
+        nbytes = self._lib.abn_oneshot_mail_bytes(self.world, self.cap)
+        if nbytes <= 0:
+            raise RuntimeError('abn_oneshot_mail_bytes refused (%d ranks, %d floats)' % (self.world, self.cap))
+        self._bytes = nbytes
+        mine = C.c_void_p()
+        rc = self._hip.hipExtMallocWithFlags(C.byref(mine), C.c_size_t(nbytes), C.c_uint(self._FINEGRAINED))
+        ok = rc == 0 and bool(mine.value)
+        handle = (C.c_char * self._HANDLE_BYTES)()
+        if ok:
+            ok = self._hip.hipMemset(mine, 0, C.c_size_t(nbytes)) == 0 and self._hip.hipIpcGetMemHandle(C.byref(handle), mine) == 0
+        self._mine = mine if mine.value else None
+        self._opened = []
+        if not all_agree(ok, group):
+            self.close()
+            raise RuntimeError('OneShotAllReduce: the mailbox could not be allocated / exported on every rank (here: %d)' % rc)
+        torch.cuda.synchronize()
+        # everybody's handle (and pid: a rank maps only OTHER processes' memory; its own it has already)
+        words = np.concatenate([[os.getpid()], np.frombuffer(bytes(handle), dtype=np.int64)]).astype(np.int64)
+        dev = _comm_device()
+        t = torch.from_numpy(words.copy()).to(dev)
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(parts, t, group=group)
+        else:
+            parts = [t]
+        self._ctx = _lib.OneShotCtx()
+        self._ctx.rank, self._ctx.world, self._ctx.cap_floats = self.rank, self.world, self.cap
+        good = True
+
+        class _Handle(C.Structure):
+            _fields_ = [('reserved', C.c_char * self._HANDLE_BYTES)]
+        self._hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), _Handle, C.c_uint]
+        for r in range(self.world):
+            if r == self.rank:
+                self._ctx.mail[r] = mine.value
+                continue
+            w = parts[r].cpu().numpy()
+            h = _Handle()
+            C.memmove(C.byref(h), w[1:].tobytes(), self._HANDLE_BYTES)
+            peer = C.c_void_p()
+            rc = self._hip.hipIpcOpenMemHandle(C.byref(peer), h, C.c_uint(self._IPC_LAZY))
+            if rc != 0 or not peer.value:
+                good = False
+                self.open_error = rc
+                break
+            self._opened.append(peer)
+            self._ctx.mail[r] = peer.value
+        if not all_agree(good, group):
+            self.close()
+            raise RuntimeError('OneShotAllReduce: hipIpcOpenMemHandle failed on some rank (here: %s)' % getattr(self, 'open_error', 0))
+        self.calls = 0
+
+    def all_reduce(self, flat):
+        """SUM over the ranks, in place, on torch's current stream; flat: contiguous fp32 on the device, a multiple of 4
+        elements (the networks' flat gradient buffer is padded to 64)."""
+        from . import _lib
+        if flat.dtype != torch.float32 or not flat.is_contiguous() or flat.numel() % 4 or flat.numel() > self.cap:
+            raise ValueError('OneShotAllReduce.all_reduce: contiguous fp32, a multiple of 4 elements, at most %d' % self.cap)
+        _lib.check(self._lib.abn_allreduce_oneshot(_lib.C.byref(self._ctx), _lib.ptr(flat), flat.numel(), _lib.stream()),
+                   'abn_allreduce_oneshot')
+        self.calls += 1
+
+    def close(self):
+        try:
+            for p in getattr(self, '_opened', []):
+                self._hip.hipIpcCloseMemHandle(p)
+            self._opened = []
+            if getattr(self, '_mine', None) is not None:
+                self._hip.hipFree(self._mine)
+                self._mine = None
+        except Exception:
+            pass
+
+    def __del__(self):
+        import sys
+        if not sys.is_finalizing():
+            self.close()
 
 
 def bn_sync(group=None):

@@ -19,6 +19,7 @@ Differences, all on purpose:
 """
 import copy
 import gc
+import os
 import pickle
 import time
 import warnings
@@ -179,6 +180,13 @@ class TrainerBuilder:
             # one RNG state on all ranks to start from; what an epoch visits is
             # broadcast from rank 0 anyway (parallel.py, the loaders' batch_iterator)
             parallel.seed_all(self.seed)
+            # the gradient bucket's exchange as ONE launch per rank over peer-mapped mailboxes (parallel.OneShotAllReduce) instead
+            # of torch.distributed's ring: behind a switch -- it has never run over xGMI (tests: two processes on one GPU)
+            if os.environ.get('ABN_ONESHOT_ALLREDUCE') == '1':
+                try:
+                    self.oneshot = parallel.OneShotAllReduce(self.network.flat_parameters().numel())
+                except (RuntimeError, OSError, AttributeError) as e:      # (every rank together: OneShotAllReduce agrees before it raises)
+                    warnings.warn('abnet3_amd: ABN_ONESHOT_ALLREDUCE: falling back to torch.distributed.all_reduce (%s)' % (e,))
             # BatchNorm statistics over ALL replicas' rows (off: every replica normalises with its own, like torch's
             # DistributedDataParallel without SyncBatchNorm): R replicas then step like one process on the whole batch
             if sync_batch_norm and getattr(self.network, 'batch_norm', False):
@@ -327,13 +335,14 @@ class TrainerSiamese(TrainerBuilder):
             loss_value.backward()
 
     overlap_allreduce = True          # data-parallel steps: two gradient buckets, the first all-reduce under the rest of the backward
+    oneshot = None                    # parallel.OneShotAllReduce: the bucket's exchange as one launch over peer-mapped mailboxes (ABN_ONESHOT_ALLREDUCE=1)
 
     def _overlap_split(self, state):
         """The layer the data-parallel backward is cut at (None: one call, one all-reduce): towers of >= 3 layers whose
         parameters all live in ONE segment of the flat buffer, no BatchNorm; the upper bucket = the top half of the layers."""
         net = self.network
         seg = state[0]
-        if not self.overlap_allreduce or getattr(net, 'batch_norm', False) or len(seg.blocks) < 3:
+        if not self.overlap_allreduce or self.oneshot is not None or getattr(net, 'batch_norm', False) or len(seg.blocks) < 3:
             return None
         one = getattr(self, '_one_segment', None)           # (the parameter walk once, not per step)
         if one is None or one[0] is not seg:
@@ -400,7 +409,7 @@ class TrainerSiamese(TrainerBuilder):
                     self.optimizer.grad_scale = 1.0 / self.world_size if self._loss_is_mean() else 1.0
                 else:
                     self.optimizer.grad_scale = parallel.all_reduce_gradients(
-                        self.network.flat_grad(), self._loss_is_mean())
+                        self.network.flat_grad(), self._loss_is_mean(), self.oneshot)
             self.optimizer.step()
         elif do_training:
             loss_value = self.give_batch_to_network(batch)
@@ -408,7 +417,7 @@ class TrainerSiamese(TrainerBuilder):
             self._backward(loss_value)
             if self.dp:
                 self.optimizer.grad_scale = parallel.all_reduce_gradients(
-                    self.network.flat_grad(), self._loss_is_mean())
+                    self.network.flat_grad(), self._loss_is_mean(), self.oneshot)
             self.optimizer.step()
         else:
             with torch.no_grad():
@@ -495,7 +504,7 @@ class TrainerSiamese(TrainerBuilder):
             else:
                 if self.dp:
                     opt.grad_scale = parallel.all_reduce_gradients(
-                        self.network.flat_grad(), self._loss_is_mean())
+                        self.network.flat_grad(), self._loss_is_mean(), self.oneshot)
                 opt.step()
             return static_loss
         step.graph = graph
@@ -611,7 +620,7 @@ class TrainerSiamese(TrainerBuilder):
     def _bucket_finish(self):
         opt = self.optimizer
         if self.dp:
-            opt.grad_scale = parallel.all_reduce_gradients(self.network.flat_grad(), self._loss_is_mean())
+            opt.grad_scale = parallel.all_reduce_gradients(self.network.flat_grad(), self._loss_is_mean(), self.oneshot)
         opt.step()
 
     def _planned_step(self, plan, bid):

@@ -327,6 +327,26 @@ int abn_tower_reduce_step(const abn_tower_desc* t, int64_t rows, const float* sc
                           float* state1, float* state2, int64_t n, float lr, float hp0,
                           float hp1, float eps, int64_t step, float grad_scale, void* stream);
 
+/* The data-parallel step's gradient exchange (the reference has no multi-process path: this sits
+ * between loss.backward() and optimizer.step(), abnet3/trainer.py:239 -> :240) as a ONE-SHOT all-reduce over peer-mapped
+ * mailboxes instead of a ring: every rank pushes shard s of its bucket into rank s's mailbox, sums the world's contributions
+ * to its own shard in RANK ORDER (deterministic: replicas stay bit-identical) and pushes the reduced shard to everybody --
+ * two hops over all xGMI links at once, one kernel launch per rank on the caller's stream (graph-capturable, no host call
+ * inside).  The caller owns the mailboxes: rank s allocates abn_oneshot_mail_bytes(world, cap_floats) bytes of FINE-GRAINED
+ * device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained)), zeroes it once, exports it (hipIpcGetMemHandle) and maps
+ * every peer's (hipIpcOpenMemHandle) into mail[]; mail[rank] is its own.  Every rank of the group makes the same sequence of
+ * calls (same n).  SUM of fp32 in place over buf[0 .. n), n % 4 == 0, n <= cap_floats, buf 16-byte aligned.  A rank whose
+ * peer never arrives gives up after a bounded spin, leaves NaN in buf and its mailbox's failure word set (zero the mailboxes
+ * again before the next use). */
+#define ABN_ONESHOT_MAX_RANKS 8
+typedef struct abn_oneshot_ctx {
+    int32_t rank, world;
+    void* mail[ABN_ONESHOT_MAX_RANKS];     /* mail[s]: rank s's mailbox as mapped in THIS process */
+    int64_t cap_floats;                    /* most floats one call reduces (what the mailboxes were sized for) */
+} abn_oneshot_ctx;
+int64_t abn_oneshot_mail_bytes(int32_t world, int64_t cap_floats);
+int abn_allreduce_oneshot(const abn_oneshot_ctx* ctx, float* buf, int64_t n, void* stream);
+
 /* One nn.Linear at a time with the same kernels (what abn_tower_* chains):
  *   forward  y = act(x W^T + b)                       (addmm + activation)
  *   dgrad    dx = (dz W) * act'(a_prev)  [a_prev NULL: plain dz W]

@@ -177,6 +177,60 @@ def main():
         res['bn.small.losses'] = np.array([float(tr.train_step(batch, True)) for _ in range(2)])
     res['bn.small.calls'] = np.array(net.bn_sync.calls)
     res['bn.small.warned'] = np.array(sum('per-replica statistics' in str(w.message) for w in caught))
+    # --- (7) the one-shot all-reduce (abn_allreduce_oneshot: peer-mapped mailboxes over hipIpcMemHandle, one launch per rank)
+    # beside torch.distributed's: random buckets of several sizes, repeated calls (the tags move on), then three trainer steps
+    # with ABN_ONESHOT_ALLREDUCE=1 against the same steps over gloo
+    try:
+        one = parallel.OneShotAllReduce(600000)
+        res['oneshot.available'] = np.array(1)
+    except (RuntimeError, OSError, AttributeError) as e:
+        one = None
+        res['oneshot.available'] = np.array(0)
+        res['oneshot.why'] = np.array(str(e))
+    if one is not None:
+        worst, same = 0.0, 1
+        rngo = np.random.default_rng(900 + rank)
+        for n in (4, 64, 4096, 571712, 1000, 571712):
+            v = torch.from_numpy(rngo.standard_normal(n).astype(np.float32)).cuda()
+            ref = v.clone()
+            torch.distributed.all_reduce(ref)
+            one.all_reduce(v)
+            torch.cuda.synchronize()
+            worst = max(worst, float((v - ref).abs().max() / ref.abs().max()))
+            both = [torch.empty_like(v) for _ in range(world)]
+            torch.distributed.all_gather(both, v)
+            same = same and all(bool(torch.equal(both[0], b)) for b in both[1:])
+        res['oneshot.worst_rel'] = np.array(worst)
+        res['oneshot.replicas_identical'] = np.array(int(same))
+        res['oneshot.calls'] = np.array(one.calls)
+        # (what a call of the C2 bucket costs between two processes sharing this GPU: the launches' and the two hand-overs'
+        # latency, not a wire time -- DESIGN.md section 4 quotes it as such)
+        v = torch.zeros(571712, device='cuda')
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            one.all_reduce(v)
+        e1.record()
+        torch.cuda.synchronize()
+        res['oneshot.us_per_call'] = np.array(e0.elapsed_time(e1) * 1e3 / 50)
+        one.close()
+        runs = {}
+        for flag in ('1', '0'):
+            os.environ['ABN_ONESHOT_ALLREDUCE'] = flag
+            net = SiameseNetwork(output_path='/tmp/abn_dp_one_%d' % rank, **kw)
+            net.load_state_dict({k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith('p.')})
+            tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1,
+                                dataloader=None, log_dir='/tmp/abn_runs_dp')
+            assert (tr.oneshot is not None) == (flag == '1')
+            net.train()
+            batch = (torch.from_numpy(x1[sl]).cuda(), torch.from_numpy(x2[sl]).cuda(), torch.from_numpy(y[sl]).cuda())
+            losses = [float(tr.train_step(batch, True)) for _ in range(3)]
+            runs[flag] = (losses, {k: p.detach().cpu().numpy() for k, p in net.named_parameters()})
+        del os.environ['ABN_ONESHOT_ALLREDUCE']
+        res['oneshot.train_losses_diff'] = np.array(max(abs(a - b) / abs(b) for a, b in zip(runs['1'][0], runs['0'][0])))
+        res['oneshot.train_param_diff'] = np.array(max(float(np.abs(runs['1'][1][k] - v).max() / max(np.abs(v).max(), 1e-6)) for k, v in runs['0'][1].items()))
     np.savez(out + '.rank%d.npz' % rank, **res)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

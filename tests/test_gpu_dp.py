@@ -155,6 +155,22 @@ def test_batch_norm_with_cross_replica_statistics_equals_one_process(ranks):
         assert int(r['bn.small.warned']) == 1
 
 
+def test_one_shot_all_reduce_between_two_processes(ranks):
+    """abn_allreduce_oneshot (SURVEY.md 8e's small-message exchange: reduce-scatter + all-gather in two hops over peer-mapped
+    mailboxes, summed in rank order): two fresh processes map each other's mailbox through hipIpcMemHandle on this box's one
+    GPU and reduce buckets of several sizes beside torch.distributed's all-reduce -- the same sums (fp32: two terms, exact
+    whatever the order), bit-identical on both ranks, call after call; three trainer steps with ABN_ONESHOT_ALLREDUCE=1 end
+    where the same steps over gloo end.  What this does not show: anything about xGMI (one GPU here)."""
+    if not all(int(r['oneshot.available']) for r in ranks):
+        pytest.skip('peer mapping over hipIpcMemHandle between two processes on one device is not available here: %s'
+                    % [str(r.get('oneshot.why')) for r in ranks])
+    for r in ranks:
+        assert float(r['oneshot.worst_rel']) == 0.0
+        assert int(r['oneshot.replicas_identical']) == 1 and int(r['oneshot.calls']) == 6
+        print('one-shot all-reduce of 571 712 floats, two processes on one GPU: %.1f us per call' % float(r['oneshot.us_per_call']))
+        assert float(r['oneshot.train_losses_diff']) < 1e-6 and float(r['oneshot.train_param_diff']) < 1e-6
+
+
 def _corpus():
     gl = load_golden('frames_loader.npz')
     feats = {k[5:]: v for k, v in gl.items() if k.startswith('feat.')}
