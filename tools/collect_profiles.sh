@@ -35,3 +35,11 @@ python3 tools/traffic_summary.py $out/traffic_fb > $out/traffic_fb.txt
 python3 tools/pmc_summary.py $out/sq abn:: > $out/sq_counters.txt
 grep -h "^{\"metric\"" $out/stats.log | tail -1 > $out/bench_line_under_rocprof.json
 echo collected $out
+# round 5: the BatchNorm step (resident tower: one launch per direction) and the filterbank's LDS counters
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bn_stats -- python3 $root/tools/step_prof_bn.py > $out/bn_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --output-format csv -d $out/fbank_sq -- python3 $root/tools/fbank_time.py 3000 > $out/fbank_sq.log 2>&1
+cd $root
+python3 tools/prof_summary.py $out/bn_stats 10 > $out/bn_step_kernel_stats.txt
+python3 tools/pmc_summary.py $out/fbank_sq abn:: > $out/fbank_counters.txt
+echo collected round-5 extras

@@ -17,4 +17,6 @@ t = json.load(open(src + '/traffic_summary.json'))
 t.update(json.load(open(src + '/traffic_fb_summary.json')))        # the filterbank leg's own passes
 json.dump(t, open('profiles/%s_pmc_traffic.json' % tag, 'w'), indent=1)
 PY
+[ -s $src/bn_step_kernel_stats.txt ] && cp $src/bn_step_kernel_stats.txt profiles/${tag}_bn_step_kernel_stats.txt
+[ -s $src/fbank_counters.txt ] && cp $src/fbank_counters.txt profiles/${tag}_fbank_counters.txt
 echo installed profiles/${tag}_*
