@@ -731,24 +731,32 @@ __device__ __forceinline__ bool bnp_bwd_layer(const BnBwdTowerP& q, int l, char*
     const float* __restrict__ mask = q.mask[lp];
     const DropGen drop = make_drop(mask ? nullptr : q.drop_seed, q.drop_p, lp);
     if (own) {
+        // (one straight-line copy per dropout mode: with the mode's branches INSIDE the unrolled loop the register allocator
+        // spilled around every one of them, and a spill's reload here is a round trip to HBM)
+        auto dz_loop = [&](auto mode) {
+            constexpr int MODE = decltype(mode)::value;   // 0 none, 1 mask tensor, 2 the forward's seed hash
 #pragma unroll
-        for (int j = 0; j < BPW; ++j)
+            for (int j = 0; j < BPW; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = 32 * (blk0 + j) + 8 * g + 4 * h;
-                const bool live = n < K;
-                const int so = 32 * j + 4 * h + 8 * g;
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(slot_s + so), a2 = *reinterpret_cast<const f32x4*>(slot_s + VS + so);
-                const f32x4 k4 = *reinterpret_cast<const f32x4*>(slot_s + 2 * VS + so);
-                f32x4 m4 = {1.f, 1.f, 1.f, 1.f};
-                if (mask) m4 = *reinterpret_cast<const f32x4*>(mask + (int64_t)grc * K + (live ? n : K - 4));
-                else if (drop.on) m4 = drop4(drop, gr, n);
+                for (int g = 0; g < 4; ++g) {
+                    const int n = 32 * (blk0 + j) + 8 * g + 4 * h;
+                    const bool live = n < K;
+                    const int so = 32 * j + 4 * h + 8 * g;
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(slot_s + so), a2 = *reinterpret_cast<const f32x4*>(slot_s + VS + so);
+                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(slot_s + 2 * VS + so);
+                    f32x4 m4 = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (MODE == 1) m4 = *reinterpret_cast<const f32x4*>(mask + (int64_t)grc * K + (live ? n : K - 4));
+                    if constexpr (MODE == 2) m4 = drop4(drop, gr, n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = k4[e] * (nf * acc[j][4 * g + e] - a1[e] - xh[j][4 * g + e] * a2[e]) * m4[e];
-                    acc[j][4 * g + e] = live && row_ok ? v : 0.0f;
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = k4[e] * (nf * acc[j][4 * g + e] - a1[e] - xh[j][4 * g + e] * a2[e]) * m4[e];
+                        acc[j][4 * g + e] = live && row_ok ? v : 0.0f;
+                    }
                 }
-            }
+        };
+        if (mask) dz_loop(std::integral_constant<int, 1>{});
+        else if (drop.on) dz_loop(std::integral_constant<int, 2>{});
+        else dz_loop(std::integral_constant<int, 0>{});
     }
     float osc = 1.0f;
     if constexpr (NP == 2) {
