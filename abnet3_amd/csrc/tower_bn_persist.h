@@ -287,23 +287,29 @@ __device__ __forceinline__ bool bnp_fwd_layer(const PlanesFwdP& p, const BnPersi
     // z = (acc x scales + bias) x dropout: Linear -> Dropout -> BatchNorm (abnet3/model.py:136-140)
     if (own) {
         const float* mrow = mask ? mask + (int64_t)(row_ok ? gr : row0) * N : nullptr;
+        auto z_loop = [&](auto mode) {                    // (a straight-line copy per dropout mode: bnp_bwd_layer)
+            constexpr int MODE = decltype(mode)::value;   // 0 none, 1 mask tensor, 2 the per-forward seed hash
 #pragma unroll
-        for (int j = 0; j < BPW; ++j)
+            for (int j = 0; j < BPW; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = 32 * (blk0 + j) + 4 * h + 8 * g;
-                const bool live = n < N;                  // N % 4 == 0: four features in or out together
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(slot_s + 32 * j + 4 * h + 8 * g);
-                f32x4 m4 = {1.f, 1.f, 1.f, 1.f};
-                if (mrow) m4 = *reinterpret_cast<const f32x4*>(mrow + (live ? n : N - 4));
-                else if (drop.on) m4 = drop4(drop, gr, n);
+                for (int g = 0; g < 4; ++g) {
+                    const int n = 32 * (blk0 + j) + 4 * h + 8 * g;
+                    const bool live = n < N;              // N % 4 == 0: four features in or out together
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(slot_s + 32 * j + 4 * h + 8 * g);
+                    f32x4 m4 = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (MODE == 1) m4 = *reinterpret_cast<const f32x4*>(mrow + (live ? n : N - 4));
+                    if constexpr (MODE == 2) m4 = drop4(drop, gr, n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = (NP == 2 ? acc[j][4 * g + e] * cinv[j] : acc[j][4 * g + e]) + b4[e];
-                    if (mrow || drop.on) v *= m4[e];
-                    acc[j][4 * g + e] = live ? v : 0.0f;
+                    for (int e = 0; e < 4; ++e) {
+                        float v = (NP == 2 ? acc[j][4 * g + e] * cinv[j] : acc[j][4 * g + e]) + b4[e];
+                        if constexpr (MODE != 0) v *= m4[e];
+                        acc[j][4 * g + e] = live ? v : 0.0f;
+                    }
                 }
-            }
+        };
+        if (mrow) z_loop(std::integral_constant<int, 1>{});
+        else if (drop.on) z_loop(std::integral_constant<int, 2>{});
+        else z_loop(std::integral_constant<int, 0>{});
         // column statistics of this workgroup's rows, shifted by its first row's value (the float32 sums stay the size of
         // the variance), and z itself for the backward
         // (staged in the K-split buffer: [feature][sum (z - c) | sum (z - c)^2 | c | -])
@@ -320,10 +326,12 @@ __device__ __forceinline__ bool bnp_fwd_layer(const PlanesFwdP& p, const BnPersi
                     const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zv), 32));
                     const float c = h ? c1 : c0;
                     const float d = row_ok ? zv - c : 0.0f;
-                    sd[e] = half_wave_sum(d);
-                    sq[e] = half_wave_sum(d * d);
+                    sd[e] = d;
+                    sq[e] = d * d;
                     cc[e] = c;
                 }
+                half_wave_sum4(sd);
+                half_wave_sum4(sq);
                 const int n = 32 * (blk0 + j) + 8 * g + 4 * h;
                 if (r == 16 && n < PL_MAXW) {
 #pragma unroll
@@ -694,9 +702,11 @@ __device__ __forceinline__ bool bnp_bwd_layer(const BnBwdTowerP& q, int l, char*
                         const float dy = live && row_ok ? acc[j][4 * g + e] * act_grad(a, ACT) : 0.0f;
                         acc[j][4 * g + e] = dy;
                         xh[j][4 * g + e] = x;
-                        sd[e] = half_wave_sum(dy);
-                        sq[e] = half_wave_sum(dy * x);
+                        sd[e] = dy;
+                        sq[e] = dy * x;
                     }
+                    half_wave_sum4(sd);
+                    half_wave_sum4(sq);
                     if (r == 16 && live) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(pw + 4 * (n + e)) = f32x4{sd[e], sq[e], 0.0f, __uint_as_float(tag_p)};
@@ -955,9 +965,11 @@ __global__ __launch_bounds__(PL_NT) void bn_bwd_tower_kernel(BnBwdTowerP q)
                             f32x4 sd, sq;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                sd[e] = half_wave_sum(dy4[e]);
-                                sq[e] = half_wave_sum(dy4[e] * x4[e]);
+                                sd[e] = dy4[e];
+                                sq[e] = dy4[e] * x4[e];
                             }
+                            half_wave_sum4(sd);
+                            half_wave_sum4(sq);
                             if (r == 16 && c < NT) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(pw + 4 * (c + e)) = f32x4{sd[e], sq[e], 0.0f, __uint_as_float(gs.base + 1u)};

@@ -662,6 +662,31 @@ __device__ __forceinline__ float half_wave_sum(float v)
     return v;
 }
 
+// The same sums (same steps, same order: the same bits) of FOUR values at once, each add carrying its DPP operand itself
+// (v_add_f32_dpp).  What the compiler makes of update_dpp + add when it sees several at once is a zeroed temporary, a
+// v_mov_b32_dpp and half a packed add per step and value -- 2.5 instructions where one does; the column sums of a BatchNorm
+// layer are 64 such sums per lane.  Four independent chains keep every DPP read three instructions behind the write of its
+// register (the hardware asks for two wait states; nothing inserts them inside an asm statement); s_nop 1 covers the
+// values' producers.
+__device__ __forceinline__ void half_wave_sum4(f32x4& v)
+{
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+#define ABN_DPP_STEP(ctrl)                                      \
+    "v_add_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf\n\t"     \
+    "v_add_f32_dpp %1, %1, %1 " ctrl " bank_mask:0xf\n\t"     \
+    "v_add_f32_dpp %2, %2, %2 " ctrl " bank_mask:0xf\n\t"     \
+    "v_add_f32_dpp %3, %3, %3 " ctrl " bank_mask:0xf\n\t"
+    asm volatile("s_nop 1\n\t"
+                 ABN_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf")
+                 ABN_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf")
+                 ABN_DPP_STEP("row_ror:4 row_mask:0xf")
+                 ABN_DPP_STEP("row_ror:8 row_mask:0xf")
+                 ABN_DPP_STEP("row_bcast:15 row_mask:0xa")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef ABN_DPP_STEP
+    v = f32x4{a, b, c, d};
+}
+
 // ---------------------------------------------------------------------------------------------
 // Staggered layers.  A chain's wide layers (more than eight output blocks: two per wave) are bound by the operand
 // stream -- a CU pulls the packed layer through its L1 at ~45 B/clk whether four or eight waves ask for it
@@ -1048,10 +1073,12 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
                     const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zv), 32));
                     const float c = h ? c1 : c0;
                     const float d = row_ok ? zv - c : 0.0f;           // (a last workgroup of a call may hold fewer rows)
-                    sd[e] = half_wave_sum(d);
-                    sq[e] = half_wave_sum(d * d);
+                    sd[e] = d;
+                    sq[e] = d * d;
                     cc[e] = c;
                 }
+                half_wave_sum4(sd);
+                half_wave_sum4(sq);
                 if (r == 16) {
                     const int n = 32 * (blk0 + j) + 8 * g + 4 * h;
                     *reinterpret_cast<f32x4*>(pw + n) = sd;
@@ -1894,9 +1921,11 @@ __device__ __forceinline__ void bn_dgrad_product(const BnBwdP& q, char* __restri
                     for (int e = 0; e < 4; ++e) {
                         const float a = act_apply(xh[e] * ga[e] + be[e], ACT);
                         const float dy = live && row_ok ? d4[e] * act_grad(a, ACT) : 0.0f;
-                        sd[e] = half_wave_sum(dy);
-                        sq[e] = half_wave_sum(dy * xh[e]);
+                        sd[e] = dy;
+                        sq[e] = dy * xh[e];
                     }
+                    half_wave_sum4(sd);
+                    half_wave_sum4(sq);
                     if (r == 16 && live) {
                         *reinterpret_cast<f32x4*>(pw + n) = sd;
                         *reinterpret_cast<f32x4*>(pw + PL_MAXW + n) = sq;
