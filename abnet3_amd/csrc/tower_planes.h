@@ -477,6 +477,10 @@ __device__ __forceinline__ void ring_kloop(f32x16* acc, WeightRing<NP>& ring, co
 #pragma unroll
         for (int i = 0; i < PL_DEPTH; ++i) {
             const int s = s0 + i;
+#if defined(PL_EXP_PRIO) && PL_EXP_PRIO == 3
+            // (experiment: the two waves of a SIMD take turns at the higher issue priority, step by step)
+            if (((threadIdx.x >> 8) ^ i) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
             // (the three regions are fenced: left alone, the machine scheduler issues a refill before
             // the slot's last MFMA -- a second register set and copies that wait for the loads at the
             // loop's end -- or gathers all refills there)

@@ -143,6 +143,18 @@ class AlignCache(object):
         self.chunks.append((g1, g2))
         return len(self.chunks) - 1
 
+    def compact(self):
+        """All chunks as ONE.  The iterator path calls align_pairs per batch -- a chunk per call, thousands of small tensors
+        -- and every plan build walks and concatenates all of them: once compacted, a plan build finds one tensor to gather
+        from (views handed out earlier keep their own storage alive)."""
+        if len(self.chunks) <= 1:
+            return
+        base = np.concatenate(([0], np.cumsum([c[0].numel() for c in self.chunks]))).astype(np.int64)
+        g1 = torch.cat([c[0] for c in self.chunks])
+        g2 = torch.cat([c[1] for c in self.chunks])
+        self.span = {k: (None if sp is None else (0, int(base[sp[0]]) + sp[1], sp[2])) for k, sp in self.span.items()}
+        self.chunks = [(g1, g2)]
+
     def put(self, key, chunk, start, n):
         self.span[key] = (chunk, start, n) if n else None
 
@@ -529,6 +541,7 @@ class OriginalDataLoader(DataLoader):
         bs = self.batch_size
         P = len(pairs)
         nb = (P + bs - 1) // bs
+        self._align.compact()
         span, token = self._align.span, self.features.token
         chunk_base = np.concatenate(([0], np.cumsum([c[0].numel() for c in self._align.chunks]))).astype(np.int64)
         n_aligned = int(chunk_base[-1])
@@ -722,6 +735,7 @@ class FramesDataLoader(OriginalDataLoader):
         dev = self.features.table.device
         # where every kept pair's rows sit in one flat source (the DTW calls' flat path tensors, then the diff pairs'
         # index runs): one gather index for the dataset instead of a view and a label array per pair
+        self._align.compact()
         span, token = self._align.span, self.features.token
         chunk_base = np.concatenate(([0], np.cumsum([c[0].numel() for c in self._align.chunks]))).astype(np.int64)
         s_off, s_len = [], []

@@ -28,6 +28,8 @@ from pathlib import Path
 import torch
 import torch.optim as optim
 
+import weakref
+
 from . import _lib, parallel
 from .loss import unit_grad
 from .model import NetworkBuilder, SiameseMultitaskNetwork
@@ -42,6 +44,22 @@ except Exception:                           # noqa: the package is optional here
         def add_scalar(self, *args, **kwargs):
             pass
 
+
+
+# Trainers that hold planned-pass state (scratch with a "left zero" ticket, captured graphs holding its address).  A library
+# error may leave the ticket dirty: the state of every live trainer is dropped -- the scratch, the graphs, their pool and
+# the pass's running loss, so that nothing of an aborted pass can be mistaken for a result -- and the error propagates out of
+# the pass (nothing in this module catches HipLibraryError); the next pass allocates and captures afresh.
+_PLANNED_TRAINERS = weakref.WeakSet()
+
+
+def _drop_planned_state():
+    for t in list(_PLANNED_TRAINERS):
+        for name in ('_loss_ws', '_buckets', '_bucket_pool', '_loss_acc'):
+            t.__dict__.pop(name, None)
+
+
+_lib._ON_ERROR.append(_drop_planned_state)
 
 class FlatOptimizer(object):
     """torch.optim.{SGD,Adadelta,Adam,Adagrad,RMSprop} semantics (torch's default
@@ -584,17 +602,7 @@ class TrainerSiamese(TrainerBuilder):
             # a failed or aborted launch may leave the ticket counter non-zero, and every later planned step or replay
             # would then elect the wrong "last" workgroup: on a library error the scratch and the graphs that captured
             # its address are dropped (the next pass allocates and captures afresh)
-            if not getattr(self, '_error_hook', False):        # (once per trainer)
-                self._error_hook = True
-                import weakref
-                me = weakref.ref(self)
-
-                def _drop_planned_state():
-                    t = me()
-                    if t is not None:
-                        t.__dict__.pop('_loss_ws', None)
-                        t.__dict__.pop('_buckets', None)
-                _lib._ON_ERROR.append(_drop_planned_state)
+            _PLANNED_TRAINERS.add(self)      # (ONE module-level hook over the live trainers: a gridsearch builds many)
         key = (npad, plan.table.shape[1], plan.labels.dtype)
         b = st.get(key)
         if b is None:

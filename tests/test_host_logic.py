@@ -214,3 +214,32 @@ def test_batch_norm_sync_callback_finds_the_buffer_a_pointer_lies_in():
     assert s._allreduce(None, a.data_ptr() + 8, 32, None) == 1                         # runs past the end of a
     assert s._allreduce(None, b.data_ptr() + 4, 2, None) == 1                          # not 8-byte aligned
     assert s._allreduce(None, 12345, 1, None) == 1 and s.calls == 2                    # in nobody's buffer
+
+
+def test_align_cache_compacts_its_chunks_and_keeps_every_path():
+    # (the iterator path adds a chunk per align_pairs call; a plan build first makes ONE of them)
+    from abnet3_amd.dataloader import AlignCache
+    cache = AlignCache()
+    rng = np.random.RandomState(0)
+    want = {}
+    for c in range(5):
+        n = [int(v) for v in rng.randint(0, 7, size=4)]
+        g1 = torch.from_numpy(rng.randint(0, 1000, size=sum(n)).astype(np.int64))
+        g2 = torch.from_numpy(rng.randint(0, 1000, size=sum(n)).astype(np.int64))
+        chunk = cache.add_chunk(g1, g2)
+        start = 0
+        for k, m in enumerate(n):
+            cache.put((c, k), chunk, start, m)
+            want[(c, k)] = None if m == 0 else (g1[start:start + m].clone(), g2[start:start + m].clone())
+            start += m
+    early = cache[(1, [k for k in range(4) if want[(1, k)] is not None][0])]      # a view handed out before
+    cache.compact()
+    assert len(cache.chunks) == 1 and len(cache) == 20
+    for key, w in want.items():
+        got = cache[key]
+        assert (got is None) == (w is None)
+        if w is not None:
+            assert torch.equal(got[0], w[0]) and torch.equal(got[1], w[1])
+    assert early[0].numel() > 0          # (still readable: it keeps its own storage)
+    cache.compact()                      # idempotent
+    assert len(cache.chunks) == 1

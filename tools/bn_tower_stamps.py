@@ -27,3 +27,14 @@ d = np.diff(s, axis=1)
 for i in range(n - 1):
     print('%-40s median %8.0f   min %8.0f   max %8.0f' % (names[i], np.median(d[:, i]), d[:, i].min(), d[:, i].max()))
 print('wg start spread: median %.0f max %.0f; wg total median %.0f; last end %.0f (ticks of 10 ns)' % (np.median(s[:, 0]), s[:, 0].max(), np.median(s[:, n - 1] - s[:, 0]), s[:, n - 1].max()))
+# who arrives late?  the time a workgroup publishes its column sums (slot 3 + 8 l), against the median workgroup
+for l in (1, 2):
+    t = s[:, 3 + 8 * l]
+    k = s[:, 2 + 8 * l] - s[:, 8 * l]          # the k-loop alone (slot 8 l = the previous layer's end)
+    late = t - np.median(t)
+    print('L%d sums published, against the median workgroup: p10 %.0f p90 %.0f max %.0f; k-loop p10 %.0f median %.0f p90 %.0f max %.0f' % (
+        l, np.percentile(late, 10), np.percentile(late, 90), late.max(), np.percentile(k, 10), np.median(k), np.percentile(k, 90), k.max()))
+    print('   by blockIdx %% 8 (XCD): ' + ' '.join('%6.0f' % np.median(late[x::8]) for x in range(8)))
+    print('   by call half / quarter of the grid: ' + ' '.join('%6.0f' % np.median(late[q * 64:(q + 1) * 64]) for q in range(4)))
+    worst = np.argsort(-late)[:12]
+    print('   the latest: ' + ' '.join('%d(%+.0f)' % (w, late[w]) for w in worst))
