@@ -1500,6 +1500,9 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
     const int nl = t->n_layers;
     const int np = planes_of(t);
     PlanesBwdP b = {};
+#ifdef ABN_STAMPS
+    b.stamps = getenv("ABN_DSTAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_DSTAMP_BUF"), nullptr, 0) : nullptr;
+#endif
     b.n_layers = nl;
     b.rows = (int)rows;
     b.d_out = d_out;

@@ -1448,7 +1448,15 @@ struct PlanesBwdP {
     // by *n_valid.  null: all B pairs.
     const int* n_valid;
     double* loss_accum;                   // optional: the call's loss is also added here (an epoch's running sum)
+#ifdef ABN_STAMPS
+    unsigned long long* stamps;           // diagnostic build (tools/dgrad_stamps.py): [workgroup][64] s_memtime per phase
+#endif
 };
+#ifdef ABN_STAMPS
+#define DSTAMP(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DSTAMP(slot) do {} while (0)
+#endif
 
 // dZ_{l-1} from dZ_l (in img, pl_steps(dims[l+1]) steps): output features = the dims[l] inputs of layer l
 template <int NP, int BPW, int KS>
@@ -1495,6 +1503,7 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
         }
         if (ws.active) ring_kloop<NP, BPW>(acc, ring, wv, dnext, chain_next, img, ws.s_first, ws.my_steps, lane);
     }
+    DSTAMP(4 + 4 * (p.n_layers - 1 - l));
 
     const float* __restrict__ mask = l >= 1 ? p.mask[l - 1] : nullptr;
     const DropGen drop = make_drop(l >= 1 && !mask ? p.drop_seed : nullptr, p.drop_p, l - 1);
@@ -1564,7 +1573,9 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
 #pragma unroll
         for (int q = 0; q < 16; ++q) part[((wave & 3) * 16 + q) * 64 + lane] = acc[0][q];
     }
+    DSTAMP(5 + 4 * (p.n_layers - 1 - l));
     __syncthreads();                               // every wave is done reading img
+    DSTAMP(6 + 4 * (p.n_layers - 1 - l));
     if (KS == 2 && ws.active && ws.khalf == 0) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[0][q] += part[(wave * 16 + q) * 64 + lane];
@@ -1610,6 +1621,7 @@ __device__ __forceinline__ void planes_dgrad_layer(const PlanesBwdP& p, int l, c
             for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<bf16x8*>(img + ((int64_t)s * NP + pl) * 1024 + lane * 16) = z;
     }
     __syncthreads();
+    DSTAMP(7 + 4 * (p.n_layers - 1 - l));
 }
 
 template <int NP>
@@ -1629,6 +1641,7 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
 #ifdef PL_EXP_PRIO
     if ((PL_EXP_PRIO == 1) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
 #endif
+    DSTAMP(0);
 
     // the pair loss, when it rides along: per-row coefficients of d loss / d e = partner * inv - self * kself
     double* const coef = reinterpret_cast<double*>(part);          // [32][2]  (the K-split buffer is idle here)
@@ -1716,6 +1729,7 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
         }
     }
 
+    DSTAMP(1);
     // dZ of the last layer -> operand fragments and transposed planes
     const int steps_t = pl_steps(NT), blocks_t = steps_t / 2;
     const int gr = row0 + r;
@@ -1813,6 +1827,7 @@ __global__ __launch_bounds__(PL_NT) void tower_dgrad_planes_kernel(PlanesBwdP p)
         }
     }
     __syncthreads();
+    DSTAMP(2);
 
     WeightRing<NP> ring;
     ring_open(ring, p.wbase, p.wbytes);
