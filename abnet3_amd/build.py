@@ -62,13 +62,33 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         results = list(ex.map(compile_one, srcs))
     objs = [o for o, _ in results]
-    if force or any(c for _, c in results) or _stale(LIB, objs):
+    # (the library's digest is kept beside it: a file that something else wrote over it -- a diagnostic build -- is not ours)
+    if force or any(c for _, c in results) or _stale(LIB, objs) or _digest(LIB) != _recorded_digest():
         cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout)
             raise RuntimeError('link failed')
+        with open(LIB + '.sha1', 'w') as f:
+            f.write(_digest(LIB))
     return LIB
+
+
+def _digest(path):
+    import hashlib
+    h = hashlib.sha1()
+    with open(path, 'rb') as f:
+        for chunk in iter(lambda: f.read(1 << 20), b''):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def _recorded_digest():
+    try:
+        with open(LIB + '.sha1') as f:
+            return f.read().strip()
+    except OSError:
+        return None
 
 
 if __name__ == '__main__':

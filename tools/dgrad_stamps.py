@@ -3,6 +3,7 @@
 (tower_dgrad_planes_kernel, csrc/tower_planes.h) inside a C2 train step: wave 0 of every workgroup, medians over the
 workgroups, cycles of s_memtime (comparable only within a workgroup: every XCD counts from a base of its own)."""
 import os, sys
+os.environ.setdefault('ABNET3_HIP_LIB', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'variants', 'lib_stamps.so'))   # tools/build_stamps.sh
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 buf = torch.zeros(1024 * 64, dtype=torch.int64, device='cuda')

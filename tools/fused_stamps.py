@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (ABN_STAMPS build): per-layer cycle shares of the fused tower forward."""
 import os, sys
+os.environ.setdefault('ABNET3_HIP_LIB', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'variants', 'lib_stamps.so'))   # tools/build_stamps.sh
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 buf = torch.zeros(1024 * 128, dtype=torch.int64, device='cuda')

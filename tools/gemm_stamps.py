@@ -2,6 +2,7 @@
 """Diagnostic: per-phase s_memtime shares of the GEMM k-loop.  Needs the
 library built with -DABN_STAMPS (tools/build_stamps.sh); never used in timing."""
 import os, sys
+os.environ.setdefault('ABNET3_HIP_LIB', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'variants', 'lib_stamps.so'))   # tools/build_stamps.sh
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 buf = torch.zeros(4096 * 128, dtype=torch.int64, device='cuda')

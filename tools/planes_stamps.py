@@ -2,6 +2,7 @@
 """Diagnostic (ABN_STAMPS build, tools/variants.sh tower "-DABN_STAMPS"): phase timeline of the planes tower forward
 (workgroup medians, s_memtime ticks of 10 ns)."""
 import os, sys
+os.environ.setdefault('ABNET3_HIP_LIB', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'variants', 'lib_stamps.so'))   # tools/build_stamps.sh
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 buf = torch.zeros(1024 * 128, dtype=torch.int64, device='cuda')

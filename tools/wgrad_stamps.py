@@ -3,6 +3,7 @@
 workgroup of the weight-gradient launch spends its time -- prologue / row-step loop / slab stores -- per layer, and
 which workgroups share a CU (s_memtime ticks of 10 ns)."""
 import os, sys
+os.environ.setdefault('ABNET3_HIP_LIB', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'variants', 'lib_stamps.so'))   # tools/build_stamps.sh
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 buf = torch.zeros(4096 * 16, dtype=torch.int64, device='cuda')
