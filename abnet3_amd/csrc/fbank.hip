@@ -179,8 +179,8 @@ __device__ __forceinline__ void dft8(cf* v)
     v[3] = cadd(E3, O3); v[7] = csub(E3, O3);
 }
 
-constexpr int FB_WAVES = 4;            // wavefronts (frames in flight) per workgroup
-constexpr int FB_SPARSE_Q = 24;        // 16-byte pieces of a filter's band in LDS (40 mel triangles over 513 bins: the widest spans 18)
+constexpr int FB_WAVES = 4;            // wavefronts (frames in flight) per workgroup, one per SIMD (6 or 8 per workgroup: 0.87 / 0.74 ms against 0.69)
+constexpr int FB_SPARSE_Q = 20;        // 16-byte pieces of a filter's band in LDS (40 mel triangles over 513 bins: the widest spans 18)
 
 // Where element i of the wave's 512-point strip lives in LDS.  The passes read it lane-linearly (z[j + 64 r]: conflict free
 // as it stands) but WRITE it at strides of 8 elements (pass 0: z[8 j + r]: sixteen lanes on two bank pairs, 8-way) and in
@@ -194,7 +194,15 @@ __device__ __forceinline__ int zsw(int i)
     return ((B ^ ((B >> 3) & 1)) << 3) + ((i & 7) ^ ((B >> 1) & 7));
 }
 
-__global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __restrict__ samples, int is_i16,
+// Three waves per SIMD: a frame is a chain of LDS round trips (three passes, split, projection), and at two waves per SIMD the
+// vector units idled half of the time (profiles/r05_fbank_counters.txt).  What kept the kernel at 247 registers were the
+// lane's constants, held through the frame loop: the 18 twiddles (52 registers) are the same for every wavefront of the
+// workgroup and live in LDS tables now (6.5 KB, lane-linear reads: conflict free), read where they are used; the 16 window
+// taps stay in registers (163 in all).  Three workgroups per CU need <= 53 KB of LDS each: 51.3 with 20 pieces per filter.
+#ifndef FB_OCC
+#define FB_OCC 3
+#endif
+__global__ __launch_bounds__(64 * FB_WAVES) __attribute__((amdgpu_waves_per_eu(FB_OCC, FB_OCC))) void fbank1024_kernel(const void* __restrict__ samples, int is_i16,
                                                                   int64_t nsamples, int wlen, double fshift, int nfilt,
                                                                   float alpha, const float* __restrict__ window,
                                                                   const float* __restrict__ melbank,
@@ -207,25 +215,26 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
     // the filters' non-zero weights as 16-byte pieces aligned to the bins' index, piece q of filter f at [q][f]: the lanes of a
     // wave read consecutive pieces (conflict free; filter after filter, 4 bytes at a time, they met on the same banks)
     __shared__ __attribute__((aligned(16))) float sw4[FB_SPARSE_Q][64][4];
+    // lane-only constants, one copy per workgroup: the twiddles of pass 1 (sub-transform size 8: angle -2 pi r (j & 7) / 64),
+    // of pass 2 (-2 pi r j / 512) and of the split (e^{-2 pi i k / 1024}, k = j + 64 q)
+    __shared__ cf tw1_s[8][8], tw2_s[8][64], tws_s[4][64];
     const int wave = threadIdx.x >> 6, j = threadIdx.x & 63;
     cf* const z = zbuf[wave];
     float* const power = pw[wave];
 
-    // lane-only twiddles: pass 1 (sub-transform size 8): angle -2 pi r (j & 7) / 64; pass 2: -2 pi r j / 512
-    cf tw1[8], tw2[8], tws[4];
-#pragma unroll
-    for (int r = 1; r < 8; ++r) {
+    for (int i = threadIdx.x; i < 8 * 64; i += 64 * FB_WAVES) {
+        const int r = i >> 6, jj = i & 63;
         float sn, cs;
-        sincospif(-2.0f * (float)(r * (j & 7)) / 64.0f, &sn, &cs);
-        tw1[r] = {cs, sn};
-        sincospif(-2.0f * (float)(r * j) / 512.0f, &sn, &cs);
-        tw2[r] = {cs, sn};
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {          // split pass: e^{-2 pi i k / 1024}, k = j + 64 q
-        float sn, cs;
-        sincospif(-2.0f * (float)(j + 64 * q) / 1024.0f, &sn, &cs);
-        tws[q] = {cs, sn};
+        sincospif(-2.0f * (float)(r * jj) / 512.0f, &sn, &cs);
+        tw2_s[r][jj] = {cs, sn};
+        if (jj < 8) {
+            sincospif(-2.0f * (float)(r * jj) / 64.0f, &sn, &cs);
+            tw1_s[r][jj] = {cs, sn};
+        }
+        if (r < 4) {
+            sincospif(-2.0f * (float)(jj + 64 * r) / 1024.0f, &sn, &cs);
+            tws_s[r][jj] = {cs, sn};
+        }
     }
     // this lane's filter: its band of bins; the band's weights go to LDS once per workgroup
     const int blo = j < nfilt ? band[2 * j] : 1, bhi = j < nfilt ? band[2 * j + 1] : 0;
@@ -253,6 +262,10 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
     }
     const int nwaves = gridDim.x * FB_WAVES;
     for (int64_t frame = (int64_t)blockIdx.x * FB_WAVES + wave; frame < nframes; frame += nwaves) {
+        // (the tables' index is opaque to the compiler in every iteration: seen as loop invariants their loads are hoisted in
+        // front of the loop and the constants are back in registers)
+        int jt = j;
+        asm volatile("" : "+v"(jt));
         int64_t fr = frame, len = nsamples;
         const char* base = (const char*)samples;
         if (n_utts > 0) {                                          // (wave-uniform: one frame per wavefront)
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = z[zsw(j + 64 * r)];
 #pragma unroll
-        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw1[r]);
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw1_s[r][jt & 7]);
         dft8(v);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = z[zsw(j + 64 * r)];
 #pragma unroll
-        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw2[r]);
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw2_s[r][jt]);
         dft8(v);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -336,7 +349,7 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank1024_kernel(const void* __
             const cf a = z[zsw(k)], b = z[zsw((512 - k) & 511)];
             const cf s = {0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};        // (Z[k] + conj Z[N-k]) / 2
             const cf d = {0.5f * (a.x - b.x), 0.5f * (a.y + b.y)};        // (Z[k] - conj Z[N-k]) / 2
-            const cf t = cmul(tws[q], d);                                 // w d ; -i w d = (t.y, -t.x)
+            const cf t = cmul(tws_s[q][jt], d);                                 // w d ; -i w d = (t.y, -t.x)
             const cf xk = {s.x + t.y, s.y - t.x};
             // mirror bin 512 - k: conj(s) - (-i) conj(w) ... = conj(s) + i conj(w d) -> (s.x - t.y, -s.y - t.x)
             const cf xm = {s.x - t.y, -s.y - t.x};

@@ -41,6 +41,9 @@ constexpr float BN_MOMENTUM = 0.1f;
 constexpr int BN_WG_GROUPS = 16;          // thread groups of the finishing kernels (tower.hip): the order their sums are added in
 
 constexpr unsigned BNP_SPIN_LIMIT = 1u << 21;
+#ifndef BNP_POLL_SLEEP
+#define BNP_POLL_SLEEP 1                  // x 64 cycles between two polls of a granule that was not there yet
+#endif
 constexpr int BNP_HDR_BYTES = 256;        // sync_ws: word 0 the launch counter, word 16 the failure word
 constexpr int BNP_MAX_CALLS = 8;
 constexpr int BNP_MAX_WGS = 1024;         // workgroups a sync buffer serves (abn_tower_sync_ws_bytes)
@@ -107,7 +110,7 @@ __device__ __forceinline__ f32x4 granule_wait(const GranuleSync& g, int byte_off
             }
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(BNP_POLL_SLEEP);
     }
     return v;
 }
