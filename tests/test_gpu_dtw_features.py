@@ -290,6 +290,22 @@ def test_fbank_matches_oracle(fs, n):
     assert np.allclose(z, np.log(1e-5))
 
 
+@pytest.mark.parametrize('fs,nfilt', [(16000, 13), (14000, 40), (16000, 64)])
+def test_fbank_wide_and_narrow_filters(fs, nfilt):
+    """Bands wider than the sparse projection's 20 pieces of four bins (few filters) take the dense projection inside the same
+    kernel; another sampling rate moves every band; 64 filters fill every lane."""
+    from abnet3_amd.features import FeaturesGenerator
+    from oracle import features_np as F
+    n = 9000
+    rng = np.random.default_rng(nfilt)
+    t = np.arange(n) / fs
+    sig = (1500 * np.sin(2 * np.pi * 500 * t) + 700 * np.sin(2 * np.pi * 1900 * t + 0.5) + 300 * rng.standard_normal(n)).astype(np.int16)
+    fb = FeaturesGenerator(n_filters=nfilt).fbank_from_samples(sig, fs).cpu().numpy()
+    ref = F.fbank(sig, fs, nfilt=nfilt)
+    assert fb.shape == ref.shape == (F.frame_count(n, fs), nfilt)
+    assert np.abs(fb - ref).max() < 5e-5, np.abs(fb - ref).max()
+
+
 def test_fbank_general_kernel_and_deltas():
     """nfft != 1024 takes the general kernel; deltas / deltasdeltas (features.py:110-111)
     append the 9-tap regression slopes of oracle/features_np.py as further columns."""
