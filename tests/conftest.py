@@ -41,17 +41,22 @@ def pytest_configure(config):
             out = os.path.join(tempfile.mkdtemp(prefix='abn_dp_'), 'res')
             port = str(_free_port())
             procs = []
+            # (these helper processes share the test box's ONE GPU with each other and with pytest itself: their BatchNorm
+            # towers train one launch per layer -- two resident grids dispatched in the same microsecond could each hold part
+            # of the CUs and wait out their bounded spins for the rest; the resident tower is under test in
+            # this process, tests/test_gpu_bn_tower.py)
+            shared_gpu = dict(os.environ, ABN_BN_PERSIST='0')
             for r in range(2):
                 log = open(out + '.rank%d.log' % r, 'w')
                 procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'),
-                                               str(r), '2', port, out], stdout=log, stderr=subprocess.STDOUT))
+                                               str(r), '2', port, out], stdout=log, stderr=subprocess.STDOUT, env=shared_gpu))
             DP_JOB.update(procs=procs, out=out)
             # ... and bench.py --gpus 2 the way the driver starts it for N > 1 (torch.distributed.run's
             # environment), two fresh ranks sharing GPU 0 over gloo: tests/test_gpu_dp.py reads rank 0's JSON line
             port = str(_free_port())
             bprocs = []
             for r in range(2):
-                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                env = dict(shared_gpu, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
                            ABN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
                 log = open(out + '.bench%d.log' % r, 'w')
                 bprocs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
@@ -63,7 +68,7 @@ def pytest_configure(config):
             log = open(out + '.rccl.log', 'w')
             wait = [str(p.pid) for p in procs + bprocs]
             DP_JOB.update(rccl=subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'rccl_worker.py'), str(_free_port()), out] + wait,
-                                                stdout=log, stderr=subprocess.STDOUT))
+                                                stdout=log, stderr=subprocess.STDOUT, env=shared_gpu))
 
 
 def pytest_unconfigure(config):
