@@ -156,6 +156,10 @@ __device__ __forceinline__ bool bnp_fwd_finish(const PlanesFwdP& p, const BnPers
         const int c = blockIdx.x * cols_per + j;
         const bool live = i < total && c < N;
         const f32x4 v = granule_wait(gs, (int)bnp_part_off() + ((g * wpc + k) * PL_MAXW + (live ? c : 0)) * 16, tag_p, live);
+#ifdef ABN_STAMPS
+        // (diagnostic: when term i of the first 16 finishing workgroups was SEEN, on the chip-wide clock: rows 256 .. of the stamp buffer)
+        if (p.stamps && l == 1 && blockIdx.x < 16 && i < 512) p.stamps[(size_t)(256 + blockIdx.x * 4 + (i >> 7)) * 128 + (i & 127)] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (i < total) {
             double a = 0.0, b = 0.0;
             if (live) {
@@ -349,6 +353,7 @@ __device__ __forceinline__ bool bnp_fwd_layer(const PlanesFwdP& p, const BnPersi
     if ((int)threadIdx.x < N)
         st_sc1_4(gs.rs, (int)bnp_part_off() + ((int)blockIdx.x * PL_MAXW + (int)threadIdx.x) * 16, *reinterpret_cast<const f32x4*>(part + 4 * threadIdx.x));
     PSTAMPF(3 + 8 * l);
+    PSTAMPR(9 + 8 * l);                                // (the chip-wide clock: when this workgroup's sums were out)
     lds_barrier();                                     // (the staging buffer is the finishing step's scratch)
     PSTAMPF(4 + 8 * l);
     if (!bnp_fwd_finish(p, q, gs, tag_p, tag_s, l, N, wpc, reinterpret_cast<double*>(part))) return false;

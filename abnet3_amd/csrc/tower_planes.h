@@ -87,8 +87,11 @@ static inline size_t pl_lds_bytes_bn(int np) { return pl_lds_bytes(np) + 4 * PL_
 
 #ifdef ABN_STAMPS
 #define PSTAMPF(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 128 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+// (s_memtime counts from a base of its own per CU group: a stamp that is compared BETWEEN workgroups takes the constant 100 MHz clock)
+#define PSTAMPR(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 128 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PSTAMPF(slot) do {} while (0)
+#define PSTAMPR(slot) do {} while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------

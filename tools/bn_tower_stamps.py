@@ -28,14 +28,33 @@ d = np.diff(s, axis=1)
 for i in range(n - 1):
     print('%-40s median %8.0f   min %8.0f   max %8.0f' % (names[i], np.median(d[:, i]), d[:, i].min(), d[:, i].max()))
 print('wg start spread: median %.0f max %.0f; wg total median %.0f; last end %.0f (ticks of 10 ns)' % (np.median(s[:, 0]), s[:, 0].max(), np.median(s[:, n - 1] - s[:, 0]), s[:, n - 1].max()))
-# who arrives late?  the time a workgroup publishes its column sums (slot 3 + 8 l), against the median workgroup
-for l in (1, 2):
-    t = s[:, 3 + 8 * l]
-    k = s[:, 2 + 8 * l] - s[:, 8 * l]          # the k-loop alone (slot 8 l = the previous layer's end)
-    late = t - np.median(t)
-    print('L%d sums published, against the median workgroup: p10 %.0f p90 %.0f max %.0f; k-loop p10 %.0f median %.0f p90 %.0f max %.0f' % (
-        l, np.percentile(late, 10), np.percentile(late, 90), late.max(), np.percentile(k, 10), np.median(k), np.percentile(k, 90), k.max()))
-    print('   by blockIdx %% 8 (XCD): ' + ' '.join('%6.0f' % np.median(late[x::8]) for x in range(8)))
-    print('   by call half / quarter of the grid: ' + ' '.join('%6.0f' % np.median(late[q * 64:(q + 1) * 64]) for q in range(4)))
-    worst = np.argsort(-late)[:12]
+# who arrives late?  slot 9 + 8 l holds s_memrealtime (the chip-wide 100 MHz clock: 10 ns a tick) at the moment a workgroup has
+# published its column sums
+full = buf.cpu().numpy().reshape(1024, 128)[:256].astype(np.float64)
+for l in (0, 1, 2, 3):
+    t = full[:, 9 + 8 * l]
+    late = (t - np.median(t)) * 10.0                     # ns against the median workgroup
+    print('L%d sums published, ns against the median workgroup: p10 %.0f p90 %.0f max %.0f' % (l, np.percentile(late, 10), np.percentile(late, 90), late.max()))
+    print('   median by blockIdx %% 8: ' + ' '.join('%6.0f' % np.median(late[x::8]) for x in range(8)))
+    print('   median by quarter of the grid (calls 0, 0, 1, 1): ' + ' '.join('%6.0f' % np.median(late[q * 64:(q + 1) * 64]) for q in range(4)))
+    worst = np.argsort(-late)[:10]
     print('   the latest: ' + ' '.join('%d(%+.0f)' % (w, late[w]) for w in worst))
+# layer 1, the first 16 finishing workgroups: when each of their 512 terms was seen (chip-wide clock) against when its producer
+# published it -- the hand-over's latency, pair by pair (term i = (feature j, call g, producer k): i = (j * 2 + g) * 128 + k)
+allb = buf.cpu().numpy().reshape(1024, 128).astype(np.float64)
+pub = allb[:256, 9 + 8 * 1]
+lat = []
+for b in range(16):
+    seen = allb[256 + 4 * b:256 + 4 * b + 4].reshape(512)
+    for i in range(512):
+        k, g = i % 128, (i // 128) % 2
+        w = g * 128 + k
+        if seen[i] > 0:
+            lat.append((seen[i] - pub[w]) * 10.0)
+lat = np.array(lat)
+own = allb[:16, 9 + 8 * 1]
+print('hand-over latency (ns, seen - published), %d pairs: p10 %.0f median %.0f p90 %.0f max %.0f' % (lat.size, np.percentile(lat, 10), np.median(lat), np.percentile(lat, 90), lat.max()))
+for b in range(3):
+    seen = allb[256 + 4 * b:256 + 4 * b + 4].reshape(512)
+    print('   finishing workgroup %d: its own publish at 0, terms seen at p10 %.0f median %.0f max %.0f ns; the latest producer published at %+.0f' % (
+        b, (np.percentile(seen, 10) - own[b]) * 10, (np.median(seen) - own[b]) * 10, (seen.max() - own[b]) * 10, (pub.max() - own[b]) * 10))
