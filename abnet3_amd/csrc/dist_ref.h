@@ -276,6 +276,78 @@ __device__ __forceinline__ f32x2 angular_distance_plain2(f32x2 dot, float nx, f3
     return div_pi2(acosf_ref2(div_normal2(dot, splat2(nx) * ny)));
 }
 
+// acosf_ref2 for arguments the CALLER has checked to lie in 2^-26 < |x| < 0.5 in every lane of the
+// wavefront: the statements of the first range alone (z = x x; p / q; pi/2 - (x - (lo - x r))), no
+// selects, no compares.  The same operations in the same order as acosf_ref takes for such an
+// argument, so the same bits.
+__device__ __forceinline__ f32x2 acosf_small2(f32x2 x)
+{
+    const f32x2 one = splat2(1.0f);
+    const f32x2 pio2_hi = splat2(bits_f32(0x3fc90fdau)), pio2_lo = splat2(bits_f32(0x33a22168u));
+    const f32x2 pS0 = splat2(bits_f32(0x3e2aaaabu)), pS1 = splat2(-bits_f32(0x3ea6b090u)), pS2 = splat2(bits_f32(0x3e4e0aa8u)),
+                pS3 = splat2(-bits_f32(0x3d241146u)), pS4 = splat2(bits_f32(0x3a4f7f04u)), pS5 = splat2(bits_f32(0x3811ef08u));
+    const f32x2 qS1 = splat2(-bits_f32(0x4019d139u)), qS2 = splat2(bits_f32(0x4001572du)), qS3 = splat2(-bits_f32(0x3f303361u)),
+                qS4 = splat2(bits_f32(0x3d9dc62eu));
+    const f32x2 z = x * x;
+    const f32x2 p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const f32x2 q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const f32x2 r = div_normal2(p, q);
+    return pio2_hi - (x - (pio2_lo - x * r));
+}
+
+// does every one of the four quotients of EVERY lane lie in acosf's first range, away from its constant-result
+// arguments?  (2^-26 < |c| < 0.5; a NaN among them fails one of the two compares unless another value
+// hides it in the maximum -- then the straight-line statements carry it through to a NaN distance, which
+// is all the callers ask of it: the pair is dropped)
+__device__ __forceinline__ bool quotients_small4_all(f32x2 a, f32x2 b)      // wave-uniform; every lane of the wavefront is here
+{
+    const float mx = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(b.x)), fabsf(b.y));
+    const float mn = fminf(fminf(fminf(fabsf(a.x), fabsf(a.y)), fabsf(b.x)), fabsf(b.y));
+    // (two ballots: each compare lands in a scalar register pair, one scalar AND, no vector select in between)
+    return (__builtin_amdgcn_ballot_w64(mx < 0.5f) & __builtin_amdgcn_ballot_w64(mn > bits_f32(0x32800000u))) == ~0ull;
+}
+
+// The straight-line statements on FOUR cells at a time: each operation becomes two independent packed
+// instructions side by side, so a dependent operation never directly follows the one it waits for.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ f32x4 div_normal4(f32x4 a, f32x4 b)
+{
+    f32x4 y = f32x4{__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y), __builtin_amdgcn_rcpf(b.z), __builtin_amdgcn_rcpf(b.w)};
+    const f32x4 e = fma4(-b, y, splat4(1.0f));
+    y = fma4(e, y, y);
+    f32x4 q = a * y;
+    f32x4 r = fma4(-b, q, a);
+    q = fma4(r, y, q);
+    r = fma4(-b, q, a);
+    return fma4(r, y, q);
+}
+
+__device__ __forceinline__ f32x4 div_pi4(f32x4 a)
+{
+    const f32x4 pi_f = splat4(bits_f32(0x40490fdbu)), inv_pi = splat4(bits_f32(0x3ea2f983u));
+    const f32x4 q = a * inv_pi;
+    const f32x4 r = fma4(-q, pi_f, a);
+    return fma4(r, inv_pi, q);
+}
+
+__device__ __forceinline__ f32x4 acosf_small4(f32x4 x)        // acosf_small2's statements (2^-26 < |x| < 0.5 in every lane)
+{
+    const f32x4 one = splat4(1.0f);
+    const f32x4 pio2_hi = splat4(bits_f32(0x3fc90fdau)), pio2_lo = splat4(bits_f32(0x33a22168u));
+    const f32x4 pS0 = splat4(bits_f32(0x3e2aaaabu)), pS1 = splat4(-bits_f32(0x3ea6b090u)), pS2 = splat4(bits_f32(0x3e4e0aa8u)),
+                pS3 = splat4(-bits_f32(0x3d241146u)), pS4 = splat4(bits_f32(0x3a4f7f04u)), pS5 = splat4(bits_f32(0x3811ef08u));
+    const f32x4 qS1 = splat4(-bits_f32(0x4019d139u)), qS2 = splat4(bits_f32(0x4001572du)), qS3 = splat4(-bits_f32(0x3f303361u)),
+                qS4 = splat4(bits_f32(0x3d9dc62eu));
+    const f32x4 z = x * x;
+    const f32x4 p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const f32x4 q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const f32x4 r = div_normal4(p, q);
+    return pio2_hi - (x - (pio2_lo - x * r));
+}
+
 // is the norm inside the range angular_distance_ref<true> is valid for?
 __device__ __forceinline__ bool norm_is_plain(float v) { return v >= 9.094947e-13f && v <= 1.0995116e12f; }
 

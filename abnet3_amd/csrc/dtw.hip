@@ -585,6 +585,27 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                     const float4 ny4 = *reinterpret_cast<const float4*>(&ny_s[q][8 * g + 4 * half]);
                     const float nyv[4] = {ny4.x, ny4.y, ny4.z, ny4.w};
                     if constexpr (decltype(pl)::value) {          // two cells per instruction (dist_ref.h)
+#if !defined(ABN_EXP_NOEPI) && !defined(ABN_EXP_NOFAST)
+                        // the four quotients first; where all 256 of the wavefront sit in acosf's first range
+                        // (unrelated frames: most groups) the straight-line statements of that range alone
+                        const f32x4 c4 = div_normal4(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]},
+                                                     splat4(nx) * f32x4{nyv[0], nyv[1], nyv[2], nyv[3]});
+                        const f32x2 c01 = f32x2{c4.x, c4.y}, c23 = f32x2{c4.z, c4.w};
+                        f32x2 d01, d23;
+                        if (quotients_small4_all(c01, c23)) {
+                            const f32x4 d4 = div_pi4(acosf_small4(c4));
+                            d01 = f32x2{d4.x, d4.y};
+                            d23 = f32x2{d4.z, d4.w};
+                        } else {
+                            d01 = div_pi2(acosf_ref2(c01));
+                            d23 = div_pi2(acosf_ref2(c23));
+                        }
+                        ob |= (__float_as_uint(d01.x) | __float_as_uint(d01.y)) | (__float_as_uint(d23.x) | __float_as_uint(d23.y));
+                        out[(8 * g) * BAND] = d01.x;                   // padded rows / columns repeat real ones: no masking needed
+                        out[(8 * g + 1) * BAND] = d01.y;
+                        out[(8 * g + 2) * BAND] = d23.x;
+                        out[(8 * g + 3) * BAND] = d23.y;
+#else
 #pragma unroll
                         for (int e = 0; e < 4; e += 2) {
 #ifndef ABN_EXP_NOEPI
@@ -596,6 +617,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                             out[(8 * g + e) * BAND] = dv.x;
                             out[(8 * g + e + 1) * BAND] = dv.y;
                         }
+#endif
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -654,6 +676,10 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
         PSTAMP_FLUSH(0);
     } else {
         // =========================== consumer ===========================
+#ifndef ABN_GANG_CPRIO
+#define ABN_GANG_CPRIO 0
+#endif
+        if (ABN_GANG_CPRIO) __builtin_amdgcn_s_setprio(ABN_GANG_CPRIO);       // the sweep is the workgroup's dependency chain
         const double INF = __builtin_inf();
         double* const bnd = P.bound + (int64_t)(GS * (int)blockIdx.x + half) * 2 * bstride + 32;
         double p1 = INF, upprev = INF;
