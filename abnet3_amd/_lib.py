@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ABNET3_HIP_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get('ABNET3_HIP_LIB') or os.path.join(HERE, 'lib', 'libabnet3_hip.so')
-ABI_VERSION = 18
+ABI_VERSION = 19
 MAX_LAYERS = 16
 
 ACT = {'none': 0, None: 0, 'sigmoid': 1, 'relu': 2, 'tanh': 3}
@@ -69,6 +69,9 @@ SYMBOLS = {
     'abn_dtw_batched': (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                                    _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp,
                                    _i64, _vp]),
+    'abn_dtw_batched_overlap': (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
+                                           _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp,
+                                           _i64, _vp, _vp]),
     'abn_cosine_distance': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     'abn_cosine_distance_f64': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     'abn_arccos_f32': (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),

@@ -63,6 +63,7 @@ struct DtwP {
     int32_t* bad;                // [pair] set when a distance is NaN / negative (utils.py:59)
     double* total_cost;          // [pair] or NULL
     float* ynorm;                // gang kernel: [slot][mcap] norms of the pair's token-2 rows, computed by band 0
+    int32_t* done;               // gang kernel<true>: [pair] set once every back-pointer of the pair has left the CU (the overlapped traceback polls it)
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -468,12 +469,25 @@ __device__ __forceinline__ double dpp_shr1_f64(double v)      // lane l <- lane 
 #ifndef ABN_GANG_YPF
 #define ABN_GANG_YPF 1       // the producer requests its rows a round ahead
 #endif
+// FLAGS: the traceback of a pair may start while this kernel still runs (abn_dtw_batched_overlap: a second launch on
+// another stream polls P.done).  What that launch reads of a pair -- back-pointers, bad flag, total cost -- is then
+// stored write-through (agent-scope stores: they leave the XCD's L2 for the level all XCDs share, which is where these
+// bytes are headed anyway: nothing in this kernel reads them again), the storing wavefront waits until they are
+// acknowledged, and only then sets the pair's flag (MI355X_MICROARCH.md, hand-offs: sc1 stores -> vmcnt(0) -> sc1 flag).
+#ifndef ABN_GANG_RELEASE
+#define ABN_GANG_RELEASE 0
+#endif
+// (Two gangs per workgroup -- six wavefronts that land as 2 producers + 1 consumer on every SIMD, where five one-gang
+// workgroups land as 3P+C, 3P+C, 2P+2C, 2P+C -- were measured in round 6: twelve wavefronts per CU instead of fifteen cost 12 %.)
+template <bool FLAGS>
 __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(ABN_GANG_OCC, ABN_GANG_OCC))) void dtw_gang_kernel(DtwP P)
 {
     __shared__ __attribute__((aligned(16))) float blk[GS][3][BAND][BAND];      // [slot][round % 3][column][row]
     __shared__ __attribute__((aligned(16))) float ny_s[GS][BAND];
     __shared__ double top_s[GS][BAND];
     __shared__ GangDesc desc[2][GS];                                             // [round parity][slot]
+    const int gid = (int)blockIdx.x;
+    auto all_idle = [&](int par) { return desc[par][0].pair < 0 && desc[par][1].pair < 0; };
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, n = lane & 31;
     const int D = KCH;
     const int64_t bstride = P.mcap;                     // a boundary row: 32 doubles of slack in front (the host pads mcap)
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
         // used, and behind the token the descriptor returns 0).
         u32x4 yq[10];
         float ynq = 1.0f;
-        float* const ynorm = P.ynorm + (int64_t)(GS * (int)blockIdx.x + q) * P.mcap;
+        float* const ynorm = P.ynorm + (int64_t)(GS * gid + q) * P.mcap;
         auto request_y = [&]() {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.feats2 + yoff), 0, M * (D * 4), 0x00020000);
             const int row = min(u * BAND + n, M - 1);
@@ -632,7 +646,12 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
             orbits |= ob;
             if (band + 1 == nbands && (u + 1) * BAND >= M) {               // the pair's last block
                 const bool isbad = __any(orbits >= 0x7f800000u);
-                if (isbad && lane == 0) P.bad[pair] = 1;                    // utils.py:59: NaN (or negative) distance
+                if (isbad) {                                                // utils.py:59: NaN (or negative) distance
+                    if (FLAGS) {                                            // in place before this round's barrier, behind which the consumer flags the pair
+                        if (lane == 0) __hip_atomic_store(&P.bad[pair], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else if (lane == 0) P.bad[pair] = 1;
+                }
                 orbits = 0u;
             }
         };
@@ -650,7 +669,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
         }
         PSTAMP_INIT;
         for (int t = -1;; ++t) {
-            if (t >= 0 && desc[t & 1][0].pair < 0 && desc[t & 1][1].pair < 0) break;
+            if (t >= 0 && all_idle(t & 1)) break;
             publish((t + 1) & 1);                                           // round t + 1 of this slot
             const bool have = pair >= 0 && u * BAND < M;
             PSTAMP(0);
@@ -681,7 +700,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
 #endif
         if (ABN_GANG_CPRIO) __builtin_amdgcn_s_setprio(ABN_GANG_CPRIO);       // the sweep is the workgroup's dependency chain
         const double INF = __builtin_inf();
-        double* const bnd = P.bound + (int64_t)(GS * (int)blockIdx.x + half) * 2 * bstride + 32;
+        double* const bnd = P.bound + (int64_t)(GS * gid + half) * 2 * bstride + 32;
         double p1 = INF, upprev = INF;
         uint32_t bits = 0u;
         // the boundary values of the NEXT round, requested while this one is swept (same band: the row
@@ -692,7 +711,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
         __syncthreads();                                                    // the first blocks are in place
         PSTAMP_INIT;
         for (int t = 0;; ++t) {
-            if (desc[t & 1][0].pair < 0 && desc[t & 1][1].pair < 0) break;
+            if (all_idle(t & 1)) break;
             const GangDesc& d = desc[t & 1][half];
             const int pair = d.pair, N = d.N, M = d.M, nbands = d.nbands, nrounds = d.nrounds, band = d.band, u = d.u;
             const bool active = pair >= 0;
@@ -753,10 +772,21 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                 upprev = up;
                 p1 = on ? cost : p1;                     // past the row's end the last cost stays put
                 if (feed) __hip_atomic_store(&bout[e], cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if ((e & 15) == 15 && active) dptr[(e >> 4) * BAND] = bits;
+                if ((e & 15) == 15 && active) {
+                    if (FLAGS && !ABN_GANG_RELEASE) __hip_atomic_store(&dptr[(e >> 4) * BAND], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else dptr[(e >> 4) * BAND] = bits;
+                }
             }
-            if (active && u + 1 == nrounds && band + 1 == nbands && P.total_cost && n == ((N - 1) & 31))
-                P.total_cost[pair] = p1;                 // lane (N-1) % 32 holds cost(N-1, M-1)
+            const bool fin = active && u + 1 == nrounds && band + 1 == nbands;      // the pair's last round
+            if (fin && P.total_cost && n == ((N - 1) & 31)) {                        // lane (N-1) % 32 holds cost(N-1, M-1)
+                if (FLAGS) __hip_atomic_store(&P.total_cost[pair], p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else P.total_cost[pair] = p1;
+            }
+            if (FLAGS && __any(fin)) {
+                if (ABN_GANG_RELEASE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // every store of this wavefront is acknowledged
+                if (fin && n == 0) __hip_atomic_store(&P.done[pair], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             // a finished band's boundary row is re-read by this wavefront (workgroup scope: the CU's own L1 /
             // L2 path, no write-through to memory): the stores only have to be complete
             if (__any(active && u + 1 == nrounds)) {
@@ -791,12 +821,28 @@ extern "C" int abn_debug_dtw_cycles(unsigned long long* out16, int reset)
 #define ABN_TB_ROWS 8
 #endif
 constexpr int TB_ROWS = ABN_TB_ROWS;
+#ifndef TB_PLAIN_LOADS
+#define TB_PLAIN_LOADS 0
+#endif
+// MODE 0: every pair of the queue, after the fill kernel (one stream).
+// MODE 1: launched on a SECOND stream beside dtw_gang_kernel<true>: a wavefront waits -- a bounded poll of the pairs' done
+//         flags, asleep in between -- until its 64 pairs (neighbours in the queue: filled at about the same time) are
+//         complete, then walks them; what the fill kernel stored write-through is read with agent-scope loads.  A pair
+//         whose flag has not come by the time limit is left alone (path_len stays 0).
+// MODE 2: the sweep behind both streams: the pairs MODE 1 left (normally none).
+#ifndef ABN_TB_WAIT_TICKS
+#define ABN_TB_WAIT_TICKS 50000000ull      // 0.5 s of the 100 MHz clock
+#endif
+#ifdef ABN_TB_STAMPS          // diagnostic build only (tools/tb_stamps.py): when each wavefront of the overlapped traceback started, saw its flags, ended
+__device__ unsigned long long g_tb_stamps[4096][4];
+#endif
+template <int MODE>
 __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __restrict__ meta, const int32_t* __restrict__ order,
-                                                           int npairs, const uint32_t* __restrict__ dirs,
-                                                           const int32_t* __restrict__ bad,
+                                                           int npairs, const uint32_t* dirs,
+                                                           const int32_t* bad, const int32_t* done,
                                                            int32_t* __restrict__ path1, int32_t* __restrict__ path2,
-                                                           int32_t* __restrict__ path_len, int64_t path_stride,
-                                                           double* __restrict__ total_cost)
+                                                           int32_t* path_len, int64_t path_stride,
+                                                           double* total_cost)
 {
     __shared__ uint32_t win[2 * TB_ROWS][64];            // [group offset * 8 + row offset][thread]: conflict-free
     const int lane = threadIdx.x;
@@ -804,9 +850,33 @@ __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __res
     // queue order (pairs of similar size side by side): the threads of a wavefront walk paths of
     // similar length.  Empty pairs are not in the queue: their path_len was zeroed by the call.
     const int p = order[blockIdx.x * 64 + lane];
+#ifdef ABN_TB_STAMPS
+    if (MODE != 2 && lane == 0 && blockIdx.x < 4096) g_tb_stamps[blockIdx.x][MODE == 0 ? 1 : 0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (MODE == 1) {
+        int ok = 0;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            if (!ok) ok = __hip_atomic_load(&done[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(ok)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > ABN_TB_WAIT_TICKS) break;
+            __builtin_amdgcn_s_sleep(127);
+        }
+        if (!ok) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // the walk is a chain of dependent steps on a SIMD it shares with the fill kernel's (older) wavefronts: without
+        // priority it gets the issue slots they leave and takes several times as long (a few hundred instructions per
+        // pair in all: nothing the fill kernel misses)
+        __builtin_amdgcn_s_setprio(3);
+#ifdef ABN_TB_STAMPS
+        if (lane == 0 && blockIdx.x < 4096) g_tb_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+    if (MODE == 2 && path_len[p] != 0) return;          // (a dropped pair is looked at again: nothing to do but its flag)
     const PairMeta m = meta[p];
     const int N = m.n1, M = m.n2;
-    if (bad[p]) {
+    const int isbad = MODE == 1 ? __hip_atomic_load(&bad[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bad[p];
+    if (isbad) {
         if (total_cost) total_cost[p] = 0.0;
         return;                                       // path_len[p] stays 0: the pair is dropped
     }
@@ -823,8 +893,13 @@ __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __res
         uint32_t w0[TB_ROWS], w1[TB_ROWS];
 #pragma unroll
         for (int q = 0; q < TB_ROWS; ++q) {
-            w0[q] = src[q];
-            w1[q] = g > 0 ? src[q - BAND] : 0u;
+            if (MODE == 1 && !TB_PLAIN_LOADS) {
+                w0[q] = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w1[q] = g > 0 ? __hip_atomic_load(src + q - BAND, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            } else {
+                w0[q] = src[q];
+                w1[q] = g > 0 ? src[q - BAND] : 0u;
+            }
         }
 #pragma unroll
         for (int q = 0; q < TB_ROWS; ++q) {
@@ -844,6 +919,9 @@ __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __res
         }
     }
     path_len[p] = k + 1;
+#ifdef ABN_TB_STAMPS
+    if (MODE != 2 && blockIdx.x < 4096) { atomicMax(&g_tb_stamps[blockIdx.x][2], (unsigned long long)__builtin_amdgcn_s_memrealtime()); g_tb_stamps[blockIdx.x][3] = k; }
+#endif
 }
 
 // plain [N, M] float64 distance matrix of one pair (abn_cosine_distance)
@@ -897,7 +975,7 @@ __global__ void arccos_kernel(const float* __restrict__ x, int64_t n, int over_p
 }
 
 struct WsPlan {
-    int64_t meta_off, order_off, bad_off, counter_off, dirs_off, bound_off, ynorm_off, total;
+    int64_t meta_off, order_off, bad_off, done_off, counter_off, dirs_off, bound_off, ynorm_off, total;
     int64_t mcap;
     int32_t nwg;
 };
@@ -906,7 +984,7 @@ struct WsPlan {
 
 using namespace abn;
 
-// Workspace: [PairMeta x P][order x P][bad x P][queue counter][back-pointers][boundary rows]
+// Workspace: [PairMeta x P][order x P][bad x P][done x P][queue counter][back-pointers][boundary rows][norm strips]
 static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P)
 {
     WsPlan w;
@@ -935,6 +1013,7 @@ static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P)
     w.meta_off = take(P * (int64_t)sizeof(PairMeta));
     w.order_off = take(P * 4);
     w.bad_off = take(P * 4);
+    w.done_off = take(P * 4);           // (between bad and counter: one memset clears all three)
     w.counter_off = take(4);
     w.dirs_off = take(dwords * 4);
     w.bound_off = take(2 * nwg * 2 * w.mcap * 8);
@@ -956,12 +1035,19 @@ extern "C" int64_t abn_dtw_host_stage_bytes(const int32_t* n1_host, const int32_
     return align_up(npairs * (int64_t)sizeof(PairMeta), 256) + align_up(npairs * 4, 256);
 }
 
-extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* feats2, int64_t rows2,
-                                    const int64_t* off1_host, const int32_t* n1_host, const int64_t* off2_host,
-                                    const int32_t* n2_host, int64_t npairs, int64_t D, int32_t* path1,
-                                    int32_t* path2, int32_t* path_len, int64_t path_stride, double* total_cost,
-                                    void* ws, int64_t ws_bytes, void* host_stage, int64_t host_stage_bytes,
-                                    void* stream)
+static void launch_gang(bool flags, int64_t ng, hipStream_t st, const DtwP& P)
+{
+    const dim3 grid((unsigned)ng), block(64 * (GS + 1));
+    if (flags) hipLaunchKernelGGL(dtw_gang_kernel<true>, grid, block, 0, st, P);
+    else hipLaunchKernelGGL(dtw_gang_kernel<false>, grid, block, 0, st, P);
+}
+
+static int dtw_batched_impl(const float* feats1, int64_t rows1, const float* feats2, int64_t rows2,
+                            const int64_t* off1_host, const int32_t* n1_host, const int64_t* off2_host,
+                            const int32_t* n2_host, int64_t npairs, int64_t D, int32_t* path1,
+                            int32_t* path2, int32_t* path_len, int64_t path_stride, double* total_cost,
+                            void* ws, int64_t ws_bytes, void* host_stage, int64_t host_stage_bytes,
+                            void* stream, void* side_stream)
 {
     ABN_REQUIRE(npairs >= 0 && npairs < (1LL << 31) && D >= 1 && D < (1 << 20), "dtw: bad npairs/D");
     if (npairs == 0) return ABN_OK;
@@ -970,7 +1056,7 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
                 "dtw: null pointer");
     const int64_t meta_bytes = align_up(npairs * (int64_t)sizeof(PairMeta), 256);
     if (host_stage_bytes < meta_bytes + align_up(npairs * 4, 256)) { set_error("dtw: host staging buffer too small"); return ABN_E_WORKSPACE; }
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = (hipStream_t)stream, side = (hipStream_t)side_stream;
     char* base = (char*)ws;
     PairMeta* hm = (PairMeta*)host_stage;
     int32_t* hord = (int32_t*)((char*)host_stage + meta_bytes);
@@ -1039,25 +1125,74 @@ extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* 
         P.bad = (int32_t*)(base + w.bad_off);
         P.total_cost = total_cost;
         P.ynorm = (float*)(base + w.ynorm_off);
+        P.done = (int32_t*)(base + w.done_off);
         int64_t nwg = (nq + 1) / 2;
         if (nwg > w.nwg) nwg = w.nwg;
         const bool vec = D % 4 == 0 && aligned16(feats1) && aligned16(feats2);
         const bool pipelined = switches().dtw_f40;     // A/B switch of the 40-d specialisation
         const bool gang = switches().dtw_pc;            // A/B switch: gang form (a producer per slot + one consumer)
+        const int32_t* qorder = (const int32_t*)(base + w.order_off);
+        const unsigned tb_grid = (unsigned)((nq + 63) / 64);
         if (vec && D == KCH && gang) {
             const int64_t ng = nwg < 256 * switches().dtw_wgs_per_cu ? nwg : 256 * switches().dtw_wgs_per_cu;
-            hipLaunchKernelGGL(dtw_gang_kernel, dim3((unsigned)ng), dim3(64 * (GS + 1)), 0, st, P);
+            if (side && side != st) {
+                // The traceback beside the fill: the second stream's launch starts once the uploads and memsets above
+                // are done, polls the pairs' flags and walks each pair as it completes; this stream then waits for it
+                // and sweeps up whatever it left.  Two transient events order the streams; nothing outlives the call.
+                hipEvent_t ready = nullptr, traced = nullptr;
+                if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&traced, hipEventDisableTiming) != hipSuccess) {
+                    if (ready) (void)hipEventDestroy(ready);
+                    set_error("dtw: hipEventCreate failed");
+                    return ABN_E_LAUNCH;
+                }
+                bool ok = hipEventRecord(ready, st) == hipSuccess && hipStreamWaitEvent(side, ready, 0) == hipSuccess;
+                if (ok) {
+                    launch_gang(true, ng, st, P);
+                    hipLaunchKernelGGL(dtw_traceback_kernel<1>, dim3(tb_grid), dim3(64), 0, side, dm, qorder, (int)nq, P.dirs, P.bad,
+                                       P.done, path1, path2, path_len, path_stride, total_cost);
+                    ok = hipEventRecord(traced, side) == hipSuccess && hipStreamWaitEvent(st, traced, 0) == hipSuccess;
+                    hipLaunchKernelGGL(dtw_traceback_kernel<2>, dim3(tb_grid), dim3(64), 0, st, dm, qorder, (int)nq, P.dirs, P.bad,
+                                       P.done, path1, path2, path_len, path_stride, total_cost);
+                }
+                (void)hipEventDestroy(ready);
+                (void)hipEventDestroy(traced);
+                if (!ok) { set_error("dtw: ordering the two streams failed"); return ABN_E_LAUNCH; }
+                ABN_CHECK_LAUNCH("dtw");
+                return ABN_OK;
+            }
+            launch_gang(false, ng, st, P);
         }
         else if (vec && D == KCH && pipelined) hipLaunchKernelGGL((dtw_fused_kernel<true, true>), dim3((unsigned)nwg), dim3(64), 0, st, P);
         else if (vec) hipLaunchKernelGGL((dtw_fused_kernel<true, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);
         else hipLaunchKernelGGL((dtw_fused_kernel<false, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(dtw_traceback_kernel<0>, dim3(tb_grid), dim3(64), 0, st, dm, qorder, (int)nq, P.dirs, P.bad,
+                           P.done, path1, path2, path_len, path_stride, total_cost);
     }
-    if (nq > 0)
-        hipLaunchKernelGGL(dtw_traceback_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, dm,
-                           (const int32_t*)(base + w.order_off), (int)nq, (const uint32_t*)(base + w.dirs_off),
-                           (const int32_t*)(base + w.bad_off), path1, path2, path_len, path_stride, total_cost);
     ABN_CHECK_LAUNCH("dtw");
     return ABN_OK;
+}
+
+extern "C" int abn_dtw_batched(const float* feats1, int64_t rows1, const float* feats2, int64_t rows2,
+                               const int64_t* off1_host, const int32_t* n1_host, const int64_t* off2_host,
+                               const int32_t* n2_host, int64_t npairs, int64_t D, int32_t* path1,
+                               int32_t* path2, int32_t* path_len, int64_t path_stride, double* total_cost,
+                               void* ws, int64_t ws_bytes, void* host_stage, int64_t host_stage_bytes,
+                               void* stream)
+{
+    return dtw_batched_impl(feats1, rows1, feats2, rows2, off1_host, n1_host, off2_host, n2_host, npairs, D, path1, path2,
+                            path_len, path_stride, total_cost, ws, ws_bytes, host_stage, host_stage_bytes, stream, nullptr);
+}
+
+extern "C" int abn_dtw_batched_overlap(const float* feats1, int64_t rows1, const float* feats2, int64_t rows2,
+                                       const int64_t* off1_host, const int32_t* n1_host, const int64_t* off2_host,
+                                       const int32_t* n2_host, int64_t npairs, int64_t D, int32_t* path1,
+                                       int32_t* path2, int32_t* path_len, int64_t path_stride, double* total_cost,
+                                       void* ws, int64_t ws_bytes, void* host_stage, int64_t host_stage_bytes,
+                                       void* stream, void* side_stream)
+{
+    return dtw_batched_impl(feats1, rows1, feats2, rows2, off1_host, n1_host, off2_host, n2_host, npairs, D, path1, path2,
+                            path_len, path_stride, total_cost, ws, ws_bytes, host_stage, host_stage_bytes, stream, side_stream);
 }
 
 extern "C" int abn_cosine_distance(const float* x, int64_t N, const float* y, int64_t M, int64_t D, double* d,
@@ -1098,3 +1233,11 @@ extern "C" int abn_arccos_f32(const float* x, int64_t n, int over_pi, float* out
     ABN_CHECK_LAUNCH("arccos_f32");
     return ABN_OK;
 }
+
+#ifdef ABN_TB_STAMPS
+extern "C" int abn_debug_tb_stamps(unsigned long long* out, int reset)
+{
+    if (reset) return hipMemcpyToSymbol(HIP_SYMBOL(abn::g_tb_stamps), out, sizeof(abn::g_tb_stamps)) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(abn::g_tb_stamps), sizeof(abn::g_tb_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif

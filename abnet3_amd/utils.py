@@ -10,6 +10,7 @@ Mirrors (file:line relative to the reference checkout)
   print_token         abnet3/utils.py:101-105   (pairs-file number format)
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -213,6 +214,16 @@ class _DtwScratch(object):
         self.ws = None
         self.stage = None
         self.done = None
+        self.side = None
+
+    def side_stream(self, device):
+        """The second stream abn_dtw_batched_overlap runs the traceback on, beside the fill kernel
+        (ABN_DTW_OVERLAP=0: one stream, the traceback behind the fill)."""
+        if os.environ.get('ABN_DTW_OVERLAP', '1') == '0':
+            return None
+        if self.side is None:
+            self.side = torch.cuda.Stream(device)
+        return self.side
 
     @classmethod
     def get(cls, device):
@@ -269,11 +280,15 @@ def dtw_align_batch(feats1, off1, n1, feats2, off2, n2):
     hs_bytes = lib.abn_dtw_host_stage_bytes(a(n1), a(n2), P)
     scratch = _DtwScratch.get(dev)
     ws, host_stage = scratch.buffers(ws_bytes, hs_bytes, dev)
-    _lib.check(lib.abn_dtw_batched(
+    # (the side stream's work is ordered inside the call, behind this stream's uploads and in front of its last launch:
+    # every buffer is used in this stream's order, nothing to record for the allocator)
+    side = scratch.side_stream(dev)
+    _lib.check(lib.abn_dtw_batched_overlap(
         _lib.ptr(feats1), feats1.shape[0], _lib.ptr(feats2), feats2.shape[0],
         a(off1), a(n1), a(off2), a(n2), P, feats1.shape[1], _lib.ptr(path1),
         _lib.ptr(path2), _lib.ptr(plen), stride, _lib.ptr(cost), _lib.ptr(ws), ws.numel(),
-        vp(host_stage.data_ptr()), host_stage.numel(), _lib.stream()), 'abn_dtw_batched')
+        vp(host_stage.data_ptr()), host_stage.numel(), _lib.stream(),
+        vp(side.cuda_stream if side is not None else 0)), 'abn_dtw_batched_overlap')
     scratch.mark()
     return DtwBatchResult(path1, path2, plen, cost)
 

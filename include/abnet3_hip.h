@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ABN_ABI_VERSION 18
+#define ABN_ABI_VERSION 19
 #define ABN_MAX_LAYERS 16
 
 enum { ABN_OK = 0, ABN_E_ARG = -1, ABN_E_LAUNCH = -2, ABN_E_WORKSPACE = -3,
@@ -452,6 +452,23 @@ int abn_dtw_batched(const float* feats1, int64_t rows1, const float* feats2,
                     int64_t path_stride, double* total_cost, void* ws,
                     int64_t ws_bytes, void* host_stage, int64_t host_stage_bytes,
                     void* stream);
+/* The same call with the traceback BESIDE the fill kernel instead of behind it (ABI v19): `side_stream` is a second
+ * stream of the caller's (same device; NULL or == stream: exactly abn_dtw_batched).  The fill kernel stores what the
+ * traceback reads of a pair write-through and flags the pair when it is complete; a traceback launch on `side_stream`
+ * polls the flags (bounded, asleep in between) and walks each pair as it completes, so that the ~0.2 ms a 10 000-pair
+ * traceback takes -- one pair's chain of dependent window fetches, a few per cent of the chip -- run under the fill's
+ * 2.7 ms; `stream` then waits for it and sweeps up whatever it left (normally nothing).  Same results, bit for bit.
+ * The library orders the two streams with two transient events (created, recorded, waited on and destroyed inside the
+ * call); on return both streams carry work of this call and `stream` alone is behind all of it: the caller
+ * synchronises with `stream` as before and need not look at `side_stream` again.  40-value frames (the gang kernel);
+ * every other frame width runs as abn_dtw_batched. */
+int abn_dtw_batched_overlap(const float* feats1, int64_t rows1, const float* feats2,
+                            int64_t rows2, const int64_t* off1_host, const int32_t* n1_host,
+                            const int64_t* off2_host, const int32_t* n2_host, int64_t npairs,
+                            int64_t D, int32_t* path1, int32_t* path2, int32_t* path_len,
+                            int64_t path_stride, double* total_cost, void* ws,
+                            int64_t ws_bytes, void* host_stage, int64_t host_stage_bytes,
+                            void* stream, void* side_stream);
 /* The distance matrix alone (utils.py:40-60), one pair, float64 [N, M] out.  The
  * reference computes in the precision of its inputs (utils.py:41-42: both float32 or
  * both float64): abn_cosine_distance is the float32 arithmetic of the hot path (the

@@ -545,3 +545,42 @@ def test_dtw_randomised_shapes_bit_exact(seed):
         assert np.array_equal(got[p][0], q1) and np.array_equal(got[p][1], q2), (p, D)
         assert cost[p] == O.dtw_cost(d), p
     assert dropped < P // 2
+
+
+def test_dtw_traceback_beside_the_fill_equals_one_stream(monkeypatch):
+    """abn_dtw_batched_overlap (the traceback on a second stream, polling the pairs' flags while the fill kernel runs)
+    against the same call on one stream: paths, lengths, costs and dropped pairs bit for bit; 40-value frames (the gang
+    kernel), token lengths 1..700, a NaN pair and an empty token among them, twice in a row on the same workspace and once
+    from a stream that is not the default one."""
+    from abnet3_amd import utils
+    rng = np.random.default_rng(77)
+    P = 1500
+    n1 = rng.integers(1, 700, P).astype(np.int32)
+    n2 = rng.integers(1, 700, P).astype(np.int32)
+    n1[5], n2[9] = 0, 0
+    o1 = np.concatenate(([0], np.cumsum(n1)[:-1])).astype(np.int64)
+    o2 = np.concatenate(([0], np.cumsum(n2)[:-1])).astype(np.int64)
+    f1 = rng.standard_normal((int(n1.sum()), 40)).astype(np.float32)
+    f2 = rng.standard_normal((int(n2.sum()), 40)).astype(np.float32)
+    f2[o2[17] + 3, 7] = np.nan                                  # pair 17 is dropped (utils.py:59)
+    d1, d2 = torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda()
+
+    def run():
+        r = utils.dtw_align_batch(d1, o1, n1, d2, o2, n2)
+        torch.cuda.synchronize()
+        return r.path1.cpu().numpy(), r.path2.cpu().numpy(), r.path_len.cpu().numpy(), r.total_cost.cpu().numpy()
+
+    monkeypatch.setenv('ABN_DTW_OVERLAP', '0')
+    a1, a2, al, ac = run()
+    assert al[5] == 0 and al[9] == 0 and al[17] == 0 and (al > 0).sum() == P - 3
+    monkeypatch.setenv('ABN_DTW_OVERLAP', '1')
+    st = a1.shape[1]
+    inside = np.arange(st)[None, :] >= (st - al)[:, None]
+    for _ in range(2):
+        b1, b2, bl, bc = run()
+        assert np.array_equal(al, bl) and np.array_equal(ac, bc)
+        assert np.array_equal(a1[inside], b1[inside]) and np.array_equal(a2[inside], b2[inside])
+    with torch.cuda.stream(torch.cuda.Stream()):
+        b1, b2, bl, bc = run()
+    assert np.array_equal(al, bl) and np.array_equal(ac, bc)
+    assert np.array_equal(a1[inside], b1[inside]) and np.array_equal(a2[inside], b2[inside])
