@@ -153,6 +153,7 @@ def reload_switches():
     load().abn_reload_switches()
 
 
+E_WORKSPACE = -3
 E_UNSUPPORTED = -4
 
 # abn_tower_path's answers (include/abnet3_hip.h)

@@ -750,33 +750,47 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                 dq[e] = (n > e ? aprev : acur)[e * BAND];
                 tq[e] = tops[e];
             }
+            // A round is INSIDE the matrix when every cell it sweeps exists: all 32 rows of the band are rows of token 1
+            // and the 63 columns the skewed block spans are columns of token 2.  Most rounds of most pairs are; when both
+            // halves' are, the step drops the cell's in-matrix test and the select that keeps the cost of a row's last cell.
+            const bool inside = active && i0 + BAND <= N && j0 >= BAND - 1 && j0 + BAND <= M;
+            auto sweep = [&](auto edge) {
 #ifdef ABN_EXP_NOSWEEP
-            for (int e = 0; e < 0; ++e) {
+                for (int e = 0; e < 0; ++e) {
 #else
 #pragma unroll
-            for (int e = 0; e < BAND; ++e) {
+                for (int e = 0; e < BAND; ++e) {
 #endif
-                const float dist = dq[e % PF];
-                const double topc = tq[e % PF];
-                if (e + PF < BAND) {
-                    dq[e % PF] = (n > e + PF ? aprev : acur)[(e + PF) * BAND];
-                    tq[e % PF] = tops[e + PF];
+                    const float dist = dq[e % PF];
+                    const double topc = tq[e % PF];
+                    if (e + PF < BAND) {
+                        dq[e % PF] = (n > e + PF ? aprev : acur)[(e + PF) * BAND];
+                        tq[e % PF] = tops[e + PF];
+                    }
+                    double up = dpp_shr1_f64(p1);
+                    up = n == 0 ? topc : up;
+                    double b1, best;
+                    min_lt(up, upprev, b1, bits);            // up < diag
+                    min_lt(p1, b1, best, bits);              // left < min(diag, up)
+                    const double cost = (double)dist + best;
+                    upprev = up;
+                    if constexpr (decltype(edge)::value) {
+                        const bool on = rowok && (uint32_t)(jb + e) < (uint32_t)M;
+                        p1 = on ? cost : p1;                 // past the row's end the last cost stays put
+                    } else {
+                        p1 = cost;
+                    }
+                    if (feed) __hip_atomic_store(&bout[e], cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((e & 15) == 15 && (!decltype(edge)::value || active)) {
+                        if (FLAGS && !ABN_GANG_RELEASE) __hip_atomic_store(&dptr[(e >> 4) * BAND], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else dptr[(e >> 4) * BAND] = bits;
+                    }
                 }
-                double up = dpp_shr1_f64(p1);
-                up = n == 0 ? topc : up;
-                double b1, best;
-                min_lt(up, upprev, b1, bits);            // up < diag
-                min_lt(p1, b1, best, bits);              // left < min(diag, up)
-                const double cost = (double)dist + best;
-                const bool on = rowok && (uint32_t)(jb + e) < (uint32_t)M;
-                upprev = up;
-                p1 = on ? cost : p1;                     // past the row's end the last cost stays put
-                if (feed) __hip_atomic_store(&bout[e], cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if ((e & 15) == 15 && active) {
-                    if (FLAGS && !ABN_GANG_RELEASE) __hip_atomic_store(&dptr[(e >> 4) * BAND], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else dptr[(e >> 4) * BAND] = bits;
-                }
-            }
+            };
+#ifndef ABN_EXP_NOINSIDE
+            if (__all(inside)) sweep(std::false_type{}); else
+#endif
+            sweep(std::true_type{});
             const bool fin = active && u + 1 == nrounds && band + 1 == nbands;      // the pair's last round
             if (fin && P.total_cost && n == ((N - 1) & 31)) {                        // lane (N-1) % 32 holds cost(N-1, M-1)
                 if (FLAGS) __hip_atomic_store(&P.total_cost[pair], p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -838,18 +852,25 @@ __device__ unsigned long long g_tb_stamps[4096][4];
 #endif
 template <int MODE>
 __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __restrict__ meta, const int32_t* __restrict__ order,
-                                                           int npairs, const uint32_t* dirs,
-                                                           const int32_t* bad, const int32_t* done,
-                                                           int32_t* __restrict__ path1, int32_t* __restrict__ path2,
+                                                           int npairs, int ntotal, const uint32_t* dirs,
+                                                           const int32_t* bad, int32_t* done,
+                                                           int32_t* path1, int32_t* path2,
                                                            int32_t* path_len, int64_t path_stride,
                                                            double* total_cost)
 {
     __shared__ uint32_t win[2 * TB_ROWS][64];            // [group offset * 8 + row offset][thread]: conflict-free
     const int lane = threadIdx.x;
-    if ((int)(blockIdx.x * 64 + lane) >= npairs) return;
-    // queue order (pairs of similar size side by side): the threads of a wavefront walk paths of
-    // similar length.  Empty pairs are not in the queue: their path_len was zeroed by the call.
-    const int p = order[blockIdx.x * 64 + lane];
+    const int idx = (int)(blockIdx.x * 64 + lane);
+    // queue order (pairs of similar size side by side): the threads of a wavefront walk paths of similar length.  Behind
+    // the npairs queued pairs the list holds the pairs with an empty token: nothing to walk, path_len = 0 (MODE 0 / 2: their
+    // grids span the whole list; every pair's path_len and total_cost are written by exactly one of the launches, no memset)
+    if (idx >= ntotal || (MODE == 1 && idx >= npairs)) return;
+    const int p = order[idx];
+    if (idx >= npairs) {
+        path_len[p] = 0;
+        if (total_cost) total_cost[p] = 0.0;
+        return;
+    }
 #ifdef ABN_TB_STAMPS
     if (MODE != 2 && lane == 0 && blockIdx.x < 4096) g_tb_stamps[blockIdx.x][MODE == 0 ? 1 : 0] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -862,23 +883,23 @@ __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __res
             if (__builtin_amdgcn_s_memrealtime() - t0 > ABN_TB_WAIT_TICKS) break;
             __builtin_amdgcn_s_sleep(127);
         }
-        if (!ok) return;
+        if (!ok) return;                              // left to the MODE 2 launch
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        // the walk is a chain of dependent steps on a SIMD it shares with the fill kernel's (older) wavefronts: without
-        // priority it gets the issue slots they leave and takes several times as long (a few hundred instructions per
-        // pair in all: nothing the fill kernel misses)
+        // the walk is a chain of dependent steps on a SIMD it shares with the fill kernel's (older) wavefronts
         __builtin_amdgcn_s_setprio(3);
 #ifdef ABN_TB_STAMPS
         if (lane == 0 && blockIdx.x < 4096) g_tb_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
-    if (MODE == 2 && path_len[p] != 0) return;          // (a dropped pair is looked at again: nothing to do but its flag)
+    if (MODE == 2 && done[p] == 2) return;            // MODE 1 has been here
     const PairMeta m = meta[p];
     const int N = m.n1, M = m.n2;
     const int isbad = MODE == 1 ? __hip_atomic_load(&bad[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bad[p];
-    if (isbad) {
+    if (isbad) {                                      // the pair is dropped
+        path_len[p] = 0;
         if (total_cost) total_cost[p] = 0.0;
-        return;                                       // path_len[p] stays 0: the pair is dropped
+        if (MODE == 1) done[p] = 2;
+        return;
     }
     const uint32_t* dp = dirs + m.dir_off;
     const int nsg = 2 * m.nrounds;
@@ -886,6 +907,9 @@ __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __res
     int32_t* o2 = path2 + (int64_t)p * path_stride + (path_stride - 1);
     int i = N - 1, j = M - 1, k = 0;
     o1[0] = i; o2[0] = j;
+    // (Round 6: a window's steps parked in LDS and stored only after the NEXT window's fetch has landed -- so that the
+    // fetch is not counted in behind the ~30 scattered stores in front of it -- made the launch slower, 263 against 216 us:
+    // the walk is a chain of ~40 dependent instructions per step, several of them lane-mask updates, not a wait for stores.)
     while (i > 0 || j > 0) {
         const int b = i >> 5, r = i & 31, g = (j + r) >> 4;
         const int rlo = max(r - (TB_ROWS - 1), 0);
@@ -911,14 +935,18 @@ __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __res
             const int rr = i & 31, s = j + rr;
             if ((i >> 5) != b || rr < rlo || (s >> 4) < g - 1) break;
             const uint32_t w = win[(g - (s >> 4)) * TB_ROWS + (rr - rlo)][lane];
-            const uint32_t c = w >> (30 - 2 * (s & 15));                  // the first of a dword's sixteen diagonals sits in its top bits
-            if (c & 1u) --j; else if (c & 2u) --i; else { --i; --j; }         // left < min(diag, up); else up < diag; else diag
+            const uint32_t c = (w >> (30 - 2 * (s & 15))) & 3u;           // the first of a dword's sixteen diagonals sits in its top bits
+            // left < min(diag, up): (0, -1); else up < diag: (-1, 0); else the diagonal: (-1, -1) -- as arithmetic, not as
+            // three lane-mask branches in the middle of a dependent chain
+            i -= (int)((c & 1u) ^ 1u);
+            j -= (int)(c != 2u);
             ++k;
             o1[-k] = i;                                                   // (16-byte stores of four cells at a time were tried: 302 against 232 us)
             o2[-k] = j;
         }
     }
     path_len[p] = k + 1;
+    if (MODE == 1) done[p] = 2;
 #ifdef ABN_TB_STAMPS
     if (MODE != 2 && blockIdx.x < 4096) { atomicMax(&g_tb_stamps[blockIdx.x][2], (unsigned long long)__builtin_amdgcn_s_memrealtime()); g_tb_stamps[blockIdx.x][3] = k; }
 #endif
@@ -985,17 +1013,10 @@ struct WsPlan {
 using namespace abn;
 
 // Workspace: [PairMeta x P][order x P][bad x P][done x P][queue counter][back-pointers][boundary rows][norm strips]
-static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P)
+// dwords: the pairs' back-pointer words; mmax: the longest token 2 (>= 1)
+static WsPlan plan_ws_of(int64_t dwords, int64_t mmax, int64_t P)
 {
     WsPlan w;
-    int64_t dwords = 0, mmax = 1;
-    for (int64_t p = 0; p < P; ++p) {
-        const int64_t a = n1[p] > 0 ? n1[p] : 0, b = n2[p] > 0 ? n2[p] : 0;
-        if (a > 0 && b > 0) {
-            dwords += ((a + BAND - 1) / BAND) * 2 * ((b + 2 * BAND - 1) / BAND) * BAND;
-            mmax = b > mmax ? b : mmax;
-        }
-    }
     // a boundary row: the longest token 2 rounded up, 32 doubles of slack in front (the gang kernel's
     // last lane writes columns -31 .. -1 of a band's first round there) and 32 behind
     w.mcap = align_up(mmax, 32) + 64;
@@ -1022,6 +1043,19 @@ static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P)
     return w;
 }
 
+static WsPlan plan_ws(const int32_t* n1, const int32_t* n2, int64_t P)
+{
+    int64_t dwords = 0, mmax = 1;
+    for (int64_t p = 0; p < P; ++p) {
+        const int64_t a = n1[p] > 0 ? n1[p] : 0, b = n2[p] > 0 ? n2[p] : 0;
+        if (a > 0 && b > 0) {
+            dwords += ((a + BAND - 1) / BAND) * 2 * ((b + 2 * BAND - 1) / BAND) * BAND;
+            mmax = b > mmax ? b : mmax;
+        }
+    }
+    return plan_ws_of(dwords, mmax, P);
+}
+
 extern "C" int64_t abn_dtw_ws_bytes(const int32_t* n1_host, const int32_t* n2_host, int64_t npairs,
                                          int64_t rows1, int64_t rows2)
 {
@@ -1033,6 +1067,20 @@ extern "C" int64_t abn_dtw_host_stage_bytes(const int32_t* n1_host, const int32_
 {
     if (!n1_host || !n2_host || npairs < 0) return -1;
     return align_up(npairs * (int64_t)sizeof(PairMeta), 256) + align_up(npairs * 4, 256);
+}
+
+// the two events abn_dtw_batched_overlap orders its streams with: one pair per host thread and device, made at first use
+static bool stream_order_events(hipEvent_t* a, hipEvent_t* b)
+{
+    struct Pair { hipEvent_t e[2] = {nullptr, nullptr}; };
+    static thread_local Pair cache[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    Pair& c = cache[dev];
+    for (int i = 0; i < 2; ++i)
+        if (!c.e[i] && hipEventCreateWithFlags(&c.e[i], hipEventDisableTiming) != hipSuccess) { c.e[i] = nullptr; return false; }
+    *a = c.e[0]; *b = c.e[1];
+    return true;
 }
 
 static void launch_gang(bool flags, int64_t ng, hipStream_t st, const DtwP& P)
@@ -1060,8 +1108,17 @@ static int dtw_batched_impl(const float* feats1, int64_t rows1, const float* fea
     char* base = (char*)ws;
     PairMeta* hm = (PairMeta*)host_stage;
     int32_t* hord = (int32_t*)((char*)host_stage + meta_bytes);
-    // one pass over the pairs: validation, the pairs' metadata, the longest path
-    int64_t maxlen = 0, dwords = 0;
+    // ONE pass over the pairs: validation, the pairs' metadata, the longest path, the longest token 2, and the histogram
+    // of the work queue's counting sort (largest pairs first -- the short ones fill the tail --, empty pairs never queued;
+    // the key is the number of rounds a pair needs, clamped: the order among giants is free)
+    constexpr int NB = 4096;
+    static thread_local std::vector<int32_t> count;
+    count.assign(NB + 1, 0);
+    auto bucket = [&](int64_t p) {
+        const int64_t work = (int64_t)hm[p].nbands * hm[p].nrounds;
+        return (int)(NB - 1 - (work < NB ? work : NB - 1));                           // descending
+    };
+    int64_t maxlen = 0, dwords = 0, mmax = 1;
     for (int64_t p = 0; p < npairs; ++p) {
         const int64_t a = n1_host[p], b = n2_host[p];
         ABN_REQUIRE(a >= 0 && b >= 0, "dtw: negative token length at pair %lld", (long long)p);
@@ -1073,45 +1130,39 @@ static int dtw_batched_impl(const float* feats1, int64_t rows1, const float* fea
         hm[p].dir_off = dwords;
         hm[p].nbands = (int32_t)((a + BAND - 1) / BAND);
         hm[p].nrounds = (int32_t)((b + 2 * BAND - 1) / BAND);
-        if (a > 0 && b > 0) dwords += (int64_t)hm[p].nbands * 2 * hm[p].nrounds * BAND;
+        if (a > 0 && b > 0) {
+            dwords += (int64_t)hm[p].nbands * 2 * hm[p].nrounds * BAND;
+            mmax = b > mmax ? b : mmax;
+            ++count[bucket(p) + 1];
+        }
     }
     ABN_REQUIRE(path_stride >= maxlen, "dtw: path_stride %lld < longest possible path %lld", (long long)path_stride,
                 (long long)maxlen);
     ABN_REQUIRE(rows1 * D < (1LL << 62) && rows2 * D < (1LL << 62), "dtw: feature array too large");
-    const WsPlan w = plan_ws(n1_host, n2_host, npairs);
+    const WsPlan w = plan_ws_of(dwords, mmax, npairs);
     if (ws_bytes < w.total) { set_error("dtw: workspace too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)w.total); return ABN_E_WORKSPACE; }
-    // Work queue: largest pairs first (the short ones fill the tail), empty pairs never queued.
-    // A counting sort over the number of rounds a pair needs (clamped: the order among giants is free).
     int64_t nq = 0;
     {
-        constexpr int NB = 4096;
-        static thread_local std::vector<int32_t> count;
-        count.assign(NB + 1, 0);
-        auto bucket = [&](int64_t p) {
-            const int64_t work = (int64_t)hm[p].nbands * hm[p].nrounds;
-            return (int)(NB - 1 - (work < NB ? work : NB - 1));                           // descending
-        };
-        for (int64_t p = 0; p < npairs; ++p)
-            if (n1_host[p] > 0 && n2_host[p] > 0) ++count[bucket(p) + 1];
         for (int b = 0; b < NB; ++b) count[b + 1] += count[b];
         nq = count[NB];
         for (int64_t p = 0; p < npairs; ++p)
             if (n1_host[p] > 0 && n2_host[p] > 0) hord[count[bucket(p)]++] = (int32_t)p;
     }
-    if (hipMemcpyAsync(base + w.meta_off, hm, npairs * sizeof(PairMeta), hipMemcpyHostToDevice, st) != hipSuccess ||
-        (nq > 0 && hipMemcpyAsync(base + w.order_off, hord, nq * 4, hipMemcpyHostToDevice, st) != hipSuccess) ||
+    // behind the queue: the pairs with an empty token (the traceback launches give them path_len = 0)
+    if (nq < npairs) {
+        int64_t ne = nq;
+        for (int64_t p = 0; p < npairs && ne < npairs; ++p)
+            if (!(n1_host[p] > 0 && n2_host[p] > 0)) hord[ne++] = (int32_t)p;
+    }
+    // metadata and queue in ONE copy (host_stage and the workspace lay them out alike), one memset for flags + counter
+    if (w.order_off != meta_bytes ||
+        hipMemcpyAsync(base + w.meta_off, hm, (size_t)(meta_bytes + npairs * 4), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemsetAsync(base + w.bad_off, 0, (size_t)(w.counter_off + 256 - w.bad_off), st) != hipSuccess) {
         set_error("dtw: metadata upload failed");
         return ABN_E_LAUNCH;
     }
-    // dropped and empty pairs keep path_len = 0, total_cost = 0
-    if (hipMemsetAsync(path_len, 0, (size_t)npairs * 4, st) != hipSuccess ||
-        (total_cost && hipMemsetAsync(total_cost, 0, (size_t)npairs * 8, st) != hipSuccess)) {
-        set_error("dtw: clearing the outputs failed");
-        return ABN_E_LAUNCH;
-    }
     const PairMeta* dm = (const PairMeta*)(base + w.meta_off);
-    if (nq > 0) {
+    {
         DtwP P = {};
         P.feats1 = feats1; P.feats2 = feats2;
         P.meta = dm;
@@ -1132,31 +1183,26 @@ static int dtw_batched_impl(const float* feats1, int64_t rows1, const float* fea
         const bool pipelined = switches().dtw_f40;     // A/B switch of the 40-d specialisation
         const bool gang = switches().dtw_pc;            // A/B switch: gang form (a producer per slot + one consumer)
         const int32_t* qorder = (const int32_t*)(base + w.order_off);
-        const unsigned tb_grid = (unsigned)((nq + 63) / 64);
-        if (vec && D == KCH && gang) {
+        const unsigned tb_grid = (unsigned)((nq + 63) / 64), tb_grid_all = (unsigned)((npairs + 63) / 64);
+        if (nq == 0) {}
+        else if (vec && D == KCH && gang) {
             const int64_t ng = nwg < 256 * switches().dtw_wgs_per_cu ? nwg : 256 * switches().dtw_wgs_per_cu;
             if (side && side != st) {
-                // The traceback beside the fill: the second stream's launch starts once the uploads and memsets above
+                // The traceback beside the fill: the second stream's launch starts once the upload and the memset above
                 // are done, polls the pairs' flags and walks each pair as it completes; this stream then waits for it
-                // and sweeps up whatever it left.  Two transient events order the streams; nothing outlives the call.
+                // and sweeps up whatever it left.  Two events order the streams (kept per thread and device between calls:
+                // creating and destroying a pair per call cost 8 us of the call's ~80 on the host).
                 hipEvent_t ready = nullptr, traced = nullptr;
-                if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&traced, hipEventDisableTiming) != hipSuccess) {
-                    if (ready) (void)hipEventDestroy(ready);
-                    set_error("dtw: hipEventCreate failed");
-                    return ABN_E_LAUNCH;
-                }
+                if (!stream_order_events(&ready, &traced)) { set_error("dtw: hipEventCreate failed"); return ABN_E_LAUNCH; }
                 bool ok = hipEventRecord(ready, st) == hipSuccess && hipStreamWaitEvent(side, ready, 0) == hipSuccess;
                 if (ok) {
                     launch_gang(true, ng, st, P);
-                    hipLaunchKernelGGL(dtw_traceback_kernel<1>, dim3(tb_grid), dim3(64), 0, side, dm, qorder, (int)nq, P.dirs, P.bad,
+                    hipLaunchKernelGGL(dtw_traceback_kernel<1>, dim3(tb_grid), dim3(64), 0, side, dm, qorder, (int)nq, (int)npairs, P.dirs, P.bad,
                                        P.done, path1, path2, path_len, path_stride, total_cost);
                     ok = hipEventRecord(traced, side) == hipSuccess && hipStreamWaitEvent(st, traced, 0) == hipSuccess;
-                    hipLaunchKernelGGL(dtw_traceback_kernel<2>, dim3(tb_grid), dim3(64), 0, st, dm, qorder, (int)nq, P.dirs, P.bad,
+                    hipLaunchKernelGGL(dtw_traceback_kernel<2>, dim3(tb_grid_all), dim3(64), 0, st, dm, qorder, (int)nq, (int)npairs, P.dirs, P.bad,
                                        P.done, path1, path2, path_len, path_stride, total_cost);
                 }
-                (void)hipEventDestroy(ready);
-                (void)hipEventDestroy(traced);
                 if (!ok) { set_error("dtw: ordering the two streams failed"); return ABN_E_LAUNCH; }
                 ABN_CHECK_LAUNCH("dtw");
                 return ABN_OK;
@@ -1166,7 +1212,7 @@ static int dtw_batched_impl(const float* feats1, int64_t rows1, const float* fea
         else if (vec && D == KCH && pipelined) hipLaunchKernelGGL((dtw_fused_kernel<true, true>), dim3((unsigned)nwg), dim3(64), 0, st, P);
         else if (vec) hipLaunchKernelGGL((dtw_fused_kernel<true, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);
         else hipLaunchKernelGGL((dtw_fused_kernel<false, false>), dim3((unsigned)nwg), dim3(64), 0, st, P);
-        hipLaunchKernelGGL(dtw_traceback_kernel<0>, dim3(tb_grid), dim3(64), 0, st, dm, qorder, (int)nq, P.dirs, P.bad,
+        hipLaunchKernelGGL(dtw_traceback_kernel<0>, dim3(tb_grid_all), dim3(64), 0, st, dm, qorder, (int)nq, (int)npairs, P.dirs, P.bad,
                            P.done, path1, path2, path_len, path_stride, total_cost);
     }
     ABN_CHECK_LAUNCH("dtw");

@@ -267,7 +267,7 @@ def dtw_align_batch(feats1, off1, n1, feats2, off2, n2):
     n2 = np.ascontiguousarray(n2, dtype=np.int32)
     P = len(n1)
     dev = feats1.device
-    stride = int(max(1, (n1.astype(np.int64) + n2).max() - 1)) if P else 1
+    stride = max(1, int(np.add(n1, n2, dtype=np.int64).max()) - 1) if P else 1
     path1 = torch.empty(P, stride, dtype=torch.int32, device=dev)
     path2 = torch.empty(P, stride, dtype=torch.int32, device=dev)
     if P == 0:
@@ -276,19 +276,26 @@ def dtw_align_batch(feats1, off1, n1, feats2, off2, n2):
     cost = torch.empty(P, dtype=torch.float64, device=dev)
     vp = ctypes.c_void_p
     a = lambda arr: arr.ctypes.data_as(vp)
-    ws_bytes = lib.abn_dtw_ws_bytes(a(n1), a(n2), P, feats1.shape[0], feats2.shape[0])
     hs_bytes = lib.abn_dtw_host_stage_bytes(a(n1), a(n2), P)
     scratch = _DtwScratch.get(dev)
-    ws, host_stage = scratch.buffers(ws_bytes, hs_bytes, dev)
+    # the call sizes its workspace in the pass over the pairs it makes anyway and says so when the cached one is too
+    # small: only then is abn_dtw_ws_bytes asked (a pass of its own) and the workspace grown
+    ws, host_stage = scratch.buffers(scratch.ws.numel() if scratch.ws is not None else
+                                     lib.abn_dtw_ws_bytes(a(n1), a(n2), P, feats1.shape[0], feats2.shape[0]), hs_bytes, dev)
     # (the side stream's work is ordered inside the call, behind this stream's uploads and in front of its last launch:
     # every buffer is used in this stream's order, nothing to record for the allocator)
     side = scratch.side_stream(dev)
-    _lib.check(lib.abn_dtw_batched_overlap(
-        _lib.ptr(feats1), feats1.shape[0], _lib.ptr(feats2), feats2.shape[0],
-        a(off1), a(n1), a(off2), a(n2), P, feats1.shape[1], _lib.ptr(path1),
-        _lib.ptr(path2), _lib.ptr(plen), stride, _lib.ptr(cost), _lib.ptr(ws), ws.numel(),
-        vp(host_stage.data_ptr()), host_stage.numel(), _lib.stream(),
-        vp(side.cuda_stream if side is not None else 0)), 'abn_dtw_batched_overlap')
+    for attempt in (0, 1):
+        rc = lib.abn_dtw_batched_overlap(
+            _lib.ptr(feats1), feats1.shape[0], _lib.ptr(feats2), feats2.shape[0],
+            a(off1), a(n1), a(off2), a(n2), P, feats1.shape[1], _lib.ptr(path1),
+            _lib.ptr(path2), _lib.ptr(plen), stride, _lib.ptr(cost), _lib.ptr(ws), ws.numel(),
+            vp(host_stage.data_ptr()), host_stage.numel(), _lib.stream(),
+            vp(side.cuda_stream if side is not None else 0))
+        if rc != _lib.E_WORKSPACE or attempt:
+            break
+        ws, host_stage = scratch.buffers(lib.abn_dtw_ws_bytes(a(n1), a(n2), P, feats1.shape[0], feats2.shape[0]), hs_bytes, dev)
+    _lib.check(rc, 'abn_dtw_batched_overlap')
     scratch.mark()
     return DtwBatchResult(path1, path2, plen, cost)
 

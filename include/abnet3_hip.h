@@ -438,7 +438,8 @@ int abn_optimizer_step(int kind, float* params, const float* grads, float* state
  * NULL.  Tokens of any length.  path_stride >= max(n1 + n2 - 1).
  * One fused kernel per call (distances on the fp32 matrix cores, the reference's division /
  * acosf / pi per cell, float64 dynamic programme, 2-bit back-pointers) plus a traceback
- * kernel, all on `stream`: no library-owned streams, events or other global state.  The cost
+ * kernel, all on `stream`: no library-owned streams, events or other global state.  path_len and total_cost need no
+ * clearing by the caller: every pair's entries are written by one of the call's launches.  The cost
  * matrix is never materialised: the workspace holds ~0.26 B per cell (back-pointers) plus
  * per-workgroup boundary rows.  rows1 / rows2 bound the offsets (checked). */
 int64_t abn_dtw_ws_bytes(const int32_t* n1_host, const int32_t* n2_host,
@@ -458,8 +459,9 @@ int abn_dtw_batched(const float* feats1, int64_t rows1, const float* feats2,
  * polls the flags (bounded, asleep in between) and walks each pair as it completes, so that the ~0.2 ms a 10 000-pair
  * traceback takes -- one pair's chain of dependent window fetches, a few per cent of the chip -- run under the fill's
  * 2.7 ms; `stream` then waits for it and sweeps up whatever it left (normally nothing).  Same results, bit for bit.
- * The library orders the two streams with two transient events (created, recorded, waited on and destroyed inside the
- * call); on return both streams carry work of this call and `stream` alone is behind all of it: the caller
+ * The library orders the two streams with two events it keeps per host thread and device (made at the first call, the
+ * only state this entry point adds to the process); on return both streams carry work of this call and `stream` alone is
+ * behind all of it: the caller
  * synchronises with `stream` as before and need not look at `side_stream` again.  40-value frames (the gang kernel);
  * every other frame width runs as abn_dtw_batched. */
 int abn_dtw_batched_overlap(const float* feats1, int64_t rows1, const float* feats2,
