@@ -303,9 +303,15 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, ReduceTable 
 // gradient is written once (p.grad stays valid) and never read back.  Parameters, gradients and
 // optimizer state share ONE flat layout: element j of layer l's dW lives at float offset
 // (t.dW[l] - grads) + j of all four buffers.
+// fail_word: the failure word of the resident BatchNorm tower's sync buffer (or null).  Set, the launches in front of this
+// one gave up on a hand-over and their gradients are garbage: the step is DROPPED -- parameters, optimizer state and the
+// gradient buffer stay as they are -- instead of carrying NaN into every parameter (the caller finds the word set, zeroes
+// the buffer and goes on with the layer launches: INTEGRATION.md, "when the resident tower gives up").
 __global__ void slab_reduce_step_kernel(const float* __restrict__ slabs, ReduceTable t, OptP o, float* __restrict__ params,
-                                        float* __restrict__ grads, float* __restrict__ s1, float* __restrict__ s2)
+                                        float* __restrict__ grads, float* __restrict__ s1, float* __restrict__ s2,
+                                        const unsigned* __restrict__ fail_word)
 {
+    if (fail_word && *fail_word != 0u) return;
     const int64_t n4 = (t.total + 3) / 4;
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4;
          q += (int64_t)gridDim.x * blockDim.x) {
@@ -2316,7 +2322,7 @@ int abn_tower_reduce_step(const abn_tower_desc* t, int64_t rows, const float* sc
     }
     hipLaunchKernelGGL(slab_reduce_step_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        scratch + B.slabs, rt, make_optp(kind, lr, hp0, hp1, eps, step, grad_scale), params, grads, state1,
-                       state2);
+                       state2, t->batch_norm && t->sync_ws ? reinterpret_cast<const unsigned*>(t->sync_ws) + 16 : nullptr);
     ABN_CHECK_LAUNCH("tower_reduce_step");
     return ABN_OK;
 }

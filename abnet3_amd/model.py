@@ -161,11 +161,31 @@ class _Segment(object):
                 d.wpack = self._wpack.data_ptr()
         # the resident BatchNorm tower's sync buffer (abn_tower_desc.sync_ws): zero once, the library's from then on
         self._sync_ws = None
-        if self.batch_norm and net._flat.is_cuda and os.environ.get('ABN_BN_SYNC_WS') != '0':
+        if self.batch_norm and net._flat.is_cuda and os.environ.get('ABN_BN_SYNC_WS') != '0' and not getattr(self, '_sync_disabled', False):
             self._sync_ws = torch.zeros(_lib.load().abn_tower_sync_ws_bytes() // 4, dtype=torch.int32, device=net._flat.device)
             d.sync_ws = self._sync_ws.data_ptr()
         self._desc_cache = (key, d, grad_slots)
         return d
+
+    # -- the resident BatchNorm tower's failure word (csrc/tower_bn_persist.h): a hand-over that is not met within its bounded
+    # spin -- part of the grid was not on the chip: another process, stream or resident kernel held CUs -- sets word 16 of
+    # the sync buffer, the launches drain with NaN outputs and the optimizer's launch drops the step (parameters untouched).
+    # The word is sticky by design; whoever owns the buffer looks at it, clears it and takes the tower off the resident path.
+    def sync_fail_word(self):
+        """1-element int32 view of the failure word, or None (no sync buffer lent)."""
+        ws = getattr(self, '_sync_ws', None)
+        return None if ws is None else ws[16:17]
+
+    def recover_sync(self):
+        """Clears the sync buffer and keeps this tower on the layer launches (ABN_PATH_BN_LAYERS) from now on."""
+        ws = getattr(self, '_sync_ws', None)
+        if ws is None:
+            return
+        ws.zero_()
+        self._sync_disabled = True
+        cached = getattr(self, '_desc_cache', None)
+        if cached is not None:
+            cached[1].sync_ws = None
 
     def _weights_key(self):
         net = self.net
@@ -658,6 +678,30 @@ class _HipNetwork(NetworkBuilder):
         else:
             flat.zero_()
         return [flat[off:off + rows * w].view(rows, w) for off, w in zip(offs, widths)]
+
+    def resident_tower_failed(self):
+        """Did a resident BatchNorm tower launch of this network give up since the last look?  ONE device-to-host read (it
+        synchronises with the stream): callers look where they synchronise anyway -- the end of a pass -- or every few
+        hundred steps.  A tower that did is cleared and kept on the layer launches from here on (a warning says so once);
+        the steps it dropped changed no parameter (the optimizer's launch skips them).  Returns the number of towers hit."""
+        words = [(seg, seg.sync_fail_word()) for seg in self._segment_list()]
+        words = [(seg, w) for seg, w in words if w is not None and not getattr(seg, '_sync_disabled', False)]
+        if not words:
+            return 0
+        got = torch.cat([w for _, w in words]).cpu()
+        hit = 0
+        for (seg, _), v in zip(words, got.tolist()):
+            if v != 0:
+                seg.recover_sync()
+                hit += 1
+        if hit:
+            import warnings
+            warnings.warn('abnet3_amd: a resident BatchNorm tower launch gave up on a hand-over between workgroups (the '
+                          'GPU is shared with another process, stream or resident kernel?).  The steps since were dropped '
+                          '-- no parameter changed, their losses are not numbers --; the sync buffer is cleared and this '
+                          'network trains on one launch per layer from here on (ABN_BN_PERSIST=0 does so from the start).',
+                          RuntimeWarning, stacklevel=2)
+        return hit
 
     def weights_changed_behind_torch(self):
         """Called by whoever rewrites the parameters without torch noticing (abn_optimizer_step, a replayed

@@ -821,6 +821,13 @@ class TrainerSiamese(TrainerBuilder):
             it = parallel.shard_batches(it, self.rank, self.world_size, drop_tail=train_mode)
         return it
 
+    RESIDENT_CHECK_EVERY = 256      # eager steps between two looks at the resident BatchNorm towers' failure words
+
+    def _forget_captured_steps(self):
+        """Captured steps hold the addresses a tower's descriptor had when they were captured (its sync buffer among them)."""
+        for name in ('_graphs', '_shape_seen', '_buckets', '_bucket_pool', '_loss_acc', '_loss_ws'):
+            self.__dict__.pop(name, None)
+
     def optimize_model(self, do_training=True):
         """Optimization model step for the Siamese network
         (abnet3/trainer.py:226-256)."""
@@ -835,16 +842,42 @@ class TrainerSiamese(TrainerBuilder):
             t_pass = time.perf_counter()
         self.network.train()
         plan = self._planned(True)
+        # A resident BatchNorm tower launch that gives up (the GPU shared with another process: csrc/tower_bn_persist.h)
+        # drops its step -- the optimizer's launch leaves the parameters alone -- and reports a loss that is not a number.
+        # The eager loop therefore sums the losses in chunks of RESIDENT_CHECK_EVERY steps and looks at the towers' failure
+        # words between chunks (one device-to-host read): a chunk with a dropped step is left out of the pass's mean, the
+        # tower is cleared and trains on the layer launches from then on (SiameseNetwork.resident_tower_failed warns once).
+        watch = do_training and hasattr(self.network, 'resident_tower_failed') and any(
+            seg.sync_fail_word() is not None for seg in self.network._segment_list())
         if plan is not None:
             num_batches_train = self._run_planned(plan, do_training, train_loss)
+            if watch and self.network.resident_tower_failed():
+                self._forget_captured_steps()        # (they hold the sync buffer's address; this pass's training loss is NaN)
         else:
+            chunk_loss, chunk_n = (torch.zeros_like(train_loss), 0) if watch else (train_loss, 0)
             for minibatch in self._batches(True):
                 # fp64 accumulator += fp32 loss in ONE launch (add_ promotes the operand)
                 if do_training:
-                    train_loss.add_(self.train_step_auto(minibatch))
+                    chunk_loss.add_(self.train_step_auto(minibatch))
                 else:
-                    train_loss.add_(self.train_step(minibatch, False))
-                num_batches_train += 1
+                    chunk_loss.add_(self.train_step(minibatch, False))
+                chunk_n += 1
+                if watch and chunk_n == self.RESIDENT_CHECK_EVERY:
+                    if self.network.resident_tower_failed():
+                        self._forget_captured_steps()
+                    else:
+                        train_loss.add_(chunk_loss)
+                        num_batches_train += chunk_n
+                    chunk_loss.zero_()
+                    chunk_n = 0
+            if watch:
+                if self.network.resident_tower_failed():
+                    self._forget_captured_steps()
+                else:
+                    train_loss.add_(chunk_loss)
+                    num_batches_train += chunk_n
+            else:
+                num_batches_train = chunk_n
 
         if timed:
             torch.cuda.synchronize()

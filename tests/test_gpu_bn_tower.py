@@ -58,7 +58,7 @@ TOWER_SHAPES = [  # (input, hidden layers, hidden, output, B): >= 8 workgroups o
 @pytest.mark.parametrize('p_drop', [0.0, 0.25])
 @pytest.mark.parametrize('act', ['sigmoid', 'tanh', 'relu'])
 @pytest.mark.parametrize('shape', TOWER_SHAPES)
-def test_resident_tower_against_the_oracle(shape, act, p_drop, split):
+def test_resident_tower_against_the_oracle(shape, act, p_drop, split, monkeypatch):
     """Embeddings, loss, running statistics, num_batches_tracked and every gradient against the numpy oracle, with shared
     dropout masks (mask tensors)."""
     import abnet3_amd.loss as L
@@ -88,24 +88,41 @@ def test_resident_tower_against_the_oracle(shape, act, p_drop, split):
     lv = L.coscos2(avg=False)(e1, e2, dev(y))
     lv.backward()
     assert _lib.last_backward_path() == _lib.PATH_BN_TOWER
-    o1, c1 = O.tower_forward(p, x1, spec, True, masks=[m[:B] for m in masks] if masks else None)
-    o2, c2 = O.tower_forward(p, x2, spec, True, masks=[m[B:] for m in masks] if masks else None)
-    ol, d1, d2, _ = O.pair_loss(o1, o2, y, 'coscos2', 0.5, False)
-    og = {}
-    O.tower_backward(p, c1, d1, spec, og)
-    O.tower_backward(p, c2, d2, spec, og)
-    assert np.isfinite(e1.detach().cpu().numpy()).all()
-    assert rel_err(e1.detach().cpu().numpy(), o1) < 2e-5
-    assert rel_err(e2.detach().cpu().numpy(), o2) < 2e-5
-    assert abs(float(lv.detach()) - ol) <= 1e-4 * abs(ol) + 1e-6
+    # The yardstick is the oracle's statements evaluated in FLOAT64 (its working dtype is one module attribute): north_star's
+    # 1e-5 on embeddings and loss, 2e-5 on the gradients.  The oracle's own float32 evaluation is judged beside it -- where
+    # float32 itself sits further from float64 than the bar (BatchNorm divides by a batch's standard deviation: a tower
+    # whose columns nearly cancel amplifies every rounding) the kernels get what float32 needs there, and no more.
+    def evaluate(dtype):
+        monkeypatch.setattr(O, 'F32', dtype)
+        pp = {k: v.astype(dtype) if v.dtype.kind == 'f' else v.copy() for k, v in p0.items()}
+        mk = [m.astype(dtype) for m in masks] if masks else None
+        o1, c1 = O.tower_forward(pp, x1.astype(dtype), spec, True, masks=[m[:B] for m in mk] if mk else None)
+        o2, c2 = O.tower_forward(pp, x2.astype(dtype), spec, True, masks=[m[B:] for m in mk] if mk else None)
+        ol, d1, d2, _ = O.pair_loss(o1, o2, y, 'coscos2', 0.5, False)
+        og = {}
+        O.tower_backward(pp, c1, d1.astype(dtype), spec, og)
+        O.tower_backward(pp, c2, d2.astype(dtype), spec, og)
+        return o1, o2, ol, og, pp
+    p0 = p
+    t1, t2, tl, tg, tp = evaluate(np.float64)                 # the truth
+    o1, o2, ol, og, op = evaluate(np.float32)                 # the oracle as the other tests use it
+    g1, g2 = e1.detach().cpu().numpy(), e2.detach().cpu().numpy()
+    assert np.isfinite(g1).all()
+    f32_emb = max(rel_err(o1, t1), rel_err(o2, t2))
+    assert max(rel_err(g1, t1), rel_err(g2, t2)) < max(1e-5, 2 * f32_emb), (rel_err(g1, t1), rel_err(g2, t2), f32_emb)
+    f32_loss = abs(ol - tl) / abs(tl)
+    assert abs(float(lv.detach()) - tl) <= max(1e-5, 2 * f32_loss) * abs(tl) + 1e-9, (float(lv.detach()), tl, f32_loss)
     sd = net.state_dict()
-    for k in p:                     # the oracle updated its running statistics in place, once per call
+    for k in p0:                    # the oracle updated its running statistics in place, once per call
         if 'running' in k:
-            assert rel_err(sd[k].cpu().numpy(), p[k]) < 1e-5, k
+            assert rel_err(sd[k].cpu().numpy(), tp[k]) < 1e-5, k
         if 'num_batches' in k:
-            assert int(sd[k]) == int(p[k]) == 2, k
+            assert int(sd[k]) == int(tp[k]) == 2, k
     grads = {k: q.grad.cpu().numpy() for k, q in net.named_parameters()}
-    check_grads(grads, og, spec.param_keys(), not p_drop, tol=2e-4)
+    keys = [k for k in spec.param_keys() if not is_pre_bn_bias(k, not p_drop)]
+    gmax = max(np.abs(tg[k]).max() for k in spec.param_keys())
+    f32_grad = max(rel_err(og[k], tg[k], floor=1e-2 * gmax) for k in keys)
+    check_grads(grads, tg, spec.param_keys(), not p_drop, tol=max(2e-5, 2 * f32_grad))
 
 
 def _step(net, x1, x2, y, how, lname='coscos2', avg=False, need_dx=False, n_valid=None):
@@ -269,3 +286,50 @@ def test_resident_tower_steps_like_the_layer_launches(monkeypatch, split):
             assert float((s0[k] - s1[k]).abs().max()) <= 1e-5, k
         else:
             assert float((s0[k] - s1[k]).abs().max()) <= 1e-4 * max(float(s1[k].abs().max()), 1e-3), k
+
+
+def test_a_tower_that_gives_up_drops_the_step_and_recovers(split):
+    """The failure word of the sync buffer set by hand -- what a hand-over that is not met in time leaves behind (the grid was
+    not all on the chip; a real give-up also turns the launch's outputs into NaN, which a test on an idle GPU cannot bring
+    about): NO parameter, optimizer state or BatchNorm weight moves in the step that follows (the optimizer's launch drops it),
+    SiameseNetwork.resident_tower_failed() reports and clears the word with a warning, and the next steps run on the layer
+    launches with the numbers an untouched twin of the network gets there."""
+    import warnings
+    from abnet3_amd import _lib
+    from abnet3_amd.loss import coscos2
+    from abnet3_amd.trainer import TrainerSiamese
+    kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=500, output_dim=100, activation_layer='sigmoid', p_dropout=0.0, batch_norm=True)
+    rng = np.random.default_rng(5)
+    B = 512
+    x1, x2 = dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32))
+    y = dev(rng.choice([1, -1], B))
+
+    def trainer(net):
+        return TrainerSiamese(network=net, loss=coscos2(avg=False), optimizer_type='adadelta', lr=0.1, dataloader=None,
+                              log_dir='/tmp/abnet3_bn_recover')
+    net = build(kw, seed=9, precision=split)
+    tr = trainer(net)
+    net.train()
+    l0 = float(tr.train_step((x1, x2, y), True))
+    assert np.isfinite(l0) and _lib.last_forward_path() == _lib.PATH_BN_TOWER and net.resident_tower_failed() == 0
+    before = {k: v.clone() for k, v in net.state_dict().items() if 'running' not in k and 'tracked' not in k}
+    for seg in net._segment_list():
+        seg.sync_fail_word().fill_(1)
+    tr.train_step((x1, x2, y), True)
+    for k, v in before.items():
+        assert torch.equal(net.state_dict()[k], v), k
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert net.resident_tower_failed() == 1
+    assert any('resident BatchNorm tower' in str(m.message) for m in w)
+    assert net.resident_tower_failed() == 0                       # cleared, and off the resident path
+    # a twin that took steps 0 and 2 on the layer launches from the start (the dropped step changed nothing but the
+    # running statistics of the layers it got through: compare what the optimizer owns)
+    l2 = float(tr.train_step((x1, x2, y), True))
+    assert _lib.last_forward_path() == _lib.PATH_BN_LAYERS and np.isfinite(l2)
+    twin = build(kw, seed=9, precision=split)
+    tw = trainer(twin)
+    twin.train()
+    m0 = float(tw.train_step((x1, x2, y), True))
+    m2 = float(tw.train_step((x1, x2, y), True))
+    assert abs(m0 - l0) <= 1e-5 * abs(m0) and abs(m2 - l2) <= 2e-5 * abs(m2), (l0, m0, l2, m2)

@@ -246,6 +246,9 @@ def test_c2_five_adadelta_steps(bn):
         opt.zero_grad()
         lv.backward()
         if s == 0:
+            from abnet3_amd import _lib
+            # (this fixture is where the resident BatchNorm tower meets the reference's own numbers: it must be the path that ran)
+            assert not bn or net.precision == 'fp32' or _lib.last_forward_path() == _lib.PATH_BN_TOWER, (net.precision, _lib.last_forward_path())
             assert rel_err(e1.detach().cpu().numpy()[:8], g['e1_rows']) < TOL
             assert rel_err(e2.detach().cpu().numpy()[-8:], g['e2_rows']) < TOL
             check_all_embedding_rows(g, e1, e2)

@@ -135,6 +135,13 @@ def test_c2_timed_step_five_adadelta_steps_vs_reference(bn, mode):
         for s in range(5):
             losses.append(float(tr.train_step(batches[s % 2], True)))
             if s == 0:
+                from abnet3_amd import _lib
+                # with BatchNorm this fixture pins the RESIDENT tower (one launch per direction) to the reference: on a
+                # device that cannot hold the grid, or without the sync buffer, the test would silently judge the layer launches
+                # (the split arithmetics; precision='fp32' runs the per-layer GEMM kernels)
+                assert not bn or net.precision == 'fp32' or (_lib.last_forward_path() == _lib.PATH_BN_TOWER and
+                                                              _lib.last_backward_path() == _lib.PATH_BN_TOWER), \
+                    (net.precision, _lib.last_forward_path(), _lib.last_backward_path())
                 check_first_gradient()
     else:
         step = tr.make_graphed_step(batches[0], warmup=1)     # its warm-up step is step 1
