@@ -13,7 +13,8 @@
 // mailboxes are mapped once, by the caller, through hipIpcMemHandle (fine-grained device memory).  Hand-overs are flags
 // in the RECEIVER's mailbox written after a system-scope release; tags are the mailbox's own call counter (every rank makes
 // the same sequence of calls), so nothing is zeroed between calls.  Every spin is bounded: a rank whose peer never arrives
-// raises its mailbox's failure word, leaves NaN in the bucket (the step's parameters read NaN: loud) and returns.
+// raises its mailbox's failure word, hands NaN to its peers in place of the shard it could not reduce and leaves NaN in its
+// own bucket: the step's gradients read NaN on every rank (loud, and the same on all replicas), and the call returns.
 //
 // Mailbox of rank s (abn_oneshot_mail_bytes; zero before the first call):
 //   header   256 B   word 0: calls made; word 1: workgroups of the call in flight that have finished phase 1;
@@ -22,13 +23,20 @@
 //   flags2   R x 128 B   flags2[r] = tag: rank r's reduced shard is in result
 //   slots    R x shard_cap floats
 //   result   cap floats
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace abn {
 
 constexpr int OS_HDR = 256;
 constexpr int OS_NT = 256;
-constexpr unsigned OS_SPIN_LIMIT = 1u << 22;
+// how long a rank waits for a peer before it gives up, on the chip-wide 100 MHz clock: a peer may be late by as much as a
+// garbage collection, a slow loader or a checkpoint being written, none of which is an error -- the bound is there so that a
+// peer that DIED does not hang the stream for ever (torch.distributed's own collectives wait minutes)
+#ifndef OS_WAIT_TICKS
+#define OS_WAIT_TICKS 6000000000ull        // 60 s
+#endif
 
 __host__ __device__ inline int64_t os_shard_cap(int64_t cap, int world) { return ((cap + world - 1) / world + 63) / 64 * 64; }
 __host__ __device__ inline int64_t os_flags1_off() { return OS_HDR; }
@@ -50,13 +58,15 @@ typedef float os4 __attribute__((ext_vector_type(4)));
 // true once *p == tag (system scope); false: gave up (the failure word of the local mailbox is raised)
 __device__ __forceinline__ bool os_wait(const unsigned* p, unsigned tag, unsigned* fail)
 {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (unsigned spins = 0;; ++spins) {
         if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == tag) return true;
-        if (spins > OS_SPIN_LIMIT || ((spins & 63u) == 63u && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
+        if ((spins & 63u) == 63u && (__builtin_amdgcn_s_memrealtime() - t0 > OS_WAIT_TICKS ||
+                                     __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
             __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return false;
         }
-        __builtin_amdgcn_s_sleep(4);
+        if (spins < 4096u) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(64);
     }
 }
 
@@ -106,13 +116,20 @@ __global__ __launch_bounds__(OS_NT) void oneshot_allreduce_kernel(OneShotP q)
     }
     __syncthreads();
     bool ok = ok_s != 0;
-    if (ok) {
-        __threadfence_system();                   // (acquire: the slots' bytes behind the flags)
+    {
+        // A rank that gave up on a contribution has no sum to hand out -- and must not let its peers take the previous call's
+        // shard (or zeros) for one: it hands out NaN instead, so that the bucket reads NaN on EVERY rank and the replicas fail
+        // together instead of drifting apart.
+        if (ok) __threadfence_system();           // (acquire: the slots' bytes behind the flags)
         const int64_t lo = (int64_t)me * per, hi = min(lo + per, q.n);
         const float* const slots = reinterpret_cast<const float*>(mine + os_slots_off(R));
+        const float nanv = __builtin_nanf("");
         for (int64_t i = (int64_t)blockIdx.x * OS_NT + threadIdx.x; i < (hi - lo + 3) / 4; i += (int64_t)gridDim.x * OS_NT) {
-            os4 acc = __builtin_nontemporal_load(reinterpret_cast<const os4*>(slots) + i);
-            for (int r = 1; r < R; ++r) acc += __builtin_nontemporal_load(reinterpret_cast<const os4*>(slots + (int64_t)r * shard) + i);
+            os4 acc = {nanv, nanv, nanv, nanv};
+            if (ok) {
+                acc = __builtin_nontemporal_load(reinterpret_cast<const os4*>(slots) + i);
+                for (int r = 1; r < R; ++r) acc += __builtin_nontemporal_load(reinterpret_cast<const os4*>(slots + (int64_t)r * shard) + i);
+            }
             for (int ds = 0; ds < R; ++ds) {
                 const int s = (me + ds) % R;
                 reinterpret_cast<os4*>(reinterpret_cast<float*>(q.mail[s] + os_result_off(q.cap, R)) + lo)[i] = acc;
@@ -176,8 +193,11 @@ int abn_allreduce_oneshot(const abn_oneshot_ctx* ctx, float* buf, int64_t n, voi
     }
     // a small grid: the call is bound by the links and the hand-overs' latency, not by the CUs, and every workgroup of every
     // rank must be resident while it waits for the peers (two ranks may share one GPU in the tests)
+    // (ABN_ONESHOT_WGS lifts the cap of 32 workgroups: DESIGN.md section 4 has the two-process timings at 32 / 64 / 128)
+    static const int64_t cap_wgs = getenv("ABN_ONESHOT_WGS") && atoi(getenv("ABN_ONESHOT_WGS")) >= 1 ? atoi(getenv("ABN_ONESHOT_WGS")) : 32;
     int64_t wgs = (n / 4 + OS_NT * 8 - 1) / (OS_NT * 8);
-    wgs = wgs < 1 ? 1 : (wgs > 32 ? 32 : wgs);
+    wgs = wgs < 1 ? 1 : (wgs > cap_wgs ? cap_wgs : wgs);
+    if (wgs > 256) wgs = 256;                     // every workgroup resident
     hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3((unsigned)wgs), dim3(OS_NT), 0, (hipStream_t)stream, q);
     ABN_CHECK_LAUNCH("allreduce_oneshot");
     return ABN_OK;

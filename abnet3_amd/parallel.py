@@ -411,6 +411,17 @@ class OneShotAllReduce:
                    'abn_allreduce_oneshot')
         self.calls += 1
 
+    def failed(self):
+        """Has a call of this rank given up on a peer (word 16 of the mailbox)?  One 4-byte read that synchronises with the
+        device: look where the loss is read back anyway.  The trainer does, and raises on every rank (the gradients of that
+        step were NaN on all of them: abn_allreduce_oneshot hands NaN to the peers of a rank that gives up)."""
+        import ctypes as C
+        word = C.c_uint32(0)
+        torch.cuda.synchronize()
+        self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = self._hip.hipMemcpy(C.byref(word), C.c_void_p(self._mine.value + 64), C.c_size_t(4), C.c_int(2))      # device to host
+        return rc != 0 or word.value != 0
+
     def close(self):
         try:
             for p in getattr(self, '_opened', []):

@@ -902,6 +902,11 @@ class TrainerSiamese(TrainerBuilder):
             torch.distributed.all_reduce(sums)
             torch.distributed.all_reduce(counts)
         train_loss, dev_loss = [float(v) for v in sums.cpu()]      # one sync per epoch
+        if self.oneshot is not None and not parallel.all_agree(not self.oneshot.failed()):
+            # a rank gave up waiting for a peer inside abn_allreduce_oneshot: that step's gradients were NaN on EVERY rank
+            # (the rank that gives up hands NaN to its peers), so are the parameters since: every rank stops here
+            raise RuntimeError('abnet3_amd: abn_allreduce_oneshot gave up on a peer during this pass (a rank died or stalled '
+                               'for more than a minute); the parameters are not numbers any more on any rank')
         num_batches_train, num_batches_dev = [max(float(v), 1.0) for v in counts.cpu()]
 
         self.train_losses.append(train_loss / num_batches_train)

@@ -591,6 +591,66 @@ def dtw_bench(torch, P, rank, world, reps=3, cpu_pairs=4000):
     return out
 
 
+def collective_bench(torch, trainer, net, world, reps=50):
+    """What the data-parallel step's gradient exchange costs ON ITS OWN, per call, on the step's own bucket (the flat
+    gradient buffer: 2.29 MB at C2), with HIP events on the launch stream -- BASELINE.md section 3, row C3: "all-reduce us" --
+    for (a) torch.distributed.all_reduce (RCCL's ring / tree on the "nccl" backend) and (b) abn_allreduce_oneshot (one
+    launch per rank over peer-mapped mailboxes); plus who the ranks are: the backend's name, the world size as
+    torch.distributed sees it, and the rank count of a communicator this process made itself on the RCCL library torch has
+    loaded (ncclCommCount on RcclBatchNormSync's communicator: RCCL's own word for how many ranks it connected).
+    EVERY rank runs this (the calls are collectives); rank 0 reports.  Nothing here has been measured over xGMI unless
+    `backend` says "nccl" and `world` > 1 on a multi-GPU node."""
+    import ctypes as C
+    from abnet3_amd import parallel
+    dist = torch.distributed
+    out = {'backend': dist.get_backend(), 'world': dist.get_world_size(), 'rank_count_seen_by_rccl': None,
+           'bucket_bytes': int(net.flat_parameters().numel()) * 4,
+           'step_uses': 'abn_allreduce_oneshot' if trainer.oneshot is not None else
+                        ('torch.distributed.all_reduce, two buckets (the upper layers\' under the rest of the backward)'
+                         if trainer.overlap_allreduce else 'torch.distributed.all_reduce, one bucket')}
+    if out['backend'] == 'nccl':
+        try:
+            sync = parallel.RcclBatchNormSync()
+            n = C.c_int(-1)
+            sync._rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            if sync._rccl.ncclCommCount(sync._comm, C.byref(n)) == 0:
+                out['rank_count_seen_by_rccl'] = int(n.value)
+            sync._destroy()
+        except (RuntimeError, OSError, AttributeError) as e:
+            out['rank_count_seen_by_rccl'] = 'unavailable: %s' % (e,)
+    buf = torch.zeros_like(net.flat_parameters())
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([a.elapsed_time(b) * 1e3 / reps], dtype=torch.float64, device=buf.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return round(float(t.item()), 2)
+    out['allreduce_us'] = {'torch.distributed.all_reduce': timed(lambda: parallel.all_reduce_gradients(buf, False))}
+    one, made_here = trainer.oneshot, False
+    if one is None:
+        try:
+            one, made_here = parallel.OneShotAllReduce(buf.numel()), True
+        except (RuntimeError, OSError, AttributeError, ValueError) as e:
+            out['allreduce_us']['abn_allreduce_oneshot'] = 'unavailable: %s' % (e,)
+    if one is not None:
+        out['allreduce_us']['abn_allreduce_oneshot'] = timed(lambda: one.all_reduce(buf))
+        out['oneshot_gave_up'] = bool(one.failed())
+        if made_here:
+            one.close()
+    out['note'] = ('per call, alone on the stream (in the step the first bucket\'s exchange runs under the rest of the backward); '
+                   'max over ranks; ' + ('RCCL' if out['backend'] == 'nccl' else 'NOT RCCL: a rehearsal backend, host memory in the path'))
+    return out
+
+
 def fbank_bench(torch, seconds=3000, fs=16000, cpu_seconds=600):
     """Filterbank leg (BASELINE.json configs[4] front end): log-mel energies of
     `seconds` of synthetic 16 kHz int16 audio already resident in HBM (50 minutes: a short
@@ -793,6 +853,7 @@ def main():
                       'operands rounded to bf16 once (~3 digits): outside the 1e-5 parity bar, never the headline value')
     variants = variants_bench(torch, pool, args, rank, world)
     dtw = dtw_bench(torch, args.dtw_pairs, rank, world) if args.dtw_pairs > 0 else None
+    coll = collective_bench(torch, trainer, net, world) if world > 1 else None
 
     if rank == 0:
         value = args.steps * BATCH * world / elapsed
@@ -853,6 +914,8 @@ def main():
             out['f32_variants'] = variants
         if dtw is not None:
             out['dtw'] = dtw
+        if coll is not None:
+            out['collective'] = coll
         if world == 1 and not args.no_cpu_baseline:
             out['fbank'] = fbank_bench(torch)
         if world == 1 and args.pipeline_utts > 0:

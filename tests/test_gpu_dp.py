@@ -247,6 +247,15 @@ def test_bench_runs_as_two_ranks():
     assert np.isfinite(out['value']) and out['value'] > 0 and np.isfinite(out['last_loss'])
     assert abs(out['value'] - 8192 / (out['ms_per_step'] * 1e-3)) <= 1e-3 * out['value']
     assert 'cpu_baseline' not in out and out['dtw']['pairs_per_gpu'] == 200
+    # who the ranks are and what the gradient exchange costs on its own: here two
+    # processes on ONE GPU over gloo + IPC mailboxes -- the fields must exist and say so
+    co = out['collective']
+    assert co['backend'] == 'gloo' and co['world'] == 2 and co['rank_count_seen_by_rccl'] is None and 'NOT RCCL' in co['note']
+    assert co["bucket_bytes"] == 4 * 571840 and 'torch.distributed.all_reduce' in co['step_uses']
+    us = co['allreduce_us']
+    assert np.isfinite(us['torch.distributed.all_reduce']) and us['torch.distributed.all_reduce'] > 0
+    assert isinstance(us['abn_allreduce_oneshot'], float) and us['abn_allreduce_oneshot'] > 0, us      # the mailboxes mapped between the two processes
+    assert co['oneshot_gave_up'] is False
 
 
 def test_planned_passes_under_two_ranks(ranks):
