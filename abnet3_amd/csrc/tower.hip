@@ -20,6 +20,7 @@
 #include "tower_planes.h"
 #include "tower_bn_persist.h"
 #include "tower_wide.h"
+#include "tower_wgrad_step.h"
 
 namespace abn {
 
@@ -1577,6 +1578,19 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
 // Backward of a forward that went through the layer-per-launch kernels (same predicate): per layer, top down,
 // one wide_dgrad_layer_kernel (the top one forms dZ_top -- from d_out or from the pair loss); then every
 // layer's weight gradient in the shared launch and the slab reduction.
+// Small batches, one process: the weight gradients over all rows + the optimizer's rule as ONE launch of
+// abn_tower_reduce_step's (tower_wgrad_step.h) instead of slabs in the backward and their sum there.  A pure function of
+// the descriptor and the row count: the backward (which then launches no weight-gradient kernel) and the step ask here.
+static bool wgrad_step_small_ok(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
+{
+    static const bool on = !(getenv("ABN_WGRAD_STEP") && atoi(getenv("ABN_WGRAD_STEP")) == 0);
+    if (!on || !t->defer_reduce || !t->fwd_ws || t->batch_norm || t->wgrad_part != 0 || planes_of(t) != 2) return false;
+    if (n_calls < 1 || rows % n_calls != 0 || !aligned16(t->fwd_ws)) return false;
+    const int64_t vrows = bn_vrows(rows, n_calls);
+    if (wide_groups_for(t, vrows) <= 0 || !planes_shape_ok(t)) return false;
+    return vrows <= 2048;                 // (a workgroup sums every row step itself: 128 of them at most)
+}
+
 static int wide_backward(const abn_tower_desc* t, const float* d_out, const LossArgs* loss, int64_t rows, int64_t n_calls,
                          const Layout& L, const BwdLayout& B, const float* ws, float* scratch, float* dx, hipStream_t st)
 {
@@ -1643,6 +1657,11 @@ static int wide_backward(const abn_tower_desc* t, const float* d_out, const Loss
         PL_LAUNCH(np, wide_dgrad_layer_kernel, grid, dim3(PL_NT), wd_lds_bytes(np), st, q);
         if (l < top || q.dz_out) cur ^= (q.dz_out ? 1 : 0);
         if (l == 0) break;
+    }
+    if (wgrad_step_small_ok(t, rows, n_calls)) {      // the weight gradients are abn_tower_reduce_step's, with the optimizer's rule
+        ABN_REQUIRE(t->fwd_ws == ws && t->fwd_calls == n_calls, "tower_backward: abn_tower_desc.fwd_ws / fwd_calls are not this call's");
+        ABN_CHECK_LAUNCH("tower_backward (layer per launch)");
+        return ABN_OK;
     }
     int n_wg = 0;
     WgradP w = make_wgrad(t, rows, L, B, ws, scratch, &n_wg, l_first, l_end);
@@ -2307,6 +2326,49 @@ int abn_tower_reduce_step(const abn_tower_desc* t, int64_t rows, const float* sc
     ABN_REQUIRE(step >= 1 && n >= 1, "tower_reduce_step: bad n/step");
     const BwdLayout B = make_bwd_layout(t, rows);
     if (scratch_floats < B.total) { set_error("tower_reduce_step: scratch too small"); return ABN_E_WORKSPACE; }
+    if (t->defer_reduce && wgrad_step_small_ok(t, rows, t->fwd_calls)) {
+        // the backward left the transposed images and no slabs: every layer's weight gradient + the rule, one launch
+        const Layout L = make_layout(t, rows, t->fwd_calls);
+        const int64_t nrb = t->fwd_calls * bn_wgs_per_call(rows, t->fwd_calls);
+        WgsP w = {};
+        w.n_layers = t->n_layers;
+        w.tp_steps = (int)(2 * nrb);
+        int n_wg = 0;
+        for (int l = 0; l < t->n_layers; ++l) {
+            WgsLayer& W = w.L[l];
+            W.N = (int)t->dims[l + 1]; W.K = (int)t->dims[l];
+            W.nblk = pl_blocks(W.N); W.kblk = pl_blocks(W.K + 1);
+            ABN_REQUIRE(t->dW[l] && t->db[l] && t->dW[l] >= grads && t->dW[l] + (int64_t)W.N * W.K <= grads + n && t->db[l] >= grads &&
+                            t->db[l] + W.N <= grads + n,
+                        "tower_reduce_step: layer %d's gradients are not inside the flat buffer", l);
+            ABN_REQUIRE(B.amax_dz[l] >= 0 && L.amax[l] >= 0, "tower_reduce_step: the images' maxima are missing");
+            W.dzp = reinterpret_cast<const char*>(scratch + B.dzp[l]);
+            W.ap = reinterpret_cast<const char*>(t->fwd_ws + L.tp[l]);
+            W.amax_dz = scratch + B.amax_dz[l];
+            W.amax_a = t->fwd_ws + L.amax[l];
+            W.tiles_k = (W.kblk + 1) / 2;
+            W.first_wg = n_wg;
+            W.w_off = t->dW[l] - grads; W.b_off = t->db[l] - grads;
+            n_wg += (((W.nblk + 1) / 2 + 1) / 2 * 2) * ((W.tiles_k + 3) / 4 * 4);      // (whole 2 x 4 chunks of tiles: a multiple of 8)
+        }
+        w.o = make_optp(kind, lr, hp0, hp1, eps, step, grad_scale);
+        w.params = params; w.grads = grads; w.s1 = state1; w.s2 = state2;
+        w.fail_word = nullptr;
+        static bool wgs_attr[16] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev = (dev >= 0 && dev < 16) ? dev : 0;
+        if (!wgs_attr[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_step_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGS_LDS_BYTES) != hipSuccess) {
+                set_error("tower_reduce_step: cannot reserve %zu bytes of LDS", WGS_LDS_BYTES);
+                return ABN_E_LAUNCH;
+            }
+            wgs_attr[dev] = true;
+        }
+        hipLaunchKernelGGL(wgrad_step_small_kernel, dim3((unsigned)n_wg), dim3(WGS_NT), WGS_LDS_BYTES, (hipStream_t)stream, w);
+        ABN_CHECK_LAUNCH("tower_reduce_step (weight gradients + step)");
+        return ABN_OK;
+    }
     ReduceTable rt = make_reduce_table(t, B);
     for (int l = 0; l < t->n_layers; ++l) {      // every gradient tensor must lie inside the flat buffers
         ABN_REQUIRE(t->dW[l] && t->db[l] && t->dW[l] >= grads && t->dW[l] + rt.nW[l] <= grads + n && t->db[l] >= grads &&
@@ -2459,3 +2521,10 @@ int abn_linear_backward_prec(const float* dz, const float* W, const float* a_in,
 }
 
 }  // extern "C"
+
+#ifdef ABN_WGS_STAMPS
+extern "C" int abn_debug_wgs_stamps(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(abn::g_wgs_stamps), sizeof(abn::g_wgs_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif

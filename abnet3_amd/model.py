@@ -389,6 +389,17 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False, n_vali
     return out, sv
 
 
+def _lend_forward_workspace(desc, sv, rows):
+    """A deferred backward on the layer-per-launch kernels lends the forward's workspace to abn_tower_reduce_step
+    (abn_tower_desc.fwd_ws): the weight gradients then wait for the optimizer's launch and are computed THERE, over all rows
+    and with the update rule, in one launch (csrc/tower_wgrad_step.h).  Only where the call really takes that path."""
+    lib = _lib.load()
+    path = lib.abn_tower_path(_lib.C.byref(desc), _lib.ptr(sv.x1), _lib.ptr(sv.x2), rows, sv.n_calls, 1, _lib.ptr(sv.ws), 1, None)
+    if path == _lib.PATH_WIDE:
+        desc.fwd_ws = sv.ws.data_ptr()
+        desc.fwd_calls = sv.n_calls
+
+
 def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False, defer_reduce=False):
     """Raw backward of one segment: abn_tower_backward into the pass's flat gradient
     buffer.  Returns (per-parameter gradient views, dx or None).  With defer_reduce the
@@ -406,6 +417,8 @@ def _segment_backward(seg, sv, d_out, grad_pass, need_dx, d_out_is_dz=False, def
     grad_buf, grads = grad_pass.views(seg)
     desc = seg.descriptor(with_grads=True, grad_buf=grad_buf, masks=sv.masks, d_out_is_dz=d_out_is_dz,
                           defer_reduce=defer_reduce)
+    if defer_reduce and not need_dx:
+        _lend_forward_workspace(desc, sv, rows)
     scratch_floats = lib.abn_tower_bwd_scratch_floats(_lib.C.byref(desc), rows)
     scratch = torch.empty(max(scratch_floats, 1), dtype=torch.float32, device=d_out.device)
     dx = torch.empty(rows, seg.input_dim, dtype=torch.float32,
@@ -920,6 +933,8 @@ class SiameseNetwork(_HipNetwork):
         desc = seg.descriptor(with_grads=True, grad_buf=grad_buf, masks=sv.masks, d_out_is_dz=True, defer_reduce=defer_reduce)
         if wgrad_split is not None:              # data-parallel overlap: this call stops after the upper layers' gradients
             desc.wgrad_part, desc.wgrad_split = 1, int(wgrad_split)
+        elif defer_reduce:
+            _lend_forward_workspace(desc, sv, rows)
         if sv.n_valid is not None:               # (a padded batch through BatchNorm: the forward's real-row count)
             desc.n_valid = sv.n_valid.data_ptr()
             if n_valid is None:

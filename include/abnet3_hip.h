@@ -176,8 +176,17 @@ typedef struct abn_tower_desc {
      * and stream (the forward and the backward of a step share it; two streams driving one tower need two).  It holds the
      * launch counter the kernels' hand-over tags derive from and the hand-over granules themselves.  NULL: BatchNorm
      * training runs one launch per layer (ABN_PATH_BN_LAYERS).  Should a launch ever give up on a hand-over (the grid was
-     * not resident: the outputs then read NaN) the buffer's failure word stays set: zero the buffer again. */
+     * not resident: the outputs then read NaN) the buffer's failure word stays set: zero the buffer again.  While it is
+     * set abn_tower_reduce_step drops its step (parameters, state and gradients untouched). */
     void* sync_ws;
+    /* Optional, backward with defer_reduce only (ABI v19): the workspace of the forward whose gradients are pending (the
+     * `ws` both calls were given) and that forward's n_calls, lent to abn_tower_reduce_step.  Small batches on the
+     * layer-per-launch kernels (ABN_PATH_WIDE, fp16 x 2) then skip the split-K weight-gradient launch in the backward:
+     * abn_tower_reduce_step computes every layer's weight gradient over ALL rows and applies the optimizer's rule in ONE
+     * launch (csrc/tower_wgrad_step.h: a workgroup per 64 x 64 tile of [dW | db], no slabs).  The workspace must stay
+     * untouched until that call.  NULL: weight gradients as slabs in the backward, their sum in abn_tower_reduce_step. */
+    const float* fwd_ws;
+    int64_t fwd_calls;
 } abn_tower_desc;
 
 /* A ready-made abn_allreduce_fn for abn_tower_desc.bn_sync_fn over RCCL, so that no host language stands between

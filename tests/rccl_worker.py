@@ -35,7 +35,11 @@ def main():
     port, out = sys.argv[1], sys.argv[2]
     wait_for(sys.argv[3:])
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0', ABN_DP_SINGLE_RANK='1')
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', ABN_DP_SINGLE_RANK='1',
+                      # (one process sums a small batch's weight gradients and steps in ONE launch -- tower_wgrad_step.h: all rows in
+                      # one sum --, a data-parallel rank in slabs + all-reduce + step: the same products in another order.  What is
+                      # compared bit for bit here is a rank's collectives against no collectives: both runs on the slab launches.)
+                      ABN_WGRAD_STEP='0')
     import ast
     import warnings
     import numpy as np

@@ -415,7 +415,9 @@ def test_graphed_step_equals_eager_step():
     for losses, params in results[1:]:
         assert np.allclose(losses, results[0][0], rtol=1e-6, atol=0)
         for k, v in params.items():           # (the flat buffer's alignment gaps hold no parameters)
-            assert rel_err(v, results[0][1][k]) < 1e-6, k
+            # (fp16 x 2, a small batch: the eager step sums its weight gradients over all rows in the optimizer's launch --
+            # tower_wgrad_step.h --, the captured autograd backward in slabs: the same products in another order, eight steps on)
+            assert rel_err(v, results[0][1][k]) < 5e-6, k
 
 
 @pytest.mark.parametrize('fixture,bn', [('train_c2_bn0.npz', False), ('train_mid_bn1.npz', True)])
@@ -597,9 +599,12 @@ def test_direct_step_equals_autograd_step(fixture, opt):
                     {k: p.grad.cpu().numpy().copy() for k, p in net.named_parameters()}))
     assert np.allclose(out[0][0], out[1][0], rtol=1e-6, atol=0)
     for k, v in out[1][1].items():
-        assert rel_err(v, out[0][1][k]) < 1e-6, k
+        # (fp16 x 2, small batches: the direct step sums its weight gradients over all rows inside the optimizer's launch,
+        # tower_wgrad_step.h; the autograd step in slabs: the same products, another order -- and Adadelta's step is the
+        # gradient over its own running size: a bias that starts at zero carries the gradients' 1e-5 one to one)
+        assert rel_err(v, out[0][1][k]) < 2e-5, k
     for k, v in out[1][2].items():
-        assert rel_err(v, out[0][2][k], floor=1e-12) < 1e-6, k
+        assert rel_err(v, out[0][2][k], floor=1e-12) < 3e-5, k      # (the last step's gradients: see tests/test_gpu_wide.py on the two launches)
 
 
 @pytest.mark.parametrize('rows,k,n,act', [(8192, 500, 500, 'sigmoid'), (200, 40, 72, 'tanh'), (1000, 500, 100, 'none')])

@@ -250,7 +250,9 @@ def test_auto_graph_with_interleaved_eager_steps_uses_fresh_gradients(oname):
         out.append((tr.train_losses, {k: p.detach().cpu().numpy().copy() for k, p in net.state_dict().items()}))
     assert np.allclose(out[0][0], out[1][0], rtol=1e-6)
     for k, v in out[1][1].items():
-        assert rel_err(v, out[0][1][k]) < 1e-6, k
+        # (fp16 x 2, small batches: eager steps sum their weight gradients over all rows in the optimizer's launch, captured
+        # autograd steps in slabs -- the same products in another order, two epochs on)
+        assert rel_err(v, out[0][1][k]) < 1e-5, k
 
 
 def test_save_whoami_pickles_the_reference_dictionary(tmp_path):
