@@ -98,7 +98,12 @@ class TowerDesc(C.Structure):
         for name in ('W', 'b', 'bn_w', 'bn_b', 'bn_rm', 'bn_rv', 'dW', 'db',
                      'dbn_w', 'dbn_b', 'drop_mask')] + [('precision', _i32), ('d_out_is_dz', _i32), ('defer_reduce', _i32), ('wpack_valid', _i32), ('forward_only', _i32), ('wgrad_part', _i32), ('wpack', _vp), ('drop_seed', _vp), ('drop_p', _f32), ('reserved2_', _i32),
                      ('bn_sync_world', _i32), ('wgrad_split', _i32), ('bn_sync_fn', _vp), ('bn_sync_ctx', _vp), ('n_valid', _vp),
-                     ('bn_nbt', _vp * MAX_LAYERS), ('sync_ws', _vp), ('fwd_ws', _vp), ('fwd_calls', _i64)]
+                     ('bn_nbt', _vp * MAX_LAYERS), ('sync_ws', _vp), ('fwd_ws', _vp), ('fwd_calls', _i64), ('source', _vp)]
+
+
+class StepSource(C.Structure):
+    """abn_step_source (include/abnet3_hip.h): a pass's batches as the plan holds them, for steps that need no gather launch."""
+    _fields_ = [('table', _vp), ('table_rows', _i64), ('idx1', _vp), ('idx2', _vp), ('labels', _vp), ('steps', _vp), ('step_ctr', _vp)]
 
 
 class OneShotCtx(C.Structure):

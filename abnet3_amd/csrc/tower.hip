@@ -310,8 +310,9 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, ReduceTable 
 // the buffer and goes on with the layer launches: INTEGRATION.md, "when the resident tower gives up").
 __global__ void slab_reduce_step_kernel(const float* __restrict__ slabs, ReduceTable t, OptP o, float* __restrict__ params,
                                         float* __restrict__ grads, float* __restrict__ s1, float* __restrict__ s2,
-                                        const unsigned* __restrict__ fail_word)
+                                        const unsigned* __restrict__ fail_word, int32_t* __restrict__ step_ctr)
 {
+    if (step_ctr && blockIdx.x == 0 && threadIdx.x == 0) *step_ctr += 1;      // abn_step_source: the step is over (every reader of its entry ran before)
     if (fail_word && *fail_word != 0u) return;
     const int64_t n4 = (t.total + 3) / 4;
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4;
@@ -1651,6 +1652,10 @@ static int wide_backward(const abn_tower_desc* t, const float* d_out, const Loss
                 q.loss_out = loss->loss_out;
                 q.n_valid = loss->n_valid;
                 q.loss_accum = loss->loss_accum;
+                if (t->source) {
+                    q.y = t->source->labels;
+                    q.g_steps = t->source->steps; q.g_ctr = t->source->step_ctr;
+                }
             }
         }
         const dim3 grid((unsigned)(nrb * q.G));
@@ -1814,6 +1819,13 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
         return ABN_E_UNSUPPORTED;
     }
     const int kind = planes_kind(t, rows, n_calls, x1, x2, ws, pmode);
+    if (t->source && !(train && !bn_train && kind == PLANES_WIDE && n_calls == 2 && x2 && !t->forward_only)) {
+        set_error("tower_forward: a step source (abn_tower_desc.source) needs the layer-per-launch kernels in training, two calls");
+        return ABN_E_UNSUPPORTED;
+    }
+    if (t->source) ABN_REQUIRE(t->source->table && t->source->idx1 && t->source->idx2 && t->source->steps && t->source->step_ctr &&
+                                   aligned16(t->source->table) && t->dims[0] % 4 == 0,
+                               "tower_forward: abn_step_source: null or misaligned array");
     if (t->drop_seed && train && !bn_train && kind == PLANES_NONE) {
         for (int l = 0; l < t->n_layers; ++l)
             if (!t->drop_mask[l]) { set_error("tower_forward: in-kernel dropout (drop_seed) needs the operand-plane kernels: pass drop_mask tensors"); return ABN_E_UNSUPPORTED; }
@@ -1907,6 +1919,11 @@ int abn_tower_forward(const abn_tower_desc* t, const float* x1, const float* x2,
                 if (np == 2 && keep) { q.amax_in = ws + L.amax[0]; q.amax_out = q.last ? nullptr : ws + L.amax[l + 1]; }
                 q.tp_steps = 2 * nrb;
                 q.drop_seed = f.drop_seed; q.drop_p = f.drop_p;
+                if (t->source && l == 0) {
+                    q.g_table = t->source->table; q.g_rows = t->source->table_rows;
+                    q.g_idx1 = t->source->idx1; q.g_idx2 = t->source->idx2;
+                    q.g_steps = t->source->steps; q.g_ctr = t->source->step_ctr;
+                }
 #ifdef ABN_STAMPS
                 q.stamps = getenv("ABN_STAMP_BUF") ? (unsigned long long*)strtoull(getenv("ABN_STAMP_BUF"), nullptr, 0) : nullptr;
 #endif
@@ -2132,6 +2149,7 @@ int abn_tower_backward(const abn_tower_desc* t, const float* x1, const float* x2
     // The forward that filled `ws` went through the planes kernels (same predicate): its workspace
     // holds W^T and the weight-gradient operands as operand fragments.  Two launches: the data
     // gradient chain (one workgroup per 32 rows, all layers), then every layer's weight gradient.
+    ABN_REQUIRE(!t->source, "tower_backward: a step source (abn_tower_desc.source) goes with abn_tower_backward_loss (the labels are the plan's)");
     {
         const int kind = planes_kind(t, rows, n_calls, x1, x2, ws);
         if (kind == PLANES_WIDE) { return wide_backward(t, d_out, nullptr, rows, n_calls, L, B, ws, scratch, dx, st); }
@@ -2305,6 +2323,10 @@ int abn_tower_backward_loss(const abn_tower_desc* t, const float* x1, const floa
                   "widths <= 512 and multiples of 4, enough rows; BatchNorm without cross-replica statistics): use abn_pair_loss_dz + abn_tower_backward");
         return ABN_E_UNSUPPORTED;
     }
+    if (t->source && (kind != PLANES_WIDE || bn || !t->source->labels)) {
+        set_error("tower_backward_loss: a step source (abn_tower_desc.source) needs the layer-per-launch kernels and its labels");
+        return ABN_E_UNSUPPORTED;
+    }
     const Layout L = make_layout(t, rows, 2);
     const BwdLayout B = make_bwd_layout(t, rows);
     if (scratch_floats < B.total) { set_error("tower_backward_loss: scratch too small"); return ABN_E_WORKSPACE; }
@@ -2354,6 +2376,7 @@ int abn_tower_reduce_step(const abn_tower_desc* t, int64_t rows, const float* sc
         w.o = make_optp(kind, lr, hp0, hp1, eps, step, grad_scale);
         w.params = params; w.grads = grads; w.s1 = state1; w.s2 = state2;
         w.fail_word = nullptr;
+        w.step_ctr = t->source ? t->source->step_ctr : nullptr;
         static bool wgs_attr[16] = {};
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -2384,7 +2407,8 @@ int abn_tower_reduce_step(const abn_tower_desc* t, int64_t rows, const float* sc
     }
     hipLaunchKernelGGL(slab_reduce_step_kernel, dim3(grid_for((rt.total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        scratch + B.slabs, rt, make_optp(kind, lr, hp0, hp1, eps, step, grad_scale), params, grads, state1,
-                       state2, t->batch_norm && t->sync_ws ? reinterpret_cast<const unsigned*>(t->sync_ws) + 16 : nullptr);
+                       state2, t->batch_norm && t->sync_ws ? reinterpret_cast<const unsigned*>(t->sync_ws) + 16 : nullptr,
+                       t->source ? t->source->step_ctr : nullptr);
     ABN_CHECK_LAUNCH("tower_reduce_step");
     return ABN_OK;
 }

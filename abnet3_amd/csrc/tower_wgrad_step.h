@@ -46,6 +46,7 @@ struct WgsP {
     float* s1;
     float* s2;
     const unsigned* fail_word;
+    int32_t* step_ctr;       // abn_step_source: advanced once per step (or null)
 };
 
 constexpr int WGS_DEPTH = 4;                       // row steps in flight per wave
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(WGS_NT) void wgrad_step_small_kernel(WgsP p)
     extern __shared__ __attribute__((aligned(16))) char wgs_smem[];
     float (*park)[4][16][64] = reinterpret_cast<float (*)[4][16][64]>(wgs_smem);                 // [wave][block][q][lane]
     float* const red = reinterpret_cast<float*>(wgs_smem + (size_t)WGS_WAVES * 4 * 16 * 64 * 4);  // [2][waves]
+    if (p.step_ctr && blockIdx.x == 0 && threadIdx.x == 0) *p.step_ctr += 1;      // (every reader of the step's entry ran in the launches before)
     if (p.fail_word && *p.fail_word != 0u) return;
     WGS_STAMP(0);
     const int lane = threadIdx.x & 63;

@@ -209,6 +209,13 @@ struct WideFwdP {
     int64_t tp_steps;
     const unsigned long long* drop_seed;
     float drop_p;
+    // l == 0, abn_tower_desc.source: the rows come from the pass's plan (abn_step_source), not from x1 / x2
+    const float* g_table;
+    int64_t g_rows;
+    const int64_t* g_idx1;
+    const int64_t* g_idx2;
+    const int64_t* g_steps;
+    const int32_t* g_ctr;
 #ifdef ABN_STAMPS
     unsigned long long* stamps;
 #endif
@@ -256,7 +263,19 @@ __global__ __launch_bounds__(PL_NT) void wide_fwd_layer_kernel(WideFwdP p)
     }
 
     const float* src;
-    if (p.l == 0) src = !row_ok ? nullptr : (p.x2 && call >= 1 ? p.x2 + (arow - p.rows_call) * K : p.x1 + arow * K);
+    if (p.l == 0 && p.g_table) {
+        // the step's pairs [first, first + n) of the plan: pair lb * 32 + r of this call's tower, a zero row behind the last
+        const int64_t st = *p.g_ctr;
+        const int64_t first = p.g_steps[2 * st];
+        const int n = (int)p.g_steps[2 * st + 1];
+        const int pair = lb * PL_ROWS + r;
+        src = nullptr;
+        if (row_ok && pair < n) {
+            const int64_t row = (call >= 1 ? p.g_idx2 : p.g_idx1)[first + pair];
+            if ((uint64_t)row < (uint64_t)p.g_rows) src = p.g_table + row * K;      // (a row outside the table reads as zeros: abn_gather_pairs)
+        }
+    }
+    else if (p.l == 0) src = !row_ok ? nullptr : (p.x2 && call >= 1 ? p.x2 + (arow - p.rows_call) * K : p.x1 + arow * K);
     else src = p.a_prev + (int64_t)vrow * K;
     char* const tp_in = p.l == 0 ? p.tp_in : nullptr;
     float ainv = 1.0f;
@@ -378,6 +397,8 @@ struct WideBwdP {
     float* loss_out;
     const int* n_valid;
     double* loss_accum;
+    const int64_t* g_steps;        // abn_tower_desc.source: the step's first pair (the labels' offset) and real-pair count
+    const int32_t* g_ctr;
 };
 
 template <int NP>
@@ -413,8 +434,15 @@ __global__ __launch_bounds__(PL_NT) void wide_dgrad_layer_kernel(WideBwdP p)
         int* const is_last_s = reinterpret_cast<int*>(term_s + 32);
         const bool with_loss = p.d_out == nullptr;
         const int B = p.rows_call;
-        const int Bv = with_loss && p.n_valid ? *p.n_valid : B;
-        const double lscale = with_loss && p.n_valid && p.scale != 1.0 ? 1.0 / (double)(Bv > 0 ? Bv : 1) : p.scale;
+        int64_t yoff = 0;
+        int Bv = with_loss && p.n_valid ? *p.n_valid : B;
+        const bool counted = with_loss && (p.n_valid || p.g_steps);
+        if (with_loss && p.g_steps) {
+            const int64_t st = *p.g_ctr;
+            yoff = p.g_steps[2 * st];
+            Bv = (int)p.g_steps[2 * st + 1];
+        }
+        const double lscale = counted && p.scale != 1.0 ? 1.0 / (double)(Bv > 0 ? Bv : 1) : p.scale;
         if (with_loss) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -446,11 +474,11 @@ __global__ __launch_bounds__(PL_NT) void wide_dgrad_layer_kernel(WideBwdP p)
                     const double cs = dot / (c1 * c2);
                     double v = 0.0;
                     switch (p.y_dtype) {
-                        case ABN_Y_I8: v = ((const int8_t*)p.y)[pi_]; break;
-                        case ABN_Y_I32: v = ((const int32_t*)p.y)[pi_]; break;
-                        case ABN_Y_I64: v = (double)((const int64_t*)p.y)[pi_]; break;
-                        case ABN_Y_F32: v = ((const float*)p.y)[pi_]; break;
-                        default: v = ((const double*)p.y)[pi_]; break;
+                        case ABN_Y_I8: v = ((const int8_t*)p.y)[yoff + pi_]; break;
+                        case ABN_Y_I32: v = ((const int32_t*)p.y)[yoff + pi_]; break;
+                        case ABN_Y_I64: v = (double)((const int64_t*)p.y)[yoff + pi_]; break;
+                        case ABN_Y_F32: v = ((const float*)p.y)[yoff + pi_]; break;
+                        default: v = ((const double*)p.y)[yoff + pi_]; break;
                     }
                     const int code = v == 1.0 ? 1 : (v == -1.0 ? -1 : 0);
                     double dcos;

@@ -290,14 +290,16 @@ class _DropSeed(object):
 
 class _Saved(object):
     """What a segment's forward leaves for its backward."""
-    __slots__ = ('x1', 'x2', 'ws', 'masks', 'n_calls', 'train', 'rows', 'bn_synced', 'n_valid')
+    __slots__ = ('x1', 'x2', 'ws', 'masks', 'n_calls', 'train', 'rows', 'bn_synced', 'n_valid', 'source')
 
 
-def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False, n_valid=None):
+def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False, n_valid=None, source=None):
     """Raw forward of one segment (no autograd): the launch sequence of
     abn_tower_forward.  Returns ([rows, out] embeddings as a view of the workspace,
     _Saved).  n_valid (device int32 tensor): a padded batch through a BatchNorm tower in training -- only the
-    first n_valid rows of every call are real (abn_tower_desc.n_valid)."""
+    first n_valid rows of every call are real (abn_tower_desc.n_valid).  source (_lib.StepSource): the first layer's launch
+    stages its rows from the pass's plan instead of from x1 / x2 (abn_tower_desc.source; HipLibraryError where the library
+    does not take the call that way: the caller asks abn_tower_path first)."""
     lib = _lib.load()
     net = seg.net
     # the reference takes strided inputs (a column slice of stacked features):
@@ -362,6 +364,9 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False, n_vali
                 warnings.warn('abnet3_amd: sync_batch_norm: a batch of %d rows (here; the ranks decide together) does not run on the '
                               'per-layer BatchNorm launches that carry the cross-replica statistics on every rank; such steps use '
                               'per-replica statistics' % rows)
+    if source is not None:
+        desc = _lib.TowerDesc.from_buffer_copy(desc)
+        desc.source = _lib.C.addressof(source)
     ws_floats = lib.abn_tower_ws_floats(_lib.C.byref(desc), rows, n_calls)
     if ws_floats < 0:
         _lib.check(-1, 'abn_tower_ws_floats')
@@ -386,6 +391,7 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False, n_vali
     sv.x1, sv.x2, sv.ws, sv.masks, sv.n_calls, sv.train, sv.rows = x1, x2, ws, masks, n_calls, train, rows
     sv.bn_synced = synced
     sv.n_valid = n_valid
+    sv.source = source
     return out, sv
 
 
@@ -850,7 +856,7 @@ class SiameseNetwork(_HipNetwork):
     def direct_ok(self):
         return self._last_act != 'softmax'
 
-    def direct_forward(self, x1, x2, forward_only=False, n_valid=None):
+    def direct_forward(self, x1, x2, forward_only=False, n_valid=None, source=None):
         """forward(x1, x2) in the current mode without building an autograd graph:
         ([2B, out] embeddings of both towers, state for direct_backward).  Dispatching
         one backward through torch's autograd engine costs ~150 us of host time per
@@ -859,7 +865,7 @@ class SiameseNetwork(_HipNetwork):
         seg = self._segment_list()[0]
         rows = 2 * x1.shape[0]
         masks = self._draw_dropout_masks(rows, x1.device) if self.training else None
-        out, sv = _segment_forward(seg, masks, 2, x1, x2, forward_only=forward_only, n_valid=n_valid)
+        out, sv = _segment_forward(seg, masks, 2, x1, x2, forward_only=forward_only, n_valid=n_valid, source=source)
         return out, (seg, sv, _GradPass(self))
 
     def takes_padded_batch_norm(self, x12, npad):
@@ -927,10 +933,13 @@ class SiameseNetwork(_HipNetwork):
         lib = _lib.load()
         y = y.contiguous()
         _lib.require_device(y)
-        if y.dtype not in _lib.Y_DTYPE or y.numel() * 2 != rows:
+        source = getattr(sv, 'source', None)      # (the labels are the plan's then: y = all of them, the step's offset is the library's to find)
+        if y.dtype not in _lib.Y_DTYPE or (y.numel() * 2 != rows and source is None):
             return None
         grad_buf, grads = grad_pass.views(seg)
         desc = seg.descriptor(with_grads=True, grad_buf=grad_buf, masks=sv.masks, d_out_is_dz=True, defer_reduce=defer_reduce)
+        if source is not None:
+            desc.source = _lib.C.addressof(source)
         if wgrad_split is not None:              # data-parallel overlap: this call stops after the upper layers' gradients
             desc.wgrad_part, desc.wgrad_split = 1, int(wgrad_split)
         elif defer_reduce:

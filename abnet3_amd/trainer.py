@@ -30,6 +30,8 @@ import torch.optim as optim
 
 import weakref
 
+import numpy as np
+
 from . import _lib, parallel
 from .loss import unit_grad
 from .model import NetworkBuilder, SiameseMultitaskNetwork
@@ -613,17 +615,47 @@ class TrainerSiamese(TrainerBuilder):
         return b
 
     def _bucket_body(self, b):
-        """The five statements of the reference's loop (abnet3/trainer.py:236-240) on a bucket's static buffers."""
+        """The five statements of the reference's loop (abnet3/trainer.py:236-240) on a bucket's static buffers -- or, for a
+        bucket that reads its batches from the pass's plan (b['source']: abn_step_source), on the plan itself."""
         net, opt, npad = self.network, self.optimizer, b['npad']
         x12 = b['x12']
+        src = b.get('source')
         # (BatchNorm: the batch statistics span the real rows only -- abn_tower_desc.n_valid, the device word the gather wrote)
-        emb, state = net.direct_forward(x12[:npad], x12[npad:], n_valid=b['nv'] if getattr(net, 'batch_norm', False) else None)
+        emb, state = net.direct_forward(x12[:npad], x12[npad:], n_valid=b['nv'] if getattr(net, 'batch_norm', False) else None,
+                                        source=src['src'] if src is not None else None)
         opt.zero_grad()
         defer = not self.dp and net.can_defer_reduce(state)
-        loss_value = net.direct_backward_loss(state, b['y'], type(self.loss).__name__, getattr(self.loss, 'margin', 0.0),
-                                              self.loss.avg, defer_reduce=defer, n_valid=b['nv'], loss_accum=self._loss_acc,
-                                              loss_ws=self._loss_ws)
+        loss_value = net.direct_backward_loss(state, src['labels'] if src is not None else b['y'], type(self.loss).__name__,
+                                              getattr(self.loss, 'margin', 0.0), self.loss.avg, defer_reduce=defer, n_valid=b['nv'],
+                                              loss_accum=self._loss_acc, loss_ws=self._loss_ws)
         return loss_value
+
+    # -- steps that read their batch from the plan (abn_step_source): no gather launch, nothing to tell a replay ------------
+    def _step_source(self, plan):
+        """The pass's plan as the library's step source, with this pass's (first pair, pairs) table uploaded and the step
+        counter at zero -- or None where a step's last launch is not the optimizer's (data-parallel, Adam) or the switch
+        says no (ABN_STEP_SOURCE=0).  The device arrays persist between passes: captured steps hold their addresses."""
+        opt = self.optimizer
+        if (self.dp or os.environ.get('ABN_STEP_SOURCE') == '0' or not isinstance(opt, FlatOptimizer) or opt.kind == 'adam'
+                or getattr(self.network, 'batch_norm', False) or not plan.order):
+            return None
+        key = (plan.table.data_ptr(), plan.idx1.data_ptr(), plan.idx2.data_ptr(), plan.labels.data_ptr(), plan.table.shape[0])
+        st = getattr(self, '_src', None)
+        if st is None or st['key'] != key or st['steps'].shape[0] < len(plan.order):
+            if st is not None:
+                self._forget_captured_steps()
+            dev = plan.table.device
+            steps = torch.zeros(max(len(plan.order), 1024), 2, dtype=torch.int64, device=dev)
+            ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+            src = _lib.StepSource()
+            src.table, src.table_rows = plan.table.data_ptr(), plan.table.shape[0]
+            src.idx1, src.idx2, src.labels = plan.idx1.data_ptr(), plan.idx2.data_ptr(), plan.labels.data_ptr()
+            src.steps, src.step_ctr = steps.data_ptr(), ctr.data_ptr()
+            st = self._src = dict(key=key, steps=steps, ctr=ctr, src=src, labels=plan.labels, plan_arrays=(plan.table, plan.idx1, plan.idx2))
+        spans = np.array([plan.span(b) for b in plan.order], dtype=np.int64).reshape(-1, 2)
+        st['steps'][:len(spans)].copy_(torch.from_numpy(spans), non_blocking=False)
+        st['ctr'].zero_()
+        return st
 
     def _bucket_finish(self):
         opt = self.optimizer
@@ -631,19 +663,34 @@ class TrainerSiamese(TrainerBuilder):
             opt.grad_scale = parallel.all_reduce_gradients(self.network.flat_grad(), self._loss_is_mean(), self.oneshot)
         opt.step()
 
-    def _planned_step(self, plan, bid):
-        """One training step on batch `bid` of the plan; returns False (nothing stepped) when the library refuses
-        the padded form for this network / batch size: the caller then takes the iterator's step on the batch."""
+    def _planned_step(self, plan, bid, source=None):
+        """One training step on batch `bid` of the plan; returns 0 (nothing stepped) when the library refuses
+        the padded form for this network / batch size: the caller then takes the iterator's step on the batch; 1: stepped;
+        2: stepped from the plan itself (`source`: the step's own last launch has advanced the pass's step counter)."""
         lib = _lib.load()
         first, n = plan.span(bid)
         if n == 0:        # no arrays: ValueError like the reference's np.vstack([]); zero frames: the iterator's (empty) step
             self._loss_acc.add_(self.train_step(plan.materialise(bid), True))
-            return True
+            return 1
         b = self._bucket_state(self._bucket(n), plan)
-        _lib.check(lib.abn_gather_pairs(_lib.ptr(plan.table), plan.table.shape[0], plan.table.shape[1], _lib.ptr(plan.idx1), _lib.ptr(plan.idx2),
-                                        first, n, b['npad'], _lib.ptr(plan.labels), plan.labels.element_size(),
-                                        _lib.ptr(b['x12']), _lib.ptr(b['y']), _lib.ptr(b['nv']), _lib.stream()),
-                   'abn_gather_pairs')
+        if 'source' not in b:
+            # a bucket reads from the plan when its size runs on the layer-per-launch kernels (asked once per bucket)
+            b['source'] = None
+            if source is not None:
+                probe = self.network._segment_list()[0].descriptor(with_grads=False)
+                x12 = b['x12']
+                if lib.abn_tower_path(_lib.C.byref(probe), _lib.ptr(x12[:b['npad']]), _lib.ptr(x12[b['npad']:]), 2 * b['npad'], 2, 1,
+                                      _lib.ptr(x12), 0, None) == _lib.PATH_WIDE and plan.table.shape[1] % 4 == 0:
+                    b['source'] = source
+        if b['source'] is not None and b['source'] is not source:
+            return 0                                  # (a bucket captured against another pass's arrays: cannot happen after _forget_captured_steps)
+        sourced = b['source'] is not None
+        if not sourced:
+            _lib.check(lib.abn_gather_pairs(_lib.ptr(plan.table), plan.table.shape[0], plan.table.shape[1], _lib.ptr(plan.idx1), _lib.ptr(plan.idx2),
+                                            first, n, b['npad'], _lib.ptr(plan.labels), plan.labels.element_size(),
+                                            _lib.ptr(b['x12']), _lib.ptr(b['y']), _lib.ptr(b['nv']), _lib.stream()),
+                       'abn_gather_pairs')
+        done = 2 if sourced else 1
         opt = self.optimizer
         in_graph_opt = not self.dp and opt.kind != 'adam'      # (Adam's bias correction is host arithmetic per step)
         if b['graph'] is not None:
@@ -659,16 +706,16 @@ class TrainerSiamese(TrainerBuilder):
             else:
                 net._pending_reduce = pending
                 self._bucket_finish()
-            return True
+            return done
         # first batch of this bucket: the step itself runs eagerly (and warms everything up), then the same
         # launch sequence is captured for the batches to come (capturing executes nothing)
         if getattr(self.network, 'batch_norm', False) and not self.network.takes_padded_batch_norm(b['x12'], b['npad']):
-            return False                      # (odd widths: the per-layer kernels, no real-row count inside their statistics)
+            return 0                          # (odd widths: the per-layer kernels, no real-row count inside their statistics)
         if self._bucket_body(b) is None:
-            return False
+            return 0
         self._bucket_finish()
         if len([1 for v in self._buckets.values() if v['graph'] is not None]) >= self.MAX_BUCKET_GRAPHS:
-            return True
+            return done
         steps_before = opt.step_count
         graph = torch.cuda.CUDAGraph()
         gc_was_enabled = gc.isenabled()
@@ -686,7 +733,7 @@ class TrainerSiamese(TrainerBuilder):
         opt.step_count = steps_before
         net = self.network
         b['graph'] = (graph, [p_.grad for p_ in net.live_parameters()], getattr(net, '_last_grad_flat', None), pending)
-        return True
+        return done
 
     def _planned_eval(self, plan, bid):
         """loss(network(batch)) of batch `bid` without gradients, in the network's current mode, added to the
@@ -761,16 +808,20 @@ class TrainerSiamese(TrainerBuilder):
             return self._run_planned_eval(plan, loss_sum)
         if not plan.order:
             return 0
+        source = self._step_source(plan)          # (first: it may drop the captured steps of another plan)
         self._bucket_state(self._bucket(plan.span(plan.order[0])[1]), plan)      # (creates the accumulator)
         self._loss_acc.zero_()
         for k, bid in enumerate(plan.order):
-            if getattr(self, '_plan_refused', False) or not self._planned_step(plan, bid):
+            done = 0 if getattr(self, '_plan_refused', False) else self._planned_step(plan, bid, source)
+            if not done:
                 # the library does not take this network / batch in the padded form (exact-fp32 arithmetic, odd widths,
                 # a tiny batch with the layer-per-launch kernels switched off): the iterator's step on the same batch;
                 # refused on the very first batch = refused for good (the next passes do not ask again)
                 if k == 0:
                     self._plan_refused = True
                 self._loss_acc.add_(self.train_step(plan.materialise(bid), True))
+            if source is not None and done != 2:
+                source['ctr'].add_(1)             # (a step that did not read the plan: the pass's step counter moves all the same)
         loss_sum.add_(self._loss_acc)
         return len(plan.order)
 
@@ -825,7 +876,7 @@ class TrainerSiamese(TrainerBuilder):
 
     def _forget_captured_steps(self):
         """Captured steps hold the addresses a tower's descriptor had when they were captured (its sync buffer among them)."""
-        for name in ('_graphs', '_shape_seen', '_buckets', '_bucket_pool', '_loss_acc', '_loss_ws'):
+        for name in ('_graphs', '_shape_seen', '_buckets', '_bucket_pool', '_loss_acc', '_loss_ws', '_src'):
             self.__dict__.pop(name, None)
 
     def optimize_model(self, do_training=True):

@@ -187,7 +187,30 @@ typedef struct abn_tower_desc {
      * untouched until that call.  NULL: weight gradients as slabs in the backward, their sum in abn_tower_reduce_step. */
     const float* fwd_ws;
     int64_t fwd_calls;
+    /* Optional (ABI v19): the step reads its batch from a PLAN of the whole pass instead of from x1 / x2 / y -- see
+     * abn_step_source below.  Layer-per-launch kernels (ABN_PATH_WIDE) in training, two forward_once calls, the pair loss
+     * inside the backward (abn_tower_backward_loss); ABN_E_UNSUPPORTED elsewhere. */
+    const struct abn_step_source* source;
 } abn_tower_desc;
+
+/* A pass's batches as the trainer's batch plan holds them (abnet3/dataloader.py:166-261: every batch = the frame pairs of
+ * some word pairs, in the order the reference's iterator yields them): pair p of the plan aligns row idx1[p] of `table`
+ * (tower 1) with row idx2[p] (tower 2) under label labels[p]; step s of the pass takes pairs [steps[2 s], steps[2 s] +
+ * steps[2 s + 1]).  With abn_tower_desc.source set, a training step needs NO gather launch and no per-step argument: the
+ * first layer's launch stages its 32 rows straight from the table (rows behind the step's last pair: zero rows, as
+ * abn_gather_pairs pads them), the pair loss reads its labels and its real-pair count from here, and the step's last launch
+ * (abn_tower_reduce_step) advances *step_ctr -- a captured hipGraph replays unchanged for every batch of its size.
+ * x1 / x2 still name the (unused) input buffers of the padded size: rows = 2 x the padded pair count as before.
+ * All arrays on the device; the struct itself is host memory read during the calls. */
+typedef struct abn_step_source {
+    const float* table;            /* [table_rows, dims[0]] */
+    int64_t table_rows;
+    const int64_t* idx1;
+    const int64_t* idx2;
+    const void* labels;            /* dtype: abn_tower_backward_loss's y_dtype (its y argument is ignored) */
+    const int64_t* steps;          /* [n_steps][2]: first pair, pairs */
+    int32_t* step_ctr;             /* the step being run; += 1 by abn_tower_reduce_step */
+} abn_step_source;
 
 /* A ready-made abn_allreduce_fn for abn_tower_desc.bn_sync_fn over RCCL, so that no host language stands between
  * two launches of a data-parallel BatchNorm step: ctx = an abn_rccl_ctx the caller fills once -- `comm` its ncclComm_t,

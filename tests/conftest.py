@@ -13,6 +13,14 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 DP_JOB = {}
 
 
+def release_dp_job():
+    """Lets the helper processes pytest_configure started (waiting in tests/wait_then_run.py) go: they take the GPU only
+    from here on -- tests/test_gpu_dp.py calls this when it wants their results --, not beside every other test's kernels."""
+    go = DP_JOB.get('go')
+    if go and not os.path.exists(go):
+        open(go, 'w').close()
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -41,6 +49,12 @@ def pytest_configure(config):
             out = os.path.join(tempfile.mkdtemp(prefix='abn_dp_'), 'res')
             port = str(_free_port())
             procs = []
+            # every helper sleeps in tests/wait_then_run.py until release_dp_job() (tests/test_gpu_dp.py): started here because
+            # this process may not start programs once it holds the GPU, released there so that they share the card with
+            # nothing but each other and the tests that wait for them
+            go = out + '.go'
+            wait = [sys.executable, os.path.join(ROOT, 'tests', 'wait_then_run.py'), go]
+            DP_JOB.update(go=go)
             # (these helper processes share the test box's ONE GPU with each other and with pytest itself: their BatchNorm
             # towers train one launch per layer -- two resident grids dispatched in the same microsecond could each hold part
             # of the CUs and wait out their bounded spins for the rest; the resident tower is under test in
@@ -48,7 +62,7 @@ def pytest_configure(config):
             shared_gpu = dict(os.environ, ABN_BN_PERSIST='0')
             for r in range(2):
                 log = open(out + '.rank%d.log' % r, 'w')
-                procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'),
+                procs.append(subprocess.Popen(wait + [os.path.join(ROOT, 'tests', 'dp_worker.py'),
                                                str(r), '2', port, out], stdout=log, stderr=subprocess.STDOUT, env=shared_gpu))
             DP_JOB.update(procs=procs, out=out)
             # ... and bench.py --gpus 2 the way the driver starts it for N > 1 (torch.distributed.run's
@@ -59,15 +73,15 @@ def pytest_configure(config):
                 env = dict(shared_gpu, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
                            ABN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
                 log = open(out + '.bench%d.log' % r, 'w')
-                bprocs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                bprocs.append(subprocess.Popen(wait + [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
                                                 '--repeats', '2', '--dtw-pairs', '200', '--pipeline-utts', '0'],
                                                stdout=log, stderr=subprocess.STDOUT, env=env))
             DP_JOB.update(bench=bprocs)
             # ... and ONE rank on the real backend (RCCL, a process group of one on this box's single GPU): it waits for
             # the four processes above to leave the card first (a box allows few processes on its GPU at once)
             log = open(out + '.rccl.log', 'w')
-            wait = [str(p.pid) for p in procs + bprocs]
-            DP_JOB.update(rccl=subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'rccl_worker.py'), str(_free_port()), out] + wait,
+            pids = [str(p.pid) for p in procs + bprocs]
+            DP_JOB.update(rccl=subprocess.Popen(wait + [os.path.join(ROOT, 'tests', 'rccl_worker.py'), str(_free_port()), out] + pids,
                                                 stdout=log, stderr=subprocess.STDOUT, env=shared_gpu))
 
 

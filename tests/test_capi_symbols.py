@@ -82,7 +82,7 @@ def test_descriptor_layout_matches_header():
     # 4 x int32 + 17 x int64 + 11 arrays of 16 pointers + precision, d_out_is_dz, defer_reduce, wpack_valid,
     # forward_only, reserved + wpack + drop_seed + drop_p, reserved2 + bn_sync_world, reserved3 + bn_sync_fn + bn_sync_ctx + n_valid
     # + bn_nbt (16 pointers) + sync_ws (ABI v18)
-    assert ctypes.sizeof(_lib.TowerDesc) == 16 + 17 * 8 + 11 * 16 * 8 + 24 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 16 * 8 + 8 + 8 + 8      # (+ fwd_ws, fwd_calls: ABI v19)
+    assert ctypes.sizeof(_lib.TowerDesc) == 16 + 17 * 8 + 11 * 16 * 8 + 24 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 16 * 8 + 8 + 8 + 8 + 8      # (+ fwd_ws, fwd_calls, source: ABI v19)
 
 
 def test_host_side_sizing_and_argument_errors(lib):

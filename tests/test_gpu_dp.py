@@ -19,6 +19,7 @@ def ranks():
     job = conftest.DP_JOB
     if not job:
         pytest.skip('the data-parallel workers were not started (run with -m gpu on a GPU box)')
+    conftest.release_dp_job()
     for r, p in enumerate(job['procs']):
         try:
             rc = p.wait(timeout=600)
@@ -230,6 +231,7 @@ def test_bench_runs_as_two_ranks():
     job = conftest.DP_JOB
     if not job.get('bench'):
         pytest.skip('the bench ranks were not started (run with -m gpu on a GPU box)')
+    conftest.release_dp_job()
     logs = []
     for r, p in enumerate(job['bench']):
         try:
@@ -280,6 +282,7 @@ def test_one_rank_on_rccl():
     job = conftest.DP_JOB
     if 'rccl' not in job:
         pytest.skip('the RCCL worker was not started (run with -m gpu on a GPU box)')
+    conftest.release_dp_job()
     p = job['rccl']
     try:
         rc = p.wait(timeout=900)

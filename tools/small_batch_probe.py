@@ -74,9 +74,16 @@ def main():
             idx1 = torch.randint(0, 20000, (nb * B,), device='cuda')
             idx2 = torch.randint(0, 20000, (nb * B,), device='cuda')
             lab = ((torch.rand(nb * B, device='cuda') > 0.5).double() * 2 - 1)
-            plan = BatchPlan(table, idx1, idx2, lab, np.arange(nb + 1) * B, list(range(nb)))
-            tr._planned_step(plan, 0)
-            t = timed(lambda i: tr._planned_step(plan, i % nb))
+            plan = BatchPlan(table, idx1, idx2, lab, np.arange(nb + 1) * B, list(range(nb)) * 8)
+            acc = torch.zeros((), dtype=torch.float64, device='cuda')
+            tr._run_planned(plan, True, acc)             # (whole passes, as optimize_model drives them: 512 steps each)
+            torch.cuda.synchronize()
+            t = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                tr._run_planned(plan, True, acc)
+                torch.cuda.synchronize()
+                t = min(t, (time.perf_counter() - t0) / len(plan.order))
             row += '  planned step %.1f us (%.2f M pairs/s)' % (t * 1e6, B / t / 1e6)
         print(row, flush=True)
 
