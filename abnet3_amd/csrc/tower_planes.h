@@ -89,7 +89,10 @@ static inline size_t pl_lds_bytes_bn(int np) { return pl_lds_bytes(np) + 4 * PL_
 #define PSTAMPF(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 128 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 // (s_memtime counts from a base of its own per CU group: a stamp that is compared BETWEEN workgroups takes the constant 100 MHz clock)
 #define PSTAMPR(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 128 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// every WAVE's clock at the end of layer l's k-loop: slots 64 + 8 l + wave (tools/planes_wave_stamps.py)
+#define PSTAMPW(l) do { if (p.stamps && (threadIdx.x & 63) == 0 && (l) < 8) p.stamps[(size_t)blockIdx.x * 128 + 64 + 8 * (l) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define PSTAMPW(l) do {} while (0)
 #define PSTAMPF(slot) do {} while (0)
 #define PSTAMPR(slot) do {} while (0)
 #endif
@@ -437,6 +440,12 @@ constexpr bool PL_HANDOVER = true;
 #else
 constexpr bool PL_HANDOVER = false;
 #endif
+#ifndef PL_THROTTLE_LAG
+#define PL_THROTTLE_LAG 0
+#endif
+#ifndef PL_THROTTLE_NAP
+#define PL_THROTTLE_NAP 2
+#endif
 template <int NP>
 struct WeightRing {
     __amdgpu_buffer_rsrc_t rs;
@@ -476,7 +485,26 @@ __device__ __forceinline__ void ring_kloop(f32x16* acc, WeightRing<NP>& ring, co
     bf16x8 af[2][NP];
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(ab + pl * 1024);
+#if PL_THROTTLE_LAG > 0
+    // (experiment, round 6: the waves of a workgroup kept within PL_THROTTLE_LAG steps of the slowest -- a wave that is
+    // further ahead naps: its weight requests leave the CU's in-order L1 to the others, who would otherwise finish
+    // thousands of cycles behind it with only their own few loads in flight)
+    __shared__ int pl_prog[PL_WAVES];
+    const int my_wave = threadIdx.x >> 6;
+#endif
     for (int s0 = 0; s0 < my_steps; s0 += PL_DEPTH) {
+#if PL_THROTTLE_LAG > 0
+        {
+            if (lane == 0) pl_prog[my_wave] = s0;
+            int mn = 1 << 20;
+#pragma unroll
+            for (int w = 0; w < PL_WAVES; ++w) {
+                const unsigned v = (unsigned)pl_prog[w];
+                mn = v < (unsigned)mn ? (int)v : mn;
+            }
+            if (s0 - mn > PL_THROTTLE_LAG) __builtin_amdgcn_s_sleep(PL_THROTTLE_NAP);
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < PL_DEPTH; ++i) {
             const int s = s0 + i;
@@ -515,6 +543,9 @@ __device__ __forceinline__ void ring_kloop(f32x16* acc, WeightRing<NP>& ring, co
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#if PL_THROTTLE_LAG > 0
+    if (lane == 0) pl_prog[my_wave] = 1 << 20;          // (done: nobody waits for this wave)
+#endif
     ring.filled = chain_next;
 }
 
@@ -875,6 +906,7 @@ __device__ __forceinline__ void planes_layer(const PlanesFwdP& p, int l, char* _
 #pragma unroll
         for (int j = 0; j < BPW; ++j) cinv[j] *= cin;
     }
+    PSTAMPW(l);
     PSTAMPF(3 + 5 * l);
 
     // epilogue.  Register q of block j is output feature 32 (blk0 + j) + (q & 3) + 8 (q >> 2) + 4 h of
