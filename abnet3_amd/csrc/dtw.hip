@@ -436,10 +436,17 @@ __device__ unsigned long long g_dtw_cycles[16];
 #define PSTAMP_FLUSH(base) do {} while (0)
 #endif
 constexpr int GS = 2;                                  // slots per workgroup
-struct GangDesc {                                      // what a slot does in one round (LDS; written by its producer)
+struct GangDesc {                                      // what a slot does in one round (LDS; written by its producer, or by the dealer)
     int32_t pair;                                      // -1: slot idle
     int32_t N, M, nbands, nrounds, band, u, pad;
     int64_t dir_off;
+    // the dealt schedule (SCHED = 1)
+    int64_t xoff, yoff;                                // float offsets of the pair's tokens
+    int32_t set;                                       // which of the gang's two sets of boundary rows / norm strips the pair uses
+    int32_t dpp;                                       // this band's upper neighbour is swept by the OTHER half, one round ahead: lane 32 takes its
+                                                       // row above over the wavefront shift, nothing comes from memory
+    int32_t feed;                                      // the band's last row goes to memory for the band below
+    int32_t final;                                     // no slot has work in this round or any later one
 };
 
 // mn = min(a, b); bits = 2 bits + (a < b)
@@ -479,13 +486,24 @@ __device__ __forceinline__ double dpp_shr1_f64(double v)      // lane l <- lane 
 #endif
 // (Two gangs per workgroup -- six wavefronts that land as 2 producers + 1 consumer on every SIMD, where five one-gang
 // workgroups land as 3P+C, 3P+C, 2P+2C, 2P+C -- were measured in round 6: twelve wavefronts per CU instead of fifteen cost 12 %.)
-template <bool FLAGS>
+// SCHED = 1 (round 6, the default): the gang's two slots are DEALT the bands of a stream of pairs in turn -- band b of a
+// pair to slot 0, band b + 1 to slot 1 ONE ROUND LATER, b + 2 to slot 0 when it is free again ... -- by wavefront 0, three
+// rounds ahead of the sweep (desc[round % 4]).  A band whose upper neighbour runs in the other half one round ahead is
+// coupled to it inside the consumer wavefront: the two halves are then one 64-row band on the skewed diagonal, lane 32's
+// row above arrives over the same wavefront shift as everybody's, no boundary row goes through memory -- and the lower
+// band's producer asks for token 2's rows ONE round after the upper band's did: the XCD's L2 still has them, so token 2
+// crosses the fabric once per 64 rows instead of once per 32 (6.8 -> ~4 B / cell).  Every other band takes its row above
+// from the gang's boundary rows as before, at least three rounds behind the band that writes them.  Nothing idles: when a
+// pair has an odd band left, the other slot starts the next pair.
+// SCHED = 0: round 4's schedule, every slot walks a pair of its own (ABN_DTW_SCHED=0).
+template <bool FLAGS, int SCHED>
 __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(ABN_GANG_OCC, ABN_GANG_OCC))) void dtw_gang_kernel(DtwP P)
 {
+    constexpr int DR = SCHED ? 4 : 2;                                            // rounds of descriptors alive at once
     __shared__ __attribute__((aligned(16))) float blk[GS][3][BAND][BAND];      // [slot][round % 3][column][row]
-    __shared__ __attribute__((aligned(16))) float ny_s[GS][BAND];
+    __shared__ __attribute__((aligned(16))) float ny_s[2][GS][BAND];           // [round parity][slot]
     __shared__ double top_s[GS][BAND];
-    __shared__ GangDesc desc[2][GS];                                             // [round parity][slot]
+    __shared__ GangDesc desc[DR][GS];                                            // [round % DR][slot]
     const int gid = (int)blockIdx.x;
     auto all_idle = [&](int par) { return desc[par][0].pair < 0 && desc[par][1].pair < 0; };
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, n = lane & 31;
@@ -498,6 +516,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
         bool exhausted = false;
         int pair = -1, N = 0, M = 0, nbands = 0, nrounds = 0, band = 0, u = 0;
         int64_t xoff = 0, yoff = 0, dir_off = 0;
+        int set = q, dpp = 0;                           // SCHED = 1: the pair's set of boundary rows / norm strip; coupled to the other half
         float xf[KST], nx = 1.0f;
         uint32_t orbits = 0u;                           // OR of the distances' bit patterns: >= 0x7f800000 iff one is NaN
         auto fetch = [&]() {                            // next pair of the queue (wave-uniform values)
@@ -537,17 +556,19 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
         // used, and behind the token the descriptor returns 0).
         u32x4 yq[10];
         float ynq = 1.0f;
-        float* const ynorm = P.ynorm + (int64_t)(GS * gid + q) * P.mcap;
+        float* const ynorm_base = P.ynorm + (int64_t)(GS * gid) * P.mcap;      // the gang's two strips (SCHED = 0: one per slot; 1: one per pair in flight)
         auto request_y = [&]() {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.feats2 + yoff), 0, M * (D * 4), 0x00020000);
             const int row = min(u * BAND + n, M - 1);
             const int vo = row * (D * 4) + (band > 0 ? 4 * half : 0);
 #pragma unroll
             for (int i = 0; i < 10; ++i) yq[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 16 * i, 0);
-            if (band > 0) ynq = __hip_atomic_load(&ynorm[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (a coupled band takes the norms from its upper neighbour's LDS copy of the round before: that band may have
+            // computed them only a round ago)
+            if (band > 0 && !dpp) ynq = __hip_atomic_load(&ynorm_base[(int64_t)set * P.mcap + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        // the block of (band, u) into buffer `buf` from the rows requested before
-        auto produce = [&](int buf) {
+        // the block of (band, u) into buffer `buf` from the rows requested before; par: the round's parity (ny_s)
+        auto produce = [&](int buf, int par) {
             f32x16 acc;
             float ny;
             {
@@ -578,14 +599,14 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                     }
                     ny = sqrtf(((r01.x + r01.y) + (r23.x + r23.y)) + ((r45.x + r45.y) + (r67.x + r67.y)));
                     if (nbands > 1 && half == 0 && u * BAND + n < M)
-                        __hip_atomic_store(&ynorm[u * BAND + n], ny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&ynorm_base[(int64_t)set * P.mcap + u * BAND + n], ny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 10; ++i) chain(i, __uint_as_float(yq[i].x), __uint_as_float(yq[i].z));
-                    ny = ynq;
+                    ny = dpp ? ny_s[par ^ 1][q ^ 1][n] : ynq;      // (coupled: the same rows, a round ago, in the other slot)
                 }
             }
-            if (half == 0) ny_s[q][n] = ny;
+            if (half == 0) ny_s[par][q][n] = ny;
             wave_lds_sync();                                               // ny_s (this wave's own writes)
             const bool plain = __all(norm_is_plain(nx) && norm_is_plain(ny));
             // accumulator c of lane (n, h) is column m = (c & 3) + 8 (c >> 2) + 4 h of the block, row n
@@ -596,7 +617,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                 for (int g = 0; g < 4; ++g) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (u * BAND + 8 * g >= M) break;                       // columns past the token's end: never read by the sweep
-                    const float4 ny4 = *reinterpret_cast<const float4*>(&ny_s[q][8 * g + 4 * half]);
+                    const float4 ny4 = *reinterpret_cast<const float4*>(&ny_s[par][q][8 * g + 4 * half]);
                     const float nyv[4] = {ny4.x, ny4.y, ny4.z, ny4.w};
                     if constexpr (decltype(pl)::value) {          // two cells per instruction (dist_ref.h)
 #if !defined(ABN_EXP_NOEPI) && !defined(ABN_EXP_NOFAST)
@@ -644,7 +665,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
             };
             if (plain) epilogue(std::true_type{}); else epilogue(std::false_type{});
             orbits |= ob;
-            if (band + 1 == nbands && (u + 1) * BAND >= M) {               // the pair's last block
+            if ((SCHED || band + 1 == nbands) && (u + 1) * BAND >= M) {    // the pair's last block (SCHED = 1: this band's -- a pair's bands are spread over both producers)
                 const bool isbad = __any(orbits >= 0x7f800000u);
                 if (isbad) {                                                // utils.py:59: NaN (or negative) distance
                     if (FLAGS) {                                            // in place before this round's barrier, behind which the consumer flags the pair
@@ -656,6 +677,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
             }
         };
 
+        if constexpr (SCHED == 0) {
         // The wave's state is one round ahead of what it publishes: while the block of round t + 1 is
         // computed, the rows of round t + 2 are already requested (they arrive under the epilogue and the
         // barrier).  Iteration t = -1 is the prologue: the first pair's first block, complete before the
@@ -676,7 +698,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
 #if !ABN_GANG_YPF
             if (have) request_y();
 #endif
-            if (have) produce((t + 1) % 3);
+            if (have) produce((t + 1) % 3, 0);
             PSTAMP(1);
             bool newband = false;
             if (pair >= 0) {                                                // on to round t + 2
@@ -692,6 +714,134 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
             __syncthreads();                                                // round t + 1 is complete; the consumer has finished round t
             PSTAMP(3);
         }
+        } else {
+        // ---- the dealer (wavefront 0, scalar work): the schedule of round r for both slots -> desc[r % 4].  Its state lives in
+        // LDS (read and written by this wavefront alone, once per round): in registers it cost the producer 48 spilled dwords
+        struct Slot { int pair, N, M, nb, nr, band, start, set, dpp, pad; int64_t x, y, dir; };
+        struct Dealer {
+            int exh, seq, turn;
+            int c_pair, c_N, c_M, c_nb, c_nr, c_set, c_next, c_last;       // the pair being dealt
+            int64_t c_x, c_y, c_dir;
+            Slot s0, s1;
+        };
+        __shared__ Dealer dl;
+        if (q == 0 && lane == 0) {
+            dl.exh = 0; dl.seq = 0; dl.turn = 0; dl.c_pair = -1; dl.c_nb = 0; dl.c_next = 0; dl.c_last = -1000;
+            dl.s0.pair = -1; dl.s1.pair = -1;
+        }
+        wave_lds_sync();
+#define d_exh dl.exh
+#define d_seq dl.seq
+#define d_turn dl.turn
+#define c_pair dl.c_pair
+#define c_N dl.c_N
+#define c_M dl.c_M
+#define c_nb dl.c_nb
+#define c_nr dl.c_nr
+#define c_set dl.c_set
+#define c_next dl.c_next
+#define c_last dl.c_last
+#define c_x dl.c_x
+#define c_y dl.c_y
+#define c_dir dl.c_dir
+#define s0 dl.s0
+#define s1 dl.s1
+        auto deal = [&](int r) {
+            if (s0.pair >= 0 && r >= s0.start + s0.nr) s0.pair = -1;
+            if (s1.pair >= 0 && r >= s1.start + s1.nr) s1.pair = -1;
+            // the slot whose turn it is takes the stream's next band, if it is free and the band may start (twice: both may start in one round)
+            auto try_assign = [&]() -> bool {
+                Slot& me = d_turn ? s1 : s0;
+                if (me.pair >= 0) return false;
+                if (c_pair < 0 || c_next >= c_nb) {                         // the stream's next pair
+                    c_pair = -1;
+                    if (d_exh) return false;
+                    int idx = 0;
+                    if (lane == 0) idx = atomicAdd(P.counter, 1);
+                    idx = __builtin_amdgcn_readfirstlane(idx);
+                    if (idx >= P.npairs) { d_exh = true; return false; }
+                    const int p = __builtin_amdgcn_readfirstlane(P.order[idx]);
+                    const PairMeta* m = P.meta + p;
+                    c_pair = p;
+                    c_N = __builtin_amdgcn_readfirstlane(m->n1); c_M = __builtin_amdgcn_readfirstlane(m->n2);
+                    c_nb = __builtin_amdgcn_readfirstlane(m->nbands); c_nr = __builtin_amdgcn_readfirstlane(m->nrounds);
+                    c_x = readlane64(m->off1, 0) * D; c_y = readlane64(m->off2, 0) * D; c_dir = readlane64(m->dir_off, 0);
+                    c_set = d_seq & 1; ++d_seq;                             // (at most two pairs are in flight, consecutive ones)
+                    c_next = 0; c_last = -1000;
+                }
+                // a band may start one round behind its upper neighbour if that one runs in slot 0 and this one goes to
+                // slot 1 (coupled inside the consumer wavefront), else three rounds behind it (through the boundary rows)
+                bool couple = false;
+                if (c_next > 0) {
+                    couple = d_turn == 1 && r - c_last == 1 && s0.pair == c_pair && s0.band == c_next - 1;
+                    if (!couple && r - c_last < 3) return false;
+                }
+                me.pair = c_pair; me.N = c_N; me.M = c_M; me.nb = c_nb; me.nr = c_nr; me.band = c_next; me.start = r;
+                me.set = c_set; me.dpp = couple ? 1 : 0; me.x = c_x; me.y = c_y; me.dir = c_dir;
+                c_last = r; ++c_next; d_turn ^= 1;
+                return true;
+            };
+            if (try_assign()) (void)try_assign();
+            const bool fin = d_exh && s0.pair < 0 && s1.pair < 0 && (c_pair < 0 || c_next >= c_nb);
+            if (lane == 0) {
+                auto put = [&](const Slot& me, int k, bool lower_coupled) {
+                    GangDesc d;
+                    d.pair = me.pair; d.N = me.N; d.M = me.M; d.nbands = me.nb; d.nrounds = me.nr; d.band = me.band;
+                    d.u = r - me.start; d.pad = 0; d.dir_off = me.dir; d.xoff = me.x; d.yoff = me.y; d.set = me.set; d.dpp = me.dpp;
+                    // (the last row goes to memory unless the band below is coupled to this one: known from the band's second round on)
+                    d.feed = me.band + 1 < me.nb && !lower_coupled ? 1 : 0;
+                    d.final = fin ? 1 : 0;
+                    desc[r & 3][k] = d;
+                };
+                put(s0, 0, s1.pair == s0.pair && s1.band == s0.band + 1 && s1.dpp != 0);
+                put(s1, 1, false);
+            }
+            wave_lds_sync();
+        };
+#undef d_exh
+#undef d_seq
+#undef d_turn
+#undef c_pair
+#undef c_N
+#undef c_M
+#undef c_nb
+#undef c_nr
+#undef c_set
+#undef c_next
+#undef c_last
+#undef c_x
+#undef c_y
+#undef c_dir
+#undef s0
+#undef s1
+        // this slot's context of a round, from its descriptor
+        auto take = [&](const GangDesc& d) {      // (wave-uniform values: scalar registers, as the round-4 producer's own state was)
+            pair = __builtin_amdgcn_readfirstlane(d.pair); N = __builtin_amdgcn_readfirstlane(d.N); M = __builtin_amdgcn_readfirstlane(d.M);
+            nbands = __builtin_amdgcn_readfirstlane(d.nbands); band = __builtin_amdgcn_readfirstlane(d.band); u = __builtin_amdgcn_readfirstlane(d.u);
+            xoff = readlane64(d.xoff, 0); yoff = readlane64(d.yoff, 0);
+            set = __builtin_amdgcn_readfirstlane(d.set); dpp = __builtin_amdgcn_readfirstlane(d.dpp);
+        };
+        // Round r's descriptors are written three iterations before the sweep reads them: iteration t produces the blocks
+        // of round t + 1 (rows asked for at iteration t - 1) and asks for the rows of round t + 2, whose band's rows of
+        // token 1 are fetched behind the old band's last block.
+        if (q == 0) { deal(0); deal(1); }
+        __syncthreads();
+        take(desc[0][q]);
+        int held_pair = -1, held_band = -1;                                 // what xf / nx hold
+        if (pair >= 0) { load_x(); held_pair = pair; held_band = band; if (u * BAND < M) request_y(); }
+        for (int t = -1;; ++t) {
+            if (t >= 0 && desc[t & 3][0].final) break;
+            if (q == 0) deal(t + 3);
+            take(desc[(t + 1) & 3][q]);
+            if (pair >= 0 && u * BAND < M) produce((t + 1) % 3, (t + 1) & 1);
+            take(desc[(t + 2) & 3][q]);
+            if (pair >= 0) {
+                if (pair != held_pair || band != held_band) { load_x(); held_pair = pair; held_band = band; }
+                if (u * BAND < M) request_y();
+            }
+            __syncthreads();                                                // round t + 1 is complete; the consumer has finished round t
+        }
+        }
         PSTAMP_FLUSH(0);
     } else {
         // =========================== consumer ===========================
@@ -700,7 +850,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
 #endif
         if (ABN_GANG_CPRIO) __builtin_amdgcn_s_setprio(ABN_GANG_CPRIO);       // the sweep is the workgroup's dependency chain
         const double INF = __builtin_inf();
-        double* const bnd = P.bound + (int64_t)(GS * gid + half) * 2 * bstride + 32;
+        double* const bnd_slot = P.bound + (int64_t)(GS * gid + half) * 2 * bstride + 32;      // (SCHED = 0: a slot's own two rows)
         double p1 = INF, upprev = INF;
         uint32_t bits = 0u;
         // the boundary values of the NEXT round, requested while this one is swept (same band: the row
@@ -708,11 +858,16 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
         double pf_top = INF;
         int pf_pair = -1, pf_band = -1, pf_u = -1;
         constexpr int PF = 4;                                               // LDS reads in flight ahead of the step that uses them
+        if (SCHED) __syncthreads();                                         // (the dealer's first two rounds)
         __syncthreads();                                                    // the first blocks are in place
         PSTAMP_INIT;
         for (int t = 0;; ++t) {
-            if (all_idle(t & 1)) break;
-            const GangDesc& d = desc[t & 1][half];
+            if (SCHED ? desc[t & (DR - 1)][0].final != 0 : all_idle(t & 1)) break;
+            const GangDesc& d = desc[t & (DR - 1)][half];
+            // SCHED = 1: the pair's set of boundary rows (two pairs at most are in flight in a gang); coupled = this half's row
+            // above is the other half's lane 31, one round ahead on the same skewed diagonal
+            double* const bnd = SCHED ? P.bound + (int64_t)(GS * gid + d.set) * 2 * bstride + 32 : bnd_slot;
+            const bool coupled = SCHED && d.dpp != 0;
             const int pair = d.pair, N = d.N, M = d.M, nbands = d.nbands, nrounds = d.nrounds, band = d.band, u = d.u;
             const bool active = pair >= 0;
             if (active && u == 0) {                      // a band starts: fresh diagonals
@@ -722,7 +877,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
             const int i0 = band * BAND, j0 = u * BAND;
             const double* const bin = bnd + (int64_t)((band & 1) ^ 1) * bstride;
             double topv = INF;
-            if (active && band > 0 && j0 + n < M) {
+            if (active && band > 0 && !coupled && j0 + n < M) {
                 const bool hit = pf_pair == pair && pf_band == band && pf_u == u;
                 topv = pf_top;
                 if (!hit) topv = __hip_atomic_load(&bin[j0 + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -730,7 +885,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
             top_s[half][n] = topv;
             wave_lds_sync();
             PSTAMP(8);
-            if (active && band > 0 && u + 1 < nrounds) {                    // stays inside the padded row (plan_ws)
+            if (active && band > 0 && !coupled && u + 1 < nrounds) {        // stays inside the padded row (plan_ws)
                 pf_top = __hip_atomic_load(&bin[j0 + BAND + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 pf_pair = pair; pf_band = band; pf_u = u + 1;
             }
@@ -739,9 +894,10 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
             const float* const aprev = &blk[half][prev][BAND - 1][n] - (n - 1) * BAND;   // + e * BAND: column 32 + e - n of the block before
             const double* const tops = top_s[half];
             const bool rowok = active && i0 + n < N;
-            const bool feed = active && band + 1 < nbands && n == BAND - 1;     // the band's last row feeds the next band
+            const bool feed = active && (SCHED ? d.feed != 0 : band + 1 < nbands) && n == BAND - 1;     // the band's last row feeds the next band
             double* const bout = bnd + (int64_t)(band & 1) * bstride + (j0 - (BAND - 1));
             const int jb = j0 - n;
+            const bool take_top = n == 0 && !coupled;           // (a coupled band's first row takes lane 31's cost: the shift crosses the halves)
             uint32_t* const dptr = P.dirs + d.dir_off + ((int64_t)(band * 2 * nrounds + 2 * u) * BAND + n);
             float dq[PF];
             double tq[PF];
@@ -768,7 +924,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                         tq[e % PF] = tops[e + PF];
                     }
                     double up = dpp_shr1_f64(p1);
-                    up = n == 0 ? topc : up;
+                    up = take_top ? topc : up;
                     double b1, best;
                     min_lt(up, upprev, b1, bits);            // up < diag
                     min_lt(p1, b1, best, bits);              // left < min(diag, up)
@@ -1086,8 +1242,14 @@ static bool stream_order_events(hipEvent_t* a, hipEvent_t* b)
 static void launch_gang(bool flags, int64_t ng, hipStream_t st, const DtwP& P)
 {
     const dim3 grid((unsigned)ng), block(64 * (GS + 1));
-    if (flags) hipLaunchKernelGGL(dtw_gang_kernel<true>, grid, block, 0, st, P);
-    else hipLaunchKernelGGL(dtw_gang_kernel<false>, grid, block, 0, st, P);
+    static const bool dealt = !(getenv("ABN_DTW_SCHED") && atoi(getenv("ABN_DTW_SCHED")) == 0);
+    if (dealt) {
+        if (flags) hipLaunchKernelGGL((dtw_gang_kernel<true, 1>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((dtw_gang_kernel<false, 1>), grid, block, 0, st, P);
+    } else {
+        if (flags) hipLaunchKernelGGL((dtw_gang_kernel<true, 0>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((dtw_gang_kernel<false, 0>), grid, block, 0, st, P);
+    }
 }
 
 static int dtw_batched_impl(const float* feats1, int64_t rows1, const float* feats2, int64_t rows2,
