@@ -2371,8 +2371,11 @@ int abn_tower_reduce_step(const abn_tower_desc* t, int64_t rows, const float* sc
             W.tiles_k = (W.kblk + 1) / 2;
             W.first_wg = n_wg;
             W.w_off = t->dW[l] - grads; W.b_off = t->db[l] - grads;
-            n_wg += (((W.nblk + 1) / 2 + 1) / 2 * 2) * ((W.tiles_k + 3) / 4 * 4);      // (whole 2 x 4 chunks of tiles: a multiple of 8)
+            n_wg += ((W.nblk + 1) / 2) * W.tiles_k;
         }
+        w.n_tiles = n_wg;
+        w.per_xcd = (n_wg + 7) / 8;
+        n_wg = 8 * w.per_xcd;
         w.o = make_optp(kind, lr, hp0, hp1, eps, step, grad_scale);
         w.params = params; w.grads = grads; w.s1 = state1; w.s2 = state2;
         w.fail_word = nullptr;

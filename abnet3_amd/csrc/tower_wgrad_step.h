@@ -33,7 +33,7 @@ struct WgsLayer {
     const float* amax_a;
     int N, K, nblk, kblk;
     int tiles_k;             // 64-wide tiles along K (+ the bias column)
-    int first_wg;
+    int first_wg;            // index of the layer's first tile among all layers' tiles
     int64_t w_off, b_off;    // float offsets of W_l / b_l in the flat parameter, gradient and state buffers
 };
 struct WgsP {
@@ -47,6 +47,7 @@ struct WgsP {
     float* s2;
     const unsigned* fail_word;
     int32_t* step_ctr;       // abn_step_source: advanced once per step (or null)
+    int n_tiles, per_xcd;    // tiles of all layers (L[].first_wg: a layer's first); tiles per XCD = ceil(n_tiles / 8)
 };
 
 constexpr int WGS_DEPTH = 4;                       // row steps in flight per wave
@@ -70,23 +71,20 @@ __global__ __launch_bounds__(WGS_NT) void wgrad_step_small_kernel(WgsP p)
     WGS_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int li = 0;
-    while (li + 1 < p.n_layers && (int)blockIdx.x >= p.L[li + 1].first_wg) ++li;
-    const WgsLayer& L = p.L[li];
     // Placement.  Every tile reads ALL row steps of its two dZ blocks and its two [A | 1] blocks, and the images were
     // written by the launches before (another XCD's L2, or none): dealt out in launch order each of the eight L2s would
     // fetch every image whole.  Workgroups b and b + 8 are observed to share an XCD (round-robin dispatch: speed only), so
-    // XCD x gets a compact rectangle of the layer's tile grid -- chunks of 2 x 4 tiles: a quarter of dZ_l and half of
-    // [A | 1] per XCD on a 8 x 8 grid.  The grid is padded to whole chunks (first_wg to multiples of 8): a workgroup on
-    // padding leaves at once.
-    const int local = blockIdx.x - L.first_wg;
+    // XCD x gets a CONTIGUOUS run of the tiles in (layer, tile row, tile column) order -- p.per_xcd of them: three tile
+    // rows of one layer at C5's shapes, i.e. 3/8 of that layer's dZ image and its [A | 1] image once.
+    const int ti = (int)(blockIdx.x & 7) * p.per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= p.per_xcd || ti >= p.n_tiles) return;
+    int li = 0;
+    while (li + 1 < p.n_layers && ti >= p.L[li + 1].first_wg) ++li;
+    const WgsLayer& L = p.L[li];
+    const int local = ti - L.first_wg;
     const int tiles_n = (L.nblk + 1) / 2;
-    const int pk = (L.tiles_k + 3) / 4 * 4, pn_tiles = (tiles_n + 1) / 2 * 2;
-    const int per_xcd = pn_tiles * pk / 8;
-    const int v = (local & 7) * per_xcd + (local >> 3);
-    const int chunk = v >> 3, within = v & 7, chunks_k = pk / 4;
-    const int tn = 2 * (chunk / chunks_k) + (within >> 2), tk = 4 * (chunk % chunks_k) + (within & 3);
-    if (tn >= tiles_n || tk >= L.tiles_k) return;
+    const int tn = local / L.tiles_k, tk = local - tn * L.tiles_k;
+    if (tn >= tiles_n) return;
     constexpr int FR = tile_bytes<2>();
     // blocks past the matrix are clamped copies of the last one: computed, never stored
     const int nb0 = 2 * tn, kb0 = 2 * tk;

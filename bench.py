@@ -108,9 +108,9 @@ def _time_launches(torch, fn, reps):
 
 def _traffic(kernel):
     """HBM bytes per launch from the TCC counters (FETCH_SIZE x2 per the gfx950
-    correction + WRITE_SIZE), collected by tools/collect_traffic.sh in separate
-    --pmc passes and committed under profiles/."""
-    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+    correction + WRITE_SIZE), collected by tools/collect_profiles.sh in separate
+    --pmc passes and committed under profiles/ (the newest round's file that names the kernel)."""
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
         try:
             t = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc_traffic.json' % rnd)))
             for name, v in t.items():
@@ -126,7 +126,7 @@ def _trace_us(kernel):
     summary of this command (profiles/rNN_bench_kernel_stats.csv): which launch is dominant IN THE STEP is read there --
     a kernel re-run alone, back to back, sees another cache than between its neighbours."""
     import csv
-    for rnd in ('r05', 'r04', 'r03', 'r02'):
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02'):
         path = os.path.join(ROOT, 'profiles', '%s_bench_kernel_stats.csv' % rnd)
         try:
             for row in csv.DictReader(open(path)):
@@ -544,7 +544,7 @@ def dtw_bench(torch, P, rank, world, reps=3, cpu_pairs=4000):
            # call (TCC counters collected under rocprofv3, profiles/) over this run's time -- what the kernel
            # really pulls -- beside the ALGORITHMIC bytes (inputs once (N+M)*40*4, paths <= (N+M)*8): the
            # cost matrix never leaves the CU, 2-bit back-pointers and the paths are the writes, the fetches
-           # are token 2's rows once per 32-row band of token 1.
+           # are token 2's rows once per 64 rows of token 1 (two coupled 32-row bands, round 6) and the boundary rows.
            'roofline': {'bound': 'valu', 'achieved': round(cells * 100.0 / best / 1e12, 2), 'peak': 157.3,
                         'unit': 'TFLOP/s', 'flop_per_cell': 100,
                         'note': 'VALU-bound: exact division / acosf / pi per cell (all 64 lanes of a producer wavefront per '
