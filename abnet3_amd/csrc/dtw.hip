@@ -1153,8 +1153,15 @@ __global__ void dist_plain_f64_kernel(const double* __restrict__ x, int N, const
 __global__ void arccos_kernel(const float* __restrict__ x, int64_t n, int over_pi, float* __restrict__ out)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float a = acosf_ref(x[i]);
-        out[i] = over_pi ? div_pi(a) : a;
+        const float v = x[i];
+        if ((over_pi & 2) && fabsf(v) < 0.5f && fabsf(v) > bits_f32(0x32800000u)) {
+            // the gang kernel's straight-line form of the first range (what quotients_small4_all admits), one cell per lane
+            const f32x4 a4 = acosf_small4(splat4(v));
+            out[i] = (over_pi & 1) ? div_pi4(a4).x : a4.x;
+            continue;
+        }
+        const float a = acosf_ref(v);
+        out[i] = (over_pi & 1) ? div_pi(a) : a;
     }
 }
 

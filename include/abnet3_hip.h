@@ -520,7 +520,9 @@ int abn_cosine_distance_f64(const double* x, int64_t N, const double* y, int64_t
  * path (utils.py:50,53: scipy.arccos = np.arccos = libm acosf): out[i] = acosf(x[i]),
  * bit-identical to glibc 2.35's acosf for every float32 argument (NaN outside [-1, 1]);
  * over_pi != 0: out[i] = acosf(x[i]) / float32(pi), the correctly rounded float32 quotient
- * (utils.py:53).  The cell function of abn_dtw_batched, exposed for verification. */
+ * (utils.py:53).  The cell function of abn_dtw_batched, exposed for verification.
+ * over_pi bit 0: divide by pi; bit 1: arguments with 2^-26 < |x| < 0.5 take the straight-line
+ * statements the gang kernel uses when a wavefront's cells all lie in that range (same bits). */
 int abn_arccos_f32(const float* x, int64_t n, int over_pi, float* out, void* stream);
 
 /* last_non_linearity='softmax' (abnet3/model.py:161-166: nn.Softmax() after the output

@@ -108,12 +108,14 @@ def test_device_arccos_equals_libm_acosf():
     import ctypes
     L.abn_oracle_acosf_array.restype = None
     L.abn_oracle_acosf_array.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
-    for over_pi in (0, 1):                  # acosf(x), and acosf(x) / float32(pi) as utils.py:53 divides
+    # acosf(x), and acosf(x) / float32(pi) as utils.py:53 divides; bit 1: the straight-line statements of the first range
+    # (2^-26 < |x| < 0.5) the gang kernel takes when a wavefront's cells all lie in it -- the same bits
+    for over_pi in (0, 1, 2, 3):
         out = torch.empty_like(xd)
         _lib.check(lib.abn_arccos_f32(_lib.ptr(xd), xd.numel(), over_pi, _lib.ptr(out), _lib.stream()), 'abn_arccos_f32')
         got = out.cpu().numpy()
         ref = np.empty_like(x)
-        L.abn_oracle_acosf_array(x.ctypes.data_as(ctypes.c_void_p), len(x), over_pi, ref.ctypes.data_as(ctypes.c_void_p))
+        L.abn_oracle_acosf_array(x.ctypes.data_as(ctypes.c_void_p), len(x), over_pi & 1, ref.ctypes.data_as(ctypes.c_void_p))
         nan = np.isnan(ref)
         assert (np.isnan(got) == nan).all()
         assert (got.view(np.uint32)[~nan] == ref.view(np.uint32)[~nan]).all()
