@@ -64,13 +64,21 @@ def build(force=False, verbose=False):
     objs = [o for o, _ in results]
     # (the library's digest is kept beside it: a file that something else wrote over it -- a diagnostic build -- is not ours)
     if force or any(c for _, c in results) or _stale(LIB, objs) or _digest(LIB) != _recorded_digest():
-        cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        # Linked beside the target and renamed into place: several ranks may find the library stale at the same moment (the
+        # first start after an upgrade), and none of them may dlopen a file another one is still writing.
+        tmp = '%s.%d.tmp' % (LIB, os.getpid())
+        cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout)
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError('link failed')
-        with open(LIB + '.sha1', 'w') as f:
-            f.write(_digest(LIB))
+        digest = _digest(tmp)
+        os.replace(tmp, LIB)
+        with open(tmp, 'w') as f:
+            f.write(digest)
+        os.replace(tmp, LIB + '.sha1')
     return LIB
 
 

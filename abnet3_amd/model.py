@@ -348,11 +348,13 @@ def _segment_forward(seg, all_masks, n_calls, x1, x2, forward_only=False, n_vali
         desc.forward_only = 0
         mine = lib.abn_tower_path(_lib.C.byref(desc), _lib.ptr(x1), _lib.ptr(x2), rows, n_calls, 1, _lib.ptr(x1), 0, None) in (_lib.PATH_BN_LAYERS, _lib.PATH_BN_TOWER)
         if torch.cuda.is_current_stream_capturing():
-            agreed = bool(getattr(net, '_bn_sync_agreed', False)) and mine
+            agreed = bool(getattr(net, '_bn_sync_agreed', {}).get(id(seg), False)) and mine      # (this segment's own answer)
         else:
             from . import parallel
             agreed = parallel.all_agree(mine, getattr(net.bn_sync, 'group', None)) if getattr(net.bn_sync, 'collective', False) else mine
-            net._bn_sync_agreed = agreed
+            if not isinstance(getattr(net, '_bn_sync_agreed', None), dict):
+                net._bn_sync_agreed = {}
+            net._bn_sync_agreed[id(seg)] = agreed
         if agreed:
             synced = True
         else:
