@@ -499,7 +499,16 @@ __device__ __forceinline__ double dpp_shr1_f64(double v)      // lane l <- lane 
 template <bool FLAGS, int SCHED>
 __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(ABN_GANG_OCC, ABN_GANG_OCC))) void dtw_gang_kernel(DtwP P)
 {
+#ifdef ABN_EXP_HALFSYNC      // (measurement only, RACY: a workgroup barrier every other round -- what looser coupling of the waves could buy)
+    constexpr int DR = SCHED ? 8 : 2;
+#ifndef ABN_EXP_SYNCMASK
+#define ABN_EXP_SYNCMASK 1
+#endif
+#define GANG_ROUND_SYNC(t) do { if (((t) & ABN_EXP_SYNCMASK) == ABN_EXP_SYNCMASK) __syncthreads(); } while (0)
+#else
     constexpr int DR = SCHED ? 4 : 2;                                            // rounds of descriptors alive at once
+#define GANG_ROUND_SYNC(t) __syncthreads()
+#endif
     __shared__ __attribute__((aligned(16))) float blk[GS][3][BAND][BAND];      // [slot][round % 3][column][row]
     __shared__ __attribute__((aligned(16))) float ny_s[2][GS][BAND];           // [round parity][slot]
     __shared__ double top_s[GS][BAND];
@@ -791,7 +800,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                     // (the last row goes to memory unless the band below is coupled to this one: known from the band's second round on)
                     d.feed = me.band + 1 < me.nb && !lower_coupled ? 1 : 0;
                     d.final = fin ? 1 : 0;
-                    desc[r & 3][k] = d;
+                    desc[r & (DR - 1)][k] = d;
                 };
                 put(s0, 0, s1.pair == s0.pair && s1.band == s0.band + 1 && s1.dpp != 0);
                 put(s1, 1, false);
@@ -830,16 +839,16 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
         int held_pair = -1, held_band = -1;                                 // what xf / nx hold
         if (pair >= 0) { load_x(); held_pair = pair; held_band = band; if (u * BAND < M) request_y(); }
         for (int t = -1;; ++t) {
-            if (t >= 0 && desc[t & 3][0].final) break;
+            if (t >= 0 && desc[t & (DR - 1)][0].final) break;
             if (q == 0) deal(t + 3);
-            take(desc[(t + 1) & 3][q]);
+            take(desc[(t + 1) & (DR - 1)][q]);
             if (pair >= 0 && u * BAND < M) produce((t + 1) % 3, (t + 1) & 1);
-            take(desc[(t + 2) & 3][q]);
+            take(desc[(t + 2) & (DR - 1)][q]);
             if (pair >= 0) {
                 if (pair != held_pair || band != held_band) { load_x(); held_pair = pair; held_band = band; }
                 if (u * BAND < M) request_y();
             }
-            __syncthreads();                                                // round t + 1 is complete; the consumer has finished round t
+            GANG_ROUND_SYNC(t);                                             // round t + 1 is complete; the consumer has finished round t
         }
         }
         PSTAMP_FLUSH(0);
@@ -964,7 +973,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                 __builtin_amdgcn_s_waitcnt(0);
             }
             PSTAMP(9);
-            __syncthreads();
+            if (SCHED) GANG_ROUND_SYNC(t); else __syncthreads();
             PSTAMP(10);
         }
         PSTAMP_FLUSH(8);
@@ -1014,6 +1023,9 @@ __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __res
                                                            int32_t* path_len, int64_t path_stride,
                                                            double* total_cost)
 {
+#ifdef ABN_EXP_NOTB          // (measurement only: the fill alone; a racy fill's back-pointers must not be walked)
+    return;
+#endif
     __shared__ uint32_t win[2 * TB_ROWS][64];            // [group offset * 8 + row offset][thread]: conflict-free
     const int lane = threadIdx.x;
     const int idx = (int)(blockIdx.x * 64 + lane);

@@ -249,6 +249,13 @@ struct ReduceTable {
     int n_extra;
     int64_t extra_off[2 * ABN_MAX_LAYERS];
     int32_t extra_n[2 * ABN_MAX_LAYERS];
+    // slab_reduce_kernel (the data-parallel step: an all-reduce follows): the failure word of the resident BatchNorm tower's
+    // sync buffer and the tensors the tower's backward wrote itself (gamma / beta gradients).  Word set = the launches in
+    // front of this one gave up: this rank hands the all-reduce a ZERO gradient instead of their poison.
+    const unsigned* fail_word;
+    int n_own;
+    float* own[2 * ABN_MAX_LAYERS];
+    int32_t own_n[2 * ABN_MAX_LAYERS];
 };
 
 // sum_s slab[s][0..3] in a FIXED order: four interleaved partial sums (s mod 4), combined as
@@ -282,6 +289,10 @@ __device__ __forceinline__ f32x4 sum_slabs(const float* __restrict__ src, int S,
 // a thread's 4 consecutive elements never straddle two layers.
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, ReduceTable t)
 {
+    const bool dropped = t.fail_word && *t.fail_word != 0u;
+    if (dropped && blockIdx.x == 0)
+        for (int k = 0; k < t.n_own; ++k)
+            for (int i = threadIdx.x; i < t.own_n[k]; i += blockDim.x) t.own[k][i] = 0.0f;
     const int64_t n4 = (t.total + 3) / 4;
     for (int64_t q = t.begin / 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4;
          q += (int64_t)gridDim.x * blockDim.x) {
@@ -289,7 +300,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, ReduceTable 
         int l = 0;
         while (l + 1 < t.n_layers && i >= t.off[l + 1]) ++l;
         const int S = t.splits[l];
-        const f32x4 s = sum_slabs(slabs + i, S, t.slab_stride);
+        const f32x4 s = dropped ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : sum_slabs(slabs + i, S, t.slab_stride);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int64_t j = i + e - t.off[l];
@@ -1255,6 +1266,13 @@ static ReduceTable make_reduce_table(const abn_tower_desc* t, const BwdLayout& B
         rt.db[l] = t->db[l];
     }
     rt.total = B.off[nl - 1] + rt.nW[nl - 1] + rt.nb[nl - 1];
+    if (t->batch_norm && t->sync_ws) {
+        rt.fail_word = reinterpret_cast<const unsigned*>(t->sync_ws) + 16;
+        for (int l = 0; l < nl; ++l) {
+            if (t->dbn_w[l]) { rt.own[rt.n_own] = t->dbn_w[l]; rt.own_n[rt.n_own++] = (int32_t)rt.nb[l]; }
+            if (t->dbn_b[l]) { rt.own[rt.n_own] = t->dbn_b[l]; rt.own_n[rt.n_own++] = (int32_t)rt.nb[l]; }
+        }
+    }
     return rt;
 }
 

@@ -177,7 +177,8 @@ typedef struct abn_tower_desc {
      * launch counter the kernels' hand-over tags derive from and the hand-over granules themselves.  NULL: BatchNorm
      * training runs one launch per layer (ABN_PATH_BN_LAYERS).  Should a launch ever give up on a hand-over (the grid was
      * not resident: the outputs then read NaN) the buffer's failure word stays set: zero the buffer again.  While it is
-     * set abn_tower_reduce_step drops its step (parameters, state and gradients untouched). */
+     * set abn_tower_reduce_step drops its step (parameters, state and gradients untouched), and a backward WITHOUT
+     * defer_reduce (the data-parallel step: the caller all-reduces the gradient next) writes a ZERO gradient. */
     void* sync_ws;
     /* Optional, backward with defer_reduce only (ABI v19): the workspace of the forward whose gradients are pending (the
      * `ws` both calls were given) and that forward's n_calls, lent to abn_tower_reduce_step.  Small batches on the

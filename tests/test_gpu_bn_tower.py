@@ -333,3 +333,34 @@ def test_a_tower_that_gives_up_drops_the_step_and_recovers(split):
     m0 = float(tw.train_step((x1, x2, y), True))
     m2 = float(tw.train_step((x1, x2, y), True))
     assert abs(m0 - l0) <= 1e-5 * abs(m0) and abs(m2 - l2) <= 2e-5 * abs(m2), (l0, m0, l2, m2)
+
+
+def test_a_tower_that_gives_up_hands_the_all_reduce_a_zero_gradient(split):
+    """The data-parallel form of the step: the backward writes the gradient itself (an all-reduce follows, the optimizer's
+    launch cannot guard it).  With the failure word set the slab sum writes ZEROS -- weights, biases and the BatchNorm
+    gradients the tower's backward had written itself -- so the rank contributes nothing to that step instead of poison."""
+    from abnet3_amd import _lib
+    import abnet3_amd.loss as L
+    kw = dict(input_dim=40, num_hidden_layers=2, hidden_dim=500, output_dim=100, activation_layer='sigmoid', p_dropout=0.0, batch_norm=True)
+    rng = np.random.default_rng(6)
+    B = 512
+    x1, x2 = dev(rng.standard_normal((B, 40)).astype(np.float32)), dev(rng.standard_normal((B, 40)).astype(np.float32))
+    y = dev(rng.choice([1, -1], B))
+    net = build(kw, seed=10, precision=split)
+    net.train()
+    e1, e2 = net(x1, x2)
+    assert _lib.last_forward_path() == _lib.PATH_BN_TOWER
+    L.coscos2(avg=False)(e1, e2, y).backward()
+    assert _lib.last_backward_path() == _lib.PATH_BN_TOWER
+    assert all(float(q.grad.abs().max()) > 0 for k, q in net.named_parameters() if not is_pre_bn_bias(k, True))
+    for q in net.parameters():
+        q.grad = None
+    e1, e2 = net(x1, x2)
+    for seg in net._segment_list():
+        seg.sync_fail_word().fill_(1)
+    L.coscos2(avg=False)(e1, e2, y).backward()
+    for k, q in net.named_parameters():
+        assert q.grad is not None and float(q.grad.abs().max()) == 0.0, k
+    for seg in net._segment_list():
+        seg.recover_sync()
+
