@@ -549,6 +549,65 @@ def test_dtw_randomised_shapes_bit_exact(seed):
     assert dropped < P // 2
 
 
+def adversarial_pairs(rng, P, D=40, longest=260):
+    """P pairs of 40-d tokens whose lengths sit on and around the gang kernel's tile edges -- 1, 2, 31 .. 33, 63 .. 65, ... --
+    half of the time, anywhere in 1 .. longest otherwise; every sixth pair with tied rows, zero rows, copied frames or
+    extreme scales (what test_dtw_randomised_shapes_bit_exact does to single pairs)."""
+    edges = np.array([1, 2, 3, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129], dtype=np.int32)
+
+    def lengths():
+        return np.where(rng.random(P) < 0.5, rng.choice(edges, P), rng.integers(1, longest, P)).astype(np.int32)
+    n1, n2 = lengths(), lengths()
+    o1 = np.concatenate(([0], np.cumsum(n1)[:-1])).astype(np.int64)
+    o2 = np.concatenate(([0], np.cumsum(n2)[:-1])).astype(np.int64)
+    f1 = rng.standard_normal((int(n1.sum()), D)).astype(np.float32)
+    f2 = rng.standard_normal((int(n2.sum()), D)).astype(np.float32)
+    for p in range(0, P, 3):
+        a, b = f1[o1[p]:o1[p] + n1[p]], f2[o2[p]:o2[p] + n2[p]]
+        kind = (p // 3) % 6
+        if kind == 1 and n1[p] > 3:
+            a[1:n1[p] // 2] = a[0]
+        elif kind == 2 and n2[p] > 2:
+            b[n2[p] // 2] = 0.0
+        elif kind == 3:
+            a[0] = 0.0
+            b[-1] = 0.0
+        elif kind == 4:
+            a *= np.float32(1e-6)
+            b *= np.float32(3e5)
+        elif kind == 5 and n2[p] > 1:
+            b[:] = a[rng.integers(0, n1[p], n2[p])]
+    return f1, o1, n1, f2, o2, n2
+
+
+@pytest.mark.parametrize('seed,P,wgs', [(0, 6000, None), (1, 2000, None), (2, 300, None), (3, 3000, '1')])
+def test_dtw_many_pairs_per_gang_bit_exact(seed, P, wgs, monkeypatch):
+    """The dealt schedule under load (round 6): with thousands of pairs every gang works through a STREAM of pairs -- bands of
+    consecutive pairs in its two slots at once, coupled and uncoupled bands, sets of boundary rows changing hands, pairs of a
+    single band, of one column -- and every path, every length and the dropped pairs must equal the C oracle's, pair by pair."""
+    from abnet3_amd.utils import dtw_align_batch
+    from oracle import dtw_oracle as O
+    if wgs:
+        monkeypatch.setenv('ABN_DTW_WGS', wgs)               # one gang per CU: a dozen pairs per stream
+    rng = np.random.default_rng(7000 + seed)
+    f1, o1, n1, f2, o2, n2 = adversarial_pairs(rng, P)
+    res = dtw_align_batch(torch.from_numpy(f1).cuda(), o1, n1, torch.from_numpy(f2).cuda(), o2, n2)
+    stride = res.path1.shape[1]
+    q1, q2, ln, _ = O.dtw_batch(f1, o1, n1, f2, o2, n2, stride, threads=8)
+    got_len = res.path_len.cpu().numpy()
+    assert np.array_equal(got_len, ln), np.nonzero(got_len != ln)[0][:10]
+    g1, g2 = res.path1.cpu().numpy(), res.path2.cpu().numpy()
+    cols = np.arange(stride)[None, :]
+    mine = cols >= (stride - ln)[:, None]                   # right-aligned here, left-aligned in the oracle's rows
+    theirs = cols < ln[:, None]
+    assert np.array_equal(g1[mine], q1[theirs]) and np.array_equal(g2[mine], q2[theirs])
+    assert 0 < int((ln == 0).sum()) < P // 2                # (the copied-frames pairs: cos rounds above 1 somewhere)
+    cost = res.total_cost.cpu().numpy()
+    for p in rng.choice(np.nonzero(ln > 0)[0], 150, replace=False):
+        d = O.cosine_distance(f1[o1[p]:o1[p] + n1[p]], f2[o2[p]:o2[p] + n2[p]])
+        assert cost[p] == O.dtw_cost(d), p
+
+
 def test_dtw_traceback_beside_the_fill_equals_one_stream(monkeypatch):
     """abn_dtw_batched_overlap (the traceback on a second stream, polling the pairs' flags while the fill kernel runs)
     against the same call on one stream: paths, lengths, costs and dropped pairs bit for bit; 40-value frames (the gang
