@@ -49,6 +49,9 @@ struct Switches {
     bool wide;                // ABN_WIDE=0: small batches on the single-launch chains / per-layer GEMMs, not tower_wide.h
     int64_t wide_max_rows;    // ABN_WIDE_MAX_ROWS: most (virtual) rows the layer-per-launch kernels take, -1 = default
     int wide_max_groups;      // ABN_WIDE_MAXG: most workgroups per 32-row block of a layer-per-launch kernel (1 .. 8, default 8)
+    bool wgrad_step;          // ABN_WGRAD_STEP=0: small batches' weight gradients as slabs + slab_reduce_step_kernel, never tower_wgrad_step.h's one launch
+    bool dtw_dealt;           // ABN_DTW_SCHED=0: the gang DTW kernel on round 4's schedule (a pair per slot), not the dealt one
+    int oneshot_wgs;          // ABN_ONESHOT_WGS: most workgroups of abn_allreduce_oneshot (default 32, <= 256)
 };
 const Switches& switches();
 void reload_switches();

@@ -1261,7 +1261,7 @@ static bool stream_order_events(hipEvent_t* a, hipEvent_t* b)
 static void launch_gang(bool flags, int64_t ng, hipStream_t st, const DtwP& P)
 {
     const dim3 grid((unsigned)ng), block(64 * (GS + 1));
-    static const bool dealt = !(getenv("ABN_DTW_SCHED") && atoi(getenv("ABN_DTW_SCHED")) == 0);
+    const bool dealt = switches().dtw_dealt;
     if (dealt) {
         if (flags) hipLaunchKernelGGL((dtw_gang_kernel<true, 1>), grid, block, 0, st, P);
         else hipLaunchKernelGGL((dtw_gang_kernel<false, 1>), grid, block, 0, st, P);

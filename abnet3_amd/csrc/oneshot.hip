@@ -194,7 +194,7 @@ int abn_allreduce_oneshot(const abn_oneshot_ctx* ctx, float* buf, int64_t n, voi
     // a small grid: the call is bound by the links and the hand-overs' latency, not by the CUs, and every workgroup of every
     // rank must be resident while it waits for the peers (two ranks may share one GPU in the tests)
     // (ABN_ONESHOT_WGS lifts the cap of 32 workgroups: DESIGN.md section 4 has the two-process timings at 32 / 64 / 128)
-    static const int64_t cap_wgs = getenv("ABN_ONESHOT_WGS") && atoi(getenv("ABN_ONESHOT_WGS")) >= 1 ? atoi(getenv("ABN_ONESHOT_WGS")) : 32;
+    const int64_t cap_wgs = switches().oneshot_wgs;
     int64_t wgs = (n / 4 + OS_NT * 8 - 1) / (OS_NT * 8);
     wgs = wgs < 1 ? 1 : (wgs > cap_wgs ? cap_wgs : wgs);
     if (wgs > 256) wgs = 256;                     // every workgroup resident

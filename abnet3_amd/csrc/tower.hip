@@ -59,6 +59,10 @@ static Switches read_switches()
     s.wgrad_tile128 = getenv("ABN_WGRAD_TILE128") ? atoi(getenv("ABN_WGRAD_TILE128")) : -1;
     s.dtw_wgs_per_cu = getenv("ABN_DTW_WGS") ? atoi(getenv("ABN_DTW_WGS")) : 6;
     if (s.dtw_wgs_per_cu < 1 || s.dtw_wgs_per_cu > 9) s.dtw_wgs_per_cu = 6;
+    s.wgrad_step = !off("ABN_WGRAD_STEP");
+    s.dtw_dealt = !off("ABN_DTW_SCHED");
+    s.oneshot_wgs = getenv("ABN_ONESHOT_WGS") ? atoi(getenv("ABN_ONESHOT_WGS")) : 32;
+    if (s.oneshot_wgs < 1 || s.oneshot_wgs > 256) s.oneshot_wgs = 32;
     return s;
 }
 static Switches g_switches = read_switches();       // (at library load: no call ever reads the environment)
@@ -1602,8 +1606,7 @@ static int planes_backward(const abn_tower_desc* t, const float* d_out, const Lo
 // the descriptor and the row count: the backward (which then launches no weight-gradient kernel) and the step ask here.
 static bool wgrad_step_small_ok(const abn_tower_desc* t, int64_t rows, int64_t n_calls)
 {
-    static const bool on = !(getenv("ABN_WGRAD_STEP") && atoi(getenv("ABN_WGRAD_STEP")) == 0);
-    if (!on || !t->defer_reduce || !t->fwd_ws || t->batch_norm || t->wgrad_part != 0 || planes_of(t) != 2) return false;
+    if (!switches().wgrad_step || !t->defer_reduce || !t->fwd_ws || t->batch_norm || t->wgrad_part != 0 || planes_of(t) != 2) return false;
     if (n_calls < 1 || rows % n_calls != 0 || !aligned16(t->fwd_ws)) return false;
     const int64_t vrows = bn_vrows(rows, n_calls);
     if (wide_groups_for(t, vrows) <= 0 || !planes_shape_ok(t)) return false;

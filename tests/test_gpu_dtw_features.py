@@ -606,6 +606,11 @@ def test_dtw_many_pairs_per_gang_bit_exact(seed, P, wgs, monkeypatch):
     for p in rng.choice(np.nonzero(ln > 0)[0], 150, replace=False):
         d = O.cosine_distance(f1[o1[p]:o1[p] + n1[p]], f2[o2[p]:o2[p] + n2[p]])
         assert cost[p] == O.dtw_cost(d), p
+    if seed == 2:                                           # round 4's schedule (a pair per slot) is one switch away: the same bits
+        monkeypatch.setenv('ABN_DTW_SCHED', '0')
+        old = dtw_align_batch(torch.from_numpy(f1).cuda(), o1, n1, torch.from_numpy(f2).cuda(), o2, n2)
+        assert torch.equal(old.path_len, res.path_len) and torch.equal(old.total_cost, res.total_cost)
+        assert np.array_equal(old.path1.cpu().numpy()[mine], g1[mine]) and np.array_equal(old.path2.cpu().numpy()[mine], g2[mine])
 
 
 def test_dtw_traceback_beside_the_fill_equals_one_stream(monkeypatch):

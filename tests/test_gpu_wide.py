@@ -258,3 +258,42 @@ def test_eight_calls_of_ragged_length(split):
     assert LIB.last_forward_path() == 6
     o, _ = O.tower_forward(p, x, spec, True)
     assert rel_err(out.cpu().numpy(), o) < 1e-5
+
+
+@pytest.mark.parametrize('oname,lr,tol', [('sgd', 0.05, 1e-5), ('adadelta', 0.1, 3e-5), ('adagrad', 0.01, 3e-4), ('RMSprop', 0.001, 3e-4),
+                                          ('adam', 0.001, 3e-4)])
+def test_the_one_launch_step_applies_every_optimizer_rule(oname, lr, tol, monkeypatch):
+    """tower_wgrad_step.h (round 6): every layer's weight gradient over all rows AND the optimizer's rule in one launch.  The
+    rule is opt_rule.h's, the one the slab path's launch applies: three steps of each optimizer_type of abnet3/trainer.py:68-87
+    end with the parameters of the two-launch path (ABN_WGRAD_STEP=0) to the tolerance the reference's own steps are held to
+    (the two sum the same products in another order; Adam / RMSprop / Adagrad divide by sqrt(v) ~ |g|: rounding noise is
+    amplified where a gradient is tiny)."""
+    import abnet3_amd.loss as L
+    from abnet3_amd.trainer import TrainerSiamese
+    kw = dict(input_dim=280, num_hidden_layers=2, hidden_dim=500, output_dim=100, activation_layer='sigmoid', p_dropout=0.0, batch_norm=False)
+    rng = np.random.default_rng(11)
+    B = 333
+    batch = (dev(rng.standard_normal((B, 280)).astype(np.float32)), dev(rng.standard_normal((B, 280)).astype(np.float32)),
+             dev(rng.choice([1, -1], B)))
+
+    def run(fused):
+        monkeypatch.setenv('ABN_WGRAD_STEP', '1' if fused else '0')
+        net, spec, p = build(kw, seed=3, precision='f16x2')
+        tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type=oname, lr=lr, dataloader=None, log_dir='/tmp/abn_runs')
+        net.train()
+        losses = [float(tr.train_step(batch, True)) for _ in range(3)]
+        assert _lib()[0].last_backward_path() == 6
+        return losses, {k: q.detach().cpu().numpy().copy() for k, q in net.named_parameters()}
+    l1, p1 = run(True)
+    l0, p0 = run(False)
+    assert np.allclose(l1, l0, rtol=2e-5), (l1, l0)
+    for k in p0:
+        if oname in ('sgd', 'adadelta'):
+            assert rel_err(p1[k], p0[k]) < tol, (k, rel_err(p1[k], p0[k]))
+        else:
+            # these rules' first steps are lr * g / |g|: where a gradient is rounding noise its SIGN differs between two
+            # summation orders and the parameter moves lr the other way -- a handful of elements; a wrong rule moves them all
+            far = np.abs(p1[k] - p0[k]) > tol * np.abs(p0[k]).max()
+            assert far.sum() <= max(3, 2e-3 * far.size), (k, int(far.sum()), far.size)
+            assert np.median(np.abs(p1[k] - p0[k])) < 1e-6 * np.abs(p0[k]).max(), k
+    assert any(not np.array_equal(p1[k], p0[k]) for k in p0)      # (another summation order: the switch did select another launch)
