@@ -244,8 +244,9 @@ class _DtwScratch(object):
         return self.ws, self.stage
 
     def mark(self):
-        self.done = torch.cuda.Event()
-        self.done.record()
+        if self.done is None:
+            self.done = torch.cuda.Event()
+        self.done.record()                       # (one event, recorded again: the previous record has been waited for in buffers())
 
 
 def release_dtw_scratch():
@@ -268,8 +269,8 @@ def dtw_align_batch(feats1, off1, n1, feats2, off2, n2):
     P = len(n1)
     dev = feats1.device
     stride = max(1, int(np.add(n1, n2, dtype=np.int64).max()) - 1) if P else 1
-    path1 = torch.empty(P, stride, dtype=torch.int32, device=dev)
-    path2 = torch.empty(P, stride, dtype=torch.int32, device=dev)
+    both = torch.empty(2, P, stride, dtype=torch.int32, device=dev)      # (one allocation: the host's share of a call is wall time)
+    path1, path2 = both[0], both[1]
     if P == 0:
         return DtwBatchResult(path1, path2, torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.float64, device=dev))
     plen = torch.empty(P, dtype=torch.int32, device=dev)         # (abn_dtw_batched clears both: dropped and empty pairs keep 0)
