@@ -484,6 +484,9 @@ __device__ __forceinline__ double dpp_shr1_f64(double v)      // lane l <- lane 
 #ifndef ABN_GANG_RELEASE
 #define ABN_GANG_RELEASE 0
 #endif
+#ifndef ABN_GANG_NT
+#define ABN_GANG_NT 0
+#endif
 // (Two gangs per workgroup -- six wavefronts that land as 2 producers + 1 consumer on every SIMD, where five one-gang
 // workgroups land as 3P+C, 3P+C, 2P+2C, 2P+C -- were measured in round 6: twelve wavefronts per CU instead of fifteen cost 12 %.)
 // SCHED = 1 (round 6, the default): the gang's two slots are DEALT the bands of a stream of pairs in turn -- band b of a
@@ -948,6 +951,7 @@ __global__ __launch_bounds__(64 * (GS + 1)) __attribute__((amdgpu_waves_per_eu(A
                     if (feed) __hip_atomic_store(&bout[e], cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if ((e & 15) == 15 && (!decltype(edge)::value || active)) {
                         if (FLAGS && !ABN_GANG_RELEASE) __hip_atomic_store(&dptr[(e >> 4) * BAND], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else if (ABN_GANG_NT) __builtin_nontemporal_store(bits, &dptr[(e >> 4) * BAND]);      // (streaming: written once, read by the traceback)
                         else dptr[(e >> 4) * BAND] = bits;
                     }
                 }
