@@ -609,15 +609,27 @@ def collective_bench(torch, trainer, net, world, reps=50):
                         ('torch.distributed.all_reduce, two buckets (the upper layers\' under the rest of the backward)'
                          if trainer.overlap_allreduce else 'torch.distributed.all_reduce, one bucket')}
     if out['backend'] == 'nccl':
-        try:
-            sync = parallel.RcclBatchNormSync()
-            n = C.c_int(-1)
-            sync._rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
-            if sync._rccl.ncclCommCount(sync._comm, C.byref(n)) == 0:
-                out['rank_count_seen_by_rccl'] = int(n.value)
-            sync._destroy()
-        except (RuntimeError, OSError, AttributeError) as e:
-            out['rank_count_seen_by_rccl'] = 'unavailable: %s' % (e,)
+        # (in a thread with a deadline: a second communicator beside torch's has only ever been made on ONE rank here, and a
+        # rendezvous that never completes must not take the measured line with it)
+        import threading
+        dev_index = torch.cuda.current_device()
+
+        def count_ranks():
+            try:
+                torch.cuda.set_device(dev_index)
+                sync = parallel.RcclBatchNormSync()
+                n = C.c_int(-1)
+                sync._rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+                if sync._rccl.ncclCommCount(sync._comm, C.byref(n)) == 0:
+                    out['rank_count_seen_by_rccl'] = int(n.value)
+                sync._destroy()
+            except Exception as e:                  # noqa: BLE001
+                out['rank_count_seen_by_rccl'] = 'unavailable: %s' % (e,)
+        th = threading.Thread(target=count_ranks, daemon=True)
+        th.start()
+        th.join(90.0)
+        if th.is_alive():
+            out['rank_count_seen_by_rccl'] = 'unavailable: making a second communicator did not finish within 90 s'
     buf = torch.zeros_like(net.flat_parameters())
 
     def timed(fn):

@@ -199,6 +199,16 @@ def main():
     run('rccl')
     graphed_bn()
     forced_fallback()
+    # bench.py's `collective` leg on the real backend (world of one): the communicator of its own that it counts the ranks
+    # of, torch.distributed's all-reduce timed on the step's bucket; the one-shot exchange needs a peer and says so
+    import bench
+    net = SiameseNetwork(output_path='/tmp/abn_rccl_cb', **kw)
+    tr = TrainerSiamese(network=net, loss=L.coscos2(avg=False), optimizer_type='adadelta', lr=0.1, dataloader=None,
+                        log_dir='/tmp/abnet3_rccl_runs')
+    co = bench.collective_bench(torch, tr, net, 1, reps=10)
+    res['collective.backend'] = np.array(str(co['backend']))
+    res['collective.rank_count'] = np.array(str(co['rank_count_seen_by_rccl']))
+    res['collective.allreduce_us'] = np.array(str(co['allreduce_us']))
     res['backend'] = np.array(torch.distributed.get_backend())
     np.savez(out + '.rccl.npz', **res)
     torch.distributed.barrier()

@@ -293,6 +293,9 @@ def test_one_rank_on_rccl():
     assert rc == 0, 'RCCL worker failed (%s):\n%s' % (rc, log[-4000:])
     r = dict(np.load(job['out'] + '.rccl.npz'))
     assert str(r['backend']) == 'nccl'
+    # bench.py's collective leg ran on RCCL: RCCL itself counts one rank in the communicator the leg made, the all-reduce was timed
+    assert str(r['collective.backend']) == 'nccl' and str(r['collective.rank_count']) == '1', (r['collective.backend'], r['collective.rank_count'])
+    assert 'torch.distributed.all_reduce' in str(r['collective.allreduce_us'])
     keys = sorted(k[6:] for k in r if k.startswith('plain.'))
     assert keys and keys == sorted(k[5:] for k in r if k.startswith('rccl.'))
     off = {}
