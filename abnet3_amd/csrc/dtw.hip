@@ -1013,6 +1013,9 @@ constexpr int TB_ROWS = ABN_TB_ROWS;
 //         complete, then walks them; what the fill kernel stored write-through is read with agent-scope loads.  A pair
 //         whose flag has not come by the time limit is left alone (path_len stays 0).
 // MODE 2: the sweep behind both streams: the pairs MODE 1 left (normally none).
+#ifndef TB_SIDE_LANES
+#define TB_SIDE_LANES 64
+#endif
 #ifndef ABN_TB_WAIT_TICKS
 #define ABN_TB_WAIT_TICKS 50000000ull      // 0.5 s of the 100 MHz clock
 #endif
@@ -1032,7 +1035,11 @@ __global__ __launch_bounds__(64) void dtw_traceback_kernel(const PairMeta* __res
 #endif
     __shared__ uint32_t win[2 * TB_ROWS][64];            // [group offset * 8 + row offset][thread]: conflict-free
     const int lane = threadIdx.x;
-    const int idx = (int)(blockIdx.x * 64 + lane);
+    // MODE 1: TB_SIDE_LANES pairs per wavefront (a wavefront starts when ALL its pairs are filled and walks as long as its
+    // longest path: fewer pairs per wavefront start earlier and end earlier behind the fill's last pairs)
+    constexpr int PER = MODE == 1 ? TB_SIDE_LANES : 64;
+    if (lane >= PER) return;
+    const int idx = (int)(blockIdx.x * PER + lane);
     // queue order (pairs of similar size side by side): the threads of a wavefront walk paths of similar length.  Behind
     // the npairs queued pairs the list holds the pairs with an empty token: nothing to walk, path_len = 0 (MODE 0 / 2: their
     // grids span the whole list; every pair's path_len and total_cost are written by exactly one of the launches, no memset)
@@ -1368,7 +1375,7 @@ static int dtw_batched_impl(const float* feats1, int64_t rows1, const float* fea
         const bool pipelined = switches().dtw_f40;     // A/B switch of the 40-d specialisation
         const bool gang = switches().dtw_pc;            // A/B switch: gang form (a producer per slot + one consumer)
         const int32_t* qorder = (const int32_t*)(base + w.order_off);
-        const unsigned tb_grid = (unsigned)((nq + 63) / 64), tb_grid_all = (unsigned)((npairs + 63) / 64);
+        const unsigned tb_grid = (unsigned)((nq + TB_SIDE_LANES - 1) / TB_SIDE_LANES), tb_grid_all = (unsigned)((npairs + 63) / 64);
         if (nq == 0) {}
         else if (vec && D == KCH && gang) {
             const int64_t ng = nwg < 256 * switches().dtw_wgs_per_cu ? nwg : 256 * switches().dtw_wgs_per_cu;
