@@ -217,6 +217,32 @@ __device__ __forceinline__ bool bnp_fwd_finish(const PlanesFwdP& p, const BnPers
     return true;
 }
 
+// (experiment, round 6, -DBNP_PREFETCH_NEXT: the NEXT layer's first PL_DEPTH ring steps requested before this layer's exchange --
+// the weights do not depend on the statistics --, so that its k-loop starts on operands that are already there)
+#ifndef BNP_PREFETCH_NEXT
+#define BNP_PREFETCH_NEXT 0
+#endif
+template <int NP, int BPW, int KS>
+__device__ __forceinline__ void bnp_prefetch_ring(WeightRing<NP>& ring, const char* wp, const char* wbase, int nblk, int nsteps, int wave, int lane)
+{
+    const WaveShare<BPW, KS> ws(wave, nblk, nsteps);
+    if (!ws.active) return;
+    const int ioff = (int)(wp - wbase);
+#pragma unroll
+    for (int i = 0; i < PL_DEPTH; ++i)
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int blk = ws.blk0 + j < nblk ? ws.blk0 + j : nblk - 1;
+            const int wv = ioff + (blk * nsteps + ws.s_first) * (NP * 1024) + lane * 16;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                ring.wq[i][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(ring.rs, wv, (i * NP + pl) * 1024, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    ring.filled = true;
+}
+
 // One layer of the resident forward.  img: the layer's input fragments (all pl_steps(K) steps); on return the output's
 // (unless it is the last layer).  Returns false when a grid barrier gave up.
 template <int NP, int BPW, int KS>
@@ -253,7 +279,7 @@ __device__ __forceinline__ bool bnp_fwd_layer(const PlanesFwdP& p, const BnPersi
         be_lane = p.bn_b[l][nfc];
     }
     if (ws.active) {
-        ring.filled = false;
+        if (!BNP_PREFETCH_NEXT) ring.filled = false;
         const int ioff = (int)(p.wp[l] - p.wbase);
         int wv[BPW], dnext[BPW];
 #pragma unroll
@@ -264,6 +290,7 @@ __device__ __forceinline__ bool bnp_fwd_layer(const PlanesFwdP& p, const BnPersi
         }
         ring_kloop<NP, BPW>(acc, ring, wv, dnext, false, img, ws.s_first, ws.my_steps, lane);
     }
+    ring.filled = false;
     PSTAMPF(2 + 8 * l);
     float* const sc = part + PL_PART_BYTES / 4;
     float* const slot_s = part + (PL_PART_BYTES + PL_SC_BYTES) / 4 + wave * 64;      // + v * (PL_BIAS_BYTES / 4): bias, mean, invstd, gamma, beta
@@ -354,6 +381,12 @@ __device__ __forceinline__ bool bnp_fwd_layer(const PlanesFwdP& p, const BnPersi
         st_sc1_4(gs.rs, (int)bnp_part_off() + ((int)blockIdx.x * PL_MAXW + (int)threadIdx.x) * 16, *reinterpret_cast<const f32x4*>(part + 4 * threadIdx.x));
     PSTAMPF(3 + 8 * l);
     PSTAMPR(9 + 8 * l);                                // (the chip-wide clock: when this workgroup's sums were out)
+    if (BNP_PREFETCH_NEXT && !last) {
+        const int nblk2 = (p.dims[l + 2] + 31) / 32, nsteps2 = pl_steps(p.dims[l + 1]);
+        if (nblk2 > PL_WAVES) bnp_prefetch_ring<NP, 2, 1>(ring, p.wp[l + 1], p.wbase, nblk2, nsteps2, wave, lane);
+        else if (nblk2 > PL_WAVES / 2 || nsteps2 % (2 * PL_DEPTH) != 0) bnp_prefetch_ring<NP, 1, 1>(ring, p.wp[l + 1], p.wbase, nblk2, nsteps2, wave, lane);
+        else bnp_prefetch_ring<NP, 1, 2>(ring, p.wp[l + 1], p.wbase, nblk2, nsteps2, wave, lane);
+    }
     lds_barrier();                                     // (the staging buffer is the finishing step's scratch)
     PSTAMPF(4 + 8 * l);
     if (!bnp_fwd_finish(p, q, gs, tag_p, tag_s, l, N, wpc, reinterpret_cast<double*>(part))) return false;
