@@ -77,6 +77,9 @@ def kernel_names(prec):
             'abn::wgrad_planes128_kernel(abn::WgradP)' if prec == 'f16x2' else 'void abn::wgrad_planes_kernel<%d>(abn::WgradP)' % planes)
 
 
+SETTLE_SCALE = 1.0      # --trace-run sets 0: the side legs' settling launches would drown the step's own in a kernel trace
+
+
 def _time_launches(torch, fn, reps):
     """Average GPU time of one fn() (a fixed launch sequence): `reps` calls are
     captured into ONE hipGraph, so the HIP events around its replays (recorded on
@@ -99,7 +102,7 @@ def _time_launches(torch, fn, reps):
     torch.cuda.synchronize()
     # (the capture above left the GPU idle: replays until the clock has settled, as everywhere in this file -- settle())
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.2:
+    while time.perf_counter() - t0 < 0.2 * SETTLE_SCALE:
         for _ in range(4):
             graph.replay()
         torch.cuda.synchronize()
@@ -482,7 +485,7 @@ def settle(torch, fn, seconds=0.3, chunk=16):
     (tools/dtw_time_many.py: 3.79, 3.30, 3.15, 3.08, 3.00 .. 2.87 ms for consecutive DTW calls).  The headline loop settles the
     same way (0.5 s) before its warm-up."""
     t0, i = time.perf_counter(), 0
-    while time.perf_counter() - t0 < seconds:
+    while time.perf_counter() - t0 < seconds * SETTLE_SCALE:
         for _ in range(chunk):
             fn(i)
             i += 1
@@ -808,6 +811,9 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--repeats', type=int, default=9, help='timed regions of --steps steps each; the median is reported')
+    ap.add_argument('--trace-run', action='store_true',
+                    help='for a run under rocprofv3 --kernel-trace (tools/collect_profiles.sh): the side legs do not settle the '
+                         'clock with thousands of untimed launches, so the trace\'s per-kernel averages are the timed step\'s own')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtw-pairs', type=int, default=10000,
                     help='token pairs per GPU for the DTW leg (0 = skip)')
@@ -816,6 +822,9 @@ def main():
                     help='replay a captured hipGraph per step instead of the eager direct step')
     ap.add_argument('--no-graph', action='store_true', help='(default; kept for old command lines)')
     args = ap.parse_args()
+    if args.trace_run:
+        global SETTLE_SCALE
+        SETTLE_SCALE = 0.0
 
     import torch
     from abnet3_amd import parallel

@@ -15,7 +15,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-args="--steps 100 --warmup 20 --no-cpu-baseline --pipeline-utts 0"
+args="--steps 100 --warmup 20 --no-cpu-baseline --pipeline-utts 0 --trace-run"
 if has bench; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py $args > $out/stats.log 2>&1
 echo stats done
