@@ -146,6 +146,25 @@ def _trace_us(kernel):
     return None, None
 
 
+def _trace_binary(trace_file):
+    """Is the committed kernel trace of the library build this run has loaded?  (a stale trace may name another
+    dominant launch than the binary being timed.)  profiles/rNN_lib_digest.txt is written when the trace is collected."""
+    if not trace_file:
+        return None
+    try:
+        import hashlib
+        from abnet3_amd import build as _b
+        want = open(os.path.join(ROOT, trace_file.replace('_bench_kernel_stats.csv', '_lib_digest.txt'))).read().strip()
+        h = hashlib.sha1()
+        with open(os.environ.get('ABNET3_HIP_LIB') or _b.LIB, 'rb') as f:
+            for chunk in iter(lambda: f.read(1 << 20), b''):
+                h.update(chunk)
+        return 'the library build this run loaded' if h.hexdigest() == want else \
+            'ANOTHER build of the library (%s..): in_step_trace_us and `dominant` may be stale' % want[:10]
+    except OSError:
+        return 'unknown (no digest beside the trace)'
+
+
 def planes_roofline(torch, net, reps=20):
     """precision f16x2 / bf16x3 / bf16 (csrc/tower_planes.h): the step is three launches of similar length -- the
     forward chain, the data-gradient chain, the weight gradients -- plus the fused reduction + optimizer.
@@ -233,6 +252,7 @@ def planes_roofline(torch, net, reps=20):
                         'avg_launch_us_is': 'this run, the launch ALONE: %d launches back to back from one hipGraph, HIP events on the launch stream' % reps,
                         'in_step_trace_us': in_step,
                         'in_step_trace_us_is': 'the same kernel between its neighbours in the step: committed rocprofv3 --kernel-trace --stats of this command (%s)' % trace_file,
+                        'in_step_trace_is_of': _trace_binary(trace_file),
                         'flop_per_launch': fl, 'traffic': _traffic(short)}
     # What the chains are actually bound by: every workgroup of 32 rows pulls the whole packed layer through
     # its CU's L1 from the XCD's L2 -- bytes per launch = workgroups x packed weight image --, at most 64 B/clk per CU.

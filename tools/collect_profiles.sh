@@ -17,6 +17,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 args="--steps 100 --warmup 20 --no-cpu-baseline --pipeline-utts 0 --trace-run"
 if has bench; then
+sha1sum $root/abnet3_amd/lib/libabnet3_hip.so | cut -d' ' -f1 > $out/lib_digest.txt      # (which build the trace is of: bench.py compares)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py $args > $out/stats.log 2>&1
 echo stats done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/traffic/fetch -- python3 $root/bench.py $args > $out/fetch.log 2>&1

@@ -5,6 +5,7 @@ tag=${1:-r04}
 src=gpurun_out/$tag
 cp $src/kernel_stats.csv profiles/${tag}_bench_kernel_stats.csv
 cp $src/kernel_stats.txt profiles/${tag}_bench_kernel_stats.txt
+[ -s $src/lib_digest.txt ] && cp $src/lib_digest.txt profiles/${tag}_lib_digest.txt
 cp $src/bench_line_under_rocprof.json profiles/${tag}_bench_line_under_rocprof.json
 [ -s $src/bench_line.json ] && cp $src/bench_line.json profiles/${tag}_bench_line.json
 cp $src/small_batch_kernel_stats.txt profiles/${tag}_small_batch_kernel_stats.txt
