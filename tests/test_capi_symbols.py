@@ -130,3 +130,18 @@ def test_dtw_workspace_planning(lib):
     assert ws < 1.0 * (300 * 280 + 50 * 600)            # under 1 B per cell even for two pairs (the matrix alone was 4.25 B / cell)
     assert lib.abn_dtw_host_stage_bytes(p(n1), p(n2), 3) >= 3 * 56 + 3 * 4
     assert lib.abn_dtw_ws_bytes(None, None, 3, 0, 0) == -1
+
+
+def test_the_library_is_renamed_into_place_with_its_digest():
+    """abnet3_amd/build.py links beside the target and renames (ranks that find the library stale at the same moment must never
+    dlopen a half-written file): after a build the recorded digest is the file's, nothing temporary is left, and the kernel
+    trace bench.py reads its in-step figures from says which build it is of."""
+    import os
+    from abnet3_amd import build
+    lib = build.build()
+    assert build._digest(lib) == build._recorded_digest()
+    assert not [f for f in os.listdir(os.path.dirname(lib)) if f.endswith('.tmp')]
+    import bench
+    assert bench._trace_binary(None) is None
+    assert bench._trace_binary('profiles/r05_bench_kernel_stats.csv').startswith('unknown')
+    assert 'library' in bench._trace_binary('profiles/r06_bench_kernel_stats.csv')
