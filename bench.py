@@ -291,7 +291,7 @@ def planes_roofline(torch, net, reps=20):
            'dominant': dominant, 'dominant_by': dominant_by,
            'kernel': e['kernel'], 'avg_launch_us': e['avg_launch_us'], 'avg_launch_us_is': e['avg_launch_us_is'],
            'in_step_trace_us': e['in_step_trace_us'], 'in_step_trace_us_is': e['in_step_trace_us_is'],
-           'flop_per_launch': e['flop_per_launch']}
+           'in_step_trace_is_of': e['in_step_trace_is_of'], 'flop_per_launch': e['flop_per_launch']}
     if e['in_step_trace_us']:
         out['frac_at_in_step_duration'] = round(e['flop_per_launch'] / (e['in_step_trace_us'] * 1e-6) / 1e12 / peak, 4)
     if 'operand_stream' in e:
